@@ -1,0 +1,372 @@
+/* fhesi_oracle.c -- CPU restatement (plain C) of fhe-si's DoubleCRT hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library, and only as the checker / reported CPU baseline.  The product path
+ * (fhe-si_amd/csrc, the HIP library behind include/fhesi_hip.h) never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference needs NTL (absent, un-vendored, no version pinned) so it cannot
+ * be built here, and its tests hold no golden vectors for this path.
+ * This restatement is pinned by (i) the independent Python big-int restatement
+ * (oracle/fhesi_pyref.py) through tests/golden fixtures, (ii) the reference's own slow definition
+ * tDFT (bluestein.cpp:149-172) and (iii) the end-to-end predicate of Test_AddMul.cpp:84-86.
+ *
+ * Conventions (same as include/fhesi_hip.h):
+ *   rows      uint64_t[phim], canonical residues in [0,q_i), Z_m^* ascending order
+ *   big ints  little-endian 64-bit limbs, two's complement, fixed nlimbs, coefficient-major
+ * Citations are file:line relative to /root/reference.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+/* ------------------------------------------------------------------ word-size modular arithmetic
+ * role of NTL AddMod/SubMod/MulMod/PowerMod/InvMod on `long` (used throughout DoubleCRT.cpp) */
+static inline u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
+static inline u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+static inline u64 mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+static u64 powmod(u64 a, u64 e, u64 q) { u64 r = 1 % q; a %= q; while (e) { if (e & 1) r = mulmod(r, a, q); a = mulmod(a, a, q); e >>= 1; } return r; }
+static u64 invmod(u64 a, u64 q) { /* q prime */ return powmod(a, q - 2, q); }
+/* precomputed-quotient multiply (role of NTL MulModPrecon, DoubleCRT.cpp:195-197) */
+static inline u64 shoup_pre(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+static inline u64 mulmod_shoup(u64 y, u64 w, u64 wp, u64 q) { u64 Q = (u64)(((u128)y * wp) >> 64); u64 r = y * w - Q * q; return r >= q ? r - q : r; }
+
+static int is_prime_u64(u64 n) {
+  static const u64 sp[] = {2,3,5,7,11,13,17,19,23,29,31,37};
+  if (n < 2) return 0;
+  for (int i = 0; i < 12; i++) { if (n % sp[i] == 0) return n == sp[i]; }
+  u64 d = n - 1; int s = 0; while ((d & 1) == 0) { d >>= 1; s++; }
+  for (int i = 0; i < 12; i++) {
+    u64 x = powmod(sp[i], d, n); if (x == 1 || x == n - 1) continue;
+    int ok = 0; for (int r = 1; r < s; r++) { x = mulmod(x, x, n); if (x == n - 1) { ok = 1; break; } }
+    if (!ok) return 0;
+  }
+  return 1;
+}
+static u64 gcd_u64(u64 a, u64 b) { while (b) { u64 t = a % b; a = b; b = t; } return a; }
+
+/* ------------------------------------------------------------------ fixed-width signed big ints */
+static int bn_sign(const u64* a, int n) { return (int)(a[n - 1] >> 63); }
+static void bn_neg(u64* a, int n) { u64 c = 1; for (int i = 0; i < n; i++) { u64 v = ~a[i] + c; c = (c && v == 0); a[i] = v; } }
+static void bn_add(u64* a, const u64* b, int n) { u64 c = 0; for (int i = 0; i < n; i++) { u128 s = (u128)a[i] + b[i] + c; a[i] = (u64)s; c = (u64)(s >> 64); } }
+static void bn_sub(u64* a, const u64* b, int n) { u64 br = 0; for (int i = 0; i < n; i++) { u128 s = (u128)a[i] - b[i] - br; a[i] = (u64)s; br = (u64)(s >> 64) & 1; } }
+static void bn_set_i64(u64* a, i64 v, int n) { a[0] = (u64)v; for (int i = 1; i < n; i++) a[i] = v < 0 ? ~0ull : 0; }
+static void bn_mul_u64(u64* a, u64 m, int n) { /* magnitude multiply, a >= 0 */ u64 c = 0; for (int i = 0; i < n; i++) { u128 s = (u128)a[i] * m + c; a[i] = (u64)s; c = (u64)(s >> 64); } }
+static u64 bn_mod_u64_mag(const u64* a, int n, u64 q) { u64 r = 0; for (int i = n - 1; i >= 0; i--) r = (u64)((((u128)r << 64) | a[i]) % q); return r; }
+/* non-negative residue of a signed big int (role of NTL rem(ZZ,long): result in [0,q)) */
+static u64 bn_mod_u64(const u64* a, int n, u64 q) {
+  if (!bn_sign(a, n)) return bn_mod_u64_mag(a, n, q);
+  u64 tmp[n]; memcpy(tmp, a, 8 * n); bn_neg(tmp, n);
+  u64 r = bn_mod_u64_mag(tmp, n, q); return r ? q - r : 0;
+}
+static int bn_cmp_signed(const u64* a, const u64* b, int n) {
+  int sa = bn_sign(a, n), sb = bn_sign(b, n); if (sa != sb) return sa ? -1 : 1;
+  for (int i = n - 1; i >= 0; i--) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1; return 0;
+}
+/* a += s * p  where s is a signed word, p a non-negative big int */
+static void bn_addmul_i64(u64* a, const u64* p, i64 s, int n) {
+  u64 t[n]; memcpy(t, p, 8 * n); u64 mag = s < 0 ? (u64)(-(s + 1)) + 1 : (u64)s; bn_mul_u64(t, mag, n);
+  if (s < 0) bn_sub(a, t, n); else bn_add(a, t, n);
+}
+/* arithmetic shift right by k bits */
+static void bn_sar(u64* a, int n, int k) {
+  u64 fill = bn_sign(a, n) ? ~0ull : 0; int w = k / 64, b = k % 64;
+  for (int i = 0; i < n; i++) { u64 lo = (i + w < n) ? a[i + w] : fill; u64 hi = (i + w + 1 < n) ? a[i + w + 1] : fill; a[i] = b ? (lo >> b) | (hi << (64 - b)) : lo; }
+}
+static void bn_shl(u64* a, int n, int k) {
+  int w = k / 64, b = k % 64;
+  for (int i = n - 1; i >= 0; i--) { u64 hi = (i - w >= 0) ? a[i - w] : 0; u64 lo = (i - w - 1 >= 0) ? a[i - w - 1] : 0; a[i] = b ? (hi << b) | (lo >> (64 - b)) : hi; }
+}
+/* sign-extending copy between widths */
+static void bn_copy_ext(u64* dst, int nd, const u64* src, int ns) {
+  u64 fill = bn_sign(src, ns) ? ~0ull : 0;
+  for (int i = 0; i < nd; i++) dst[i] = i < ns ? src[i] : fill;
+}
+
+/* ------------------------------------------------------------------ context (FHEcontext / PAlgebra / Cmodulus) */
+typedef struct {
+  u64 q, root, rinv;          /* CModulus.h:44,53-54 */
+  int pow2;
+  /* power-of-two m: negacyclic tables, psi = root^2 */
+  u64 *psi, *psi_sh, *ipsi, *ipsi_sh; u64 ninv, ninv_sh;
+  /* general m: Bluestein tables (bluestein.cpp:103-109,121-133) */
+  u64 *powers, *b, *ipowers, *ib; u64 minv;
+} orc_prime;
+
+typedef struct {
+  i64 m, phim; int L;
+  int* zms_idx;               /* PAlgebra.cpp:50-52 */
+  i64* phi;                   /* Phi_m(X) coefficients, length phim+1 (PAlgebra.cpp:55) */
+  orc_prime* pr;
+  int use_slow_dft;           /* evaluate through the tDFT definition instead (bluestein.cpp:149-172) */
+} orc_ctx;
+
+static int mobius_i(i64 n) { int mu = 1; for (i64 p = 2; p * p <= n; p++) if (n % p == 0) { n /= p; if (n % p == 0) return 0; mu = -mu; } if (n > 1) mu = -mu; return mu; }
+
+/* Cyclotomic (NumbTh.cpp:142-158): prod over d|m of (X^{m/d}-1)^{mu(d)}; small integer coefficients for the
+ * m handled here (i64 suffices; checked against the Python restatement in tests). */
+static i64* cyclotomic(i64 m, i64 phim) {
+  i64* num = calloc(m + 2, 8); i64* den = calloc(m + 2, 8); i64 dn = 0, dd = 0; num[0] = 1; den[0] = 1;
+  for (i64 d = 1; d <= m; d++) if (m % d == 0) {
+    int mu = mobius_i(d); if (!mu) continue; i64 e = m / d;
+    i64* t = mu == 1 ? num : den; i64* dg = mu == 1 ? &dn : &dd;
+    /* t *= (X^e - 1) */
+    for (i64 i = *dg + e; i >= 0; i--) { i64 hi = (i - e >= 0 && i - e <= *dg) ? t[i - e] : 0; i64 lo = (i <= *dg) ? t[i] : 0; t[i] = hi - lo; }
+    *dg += e;
+  }
+  /* exact division num/den, den monic up to sign */
+  i64* quo = calloc(phim + 1, 8);
+  for (i64 i = dn - dd; i >= 0; i--) { i64 c = num[i + dd] / den[dd]; quo[i] = c; for (i64 j = 0; j <= dd; j++) num[i + j] -= c * den[j]; }
+  free(num); free(den); return quo;
+}
+
+static u64 brv(u64 x, int bits) { u64 r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+static int ilog2(i64 n) { int k = 0; while ((1ll << k) < n) k++; return k; }
+
+static char orc_err[256];
+const char* orc_last_error(void) { return orc_err; }
+
+void orc_ctx_destroy(orc_ctx* c) {
+  if (!c) return;
+  for (int i = 0; i < c->L; i++) { orc_prime* p = &c->pr[i]; free(p->psi); free(p->psi_sh); free(p->ipsi); free(p->ipsi_sh); free(p->powers); free(p->b); free(p->ipowers); free(p->ib); }
+  free(c->pr); free(c->zms_idx); free(c->phi); free(c);
+}
+
+/* FHEcontext::AddPrime (FHEContext.cpp:30-43) + Cmod::privateInit (CModulus.cpp:60-86); tables are built
+ * eagerly instead of lazily (bluestein.cpp:103,121). root[i]==0 is rejected: the caller supplies roots. */
+orc_ctx* orc_ctx_create(i64 m, int L, const u64* q, const u64* root) {
+  orc_err[0] = 0;
+  if (m < 2 || m > (1 << 20)) { snprintf(orc_err, 256, "m undefined or larger than 2^20"); return NULL; }
+  orc_ctx* c = calloc(1, sizeof(*c)); c->m = m; c->L = L;
+  c->zms_idx = malloc(sizeof(int) * m); i64 k = 0;
+  for (i64 i = 0; i < m; i++) c->zms_idx[i] = (gcd_u64(i, m) == 1) ? (int)k++ : -1;
+  c->phim = k; c->phi = cyclotomic(m, k);
+  c->pr = calloc(L, sizeof(orc_prime));
+  int pow2 = (m & (m - 1)) == 0 && m >= 4;
+  for (int i = 0; i < L; i++) {
+    orc_prime* p = &c->pr[i]; p->q = q[i]; p->root = root[i]; p->pow2 = pow2;
+    int dup = 0; for (int j = 0; j < i; j++) dup |= (q[j] == q[i]);
+    if (!is_prime_u64(q[i]) || q[i] % (2 * m) != 1 || dup) { snprintf(orc_err, 256, "AddPrime: prime %d rejected (not prime, not 1 mod 2m, or already in chain)", i); orc_ctx_destroy(c); return NULL; }
+    if (powmod(root[i], m, q[i]) != q[i] - 1) { snprintf(orc_err, 256, "root %d is not a primitive 2m-th root of unity", i); orc_ctx_destroy(c); return NULL; }
+    p->rinv = invmod(p->root, p->q);
+    u64 Q = p->q;
+    if (pow2) {
+      i64 n = m / 2; int lg = ilog2(n); u64 psi = mulmod(p->root, p->root, Q), ipsi = invmod(psi, Q);
+      p->psi = malloc(8 * n); p->psi_sh = malloc(8 * n); p->ipsi = malloc(8 * n); p->ipsi_sh = malloc(8 * n);
+      for (i64 j = 0; j < n; j++) { u64 e = brv(j, lg); p->psi[j] = powmod(psi, e, Q); p->psi_sh[j] = shoup_pre(p->psi[j], Q); p->ipsi[j] = powmod(ipsi, e, Q); p->ipsi_sh[j] = shoup_pre(p->ipsi[j], Q); }
+      p->ninv = invmod(n % Q, Q); p->ninv_sh = shoup_pre(p->ninv, Q);
+    } else {
+      p->powers = malloc(8 * m); p->ipowers = malloc(8 * m); p->b = calloc(2 * m, 8); p->ib = calloc(2 * m, 8);
+      for (i64 j = 0; j < m; j++) { u64 e = (u64)(((u128)j * j) % (2 * m)); p->powers[j] = powmod(p->root, e, Q); p->ipowers[j] = powmod(p->rinv, e, Q); }
+      /* b[m-1+-j] = root^{-j^2}  (bluestein.cpp:126-132); inverse direction swaps the roles of root and rInv */
+      for (i64 j = 0; j < m; j++) { p->b[m - 1 + j] = p->b[m - 1 - j] = p->ipowers[j]; p->ib[m - 1 + j] = p->ib[m - 1 - j] = p->powers[j]; }
+      p->minv = invmod(m % Q, Q);
+    }
+  }
+  return c;
+}
+i64 orc_phim(const orc_ctx* c) { return c->phim; }
+void orc_set_slow_dft(orc_ctx* c, int on) { c->use_slow_dft = on; }
+void orc_get_tables(const orc_ctx* c, int* zms_idx_out, i64* phi_out) { memcpy(zms_idx_out, c->zms_idx, sizeof(int) * c->m); memcpy(phi_out, c->phi, 8 * (c->phim + 1)); }
+
+/* ---- the length-m DFT at all m-th roots: x[k] = sum_i a[i] (root^2)^{ik} ------------------------------- */
+/* tDFT (bluestein.cpp:149-172): the reference's own slow definition */
+static void tdft(u64* x, const u64* a, i64 n, u64 w, u64 q) {
+  for (i64 k = 0; k < n; k++) { u64 base = powmod(w, k, q), term = 1, sum = 0; for (i64 i = 0; i < n; i++) { sum = addmod(sum, mulmod(a[i], term, q), q); term = mulmod(term, base, q); } x[k] = sum; }
+}
+/* tBluesteinFFT (bluestein.cpp:93-144).  The N-point cyclic product of :138 is evaluated only on the output
+ * window n-1..2n-2 (:139); wrap-around terms of the cyclic product never reach that window because N >= 2n-1. */
+static void bluestein(u64* x, const u64* a, i64 n, const u64* powers, const u64* b, u64 q) {
+  int zero = 1; for (i64 i = 0; i < n; i++) zero &= (a[i] == 0);
+  if (zero) { memset(x, 0, 8 * n); return; }                            /* :96-97 */
+  u64* t = malloc(8 * n);
+  for (i64 i = 0; i < n; i++) t[i] = mulmod(a[i], powers[i], q);        /* :111-113 */
+  for (i64 k = 0; k < n; k++) {
+    u128 acc = 0; const u64* bb = b + (n - 1 + k);
+    for (i64 i = 0; i < n; i++) { acc += (u128)mulmod(t[i], bb[-i], q); }  /* sum of < 2^20 residues < 2^84 */
+    x[k] = mulmod((u64)(acc % q), powers[k], q);                         /* :139-142 */
+  }
+  free(t);
+}
+
+/* negacyclic NTT, natural-order in and out (power-of-two m): y[j] = sum_k a_k psi^{(2j+1)k} */
+static void ntt_pow2_fwd(u64* y, const u64* a_in, i64 n, const orc_prime* p) {
+  u64 q = p->q; int lg = ilog2(n); u64* a = malloc(8 * n); memcpy(a, a_in, 8 * n);
+  i64 t = n;
+  for (i64 mm = 1; mm < n; mm <<= 1) { t >>= 1;
+    for (i64 i = 0; i < mm; i++) { u64 s = p->psi[mm + i], sp = p->psi_sh[mm + i]; i64 j1 = 2 * i * t;
+      for (i64 j = j1; j < j1 + t; j++) { u64 u = a[j], v = mulmod_shoup(a[j + t], s, sp, q); a[j] = addmod(u, v, q); a[j + t] = submod(u, v, q); } } }
+  for (i64 j = 0; j < n; j++) y[j] = a[brv(j, lg)];
+  free(a);
+}
+static void ntt_pow2_inv(u64* x, const u64* y, i64 n, const orc_prime* p) {
+  u64 q = p->q; int lg = ilog2(n); u64* a = malloc(8 * n);
+  for (i64 j = 0; j < n; j++) a[j] = y[brv(j, lg)];
+  i64 t = 1;
+  for (i64 mm = n; mm > 1; mm >>= 1) { i64 h = mm >> 1, j1 = 0;
+    for (i64 i = 0; i < h; i++) { u64 s = p->ipsi[h + i], sp = p->ipsi_sh[h + i];
+      for (i64 j = j1; j < j1 + t; j++) { u64 u = a[j], v = a[j + t]; a[j] = addmod(u, v, q); a[j + t] = mulmod_shoup(submod(u, v, q), s, sp, q); } j1 += 2 * t; }
+    t <<= 1; }
+  for (i64 j = 0; j < n; j++) x[j] = mulmod_shoup(a[j], p->ninv, p->ninv_sh, q);
+  free(a);
+}
+
+/* Cmod::FFT on residues (CModulus.cpp:90-107 after conv :96): xres has ncoeffs entries in [0,q) */
+void orc_fft_residues(const orc_ctx* c, int i, const u64* xres, i64 ncoeffs, u64* y) {
+  const orc_prime* p = &c->pr[i]; i64 m = c->m; u64 q = p->q;
+  if (p->pow2 && !c->use_slow_dft) {
+    i64 n = m / 2; u64* a = calloc(n, 8);
+    /* degree >= m ignored (bluestein.cpp:111-113); X^n = -1 at primitive m-th roots folds n..m-1 */
+    for (i64 k = 0; k < ncoeffs && k < m; k++) { if (k < n) a[k] = addmod(a[k], xres[k], q); else a[k - n] = submod(a[k - n], xres[k], q); }
+    ntt_pow2_fwd(y, a, n, p); free(a); return;
+  }
+  u64* in = calloc(m, 8); u64* out = malloc(8 * m);
+  for (i64 k = 0; k < ncoeffs && k < m; k++) in[k] = xres[k];
+  if (c->use_slow_dft || p->pow2) { u64 w = mulmod(p->root, p->root, q); int zero = 1; for (i64 k = 0; k < m; k++) zero &= !in[k]; if (zero) memset(out, 0, 8 * m); else tdft(out, in, m, w, q); }
+  else bluestein(out, in, m, p->powers, p->b, q);
+  for (i64 k = 0, j = 0; k < m; k++) if (c->zms_idx[k] >= 0) y[j++] = out[k];   /* CModulus.cpp:103-106 */
+  free(in); free(out);
+}
+
+/* Cmod::FFT (CModulus.cpp:90-107) on big-int coefficients */
+void orc_cmod_fft(const orc_ctx* c, int i, const u64* limbs, int nlimbs, i64 ncoeffs, u64* y) {
+  u64* r = malloc(8 * (ncoeffs ? ncoeffs : 1));
+  for (i64 k = 0; k < ncoeffs; k++) r[k] = bn_mod_u64(limbs + k * nlimbs, nlimbs, c->pr[i].q);   /* conv(in,x) :96 */
+  orc_fft_residues(c, i, r, ncoeffs, y); free(r);
+}
+
+/* Cmod::iFFT (CModulus.cpp:110-132): returns phim coefficients in [0,q) */
+void orc_cmod_ifft(const orc_ctx* c, int i, const u64* y, u64* x) {
+  const orc_prime* p = &c->pr[i]; i64 m = c->m, phim = c->phim; u64 q = p->q;
+  if (p->pow2 && !c->use_slow_dft) { ntt_pow2_inv(x, y, phim, p); return; }
+  u64* in = calloc(m, 8); u64* out = malloc(8 * m);
+  for (i64 k = 0, j = 0; k < m; k++) if (c->zms_idx[k] >= 0) in[k] = y[j++];      /* :117-121 */
+  u64 minv = p->pow2 ? invmod(m % q, q) : p->minv;
+  if (c->use_slow_dft || p->pow2) { u64 w = mulmod(p->rinv, p->rinv, q); int zero = 1; for (i64 k = 0; k < m; k++) zero &= !in[k]; if (zero) memset(out, 0, 8 * m); else tdft(out, in, m, w, q); }
+  else bluestein(out, in, m, p->ipowers, p->ib, q);                                /* :124 */
+  for (i64 k = 0; k < m; k++) out[k] = mulmod(out[k], minv, q);                    /* :125 */
+  /* rem(out, out, Phi_m) over Z_q (:128-129), Phi_m monic */
+  for (i64 k = m - 1; k >= phim; k--) { u64 cc = out[k]; if (!cc) continue;
+    for (i64 j = 0; j <= phim; j++) { i64 f = c->phi[j]; if (!f) continue; u64 fm = f < 0 ? q - ((u64)(-f) % q) : (u64)f % q; if (fm == q) fm = 0; out[k - phim + j] = submod(out[k - phim + j], mulmod(cc, fm, q), q); } }
+  memcpy(x, out, 8 * phim); free(in); free(out);
+}
+
+/* ------------------------------------------------------------------ DoubleCRT (rows: [L][phim], all primes) */
+/* DoubleCRT(const ZZX&) (DoubleCRT.cpp:244-257) */
+void orc_dcrt_from_poly(const orc_ctx* c, const u64* limbs, int nlimbs, i64 ncoeffs, u64* rows) {
+  for (int i = 0; i < c->L; i++) orc_cmod_fft(c, i, limbs, nlimbs, ncoeffs, rows + (i64)i * c->phim);
+}
+/* DoubleCRT::Op (DoubleCRT.cpp:79-113), op: 0 add, 1 sub, 2 mul; a <- a op b */
+void orc_dcrt_op(const orc_ctx* c, u64* a, const u64* b, int op) {
+  for (int i = 0; i < c->L; i++) { u64 q = c->pr[i].q; u64* ra = a + (i64)i * c->phim; const u64* rb = b + (i64)i * c->phim;
+    for (i64 j = 0; j < c->phim; j++) ra[j] = op == 0 ? addmod(ra[j], rb[j], q) : op == 1 ? submod(ra[j], rb[j], q) : mulmod(ra[j], rb[j], q); }
+}
+/* DoubleCRT::Op(const ZZ&) (DoubleCRT.cpp:115-129); op 3 = operator/= (:407-420); op 4 = operator=(ZZ) (:333-347) */
+void orc_dcrt_op_scalar(const orc_ctx* c, u64* a, const u64* num, int nlimbs, int op) {
+  for (int i = 0; i < c->L; i++) { u64 q = c->pr[i].q; u64 s = bn_mod_u64(num, nlimbs, q); if (op == 3) s = invmod(s, q); u64* ra = a + (i64)i * c->phim;
+    for (i64 j = 0; j < c->phim; j++) ra[j] = op == 0 ? addmod(ra[j], s, q) : op == 1 ? submod(ra[j], s, q) : op == 4 ? s : mulmod(ra[j], s, q); }
+}
+/* DoubleCRT::automorph (DoubleCRT.cpp:439-465); returns -1 if k not in Zm* (:442-443) */
+int orc_dcrt_automorph(const orc_ctx* c, u64* a, i64 k) {
+  i64 m = c->m; if (k <= 0 || k >= m || c->zms_idx[k] < 0) return -1;
+  u64* tmp = malloc(8 * m);
+  for (int i = 0; i < c->L; i++) { u64* row = a + (i64)i * c->phim;
+    for (i64 j = 1; j < m; j++) if (c->zms_idx[j] >= 0) tmp[j] = row[c->zms_idx[j]];
+    for (i64 j = 1; j < m; j++) if (c->zms_idx[j] >= 0) row[c->zms_idx[j]] = tmp[(j * k) % m]; }
+  free(tmp); return 0;
+}
+
+/* intVecCRT (NumbTh.cpp:307-335) on fixed-width signed big ints vp[n][W]; P non-negative big int */
+static void int_vec_crt(u64* vp, const u64* P, int W, const u64* vq, i64 n, u64 q) {
+  u64 pinv = invmod(bn_mod_u64_mag(P, W, q), q); u64 q2 = q / 2;
+  for (i64 i = 0; i < n; i++) { u64* v = vp + i * W;
+    u64 d = mulmod(submod(vq[i], bn_mod_u64(v, W, q), q), pinv, q);
+    i64 ds = d > q2 ? (i64)d - (i64)q : (i64)d;
+    bn_addmul_i64(v, P, ds, W); }
+}
+
+/* DoubleCRT::toPoly (DoubleCRT.cpp:349-398).  idx: ascending prime indices (NULL = all), out[phim][nlimbs]
+ * two's complement (values that do not fit are truncated mod 2^(64 nlimbs), like any fixed-width store). */
+void orc_dcrt_to_poly(const orc_ctx* c, const u64* rows, const int* idx, int nidx, int positive, u64* out, int nlimbs) {
+  i64 n = c->phim; int all[64]; if (!idx) { nidx = c->L; for (int i = 0; i < nidx; i++) all[i] = i; idx = all; }
+  if (nidx == 0) { memset(out, 0, 8 * n * nlimbs); return; }
+  int W = nidx + 2; u64* vp = calloc(n * W, 8); u64* cur = malloc(8 * n); u64* P = calloc(W, 8);
+  u64 p0 = c->pr[idx[0]].q; P[0] = p0;
+  orc_cmod_ifft(c, idx[0], rows + (i64)idx[0] * n, cur);
+  for (i64 j = 0; j < n; j++) { i64 v = cur[j] > p0 / 2 ? (i64)cur[j] - (i64)p0 : (i64)cur[j]; bn_set_i64(vp + j * W, v, W); }   /* :375-376 */
+  for (int t = 1; t < nidx; t++) { u64 q = c->pr[idx[t]].q;
+    orc_cmod_ifft(c, idx[t], rows + (i64)idx[t] * n, cur);
+    int_vec_crt(vp, P, W, cur, n, q); bn_mul_u64(P, q, W); }                        /* :381-388 */
+  for (i64 j = 0; j < n; j++) { u64* v = vp + j * W; if (positive && bn_sign(v, W)) bn_add(v, P, W); bn_copy_ext(out + j * nlimbs, nlimbs, v, W); }
+  free(vp); free(cur); free(P);
+}
+
+/* ------------------------------------------------------------------ Util.cpp / Ciphertext.cpp / FHE-SI.cpp */
+/* Reduce (Util.cpp:3-26) in place on a two's complement value of `n` limbs */
+static void reduce_logq(u64* v, int n, int logQ, int positive) {
+  int sign_bit = positive ? 0 : (int)((v[(logQ - 1) / 64] >> ((logQ - 1) % 64)) & 1);
+  for (int i = 0; i < n; i++) { int lo = i * 64; if (lo >= logQ) v[i] = sign_bit ? ~0ull : 0; else if (lo + 64 > logQ) { u64 mask = (1ull << (logQ - lo)) - 1; v[i] = sign_bit ? (v[i] | ~mask) : (v[i] & mask); } }
+}
+void orc_reduce_coeffs(u64* poly, i64 ncoeffs, int nlimbs, int logQ, int positive) { for (i64 j = 0; j < ncoeffs; j++) reduce_logq(poly + j * nlimbs, nlimbs, logQ, positive); }
+
+/* Ciphertext::ScaleDown per component (Ciphertext.cpp:194-218): rows of one tProd component -> nlimbs_out-limb
+ * coefficients round-half-up(x / 2^logQ) then centered mod 2^logQ.  floor((2x+q)/(2q)) == (x + q/2) >> logQ. */
+void orc_scale_down(const orc_ctx* c, const u64* rows, int logQ, u64* out, int nlimbs_out) {
+  i64 n = c->phim; int W = c->L + 3; u64* big = malloc(8 * n * W); orc_dcrt_to_poly(c, rows, NULL, 0, 0, big, W);
+  u64 half[W]; memset(half, 0, sizeof(half)); half[(logQ - 1) / 64] = 1ull << ((logQ - 1) % 64);
+  for (i64 j = 0; j < n; j++) { u64* v = big + j * W; bn_add(v, half, W); bn_sar(v, W, logQ); reduce_logq(v, W, logQ, 0); bn_copy_ext(out + j * nlimbs_out, nlimbs_out, v, W); }
+  free(big);
+}
+
+/* Ciphertext::ByteDecompPart (Ciphertext.cpp:82-105): digit d of coefficient j -> digits[d][j] (word each) */
+void orc_byte_decomp_part(const u64* poly, i64 ncoeffs, int nlimbs, int logQ, int nd, int decomp_bytes, u64* digits) {
+  int bits = 8 * decomp_bytes; u64 tmp[nlimbs + 1];
+  for (i64 j = 0; j < ncoeffs; j++) { memcpy(tmp, poly + j * nlimbs, 8 * nlimbs); tmp[nlimbs] = bn_sign(tmp, nlimbs) ? ~0ull : 0; reduce_logq(tmp, nlimbs + 1, logQ, 1);
+    for (int d = 0; d < nd; d++) { int lo = bits * d, w = lo / 64, b = lo % 64; u64 v = tmp[w] >> b; if (b + bits > 64 && w + 1 <= nlimbs) v |= tmp[w + 1] << (64 - b); digits[(i64)d * ncoeffs + j] = v & ((1ull << bits) - 1); } }
+}
+
+/* Ciphertext::operator*= (Ciphertext.cpp:167-192) for two 2-part ciphertexts: a, b are [2][phim][nlimbs];
+ * tprod out is [3][L][phim] */
+void orc_ct_mul(const orc_ctx* c, const u64* a, const u64* b, int nlimbs, u64 p, u64* tprod) {
+  i64 n = c->phim; i64 rs = (i64)c->L * n; int W = nlimbs + 1;
+  u64* c1 = malloc(8 * 2 * rs); u64* c2 = malloc(8 * 2 * rs); u64* lifted = malloc(8 * n * W); u64* tmp = malloc(8 * rs);
+  for (int i = 0; i < 2; i++) {
+    for (i64 j = 0; j < n; j++) { u64* v = lifted + j * W; bn_copy_ext(v, W, a + ((i64)i * n + j) * nlimbs, nlimbs); int s = bn_sign(v, W); if (s) bn_neg(v, W); bn_mul_u64(v, p, W); if (s) bn_neg(v, W); }   /* poly * p (:171) */
+    orc_dcrt_from_poly(c, lifted, W, n, c1 + i * rs);
+    orc_dcrt_from_poly(c, b + (i64)i * n * nlimbs, nlimbs, n, c2 + i * rs);
+  }
+  memset(tprod, 0, 8 * 3 * rs);
+  for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) { memcpy(tmp, c1 + i * rs, 8 * rs); orc_dcrt_op(c, tmp, c2 + j * rs, 2); orc_dcrt_op(c, tprod + (i + j) * rs, tmp, 0); }   /* :179-186 */
+  free(c1); free(c2); free(lifted); free(tmp);
+}
+
+/* KeySwitchSI::ApplyKeySwitch (FHE-SI.cpp:241-260) on a 3-component scaled-up ciphertext.
+ * ksm: [2][3*nd][L][phim] (matrix[0]=b, [1]=A; column index i*nd+j, FHE-SI.cpp:176-177,206-208).
+ * out: [2][phim][nlimbs] */
+void orc_apply_key_switch(const orc_ctx* c, const u64* ksm, const u64* tprod, int ncomp, int logQ, int decomp_bytes, u64* out, int nlimbs) {
+  i64 n = c->phim; i64 rs = (i64)c->L * n; int nd = (logQ + 8 * decomp_bytes - 1) / (8 * decomp_bytes); int ncol = ncomp * nd;
+  u64* parts = malloc(8 * ncomp * n * nlimbs); u64* dig = malloc(8 * (i64)ncol * n); u64* bd = malloc(8 * (i64)ncol * rs); u64* acc = malloc(8 * rs); u64* tmp = malloc(8 * rs);
+  for (int i = 0; i < ncomp; i++) orc_scale_down(c, tprod + i * rs, logQ, parts + (i64)i * n * nlimbs, nlimbs);                      /* ScaleDown :243 */
+  for (int i = 0; i < ncomp; i++) orc_byte_decomp_part(parts + (i64)i * n * nlimbs, n, nlimbs, logQ, nd, decomp_bytes, dig + (i64)i * nd * n);  /* ByteDecomp :244 */
+  for (int k = 0; k < ncol; k++) orc_dcrt_from_poly(c, dig + (i64)k * n, 1, n, bd + (i64)k * rs);                                     /* :246-249 (digits < 2^24: one non-negative limb) */
+  int W = c->L + 3; u64* big = malloc(8 * n * W);
+  for (int r = 0; r < 2; r++) { const u64* key = ksm + (i64)r * ncol * rs;
+    memcpy(acc, key, 8 * rs); orc_dcrt_op(c, acc, bd, 2);                                                                              /* DotProduct Util.h:79-98 */
+    for (int k = 1; k < ncol; k++) { memcpy(tmp, key + (i64)k * rs, 8 * rs); orc_dcrt_op(c, tmp, bd + (i64)k * rs, 2); orc_dcrt_op(c, acc, tmp, 0); }
+    orc_dcrt_to_poly(c, acc, NULL, 0, 0, big, W);                                                                                      /* :255 */
+    for (i64 j = 0; j < n; j++) { reduce_logq(big + j * W, W, logQ, 0); bn_copy_ext(out + ((i64)r * n + j) * nlimbs, nlimbs, big + j * W, W); }   /* :256 */
+  }
+  free(parts); free(dig); free(bd); free(acc); free(tmp); free(big);
+}
+
+/* The metric's unit of work (Test_AddMul.cpp:59-67): operator*= then ApplyKeySwitch */
+void orc_ct_mul_relin(const orc_ctx* c, const u64* ksm, const u64* a, const u64* b, int nlimbs, int logQ, u64 p, int decomp_bytes, u64* out) {
+  i64 rs = (i64)c->L * c->phim; u64* tprod = malloc(8 * 3 * rs);
+  orc_ct_mul(c, a, b, nlimbs, p, tprod);
+  orc_apply_key_switch(c, ksm, tprod, 3, logQ, decomp_bytes, out, nlimbs);
+  free(tprod);
+}

@@ -1,0 +1,205 @@
+"""ctypes wrapper around oracle/libfhesi_oracle.so (the C restatement).  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+_SO = os.path.join(ROOT, "oracle", "libfhesi_oracle.so")
+
+u64p = C.POINTER(C.c_uint64)
+
+
+def build():
+    src = os.path.join(ROOT, "oracle", "fhesi_oracle.c")
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_ctx_create.restype = C.c_void_p
+        _lib.orc_ctx_create.argtypes = [C.c_int64, C.c_int, u64p, u64p]
+        _lib.orc_ctx_destroy.argtypes = [C.c_void_p]
+        _lib.orc_phim.restype = C.c_int64
+        _lib.orc_phim.argtypes = [C.c_void_p]
+        _lib.orc_last_error.restype = C.c_char_p
+        _lib.orc_set_slow_dft.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_fft_residues.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        _lib.orc_cmod_fft.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+        _lib.orc_cmod_ifft.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.orc_dcrt_from_poly.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+        _lib.orc_dcrt_op.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.orc_dcrt_op_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _lib.orc_dcrt_automorph.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        _lib.orc_dcrt_automorph.restype = C.c_int
+        _lib.orc_dcrt_to_poly.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _lib.orc_reduce_coeffs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
+        _lib.orc_scale_down.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        _lib.orc_byte_decomp_part.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.orc_ct_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+        _lib.orc_apply_key_switch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _lib.orc_ct_mul_relin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- big-int <-> limb arrays -------------------------------------------------------------------
+def ints_to_limbs(vals, nlimbs: int) -> np.ndarray:
+    """signed Python ints -> [len][nlimbs] uint64 two's complement little-endian."""
+    out = np.zeros((len(vals), nlimbs), dtype=np.uint64)
+    mod = 1 << (64 * nlimbs)
+    for i, v in enumerate(vals):
+        v %= mod
+        for k in range(nlimbs):
+            out[i, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def limbs_to_ints(arr: np.ndarray):
+    nl = arr.shape[-1]
+    flat = arr.reshape(-1, nl)
+    res = []
+    for row in flat:
+        v = 0
+        for k in range(nl):
+            v |= int(row[k]) << (64 * k)
+        if v >> (64 * nl - 1):
+            v -= 1 << (64 * nl)
+        res.append(v)
+    return res
+
+
+class Oracle:
+    """One FHEcontext worth of oracle state (m, primes, roots)."""
+
+    def __init__(self, m: int, primes, roots):
+        self.m, self.primes, self.roots = m, [int(q) for q in primes], [int(r) for r in roots]
+        self.L = len(self.primes)
+        q = np.array(self.primes, dtype=np.uint64)
+        r = np.array(self.roots, dtype=np.uint64)
+        self.h = lib().orc_ctx_create(m, self.L, q.ctypes.data_as(u64p), r.ctypes.data_as(u64p))
+        if not self.h:
+            raise ValueError(lib().orc_last_error().decode())
+        self.phim = lib().orc_phim(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ctx_destroy(self.h)
+            self.h = None
+
+    def set_slow_dft(self, on: bool):
+        lib().orc_set_slow_dft(self.h, int(on))
+
+    def tables(self):
+        z = np.zeros(self.m, dtype=np.int32)
+        phi = np.zeros(self.phim + 1, dtype=np.int64)
+        lib().orc_get_tables(self.h, _p(z), _p(phi))
+        return z, phi
+
+    def fft_residues(self, i, xres: np.ndarray) -> np.ndarray:
+        xres = np.ascontiguousarray(xres, dtype=np.uint64)
+        y = np.zeros(self.phim, dtype=np.uint64)
+        lib().orc_fft_residues(self.h, i, _p(xres), len(xres), _p(y))
+        return y
+
+    def cmod_fft(self, i, limbs: np.ndarray) -> np.ndarray:
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        y = np.zeros(self.phim, dtype=np.uint64)
+        lib().orc_cmod_fft(self.h, i, _p(limbs), limbs.shape[1], limbs.shape[0], _p(y))
+        return y
+
+    def cmod_ifft(self, i, y: np.ndarray) -> np.ndarray:
+        y = np.ascontiguousarray(y, dtype=np.uint64)
+        x = np.zeros(self.phim, dtype=np.uint64)
+        lib().orc_cmod_ifft(self.h, i, _p(y), _p(x))
+        return x
+
+    def dcrt_from_poly(self, limbs: np.ndarray) -> np.ndarray:
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        rows = np.zeros((self.L, self.phim), dtype=np.uint64)
+        lib().orc_dcrt_from_poly(self.h, _p(limbs), limbs.shape[1], limbs.shape[0], _p(rows))
+        return rows
+
+    def dcrt_op(self, a: np.ndarray, b: np.ndarray, op: int) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64, copy=True)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        lib().orc_dcrt_op(self.h, _p(a), _p(b), op)
+        return a
+
+    def dcrt_op_scalar(self, a: np.ndarray, num: int, op: int, nlimbs: int = 4) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64, copy=True)
+        s = ints_to_limbs([num], nlimbs)
+        lib().orc_dcrt_op_scalar(self.h, _p(a), _p(s), nlimbs, op)
+        return a
+
+    def dcrt_automorph(self, a: np.ndarray, k: int) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64, copy=True)
+        if lib().orc_dcrt_automorph(self.h, _p(a), k) != 0:
+            raise ValueError("DoubleCRT::automorph: k not in Zm*")
+        return a
+
+    def dcrt_to_poly(self, rows: np.ndarray, nlimbs: int, idx=None, positive=False) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros((self.phim, nlimbs), dtype=np.uint64)
+        if idx is None:
+            lib().orc_dcrt_to_poly(self.h, _p(rows), None, 0, int(positive), _p(out), nlimbs)
+        else:
+            ia = np.array(idx, dtype=np.int32)
+            lib().orc_dcrt_to_poly(self.h, _p(rows), _p(ia), len(ia), int(positive), _p(out), nlimbs)
+        return out
+
+    def scale_down(self, rows: np.ndarray, logQ: int, nlimbs: int) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros((self.phim, nlimbs), dtype=np.uint64)
+        lib().orc_scale_down(self.h, _p(rows), logQ, _p(out), nlimbs)
+        return out
+
+    def byte_decomp_part(self, poly: np.ndarray, logQ: int, nd: int, decomp_bytes: int = 3) -> np.ndarray:
+        poly = np.ascontiguousarray(poly, dtype=np.uint64)
+        out = np.zeros((nd, poly.shape[0]), dtype=np.uint64)
+        lib().orc_byte_decomp_part(_p(poly), poly.shape[0], poly.shape[1], logQ, nd, decomp_bytes, _p(out))
+        return out
+
+    def ct_mul(self, a: np.ndarray, b: np.ndarray, p: int) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        t = np.zeros((3, self.L, self.phim), dtype=np.uint64)
+        lib().orc_ct_mul(self.h, _p(a), _p(b), a.shape[-1], p, _p(t))
+        return t
+
+    def apply_key_switch(self, ksm: np.ndarray, tprod: np.ndarray, logQ: int, nlimbs: int, decomp_bytes: int = 3):
+        ksm = np.ascontiguousarray(ksm, dtype=np.uint64)
+        tprod = np.ascontiguousarray(tprod, dtype=np.uint64)
+        out = np.zeros((2, self.phim, nlimbs), dtype=np.uint64)
+        lib().orc_apply_key_switch(self.h, _p(ksm), _p(tprod), tprod.shape[0], logQ, decomp_bytes, _p(out), nlimbs)
+        return out
+
+    def ct_mul_relin(self, ksm: np.ndarray, a: np.ndarray, b: np.ndarray, logQ: int, p: int, decomp_bytes: int = 3):
+        ksm = np.ascontiguousarray(ksm, dtype=np.uint64)
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros((2, self.phim, a.shape[-1]), dtype=np.uint64)
+        lib().orc_ct_mul_relin(self.h, _p(ksm), _p(a), _p(b), a.shape[-1], logQ, p, decomp_bytes, _p(out))
+        return out
+
+
+def reduce_coeffs(poly: np.ndarray, logQ: int, positive: bool = False) -> np.ndarray:
+    poly = np.array(poly, dtype=np.uint64, copy=True)
+    lib().orc_reduce_coeffs(_p(poly), poly.shape[0], poly.shape[1], logQ, int(positive))
+    return poly
