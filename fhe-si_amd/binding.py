@@ -1,0 +1,405 @@
+"""ctypes binding of include/fhesi_hip.h (the C ABI of the HIP library).
+
+No compute happens in Python and there is no CPU fallback: if the shared library is missing or a HIP call fails,
+the binding raises FhesiError with the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_DIR, "csrc")
+_SO = os.path.join(_CSRC, "libfhesi_hip.so")
+
+OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SET = 0, 1, 2, 3, 4
+
+# every symbol include/fhesi_hip.h declares (tests/test_abi.py checks the library exports all of them)
+ABI_SYMBOLS = [
+    "fhesi_last_error", "fhesi_device_count", "fhesi_ctx_create", "fhesi_ctx_destroy", "fhesi_ctx_m", "fhesi_ctx_phim",
+    "fhesi_ctx_nprimes", "fhesi_ctx_prime", "fhesi_ctx_zms_idx", "fhesi_ctx_phi_m", "fhesi_ctx_sync", "fhesi_ctx_stream",
+    "fhesi_timer_start", "fhesi_timer_stop", "fhesi_cmod_fft", "fhesi_cmod_ifft", "fhesi_dcrt_alloc", "fhesi_dcrt_free",
+    "fhesi_dcrt_copy", "fhesi_dcrt_index_set", "fhesi_dcrt_equal", "fhesi_dcrt_upload_row", "fhesi_dcrt_download_row",
+    "fhesi_dcrt_device_ptr", "fhesi_dcrt_from_poly", "fhesi_dcrt_to_poly", "fhesi_dcrt_op", "fhesi_dcrt_op_scalar",
+    "fhesi_dcrt_automorph", "fhesi_dcrt_add_primes", "fhesi_dcrt_remove_primes", "fhesi_dcrt_from_scrt", "fhesi_dcrt_to_scrt",
+    "fhesi_rows_ntt_fwd_dev", "fhesi_rows_ntt_inv_dev", "fhesi_rows_op_dev", "fhesi_ksk_create", "fhesi_ksk_free",
+    "fhesi_ksk_upload", "fhesi_ksk_device_ptr", "fhesi_ksk_bytes", "fhesi_ct_mul_relin_batch", "fhesi_ct_mul_relin_batch_dev",
+    "fhesi_ct_mul_dev", "fhesi_apply_key_switch_dev", "fhesi_dev_alloc", "fhesi_dev_free", "fhesi_dev_upload", "fhesi_dev_download",
+]
+
+
+class FhesiError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _SO
+
+
+def build_library(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".h", ".inc"))]
+    srcs.append(os.path.join(os.path.dirname(_DIR), "include", "fhesi_hip.h"))
+    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-j8"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+_vp, _i32, _i64, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise FhesiError(f"HIP extension not built: {_SO} is missing (run __graft_entry__.build())")
+    lib = C.CDLL(_SO)
+    lib.fhesi_last_error.restype = C.c_char_p
+    sig = {
+        "fhesi_device_count": [_vp],
+        "fhesi_ctx_create": [_vp, _i64, _i32, _vp, _vp, _i32],
+        "fhesi_ctx_destroy": [_vp],
+        "fhesi_ctx_prime": [_vp, _i32, _vp, _vp],
+        "fhesi_ctx_zms_idx": [_vp, _vp],
+        "fhesi_ctx_phi_m": [_vp, _vp],
+        "fhesi_ctx_sync": [_vp],
+        "fhesi_timer_start": [_vp],
+        "fhesi_timer_stop": [_vp, _vp],
+        "fhesi_cmod_fft": [_vp, _i32, _vp, _i32, _i64, _vp],
+        "fhesi_cmod_ifft": [_vp, _i32, _vp, _vp],
+        "fhesi_dcrt_alloc": [_vp, _vp, _i32, _vp],
+        "fhesi_dcrt_free": [_vp],
+        "fhesi_dcrt_copy": [_vp, _vp],
+        "fhesi_dcrt_index_set": [_vp, _vp, _vp],
+        "fhesi_dcrt_equal": [_vp, _vp, _vp],
+        "fhesi_dcrt_upload_row": [_vp, _i32, _vp],
+        "fhesi_dcrt_download_row": [_vp, _i32, _vp],
+        "fhesi_dcrt_from_poly": [_vp, _vp, _i32, _i64],
+        "fhesi_dcrt_to_poly": [_vp, _vp, _i32, _i32, _vp, _i32],
+        "fhesi_dcrt_op": [_vp, _vp, _i32],
+        "fhesi_dcrt_op_scalar": [_vp, _vp, _i32, _i32],
+        "fhesi_dcrt_automorph": [_vp, _i64],
+        "fhesi_dcrt_add_primes": [_vp, _vp, _i32],
+        "fhesi_dcrt_remove_primes": [_vp, _vp, _i32],
+        "fhesi_dcrt_from_scrt": [_vp, _vp],
+        "fhesi_dcrt_to_scrt": [_vp, _vp],
+        "fhesi_rows_ntt_fwd_dev": [_vp, _vp, _i64],
+        "fhesi_rows_ntt_inv_dev": [_vp, _vp, _i64],
+        "fhesi_rows_op_dev": [_vp, _vp, _vp, _i64, _i32],
+        "fhesi_ksk_create": [_vp, _i32, _i32, _vp],
+        "fhesi_ksk_free": [_vp],
+        "fhesi_ksk_upload": [_vp, _vp],
+        "fhesi_ct_mul_relin_batch": [_vp, _vp, _i32, _u64, _i32, _vp, _vp, _vp, _i32, _i64],
+        "fhesi_ct_mul_relin_batch_dev": [_vp, _vp, _i32, _u64, _i32, _vp, _vp, _vp, _i32, _i64],
+        "fhesi_ct_mul_dev": [_vp, _u64, _vp, _vp, _i32, _i64, _vp],
+        "fhesi_apply_key_switch_dev": [_vp, _vp, _i32, _i32, _vp, _i64, _vp, _i32],
+        "fhesi_dev_alloc": [_vp, C.c_size_t, _vp],
+        "fhesi_dev_free": [_vp, _vp],
+        "fhesi_dev_upload": [_vp, _vp, _vp, C.c_size_t],
+        "fhesi_dev_download": [_vp, _vp, _vp, C.c_size_t],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name in ("fhesi_ctx_m", "fhesi_ctx_phim"):
+        getattr(lib, name).argtypes = [_vp]
+        getattr(lib, name).restype = _i64
+    lib.fhesi_ctx_nprimes.argtypes = [_vp]
+    lib.fhesi_ctx_nprimes.restype = _i32
+    for name in ("fhesi_ctx_stream", "fhesi_dcrt_device_ptr", "fhesi_ksk_device_ptr"):
+        getattr(lib, name).argtypes = [_vp]
+        getattr(lib, name).restype = _vp
+    lib.fhesi_ksk_bytes.argtypes = [_vp]
+    lib.fhesi_ksk_bytes.restype = C.c_size_t
+    _lib = lib
+    return lib
+
+
+def _ck(rc: int):
+    if rc != 0:
+        raise FhesiError(_load().fhesi_last_error().decode())
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_vp)
+
+
+class Backend:
+    @staticmethod
+    def lib():
+        return _load()
+
+    @staticmethod
+    def device_count() -> int:
+        n = _i32(0)
+        _ck(_load().fhesi_device_count(C.byref(n)))
+        return n.value
+
+
+class DevBuf:
+    """Plain HBM buffer owned through the C ABI."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, nbytes
+        self.ptr = _vp()
+        _ck(_load().fhesi_dev_alloc(ctx.h, nbytes, C.byref(self.ptr)))
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _ck(_load().fhesi_dev_upload(self.ctx.h, self.ptr, _p(arr), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.uint64) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _ck(_load().fhesi_dev_download(self.ctx.h, _p(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _load().fhesi_dev_free(self.ctx.h, self.ptr)
+            self.ptr = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """FHEcontext + Cmodulus chain on one GPU (fhesi_ctx_create)."""
+
+    def __init__(self, m: int, primes, roots, device: int = 0):
+        q = np.array([int(x) for x in primes], dtype=np.uint64)
+        r = np.array([int(x) for x in roots], dtype=np.uint64)
+        self.h = _vp()
+        _ck(_load().fhesi_ctx_create(C.byref(self.h), m, len(q), _p(q), _p(r), device))
+        self.m, self.primes, self.roots = m, [int(x) for x in q], [int(x) for x in r]
+        self.L = len(self.primes)
+        self.phim = _load().fhesi_ctx_phim(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            _load().fhesi_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _ck(_load().fhesi_ctx_sync(self.h))
+
+    def zms_idx(self) -> np.ndarray:
+        out = np.zeros(self.m, dtype=np.int32)
+        _ck(_load().fhesi_ctx_zms_idx(self.h, _p(out)))
+        return out
+
+    def phi_m(self) -> np.ndarray:
+        out = np.zeros(self.phim + 1, dtype=np.int64)
+        _ck(_load().fhesi_ctx_phi_m(self.h, _p(out)))
+        return out
+
+    def timer_start(self):
+        _ck(_load().fhesi_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        _ck(_load().fhesi_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    # Cmodulus::FFT / iFFT
+    def cmod_fft(self, prime: int, limbs: np.ndarray) -> np.ndarray:
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        y = np.zeros(self.phim, dtype=np.uint64)
+        _ck(_load().fhesi_cmod_fft(self.h, prime, _p(limbs), limbs.shape[1], limbs.shape[0], _p(y)))
+        return y
+
+    def cmod_ifft(self, prime: int, y: np.ndarray) -> np.ndarray:
+        y = np.ascontiguousarray(y, dtype=np.uint64)
+        x = np.zeros(self.phim, dtype=np.uint64)
+        _ck(_load().fhesi_cmod_ifft(self.h, prime, _p(y), _p(x)))
+        return x
+
+    def alloc(self, nbytes: int) -> DevBuf:
+        return DevBuf(self, nbytes)
+
+    def upload(self, arr: np.ndarray) -> DevBuf:
+        arr = np.ascontiguousarray(arr)
+        return DevBuf(self, max(arr.nbytes, 8)).upload(arr)
+
+    # batched device-resident rows [count][L][phim]
+    def rows_ntt_fwd(self, buf: DevBuf, count: int):
+        _ck(_load().fhesi_rows_ntt_fwd_dev(self.h, buf.ptr, count))
+
+    def rows_ntt_inv(self, buf: DevBuf, count: int):
+        _ck(_load().fhesi_rows_ntt_inv_dev(self.h, buf.ptr, count))
+
+    def rows_op(self, dst: DevBuf, src: DevBuf, count: int, op: int):
+        _ck(_load().fhesi_rows_op_dev(self.h, dst.ptr, src.ptr, count, op))
+
+    def ct_mul_dev(self, p: int, a: DevBuf, b: DevBuf, nlimbs: int, count: int, tprod: DevBuf):
+        _ck(_load().fhesi_ct_mul_dev(self.h, p, a.ptr, b.ptr, nlimbs, count, tprod.ptr))
+
+    def apply_key_switch_dev(self, ksk: "KeySwitchMatrix", logQ: int, tprod: DevBuf, count: int, out: DevBuf, nlimbs: int, decomp_bytes: int = 3):
+        _ck(_load().fhesi_apply_key_switch_dev(self.h, ksk.h, logQ, decomp_bytes, tprod.ptr, count, out.ptr, nlimbs))
+
+    def ct_mul_relin_dev(self, ksk: "KeySwitchMatrix", logQ: int, p: int, a: DevBuf, b: DevBuf, out: DevBuf, nlimbs: int, count: int, decomp_bytes: int = 3):
+        _ck(_load().fhesi_ct_mul_relin_batch_dev(self.h, ksk.h, logQ, p, decomp_bytes, a.ptr, b.ptr, out.ptr, nlimbs, count))
+
+    def ct_mul_relin(self, ksk: "KeySwitchMatrix", logQ: int, p: int, a: np.ndarray, b: np.ndarray, decomp_bytes: int = 3) -> np.ndarray:
+        """a, b: [count][2][phim][nlimbs] uint64 two's complement -> same shape."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros_like(a)
+        _ck(_load().fhesi_ct_mul_relin_batch(self.h, ksk.h, logQ, p, decomp_bytes, _p(a), _p(b), _p(out), a.shape[-1], a.shape[0]))
+        return out
+
+
+class DoubleCRT:
+    """One DoubleCRT object resident in HBM (DoubleCRT.h:83-365 through the C ABI)."""
+
+    def __init__(self, ctx: Context, index_set=None):
+        self.ctx = ctx
+        self.h = _vp()
+        if index_set is None:
+            _ck(_load().fhesi_dcrt_alloc(ctx.h, None, 0, C.byref(self.h)))
+        else:
+            ia = np.array(list(index_set), dtype=np.int32)
+            if len(ia) == 0:
+                raise FhesiError("DoubleCRT: empty index set")
+            _ck(_load().fhesi_dcrt_alloc(ctx.h, _p(ia), len(ia), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _load().fhesi_dcrt_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def from_poly(cls, ctx: Context, limbs: np.ndarray, index_set=None) -> "DoubleCRT":
+        d = cls(ctx, index_set)
+        d.assign_poly(limbs)
+        return d
+
+    def index_set(self):
+        n = _i32(0)
+        buf = np.zeros(self.ctx.L, dtype=np.int32)
+        _ck(_load().fhesi_dcrt_index_set(self.h, _p(buf), C.byref(n)))
+        return [int(x) for x in buf[:n.value]]
+
+    def assign_poly(self, limbs: np.ndarray):
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        _ck(_load().fhesi_dcrt_from_poly(self.h, _p(limbs), limbs.shape[1], limbs.shape[0]))
+
+    def assign(self, other: "DoubleCRT"):
+        _ck(_load().fhesi_dcrt_copy(self.h, other.h))
+
+    def copy(self) -> "DoubleCRT":
+        d = DoubleCRT(self.ctx, self.index_set())
+        d.assign(self)
+        return d
+
+    def to_poly(self, nlimbs: int, index_set=None, positive: bool = False) -> np.ndarray:
+        out = np.zeros((self.ctx.phim, nlimbs), dtype=np.uint64)
+        if index_set is None:
+            _ck(_load().fhesi_dcrt_to_poly(self.h, None, 0, int(positive), _p(out), nlimbs))
+        else:
+            ia = np.array(list(index_set), dtype=np.int32)
+            if len(ia) == 0:      # empty intersection -> zero polynomial (DoubleCRT.cpp:354-357)
+                return out
+            _ck(_load().fhesi_dcrt_to_poly(self.h, _p(ia), len(ia), int(positive), _p(out), nlimbs))
+        return out
+
+    def row(self, prime: int) -> np.ndarray:
+        out = np.zeros(self.ctx.phim, dtype=np.uint64)
+        _ck(_load().fhesi_dcrt_download_row(self.h, prime, _p(out)))
+        return out
+
+    def set_row(self, prime: int, row: np.ndarray):
+        row = np.ascontiguousarray(row, dtype=np.uint64)
+        _ck(_load().fhesi_dcrt_upload_row(self.h, prime, _p(row)))
+
+    def rows(self) -> np.ndarray:
+        return np.stack([self.row(i) for i in self.index_set()])
+
+    def op(self, other: "DoubleCRT", op: int):
+        _ck(_load().fhesi_dcrt_op(self.h, other.h, op))
+        return self
+
+    def op_scalar(self, num: int, op: int, nlimbs: int = 4):
+        mod = 1 << (64 * nlimbs)
+        v = num % mod
+        s = np.array([(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(nlimbs)], dtype=np.uint64)
+        _ck(_load().fhesi_dcrt_op_scalar(self.h, _p(s), nlimbs, op))
+        return self
+
+    def automorph(self, k: int):
+        _ck(_load().fhesi_dcrt_automorph(self.h, k))
+        return self
+
+    def add_primes(self, idx):
+        ia = np.array(list(idx), dtype=np.int32)
+        _ck(_load().fhesi_dcrt_add_primes(self.h, _p(ia), len(ia)))
+
+    def remove_primes(self, idx):
+        ia = np.array(list(idx), dtype=np.int32)
+        _ck(_load().fhesi_dcrt_remove_primes(self.h, _p(ia), len(ia)))
+
+    def equals(self, other: "DoubleCRT") -> bool:
+        eq = _i32(0)
+        _ck(_load().fhesi_dcrt_equal(self.h, other.h, C.byref(eq)))
+        return bool(eq.value)
+
+    def from_scrt(self, coeff_rows: np.ndarray):
+        coeff_rows = np.ascontiguousarray(coeff_rows, dtype=np.uint64)
+        _ck(_load().fhesi_dcrt_from_scrt(self.h, _p(coeff_rows)))
+
+    def to_scrt(self) -> np.ndarray:
+        out = np.zeros((len(self.index_set()), self.ctx.phim), dtype=np.uint64)
+        _ck(_load().fhesi_dcrt_to_scrt(self.h, _p(out)))
+        return out
+
+
+class KeySwitchMatrix:
+    """KeySwitchSI::keySwitchMatrix resident in HBM: [2][ncomp*ndigits][L][phim]."""
+
+    def __init__(self, ctx: Context, ncomp: int, ndigits: int):
+        self.ctx, self.ncomp, self.ndigits = ctx, ncomp, ndigits
+        self.h = _vp()
+        _ck(_load().fhesi_ksk_create(ctx.h, ncomp, ndigits, C.byref(self.h)))
+
+    def upload(self, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        assert rows.nbytes == self.nbytes, (rows.nbytes, self.nbytes)
+        _ck(_load().fhesi_ksk_upload(self.h, _p(rows)))
+        return self
+
+    @property
+    def nbytes(self) -> int:
+        return _load().fhesi_ksk_bytes(self.h)
+
+    @property
+    def device_ptr(self) -> int:
+        return _load().fhesi_ksk_device_ptr(self.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _load().fhesi_ksk_free(self.h)
+                self.h = None
+        except Exception:
+            pass

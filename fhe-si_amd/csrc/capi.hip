@@ -1,0 +1,739 @@
+// capi.hip -- implementation of include/fhesi_hip.h on top of the HIP kernels in this directory.
+// Product path only: nothing here touches oracle/ and there is no CPU fallback -- every entry point that computes
+// fails with an error string if HIP is unavailable.
+#include "../../include/fhesi_hip.h"
+#include "fhesi_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+// --------------------------------------------------------------------------------------------- helpers
+int ws_reserve(fhesi_ctx* ctx, int slot, size_t bytes, void** out) {
+  if (ctx->ws_bytes[slot] < bytes) {
+    if (ctx->ws[slot]) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->ws[slot])); ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0; }
+    size_t want = bytes + (bytes >> 3) + 4096;
+    HIP_TRY(hipMalloc(&ctx->ws[slot], want));
+    ctx->ws_bytes[slot] = want;
+  }
+  *out = ctx->ws[slot];
+  return 0;
+}
+
+#define CHECK_CTX(c) do { if (!(c)) FHESI_FAIL("null context"); HIP_TRY(hipSetDevice((c)->device)); } while (0)
+
+static int row_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_pos, const int* h_pos) {
+  if (ctx->pow2) return launch_ntt_fwd(ctx, d_rows, count, nslots, d_pos, true);
+  return launch_bluestein_fwd(ctx, d_rows, count, nslots, h_pos);
+}
+static int row_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_pos, const int* h_pos) {
+  if (ctx->pow2) return launch_ntt_inv(ctx, d_rows, count, nslots, d_pos, true);
+  return launch_bluestein_inv(ctx, d_rows, count, nslots, h_pos);
+}
+
+// device copy of an index list (small, cached per call in workspace slot 3)
+static int upload_idx(fhesi_ctx* ctx, const std::vector<int>& idx, int** d_out) {
+  bool identity = (int)idx.size() == ctx->L;
+  for (size_t i = 0; identity && i < idx.size(); ++i) identity = idx[i] == (int)i;
+  if (identity) { *d_out = nullptr; return 0; }
+  void* p;
+  FHESI_TRY(ws_reserve(ctx, 3, idx.size() * sizeof(int) + 64, &p));
+  HIP_TRY(hipMemcpyAsync(p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *d_out = (int*)p;
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------- context
+extern "C" int fhesi_device_count(int32_t* count) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *count = 0; FHESI_FAIL("hipGetDeviceCount failed: %s", hipGetErrorString(e)); }
+  *count = c;
+  return 0;
+}
+
+static void build_tile_order(const std::vector<Shoup2>& tw, int logn, std::vector<Shoup2>& twt) {
+  const i64 n = 1ll << logn;
+  const int R = logn - 10;
+  twt.assign(n, Shoup2{0, 0});
+  for (int i = 0; i < 32; ++i) twt[i] = tw[i];
+  for (int u = 0; u < 5; ++u)
+    for (int x = 0; x < (1 << u); ++x)
+      for (int p1 = 0; p1 < 32; ++p1) twt[32 + ((1 << u) - 1 + x) * 32 + p1] = tw[(1 << (5 + u)) + (p1 << u) + x];
+  for (int u = 0; u < R; ++u)
+    for (int x = 0; x < (1 << u); ++x)
+      for (int jl = 0; jl < 1024; ++jl) twt[1024 + (i64)((1 << u) - 1 + x) * 1024 + jl] = tw[(1 << (10 + u)) + ((i64)hm::brv(jl, 10) << u) + x];
+}
+
+extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, const uint64_t* q, const uint64_t* root, int32_t device) {
+  if (!out) FHESI_FAIL("null output pointer");
+  *out = nullptr;
+  if (m < 2 || m > (1 << 20)) FHESI_FAIL("FHEcontext: m undefined or larger than 2^20");     // FHEContext.cpp:89
+  if (nprimes < 1 || nprimes > 64) FHESI_FAIL("FHEcontext: number of primes %d outside [1,64]", nprimes);
+  for (int i = 0; i < nprimes; ++i) {
+    // FHEContext.cpp:31-34: assert( ProbPrime(p) && p % twoM == 1 && !inChain(p) )
+    if (q[i] >= (1ull << 62)) FHESI_FAIL("AddPrime: prime %d does not fit 62 bits", i);
+    if (!hm::is_prime(q[i])) FHESI_FAIL("AddPrime: modulus %d (%llu) is not prime", i, (unsigned long long)q[i]);
+    if (q[i] % (2 * (u64)m) != 1) FHESI_FAIL("AddPrime: prime %d (%llu) is not 1 mod 2m", i, (unsigned long long)q[i]);
+    for (int j = 0; j < i; ++j)
+      if (q[j] == q[i]) FHESI_FAIL("AddPrime: prime %d (%llu) already in chain", i, (unsigned long long)q[i]);
+    if (!hm::is_primitive_2m_root(root[i], m, q[i])) FHESI_FAIL("Cmodulus: root %d is not a primitive 2m-th root of unity mod q", i);
+  }
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) FHESI_FAIL("device %d not available (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  fhesi_ctx* c = new fhesi_ctx();
+  c->device = device;
+  c->m = m;
+  c->L = nprimes;
+  c->q.assign(q, q + nprimes);
+  c->root.assign(root, root + nprimes);
+  c->zms_idx = hm::zms_idx(m, &c->phim);
+  c->phi = hm::cyclotomic(m);
+  c->pow2 = (m & (m - 1)) == 0 && m >= 4;
+  c->logn = c->pow2 ? hm::ilog2_ceil(c->phim) : 0;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+
+  const i64 n = c->phim;
+  c->pc.resize(nprimes);
+  for (int i = 0; i < nprimes; ++i) {
+    PrimeConst& pc = c->pc[i];
+    const u64 Q = q[i];
+    pc.q = Q;
+    pc.two_q = 2 * Q;
+    int k = 64 - __builtin_clzll(Q);
+    pc.bar_k = (u32)k;
+    pc.bar_mu = (u64)((((u128)1) << (2 * k)) / Q);
+    pc.pad0 = 0;
+    pc.r64 = (u64)(((u128)1 << 64) % Q);
+    pc.r64_sh = hm::shoup(pc.r64, Q);
+    pc.ninv = pc.ninv_sh = pc.ninv_w = pc.ninv_w_sh = 0;
+  }
+  if (c->pow2) {
+    const int lg = c->logn;
+    std::vector<Shoup2> twf((size_t)nprimes * n), twi((size_t)nprimes * n);
+    for (int i = 0; i < nprimes; ++i) {
+      const u64 Q = q[i];
+      const u64 psi = hm::mulmod(root[i], root[i], Q), ipsi = hm::invmod(psi, Q);
+      // powers in natural order, then scatter to bit-reversed slots
+      std::vector<u64> pw(n), ipw(n);
+      pw[0] = ipw[0] = 1;
+      for (i64 e = 1; e < n; ++e) { pw[e] = hm::mulmod(pw[e - 1], psi, Q); ipw[e] = hm::mulmod(ipw[e - 1], ipsi, Q); }
+      for (i64 j = 0; j < n; ++j) {
+        const u64 e = hm::brv((u64)j, lg);
+        twf[(size_t)i * n + j] = {pw[e], hm::shoup(pw[e], Q)};
+        twi[(size_t)i * n + j] = {ipw[e], hm::shoup(ipw[e], Q)};
+      }
+      PrimeConst& pc = c->pc[i];
+      pc.ninv = hm::invmod((u64)n % Q, Q);
+      pc.ninv_sh = hm::shoup(pc.ninv, Q);
+      pc.ninv_w = hm::mulmod(pc.ninv, n > 1 ? twi[(size_t)i * n + 1].w : 1, Q);
+      pc.ninv_w_sh = hm::shoup(pc.ninv_w, Q);
+    }
+    const size_t tb = twf.size() * sizeof(Shoup2);
+    HIP_TRY(hipMalloc(&c->d_tw_fwd, tb));
+    HIP_TRY(hipMalloc(&c->d_tw_inv, tb));
+    HIP_TRY(hipMemcpy(c->d_tw_fwd, twf.data(), tb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_tw_inv, twi.data(), tb, hipMemcpyHostToDevice));
+    if (lg >= 11 && lg <= 14) {
+      std::vector<Shoup2> all_f((size_t)nprimes * n), all_i((size_t)nprimes * n), one, tmp;
+      for (int i = 0; i < nprimes; ++i) {
+        one.assign(twf.begin() + (size_t)i * n, twf.begin() + (size_t)(i + 1) * n);
+        build_tile_order(one, lg, tmp);
+        std::copy(tmp.begin(), tmp.end(), all_f.begin() + (size_t)i * n);
+        one.assign(twi.begin() + (size_t)i * n, twi.begin() + (size_t)(i + 1) * n);
+        build_tile_order(one, lg, tmp);
+        std::copy(tmp.begin(), tmp.end(), all_i.begin() + (size_t)i * n);
+      }
+      HIP_TRY(hipMalloc(&c->d_twt_fwd, tb));
+      HIP_TRY(hipMalloc(&c->d_twt_inv, tb));
+      HIP_TRY(hipMemcpy(c->d_twt_fwd, all_f.data(), tb, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(c->d_twt_inv, all_i.data(), tb, hipMemcpyHostToDevice));
+    }
+  }
+  HIP_TRY(hipMalloc(&c->d_pc, sizeof(PrimeConst) * nprimes));
+  HIP_TRY(hipMemcpy(c->d_pc, c->pc.data(), sizeof(PrimeConst) * nprimes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&c->d_zms_idx, sizeof(int) * m));
+  HIP_TRY(hipMemcpy(c->d_zms_idx, c->zms_idx.data(), sizeof(int) * m, hipMemcpyHostToDevice));
+  std::vector<int> zl(n);
+  for (i64 i = 0; i < m; ++i)
+    if (c->zms_idx[i] >= 0) zl[c->zms_idx[i]] = (int)i;
+  HIP_TRY(hipMalloc(&c->d_zms_list, sizeof(int) * n));
+  HIP_TRY(hipMemcpy(c->d_zms_list, zl.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+  if (!c->pow2) {
+    int r = bluestein_init(c);
+    if (r) { fhesi_ctx_destroy(c); return r; }
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  bluestein_destroy(c);
+  for (auto& kv : c->crt_cache) { hipFree(kv.second->d_blob); delete kv.second; }
+  for (auto& kv : c->pow64_cache) hipFree(kv.second);
+  for (int i = 0; i < 10; ++i) if (c->ws[i]) hipFree(c->ws[i]);
+  hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv);
+  hipFree(c->d_zms_idx); hipFree(c->d_zms_list);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int64_t fhesi_ctx_m(const fhesi_ctx* c) { return c ? c->m : 0; }
+extern "C" int64_t fhesi_ctx_phim(const fhesi_ctx* c) { return c ? c->phim : 0; }
+extern "C" int32_t fhesi_ctx_nprimes(const fhesi_ctx* c) { return c ? c->L : 0; }
+extern "C" int fhesi_ctx_prime(const fhesi_ctx* c, int32_t i, uint64_t* q, uint64_t* root) {
+  if (!c || i < 0 || i >= c->L) FHESI_FAIL("ithPrime: index %d out of range", i);
+  if (q) *q = c->q[i];
+  if (root) *root = c->root[i];
+  return 0;
+}
+extern "C" int fhesi_ctx_zms_idx(const fhesi_ctx* c, int32_t* out_m) {
+  if (!c) FHESI_FAIL("null context");
+  for (i64 i = 0; i < c->m; ++i) out_m[i] = c->zms_idx[i];
+  return 0;
+}
+extern "C" int fhesi_ctx_phi_m(const fhesi_ctx* c, int64_t* o) {
+  if (!c) FHESI_FAIL("null context");
+  for (size_t i = 0; i < c->phi.size(); ++i) o[i] = c->phi[i];
+  return 0;
+}
+extern "C" int fhesi_ctx_sync(fhesi_ctx* c) { CHECK_CTX(c); HIP_TRY(hipStreamSynchronize(c->stream)); return 0; }
+extern "C" void* fhesi_ctx_stream(fhesi_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int fhesi_timer_start(fhesi_ctx* c) { CHECK_CTX(c); HIP_TRY(hipEventRecord(c->ev0, c->stream)); return 0; }
+extern "C" int fhesi_timer_stop(fhesi_ctx* c, float* ms) {
+  CHECK_CTX(c);
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------- plain device memory
+extern "C" int fhesi_dev_alloc(fhesi_ctx* c, size_t bytes, void** out) { CHECK_CTX(c); HIP_TRY(hipMalloc(out, bytes ? bytes : 8)); return 0; }
+extern "C" int fhesi_dev_free(fhesi_ctx* c, void* p) { CHECK_CTX(c); HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(p)); return 0; }
+extern "C" int fhesi_dev_upload(fhesi_ctx* c, void* dst, const void* src, size_t bytes) {
+  CHECK_CTX(c);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int fhesi_dev_download(fhesi_ctx* c, void* dst, const void* src, size_t bytes) {
+  CHECK_CTX(c);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------- Cmodulus::FFT / iFFT
+extern "C" int fhesi_cmod_fft(fhesi_ctx* c, int32_t prime, const uint64_t* limbs, int32_t nlimbs, int64_t ncoeffs, uint64_t* y) {
+  CHECK_CTX(c);
+  if (prime < 0 || prime >= c->L) FHESI_FAIL("Cmodulus::FFT: prime index %d out of range", prime);
+  if (nlimbs < 1 || ncoeffs < 0) FHESI_FAIL("Cmodulus::FFT: bad coefficient shape");
+  const i64 n = c->phim;
+  // conv(in,x) (CModulus.cpp:96) on the host for this single-row compatibility entry; coefficients of degree >= m are
+  // ignored (bluestein.cpp:111-113) and degrees phi(m)..m-1 are folded modulo Phi_m so that one length-phi(m) row goes in.
+  std::vector<u64> res(c->m, 0);
+  const u64 Q = c->q[prime];
+  for (i64 k = 0; k < ncoeffs && k < c->m; ++k) res[k] = hm::bn_mod((const u64*)limbs + k * nlimbs, nlimbs, Q);
+  for (i64 k = c->m - 1; k >= n; --k) {          // reduce modulo the monic Phi_m over Z_q
+    const u64 cc = res[k];
+    if (!cc) continue;
+    res[k] = 0;
+    for (i64 j = 0; j < n; ++j) {
+      const i64 f = c->phi[j];
+      if (!f) continue;
+      const u64 fm = f < 0 ? (Q - ((u64)(-f) % Q)) % Q : (u64)f % Q;
+      res[k - n + j] = (res[k - n + j] + Q - hm::mulmod(cc, fm, Q)) % Q;
+    }
+  }
+  void* d;
+  FHESI_TRY(ws_reserve(c, 0, n * 8, &d));
+  HIP_TRY(hipMemcpyAsync(d, res.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+  std::vector<int> pos(1, prime);
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, pos, &d_pos));
+  FHESI_TRY(row_fwd(c, (u64*)d, 1, 1, d_pos, pos.data()));
+  HIP_TRY(hipMemcpyAsync(y, d, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fhesi_cmod_ifft(fhesi_ctx* c, int32_t prime, const uint64_t* y, uint64_t* x) {
+  CHECK_CTX(c);
+  if (prime < 0 || prime >= c->L) FHESI_FAIL("Cmodulus::iFFT: prime index %d out of range", prime);
+  const i64 n = c->phim;
+  void* d;
+  FHESI_TRY(ws_reserve(c, 0, n * 8, &d));
+  HIP_TRY(hipMemcpyAsync(d, y, n * 8, hipMemcpyHostToDevice, c->stream));
+  std::vector<int> pos(1, prime);
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, pos, &d_pos));
+  FHESI_TRY(row_inv(c, (u64*)d, 1, 1, d_pos, pos.data()));
+  HIP_TRY(hipMemcpyAsync(x, d, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------- DoubleCRT objects
+static int slot_of(const fhesi_dcrt* d, int prime) {
+  auto it = std::lower_bound(d->idx.begin(), d->idx.end(), prime);
+  return (it != d->idx.end() && *it == prime) ? (int)(it - d->idx.begin()) : -1;
+}
+
+extern "C" int fhesi_dcrt_alloc(fhesi_ctx* c, const int32_t* prime_idx, int32_t nidx, fhesi_dcrt** out) {
+  CHECK_CTX(c);
+  fhesi_dcrt* d = new fhesi_dcrt();
+  d->ctx = c;
+  if (nidx == 0) { d->idx.resize(c->L); for (int i = 0; i < c->L; ++i) d->idx[i] = i; }
+  else {
+    d->idx.assign(prime_idx, prime_idx + nidx);
+    for (int i = 0; i < nidx; ++i)
+      if (d->idx[i] < 0 || d->idx[i] >= c->L || (i && d->idx[i] <= d->idx[i - 1])) { delete d; FHESI_FAIL("DoubleCRT: index set must be ascending and inside the chain"); }   // DoubleCRT.cpp:215
+  }
+  const size_t bytes = d->idx.size() * c->phim * 8;
+  HIP_TRY(hipMalloc(&d->d_rows, bytes ? bytes : 8));
+  HIP_TRY(hipMemsetAsync(d->d_rows, 0, bytes, c->stream));
+  *out = d;
+  return 0;
+}
+extern "C" int fhesi_dcrt_free(fhesi_dcrt* d) {
+  if (!d) return 0;
+  hipSetDevice(d->ctx->device);
+  hipStreamSynchronize(d->ctx->stream);
+  hipFree(d->d_rows);
+  delete d;
+  return 0;
+}
+static int dcrt_resize(fhesi_dcrt* d, const std::vector<int>& idx) {
+  if (idx.size() != d->idx.size()) {
+    HIP_TRY(hipStreamSynchronize(d->ctx->stream));
+    HIP_TRY(hipFree(d->d_rows));
+    HIP_TRY(hipMalloc(&d->d_rows, std::max<size_t>(8, idx.size() * d->ctx->phim * 8)));
+  }
+  d->idx = idx;
+  return 0;
+}
+extern "C" int fhesi_dcrt_copy(fhesi_dcrt* dst, const fhesi_dcrt* src) {
+  if (!dst || !src) FHESI_FAIL("null DoubleCRT");
+  if (dst->ctx != src->ctx) FHESI_FAIL("DoubleCRT assigment: incompatible contexts");   // DoubleCRT.cpp:315-316
+  CHECK_CTX(dst->ctx);
+  if (dst == src) return 0;
+  FHESI_TRY(dcrt_resize(dst, src->idx));
+  HIP_TRY(hipMemcpyAsync(dst->d_rows, src->d_rows, src->idx.size() * src->ctx->phim * 8, hipMemcpyDeviceToDevice, dst->ctx->stream));
+  return 0;
+}
+extern "C" int fhesi_dcrt_index_set(const fhesi_dcrt* d, int32_t* idx_out, int32_t* nidx) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  *nidx = (int32_t)d->idx.size();
+  if (idx_out) for (size_t i = 0; i < d->idx.size(); ++i) idx_out[i] = d->idx[i];
+  return 0;
+}
+extern "C" int fhesi_dcrt_equal(const fhesi_dcrt* a, const fhesi_dcrt* b, int32_t* equal) {
+  if (!a || !b) FHESI_FAIL("null DoubleCRT");
+  *equal = 0;
+  if (a->ctx != b->ctx || a->idx != b->idx) return 0;    // DoubleCRT.h:167-169
+  CHECK_CTX(a->ctx);
+  int eq = 0;
+  FHESI_TRY(launch_rows_equal(a->ctx, a->d_rows, b->d_rows, (i64)a->idx.size() * a->ctx->phim, &eq));
+  *equal = eq;
+  return 0;
+}
+extern "C" int fhesi_dcrt_upload_row(fhesi_dcrt* d, int32_t prime, const uint64_t* row) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  CHECK_CTX(d->ctx);
+  const int s = slot_of(d, prime);
+  if (s < 0) FHESI_FAIL("DoubleCRT: prime %d not in the index set", prime);
+  const i64 n = d->ctx->phim;
+  const u64 Q = d->ctx->q[prime];
+  for (i64 j = 0; j < n; ++j) if (row[j] >= Q) FHESI_FAIL("DoubleCRT object has inconsistent data");   // DoubleCRT::verify, DoubleCRT.cpp:66-68
+  HIP_TRY(hipMemcpyAsync(d->d_rows + (i64)s * n, row, n * 8, hipMemcpyHostToDevice, d->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(d->ctx->stream));
+  return 0;
+}
+extern "C" int fhesi_dcrt_download_row(const fhesi_dcrt* d, int32_t prime, uint64_t* row) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  CHECK_CTX(d->ctx);
+  const int s = slot_of(d, prime);
+  if (s < 0) FHESI_FAIL("DoubleCRT: prime %d not in the index set", prime);
+  const i64 n = d->ctx->phim;
+  HIP_TRY(hipMemcpyAsync(row, d->d_rows + (i64)s * n, n * 8, hipMemcpyDeviceToHost, d->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(d->ctx->stream));
+  return 0;
+}
+extern "C" void* fhesi_dcrt_device_ptr(fhesi_dcrt* d) { return d ? d->d_rows : nullptr; }
+
+extern "C" int fhesi_dcrt_from_poly(fhesi_dcrt* d, const uint64_t* limbs, int32_t nlimbs, int64_t ncoeffs) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  if (nlimbs < 1 || ncoeffs < 0) FHESI_FAIL("DoubleCRT(ZZX): bad coefficient shape");
+  const i64 n = c->phim;
+  const int K = (int)d->idx.size();
+  if (!K) return 0;
+  if (ncoeffs > n) {
+    // a polynomial of degree >= phi(m): take the per-row compatibility path (host reduction modulo Phi_m, CModulus.cpp:96-99)
+    std::vector<u64> y(n);
+    for (int s = 0; s < K; ++s) {
+      FHESI_TRY(fhesi_cmod_fft(c, d->idx[s], limbs, nlimbs, ncoeffs, y.data()));
+      HIP_TRY(hipMemcpyAsync(d->d_rows + (i64)s * n, y.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+  }
+  void* d_l;
+  FHESI_TRY(ws_reserve(c, 0, std::max<size_t>(8, (size_t)ncoeffs * nlimbs * 8), &d_l));
+  HIP_TRY(hipMemcpyAsync(d_l, limbs, (size_t)ncoeffs * nlimbs * 8, hipMemcpyHostToDevice, c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, d->idx, &d_pos));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)d_l, nlimbs, ncoeffs, 1, 1, nullptr, d->d_rows, K, d_pos));
+  FHESI_TRY(row_fwd(c, d->d_rows, 1, K, d_pos, d->idx.data()));
+  HIP_TRY(hipStreamSynchronize(c->stream));   // caller's limbs buffer may be released
+  return 0;
+}
+
+extern "C" int fhesi_dcrt_to_poly(const fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, int32_t positive, uint64_t* out, int32_t nlimbs) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  const i64 n = c->phim;
+  // s1 = map.getIndexSet() & s  (DoubleCRT.cpp:352)
+  std::vector<int> s1;
+  if (nidx == 0 && prime_idx == nullptr) s1 = d->idx;
+  else for (int i = 0; i < nidx; ++i) if (slot_of(d, prime_idx[i]) >= 0) s1.push_back(prime_idx[i]);
+  std::sort(s1.begin(), s1.end());
+  s1.erase(std::unique(s1.begin(), s1.end()), s1.end());
+  if (s1.empty()) { memset(out, 0, (size_t)n * nlimbs * 8); return 0; }      // :354-357
+  const int K = (int)s1.size();
+  // inverse transforms on a scratch copy of the selected rows
+  void* d_tmp;
+  FHESI_TRY(ws_reserve(c, 0, (size_t)K * n * 8, &d_tmp));
+  for (int k = 0; k < K; ++k)
+    HIP_TRY(hipMemcpyAsync((u64*)d_tmp + (i64)k * n, d->d_rows + (i64)slot_of(d, s1[k]) * n, n * 8, hipMemcpyDeviceToDevice, c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, s1, &d_pos));
+  FHESI_TRY(row_inv(c, (u64*)d_tmp, 1, K, d_pos, s1.data()));
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, s1, &t));
+  // slots in the scratch layout are 0..K-1
+  std::vector<int> slots(K);
+  for (int k = 0; k < K; ++k) slots[k] = k;
+  void* d_slots;
+  FHESI_TRY(ws_reserve(c, 4, K * sizeof(int) + 64, &d_slots));
+  HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  void* d_out;
+  FHESI_TRY(ws_reserve(c, 1, (size_t)n * nlimbs * 8, &d_out));
+  FHESI_TRY(launch_crt(c, t, (const u64*)d_tmp, K, (const int*)d_slots, 1, 0, positive, 0, (u64*)d_out, nlimbs));
+  HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * nlimbs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fhesi_dcrt_op(fhesi_dcrt* dst, const fhesi_dcrt* src, int32_t op) {
+  if (!dst || !src) FHESI_FAIL("null DoubleCRT");
+  if (dst->ctx != src->ctx) FHESI_FAIL("DoubleCRT::Op: incompatible objects");           // DoubleCRT.cpp:82-83
+  if (dst->idx != src->idx) FHESI_FAIL("DoubleCRT::Op: index sets differ (match them with add_primes first)");
+  if (op < FHESI_OP_ADD || op > FHESI_OP_MUL) FHESI_FAIL("DoubleCRT::Op: unknown operation %d", op);
+  fhesi_ctx* c = dst->ctx;
+  CHECK_CTX(c);
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, dst->idx, &d_pos));
+  return launch_ew_op(c, dst->d_rows, src->d_rows, 1, (int)dst->idx.size(), d_pos, op);
+}
+
+extern "C" int fhesi_dcrt_op_scalar(fhesi_dcrt* d, const uint64_t* num, int32_t nlimbs, int32_t op) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  if (op < FHESI_OP_ADD || op > FHESI_OP_SET) FHESI_FAIL("DoubleCRT scalar op: unknown operation %d", op);
+  const int K = (int)d->idx.size();
+  if (!K) return 0;
+  std::vector<u64> sc(K);
+  for (int s = 0; s < K; ++s) {
+    const u64 Q = c->q[d->idx[s]];
+    u64 v = hm::bn_mod((const u64*)num, nlimbs, Q);                 // n = rem(num, pi)  (DoubleCRT.cpp:123)
+    if (op == FHESI_OP_DIV) {
+      if (v == 0) FHESI_FAIL("DoubleCRT::operator/=: divisor is zero modulo prime %d", d->idx[s]);   // InvMod error
+      v = hm::invmod(v, Q);                                         // :416
+    }
+    sc[s] = v;
+  }
+  void* d_sc;
+  FHESI_TRY(ws_reserve(c, 4, K * 8 + 64, &d_sc));
+  HIP_TRY(hipMemcpyAsync(d_sc, sc.data(), K * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, d->idx, &d_pos));
+  return launch_ew_scalar(c, d->d_rows, (const u64*)d_sc, 1, K, d_pos, op);
+}
+
+extern "C" int fhesi_dcrt_automorph(fhesi_dcrt* d, int64_t k) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  if (k <= 0 || k >= c->m || c->zms_idx[k] < 0) FHESI_FAIL("DoubleCRT::automorph: k not in Zm*");     // DoubleCRT.cpp:442-443
+  const i64 K = (i64)d->idx.size();
+  if (!K) return 0;
+  void* tmp;
+  FHESI_TRY(ws_reserve(c, 0, (size_t)K * c->phim * 8, &tmp));
+  HIP_TRY(hipMemcpyAsync(tmp, d->d_rows, (size_t)K * c->phim * 8, hipMemcpyDeviceToDevice, c->stream));
+  return launch_automorph(c, d->d_rows, (const u64*)tmp, K, k);
+}
+
+extern "C" int fhesi_dcrt_add_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  if (nidx == 0) return 0;                                                               // DoubleCRT.cpp:144
+  std::vector<int> add(prime_idx, prime_idx + nidx);
+  std::sort(add.begin(), add.end());
+  for (int p : add) {
+    if (p < 0 || p >= c->L) FHESI_FAIL("addPrimes: prime index %d out of range", p);
+    if (slot_of(d, p) >= 0) FHESI_FAIL("addPrimes: index sets must be disjoint");        // :145
+  }
+  const i64 n = c->phim;
+  // toPoly over the current set (:147-148) -- wide enough for the product of the current primes
+  const int W = (int)d->idx.size() + 2;
+  std::vector<u64> poly((size_t)n * W);
+  FHESI_TRY(fhesi_dcrt_to_poly(d, nullptr, 0, 0, poly.data(), W));
+  // new object over the union; old rows kept, new rows = FFT of poly (:150-155)
+  std::vector<int> uni(d->idx);
+  uni.insert(uni.end(), add.begin(), add.end());
+  std::sort(uni.begin(), uni.end());
+  u64* d_new;
+  HIP_TRY(hipMalloc(&d_new, uni.size() * n * 8));
+  fhesi_dcrt tmp;
+  tmp.ctx = c; tmp.idx = add;
+  HIP_TRY(hipMalloc(&tmp.d_rows, add.size() * n * 8));
+  int r = fhesi_dcrt_from_poly(&tmp, poly.data(), W, n);
+  if (!r) {
+    for (size_t u = 0; u < uni.size(); ++u) {
+      const int so = slot_of(d, uni[u]);
+      const u64* src = so >= 0 ? d->d_rows + (i64)so * n : tmp.d_rows + (i64)slot_of(&tmp, uni[u]) * n;
+      hipMemcpyAsync(d_new + (i64)u * n, src, n * 8, hipMemcpyDeviceToDevice, c->stream);
+    }
+    hipStreamSynchronize(c->stream);
+    hipFree(d->d_rows);
+    d->d_rows = d_new;
+    d->idx = uni;
+  } else hipFree(d_new);
+  hipFree(tmp.d_rows);
+  return r;
+}
+
+extern "C" int fhesi_dcrt_remove_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  std::vector<int> keep;
+  for (int p : d->idx) if (std::find(prime_idx, prime_idx + nidx, p) == prime_idx + nidx) keep.push_back(p);
+  if (keep.size() == d->idx.size()) return 0;
+  const i64 n = c->phim;
+  u64* d_new;
+  HIP_TRY(hipMalloc(&d_new, std::max<size_t>(8, keep.size() * n * 8)));
+  for (size_t u = 0; u < keep.size(); ++u)
+    HIP_TRY(hipMemcpyAsync(d_new + (i64)u * n, d->d_rows + (i64)slot_of(d, keep[u]) * n, n * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipFree(d->d_rows));
+  d->d_rows = d_new;
+  d->idx = keep;
+  return 0;
+}
+
+extern "C" int fhesi_dcrt_from_scrt(fhesi_dcrt* d, const uint64_t* coeff_rows) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  const int K = (int)d->idx.size();
+  const i64 n = c->phim;
+  for (int s = 0; s < K; ++s) { const u64 Q = c->q[d->idx[s]]; for (i64 j = 0; j < n; ++j) if (coeff_rows[(i64)s * n + j] >= Q) FHESI_FAIL("SingleCRT object has inconsistent data"); }
+  HIP_TRY(hipMemcpyAsync(d->d_rows, coeff_rows, (size_t)K * n * 8, hipMemcpyHostToDevice, c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, d->idx, &d_pos));
+  FHESI_TRY(row_fwd(c, d->d_rows, 1, K, d_pos, d->idx.data()));     // DoubleCRT.cpp:493-494
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int fhesi_dcrt_to_scrt(const fhesi_dcrt* d, uint64_t* out) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  const int K = (int)d->idx.size();
+  const i64 n = c->phim;
+  void* tmp;
+  FHESI_TRY(ws_reserve(c, 0, std::max<size_t>(8, (size_t)K * n * 8), &tmp));
+  HIP_TRY(hipMemcpyAsync(tmp, d->d_rows, (size_t)K * n * 8, hipMemcpyDeviceToDevice, c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, d->idx, &d_pos));
+  FHESI_TRY(row_inv(c, (u64*)tmp, 1, K, d_pos, d->idx.data()));     // DoubleCRT.cpp:508-509
+  HIP_TRY(hipMemcpyAsync(out, tmp, (size_t)K * n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------- batched row kernels
+extern "C" int fhesi_rows_ntt_fwd_dev(fhesi_ctx* c, uint64_t* rows, int64_t count) {
+  CHECK_CTX(c);
+  std::vector<int> all(c->L);
+  for (int i = 0; i < c->L; ++i) all[i] = i;
+  return row_fwd(c, (u64*)rows, count, c->L, nullptr, all.data());
+}
+extern "C" int fhesi_rows_ntt_inv_dev(fhesi_ctx* c, uint64_t* rows, int64_t count) {
+  CHECK_CTX(c);
+  std::vector<int> all(c->L);
+  for (int i = 0; i < c->L; ++i) all[i] = i;
+  return row_inv(c, (u64*)rows, count, c->L, nullptr, all.data());
+}
+extern "C" int fhesi_rows_op_dev(fhesi_ctx* c, uint64_t* dst, const uint64_t* src, int64_t count, int32_t op) {
+  CHECK_CTX(c);
+  if (op < FHESI_OP_ADD || op > FHESI_OP_MUL) FHESI_FAIL("DoubleCRT::Op: unknown operation %d", op);
+  return launch_ew_op(c, (u64*)dst, (const u64*)src, count, c->L, nullptr, op);
+}
+
+// --------------------------------------------------------------------------------------------- key-switch matrix
+extern "C" int fhesi_ksk_create(fhesi_ctx* c, int32_t ncomp, int32_t ndigits, fhesi_ksk** out) {
+  CHECK_CTX(c);
+  if (ncomp < 1 || ndigits < 1) FHESI_FAIL("KeySwitchSI: bad shape");
+  fhesi_ksk* k = new fhesi_ksk();
+  k->ctx = c; k->ncomp = ncomp; k->ndigits = ndigits;
+  k->bytes = (size_t)2 * ncomp * ndigits * c->L * c->phim * 8;
+  HIP_TRY(hipMalloc(&k->d_rows, k->bytes));
+  HIP_TRY(hipMemsetAsync(k->d_rows, 0, k->bytes, c->stream));
+  *out = k;
+  return 0;
+}
+extern "C" int fhesi_ksk_free(fhesi_ksk* k) {
+  if (!k) return 0;
+  hipSetDevice(k->ctx->device);
+  hipStreamSynchronize(k->ctx->stream);
+  hipFree(k->d_rows);
+  delete k;
+  return 0;
+}
+extern "C" int fhesi_ksk_upload(fhesi_ksk* k, const uint64_t* rows_host) {
+  if (!k) FHESI_FAIL("null key-switch matrix");
+  CHECK_CTX(k->ctx);
+  HIP_TRY(hipMemcpyAsync(k->d_rows, rows_host, k->bytes, hipMemcpyHostToDevice, k->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(k->ctx->stream));
+  return 0;
+}
+extern "C" void* fhesi_ksk_device_ptr(fhesi_ksk* k) { return k ? k->d_rows : nullptr; }
+extern "C" size_t fhesi_ksk_bytes(const fhesi_ksk* k) { return k ? k->bytes : 0; }
+
+// --------------------------------------------------------------------------------------------- ciphertext pipeline
+static std::vector<int> full_set(const fhesi_ctx* c) { std::vector<int> v(c->L); for (int i = 0; i < c->L; ++i) v[i] = i; return v; }
+
+extern "C" int fhesi_ct_mul_dev(fhesi_ctx* c, uint64_t p, const uint64_t* a, const uint64_t* b, int32_t nlimbs, int64_t count, uint64_t* tprod) {
+  CHECK_CTX(c);
+  if (!count) return 0;
+  const i64 n = c->phim;
+  const int L = c->L;
+  const std::vector<int> all = full_set(c);
+  // c1[i] = DoubleCRT(parts[i].poly * p), c2[j] = DoubleCRT(other.parts[j].poly)   (Ciphertext.cpp:169-176)
+  void* d_c;
+  FHESI_TRY(ws_reserve(c, 0, (size_t)count * 4 * L * n * 8, &d_c));
+  u64* ca = (u64*)d_c;
+  u64* cb = ca + (size_t)count * 2 * L * n;
+  const u64 lift[2] = {p, p};
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)a, nlimbs, n, count, 2, lift, ca, L, nullptr));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)b, nlimbs, n, count, 2, nullptr, cb, L, nullptr));
+  FHESI_TRY(row_fwd(c, ca, count * 4, L, nullptr, all.data()));
+  // tProd[i+j] += c1[i] * c2[j]   (Ciphertext.cpp:179-186)
+  FHESI_TRY(launch_tensor2x2(c, ca, cb, (u64*)tprod, count));
+  return 0;
+}
+
+extern "C" int fhesi_apply_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, const uint64_t* tprod, int64_t count,
+                                          uint64_t* out, int32_t nlimbs) {
+  CHECK_CTX(c);
+  if (!k || k->ctx != c) FHESI_FAIL("KeySwitchSI: context mismatch");            // FHE-SI.cpp:279-281
+  if (decomp_bytes < 1 || decomp_bytes > 7) FHESI_FAIL("decompSize %d not supported", decomp_bytes);
+  const int nd = (logQ + 8 * decomp_bytes - 1) / (8 * decomp_bytes);            // FHEContext.h:115
+  if (nd != k->ndigits) FHESI_FAIL("KeySwitchSI: matrix has %d digits per component, context needs %d", k->ndigits, nd);
+  if (nlimbs * 64 < logQ) FHESI_FAIL("output coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  if (!count) return 0;
+  const i64 n = c->phim;
+  const int L = c->L, ncomp = k->ncomp, ncol = ncomp * nd, nlq = (logQ + 63) / 64;
+  const std::vector<int> all = full_set(c);
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, all, &t));
+  // ScaleDown (Ciphertext.cpp:194-218): toPoly + round(x/q) + Reduce, kept as positive residues for ByteDecomp
+  void* d_t;
+  FHESI_TRY(ws_reserve(c, 1, (size_t)count * ncomp * L * n * 8, &d_t));
+  HIP_TRY(hipMemcpyAsync(d_t, tprod, (size_t)count * ncomp * L * n * 8, hipMemcpyDeviceToDevice, c->stream));
+  FHESI_TRY(row_inv(c, (u64*)d_t, count * ncomp, L, nullptr, all.data()));
+  void* d_parts;
+  FHESI_TRY(ws_reserve(c, 2, (size_t)count * ncomp * nlq * n * 8, &d_parts));
+  FHESI_TRY(launch_crt(c, t, (const u64*)d_t, L, nullptr, count * ncomp, 1, 0, logQ, (u64*)d_parts, nlq));
+  // ByteDecomp + DoubleCRT(digit polys)   (Ciphertext.cpp:82-121, FHE-SI.cpp:244-249)
+  void* d_dig;
+  FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * L * n * 8, &d_dig));
+  FHESI_TRY(launch_digits(c, (const u64*)d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
+  FHESI_TRY(row_fwd(c, (u64*)d_dig, count * ncol, L, nullptr, all.data()));
+  // DotProduct with both key rows (FHE-SI.cpp:251-254)
+  FHESI_TRY(launch_dot_accum(c, k->d_rows, (const u64*)d_dig, ncol, count, (u64*)d_t));
+  // toPoly + ReduceCoefficients (FHE-SI.cpp:255-256)
+  FHESI_TRY(row_inv(c, (u64*)d_t, count * 2, L, nullptr, all.data()));
+  FHESI_TRY(launch_crt(c, t, (const u64*)d_t, L, nullptr, count * 2, 2, 0, logQ, (u64*)out, nlimbs));
+  return 0;
+}
+
+static i64 batch_chunk(const fhesi_ctx* c, int ncol) {
+  const char* e = getenv("FHESI_BATCH_CHUNK");
+  if (e && atoll(e) > 0) return atoll(e);
+  // bound the digit-row working set (count * ncol * L * n * 8 bytes) to about 4 GiB
+  const double per = (double)ncol * c->L * c->phim * 8.0;
+  i64 ch = (i64)(4.0 * 1024 * 1024 * 1024 / per);
+  return ch < 1 ? 1 : ch;
+}
+
+extern "C" int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a,
+                                            const uint64_t* b, uint64_t* out, int32_t nlimbs, int64_t count) {
+  CHECK_CTX(c);
+  if (!k || k->ctx != c) FHESI_FAIL("KeySwitchSI: context mismatch");
+  if (k->ncomp != 3) FHESI_FAIL("ct_mul_relin needs the s^2 -> s matrix (3 source components), got %d", k->ncomp);
+  if (nlimbs * 64 < logQ) FHESI_FAIL("coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  const i64 n = c->phim;
+  const int L = c->L;
+  const i64 chunk = batch_chunk(c, 3 * k->ndigits);
+  for (i64 done = 0; done < count; done += chunk) {
+    const i64 cnt = std::min(chunk, count - done);
+    void* d_tp;
+    FHESI_TRY(ws_reserve(c, 5, (size_t)cnt * 3 * L * n * 8, &d_tp));
+    const size_t off = (size_t)done * 2 * n * nlimbs;
+    FHESI_TRY(fhesi_ct_mul_dev(c, p, a + off, b + off, nlimbs, cnt, (uint64_t*)d_tp));
+    FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_tp, cnt, out + off, nlimbs));
+  }
+  return 0;
+}
+
+extern "C" int fhesi_ct_mul_relin_batch(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a,
+                                        const uint64_t* b, uint64_t* out, int32_t nlimbs, int64_t count) {
+  CHECK_CTX(c);
+  if (!count) return 0;
+  const size_t bytes = (size_t)count * 2 * c->phim * nlimbs * 8;
+  u64 *da, *db, *dout;
+  HIP_TRY(hipMalloc(&da, bytes));
+  HIP_TRY(hipMalloc(&db, bytes));
+  HIP_TRY(hipMalloc(&dout, bytes));
+  int r = 0;
+  if (hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+    fhesi_set_error("upload of ciphertext batch failed"); r = 1;
+  }
+  if (!r) r = fhesi_ct_mul_relin_batch_dev(c, k, logQ, p, decomp_bytes, da, db, dout, nlimbs, count);
+  if (!r && hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { fhesi_set_error("download of ciphertext batch failed"); r = 1; }
+  hipStreamSynchronize(c->stream);
+  hipFree(da); hipFree(db); hipFree(dout);
+  return r;
+}

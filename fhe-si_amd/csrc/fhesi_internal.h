@@ -1,0 +1,187 @@
+// fhesi_internal.h -- shared declarations of the gfx950 DoubleCRT backend (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef unsigned int u32;
+typedef unsigned __int128 u128;
+
+// --------------------------------------------------------------------------------- error plumbing
+void fhesi_set_error(const char* fmt, ...);
+#define FHESI_FAIL(...) do { fhesi_set_error(__VA_ARGS__); return 1; } while (0)
+#define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fhesi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return 1; } } while (0)
+#define FHESI_OP_SET_ 4
+#define FHESI_TRY(expr) do { int r__ = (expr); if (r__) return r__; } while (0)
+
+// --------------------------------------------------------------------------------- per-prime device constants
+// One entry per chain prime (role of the reference's Cmodulus object, CModulus.h:42-61).
+struct PrimeConst {
+  u64 q;            // the modulus (CModulus.h:44)
+  u64 two_q;
+  u64 bar_mu;       // Barrett: floor(2^(2k)/q), k = bit length of q
+  u32 bar_k;        // bit length of q
+  u32 pad0;
+  u64 ninv, ninv_sh;        // phi(m)^-1 mod q and its Shoup quotient (power-of-two m: the /m of CModulus.cpp:125 folded with X^n=-1)
+  u64 ninv_w, ninv_w_sh;    // ninv * psi^-brv(1) (last inverse stage twiddle folded with the scaling)
+  u64 r64, r64_sh;          // 2^64 mod q (Horner step of the big-int -> residue reduction, CModulus.cpp:96 conv)
+};
+
+struct Shoup2 { u64 w, wp; };   // constant multiplier and floor(w*2^64/q)
+
+// CRT tables for one ordered prime subset (DoubleCRT::toPoly, DoubleCRT.cpp:349-398 / NumbTh.cpp:307-335)
+struct CrtTables {
+  int nidx = 0, W = 0;                 // W = limbs of the product of the subset (+1 for sign)
+  std::vector<int> idx;
+  u64* d_blob = nullptr;               // device copy of everything below
+  // device pointers into d_blob
+  int* d_idx = nullptr;                // [nidx]
+  Shoup2* d_pow64 = nullptr;           // [nidx][W]   2^(64 j) mod q_k (+Shoup quotient)
+  Shoup2* d_pinv = nullptr;            // [nidx]      (q_0...q_{k-1})^-1 mod q_k
+  u64* d_P = nullptr;                  // [nidx+1][W] partial products P_k = q_0...q_{k-1}; row nidx = full product
+  u64* d_halfP = nullptr;              // [W]         (P-1)/2
+};
+
+struct BluesteinTables;                // general-m path, defined in bluestein.hip
+
+struct fhesi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  i64 m = 0, phim = 0;
+  int L = 0;
+  bool pow2 = false;
+  int logn = 0;                        // log2(phim) when pow2
+  std::vector<u64> q, root;
+  std::vector<int> zms_idx;            // PAlgebra::zmsIdx (PAlgebra.cpp:50-52)
+  std::vector<i64> phi;                // Phi_m(X) (PAlgebra.cpp:55)
+  std::vector<PrimeConst> pc;
+  PrimeConst* d_pc = nullptr;          // [L]
+  Shoup2* d_tw_fwd = nullptr;          // [L][phim]  psi^brv(i)     (pow2)
+  Shoup2* d_tw_inv = nullptr;          // [L][phim]  psi^-brv(i)    (pow2)
+  Shoup2* d_twt_fwd = nullptr;         // [L][phim]  same values in the tile kernel's permuted order (ntt_tile.inc), logn 11..14
+  Shoup2* d_twt_inv = nullptr;
+  int* d_zms_idx = nullptr;            // [m]
+  int* d_zms_list = nullptr;           // [phim] ascending elements of Z_m^*
+  BluesteinTables* blue = nullptr;
+  std::map<std::vector<int>, CrtTables*> crt_cache;
+  std::map<int, Shoup2*> pow64_cache;  // nlimbs -> device [L][nlimbs+1] table for rns_reduce
+  // grow-only workspace
+  void* ws[10] = {};
+  size_t ws_bytes[10] = {};
+};
+
+struct fhesi_dcrt {
+  fhesi_ctx* ctx = nullptr;
+  std::vector<int> idx;                // ascending prime indices (IndexSet, IndexSet.h)
+  u64* d_rows = nullptr;               // [idx.size()][phim]
+};
+
+struct fhesi_ksk {
+  fhesi_ctx* ctx = nullptr;
+  int ncomp = 0, ndigits = 0;
+  u64* d_rows = nullptr;               // [2][ncomp*ndigits][L][phim]
+  size_t bytes = 0;
+};
+
+int ws_reserve(fhesi_ctx* ctx, int slot, size_t bytes, void** out);
+
+// --------------------------------------------------------------------------------- host number theory (hostmath.cpp)
+namespace hm {
+u64 mulmod(u64 a, u64 b, u64 q);
+u64 powmod(u64 a, u64 e, u64 q);
+u64 invmod(u64 a, u64 q);              // q prime
+bool is_prime(u64 n);
+u64 shoup(u64 w, u64 q);
+u64 brv(u64 x, int bits);
+int ilog2_ceil(i64 n);
+std::vector<int> zms_idx(i64 m, i64* phim);
+std::vector<i64> cyclotomic(i64 m);
+bool is_primitive_2m_root(u64 root, i64 m, u64 q);
+u64 bn_mod(const u64* limbs, int nlimbs, u64 q);          // signed two's complement -> [0,q)  (role of NTL rem(ZZ,long))
+std::vector<u64> bn_mul_small(const std::vector<u64>& a, u64 b);   // non-negative
+}  // namespace hm
+
+// --------------------------------------------------------------------------------- kernel launchers
+// kernels_ntt.hip : negacyclic NTT for power-of-two m.  rows: [count][nprimes_in_layout][n]; the prime of layout
+// slot s is prime_of_slot[s] (nullptr = identity).  bitrev=false leaves the forward output / takes the inverse input in
+// bit-reversed order (used by the Bluestein convolution engine).
+int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev = true);
+int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev = true);
+// digit-row forward NTT: source is the scaled-down part in limb-major layout, see kernels_crt.hip
+int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts_limbmajor, int nl_q, int logQ, int digit_bits, int ncomp, int nd,
+                          i64 count, u64* d_out_rows /* [count][ncomp*nd][L][n] */);
+
+// kernels_ew.hip
+int launch_ew_op(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 count, int nslots, const int* d_prime_of_slot, int op);
+int launch_ew_scalar(fhesi_ctx* ctx, u64* d_dst, const u64* d_scalars /* [nslots] residues */, i64 count, int nslots, const int* d_prime_of_slot, int op);
+int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a /* [count][2][L][n] */, const u64* d_b /* [count][2][L][n] */, u64* d_t /* [count][3][L][n] */, i64 count);
+int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key /* [2][ncol][L][n] */, const u64* d_dig /* [count][ncol][L][n] */, int ncol, i64 count,
+                     u64* d_out /* [count][2][L][n] */);
+int launch_automorph(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 nrows, i64 k);
+int launch_rows_equal(fhesi_ctx* ctx, const u64* a, const u64* b, i64 nwords, int* equal);
+
+// kernels_crt.hip
+int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out);
+// big-int coefficients [count][npoly][n][nlimbs] -> residue rows [count][npoly][L][n]; scalar_mul[poly] (0 = none) multiplies
+// the residue by (scalar mod q) -- the `parts[i].poly * p` lift of Ciphertext.cpp:171.
+int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeffs, i64 count, int npoly, const u64* scalar_mul,
+                      u64* d_rows, int nslots, const int* d_prime_of_slot);
+// CRT reconstruct rows [npolys][nslots_layout][n] over the subset in `t` -> W-limb coefficients.
+// mode 0: centered / positive value as is (toPoly), out [count][npoly][n][nl_out] coefficient-major
+// mode 1: ScaleDown: round-half-up(x / 2^logQ) mod 2^logQ, positive residue, limb-major [count][npoly][nl_out][n]
+// mode 2: Reduce: centered mod 2^logQ, coefficient-major two's complement [count][npoly][n][nl_out]
+// d_slot_of: device [K] layout slot of the k-th prime of the subset (nullptr: slot = prime index); npolys = number of polynomials.
+int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode, int positive,
+               int logQ, u64* d_out, int nl_out);
+// ByteDecomp: parts limb-major [npolys][nl][n] -> digit residue rows [npolys][nd][L][n]
+int launch_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_rows);
+
+// bluestein.hip (general m)
+int bluestein_init(fhesi_ctx* ctx);
+void bluestein_destroy(fhesi_ctx* ctx);
+int launch_bluestein_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* prime_of_slot_host);
+int launch_bluestein_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* prime_of_slot_host);
+
+// --------------------------------------------------------------------------------- device arithmetic
+#if defined(__HIPCC__)
+// All residues are < q < 2^62 (NTL_SP_NBITS <= 60 in the reference, FHEContext.cpp:92), so 4q fits a word.
+__device__ __forceinline__ u64 d_mulhi(u64 a, u64 b) { return __umul64hi(a, b); }
+
+// Shoup / Harvey multiplication by a constant w with wp = floor(w 2^64 / q): returns y*w mod q in [0, 2q)
+// for ANY 64-bit y (role of NTL MulModPrecon, DoubleCRT.cpp:195-197).
+__device__ __forceinline__ u64 d_shoup_lazy(u64 y, u64 w, u64 wp, u64 q) {
+  u64 Q = d_mulhi(y, wp);
+  return y * w - Q * q;
+}
+__device__ __forceinline__ u64 d_shoup(u64 y, u64 w, u64 wp, u64 q) {
+  u64 r = d_shoup_lazy(y, w, wp, q);
+  return r >= q ? r - q : r;
+}
+__device__ __forceinline__ u64 d_addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
+__device__ __forceinline__ u64 d_submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+
+// Barrett reduction of x = (hi:lo) < 2^(2k) (k = bit length of q): result in [0,q)
+__device__ __forceinline__ u64 d_barrett128(u64 hi, u64 lo, u64 q, u64 mu, u32 k) {
+  // xs = floor(x / 2^(k-1))  (k+1 bits)
+  u64 xs = (k == 1) ? lo : ((lo >> (k - 1)) | (hi << (65 - k)));
+  if (k == 1) xs = lo;
+  // qhat = floor(xs * mu / 2^(k+1))
+  u64 ph = d_mulhi(xs, mu), pl = xs * mu;
+  u64 qhat = (k + 1 >= 64) ? ph : ((pl >> (k + 1)) | (ph << (63 - k)));
+  u64 r = lo - qhat * q;                   // true remainder in [0, 3q) -> fits since 3q < 2^64
+  if (r >= q) r -= q;
+  if (r >= q) r -= q;
+  return r;
+}
+// generic a*b mod q for a,b in [0,q)  (role of NTL MulMod, DoubleCRT.cpp:110)
+__device__ __forceinline__ u64 d_mulmod(u64 a, u64 b, const PrimeConst& pc) {
+  u64 hi = d_mulhi(a, b), lo = a * b;
+  return d_barrett128(hi, lo, pc.q, pc.bar_mu, pc.bar_k);
+}
+#endif

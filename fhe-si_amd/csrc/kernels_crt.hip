@@ -1,0 +1,324 @@
+// kernels_crt.hip -- big-integer <-> residue conversions of the DoubleCRT path.
+//   rns_reduce   conv(in,x) of Cmod::FFT (CModulus.cpp:96): signed multi-limb coefficient -> residue mod each q_i,
+//                optionally times a word scalar (the `poly * p` lift of Ciphertext.cpp:171)
+//   crt          DoubleCRT::toPoly (DoubleCRT.cpp:349-398) = incremental intVecCRT (NumbTh.cpp:307-335), fused with
+//                  mode 1: Ciphertext::ScaleDown rounding (Ciphertext.cpp:205-213) + positive Reduce (Util.cpp:3-26, Ciphertext.cpp:94)
+//                  mode 2: ReduceCoefficients centered mod 2^logQ (Util.cpp:28-33; FHE-SI.cpp:256)
+//   digits       Ciphertext::ByteDecompPart (Ciphertext.cpp:82-105) + conv of the digit polys (FHE-SI.cpp:246-249)
+//
+// The reference's intVecCRT keeps a centred accumulator at every step; the final value is the unique symmetric
+// residue of x modulo the full product P, so this kernel runs the mixed-radix recurrence with non-negative digits
+// (x stays in [0, P_k) ) and centres once at the end -- same value, no signed big-int arithmetic per step.
+#include "fhesi_internal.h"
+
+// ----------------------------------------------------------------------------------------- rns_reduce
+// limbs: [npolys_total][n][nlimbs] two's complement.  rows: [npolys_total][nslots][n].  pow64: [L][nlimbs+1].
+__global__ void __launch_bounds__(256) rns_reduce_kernel(const u64* __restrict__ limbs, int nlimbs, i64 ncoeffs, i64 n, int npoly_mod,
+                                                          const u64* __restrict__ scalar_res /* [npoly_mod][L] residues or null */,
+                                                          u64* __restrict__ rows, int nslots, const int* __restrict__ prime_of_slot,
+                                                          const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ pow64) {
+  const i64 poly = blockIdx.z;
+  const int slot = blockIdx.y;
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const PrimeConst pc = pcs[prime];
+  const u64 q = pc.q, two_q = pc.two_q;
+  const Shoup2* pw = pow64 + (i64)prime * (nlimbs + 1);
+  const u64* src = limbs + poly * ncoeffs * nlimbs;
+  u64* dst = rows + (poly * nslots + slot) * n;
+  const bool has_scalar = scalar_res != nullptr;
+  const u64 sc = has_scalar ? scalar_res[(poly % npoly_mod) * gridDim.y + slot] : 0;   // 0 = no scalar for this poly
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    u64 acc = 0;
+    if (j < ncoeffs) {
+      const u64* c = src + j * nlimbs;
+      u64 top = 0;
+      for (int k = 0; k < nlimbs; ++k) {
+        const u64 limb = c[k];
+        top = limb;
+        acc += d_shoup_lazy(limb, pw[k].w, pw[k].wp, q);       // each term in [0,2q)
+        if (acc >= two_q) acc -= two_q;                         // keep acc in [0,2q)
+      }
+      if (acc >= q) acc -= q;
+      if (top >> 63) acc = d_submod(acc, pw[nlimbs].w, q);      // two's complement: value = unsigned - 2^(64 nlimbs)
+      if (has_scalar && sc) acc = d_mulmod(acc, sc, pc);
+    }
+    dst[j] = acc;
+  }
+}
+
+int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeffs, i64 count, int npoly, const u64* scalar_mul,
+                      u64* d_rows, int nslots, const int* d_prime_of_slot) {
+  if (!count || !npoly) return 0;
+  // 2^(64k) mod q table for this limb count
+  Shoup2* d_pow = nullptr;
+  auto it = ctx->pow64_cache.find(nlimbs);
+  if (it == ctx->pow64_cache.end()) {
+    std::vector<Shoup2> h((size_t)ctx->L * (nlimbs + 1));
+    for (int l = 0; l < ctx->L; ++l) {
+      const u64 q = ctx->q[l];
+      const u64 b = (u64)(((u128)1 << 64) % q);
+      u64 cur = 1 % q;
+      for (int k = 0; k <= nlimbs; ++k) { h[(size_t)l * (nlimbs + 1) + k] = {cur, hm::shoup(cur, q)}; cur = hm::mulmod(cur, b, q); }
+    }
+    HIP_TRY(hipMalloc(&d_pow, h.size() * sizeof(Shoup2)));
+    HIP_TRY(hipMemcpyAsync(d_pow, h.data(), h.size() * sizeof(Shoup2), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->pow64_cache[nlimbs] = d_pow;
+  } else d_pow = it->second;
+  // per-(poly, slot) scalar residues
+  u64* d_sc = nullptr;
+  if (scalar_mul) {
+    std::vector<u64> h((size_t)npoly * nslots, 0);
+    std::vector<int> pos(nslots);
+    if (d_prime_of_slot) FHESI_FAIL("rns_reduce: scalar lift only supported on the full prime set");
+    for (int p = 0; p < npoly; ++p)
+      for (int s = 0; s < nslots; ++s) h[(size_t)p * nslots + s] = scalar_mul[p] ? scalar_mul[p] % ctx->q[s] : 0;
+    FHESI_TRY(ws_reserve(ctx, 4, h.size() * 8 + 64, (void**)&d_sc));
+    HIP_TRY(hipMemcpyAsync(d_sc, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // h goes out of scope
+  }
+  const i64 n = ctx->phim;
+  unsigned gx = (unsigned)((n + 255) / 256);
+  if (gx > 64) gx = 64;
+  dim3 grid(gx, (unsigned)nslots, (unsigned)(count * npoly));
+  rns_reduce_kernel<<<grid, 256, 0, ctx->stream>>>(d_limbs, nlimbs, ncoeffs < n ? ncoeffs : n, n, npoly, d_sc, d_rows, nslots, d_prime_of_slot, ctx->d_pc, d_pow);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------- CRT tables
+int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out) {
+  auto it = ctx->crt_cache.find(idx);
+  if (it != ctx->crt_cache.end()) { *out = it->second; return 0; }
+  const int K = (int)idx.size();
+  if (K == 0) FHESI_FAIL("CRT over an empty prime set");
+  // product limbs
+  std::vector<std::vector<u64>> P(K + 1);
+  P[0] = {1};
+  for (int k = 0; k < K; ++k) P[k + 1] = hm::bn_mul_small(P[k], ctx->q[idx[k]]);
+  const int W = (int)P[K].size() + 1;   // one spare limb for the sign / rounding carry
+  CrtTables* t = new CrtTables();
+  t->nidx = K; t->W = W; t->idx = idx;
+  // blob layout (u64 words): idx[K] (as u64) | pow64[K][W] (2 words each) | pinv[K] (2 words) | P[K+1][W] | halfP[W]
+  const size_t n_idx = K, n_pow = (size_t)K * W * 2, n_pinv = (size_t)K * 2, n_P = (size_t)(K + 1) * W, n_half = W;
+  std::vector<u64> blob(n_idx + n_pow + n_pinv + n_P + n_half, 0);
+  u64* b_idx = blob.data();
+  u64* b_pow = b_idx + n_idx;
+  u64* b_pinv = b_pow + n_pow;
+  u64* b_P = b_pinv + n_pinv;
+  u64* b_half = b_P + n_P;
+  for (int k = 0; k < K; ++k) {
+    const u64 q = ctx->q[idx[k]];
+    ((int*)b_idx)[k] = idx[k];
+    const u64 base = (u64)(((u128)1 << 64) % q);
+    u64 cur = 1 % q;
+    for (int j = 0; j < W; ++j) { b_pow[((size_t)k * W + j) * 2] = cur; b_pow[((size_t)k * W + j) * 2 + 1] = hm::shoup(cur, q); cur = hm::mulmod(cur, base, q); }
+    // P_k mod q_k
+    u64 pk = 0;
+    for (int j = (int)P[k].size() - 1; j >= 0; --j) pk = (u64)((((u128)pk << 64) | P[k][j]) % q);
+    const u64 inv = hm::invmod(pk, q);
+    b_pinv[k * 2] = inv; b_pinv[k * 2 + 1] = hm::shoup(inv, q);
+  }
+  for (int k = 0; k <= K; ++k)
+    for (size_t j = 0; j < P[k].size(); ++j) b_P[(size_t)k * W + j] = P[k][j];
+  // halfP = (P-1)/2  (P odd)
+  {
+    std::vector<u64> h(W, 0);
+    for (size_t j = 0; j < P[K].size(); ++j) h[j] = P[K][j];
+    h[0] -= 1;   // P odd -> no borrow
+    for (int j = 0; j < W; ++j) h[j] = (h[j] >> 1) | (j + 1 < W ? h[j + 1] << 63 : 0);
+    for (int j = 0; j < W; ++j) b_half[j] = h[j];
+  }
+  HIP_TRY(hipMalloc(&t->d_blob, blob.size() * 8));
+  HIP_TRY(hipMemcpyAsync(t->d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  t->d_idx = (int*)t->d_blob;
+  t->d_pow64 = (Shoup2*)(t->d_blob + n_idx);
+  t->d_pinv = (Shoup2*)(t->d_blob + n_idx + n_pow);
+  t->d_P = t->d_blob + n_idx + n_pow + n_pinv;
+  t->d_halfP = t->d_P + n_P;
+  ctx->crt_cache[idx] = t;
+  *out = t;
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------- CRT kernel
+// One thread per coefficient.  MAXW = compile-time bound on the limb count (register array, static indices only);
+// the finished W-limb integer is staged in LDS (limb-major, conflict-free) for the mode-dependent epilogue that
+// needs run-time limb indices (shift by logQ).
+template <int MAXW>
+__global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, i64 n, int nslots_layout, const int* __restrict__ slot_of /* [K] or null */,
+                                                  int K, int W, const int* __restrict__ idx, const Shoup2* __restrict__ pow64,
+                                                  const Shoup2* __restrict__ pinv, const u64* __restrict__ Ptab, const u64* __restrict__ halfP,
+                                                  const PrimeConst* __restrict__ pcs, int mode, int positive, int logQ,
+                                                  u64* __restrict__ out, int nl_out) {
+  extern __shared__ __attribute__((aligned(16))) u64 sx[];   // [W][blockDim.x]
+  const i64 poly = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < n;
+  const u64* base = rows + poly * nslots_layout * n;
+  u64 x[MAXW];
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) x[i] = 0;
+  if (active) {
+    x[0] = base[(i64)(slot_of ? slot_of[0] : idx[0]) * n + j];
+    for (int k = 1; k < K; ++k) {
+      const PrimeConst pc = pcs[idx[k]];
+      const u64 q = pc.q, two_q = pc.two_q;
+      const u64 rk = base[(i64)(slot_of ? slot_of[k] : idx[k]) * n + j];
+      // t = x mod q_k   (x < P_k < 2^(64k): k limbs)
+      u64 t = 0;
+      const Shoup2* pw = pow64 + (i64)k * W;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i < k && i < W) {
+          t += d_shoup_lazy(x[i], pw[i].w, pw[i].wp, q);
+          if (t >= two_q) t -= two_q;
+        }
+      }
+      if (t >= q) t -= q;
+      // v = (r_k - t) * P_k^-1 mod q_k   (NumbTh.cpp:314-317 without the centring, see file header)
+      const u64 v = d_shoup(d_submod(rk, t, q), pinv[k].w, pinv[k].wp, q);
+      // x += v * P_k
+      const u64* Pk = Ptab + (i64)k * W;
+      u64 carry = 0;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i <= k && i < W) {
+          const u64 p = Pk[i];
+          const u64 lo = v * p, hi = d_mulhi(v, p);
+          u64 s = x[i] + lo;
+          u64 c1 = s < lo;
+          s += carry;
+          c1 += s < carry;
+          x[i] = s;
+          carry = hi + c1;
+        }
+      }
+    }
+    // centre: if x > (P-1)/2 then x -= P   (DoubleCRT.cpp:375-376 / NumbTh.cpp:318; `positive` keeps [0,P), :392-395)
+    if (!positive) {
+      bool gt = false, decided = false;
+#pragma unroll
+      for (int i = MAXW - 1; i >= 0; --i) {
+        if (i < W) {
+          const u64 h = halfP[i];
+          if (!decided && x[i] != h) { gt = x[i] > h; decided = true; }
+        }
+      }
+      if (gt) {
+        const u64* Pf = Ptab + (i64)K * W;
+        u64 borrow = 0;
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i) {
+          if (i < W) {
+            const u64 p = Pf[i];
+            const u64 d = x[i] - p;
+            const u64 b1 = x[i] < p;
+            const u64 d2 = d - borrow;
+            const u64 b2 = d < borrow;
+            x[i] = d2;
+            borrow = b1 | b2;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i)
+    if (i < W) sx[i * blockDim.x + threadIdx.x] = x[i];
+  // (each thread only reads back its own column: no barrier needed)
+  if (!active) return;
+  const u64 sign_fill = (sx[(W - 1) * blockDim.x + threadIdx.x] >> 63) ? ~0ull : 0ull;
+  auto X = [&](int i) -> u64 { return i < W ? sx[i * blockDim.x + threadIdx.x] : sign_fill; };
+  if (mode == 0) {
+    u64* o = out + (poly * n + j) * nl_out;
+    for (int i = 0; i < nl_out; ++i) o[i] = X(i);
+  } else if (mode == 1) {
+    // y = floor((2x + q) / 2q) = (x >> logQ) + bit_{logQ-1}(x), q = 2^logQ (arithmetic shift = floor);
+    // keep the positive residue mod 2^logQ, limb-major [nl_out][n]
+    const int w = logQ >> 6, b = logQ & 63;
+    u64 carry = (X((logQ - 1) >> 6) >> ((logQ - 1) & 63)) & 1;
+    u64* o = out + poly * nl_out * n + j;
+    for (int i = 0; i < nl_out; ++i) {
+      const u64 lo = X(i + w), hi = X(i + w + 1);
+      u64 val = b ? ((lo >> b) | (hi << (64 - b))) : lo;
+      val += carry;
+      carry = (carry && val == 0);
+      const int bits_left = logQ - 64 * i;
+      if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << bits_left) - 1);
+      o[(i64)i * n] = val;
+    }
+  } else {
+    // centred residue mod 2^logQ, two's complement, coefficient-major
+    const u64 sbit = (X((logQ - 1) >> 6) >> ((logQ - 1) & 63)) & 1;
+    u64* o = out + (poly * n + j) * nl_out;
+    for (int i = 0; i < nl_out; ++i) {
+      u64 val = X(i);
+      const int bits_left = logQ - 64 * i;
+      if (bits_left <= 0) val = sbit ? ~0ull : 0ull;
+      else if (bits_left < 64) { const u64 mask = (1ull << bits_left) - 1; val = sbit ? (val | ~mask) : (val & mask); }
+      o[i] = val;
+    }
+  }
+}
+
+template <int MAXW>
+static int launch_crt_t(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode,
+                        int positive, int logQ, u64* d_out, int nl_out) {
+  const int TB = 128;
+  const size_t shmem = (size_t)t->W * TB * sizeof(u64);
+  static bool attr_done = false;
+  if (!attr_done) { HIP_TRY(hipFuncSetAttribute((const void*)crt_kernel<MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, MAXW * TB * 8)); attr_done = true; }
+  dim3 grid((unsigned)((ctx->phim + TB - 1) / TB), (unsigned)npolys);
+  crt_kernel<MAXW><<<grid, TB, shmem, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->nidx, t->W, t->d_idx, t->d_pow64, t->d_pinv, t->d_P,
+                                                    t->d_halfP, ctx->d_pc, mode, positive, logQ, d_out, nl_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode, int positive,
+               int logQ, u64* d_out, int nl_out) {
+  if (!npolys) return 0;
+  if (mode != 0 && (logQ < 1 || logQ > 64 * (t->W - 1))) FHESI_FAIL("CRT: logQ=%d outside the range covered by the prime set", logQ);
+  const int W = t->W;
+  if (W <= 4) return launch_crt_t<4>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
+  if (W <= 8) return launch_crt_t<8>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
+  if (W <= 12) return launch_crt_t<12>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
+  if (W <= 20) return launch_crt_t<20>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
+  if (W <= 28) return launch_crt_t<28>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
+  if (W <= 44) return launch_crt_t<44>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
+  FHESI_FAIL("CRT: prime-set product of %d limbs exceeds the supported 44", W);
+}
+
+// ----------------------------------------------------------------------------------------- byte decomposition -> digit rows
+// parts: positive residues mod 2^logQ, limb-major [npolys][nl][n] (mode-1 output of crt_kernel).
+// rows out: [npolys][nd][L][n], digit d of coefficient j reduced mod q_l (digits < 2^digit_bits; Ciphertext.cpp:95-102,
+// zero digits simply give zero coefficients).
+__global__ void __launch_bounds__(256) digits_kernel(const u64* __restrict__ parts, int nl, i64 n, int logQ, int digit_bits, int nd, int L,
+                                                      u64* __restrict__ rows, const PrimeConst* __restrict__ pcs) {
+  const i64 poly = blockIdx.z;
+  const int d = blockIdx.y;
+  const int lo = d * digit_bits, w = lo >> 6, b = lo & 63;
+  const u64 mask = (digit_bits >= 64) ? ~0ull : ((1ull << digit_bits) - 1);
+  const u64* src = parts + poly * nl * n;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    u64 v = (w < nl) ? (src[(i64)w * n + j] >> b) : 0;
+    if (b + digit_bits > 64 && w + 1 < nl) v |= src[(i64)(w + 1) * n + j] << (64 - b);
+    v &= mask;
+    for (int l = 0; l < L; ++l) {
+      const u64 q = pcs[l].q;
+      rows[((poly * nd + d) * L + l) * n + j] = v < q ? v : v % q;
+    }
+  }
+}
+
+int launch_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_rows) {
+  if (!npolys) return 0;
+  unsigned gx = (unsigned)((ctx->phim + 255) / 256);
+  if (gx > 64) gx = 64;
+  dim3 grid(gx, (unsigned)nd, (unsigned)npolys);
+  digits_kernel<<<grid, 256, 0, ctx->stream>>>(d_parts, nl, ctx->phim, logQ, digit_bits, nd, ctx->L, d_rows, ctx->d_pc);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

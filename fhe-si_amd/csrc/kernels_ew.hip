@@ -1,0 +1,192 @@
+// kernels_ew.hip -- coefficient-wise DoubleCRT kernels (HBM-bound streaming kernels, 16 B per lane).
+//   ew_op        DoubleCRT::Op(DoubleCRT)            DoubleCRT.cpp:79-113   (AddMod / SubMod / MulMod per element)
+//   ew_scalar    DoubleCRT::Op(ZZ), /=, =(ZZ)        DoubleCRT.cpp:115-129, 407-420, 333-347
+//   tensor2x2    Ciphertext::operator*= tensor step   Ciphertext.cpp:179-186 (t0=a0b0, t1=a0b1+a1b0, t2=a1b1, fused)
+//   dot_accum    DotProduct<DoubleCRT>                Util.h:79-98 as used by FHE-SI.cpp:253-254 (fused multiply-accumulate)
+//   automorph    DoubleCRT::automorph                 DoubleCRT.cpp:439-465
+#include "fhesi_internal.h"
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u64 ew_apply(u64 a, u64 b, const PrimeConst& pc, int op) {
+  switch (op) {
+    case 0: return d_addmod(a, b, pc.q);
+    case 1: return d_submod(a, b, pc.q);
+    default: return d_mulmod(a, b, pc);
+  }
+}
+
+// rows: [nrows][n]; prime of row r = prime_of_slot[r % nslots].  grid.y = row, grid.x strides the row.
+template <int OP>
+__global__ void __launch_bounds__(256) ew_op_kernel(u64* __restrict__ dst, const u64* __restrict__ src, i64 n, int nslots,
+                                                     const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs) {
+  const i64 row = blockIdx.y;
+  const int slot = (int)(row % nslots);
+  const PrimeConst pc = pcs[prime_of_slot ? prime_of_slot[slot] : slot];
+  u64* d = dst + row * n;
+  const u64* s = src + row * n;
+  const i64 n2 = n >> 1;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (i64)gridDim.x * blockDim.x) {
+    u64x2 a = ((const u64x2*)d)[i], b = ((const u64x2*)s)[i];
+    a.x = ew_apply(a.x, b.x, pc, OP);
+    a.y = ew_apply(a.y, b.y, pc, OP);
+    ((u64x2*)d)[i] = a;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) d[n - 1] = ew_apply(d[n - 1], s[n - 1], pc, OP);
+}
+
+// scalar ops: scalars[slot] already reduced mod the slot's prime (and inverted for DIV) on the host.
+template <int OP>
+__global__ void __launch_bounds__(256) ew_scalar_kernel(u64* __restrict__ dst, const u64* __restrict__ scalars, i64 n, int nslots,
+                                                         const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs) {
+  const i64 row = blockIdx.y;
+  const int slot = (int)(row % nslots);
+  const PrimeConst pc = pcs[prime_of_slot ? prime_of_slot[slot] : slot];
+  const u64 sc = scalars[slot];
+  u64* d = dst + row * n;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    if (OP == FHESI_OP_SET_) d[i] = sc;
+    else d[i] = ew_apply(d[i], sc, pc, OP);
+  }
+}
+
+// ca: [count][2][L][n] = NTT(a0*p), NTT(a1*p);  cb: [count][2][L][n] = NTT(b0), NTT(b1);  t: [count][3][L][n]
+__global__ void __launch_bounds__(256) tensor2x2_kernel(const u64* __restrict__ ca, const u64* __restrict__ cb, u64* __restrict__ t, i64 n, int L, const PrimeConst* __restrict__ pcs) {
+  const i64 ct = blockIdx.z;
+  const int l = blockIdx.y;
+  const PrimeConst pc = pcs[l];
+  const i64 rs = (i64)L * n;
+  const u64* a0 = ca + ((ct * 2 + 0) * L + l) * n;
+  const u64* a1 = a0 + rs;
+  const u64* b0 = cb + ((ct * 2 + 0) * L + l) * n;
+  const u64* b1 = b0 + rs;
+  u64* t0 = t + ((ct * 3 + 0) * L + l) * n;
+  u64* t1 = t0 + rs;
+  u64* t2 = t1 + rs;
+  const i64 n2 = n >> 1;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (i64)gridDim.x * blockDim.x) {
+    const u64x2 x0 = ((const u64x2*)a0)[i], x1 = ((const u64x2*)a1)[i], y0 = ((const u64x2*)b0)[i], y1 = ((const u64x2*)b1)[i];
+    u64x2 r0, r1, r2;
+    r0.x = d_mulmod(x0.x, y0.x, pc);  r0.y = d_mulmod(x0.y, y0.y, pc);
+    r2.x = d_mulmod(x1.x, y1.x, pc);  r2.y = d_mulmod(x1.y, y1.y, pc);
+    r1.x = d_addmod(d_mulmod(x0.x, y1.x, pc), d_mulmod(x1.x, y0.x, pc), pc.q);
+    r1.y = d_addmod(d_mulmod(x0.y, y1.y, pc), d_mulmod(x1.y, y0.y, pc), pc.q);
+    ((u64x2*)t0)[i] = r0;  ((u64x2*)t1)[i] = r1;  ((u64x2*)t2)[i] = r2;
+  }
+}
+
+// out[ct][r][l][:] = sum_k key[r][k][l][:] * dig[ct][k][l][:]   (r = 0,1)
+__global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ key, const u64* __restrict__ dig, int ncol, i64 n, int L,
+                                                         u64* __restrict__ out, const PrimeConst* __restrict__ pcs) {
+  const i64 ct = blockIdx.z;
+  const int l = blockIdx.y;
+  const PrimeConst pc = pcs[l];
+  const i64 rs = (i64)L * n;
+  const u64* k0 = key + (i64)l * n;
+  const u64* k1 = key + ((i64)ncol * L + l) * n;
+  const u64* dg = dig + (ct * ncol * L + l) * n;
+  const i64 n2 = n >> 1;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (i64)gridDim.x * blockDim.x) {
+    u64x2 acc0 = {0, 0}, acc1 = {0, 0};
+    for (int k = 0; k < ncol; ++k) {
+      const u64x2 d = ((const u64x2*)(dg + k * rs))[i];
+      const u64x2 a = ((const u64x2*)(k0 + k * rs))[i];
+      const u64x2 b = ((const u64x2*)(k1 + k * rs))[i];
+      acc0.x = d_addmod(acc0.x, d_mulmod(a.x, d.x, pc), pc.q);
+      acc0.y = d_addmod(acc0.y, d_mulmod(a.y, d.y, pc), pc.q);
+      acc1.x = d_addmod(acc1.x, d_mulmod(b.x, d.x, pc), pc.q);
+      acc1.y = d_addmod(acc1.y, d_mulmod(b.y, d.y, pc), pc.q);
+    }
+    ((u64x2*)(out + ((ct * 2 + 0) * L + l) * n))[i] = acc0;
+    ((u64x2*)(out + ((ct * 2 + 1) * L + l) * n))[i] = acc1;
+  }
+}
+
+// new[idx(j)] = old[idx(j*k mod m)] for j in Z_m^*  (zms_list[i] = i-th element of Z_m^*)
+__global__ void __launch_bounds__(256) automorph_kernel(u64* __restrict__ dst, const u64* __restrict__ src, i64 phim, i64 m, i64 k,
+                                                         const int* __restrict__ zms_idx, const int* __restrict__ zms_list) {
+  const i64 row = blockIdx.y;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < phim; i += (i64)gridDim.x * blockDim.x) {
+    const i64 j = zms_list[i];
+    const i64 jk = (i64)(((unsigned __int128)j * (u64)k) % (u64)m);
+    dst[row * phim + i] = src[row * phim + zms_idx[jk]];
+  }
+}
+
+__global__ void __launch_bounds__(256) rows_equal_kernel(const u64* __restrict__ a, const u64* __restrict__ b, i64 nwords, int* __restrict__ differ) {
+  int d = 0;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (i64)gridDim.x * blockDim.x) d |= (a[i] != b[i]);
+  if (d) atomicOr(differ, 1);
+}
+
+static unsigned grid_x_for(i64 work_items) {
+  i64 b = (work_items + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 64 ? 64 : b));
+}
+
+int launch_ew_op(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 count, int nslots, const int* d_prime_of_slot, int op) {
+  const i64 n = ctx->phim, nrows = count * nslots;
+  if (!nrows) return 0;
+  dim3 grid(grid_x_for(n / 2), (unsigned)nrows);
+  switch (op) {
+    case 0: ew_op_kernel<0><<<grid, 256, 0, ctx->stream>>>(d_dst, d_src, n, nslots, d_prime_of_slot, ctx->d_pc); break;
+    case 1: ew_op_kernel<1><<<grid, 256, 0, ctx->stream>>>(d_dst, d_src, n, nslots, d_prime_of_slot, ctx->d_pc); break;
+    case 2: ew_op_kernel<2><<<grid, 256, 0, ctx->stream>>>(d_dst, d_src, n, nslots, d_prime_of_slot, ctx->d_pc); break;
+    default: FHESI_FAIL("DoubleCRT::Op: unknown operation %d", op);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_ew_scalar(fhesi_ctx* ctx, u64* d_dst, const u64* d_scalars, i64 count, int nslots, const int* d_prime_of_slot, int op) {
+  const i64 n = ctx->phim, nrows = count * nslots;
+  if (!nrows) return 0;
+  dim3 grid(grid_x_for(n), (unsigned)nrows);
+  switch (op) {
+    case 0: ew_scalar_kernel<0><<<grid, 256, 0, ctx->stream>>>(d_dst, d_scalars, n, nslots, d_prime_of_slot, ctx->d_pc); break;
+    case 1: ew_scalar_kernel<1><<<grid, 256, 0, ctx->stream>>>(d_dst, d_scalars, n, nslots, d_prime_of_slot, ctx->d_pc); break;
+    case 2: case 3: ew_scalar_kernel<2><<<grid, 256, 0, ctx->stream>>>(d_dst, d_scalars, n, nslots, d_prime_of_slot, ctx->d_pc); break;
+    case 4: ew_scalar_kernel<FHESI_OP_SET_><<<grid, 256, 0, ctx->stream>>>(d_dst, d_scalars, n, nslots, d_prime_of_slot, ctx->d_pc); break;
+    default: FHESI_FAIL("DoubleCRT scalar op: unknown operation %d", op);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a, const u64* d_b, u64* d_t, i64 count) {
+  if (!count) return 0;
+  if (ctx->phim & 1) FHESI_FAIL("tensor2x2: odd phi(m) not supported by the batched pipeline");
+  dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ctx->L, (unsigned)count);
+  tensor2x2_kernel<<<grid, 256, 0, ctx->stream>>>(d_a, d_b, d_t, ctx->phim, ctx->L, ctx->d_pc);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int ncol, i64 count, u64* d_out) {
+  if (!count) return 0;
+  if (ctx->phim & 1) FHESI_FAIL("dot_accum: odd phi(m) not supported by the batched pipeline");
+  dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ctx->L, (unsigned)count);
+  dot_accum_kernel<<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, d_out, ctx->d_pc);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_automorph(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 nrows, i64 k) {
+  if (!nrows) return 0;
+  dim3 grid(grid_x_for(ctx->phim), (unsigned)nrows);
+  automorph_kernel<<<grid, 256, 0, ctx->stream>>>(d_dst, d_src, ctx->phim, ctx->m, k, ctx->d_zms_idx, ctx->d_zms_list);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_rows_equal(fhesi_ctx* ctx, const u64* a, const u64* b, i64 nwords, int* equal) {
+  int* d_flag;
+  FHESI_TRY(ws_reserve(ctx, 4, 64, (void**)&d_flag));
+  HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
+  if (nwords) rows_equal_kernel<<<grid_x_for(nwords) * 4, 256, 0, ctx->stream>>>(a, b, nwords, d_flag);
+  int h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *equal = !h;
+  return 0;
+}

@@ -1,0 +1,247 @@
+// kernels_ntt.hip -- negacyclic number-theoretic transform for power-of-two m (n = phi(m) = m/2) on gfx950.
+//
+// Replaces Cmod::FFT / Cmod::iFFT (CModulus.cpp:90-107, 110-132) + tBluesteinFFT (bluestein.cpp:93-144) for
+// m = 2^k: there Cmod::FFT is exactly  y[j] = sum_k a_k psi^{(2j+1)k} mod q,  psi = root^2, natural order in and out
+// (SURVEY.md fact 5), and Cmod::iFFT its inverse (scatter to odd exponents, DFT with root^-1, /m, mod X^n+1).
+//
+// Arithmetic: 64-bit residues, Shoup/Harvey lazy butterflies (values kept in [0,4q) forward, [0,2q) inverse),
+// canonical [0,q) on store.  No MFMA: this is integer NTT.
+//
+// Two implementations:
+//   * ntt_*_tile: the tuned path, n = 2^11..2^14.  One workgroup per row, n/32 threads, 32 residues per thread in
+//     registers, radix-32 register passes (5+5+rest stages) separated by two LDS exchanges; coalesced row loads/stores,
+//     the bit-reversal permutation is absorbed by the exchange addressing.
+//   * ntt_*_lds: generic radix-2 LDS path for every other power of two (n = 2 .. 2^14 per block); rows larger than 2^14
+//     run their outer stages through global-memory stage kernels first (n = 2^15, 2^16, 2^17: Bluestein sizes, stress config).
+#include "fhesi_internal.h"
+
+#define NTT_LDS_MAX_LOG 14
+
+__device__ __forceinline__ u32 brv_bits(u32 x, int bits) { return __brev(x) >> (32 - bits); }
+
+// ------------------------------------------------------------------------------------------ lazy butterflies
+// forward (Cooley-Tukey, Harvey): X,Y in [0,4q) -> [0,4q)
+__device__ __forceinline__ void bfly_fwd(u64& X, u64& Y, u64 w, u64 wp, u64 q, u64 two_q) {
+  u64 x = X >= two_q ? X - two_q : X;
+  u64 t = d_shoup_lazy(Y, w, wp, q);
+  X = x + t;
+  Y = x - t + two_q;
+}
+// inverse (Gentleman-Sande): X,Y in [0,2q) -> [0,2q)
+__device__ __forceinline__ void bfly_inv(u64& X, u64& Y, u64 w, u64 wp, u64 q, u64 two_q) {
+  u64 s = X + Y;
+  u64 d = X - Y + two_q;
+  X = s >= two_q ? s - two_q : s;
+  Y = d_shoup_lazy(d, w, wp, q);
+}
+__device__ __forceinline__ u64 norm4(u64 v, u64 q, u64 two_q) {
+  if (v >= two_q) v -= two_q;
+  if (v >= q) v -= q;
+  return v;
+}
+__device__ __forceinline__ u64 norm2(u64 v, u64 q) { return v >= q ? v - q : v; }
+
+// ------------------------------------------------------------------------------------------ generic LDS kernels
+// One block handles one contiguous sub-block of 2^logb residues of a row of 2^logn; tw_mul = 2^(logn-logb) + subblock
+// selects the twiddles of the remaining stages (twiddle index = mm_local * tw_mul + i_local).
+template <bool BITREV>
+__global__ void __launch_bounds__(1024) ntt_fwd_lds(u64* __restrict__ rows, int logn, int logb, int nslots, const int* __restrict__ prime_of_slot,
+                                                     const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ tw_all) {
+  extern __shared__ __attribute__((aligned(16))) u64 s[];
+  const int nb = 1 << logb, T = blockDim.x, tid = threadIdx.x;
+  const int sub_per_row = 1 << (logn - logb);
+  const i64 row = blockIdx.x / sub_per_row;
+  const int sb = blockIdx.x % sub_per_row;
+  const int slot = (int)(row % nslots);
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const PrimeConst pc = pcs[prime];
+  const u64 q = pc.q, two_q = pc.two_q;
+  const Shoup2* tw = tw_all + ((i64)prime << logn);
+  u64* g = rows + (row << logn) + ((i64)sb << logb);
+  const u32 tw_mul = (u32)sub_per_row + sb;
+
+  for (int i = tid; i < nb; i += T) s[i] = g[i];
+  __syncthreads();
+  int logt = logb;
+  for (int mm = 1; mm < nb; mm <<= 1) {
+    --logt;
+    const int t = 1 << logt;
+    for (int b = tid; b < (nb >> 1); b += T) {
+      const int i = b >> logt, j = ((i << 1) << logt) + (b & (t - 1));
+      const Shoup2 w = tw[(u32)mm * tw_mul + i];
+      u64 X = s[j], Y = s[j + t];
+      bfly_fwd(X, Y, w.w, w.wp, q, two_q);
+      s[j] = X;
+      s[j + t] = Y;
+    }
+    __syncthreads();
+  }
+  if (BITREV) {   // full rows only (logb == logn): natural-order output y[j] = a[brv(j)]
+    for (int j = tid; j < nb; j += T) g[j] = norm4(s[brv_bits(j, logb)], q, two_q);
+  } else {
+    for (int j = tid; j < nb; j += T) g[j] = norm4(s[j], q, two_q);
+  }
+}
+
+template <bool BITREV>
+__global__ void __launch_bounds__(1024) ntt_inv_lds(u64* __restrict__ rows, int logn, int logb, int nslots, const int* __restrict__ prime_of_slot,
+                                                     const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ tw_all) {
+  extern __shared__ __attribute__((aligned(16))) u64 s[];
+  const int nb = 1 << logb, T = blockDim.x, tid = threadIdx.x;
+  const int sub_per_row = 1 << (logn - logb);
+  const i64 row = blockIdx.x / sub_per_row;
+  const int sb = blockIdx.x % sub_per_row;
+  const int slot = (int)(row % nslots);
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const PrimeConst pc = pcs[prime];
+  const u64 q = pc.q, two_q = pc.two_q;
+  const Shoup2* tw = tw_all + ((i64)prime << logn);
+  u64* g = rows + (row << logn) + ((i64)sb << logb);
+  const u32 tw_mul = (u32)sub_per_row + sb;
+  const bool full = (logb == logn);
+
+  if (BITREV) { for (int j = tid; j < nb; j += T) s[brv_bits(j, logb)] = g[j]; }
+  else        { for (int j = tid; j < nb; j += T) s[j] = g[j]; }
+  __syncthreads();
+  int logt = 0;
+  for (int mm = nb; mm > 1; mm >>= 1) {
+    const int h = mm >> 1, t = 1 << logt;
+    const bool last = full && (h == 1);
+    for (int b = tid; b < (nb >> 1); b += T) {
+      const int i = b >> logt, j = ((i << 1) << logt) + (b & (t - 1));
+      u64 X = s[j], Y = s[j + t];
+      if (!last) {
+        const Shoup2 w = tw[(u32)h * tw_mul + i];
+        bfly_inv(X, Y, w.w, w.wp, q, two_q);
+      } else {   // final stage folded with the 1/n scaling (the /m of CModulus.cpp:125)
+        u64 sum = X + Y, d = X - Y + two_q;
+        X = d_shoup_lazy(sum, pc.ninv, pc.ninv_sh, q);
+        Y = d_shoup_lazy(d, pc.ninv_w, pc.ninv_w_sh, q);
+      }
+      s[j] = X;
+      s[j + t] = Y;
+    }
+    __syncthreads();
+    ++logt;
+  }
+  for (int j = tid; j < nb; j += T) g[j] = norm2(s[j], q);
+}
+
+// outer stages of rows larger than one LDS block: one butterfly per thread straight on HBM
+__global__ void __launch_bounds__(256) ntt_fwd_global_stage(u64* __restrict__ rows, int logn, int stage /* mm = 2^stage */, int nslots,
+                                                             const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs,
+                                                             const Shoup2* __restrict__ tw_all, i64 total_bfly) {
+  i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total_bfly) return;
+  const i64 row = gid >> (logn - 1);
+  const u32 b = (u32)(gid & ((1ll << (logn - 1)) - 1));
+  const int slot = (int)(row % nslots);
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const PrimeConst pc = pcs[prime];
+  const int logt = logn - 1 - stage;
+  const u32 t = 1u << logt, i = b >> logt, j = ((i << 1) << logt) + (b & (t - 1));
+  const Shoup2 w = tw_all[((i64)prime << logn) + (1u << stage) + i];
+  u64* g = rows + (row << logn);
+  u64 X = g[j], Y = g[j + t];
+  bfly_fwd(X, Y, w.w, w.wp, pc.q, pc.two_q);
+  g[j] = X;       // stays lazy in [0,4q); the LDS pass normalises
+  g[j + t] = Y;
+}
+__global__ void __launch_bounds__(256) ntt_inv_global_stage(u64* __restrict__ rows, int logn, int stage /* h = 2^stage */, int nslots,
+                                                             const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs,
+                                                             const Shoup2* __restrict__ tw_all, i64 total_bfly) {
+  i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total_bfly) return;
+  const i64 row = gid >> (logn - 1);
+  const u32 b = (u32)(gid & ((1ll << (logn - 1)) - 1));
+  const int slot = (int)(row % nslots);
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const PrimeConst pc = pcs[prime];
+  const int logt = logn - 1 - stage;
+  const u32 t = 1u << logt, i = b >> logt, j = ((i << 1) << logt) + (b & (t - 1));
+  u64* g = rows + (row << logn);
+  u64 X = g[j], Y = g[j + t];
+  if (stage > 0) {
+    const Shoup2 w = tw_all[((i64)prime << logn) + (1u << stage) + i];
+    bfly_inv(X, Y, w.w, w.wp, pc.q, pc.two_q);
+    g[j] = norm2(X, pc.q);
+    g[j + t] = norm2(Y, pc.q);
+  } else {
+    u64 sum = X + Y, d = X - Y + pc.two_q;
+    g[j] = norm2(d_shoup_lazy(sum, pc.ninv, pc.ninv_sh, pc.q), pc.q);
+    g[j + t] = norm2(d_shoup_lazy(d, pc.ninv_w, pc.ninv_w_sh, pc.q), pc.q);
+  }
+}
+__global__ void __launch_bounds__(256) bitrev_rows(const u64* __restrict__ src, u64* __restrict__ dst, int logn, i64 total) {
+  i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const i64 row = gid >> logn;
+  const u32 j = (u32)(gid & ((1ll << logn) - 1));
+  dst[gid] = src[(row << logn) + brv_bits(j, logn)];
+}
+
+// ------------------------------------------------------------------------------------------ tuned register-tile kernels
+#include "ntt_tile.inc"
+
+// ------------------------------------------------------------------------------------------ launchers
+static int lds_threads(int logb) { int t = 1 << (logb > 0 ? logb - 1 : 0); return t > 1024 ? 1024 : (t < 64 ? 64 : t); }
+
+int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev) {
+  const int logn = ctx->logn;
+  const i64 nrows = count * nslots;
+  if (nrows == 0) return 0;
+  if (bitrev && ntt_tile_supported(logn)) return launch_ntt_fwd_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
+  const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
+  for (int st = 0; st < logn - logb; ++st) {
+    i64 total = nrows << (logn - 1);
+    ntt_fwd_global_stage<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(d_rows, logn, st, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_fwd, total);
+  }
+  const size_t shmem = sizeof(u64) << logb;
+  const unsigned grid = (unsigned)(nrows << (logn - logb));
+  if (bitrev && logb == logn) {
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_fwd_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    ntt_fwd_lds<true><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_fwd);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_fwd_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    ntt_fwd_lds<false><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_fwd);
+    if (bitrev) {
+      void* tmp;
+      FHESI_TRY(ws_reserve(ctx, 6, (size_t)nrows << (logn + 3), &tmp));
+      i64 total = nrows << logn;
+      bitrev_rows<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(d_rows, (u64*)tmp, logn, total);
+      HIP_TRY(hipMemcpyAsync(d_rows, tmp, (size_t)total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev) {
+  const int logn = ctx->logn;
+  const i64 nrows = count * nslots;
+  if (nrows == 0) return 0;
+  if (bitrev && ntt_tile_supported(logn)) return launch_ntt_inv_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
+  const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
+  const size_t shmem = sizeof(u64) << logb;
+  const unsigned grid = (unsigned)(nrows << (logn - logb));
+  if (bitrev && logb == logn) {
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_inv_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    ntt_inv_lds<true><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_inv);
+  } else {
+    if (bitrev) {
+      void* tmp;
+      FHESI_TRY(ws_reserve(ctx, 6, (size_t)nrows << (logn + 3), &tmp));
+      i64 total = nrows << logn;
+      bitrev_rows<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(d_rows, (u64*)tmp, logn, total);
+      HIP_TRY(hipMemcpyAsync(d_rows, tmp, (size_t)total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_inv_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    ntt_inv_lds<false><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_inv);
+  }
+  for (int st = logn - logb - 1; st >= 0; --st) {
+    i64 total = nrows << (logn - 1);
+    ntt_inv_global_stage<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(d_rows, logn, st, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_inv, total);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

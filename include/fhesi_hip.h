@@ -1,0 +1,125 @@
+/* fhesi_hip.h -- C ABI of the MI355X (gfx950) DoubleCRT backend for fhe-si.
+ *
+ * The reference (dwu4/fhe-si) has no FFI: its hot path is the C++ class graph
+ *   Ciphertext / KeySwitchSI  ->  DoubleCRT methods  ->  Cmodulus::FFT / iFFT  ->  BluesteinFFT  ->  NTL fftRep.
+ * This header is the seam a maintainer binds the *bodies* of those methods to (INTEGRATION.md shows the
+ * binding); every entry point names the reference interface it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - plain C, no C++/torch/NTL types; all functions return 0 on success, non-zero on error
+ *     (fhesi_last_error() gives the message).  The reference aborts through NTL Error()/assert
+ *     (e.g. DoubleCRT.cpp:83,316,443; FHEContext.cpp:34): the C++ mirror turns a non-zero status
+ *     into the same abort-style Error(msg).  No exception crosses this boundary.
+ *   - residue rows: uint64_t[phi(m)], canonical values in [0,q_i), Z_m^* ascending order
+ *     (the reference's vec_long rows, CModulus.cpp:103-106).
+ *   - big integers: little-endian 64-bit limbs, two's complement, fixed nlimbs per call,
+ *     coefficient-major [ncoeffs][nlimbs] (the reference's ZZX coefficients).
+ *   - "host" pointers are ordinary memory; "_dev" entry points take device (HBM) pointers that
+ *     must belong to the context's device.  Work is enqueued on the context's HIP stream;
+ *     functions that return data to the host synchronise that stream.
+ *   - one host thread per context; contexts are independent (one per GPU in the multi-GPU model).
+ */
+#ifndef FHESI_HIP_H_
+#define FHESI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fhesi_ctx fhesi_ctx;     /* FHEcontext + vector<Cmodulus> + PAlgebra (FHEContext.h, CModulus.h, PAlgebra.h) */
+typedef struct fhesi_dcrt fhesi_dcrt;   /* one DoubleCRT object (DoubleCRT.h:83-365), rows resident in HBM */
+typedef struct fhesi_ksk fhesi_ksk;     /* one KeySwitchSI matrix (FHE-SI.cpp:206-208), resident in HBM */
+
+enum { FHESI_OP_ADD = 0, FHESI_OP_SUB = 1, FHESI_OP_MUL = 2, FHESI_OP_DIV = 3, FHESI_OP_SET = 4 };
+
+const char* fhesi_last_error(void);
+int fhesi_device_count(int32_t* count);
+
+/* ---- context: FHEcontext::AddPrime (FHEContext.cpp:30-43) + Cmod::privateInit (CModulus.cpp:60-86) +
+ * PAlgebra::init (PAlgebra.cpp:40-56).  Tables (twiddles / Bluestein powers and Rb) are built eagerly and
+ * uploaded once (the reference fills them lazily: bluestein.cpp:103,121).  Rejects q not prime, q != 1 mod 2m,
+ * duplicate q (FHEContext.cpp:34), m outside [2, 2^20] (FHEContext.cpp:89), or root not a primitive 2m-th root.
+ * root[i] must be supplied (the reference draws a random one when 0, NumbTh.cpp:101-115; the C++ mirror does
+ * that search on the host and passes the result here so row values are reproducible). */
+int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, const uint64_t* q, const uint64_t* root, int32_t device);
+int fhesi_ctx_destroy(fhesi_ctx* ctx);
+int64_t fhesi_ctx_m(const fhesi_ctx* ctx);
+int64_t fhesi_ctx_phim(const fhesi_ctx* ctx);               /* PAlgebra::phiM (PAlgebra.h:78) */
+int32_t fhesi_ctx_nprimes(const fhesi_ctx* ctx);            /* FHEcontext::numPrimes (FHEContext.h:149) */
+int fhesi_ctx_prime(const fhesi_ctx* ctx, int32_t i, uint64_t* q, uint64_t* root);   /* ithPrime / getRoot */
+int fhesi_ctx_zms_idx(const fhesi_ctx* ctx, int32_t* out_m);                        /* PAlgebra::indexInZmstar table */
+int fhesi_ctx_phi_m(const fhesi_ctx* ctx, int64_t* out_phim_plus_1);                /* PAlgebra::PhimX coefficients */
+int fhesi_ctx_sync(fhesi_ctx* ctx);
+void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t all work of this context runs on */
+/* HIP-event stopwatch on the context's stream (bench.py's per-kernel timing) */
+int fhesi_timer_start(fhesi_ctx* ctx);
+int fhesi_timer_stop(fhesi_ctx* ctx, float* elapsed_ms);
+
+/* ---- Cmodulus::FFT / iFFT, one row (CModulus.h:165-166; CModulus.cpp:90-107, 110-132) */
+int fhesi_cmod_fft(fhesi_ctx* ctx, int32_t prime, const uint64_t* coeff_limbs, int32_t nlimbs, int64_t ncoeffs, uint64_t* y_out);
+int fhesi_cmod_ifft(fhesi_ctx* ctx, int32_t prime, const uint64_t* y, uint64_t* x_out /* phi(m) values in [0,q) */);
+
+/* ---- DoubleCRT objects (DoubleCRT.h:83-365).  prime_idx = ascending index set; nidx==0 means ctxtPrimes = all
+ * (DoubleCRT.cpp:244-250).  A new object holds the zero polynomial (DoubleCRT.cpp:261-311). */
+int fhesi_dcrt_alloc(fhesi_ctx* ctx, const int32_t* prime_idx, int32_t nidx, fhesi_dcrt** out);
+int fhesi_dcrt_free(fhesi_dcrt* d);
+int fhesi_dcrt_copy(fhesi_dcrt* dst, const fhesi_dcrt* src);        /* operator=(DoubleCRT) DoubleCRT.cpp:313-320: error if contexts differ */
+int fhesi_dcrt_index_set(const fhesi_dcrt* d, int32_t* idx_out, int32_t* nidx);   /* getIndexSet (DoubleCRT.h:303) */
+int fhesi_dcrt_equal(const fhesi_dcrt* a, const fhesi_dcrt* b, int32_t* equal);  /* operator== (DoubleCRT.h:167-169) */
+int fhesi_dcrt_upload_row(fhesi_dcrt* d, int32_t prime, const uint64_t* row);      /* setMap / Import (Serialization.cpp:56-81) */
+int fhesi_dcrt_download_row(const fhesi_dcrt* d, int32_t prime, uint64_t* row);    /* getMap / Export */
+void* fhesi_dcrt_device_ptr(fhesi_dcrt* d);                                          /* [nidx][phi(m)] uint64 in HBM */
+int fhesi_dcrt_from_poly(fhesi_dcrt* d, const uint64_t* coeff_limbs, int32_t nlimbs, int64_t ncoeffs);   /* DoubleCRT(const ZZX&) / operator=(ZZX): DoubleCRT.cpp:212-257,323-331 */
+int fhesi_dcrt_to_poly(const fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, int32_t positive,
+                       uint64_t* coeff_limbs_out, int32_t nlimbs);                   /* toPoly: DoubleCRT.cpp:349-404 (+ intVecCRT NumbTh.cpp:307-335) */
+int fhesi_dcrt_op(fhesi_dcrt* dst, const fhesi_dcrt* src, int32_t op);              /* Op(DoubleCRT): DoubleCRT.cpp:79-113 (equal index sets; ADD/SUB/MUL) */
+int fhesi_dcrt_op_scalar(fhesi_dcrt* d, const uint64_t* num_limbs, int32_t nlimbs, int32_t op);
+                                                                                     /* Op(ZZ) :115-129, operator/= :407-420, operator=(ZZ) :333-347 */
+int fhesi_dcrt_automorph(fhesi_dcrt* d, int64_t k);                                 /* automorph: DoubleCRT.cpp:439-465; error if k not in Zm* */
+int fhesi_dcrt_add_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx);   /* addPrimes: DoubleCRT.cpp:142-156 */
+int fhesi_dcrt_remove_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx);/* removePrimes: DoubleCRT.h:197-199 */
+/* SingleCRT <-> DoubleCRT (DoubleCRT.cpp:484-515): coefficient-domain residues per prime, [nidx][phi(m)] */
+int fhesi_dcrt_from_scrt(fhesi_dcrt* d, const uint64_t* coeff_rows);
+int fhesi_dcrt_to_scrt(const fhesi_dcrt* d, uint64_t* coeff_rows_out);
+
+/* ---- batched device-resident row kernels.  rows_dev: [count][L][phi(m)] uint64 in HBM, all L primes */
+int fhesi_rows_ntt_fwd_dev(fhesi_ctx* ctx, uint64_t* rows_dev, int64_t count);      /* coefficient residues -> evaluations, in place (Cmod::FFT after conv) */
+int fhesi_rows_ntt_inv_dev(fhesi_ctx* ctx, uint64_t* rows_dev, int64_t count);      /* evaluations -> coefficient residues, in place (Cmod::iFFT) */
+int fhesi_rows_op_dev(fhesi_ctx* ctx, uint64_t* dst_dev, const uint64_t* src_dev, int64_t count, int32_t op);   /* DoubleCRT::Op over a batch */
+
+/* ---- key-switch matrix (KeySwitchSI::keySwitchMatrix, FHE-SI.cpp:206-208): [2][ncomp*ndigits][L][phi(m)],
+ * matrix[0]=b, matrix[1]=A, column i*ndigits+j (FHE-SI.cpp:176-177) */
+int fhesi_ksk_create(fhesi_ctx* ctx, int32_t ncomp, int32_t ndigits, fhesi_ksk** out);
+int fhesi_ksk_free(fhesi_ksk* k);
+int fhesi_ksk_upload(fhesi_ksk* k, const uint64_t* rows_host);                       /* whole matrix, host layout as above */
+void* fhesi_ksk_device_ptr(fhesi_ksk* k);                                            /* HBM buffer (target of the RCCL broadcast) */
+size_t fhesi_ksk_bytes(const fhesi_ksk* k);
+
+/* ---- the metric's unit of work, batched: Ciphertext::operator*= (Ciphertext.cpp:167-192) followed by
+ * KeySwitchSI::ApplyKeySwitch (FHE-SI.cpp:241-260) = ScaleDown (Ciphertext.cpp:194-218) + ByteDecomp (:82-121)
+ * + DotProduct (Util.h:79-98) + toPoly + ReduceCoefficients (Util.cpp:3-33).
+ * a, b: [count][2][phi(m)][nlimbs] two's complement coefficients mod 2^logQ (centered); out: same shape.
+ * nlimbs must be >= ceil(logQ/64).  decomp_bytes = FHEcontext::decompSize (3 at every reference call site). */
+int fhesi_ct_mul_relin_batch(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes,
+                             const uint64_t* a_host, const uint64_t* b_host, uint64_t* out_host, int32_t nlimbs, int64_t count);
+int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes,
+                                 const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev, int32_t nlimbs, int64_t count);
+/* Separately callable stages of the same pipeline (parity tests check each against the oracle) */
+int fhesi_ct_mul_dev(fhesi_ctx* ctx, uint64_t p, const uint64_t* a_dev, const uint64_t* b_dev, int32_t nlimbs, int64_t count,
+                     uint64_t* tprod_dev /* [count][3][L][phi(m)] */);              /* Ciphertext::operator*= */
+int fhesi_apply_key_switch_dev(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes,
+                               const uint64_t* tprod_dev, int64_t count, uint64_t* out_dev, int32_t nlimbs);   /* ApplyKeySwitch */
+
+/* plain device-memory helpers so C callers need no HIP headers */
+int fhesi_dev_alloc(fhesi_ctx* ctx, size_t bytes, void** out_dev);
+int fhesi_dev_free(fhesi_ctx* ctx, void* dev);
+int fhesi_dev_upload(fhesi_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int fhesi_dev_download(fhesi_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHESI_HIP_H_ */

@@ -1,0 +1,60 @@
+"""GPU parity: Cmod::FFT / iFFT rows (power-of-two m) through the C ABI vs the C oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+import fhe_si_amd as F
+import oracle_lib as O
+import params as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("logn", [1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16])
+def test_rows_fwd_inv_vs_oracle(logn):
+    n = 1 << logn
+    m = 2 * n
+    L = 3 if logn < 15 else 2
+    primes, roots = P.first_primes(m, L)
+    if logn <= 12:     # also a small / odd-sized prime, like the last prime of a chain (FHEContext.cpp:101-107)
+        small, sroots = P.first_primes(m, 1, sp_nbits=max(20, logn + 4))
+        primes, roots = primes[:2] + small, roots[:2] + sroots
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    rng = np.random.default_rng(100 + logn)
+    count = 3
+    rows = P.rand_rows(rng, primes, n, count)
+    rows[0, 0, :] = 0                      # zero row stays zero (bluestein.cpp:96-97)
+    rows[1, 1, :] = np.uint64(primes[1] - 1)   # extreme residues
+    buf = ctx.upload(rows)
+    ctx.rows_ntt_fwd(buf, count)
+    got = buf.download(rows.shape)
+    for c in range(count):
+        for i in range(len(primes)):
+            exp = orc.fft_residues(i, rows[c, i])
+            assert np.array_equal(got[c, i], exp), (logn, c, i)
+    ctx.rows_ntt_inv(buf, count)
+    back = buf.download(rows.shape)
+    assert np.array_equal(back, rows)
+    # inverse against the oracle on fresh evaluations
+    ev = P.rand_rows(rng, primes, n, 1)
+    buf2 = ctx.upload(ev)
+    ctx.rows_ntt_inv(buf2, 1)
+    got2 = buf2.download(ev.shape)
+    for i in range(len(primes)):
+        assert np.array_equal(got2[0, i], orc.cmod_ifft(i, ev[0, i])), (logn, i)
+
+
+def test_cmod_fft_single_row_bigint():
+    m = 64
+    primes, roots = P.chain_for(m, 100, 23)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    rng = np.random.default_rng(7)
+    # signed big coefficients, more coefficients than phi(m) (degree >= phi(m) folds modulo Phi_m, >= m ignored)
+    for ncoeffs in (5, 32, 40, 64, 70):
+        limbs = P.rand_limbs(rng, (ncoeffs,), 3, 150)
+        for i in range(len(primes)):
+            assert np.array_equal(ctx.cmod_fft(i, limbs), orc.cmod_fft(i, limbs)), (ncoeffs, i)
+    y = P.rand_rows(rng, primes, ctx.phim)[0]
+    for i in range(len(primes)):
+        assert np.array_equal(ctx.cmod_ifft(i, y[i]), orc.cmod_ifft(i, y[i]))
