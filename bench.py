@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- ciphertext mult + relinearize throughput of the gfx950 DoubleCRT backend (BASELINE.json's metric).
+
+One step = one batch of B independent ciphertext mults (Ciphertext::operator*= + KeySwitchSI::ApplyKeySwitch,
+Test_AddMul.cpp:59-67) per GPU at the metric configuration: m = 2^15 (n = phi(m) = 2^14), fhe-si logQ = 512, p = 23,
+decompSize = 3  =>  L = 18 chain primes (60-bit rule of FHEContext.cpp:88-115), ndigits = 22.
+Inputs are synthetic (uniform coefficients in [-2^511, 2^511), uniform key-switch rows) and resident in HBM before the
+timed region.  N > 1: one process per GPU, ciphertext batches sharded (each rank its own B), key-switch matrix generated
+on rank 0 and broadcast with RCCL; no collective inside the timed loop (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task description) including
+  roofline     -- forward-NTT kernel: algorithmic bytes (2*n*8 per row) / HIP-event time of its launches, vs 8 TB/s
+  cpu_baseline -- the C oracle (oracle/fhesi_oracle.c, single thread) on a bounded sample of the same workload
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M_RING = 1 << 15
+LOGQ = 512
+P_PLAIN = 23
+DECOMP = 3
+SP_NBITS = 60
+HBM_PEAK_GBS = 8000.0
+
+
+# ---- host-side setup (pure integer helpers; the chain rule restates FHEContext.cpp:83-115) -----------------------
+def _is_prime(n):
+    if n < 2:
+        return False
+    sp = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
+    for p in sp:
+        if n % p == 0:
+            return n == p
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    for a in sp:
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def prime_chain(m, logQ, p, phim, xi=1, sp_nbits=SP_NBITS):
+    total = logQ * math.log(2.0) * 2 + math.log(p) + math.log(phim) * 2 + math.log(2) + math.log(xi)
+    chain, q, two_m, last, left = [], (1 << sp_nbits) - 1, 2 * m, False, total
+    q -= q % two_m
+    q += two_m + 1
+    while left > 0.0:
+        if left < math.log(float(q)) and not last:
+            last = True
+            q = int(math.ceil(math.exp(left)))
+            q -= (q % two_m) - 1
+            two_m = -two_m
+        while True:
+            q -= two_m
+            if _is_prime(q):
+                break
+        if q not in chain:
+            chain.append(q)
+            left -= math.log(float(q))
+    return chain
+
+
+def root_2m(q, m):
+    e = 2 * m
+    facts, t, f = [], e, 2
+    while f * f <= t:
+        if t % f == 0:
+            facts.append(f)
+            while t % f == 0:
+                t //= f
+        f += 1
+    if t > 1:
+        facts.append(t)
+    for s in range(2, 1000):
+        r = pow(s, (q - 1) // e, q)
+        if pow(r, e, q) == 1 and all(pow(r, e // g, q) != 1 for g in facts):
+            return r
+    raise RuntimeError("no root")
+
+
+def rand_residue_rows(rng, primes, shape_prefix, n):
+    out = np.empty(tuple(shape_prefix) + (len(primes), n), dtype=np.uint64)
+    for i, q in enumerate(primes):
+        out[..., i, :] = rng.integers(0, q, size=tuple(shape_prefix) + (n,), dtype=np.uint64)
+    return out
+
+
+def rand_coeffs(rng, shape, nlimbs):
+    """uniform in [-2^(64 nlimbs - 1), 2^(64 nlimbs - 1)): any limb pattern is a valid two's complement value."""
+    hi = rng.integers(0, 1 << 63, size=tuple(shape) + (nlimbs,), dtype=np.uint64)
+    lo = rng.integers(0, 2, size=tuple(shape) + (nlimbs,), dtype=np.uint64)
+    return hi * np.uint64(2) + lo
+
+
+def cpu_baseline(primes, roots, ksm, a, b, n_sample):
+    """Oracle (single-thread C restatement) timed on the host cores: the reported CPU figure, never the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    orc = O.Oracle(M_RING, primes, roots)
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n_sample):
+        orc.ct_mul_relin(ksm, a[i], b[i], LOGQ, P_PLAIN, DECOMP)
+        done += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "ciphertext-mults/s", "cores": 1, "kind": "port",
+            "sample": f"{done} ciphertext mult+relin at the bench config (n=2^14, L={len(primes)}, ndigits={ksm.shape[1] // 3}) "
+                      f"with the C oracle's direct negacyclic NTT (optimistic vs the reference's Bluestein over NTL), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="ciphertext mults per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import fhe_si_amd as F
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (HIP path only; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = M_RING // 2
+    primes = prime_chain(M_RING, LOGQ, P_PLAIN, n)
+    roots = [root_2m(q, M_RING) for q in primes]
+    L = len(primes)
+    nd = (LOGQ + 8 * DECOMP - 1) // (8 * DECOMP)
+    nl = (LOGQ + 63) // 64
+    ncol = 3 * nd
+    chain_bits = sum(math.log2(q) for q in primes)
+    B = args.batch
+
+    ctx = F.Context(M_RING, primes, roots, device=local_rank)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd)
+
+    # key-switch matrix: generated on rank 0, RCCL-broadcast over xGMI into every rank's HBM copy
+    ksm_host = None
+    if rank == 0:
+        ksm_host = rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n)
+    if world > 1:
+        stage = torch.empty(ksk.nbytes // 8, dtype=torch.int64, device=f"cuda:{local_rank}")
+        if rank == 0:
+            stage.copy_(torch.from_numpy(ksm_host.view(np.int64).reshape(-1)))
+        dist.broadcast(stage, src=0)
+        torch.cuda.synchronize()
+        ctx.dev_copy(ksk.device_ptr, stage.data_ptr(), ksk.nbytes)
+        del stage
+    else:
+        ksk.upload(ksm_host)
+
+    rng = np.random.default_rng(7 + rank)
+    a_host = rand_coeffs(rng, (B, 2, n), nl)
+    b_host = rand_coeffs(rng, (B, 2, n), nl)
+    da, db = ctx.upload(a_host), ctx.upload(b_host)
+    dout = ctx.alloc(a_host.nbytes)
+
+    def step():
+        ctx.ct_mul_relin_dev(ksk, LOGQ, P_PLAIN, da, db, dout, nl, B, DECOMP)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # live per-kernel timing of the timed region (HIP events on the context's stream)
+    prof = {k: ctx.prof_read(k) for k in F.binding.PROF_CLASSES}
+    ctx.prof_enable(False)
+    launches, rows, ms = prof["ntt_fwd"]
+    row_bytes = 2 * n * 8                                   # row read once + written once
+    if args.ntt_rows:
+        # optional standalone measurement on a fixed row count
+        cnt = max(1, args.ntt_rows // L)
+        buf = ctx.upload(rand_residue_rows(np.random.default_rng(1), primes, (cnt,), n))
+        ctx.rows_ntt_fwd(buf, cnt)
+        ctx.prof_enable(True)
+        for _ in range(10):
+            ctx.rows_ntt_fwd(buf, cnt)
+        launches, rows, ms = ctx.prof_read("ntt_fwd")
+        ctx.prof_enable(False)
+    achieved = rows * row_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_ntt_fwd.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "ntt_fwd_tile<14>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
+                "rows_per_launch": round(rows / launches, 1) if launches else None,
+                "row_ntts_per_s": round(rows / (ms * 1e-3), 1) if ms > 0 else None}
+
+    if rank == 0:
+        total_mults = B * args.steps * world
+        value = total_mults / dt
+        breakdown = {k: round(v[2] / args.steps, 3) for k, v in prof.items() if v[0]}
+        cpu = None
+        if args.cpu_sample > 0:
+            cpu = cpu_baseline(primes, roots, ksm_host, a_host, b_host, min(args.cpu_sample, B))
+        line = {
+            "metric": "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^14, logQ=512",
+            "value": round(value, 2), "unit": "ciphertext-mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3",
+                       "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B,
+                       "fwd_row_ntts_per_mult": (4 + ncol) * L, "inv_row_ntts_per_mult": 5 * L,
+                       "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
+        }
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

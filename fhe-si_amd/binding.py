@@ -28,7 +28,9 @@ ABI_SYMBOLS = [
     "fhesi_rows_ntt_fwd_dev", "fhesi_rows_ntt_inv_dev", "fhesi_rows_op_dev", "fhesi_ksk_create", "fhesi_ksk_free",
     "fhesi_ksk_upload", "fhesi_ksk_device_ptr", "fhesi_ksk_bytes", "fhesi_ct_mul_relin_batch", "fhesi_ct_mul_relin_batch_dev",
     "fhesi_ct_mul_dev", "fhesi_apply_key_switch_dev", "fhesi_dev_alloc", "fhesi_dev_free", "fhesi_dev_upload", "fhesi_dev_download",
+    "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
 ]
+PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7}
 
 
 class FhesiError(RuntimeError):
@@ -103,6 +105,9 @@ def _load():
         "fhesi_dev_free": [_vp, _vp],
         "fhesi_dev_upload": [_vp, _vp, _vp, C.c_size_t],
         "fhesi_dev_download": [_vp, _vp, _vp, C.c_size_t],
+        "fhesi_dev_copy": [_vp, _vp, _vp, C.c_size_t],
+        "fhesi_prof_enable": [_vp, _i32],
+        "fhesi_prof_read": [_vp, _i32, _vp, _vp, _vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -218,6 +223,18 @@ class Context:
         ms = C.c_float(0)
         _ck(_load().fhesi_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+    def prof_enable(self, on: bool = True):
+        _ck(_load().fhesi_prof_enable(self.h, int(on)))
+
+    def prof_read(self, cls: str):
+        """-> (launches, units, total_ms) for one kernel class of PROF_CLASSES."""
+        n, u, ms = _i64(0), C.c_double(0), C.c_double(0)
+        _ck(_load().fhesi_prof_read(self.h, PROF_CLASSES[cls], C.byref(n), C.byref(u), C.byref(ms)))
+        return n.value, u.value, ms.value
+
+    def dev_copy(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        _ck(_load().fhesi_dev_copy(self.h, _vp(dst_ptr), _vp(src_ptr), nbytes))
 
     # Cmodulus::FFT / iFFT
     def cmod_fft(self, prime: int, limbs: np.ndarray) -> np.ndarray:

@@ -220,7 +220,37 @@ extern "C" int fhesi_timer_stop(fhesi_ctx* c, float* ms) {
   return 0;
 }
 
+// --------------------------------------------------------------------------------------------- per-kernel stopwatch
+extern "C" int fhesi_prof_enable(fhesi_ctx* c, int32_t on) {
+  CHECK_CTX(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (auto& r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  c->prof.clear();
+  c->prof_on = on != 0;
+  return 0;
+}
+extern "C" int fhesi_prof_read(fhesi_ctx* c, int32_t cls, int64_t* launches, double* units, double* total_ms) {
+  CHECK_CTX(c);
+  if (cls < 0 || cls >= PROF_NCLASS) FHESI_FAIL("unknown kernel class %d", cls);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int64_t n = 0; double u = 0, ms = 0;
+  for (auto& r : c->prof) {
+    if (r.cls != cls) continue;
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+    ++n; u += r.units; ms += t;
+  }
+  *launches = n; *units = u; *total_ms = ms;
+  return 0;
+}
+
 // --------------------------------------------------------------------------------------------- plain device memory
+extern "C" int fhesi_dev_copy(fhesi_ctx* c, void* dst_dev, const void* src_dev, size_t bytes) {
+  CHECK_CTX(c);
+  HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
 extern "C" int fhesi_dev_alloc(fhesi_ctx* c, size_t bytes, void** out) { CHECK_CTX(c); HIP_TRY(hipMalloc(out, bytes ? bytes : 8)); return 0; }
 extern "C" int fhesi_dev_free(fhesi_ctx* c, void* p) { CHECK_CTX(c); HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(p)); return 0; }
 extern "C" int fhesi_dev_upload(fhesi_ctx* c, void* dst, const void* src, size_t bytes) {

@@ -49,6 +49,10 @@ struct CrtTables {
 
 struct BluesteinTables;                // general-m path, defined in bluestein.hip
 
+// per-kernel-class HIP-event stopwatch (bench.py's live kernel timing; off by default)
+enum { PROF_NTT_FWD = 0, PROF_NTT_INV = 1, PROF_RNS = 2, PROF_TENSOR = 3, PROF_CRT = 4, PROF_DIGITS = 5, PROF_DOT = 6, PROF_EW = 7, PROF_NCLASS = 8 };
+struct ProfRec { int cls; double units; hipEvent_t e0, e1; };
+
 struct fhesi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -71,6 +75,8 @@ struct fhesi_ctx {
   BluesteinTables* blue = nullptr;
   std::map<std::vector<int>, CrtTables*> crt_cache;
   std::map<int, Shoup2*> pow64_cache;  // nlimbs -> device [L][nlimbs+1] table for rns_reduce
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
   // grow-only workspace
   void* ws[10] = {};
   size_t ws_bytes[10] = {};
@@ -90,6 +96,19 @@ struct fhesi_ksk {
 };
 
 int ws_reserve(fhesi_ctx* ctx, int slot, size_t bytes, void** out);
+
+// RAII scope: records an event pair around the launches issued while it is alive (only when profiling is on)
+struct ProfScope {
+  fhesi_ctx* c; int idx = -1;
+  ProfScope(fhesi_ctx* ctx, int cls, double units) : c(ctx) {
+    if (!c->prof_on) return;
+    ProfRec r; r.cls = cls; r.units = units;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    hipEventRecord(r.e0, c->stream);
+    c->prof.push_back(r); idx = (int)c->prof.size() - 1;
+  }
+  ~ProfScope() { if (idx >= 0) hipEventRecord(c->prof[idx].e1, c->stream); }
+};
 
 // --------------------------------------------------------------------------------- host number theory (hostmath.cpp)
 namespace hm {

@@ -78,6 +78,7 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // h goes out of scope
   }
   const i64 n = ctx->phim;
+  ProfScope prof(ctx, PROF_RNS, (double)(count * npoly));
   unsigned gx = (unsigned)((n + 255) / 256);
   if (gx > 64) gx = 64;
   dim3 grid(gx, (unsigned)nslots, (unsigned)(count * npoly));
@@ -282,6 +283,7 @@ int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots
   if (!npolys) return 0;
   if (mode != 0 && (logQ < 1 || logQ > 64 * (t->W - 1))) FHESI_FAIL("CRT: logQ=%d outside the range covered by the prime set", logQ);
   const int W = t->W;
+  ProfScope prof(ctx, PROF_CRT, (double)npolys);
   if (W <= 4) return launch_crt_t<4>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (W <= 8) return launch_crt_t<8>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (W <= 12) return launch_crt_t<12>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
@@ -315,6 +317,7 @@ __global__ void __launch_bounds__(256) digits_kernel(const u64* __restrict__ par
 
 int launch_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_rows) {
   if (!npolys) return 0;
+  ProfScope prof(ctx, PROF_DIGITS, (double)npolys);
   unsigned gx = (unsigned)((ctx->phim + 255) / 256);
   if (gx > 64) gx = 64;
   dim3 grid(gx, (unsigned)nd, (unsigned)npolys);

@@ -127,6 +127,7 @@ static unsigned grid_x_for(i64 work_items) {
 int launch_ew_op(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 count, int nslots, const int* d_prime_of_slot, int op) {
   const i64 n = ctx->phim, nrows = count * nslots;
   if (!nrows) return 0;
+  ProfScope prof(ctx, PROF_EW, (double)nrows);
   dim3 grid(grid_x_for(n / 2), (unsigned)nrows);
   switch (op) {
     case 0: ew_op_kernel<0><<<grid, 256, 0, ctx->stream>>>(d_dst, d_src, n, nslots, d_prime_of_slot, ctx->d_pc); break;
@@ -156,6 +157,7 @@ int launch_ew_scalar(fhesi_ctx* ctx, u64* d_dst, const u64* d_scalars, i64 count
 int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a, const u64* d_b, u64* d_t, i64 count) {
   if (!count) return 0;
   if (ctx->phim & 1) FHESI_FAIL("tensor2x2: odd phi(m) not supported by the batched pipeline");
+  ProfScope prof(ctx, PROF_TENSOR, (double)count);
   dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ctx->L, (unsigned)count);
   tensor2x2_kernel<<<grid, 256, 0, ctx->stream>>>(d_a, d_b, d_t, ctx->phim, ctx->L, ctx->d_pc);
   HIP_TRY(hipGetLastError());
@@ -165,6 +167,7 @@ int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a, const u64* d_b, u64* d_t, i
 int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int ncol, i64 count, u64* d_out) {
   if (!count) return 0;
   if (ctx->phim & 1) FHESI_FAIL("dot_accum: odd phi(m) not supported by the batched pipeline");
+  ProfScope prof(ctx, PROF_DOT, (double)count);
   dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ctx->L, (unsigned)count);
   dot_accum_kernel<<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, d_out, ctx->d_pc);
   HIP_TRY(hipGetLastError());

@@ -190,6 +190,7 @@ int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   const int logn = ctx->logn;
   const i64 nrows = count * nslots;
   if (nrows == 0) return 0;
+  ProfScope prof(ctx, PROF_NTT_FWD, (double)nrows);
   if (bitrev && ntt_tile_supported(logn)) return launch_ntt_fwd_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
   const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
   for (int st = 0; st < logn - logb; ++st) {
@@ -220,6 +221,7 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   const int logn = ctx->logn;
   const i64 nrows = count * nslots;
   if (nrows == 0) return 0;
+  ProfScope prof(ctx, PROF_NTT_INV, (double)nrows);
   if (bitrev && ntt_tile_supported(logn)) return launch_ntt_inv_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
   const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
   const size_t shmem = sizeof(u64) << logb;

@@ -58,6 +58,13 @@ void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t a
 int fhesi_timer_start(fhesi_ctx* ctx);
 int fhesi_timer_stop(fhesi_ctx* ctx, float* elapsed_ms);
 
+/* per-kernel-class stopwatch: while enabled every launch of a class is bracketed by a HIP-event pair on the context's
+ * stream; read returns (#launches, units processed -- rows for the NTT classes, polynomials/ciphertexts otherwise --, total ms) */
+enum { FHESI_PROF_NTT_FWD = 0, FHESI_PROF_NTT_INV = 1, FHESI_PROF_RNS = 2, FHESI_PROF_TENSOR = 3, FHESI_PROF_CRT = 4,
+       FHESI_PROF_DIGITS = 5, FHESI_PROF_DOT = 6, FHESI_PROF_EW = 7 };
+int fhesi_prof_enable(fhesi_ctx* ctx, int32_t on);      /* also clears the records */
+int fhesi_prof_read(fhesi_ctx* ctx, int32_t kernel_class, int64_t* launches, double* units, double* total_ms);
+
 /* ---- Cmodulus::FFT / iFFT, one row (CModulus.h:165-166; CModulus.cpp:90-107, 110-132) */
 int fhesi_cmod_fft(fhesi_ctx* ctx, int32_t prime, const uint64_t* coeff_limbs, int32_t nlimbs, int64_t ncoeffs, uint64_t* y_out);
 int fhesi_cmod_ifft(fhesi_ctx* ctx, int32_t prime, const uint64_t* y, uint64_t* x_out /* phi(m) values in [0,q) */);
@@ -118,6 +125,7 @@ int fhesi_dev_alloc(fhesi_ctx* ctx, size_t bytes, void** out_dev);
 int fhesi_dev_free(fhesi_ctx* ctx, void* dev);
 int fhesi_dev_upload(fhesi_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int fhesi_dev_download(fhesi_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int fhesi_dev_copy(fhesi_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);    /* e.g. RCCL receive buffer -> key matrix */
 
 #ifdef __cplusplus
 }
