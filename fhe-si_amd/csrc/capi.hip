@@ -112,6 +112,7 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
     pc.pad0 = 0;
     pc.r64 = (u64)(((u128)1 << 64) % Q);
     pc.r64_sh = hm::shoup(pc.r64, Q);
+    pc.one_sh = hm::shoup(1, Q);
     pc.ninv = pc.ninv_sh = pc.ninv_w = pc.ninv_w_sh = 0;
   }
   if (c->pow2) {
@@ -709,8 +710,11 @@ extern "C" int fhesi_apply_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
   // ByteDecomp + DoubleCRT(digit polys)   (Ciphertext.cpp:82-121, FHE-SI.cpp:244-249)
   void* d_dig;
   FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * L * n * 8, &d_dig));
-  FHESI_TRY(launch_digits(c, (const u64*)d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
-  FHESI_TRY(row_fwd(c, (u64*)d_dig, count * ncol, L, nullptr, all.data()));
+  if (c->pow2) FHESI_TRY(launch_ntt_fwd_digits(c, (const u64*)d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
+  else {
+    FHESI_TRY(launch_digits(c, (const u64*)d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
+    FHESI_TRY(row_fwd(c, (u64*)d_dig, count * ncol, L, nullptr, all.data()));
+  }
   // DotProduct with both key rows (FHE-SI.cpp:251-254)
   FHESI_TRY(launch_dot_accum(c, k->d_rows, (const u64*)d_dig, ncol, count, (u64*)d_t));
   // toPoly + ReduceCoefficients (FHE-SI.cpp:255-256)

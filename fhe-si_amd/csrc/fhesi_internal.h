@@ -27,6 +27,7 @@ struct PrimeConst {
   u64 bar_mu;       // Barrett: floor(2^(2k)/q), k = bit length of q
   u32 bar_k;        // bit length of q
   u32 pad0;
+  u64 one_sh;       // floor(2^64/q): Shoup quotient of the constant 1 (reduces any 64-bit word)
   u64 ninv, ninv_sh;        // phi(m)^-1 mod q and its Shoup quotient (power-of-two m: the /m of CModulus.cpp:125 folded with X^n=-1)
   u64 ninv_w, ninv_w_sh;    // ninv * psi^-brv(1) (last inverse stage twiddle folded with the scaling)
   u64 r64, r64_sh;          // 2^64 mod q (Horner step of the big-int -> residue reduction, CModulus.cpp:96 conv)
@@ -133,8 +134,8 @@ std::vector<u64> bn_mul_small(const std::vector<u64>& a, u64 b);   // non-negati
 int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev = true);
 int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev = true);
 // digit-row forward NTT: source is the scaled-down part in limb-major layout, see kernels_crt.hip
-int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts_limbmajor, int nl_q, int logQ, int digit_bits, int ncomp, int nd,
-                          i64 count, u64* d_out_rows /* [count][ncomp*nd][L][n] */);
+int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts_limbmajor, int nl, int logQ, int digit_bits, int nd, i64 npolys,
+                          u64* d_out_rows /* [npolys*nd][L][n] */);
 
 // kernels_ew.hip
 int launch_ew_op(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 count, int nslots, const int* d_prime_of_slot, int op);

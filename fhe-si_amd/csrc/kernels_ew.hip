@@ -76,29 +76,64 @@ __global__ void __launch_bounds__(256) tensor2x2_kernel(const u64* __restrict__ 
 }
 
 // out[ct][r][l][:] = sum_k key[r][k][l][:] * dig[ct][k][l][:]   (r = 0,1)
-__global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ key, const u64* __restrict__ dig, int ncol, i64 n, int L,
+// One block column handles CT_TILE ciphertexts so that every key element is loaded once per CT_TILE uses; products are
+// accumulated as exact 128-bit integers (ncol * q^2 < 2^128, checked by the launcher) and reduced once at the end.
+struct Acc128 { u64 lo, hi; };
+__device__ __forceinline__ void acc_mad(Acc128& a, u64 x, u64 y) {
+  const u64 pl = x * y, ph = d_mulhi(x, y);
+  a.lo += pl;
+  a.hi += ph + (a.lo < pl);
+}
+__device__ __forceinline__ u64 acc_reduce(const Acc128& a, const PrimeConst& pc) {
+  const u64 q = pc.q;
+  const u64 h = d_shoup(a.hi, 1, pc.one_sh, q);              // hi mod q
+  const u64 t = d_shoup_lazy(h, pc.r64, pc.r64_sh, q);       // hi * 2^64 mod q, in [0,2q)
+  const u64 l = d_shoup_lazy(a.lo, 1, pc.one_sh, q);         // lo mod q, in [0,2q)
+  u64 r = t + l;                                              // < 4q
+  if (r >= pc.two_q) r -= pc.two_q;
+  if (r >= q) r -= q;
+  return r;
+}
+template <int CT_TILE>
+__global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ key, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
                                                          u64* __restrict__ out, const PrimeConst* __restrict__ pcs) {
-  const i64 ct = blockIdx.z;
+  const i64 ct0 = (i64)blockIdx.z * CT_TILE;
   const int l = blockIdx.y;
   const PrimeConst pc = pcs[l];
   const i64 rs = (i64)L * n;
   const u64* k0 = key + (i64)l * n;
   const u64* k1 = key + ((i64)ncol * L + l) * n;
-  const u64* dg = dig + (ct * ncol * L + l) * n;
   const i64 n2 = n >> 1;
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (i64)gridDim.x * blockDim.x) {
-    u64x2 acc0 = {0, 0}, acc1 = {0, 0};
+    Acc128 acc[CT_TILE][4];
+#pragma unroll
+    for (int c = 0; c < CT_TILE; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[c][e] = Acc128{0, 0};
     for (int k = 0; k < ncol; ++k) {
-      const u64x2 d = ((const u64x2*)(dg + k * rs))[i];
       const u64x2 a = ((const u64x2*)(k0 + k * rs))[i];
       const u64x2 b = ((const u64x2*)(k1 + k * rs))[i];
-      acc0.x = d_addmod(acc0.x, d_mulmod(a.x, d.x, pc), pc.q);
-      acc0.y = d_addmod(acc0.y, d_mulmod(a.y, d.y, pc), pc.q);
-      acc1.x = d_addmod(acc1.x, d_mulmod(b.x, d.x, pc), pc.q);
-      acc1.y = d_addmod(acc1.y, d_mulmod(b.y, d.y, pc), pc.q);
+#pragma unroll
+      for (int c = 0; c < CT_TILE; ++c) {
+        if (ct0 + c < count) {
+          const u64x2 d = ((const u64x2*)(dig + ((ct0 + c) * ncol + k) * rs + (i64)l * n))[i];
+          acc_mad(acc[c][0], a.x, d.x);
+          acc_mad(acc[c][1], a.y, d.y);
+          acc_mad(acc[c][2], b.x, d.x);
+          acc_mad(acc[c][3], b.y, d.y);
+        }
+      }
     }
-    ((u64x2*)(out + ((ct * 2 + 0) * L + l) * n))[i] = acc0;
-    ((u64x2*)(out + ((ct * 2 + 1) * L + l) * n))[i] = acc1;
+#pragma unroll
+    for (int c = 0; c < CT_TILE; ++c) {
+      if (ct0 + c < count) {
+        u64x2 r0, r1;
+        r0.x = acc_reduce(acc[c][0], pc);  r0.y = acc_reduce(acc[c][1], pc);
+        r1.x = acc_reduce(acc[c][2], pc);  r1.y = acc_reduce(acc[c][3], pc);
+        ((u64x2*)(out + (((ct0 + c) * 2 + 0) * L + l) * n))[i] = r0;
+        ((u64x2*)(out + (((ct0 + c) * 2 + 1) * L + l) * n))[i] = r1;
+      }
+    }
   }
 }
 
@@ -167,9 +202,16 @@ int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a, const u64* d_b, u64* d_t, i
 int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int ncol, i64 count, u64* d_out) {
   if (!count) return 0;
   if (ctx->phim & 1) FHESI_FAIL("dot_accum: odd phi(m) not supported by the batched pipeline");
+  // exact 128-bit accumulation needs ncol * q^2 < 2^128
+  for (int l = 0; l < ctx->L; ++l) {
+    const int k = (int)ctx->pc[l].bar_k;
+    int lg = 0; while ((1 << lg) < ncol) ++lg;
+    if (2 * k + lg > 128) FHESI_FAIL("dot_accum: %d columns of %d-bit residues overflow the 128-bit accumulator", ncol, k);
+  }
   ProfScope prof(ctx, PROF_DOT, (double)count);
-  dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ctx->L, (unsigned)count);
-  dot_accum_kernel<<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, d_out, ctx->d_pc);
+  constexpr int CT_TILE = 4;
+  dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ctx->L, (unsigned)((count + CT_TILE - 1) / CT_TILE));
+  dot_accum_kernel<CT_TILE><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc);
   HIP_TRY(hipGetLastError());
   return 0;
 }
