@@ -13,7 +13,7 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_DIR, "csrc")
-_SO = os.path.join(_CSRC, "libfhesi_hip.so")
+_SO = os.environ.get("FHESI_LIB") or os.path.join(_CSRC, "libfhesi_hip.so")     # FHESI_LIB: dev override (ablation builds)
 
 OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SET = 0, 1, 2, 3, 4
 

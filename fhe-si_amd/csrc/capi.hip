@@ -65,6 +65,10 @@ static void build_tile_order(const std::vector<Shoup2>& tw, int logn, std::vecto
     for (int x = 0; x < (1 << u); ++x)
       for (int jl = 0; jl < 1024; ++jl) twt[1024 + (i64)((1 << u) - 1 + x) * 1024 + jl] = tw[(1 << (10 + u)) + ((i64)hm::brv(jl, 10) << u) + x];
 }
+// the tile kernels use quotients scaled by 2^63 (modarith63.h)
+static void to_q63(std::vector<Shoup2>& t, u64 q) {
+  for (auto& e : t) e.wp = hm::shoup63(e.w, q);
+}
 
 extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, const uint64_t* q, const uint64_t* root, int32_t device) {
   if (!out) FHESI_FAIL("null output pointer");
@@ -113,6 +117,8 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
     pc.r64 = (u64)(((u128)1 << 64) % Q);
     pc.r64_sh = hm::shoup(pc.r64, Q);
     pc.one_sh = hm::shoup(1, Q);
+    pc.one_q63 = hm::shoup63(1, Q);
+    if (Q < (1ull << 48)) c->has_small_prime = true;
     pc.ninv = pc.ninv_sh = pc.ninv_w = pc.ninv_w_sh = 0;
   }
   if (c->pow2) {
@@ -135,6 +141,8 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
       pc.ninv_sh = hm::shoup(pc.ninv, Q);
       pc.ninv_w = hm::mulmod(pc.ninv, n > 1 ? twi[(size_t)i * n + 1].w : 1, Q);
       pc.ninv_w_sh = hm::shoup(pc.ninv_w, Q);
+      pc.ninv_q63 = hm::shoup63(pc.ninv, Q);
+      pc.ninv_w_q63 = hm::shoup63(pc.ninv_w, Q);
     }
     const size_t tb = twf.size() * sizeof(Shoup2);
     HIP_TRY(hipMalloc(&c->d_tw_fwd, tb));
@@ -146,9 +154,11 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
       for (int i = 0; i < nprimes; ++i) {
         one.assign(twf.begin() + (size_t)i * n, twf.begin() + (size_t)(i + 1) * n);
         build_tile_order(one, lg, tmp);
+        to_q63(tmp, q[i]);
         std::copy(tmp.begin(), tmp.end(), all_f.begin() + (size_t)i * n);
         one.assign(twi.begin() + (size_t)i * n, twi.begin() + (size_t)(i + 1) * n);
         build_tile_order(one, lg, tmp);
+        to_q63(tmp, q[i]);
         std::copy(tmp.begin(), tmp.end(), all_i.begin() + (size_t)i * n);
       }
       HIP_TRY(hipMalloc(&c->d_twt_fwd, tb));

@@ -31,6 +31,8 @@ struct PrimeConst {
   u64 ninv, ninv_sh;        // phi(m)^-1 mod q and its Shoup quotient (power-of-two m: the /m of CModulus.cpp:125 folded with X^n=-1)
   u64 ninv_w, ninv_w_sh;    // ninv * psi^-brv(1) (last inverse stage twiddle folded with the scaling)
   u64 r64, r64_sh;          // 2^64 mod q (Horner step of the big-int -> residue reduction, CModulus.cpp:96 conv)
+  u64 one_q63;              // floor(2^63/q)
+  u64 ninv_q63, ninv_w_q63; // floor(ninv 2^63/q), floor(ninv_w 2^63/q): quotients in the tile kernels' 63-bit convention (modarith63.h)
 };
 
 struct Shoup2 { u64 w, wp; };   // constant multiplier and floor(w*2^64/q)
@@ -61,6 +63,7 @@ struct fhesi_ctx {
   i64 m = 0, phim = 0;
   int L = 0;
   bool pow2 = false;
+  bool has_small_prime = false;        // some chain prime is below the tile kernels' 2^48 bound (ntt_tile.inc)
   int logn = 0;                        // log2(phim) when pow2
   std::vector<u64> q, root;
   std::vector<int> zms_idx;            // PAlgebra::zmsIdx (PAlgebra.cpp:50-52)
@@ -118,6 +121,7 @@ u64 powmod(u64 a, u64 e, u64 q);
 u64 invmod(u64 a, u64 q);              // q prime
 bool is_prime(u64 n);
 u64 shoup(u64 w, u64 q);
+u64 shoup63(u64 w, u64 q);             // floor(w 2^63 / q)
 u64 brv(u64 x, int bits);
 int ilog2_ceil(i64 n);
 std::vector<int> zms_idx(i64 m, i64* phim);

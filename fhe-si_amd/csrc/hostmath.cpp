@@ -53,6 +53,7 @@ bool is_prime(u64 n) {
 }
 
 u64 shoup(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+u64 shoup63(u64 w, u64 q) { return (u64)(((u128)w << 63) / q); }
 
 u64 brv(u64 x, int bits) {
   u64 r = 0;

@@ -46,7 +46,7 @@ __device__ __forceinline__ u64 norm2(u64 v, u64 q) { return v >= q ? v - q : v; 
 // selects the twiddles of the remaining stages (twiddle index = mm_local * tw_mul + i_local).
 template <bool BITREV>
 __global__ void __launch_bounds__(1024) ntt_fwd_lds(u64* __restrict__ rows, int logn, int logb, int nslots, const int* __restrict__ prime_of_slot,
-                                                     const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ tw_all) {
+                                                     const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ tw_all, u64 skip_q) {
   extern __shared__ __attribute__((aligned(16))) u64 s[];
   const int nb = 1 << logb, T = blockDim.x, tid = threadIdx.x;
   const int sub_per_row = 1 << (logn - logb);
@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(1024) ntt_fwd_lds(u64* __restrict__ rows, int 
   const int slot = (int)(row % nslots);
   const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
   const PrimeConst pc = pcs[prime];
+  if (skip_q && pc.q >= skip_q) return;       // this row belongs to the tile kernel
   const u64 q = pc.q, two_q = pc.two_q;
   const Shoup2* tw = tw_all + ((i64)prime << logn);
   u64* g = rows + (row << logn) + ((i64)sb << logb);
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(1024) ntt_fwd_lds(u64* __restrict__ rows, int 
 
 template <bool BITREV>
 __global__ void __launch_bounds__(1024) ntt_inv_lds(u64* __restrict__ rows, int logn, int logb, int nslots, const int* __restrict__ prime_of_slot,
-                                                     const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ tw_all) {
+                                                     const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ tw_all, u64 skip_q) {
   extern __shared__ __attribute__((aligned(16))) u64 s[];
   const int nb = 1 << logb, T = blockDim.x, tid = threadIdx.x;
   const int sub_per_row = 1 << (logn - logb);
@@ -94,6 +95,7 @@ __global__ void __launch_bounds__(1024) ntt_inv_lds(u64* __restrict__ rows, int 
   const int slot = (int)(row % nslots);
   const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
   const PrimeConst pc = pcs[prime];
+  if (skip_q && pc.q >= skip_q) return;       // this row belongs to the tile kernel
   const u64 q = pc.q, two_q = pc.two_q;
   const Shoup2* tw = tw_all + ((i64)prime << logn);
   u64* g = rows + (row << logn) + ((i64)sb << logb);
@@ -191,7 +193,12 @@ int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   const i64 nrows = count * nslots;
   if (nrows == 0) return 0;
   ProfScope prof(ctx, PROF_NTT_FWD, (double)nrows);
-  if (bitrev && ntt_tile_supported(logn)) return launch_ntt_fwd_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
+  u64 skip_q = 0;
+  if (bitrev && ntt_tile_supported(logn)) {
+    FHESI_TRY(launch_ntt_fwd_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot));
+    if (!ctx->has_small_prime) return 0;
+    skip_q = NTT_TILE_MIN_Q;      // the tile kernel skipped the rows of small primes: the generic kernel takes exactly those
+  }
   const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
   for (int st = 0; st < logn - logb; ++st) {
     i64 total = nrows << (logn - 1);
@@ -201,10 +208,10 @@ int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   const unsigned grid = (unsigned)(nrows << (logn - logb));
   if (bitrev && logb == logn) {
     HIP_TRY(hipFuncSetAttribute((const void*)ntt_fwd_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    ntt_fwd_lds<true><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_fwd);
+    ntt_fwd_lds<true><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_fwd, skip_q);
   } else {
     HIP_TRY(hipFuncSetAttribute((const void*)ntt_fwd_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    ntt_fwd_lds<false><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_fwd);
+    ntt_fwd_lds<false><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_fwd, skip_q);
     if (bitrev) {
       void* tmp;
       FHESI_TRY(ws_reserve(ctx, 6, (size_t)nrows << (logn + 3), &tmp));
@@ -222,13 +229,18 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   const i64 nrows = count * nslots;
   if (nrows == 0) return 0;
   ProfScope prof(ctx, PROF_NTT_INV, (double)nrows);
-  if (bitrev && ntt_tile_supported(logn)) return launch_ntt_inv_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
+  u64 skip_q = 0;
+  if (bitrev && ntt_tile_supported(logn)) {
+    FHESI_TRY(launch_ntt_inv_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot));
+    if (!ctx->has_small_prime) return 0;
+    skip_q = NTT_TILE_MIN_Q;
+  }
   const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
   const size_t shmem = sizeof(u64) << logb;
   const unsigned grid = (unsigned)(nrows << (logn - logb));
   if (bitrev && logb == logn) {
     HIP_TRY(hipFuncSetAttribute((const void*)ntt_inv_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    ntt_inv_lds<true><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_inv);
+    ntt_inv_lds<true><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_inv, skip_q);
   } else {
     if (bitrev) {
       void* tmp;
@@ -238,7 +250,7 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
       HIP_TRY(hipMemcpyAsync(d_rows, tmp, (size_t)total * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     HIP_TRY(hipFuncSetAttribute((const void*)ntt_inv_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    ntt_inv_lds<false><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_inv);
+    ntt_inv_lds<false><<<grid, lds_threads(logb), shmem, ctx->stream>>>(d_rows, logn, logb, nslots, d_prime_of_slot, ctx->d_pc, ctx->d_tw_inv, skip_q);
   }
   for (int st = logn - logb - 1; st >= 0; --st) {
     i64 total = nrows << (logn - 1);
@@ -258,9 +270,18 @@ int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, 
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * ctx->L));
   const DigitSrc ds{d_parts, nl, digit_bits, nd};
   switch (ctx->logn) {
-    case 11: return launch_tile_digits<11>(ctx, ds, npolys * nd, d_out_rows);
-    case 12: return launch_tile_digits<12>(ctx, ds, npolys * nd, d_out_rows);
-    case 13: return launch_tile_digits<13>(ctx, ds, npolys * nd, d_out_rows);
-    default: return launch_tile_digits<14>(ctx, ds, npolys * nd, d_out_rows);
+    case 11: FHESI_TRY(launch_tile_digits<11>(ctx, ds, npolys * nd, d_out_rows)); break;
+    case 12: FHESI_TRY(launch_tile_digits<12>(ctx, ds, npolys * nd, d_out_rows)); break;
+    case 13: FHESI_TRY(launch_tile_digits<13>(ctx, ds, npolys * nd, d_out_rows)); break;
+    default: FHESI_TRY(launch_tile_digits<14>(ctx, ds, npolys * nd, d_out_rows)); break;
   }
+  if (ctx->has_small_prime) {     // the tile kernel stored the digit residues of small-prime rows untransformed
+    const int logn = ctx->logn;
+    const size_t shmem = sizeof(u64) << logn;
+    HIP_TRY(hipFuncSetAttribute((const void*)ntt_fwd_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    ntt_fwd_lds<true><<<(unsigned)(npolys * nd * ctx->L), lds_threads(logn), shmem, ctx->stream>>>(d_out_rows, logn, logn, ctx->L, nullptr, ctx->d_pc, ctx->d_tw_fwd,
+                                                                                                 NTT_TILE_MIN_Q);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
 }

@@ -1,0 +1,108 @@
+// modarith63.h -- the butterfly arithmetic of the tuned NTT kernels (gfx950 VALU, no MFMA).
+//
+// Multiplication by a constant w modulo q < 2^60 uses a Shoup quotient scaled by 2^63 instead of 2^64:
+//   wq = floor(w * 2^63 / q) < 2^63,   Q = floor(y * wq / 2^63),   T = y*w - Q*q  in [0, q + y*q/2^63)
+// so for y < 2^63 - 2^33 the result is below 2q.  With y1 < 2^31 and wq1 < 2^31 the middle sum
+//   y1*wq0 + y0*wq1 + hi32(y0*wq0)
+// cannot overflow 64 bits, which makes the whole quotient one carry-free chain of v_mad_u64_u32, and the exact floor is
+//   Q = 2*y1*wq1 + (middle >> 31).
+// The remainder is accumulated as y*w + Q*(-q) mod 2^64 (cross terms through a second carry-free chain whose low word is
+// added to the high word), so there is no 64-bit subtraction and no carry pair anywhere.
+// Lazy ranges: forward values stay below 4q + 2^32, inverse values below 2q + 2^47 (q < 2^60): the range correction only
+// compares HIGH words against (2q)>>32 -- v >= 2q + 2^32 is always corrected, v < 2q never -- one v_cmp + two v_cndmask.
+//
+// hipcc rewrites such chains into v_mul_hi + zero-extension moves and pads every one-instruction asm with a wait
+// state, so the hot butterflies are emitted as ONE asm block per PAIR of butterflies (two interleaved dependency chains)
+// using fixed scratch VGPRs (clobbered), which gives access to register halves: 24 instructions / ~40 issue slots per
+// forward butterfly instead of hipcc's 39 / ~60.  Hazards inside the block: the only VCC producer (v_cmp) is always
+// followed by >= 2 unrelated VALU instructions before the v_cndmask that reads it; the carry-outs of v_mad_u64_u32 go to
+// a dummy SGPR pair that nothing reads.
+#pragma once
+#include "fhesi_internal.h"
+
+struct Tw63 { u32 w0, w1, p0, p1; };     // w = w1:w0,  floor(w 2^63 / q) = p1:p0   (same 16 bytes as Shoup2)
+struct Mod63 {
+  u32 nq0, nq1;        // -q mod 2^64
+  u32 twoq_hi;         // (2q) >> 32
+  u32 m2q_lo, m2q_hi;  // -2q mod 2^64
+  u64 twoq1;           // 2q + 1   (x - T = x + ~T + 1)
+  u64 threeq1;         // 3q + 1
+  u64 q, twoq;
+};
+
+__device__ __forceinline__ Mod63 make_mod63(u64 q) {
+  Mod63 m;
+  const u64 nq = 0 - q, m2q = 0 - 2 * q;
+  m.nq0 = (u32)nq; m.nq1 = (u32)(nq >> 32);
+  m.twoq_hi = (u32)((2 * q) >> 32);
+  m.m2q_lo = (u32)m2q; m.m2q_hi = (u32)(m2q >> 32);
+  m.twoq1 = 2 * q + 1; m.threeq1 = 3 * q + 1;
+  m.q = q; m.twoq = 2 * q;
+  return m;
+}
+
+// ---- plain C++ version (compiler-scheduled): used outside the hot loops (last inverse stage, tests of the asm)
+__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+__device__ __forceinline__ u64 mulmod63(u64 y, const Tw63& t, const Mod63& m) {
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+  u64 M = (u64)__umulhi(y0, t.p0);
+  M = mad32(y1, t.p0, M);
+  M = mad32(y0, t.p1, M);
+  const u64 Q = mad32(y1 << 1, t.p1, M >> 31);
+  const u32 q0 = (u32)Q, q1 = (u32)(Q >> 32);
+  u64 R = mad32(y0, t.w0, 0);
+  R = mad32(q0, m.nq0, R);
+  const u32 hi = (u32)(R >> 32) + y0 * t.w1 + y1 * t.w0 + q0 * m.nq1 + q1 * m.nq0;
+  return (R & 0xffffffffull) | ((u64)hi << 32);
+}
+
+// ---- asm butterflies.  Scratch register sets (clobbered): A = v[104:115], B = v[116:127].
+//  +0,+1 : M / Q      +2,+3 : C (cross terms)     +4,+5 : R = T      +6,+7 : D (inverse) / 2*y1      +8,+9 : sel, xc
+#define FHESI_STR2(x) #x
+#define FHESI_STR(x) FHESI_STR2(x)
+#define VR_(n) "v" FHESI_STR(n)
+#define VP_(a, b) "v[" FHESI_STR(a) ":" FHESI_STR(b) "]"
+
+// quotient + remainder of (y1:y0) * w, result T in v[b+4 : b+5]; y0,y1,w0,w1,p0,p1 are operand strings
+#define MULMOD63_ASM(b0, b1, b2, b3, b4, b5, b6, Y0, Y1, W0, W1, P0, P1)                      \
+  "v_mul_hi_u32 " VR_(b0) ", " Y0 ", " P0 "\n\t"                                               \
+  "v_mov_b32 " VR_(b1) ", 0\n\t"                                                               \
+  "v_mad_u64_u32 " VP_(b0, b1) ", %[cy], " Y1 ", " P0 ", " VP_(b0, b1) "\n\t"                  \
+  "v_mad_u64_u32 " VP_(b2, b3) ", %[cy], " Y0 ", " W1 ", 0\n\t"                                \
+  "v_mad_u64_u32 " VP_(b0, b1) ", %[cy], " Y0 ", " P1 ", " VP_(b0, b1) "\n\t"                  \
+  "v_lshlrev_b32 " VR_(b6) ", 1, " Y1 "\n\t"                                                   \
+  "v_mad_u64_u32 " VP_(b2, b3) ", %[cy], " Y1 ", " W0 ", " VP_(b2, b3) "\n\t"                  \
+  "v_lshrrev_b64 " VP_(b0, b1) ", 31, " VP_(b0, b1) "\n\t"                                     \
+  "v_mad_u64_u32 " VP_(b4, b5) ", %[cy], " Y0 ", " W0 ", 0\n\t"                                \
+  "v_mad_u64_u32 " VP_(b0, b1) ", %[cy], " VR_(b6) ", " P1 ", " VP_(b0, b1) "\n\t"             \
+  "v_mad_u64_u32 " VP_(b2, b3) ", %[cy], " VR_(b0) ", %[nq1], " VP_(b2, b3) "\n\t"             \
+  "v_mad_u64_u32 " VP_(b4, b5) ", %[cy], " VR_(b0) ", %[nq0], " VP_(b4, b5) "\n\t"             \
+  "v_mad_u64_u32 " VP_(b2, b3) ", %[cy], " VR_(b1) ", %[nq0], " VP_(b2, b3) "\n\t"             \
+  "v_add_u32 " VR_(b5) ", " VR_(b5) ", " VR_(b2) "\n\t"
+
+#define BFLY_FWD_NAME bfly_fwd63_x2
+#define BFLY_INV_NAME bfly_inv63_x2
+#define BFLY_TWC "v"
+#include "bfly63_body.inc"
+#undef BFLY_FWD_NAME
+#undef BFLY_INV_NAME
+#undef BFLY_TWC
+// wave-uniform twiddles held in SGPRs (phase A / A' of the tile kernels: the twiddle depends only on the register index)
+#define BFLY_FWD_NAME bfly_fwd63_x2_s
+#define BFLY_INV_NAME bfly_inv63_x2_s
+#define BFLY_TWC "s"
+#include "bfly63_body.inc"
+#undef BFLY_FWD_NAME
+#undef BFLY_INV_NAME
+#undef BFLY_TWC
+
+// exact normalisations on store
+__device__ __forceinline__ u64 norm_fwd63(u64 v, const Mod63& m) {   // v < 4q + 2^32  ->  [0,q)
+  if (v >= m.twoq) v -= m.twoq;
+  if (v >= m.q) v -= m.q;
+  if (v >= m.q) v -= m.q;
+  return v;
+}
+__device__ __forceinline__ u64 norm_inv63(u64 v, const Mod63& m) {   // v < 2q  ->  [0,q)   (outputs of mulmod63)
+  return v >= m.q ? v - m.q : v;
+}
