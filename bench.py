@@ -173,10 +173,8 @@ def main():
     if rank == 0:
         ksm_host = rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n)
     if world > 1:
-        stage = torch.empty(ksk.nbytes // 8, dtype=torch.int64, device=f"cuda:{local_rank}")
-        if rank == 0:
-            stage.copy_(torch.from_numpy(ksm_host.view(np.int64).reshape(-1)))
-        dist.broadcast(stage, src=0)
+        from fhe_si_amd import shard
+        stage = shard.broadcast_key_matrix(ksm_host, ksk.nbytes, dist, device=f"cuda:{local_rank}")   # one RCCL broadcast
         torch.cuda.synchronize()
         ctx.dev_copy(ksk.device_ptr, stage.data_ptr(), ksk.nbytes)
         del stage
