@@ -70,10 +70,12 @@ static void to_q63(std::vector<Shoup2>& t, u64 q) {
   for (auto& e : t) e.wp = hm::shoup63(e.w, q);
 }
 
+thread_local bool g_fhesi_internal_ctx = false;   // set by bluestein_init: its convolution context needs sizes up to 4m
+
 extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, const uint64_t* q, const uint64_t* root, int32_t device) {
   if (!out) FHESI_FAIL("null output pointer");
   *out = nullptr;
-  if (m < 2 || m > (1 << 20)) FHESI_FAIL("FHEcontext: m undefined or larger than 2^20");     // FHEContext.cpp:89
+  if (m < 2 || m > (g_fhesi_internal_ctx ? (1 << 23) : (1 << 20))) FHESI_FAIL("FHEcontext: m undefined or larger than 2^20");     // FHEContext.cpp:89
   if (nprimes < 1 || nprimes > 64) FHESI_FAIL("FHEcontext: number of primes %d outside [1,64]", nprimes);
   for (int i = 0; i < nprimes; ++i) {
     // FHEContext.cpp:31-34: assert( ProbPrime(p) && p % twoM == 1 && !inChain(p) )

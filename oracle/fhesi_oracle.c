@@ -110,7 +110,8 @@ static int mobius_i(i64 n) { int mu = 1; for (i64 p = 2; p * p <= n; p++) if (n 
 /* Cyclotomic (NumbTh.cpp:142-158): prod over d|m of (X^{m/d}-1)^{mu(d)}; small integer coefficients for the
  * m handled here (i64 suffices; checked against the Python restatement in tests). */
 static i64* cyclotomic(i64 m, i64 phim) {
-  i64* num = calloc(m + 2, 8); i64* den = calloc(m + 2, 8); i64 dn = 0, dd = 0; num[0] = 1; den[0] = 1;
+  /* numerator / denominator degrees are sums of m/d over the divisors with mu(d) = +-1: bounded by sigma(m) < m (1 + ln m) */
+  i64* num = calloc(32 * m + 2, 8); i64* den = calloc(32 * m + 2, 8); i64 dn = 0, dd = 0; num[0] = 1; den[0] = 1;
   for (i64 d = 1; d <= m; d++) if (m % d == 0) {
     int mu = mobius_i(d); if (!mu) continue; i64 e = m / d;
     i64* t = mu == 1 ? num : den; i64* dg = mu == 1 ? &dn : &dd;
