@@ -1,0 +1,524 @@
+// fhesi_host.h -- C++ mirror of the reference's class surface for the DoubleCRT path, with every body bound to the
+// C ABI of include/fhesi_hip.h (the HIP library).  Same class and method names, argument meaning and error behaviour
+// (NTL-style Error(msg) -> abort) as the reference so that code written against
+//   PAlgebra (PAlgebra.h:53-88), IndexSet (IndexSet.h:26-127), Cmodulus (CModulus.h:42-170), FHEcontext (FHEContext.h:40-205),
+//   DoubleCRT (DoubleCRT.h:83-365), CiphertextPart / Ciphertext (Ciphertext.h:10-97), FHESISecKey / FHESIPubKey /
+//   KeySwitchSI (FHE-SI.h), Reduce / ReduceCoefficients / DotProduct (Util.h)
+// reads the same.  NTL is not available here, so ZZ / ZZX come from zz.h and randomness from a documented SplitMix64
+// stream (NTL's SetSeed/RandomBnd and lrand48 streams are not reproducible anyway).
+// Rows live in HBM behind fhesi_dcrt handles; getMap()-style access materialises them on demand.
+#pragma once
+#include <cassert>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <set>
+#include <vector>
+
+#include "../../include/fhesi_hip.h"
+#include "zz.h"
+
+namespace fhesi {
+
+typedef std::vector<long> vec_long;
+
+inline void ck(int rc) { if (rc) Error(fhesi_last_error()); }
+
+// ---------------------------------------------------------------- PRNG (replaces srand48 / SetSeed / RandomBnd / lrand48)
+class SplitMix64 {
+  uint64_t s;
+ public:
+  explicit SplitMix64(uint64_t seed = 0) : s(seed) {}
+  void seed(uint64_t v) { s = v; }
+  uint64_t next() { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+  ZZ bits(long nbits) { ZZ r; long words = (nbits + 63) / 64; r.mag.resize(words); for (long i = 0; i < words; ++i) r.mag[i] = next(); if (nbits % 64) r.mag[words - 1] &= (1ull << (nbits % 64)) - 1; r.trim(); return r; }
+  ZZ bnd(const ZZ& n) { if (n <= ZZ(1L)) return ZZ(); long k = (n - ZZ(1L)).bits(); for (;;) { ZZ v = bits(k); if (v < n) return v; } }
+  long bnd(long n) { return bnd(ZZ(n)).to_long(); }
+};
+inline SplitMix64& global_rng() { static SplitMix64 g(0); return g; }
+inline void SetSeed(uint64_t seed) { global_rng().seed(seed); }
+inline ZZ RandomBnd(const ZZ& n) { return global_rng().bnd(n); }
+inline long RandomBnd(long n) { return global_rng().bnd(n); }
+
+// ---------------------------------------------------------------- number theory (NumbTh.cpp)
+inline uint64_t MulMod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((unsigned __int128)a * b) % q); }
+inline uint64_t PowerMod(uint64_t a, uint64_t e, uint64_t q) { uint64_t r = 1 % q; a %= q; for (; e; e >>= 1) { if (e & 1) r = MulMod(r, a, q); a = MulMod(a, a, q); } return r; }
+inline bool ProbPrime(uint64_t n) {
+  static const uint64_t b[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+  if (n < 2) return false;
+  for (uint64_t p : b) if (n % p == 0) return n == p;
+  uint64_t d = n - 1; int s = 0; while (!(d & 1)) { d >>= 1; ++s; }
+  for (uint64_t a : b) { uint64_t x = PowerMod(a, d, n); if (x == 1 || x == n - 1) continue; bool comp = true; for (int r = 1; r < s && comp; ++r) { x = MulMod(x, x, n); if (x == n - 1) comp = false; } if (comp) return false; }
+  return true;
+}
+// FindPrimitiveRoot (NumbTh.cpp:85-118): the reference tries random bases; this mirror takes the smallest base that
+// passes the same order test so that row values are reproducible.
+inline long FindPrimitiveRoot(long q, unsigned long e) {
+  if ((q - 1) % e) return 0;
+  std::vector<unsigned long> facts; unsigned long t = e;
+  for (unsigned long f = 2; f * f <= t; ++f) if (t % f == 0) { facts.push_back(f); while (t % f == 0) t /= f; }
+  if (t > 1) facts.push_back(t);
+  for (uint64_t s = 2; s < 1000; ++s) {
+    uint64_t r = PowerMod(s, (q - 1) / e, q);
+    if (PowerMod(r, e, q) != 1) continue;
+    bool ok = true; for (unsigned long f : facts) if (PowerMod(r, e / f, q) == 1) ok = false;
+    if (ok) return (long)r;
+  }
+  Error("FindPrimitiveRoot(): gave up after 1000 trials");
+}
+
+// ---------------------------------------------------------------- IndexSet (IndexSet.h:26-127), ordered set of prime indices
+class IndexSet {
+  std::set<long> s;
+ public:
+  IndexSet() {}
+  IndexSet(long lo, long hi) { for (long i = lo; i <= hi; ++i) s.insert(i); }
+  explicit IndexSet(long j) { s.insert(j); }
+  static const IndexSet& emptySet() { static IndexSet e; return e; }
+  long first() const { return s.empty() ? 0 : *s.begin(); }
+  long last() const { return s.empty() ? -1 : *s.rbegin(); }
+  long next(long j) const { auto it = s.upper_bound(j); return it == s.end() ? last() + 1 : *it; }
+  long card() const { return (long)s.size(); }
+  bool contains(long j) const { return s.count(j) != 0; }
+  void insert(long j) { s.insert(j); }
+  void insert(const IndexSet& o) { s.insert(o.s.begin(), o.s.end()); }
+  void remove(long j) { s.erase(j); }
+  void remove(const IndexSet& o) { for (long j : o.s) s.erase(j); }
+  void clear() { s.clear(); }
+  bool operator==(const IndexSet& o) const { return s == o.s; }
+  bool operator!=(const IndexSet& o) const { return s != o.s; }
+  bool contains(const IndexSet& o) const { for (long j : o.s) if (!s.count(j)) return false; return true; }
+  std::vector<int32_t> vec() const { return std::vector<int32_t>(s.begin(), s.end()); }
+  friend IndexSet operator|(const IndexSet& a, const IndexSet& b) { IndexSet r = a; r.insert(b); return r; }
+  friend IndexSet operator&(const IndexSet& a, const IndexSet& b) { IndexSet r; for (long j : a.s) if (b.s.count(j)) r.s.insert(j); return r; }
+  friend IndexSet operator/(const IndexSet& a, const IndexSet& b) { IndexSet r; for (long j : a.s) if (!b.s.count(j)) r.s.insert(j); return r; }   // set minus
+  friend bool operator>=(const IndexSet& a, const IndexSet& b) { return a.contains(b); }
+  friend bool operator>(const IndexSet& a, const IndexSet& b) { return a.contains(b) && a != b; }
+};
+inline long card(const IndexSet& s) { return s.card(); }
+inline bool disjoint(const IndexSet& a, const IndexSet& b) { return (a & b).card() == 0; }
+
+// ---------------------------------------------------------------- PAlgebra (PAlgebra.h:53-88)
+class PAlgebra {
+  unsigned m = 0, g = 0, phim = 0;
+  ZZX Phi_mX;
+  std::vector<long> zmsIdx;
+ public:
+  void init(unsigned mm, unsigned gg, const std::vector<int32_t>& idx, const std::vector<int64_t>& phi) {
+    m = mm; g = gg; zmsIdx.assign(idx.begin(), idx.end()); phim = 0;
+    for (long v : zmsIdx) if (v >= 0) ++phim;
+    Phi_mX.rep.clear(); for (int64_t c : phi) Phi_mX.rep.push_back(ZZ((long)c)); Phi_mX.normalize();
+  }
+  unsigned M() const { return m; }
+  unsigned G() const { return g; }
+  unsigned phiM() const { return phim; }
+  const ZZX& PhimX() const { return Phi_mX; }
+  int indexInZmstar(unsigned t) const { return (t > 0 && t < m) ? (int)zmsIdx[t] : -1; }
+  bool inZmStar(unsigned t) const { return t > 0 && t < m && zmsIdx[t] > -1; }
+};
+
+class FHEcontext;
+
+// ---------------------------------------------------------------- Cmodulus (CModulus.h:42-170)
+class Cmodulus {
+  const FHEcontext* ctx;
+  long q, root;
+  int index;
+ public:
+  Cmodulus(const FHEcontext* c, long qq, long rt, int idx) : ctx(c), q(qq), root(rt), index(idx) {}
+  const long& getQ() const { return q; }
+  const long& getRoot() const { return root; }
+  void FFT(vec_long& y, const ZZX& x) const;    // y = FFT(x)       (CModulus.cpp:90-107)
+  void iFFT(ZZX& x, const vec_long& y) const;   // x = FFT^{-1}(y)  (CModulus.cpp:110-132)
+};
+
+// ---------------------------------------------------------------- FHEcontext (FHEContext.h:40-205, FHEContext.cpp)
+class FHEcontext {
+  std::vector<Cmodulus> moduli;
+  mutable fhesi_ctx* dev = nullptr;
+  ZZ ptxtP;
+  unsigned generator = 0;
+  int device;
+ public:
+  PAlgebra zMstar;
+  IndexSet ctxtPrimes, specialPrimes;
+  double stdev = 3.2;
+  ZZ modulusQ;
+  unsigned logQ = 0, decompSize = 3, ndigits = 0;
+
+  FHEcontext(unsigned m, unsigned logQ_, unsigned p, unsigned gen, unsigned decomp = 3, int device_ = 0) : device(device_) { Init(m, logQ_, ZZ((long)p), gen, decomp); }
+  ~FHEcontext() { if (dev) fhesi_ctx_destroy(dev); }
+  FHEcontext(const FHEcontext&) = delete;
+  void Init(unsigned m, unsigned logQ_, const ZZ& p, unsigned gen, unsigned decomp = 3) {   // FHEContext.h:105-118
+    m_ = m; logQ = logQ_; modulusQ = ZZ(1L) << (long)logQ_; decompSize = decomp;
+    ndigits = (logQ_ + 8 * decomp - 1) / (8 * decomp);
+    ptxtP = p; generator = gen;
+    // PAlgebra tables: phi(m) and zmsIdx are needed before any prime exists (SetUpSIContext sizes the chain with phi(m))
+    std::vector<int32_t> idx(m, -1); int k = 0;
+    for (unsigned i = 0; i < m; ++i) { unsigned a = i, b = m; while (b) { unsigned t2 = a % b; a = b; b = t2; } if (a == 1) idx[i] = k++; }
+    zMstar.init(m, gen, idx, std::vector<int64_t>());
+  }
+  unsigned Generator() const { return generator; }
+  const ZZ& ModulusP() const { return ptxtP; }
+  long ithPrime(unsigned i) const { return i < moduli.size() ? moduli[i].getQ() : 0; }
+  const Cmodulus& ithModulus(unsigned i) const { return moduli[i]; }
+  long numPrimes() const { return (long)moduli.size(); }
+  bool inChain(long p) const { for (auto& c : moduli) if (c.getQ() == p) return true; return false; }
+  ZZ productOfPrimes(const IndexSet& s) const { ZZ p(1L); for (long i = s.first(); i <= s.last(); i = s.next(i)) p *= ZZ(ithPrime(i)); return p; }
+  ZZ productOfPrimes() const { return productOfPrimes(ctxtPrimes); }
+
+  void AddPrime(long p, bool special, long root = 0) {   // FHEContext.cpp:30-43
+    if (dev) Error("FHEcontext::AddPrime: the chain is already bound to the device");
+    long twoM = 2 * (long)zMstar.M();
+    if (!(ProbPrime(p) && p % twoM == 1 && !inChain(p))) Error("FHEcontext::AddPrime: assertion ProbPrime(p) && p % twoM == 1 && !inChain(p) failed");
+    if (!root) root = FindPrimitiveRoot(p, (unsigned long)twoM);       // CModulus.cpp:69-76
+    long i = (long)moduli.size();
+    moduli.push_back(Cmodulus(this, p, root, (int)i));
+    if (special) specialPrimes.insert(i); else ctxtPrimes.insert(i);
+  }
+  void SetUpSIContext(long xi = 1) {   // FHEContext.cpp:83-85
+    AddPrimesBySize(log(modulusQ) * 2 + log(ModulusP()) + std::log((double)zMstar.phiM()) * 2 + std::log(2.0) + std::log((double)xi), false);
+  }
+  double AddPrimesBySize(double totalSize, bool special, int sp_nbits = 60) {   // FHEContext.cpp:88-115
+    if (!zMstar.M() || zMstar.M() > (1u << 20)) Error("AddModuli1: m undefined or larger than 2^20");
+    long p = (long)((1ull << sp_nbits) - 1), twoM = 2 * (long)zMstar.M();
+    p -= p % twoM; p += twoM + 1;
+    bool lastPrime = false; double sizeLeft = totalSize;
+    while (sizeLeft > 0.0) {
+      if (sizeLeft < std::log((double)p) && !lastPrime) { lastPrime = true; p = (long)std::ceil(std::exp(sizeLeft)); p -= (p % twoM) - 1; twoM = -twoM; }
+      do { p -= twoM; } while (!ProbPrime(p));
+      if (!inChain(p)) { AddPrime(p, special); sizeLeft -= std::log((double)p); }
+    }
+    return totalSize - sizeLeft;
+  }
+  // the device context is created on first use, from the finished chain
+  fhesi_ctx* handle() const {
+    if (!dev) {
+      std::vector<uint64_t> q, r;
+      for (auto& c : moduli) { q.push_back((uint64_t)c.getQ()); r.push_back((uint64_t)c.getRoot()); }
+      if (q.empty()) Error("FHEcontext: no primes in the chain");
+      ck(fhesi_ctx_create(&dev, m_, (int32_t)q.size(), q.data(), r.data(), device));
+      std::vector<int32_t> idx(m_); std::vector<int64_t> phi(fhesi_ctx_phim(dev) + 1);
+      ck(fhesi_ctx_zms_idx(dev, idx.data())); ck(fhesi_ctx_phi_m(dev, phi.data()));
+      const_cast<PAlgebra&>(zMstar).init(m_, generator, idx, phi);
+    }
+    return dev;
+  }
+ private:
+  unsigned m_ = 0;
+};
+extern FHEcontext* activeContext;   // FHEContext.cpp:21
+
+// ---------------------------------------------------------------- ZZX <-> limb buffers
+inline int limbs_for(const ZZX& p) { long b = 1; for (auto& c : p.rep) b = std::max(b, c.bits() + 1); return (int)((b + 63) / 64); }
+inline std::vector<uint64_t> to_limbs(const ZZX& p, int nl) { std::vector<uint64_t> v(std::max<size_t>(1, p.rep.size()) * nl, 0); for (size_t i = 0; i < p.rep.size(); ++i) p.rep[i].to_limbs(&v[i * nl], nl); return v; }
+inline ZZX from_limbs(const std::vector<uint64_t>& v, long n, int nl) { ZZX p; p.rep.resize(n); for (long i = 0; i < n; ++i) p.rep[i] = ZZ::from_limbs(&v[i * nl], nl); p.normalize(); return p; }
+
+inline void Cmodulus::FFT(vec_long& y, const ZZX& x) const {
+  fhesi_ctx* h = ctx->handle(); long n = fhesi_ctx_phim(h);
+  int nl = limbs_for(x); std::vector<uint64_t> lim = to_limbs(x, nl), out(n);
+  ck(fhesi_cmod_fft(h, index, lim.data(), nl, (int64_t)x.rep.size(), out.data()));
+  y.assign(out.begin(), out.end());
+}
+inline void Cmodulus::iFFT(ZZX& x, const vec_long& y) const {
+  fhesi_ctx* h = ctx->handle(); long n = fhesi_ctx_phim(h);
+  if ((long)y.size() != n) Error("Cmodulus::iFFT: bad row length");
+  std::vector<uint64_t> in(y.begin(), y.end()), out(n);
+  ck(fhesi_cmod_ifft(h, index, in.data(), out.data()));
+  x.rep.assign(n, ZZ()); for (long i = 0; i < n; ++i) x.rep[i] = ZZ((unsigned long)out[i]); x.normalize();
+}
+
+// ---------------------------------------------------------------- DoubleCRT (DoubleCRT.h:83-365, DoubleCRT.cpp)
+enum { OP_ADD = FHESI_OP_ADD, OP_SUB = FHESI_OP_SUB, OP_MUL = FHESI_OP_MUL, OP_DIV = FHESI_OP_DIV, OP_SET = FHESI_OP_SET };
+class DoubleCRT {
+  const FHEcontext& context;
+  fhesi_dcrt* h = nullptr;
+  void alloc(const IndexSet& s) { auto v = s.vec(); if (v.empty()) Error("DoubleCRT: empty index set"); ck(fhesi_dcrt_alloc(context.handle(), v.data(), (int32_t)v.size(), &h)); }
+  DoubleCRT& Op(const DoubleCRT& other, int op, bool matchIndexSets = true) {   // DoubleCRT.cpp:79-113
+    if (&context != &other.context) Error("DoubleCRT::Op: incompatible objects");
+    if (matchIndexSets && !(getIndexSet() >= other.getIndexSet())) addPrimes(other.getIndexSet() / getIndexSet());
+    if (getIndexSet() > other.getIndexSet()) { DoubleCRT tmp(other); tmp.addPrimes(getIndexSet() / other.getIndexSet()); ck(fhesi_dcrt_op(h, tmp.h, op)); }
+    else if (getIndexSet() == other.getIndexSet()) ck(fhesi_dcrt_op(h, other.h, op));
+    else { DoubleCRT tmp(other); tmp.removePrimes(other.getIndexSet() / getIndexSet()); ck(fhesi_dcrt_op(h, tmp.h, op)); }   // !matchIndexSets: this object's set rules
+    return *this;
+  }
+  DoubleCRT& Op(const ZZ& num, int op) { int nl = (int)(num.bits() / 64 + 2); std::vector<uint64_t> v(nl); num.to_limbs(v.data(), nl); ck(fhesi_dcrt_op_scalar(h, v.data(), nl, op)); return *this; }   // :115-129
+  DoubleCRT& Op(const ZZX& poly, int op) { DoubleCRT other(poly, context, getIndexSet()); return Op(other, op); }   // :131-137
+ public:
+  DoubleCRT(const DoubleCRT& o) : context(o.context) { alloc(o.getIndexSet()); ck(fhesi_dcrt_copy(h, o.h)); }
+  DoubleCRT(const ZZX& poly, const FHEcontext& c, const IndexSet& s) : context(c) { alloc(s); *this = poly; }
+  DoubleCRT(const ZZX& poly, const FHEcontext& c) : context(c) { alloc(c.ctxtPrimes); *this = poly; }
+  explicit DoubleCRT(const ZZX& poly) : context(*activeContext) { alloc(context.ctxtPrimes); *this = poly; }
+  DoubleCRT(const FHEcontext& c, const IndexSet& s) : context(c) { alloc(s); }
+  explicit DoubleCRT(const FHEcontext& c) : context(c) { alloc(c.ctxtPrimes); }
+  DoubleCRT() : context(*activeContext) { alloc(context.ctxtPrimes); }
+  ~DoubleCRT() { if (h) fhesi_dcrt_free(h); }
+
+  DoubleCRT& operator=(const DoubleCRT& o) { if (&context != &o.context) Error("DoubleCRT assigment: incompatible contexts"); ck(fhesi_dcrt_copy(h, o.h)); return *this; }   // :313-320
+  DoubleCRT& operator=(const ZZX& poly) { int nl = limbs_for(poly); auto v = to_limbs(poly, nl); ck(fhesi_dcrt_from_poly(h, v.data(), nl, (int64_t)poly.rep.size())); return *this; }   // :323-331
+  DoubleCRT& operator=(const ZZ& num) { return Op(num, OP_SET); }   // :333-347
+  DoubleCRT& operator=(long num) { return *this = ZZ(num); }
+
+  void toPoly(ZZX& p, const IndexSet& s, bool positive = false) const {   // :349-404
+    IndexSet s1 = getIndexSet() & s;
+    if (card(s1) == 0) { clear(p); return; }
+    int nl = (int)card(s1) + 2; long n = context.zMstar.phiM(); auto idx = s1.vec();
+    std::vector<uint64_t> out((size_t)n * nl);
+    ck(fhesi_dcrt_to_poly(h, idx.data(), (int32_t)idx.size(), positive ? 1 : 0, out.data(), nl));
+    p = from_limbs(out, n, nl);
+  }
+  void toPoly(ZZX& p, bool positive = false) const { toPoly(p, getIndexSet(), positive); }
+  bool operator==(const DoubleCRT& o) const { if (&context != &o.context) return false; int32_t eq = 0; ck(fhesi_dcrt_equal(h, o.h, &eq)); return eq != 0; }
+  bool operator!=(const DoubleCRT& o) const { return !(*this == o); }
+  DoubleCRT& SetZero() { return *this = ZZ(); }
+  DoubleCRT& SetOne() { return *this = 1L; }
+  void addPrimes(const IndexSet& s1) { auto v = s1.vec(); if (v.empty()) return; ck(fhesi_dcrt_add_primes(h, v.data(), (int32_t)v.size())); }       // :142-156
+  void removePrimes(const IndexSet& s1) { auto v = s1.vec(); if (v.empty()) return; ck(fhesi_dcrt_remove_primes(h, v.data(), (int32_t)v.size())); }  // DoubleCRT.h:197-199
+  DoubleCRT& operator+=(const DoubleCRT& o) { return Op(o, OP_ADD); }
+  DoubleCRT& operator+=(const ZZX& p) { return Op(p, OP_ADD); }
+  DoubleCRT& operator+=(const ZZ& n) { return Op(n, OP_ADD); }
+  DoubleCRT& operator+=(long n) { return Op(ZZ(n), OP_ADD); }
+  DoubleCRT& operator-=(const DoubleCRT& o) { return Op(o, OP_SUB); }
+  DoubleCRT& operator-=(const ZZX& p) { return Op(p, OP_SUB); }
+  DoubleCRT& operator-=(const ZZ& n) { return Op(n, OP_SUB); }
+  DoubleCRT& operator-=(long n) { return Op(ZZ(n), OP_SUB); }
+  DoubleCRT& operator*=(const DoubleCRT& o) { return Op(o, OP_MUL); }
+  DoubleCRT& operator*=(const ZZX& p) { return Op(p, OP_MUL); }
+  DoubleCRT& operator*=(const ZZ& n) { return Op(n, OP_MUL); }
+  DoubleCRT& operator*=(long n) { return Op(ZZ(n), OP_MUL); }
+  void Add(const DoubleCRT& o, bool match = true) { Op(o, OP_ADD, match); }
+  void Sub(const DoubleCRT& o, bool match = true) { Op(o, OP_SUB, match); }
+  void Mul(const DoubleCRT& o, bool match = true) { Op(o, OP_MUL, match); }
+  DoubleCRT& operator/=(const ZZ& n) { return Op(n, OP_DIV); }   // :407-420
+  DoubleCRT& operator/=(long n) { return Op(ZZ(n), OP_DIV); }
+  void automorph(long k) { if (!context.zMstar.inZmStar((unsigned)k)) Error("DoubleCRT::automorph: k not in Zm*"); ck(fhesi_dcrt_automorph(h, k)); }   // :439-465
+  DoubleCRT& operator>>=(long k) { automorph(k); return *this; }
+  const FHEcontext& getContext() const { return context; }
+  IndexSet getIndexSet() const { int32_t n = 0; std::vector<int32_t> v(64); ck(fhesi_dcrt_index_set(h, v.data(), &n)); IndexSet s; for (int i = 0; i < n; ++i) s.insert(v[i]); return s; }
+  // getMap(): rows materialised from HBM (the reference's IndexMap<vec_long>, DoubleCRT.h:302)
+  std::map<long, vec_long> getMap() const {
+    std::map<long, vec_long> m; long n = context.zMstar.phiM(); std::vector<uint64_t> row(n); IndexSet s = getIndexSet();
+    for (long i = s.first(); i <= s.last(); i = s.next(i)) { ck(fhesi_dcrt_download_row(h, (int32_t)i, row.data())); m[i] = vec_long(row.begin(), row.end()); }
+    return m;
+  }
+  void setRow(long i, const vec_long& r) { std::vector<uint64_t> v(r.begin(), r.end()); ck(fhesi_dcrt_upload_row(h, (int32_t)i, v.data())); }
+  fhesi_dcrt* handle() const { return h; }
+  void randomize() { IndexSet s = getIndexSet(); long n = context.zMstar.phiM(); for (long i = s.first(); i <= s.last(); i = s.next(i)) { vec_long r(n); for (long j = 0; j < n; ++j) r[j] = RandomBnd(context.ithPrime(i)); setRow(i, r); } }   // :468-481
+  void sampleHWt(long Hwt);
+  void sampleGaussian(double stdev = 0.0);
+  ZZ getCoefficientModulus() const { return context.productOfPrimes(); }
+};
+inline ZZX to_ZZX(const DoubleCRT& d) { ZZX p; d.toPoly(p); return p; }
+
+// ---------------------------------------------------------------- samplers (NumbTh.cpp:340-404) on the documented PRNG
+inline void sampleHWt(ZZX& poly, long Hwt, long n) {
+  poly.rep.assign(n, ZZ()); if (Hwt > n) Hwt = n; long i = 0;
+  while (i < Hwt) { long u = RandomBnd(n); if (poly.rep[u].is_zero()) { long b = (long)(global_rng().next() & 2) - 1; poly.rep[u] = ZZ(b); ++i; } }
+  poly.normalize();
+}
+inline void sampleGaussian(ZZX& poly, long n, double stdev) {
+  static const double Pi = 4.0 * std::atan(1.0); static const long bignum = 0xfffffff;
+  poly.rep.assign(n, ZZ());
+  for (long i = 0; i < n; i += 2) {
+    double r1 = (1 + RandomBnd(bignum)) / ((double)bignum + 1), r2 = (1 + RandomBnd(bignum)) / ((double)bignum + 1);
+    double theta = 2 * Pi * r1, rr = std::sqrt(-2.0 * std::log(r2)) * stdev;
+    poly.rep[i] = ZZ((long)std::floor(rr * std::cos(theta) + 0.5));
+    if (i + 1 < n) poly.rep[i + 1] = ZZ((long)std::floor(rr * std::sin(theta) + 0.5));
+  }
+  poly.normalize();
+}
+inline void SampleRandom(ZZX& poly, const ZZ& modulus, unsigned degn) {   // Util.cpp:49-55
+  ZZ offset = modulus / ZZ(2L); poly.rep.assign(degn, ZZ());
+  for (unsigned i = 0; i < degn; ++i) poly.rep[i] = RandomBnd(modulus) - offset;
+  poly.normalize();
+}
+inline void DoubleCRT::sampleHWt(long Hwt) { ZZX p; fhesi::sampleHWt(p, Hwt, context.zMstar.phiM()); *this = p; }
+inline void DoubleCRT::sampleGaussian(double sd) { if (sd == 0.0) sd = context.stdev; ZZX p; fhesi::sampleGaussian(p, context.zMstar.phiM(), sd); *this = p; }
+
+// ---------------------------------------------------------------- Util.cpp
+inline void Reduce(ZZ& val, unsigned logQ, bool positive = false) {   // Util.cpp:3-26
+  ZZ Q = ZZ(1L) << (long)logQ, r = val % Q;        // canonical residue in [0, 2^logQ)
+  if (!positive && r.bit(logQ - 1)) r -= Q;
+  val = r;
+}
+inline void ReduceCoefficients(ZZX& poly, unsigned logQ, bool positive = false) { for (auto& c : poly.rep) Reduce(c, logQ, positive); poly.normalize(); }
+template <typename T> void DotProduct(T& res, const std::vector<T>& v1, const std::vector<T>& v2) {   // Util.h:79-98
+  if (v1.empty()) return;
+  res = v1[0]; res *= v2[0];
+  for (size_t i = 1; i < v1.size(); ++i) { T val = v1[i]; val *= v2[i]; res += val; }
+}
+
+// ---------------------------------------------------------------- Ciphertext (Ciphertext.h, Ciphertext.cpp)
+class CiphertextPart {
+  const FHEcontext& context;
+ public:
+  ZZX poly;
+  CiphertextPart() : context(*activeContext) {}
+  CiphertextPart(const FHEcontext& c) : context(c) {}
+  explicit CiphertextPart(const ZZX& p) : context(*activeContext), poly(p) {}
+  CiphertextPart(const CiphertextPart& o) : context(o.context), poly(o.poly) {}
+  CiphertextPart& operator=(const CiphertextPart& o) { if (&context != &o.context) Error("Incompatible contexts."); poly = o.poly; return *this; }
+  CiphertextPart& operator+=(const ZZX& o) { poly += o; return *this; }
+  CiphertextPart& operator+=(const CiphertextPart& o) { poly += o.poly; return *this; }
+  CiphertextPart& operator*=(long l) { for (auto& c : poly.rep) { c *= ZZ(l); Reduce(c, context.logQ); } poly.normalize(); return *this; }   // Ciphertext.cpp:21-27
+  CiphertextPart& operator>>=(long k) { DoubleCRT tmp(poly); tmp >>= k; tmp.toPoly(poly); return *this; }                                    // :54-59
+  bool operator==(const CiphertextPart& o) const { return poly == o.poly; }
+};
+
+class Ciphertext {
+  const FHEcontext* context;
+  std::vector<DoubleCRT> tProd;
+  bool scaledUp = false;
+ public:
+  std::vector<CiphertextPart> parts;
+  Ciphertext() : context(activeContext) {}
+  Ciphertext(const FHEcontext& c) : context(&c) {}
+  void Initialize(unsigned n, const FHEcontext& c) { context = &c; parts.assign(n, CiphertextPart(c)); }
+  unsigned size() const { return scaledUp ? (unsigned)tProd.size() : (unsigned)parts.size(); }
+  CiphertextPart& operator[](unsigned i) { return parts[i]; }
+  CiphertextPart GetPart(unsigned i) const { return parts[i]; }
+  bool isScaledUp() const { return scaledUp; }
+
+  Ciphertext& operator+=(const Ciphertext& o) {   // Ciphertext.cpp:123-145
+    assert(scaledUp == o.scaledUp);
+    if (!scaledUp) {
+      unsigned i = 0;
+      for (; i < parts.size() && i < o.parts.size(); ++i) { parts[i] += o.parts[i]; ReduceCoefficients(parts[i].poly, context->logQ); }
+      for (; i < o.parts.size(); ++i) parts.push_back(o.parts[i]);
+    } else {
+      unsigned i = 0;
+      for (; i < tProd.size() && i < o.tProd.size(); ++i) tProd[i] += o.tProd[i];
+      for (; i < o.tProd.size(); ++i) tProd.push_back(o.tProd[i]);
+    }
+    return *this;
+  }
+  Ciphertext& operator*=(const Ciphertext& o) {   // Ciphertext.cpp:167-192
+    std::vector<DoubleCRT> c1, c2;
+    for (auto& p : parts) c1.push_back(DoubleCRT(p.poly * context->ModulusP(), *context));
+    for (auto& p : o.parts) c2.push_back(DoubleCRT(p.poly, *context));
+    tProd.assign(c1.size() + c2.size() - 1, DoubleCRT(*context));
+    for (size_t i = 0; i < c1.size(); ++i)
+      for (size_t j = 0; j < c2.size(); ++j) { DoubleCRT tmp = c1[i]; tmp *= c2[j]; tProd[i + j] += tmp; }
+    parts.clear(); scaledUp = true;
+    return *this;
+  }
+  Ciphertext& operator*=(long l) { if (!scaledUp) for (auto& p : parts) p *= l; else for (auto& t : tProd) t *= l; return *this; }   // :232-243
+  Ciphertext& operator>>=(long k) { if (!scaledUp) for (auto& p : parts) p >>= k; else for (auto& t : tProd) t >>= k; return *this; }   // :264-275
+  void ScaleDown() {   // Ciphertext.cpp:194-218
+    if (!scaledUp) return;
+    ZZ q = context->modulusQ, q2 = q * ZZ(2L);
+    parts.clear();
+    for (auto& t : tProd) {
+      ZZX part; t.toPoly(part);
+      for (auto& c : part.rep) { c *= ZZ(2L); c += q; c /= q2; }     // floor division, like NTL
+      part.normalize(); ReduceCoefficients(part, context->logQ);
+      CiphertextPart cp(*context); cp.poly = part; parts.push_back(cp);
+    }
+    scaledUp = false; tProd.clear();
+  }
+  Ciphertext& ByteDecomp() {   // Ciphertext.cpp:82-121: part-major, digit-minor
+    std::vector<CiphertextPart> orig = parts; const unsigned nd = context->ndigits, bits = 8 * context->decompSize;
+    parts.assign(orig.size() * nd, CiphertextPart(*context));
+    ZZ mask = (ZZ(1L) << (long)bits) - ZZ(1L);
+    for (size_t pi = 0; pi < orig.size(); ++pi)
+      for (long i = 0; i <= deg(orig[pi].poly); ++i) {
+        ZZ c = coeff(orig[pi].poly, i); Reduce(c, context->logQ, true);
+        for (unsigned d = 0; d < nd; ++d) { ZZ dig = c >> (long)(bits * d); ZZ low; low.mag = dig.mag; if (low.mag.size() > 1) low.mag.resize(1); if (!low.mag.empty()) low.mag[0] &= (bits >= 64 ? ~0ull : ((1ull << bits) - 1)); low.trim(); if (!low.is_zero()) SetCoeff(parts[pi * nd + d].poly, i, low); }
+      }
+    return *this;
+  }
+};
+
+// ---------------------------------------------------------------- Plaintext (coefficient form only; slot packing is out of scope)
+struct Plaintext { std::vector<long> message; };
+
+// ---------------------------------------------------------------- FHE-SI.cpp: keys and key switching
+class FHESISecKey {
+  const FHEcontext& context;
+  std::vector<DoubleCRT> sKeys;
+ public:
+  FHESISecKey(const FHEcontext& c) : context(c) { Init(c); }
+  void Init(const FHEcontext& c) { sKeys.assign(2, DoubleCRT(c)); sKeys[0] = 1L; sKeys[1].sampleHWt(64); }   // FHE-SI.cpp:86-91
+  const std::vector<DoubleCRT>& GetRepresentation() const { return sKeys; }
+  void UpdateRepresentation(const std::vector<DoubleCRT>& r) { sKeys = r; }
+  const FHEcontext& GetContext() const { return context; }
+  size_t GetSize() const { return sKeys.size(); }
+  void Decrypt(Plaintext& ptxt, const Ciphertext& ctxt) const {   // FHE-SI.cpp:93-119
+    std::vector<DoubleCRT> cp, sp;
+    for (size_t i = 0; i < sKeys.size(); ++i) { cp.push_back(DoubleCRT(ctxt.GetPart((unsigned)i).poly, context)); sp.push_back(sKeys[i]); }
+    DoubleCRT tmp(context); DotProduct(tmp, cp, sp);
+    ZZX z; tmp.toPoly(z);
+    ZZ p = context.ModulusP(), q = context.modulusQ, q2 = q * ZZ(2L);
+    ptxt.message.assign(context.zMstar.phiM(), 0);
+    for (long i = 0; i <= deg(z); ++i) { ZZ c = z.rep[i]; c *= ZZ(2L) * p; c += q; c /= q2; ptxt.message[i] = rem(c, p.to_long()); }
+  }
+};
+class FHESIPubKey {
+  const FHEcontext& context;
+  std::vector<DoubleCRT> publicKey;
+ public:
+  FHESIPubKey(const FHESISecKey& sk) : context(sk.GetContext()) { Init(sk); }
+  const FHEcontext& GetContext() const { return context; }
+  void Init(const FHESISecKey& sk) {   // FHE-SI.cpp:42-63
+    ZZX c0, c1; sampleGaussian(c0, context.zMstar.phiM(), context.stdev); SampleRandom(c1, context.modulusQ, context.zMstar.phiM());
+    ZZX tmp; sk.GetRepresentation()[1].toPoly(tmp); tmp = mul(tmp, c1);
+    c0 += tmp; rem(c0, c0, context.zMstar.PhimX()); c1 *= ZZ(-1L);
+    ReduceCoefficients(c0, context.logQ); ReduceCoefficients(c1, context.logQ);
+    publicKey.clear(); publicKey.push_back(DoubleCRT(c0, context)); publicKey.push_back(DoubleCRT(c1, context));
+  }
+  void Encrypt(Ciphertext& ctxt, const Plaintext& ptxt) const {   // FHE-SI.cpp:10-36
+    ctxt.Initialize(2, context);
+    ZZX small; small.rep.assign(context.zMstar.phiM(), ZZ());
+    for (auto& c : small.rep) c = ZZ(RandomBnd(2L));
+    small.normalize();
+    DoubleCRT r(small, context), e(context);
+    std::vector<DoubleCRT> ct = publicKey;
+    for (size_t i = 0; i < ct.size(); ++i) { e.sampleGaussian(); e *= context.ModulusP(); ct[i] *= r; ct[i] += e; ct[i].toPoly(ctxt[(unsigned)i].poly); }
+    ZZ delta = context.modulusQ / context.ModulusP(); ZZX msg;
+    for (size_t k = 0; k < ptxt.message.size(); ++k) SetCoeff(msg, (long)k, ZZ(ptxt.message[k]));
+    ctxt[0] += delta * msg;
+    for (size_t i = 0; i < ct.size(); ++i) ReduceCoefficients(ctxt[(unsigned)i].poly, context.logQ);
+  }
+};
+class KeySwitchSI {
+  const FHEcontext& context;
+  std::vector<std::vector<DoubleCRT>> keySwitchMatrix;
+ public:
+  KeySwitchSI(const FHESISecKey& s) : context(s.GetContext()) { InitS2(s); }
+  KeySwitchSI(const FHESISecKey& src, const FHESISecKey& dst) : context(src.GetContext()) { Init(src, dst); }
+  const std::vector<std::vector<DoubleCRT>>& GetRepresentation() const { return keySwitchMatrix; }
+  void Init(const FHESISecKey& src, const FHESISecKey& dst) {   // FHE-SI.cpp:153-209
+    std::vector<DoubleCRT> s = src.GetRepresentation(); std::vector<ZZX> sCoeff(s.size());
+    for (size_t i = 0; i < s.size(); ++i) s[i].toPoly(sCoeff[i]);
+    DoubleCRT t = dst.GetRepresentation()[1]; size_t n = src.GetSize();
+    std::vector<DoubleCRT> A, b;
+    for (size_t i = 0; i < n; ++i)
+      for (unsigned j = 0; j < context.ndigits; ++j) {
+        ZZX poly; SampleRandom(poly, context.modulusQ, context.zMstar.phiM());
+        DoubleCRT a(poly, context), bb = a; a *= -1L; bb *= t;
+        ZZX bCoeff; bb.toPoly(bCoeff);
+        ZZX err; sampleGaussian(err, context.zMstar.phiM(), context.stdev);
+        bCoeff += err; bCoeff += sCoeff[i];
+        for (auto& c : sCoeff[i].rep) c <<= (long)(8 * context.decompSize);
+        ReduceCoefficients(bCoeff, context.logQ);
+        A.push_back(a); b.push_back(DoubleCRT(bCoeff, context));
+      }
+    keySwitchMatrix.clear(); keySwitchMatrix.push_back(b); keySwitchMatrix.push_back(A);
+  }
+  void InitS2(const FHESISecKey& s) {   // FHE-SI.cpp:211-227
+    std::vector<DoubleCRT> sKeys = s.GetRepresentation(), tKeys(sKeys.size() * 2 - 1, sKeys[1]);
+    tKeys[0] = sKeys[0];
+    for (size_t i = 2; i < tKeys.size(); ++i) tKeys[i] *= tKeys[i - 1];
+    FHESISecKey tensored(s.GetContext()); tensored.UpdateRepresentation(tKeys);
+    Init(tensored, s);
+  }
+  void ApplyKeySwitch(Ciphertext& ctxt) const {   // FHE-SI.cpp:241-260
+    ctxt.ScaleDown(); ctxt.ByteDecomp();
+    std::vector<DoubleCRT> bd; for (auto& p : ctxt.parts) bd.push_back(DoubleCRT(p.poly, context));
+    std::vector<CiphertextPart> newCtxt(keySwitchMatrix.size(), CiphertextPart(context));
+    for (size_t i = 0; i < keySwitchMatrix.size(); ++i) { DoubleCRT dp(context); DotProduct(dp, keySwitchMatrix[i], bd); dp.toPoly(newCtxt[i].poly); ReduceCoefficients(newCtxt[i].poly, context.logQ); }
+    ctxt.parts = newCtxt;
+  }
+};
+
+}  // namespace fhesi

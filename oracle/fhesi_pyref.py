@@ -650,6 +650,9 @@ def key_switch_init(ctx: Ctx, src_keys: Sequence[Sequence[int]], t: Sequence[int
 def key_switch_init_s2(ctx: Ctx, t: Sequence[int], rng: SplitMix64):
     """KeySwitchSI::InitS2 (FHE-SI.cpp:211-227): source key (1, t, t^2) in coefficient form mod P."""
     one = [1] + [0] * (ctx.phim - 1)
+    # the reference builds `FHESISecKey tensoredKey(context)` (FHE-SI.cpp:221), whose constructor samples (and then
+    # discards) a fresh Hamming-weight-64 key: the draw is reproduced so PRNG streams stay aligned with the C++ mirror
+    sample_hwt(rng, 64, ctx.phim)
     tD = dcrt_from_poly(ctx, t)
     t2 = dcrt_to_poly(ctx, dcrt_op(ctx, tD, tD, "mul"))
     return key_switch_init(ctx, [one, list(t), t2], t, rng)

@@ -1,0 +1,43 @@
+"""GPU: the C++ mirror of the reference's class surface (fhe-si_amd/host: FHEcontext / Cmodulus / DoubleCRT / Ciphertext /
+FHESISecKey / FHESIPubKey / KeySwitchSI over the C ABI) running the reference's Test_AddMul sequence
+(Test_AddMul.cpp:11-113), and bit-exact agreement of its ciphertexts with the committed fixture produced by the
+independent Python model from the same documented PRNG stream."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "fhe-si_amd", "host", "test_addmul")
+
+
+def build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "fhe-si_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "fhe-si_amd", "host")], stdout=subprocess.DEVNULL)
+
+
+def test_addmul_sequence_readme_parameters():
+    """README smoke parameters `80 23 7` (README:46-47): exit code = number of failed seeds."""
+    build()
+    r = subprocess.run([EXE, "80", "23", "7", "--tests=8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "All tests SUCCEEDED!" in r.stdout
+
+
+def test_addmul_power_of_two_ring():
+    build()
+    r = subprocess.run([EXE, "100", "257", "3", "--tests=3"], capture_output=True, text=True, timeout=600)     # m = 256
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_dump_matches_python_model_fixture():
+    build()
+    fx = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "ciphertext.json")))["mul_relin"] if c["m"] == 22][0]
+    r = subprocess.run([EXE, str(fx["logQ"]), str(fx["p"]), "7", str(fx["seed"]), "--dump"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["t"] == fx["t"]
+    assert [d["c1_0"], d["c1_1"]] == fx["c1"] and [d["c2_0"], d["c2_1"]] == fx["c2"]
+    assert [d["res_0"], d["res_1"]] == fx["result"]
