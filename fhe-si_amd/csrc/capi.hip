@@ -738,9 +738,9 @@ extern "C" int fhesi_apply_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
 static i64 batch_chunk(const fhesi_ctx* c, int ncol) {
   const char* e = getenv("FHESI_BATCH_CHUNK");
   if (e && atoll(e) > 0) return atoll(e);
-  // bound the digit-row working set (count * ncol * L * n * 8 bytes) to about 4 GiB
+  // bound the digit-row working set (count * ncol * L * n * 8 bytes) to about 6 GiB
   const double per = (double)ncol * c->L * c->phim * 8.0;
-  i64 ch = (i64)(4.0 * 1024 * 1024 * 1024 / per);
+  i64 ch = (i64)(6.0 * 1024 * 1024 * 1024 / per);
   return ch < 1 ? 1 : ch;
 }
 

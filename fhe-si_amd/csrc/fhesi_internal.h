@@ -164,7 +164,7 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
 int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode, int positive,
                int logQ, u64* d_out, int nl_out);
 // ByteDecomp: parts limb-major [npolys][nl][n] -> digit residue rows [npolys][nd][L][n]
-int launch_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_rows);
+int launch_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_rows, u64 only_below_q = 0);
 
 // bluestein.hip (general m)
 int bluestein_init(fhesi_ctx* ctx);

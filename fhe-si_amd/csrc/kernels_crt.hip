@@ -298,7 +298,7 @@ int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots
 // rows out: [npolys][nd][L][n], digit d of coefficient j reduced mod q_l (digits < 2^digit_bits; Ciphertext.cpp:95-102,
 // zero digits simply give zero coefficients).
 __global__ void __launch_bounds__(256) digits_kernel(const u64* __restrict__ parts, int nl, i64 n, int logQ, int digit_bits, int nd, int L,
-                                                      u64* __restrict__ rows, const PrimeConst* __restrict__ pcs) {
+                                                      u64* __restrict__ rows, const PrimeConst* __restrict__ pcs, u64 only_below_q) {
   const i64 poly = blockIdx.z;
   const int d = blockIdx.y;
   const int lo = d * digit_bits, w = lo >> 6, b = lo & 63;
@@ -310,18 +310,19 @@ __global__ void __launch_bounds__(256) digits_kernel(const u64* __restrict__ par
     v &= mask;
     for (int l = 0; l < L; ++l) {
       const u64 q = pcs[l].q;
+      if (only_below_q && q >= only_below_q) continue;        // rows of the other primes are produced by the fused tile kernel
       rows[((poly * nd + d) * L + l) * n + j] = v < q ? v : v % q;
     }
   }
 }
 
-int launch_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_rows) {
+int launch_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_rows, u64 only_below_q) {
   if (!npolys) return 0;
   ProfScope prof(ctx, PROF_DIGITS, (double)npolys);
   unsigned gx = (unsigned)((ctx->phim + 255) / 256);
   if (gx > 64) gx = 64;
   dim3 grid(gx, (unsigned)nd, (unsigned)npolys);
-  digits_kernel<<<grid, 256, 0, ctx->stream>>>(d_parts, nl, ctx->phim, logQ, digit_bits, nd, ctx->L, d_rows, ctx->d_pc);
+  digits_kernel<<<grid, 256, 0, ctx->stream>>>(d_parts, nl, ctx->phim, logQ, digit_bits, nd, ctx->L, d_rows, ctx->d_pc, only_below_q);
   HIP_TRY(hipGetLastError());
   return 0;
 }

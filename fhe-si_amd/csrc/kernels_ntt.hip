@@ -195,9 +195,7 @@ int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   ProfScope prof(ctx, PROF_NTT_FWD, (double)nrows);
   u64 skip_q = 0;
   if (bitrev && ntt_tile_supported(logn)) {
-    FHESI_TRY(launch_ntt_fwd_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot));
-    if (!ctx->has_small_prime) return 0;
-    skip_q = NTT_TILE_MIN_Q;      // the tile kernel skipped the rows of small primes: the generic kernel takes exactly those
+    return launch_ntt_fwd_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);     // (rows of small primes: its EXACT instantiation)
   }
   const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
   for (int st = 0; st < logn - logb; ++st) {
@@ -231,9 +229,7 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   ProfScope prof(ctx, PROF_NTT_INV, (double)nrows);
   u64 skip_q = 0;
   if (bitrev && ntt_tile_supported(logn)) {
-    FHESI_TRY(launch_ntt_inv_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot));
-    if (!ctx->has_small_prime) return 0;
-    skip_q = NTT_TILE_MIN_Q;
+    return launch_ntt_inv_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
   }
   const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
   const size_t shmem = sizeof(u64) << logb;
@@ -274,14 +270,6 @@ int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, 
     case 12: FHESI_TRY(launch_tile_digits<12>(ctx, ds, npolys * nd, d_out_rows)); break;
     case 13: FHESI_TRY(launch_tile_digits<13>(ctx, ds, npolys * nd, d_out_rows)); break;
     default: FHESI_TRY(launch_tile_digits<14>(ctx, ds, npolys * nd, d_out_rows)); break;
-  }
-  if (ctx->has_small_prime) {     // the tile kernel stored the digit residues of small-prime rows untransformed
-    const int logn = ctx->logn;
-    const size_t shmem = sizeof(u64) << logn;
-    HIP_TRY(hipFuncSetAttribute((const void*)ntt_fwd_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    ntt_fwd_lds<true><<<(unsigned)(npolys * nd * ctx->L), lds_threads(logn), shmem, ctx->stream>>>(d_out_rows, logn, logn, ctx->L, nullptr, ctx->d_pc, ctx->d_tw_fwd,
-                                                                                                 NTT_TILE_MIN_Q);
-    HIP_TRY(hipGetLastError());
   }
   return 0;
 }

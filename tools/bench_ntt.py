@@ -28,7 +28,8 @@ def run(logn, L=4, rows_target=16384, iters=10):
     return out
 
 if __name__ == "__main__":
+    L = int(os.environ.get("NTT_L", "4"))
     logs = [int(x) for x in sys.argv[1:]] or [11, 12, 13, 14]
     for lg in logs:
-        r = run(lg)
+        r = run(lg, L=L, rows_target=int(os.environ.get("NTT_ROWS", "16384")))
         print(lg, json.dumps({k: {a: round(b, 4) if isinstance(b, float) else b for a, b in v.items()} for k, v in r.items()}))
