@@ -213,7 +213,7 @@ def main():
     # live per-kernel timing of the timed region (HIP events on the context's stream)
     prof = {k: ctx.prof_read(k) for k in F.binding.PROF_CLASSES}
     ctx.prof_enable(False)
-    launches, rows, ms = prof["ntt_fwd"]
+    launches, rows, ms = prof["ntt_fwd_digits_main"]       # the dominant kernel: fused ByteDecomp + forward NTT, rows of the 60-bit primes
     row_bytes = 2 * n * 8                                   # row read once + written once
     if args.ntt_rows:
         # optional standalone measurement on a fixed row count
@@ -233,7 +233,7 @@ def main():
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "ntt_fwd_tile<14>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "ntt_fwd_tile<14, true, false>" if not args.ntt_rows else "ntt_fwd_tile<14, false, false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
                 "rows_per_launch": round(rows / launches, 1) if launches else None,
@@ -242,7 +242,7 @@ def main():
     if rank == 0:
         total_mults = B * args.steps * world
         value = total_mults / dt
-        breakdown = {k: round(v[2] / args.steps, 3) for k, v in prof.items() if v[0]}
+        breakdown = {k: round(v[2] / args.steps, 3) for k, v in prof.items() if v[0] and k != "ntt_fwd_digits_main"}
         cpu = None
         if args.cpu_sample > 0:
             cpu = cpu_baseline(primes, roots, ksm_host, a_host, b_host, min(args.cpu_sample, B))

@@ -120,7 +120,7 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
     pc.r64_sh = hm::shoup(pc.r64, Q);
     pc.one_sh = hm::shoup(1, Q);
     pc.one_q63 = hm::shoup63(1, Q);
-    if (Q < (1ull << 48)) c->has_small_prime = true;
+    if (Q < (1ull << 48)) c->has_small_prime = true; else c->n_big_primes++;
     pc.ninv = pc.ninv_sh = pc.ninv_w = pc.ninv_w_sh = 0;
   }
   if (c->pow2) {

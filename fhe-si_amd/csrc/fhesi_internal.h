@@ -53,7 +53,7 @@ struct CrtTables {
 struct BluesteinTables;                // general-m path, defined in bluestein.hip
 
 // per-kernel-class HIP-event stopwatch (bench.py's live kernel timing; off by default)
-enum { PROF_NTT_FWD = 0, PROF_NTT_INV = 1, PROF_RNS = 2, PROF_TENSOR = 3, PROF_CRT = 4, PROF_DIGITS = 5, PROF_DOT = 6, PROF_EW = 7, PROF_NCLASS = 8 };
+enum { PROF_NTT_FWD = 0, PROF_NTT_INV = 1, PROF_RNS = 2, PROF_TENSOR = 3, PROF_CRT = 4, PROF_DIGITS = 5, PROF_DOT = 6, PROF_EW = 7, PROF_NTT_FWD_DIGITS_MAIN = 8, PROF_NCLASS = 9 };
 struct ProfRec { int cls; double units; hipEvent_t e0, e1; };
 
 struct fhesi_ctx {
@@ -63,6 +63,7 @@ struct fhesi_ctx {
   i64 m = 0, phim = 0;
   int L = 0;
   bool pow2 = false;
+  int n_big_primes = 0;                // chain primes >= 2^48 (rows handled by the asm tile kernels)
   bool has_small_prime = false;        // some chain prime is below the tile kernels' 2^48 bound (ntt_tile.inc)
   int logn = 0;                        // log2(phim) when pow2
   std::vector<u64> q, root;

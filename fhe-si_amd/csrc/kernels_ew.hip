@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ 
 #pragma unroll
       for (int c = 0; c < CT_TILE; ++c) {
         if (ct0 + c < count) {
-          const u64x2 d = ((const u64x2*)(dig + ((ct0 + c) * ncol + k) * rs + (i64)l * n))[i];
+          const u64x2 d = __builtin_nontemporal_load(&((const u64x2*)(dig + ((ct0 + c) * ncol + k) * rs + (i64)l * n))[i]);   // digit rows are read once
           acc_mad(acc[c][0], a.x, d.x);
           acc_mad(acc[c][1], a.y, d.y);
           acc_mad(acc[c][2], b.x, d.x);

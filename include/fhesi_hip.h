@@ -61,7 +61,8 @@ int fhesi_timer_stop(fhesi_ctx* ctx, float* elapsed_ms);
 /* per-kernel-class stopwatch: while enabled every launch of a class is bracketed by a HIP-event pair on the context's
  * stream; read returns (#launches, units processed -- rows for the NTT classes, polynomials/ciphertexts otherwise --, total ms) */
 enum { FHESI_PROF_NTT_FWD = 0, FHESI_PROF_NTT_INV = 1, FHESI_PROF_RNS = 2, FHESI_PROF_TENSOR = 3, FHESI_PROF_CRT = 4,
-       FHESI_PROF_DIGITS = 5, FHESI_PROF_DOT = 6, FHESI_PROF_EW = 7 };
+       FHESI_PROF_DIGITS = 5, FHESI_PROF_DOT = 6, FHESI_PROF_EW = 7,
+       FHESI_PROF_NTT_FWD_DIGITS_MAIN = 8 /* the fused ByteDecomp + forward-NTT tile kernel alone; units = rows it transformed */ };
 int fhesi_prof_enable(fhesi_ctx* ctx, int32_t on);      /* also clears the records */
 int fhesi_prof_read(fhesi_ctx* ctx, int32_t kernel_class, int64_t* launches, double* units, double* total_ms);
 
