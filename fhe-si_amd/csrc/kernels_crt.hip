@@ -13,36 +13,41 @@
 
 // ----------------------------------------------------------------------------------------- rns_reduce
 // limbs: [npolys_total][n][nlimbs] two's complement.  rows: [npolys_total][nslots][n].  pow64: [L][nlimbs+1].
+// One block stages 256 coefficients (all limbs, coalesced) in LDS, limb-major, and then produces their residues for every
+// prime slot: the limbs leave HBM/L2 once instead of once per prime.
 __global__ void __launch_bounds__(256) rns_reduce_kernel(const u64* __restrict__ limbs, int nlimbs, i64 ncoeffs, i64 n, int npoly_mod,
-                                                          const u64* __restrict__ scalar_res /* [npoly_mod][L] residues or null */,
+                                                          const u64* __restrict__ scalar_res /* [npoly_mod][nslots] residues or null */,
                                                           u64* __restrict__ rows, int nslots, const int* __restrict__ prime_of_slot,
                                                           const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ pow64) {
-  const i64 poly = blockIdx.z;
-  const int slot = blockIdx.y;
-  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
-  const PrimeConst pc = pcs[prime];
-  const u64 q = pc.q, two_q = pc.two_q;
-  const Shoup2* pw = pow64 + (i64)prime * (nlimbs + 1);
+  extern __shared__ __attribute__((aligned(16))) u64 sl[];       // [nlimbs][256]
+  const i64 poly = blockIdx.y;
+  const i64 j0 = (i64)blockIdx.x * 256;
+  const int tid = threadIdx.x;
   const u64* src = limbs + poly * ncoeffs * nlimbs;
-  u64* dst = rows + (poly * nslots + slot) * n;
-  const bool has_scalar = scalar_res != nullptr;
-  const u64 sc = has_scalar ? scalar_res[(poly % npoly_mod) * gridDim.y + slot] : 0;   // 0 = no scalar for this poly
-  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+  const i64 navail = ncoeffs - j0 < 256 ? (ncoeffs - j0 < 0 ? 0 : ncoeffs - j0) : 256;     // coefficients of this tile that exist
+  const i64 nwords = navail * nlimbs;
+  for (i64 e = tid; e < 256 * (i64)nlimbs; e += 256) {
+    const int cj = (int)(e / nlimbs), k = (int)(e % nlimbs);
+    sl[k * 256 + cj] = e < nwords ? src[j0 * nlimbs + e] : 0;
+  }
+  __syncthreads();
+  const i64 j = j0 + tid;
+  if (j >= n) return;
+  const bool neg = (sl[(nlimbs - 1) * 256 + tid] >> 63) != 0;
+  for (int slot = 0; slot < nslots; ++slot) {
+    const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+    const PrimeConst pc = pcs[prime];
+    const u64 q = pc.q, two_q = pc.two_q;
+    const Shoup2* pw = pow64 + (i64)prime * (nlimbs + 1);
     u64 acc = 0;
-    if (j < ncoeffs) {
-      const u64* c = src + j * nlimbs;
-      u64 top = 0;
-      for (int k = 0; k < nlimbs; ++k) {
-        const u64 limb = c[k];
-        top = limb;
-        acc += d_shoup_lazy(limb, pw[k].w, pw[k].wp, q);       // each term in [0,2q)
-        if (acc >= two_q) acc -= two_q;                         // keep acc in [0,2q)
-      }
-      if (acc >= q) acc -= q;
-      if (top >> 63) acc = d_submod(acc, pw[nlimbs].w, q);      // two's complement: value = unsigned - 2^(64 nlimbs)
-      if (has_scalar && sc) acc = d_mulmod(acc, sc, pc);
+    for (int k = 0; k < nlimbs; ++k) {
+      acc += d_shoup_lazy(sl[k * 256 + tid], pw[k].w, pw[k].wp, q);     // each term in [0,2q)
+      if (acc >= two_q) acc -= two_q;                                      // keep acc in [0,2q)
     }
-    dst[j] = acc;
+    if (acc >= q) acc -= q;
+    if (neg) acc = d_submod(acc, pw[nlimbs].w, q);                         // two's complement: value = unsigned - 2^(64 nlimbs)
+    if (scalar_res) { const u64 sc = scalar_res[(poly % npoly_mod) * nslots + slot]; if (sc) acc = d_mulmod(acc, sc, pc); }
+    rows[(poly * nslots + slot) * n + j] = acc;
   }
 }
 
@@ -79,10 +84,11 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
   }
   const i64 n = ctx->phim;
   ProfScope prof(ctx, PROF_RNS, (double)(count * npoly));
-  unsigned gx = (unsigned)((n + 255) / 256);
-  if (gx > 64) gx = 64;
-  dim3 grid(gx, (unsigned)nslots, (unsigned)(count * npoly));
-  rns_reduce_kernel<<<grid, 256, 0, ctx->stream>>>(d_limbs, nlimbs, ncoeffs < n ? ncoeffs : n, n, npoly, d_sc, d_rows, nslots, d_prime_of_slot, ctx->d_pc, d_pow);
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)(count * npoly));
+  const size_t shmem = (size_t)nlimbs * 256 * sizeof(u64);
+  if (shmem > 160 * 1024) FHESI_FAIL("rns_reduce: coefficients of %d limbs are too wide", nlimbs);
+  HIP_TRY(hipFuncSetAttribute((const void*)rns_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  rns_reduce_kernel<<<grid, 256, shmem, ctx->stream>>>(d_limbs, nlimbs, ncoeffs < n ? ncoeffs : n, n, npoly, d_sc, d_rows, nslots, d_prime_of_slot, ctx->d_pc, d_pow);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -147,9 +153,11 @@ int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out)
 // One thread per coefficient.  MAXW = compile-time bound on the limb count (register array, static indices only);
 // the finished W-limb integer is staged in LDS (limb-major, conflict-free) for the mode-dependent epilogue that
 // needs run-time limb indices (shift by logQ).
-template <int MAXW>
+// KFIX / WFIX > 0: the prime count and limb count are compile-time constants, so the triangular recurrence unrolls
+// completely (no uniform branches, constants hoisted); 0 = run-time values.
+template <int MAXW, int KFIX, int WFIX>
 __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, i64 n, int nslots_layout, const int* __restrict__ slot_of /* [K] or null */,
-                                                  int K, int W, const int* __restrict__ idx, const Shoup2* __restrict__ pow64,
+                                                  int K_rt, int W_rt, const int* __restrict__ idx, const Shoup2* __restrict__ pow64,
                                                   const Shoup2* __restrict__ pinv, const u64* __restrict__ Ptab, const u64* __restrict__ halfP,
                                                   const PrimeConst* __restrict__ pcs, int mode, int positive, int logQ,
                                                   u64* __restrict__ out, int nl_out) {
@@ -157,19 +165,21 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
   const i64 poly = blockIdx.y;
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = j < n;
+  const int K = KFIX ? KFIX : K_rt, W = WFIX ? WFIX : W_rt;
   const u64* base = rows + poly * nslots_layout * n;
   u64 x[MAXW];
 #pragma unroll
   for (int i = 0; i < MAXW; ++i) x[i] = 0;
   if (active) {
     x[0] = base[(i64)(slot_of ? slot_of[0] : idx[0]) * n + j];
-    for (int k = 1; k < K; ++k) {
+#pragma unroll
+    for (int k = 1; k < (KFIX ? KFIX : K); ++k) {
       const PrimeConst pc = pcs[idx[k]];
       const u64 q = pc.q, two_q = pc.two_q;
       const u64 rk = base[(i64)(slot_of ? slot_of[k] : idx[k]) * n + j];
       // t = x mod q_k   (x < P_k < 2^(64k): k limbs)
       u64 t = 0;
-      const Shoup2* pw = pow64 + (i64)k * W;
+      const Shoup2* pw = pow64 + (i64)k * W;      // wave-uniform scalar loads (an LDS copy of the tables measured slower)
 #pragma unroll
       for (int i = 0; i < MAXW; ++i) {
         if (i < k && i < W) {
@@ -264,15 +274,15 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
   }
 }
 
-template <int MAXW>
+template <int MAXW, int KFIX = 0, int WFIX = 0>
 static int launch_crt_t(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode,
                         int positive, int logQ, u64* d_out, int nl_out) {
   const int TB = 128;
   const size_t shmem = (size_t)t->W * TB * sizeof(u64);
   static bool attr_done = false;
-  if (!attr_done) { HIP_TRY(hipFuncSetAttribute((const void*)crt_kernel<MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, MAXW * TB * 8)); attr_done = true; }
+  if (!attr_done) { HIP_TRY(hipFuncSetAttribute((const void*)crt_kernel<MAXW, KFIX, WFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, MAXW * TB * 8)); attr_done = true; }
   dim3 grid((unsigned)((ctx->phim + TB - 1) / TB), (unsigned)npolys);
-  crt_kernel<MAXW><<<grid, TB, shmem, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->nidx, t->W, t->d_idx, t->d_pow64, t->d_pinv, t->d_P,
+  crt_kernel<MAXW, KFIX, WFIX><<<grid, TB, shmem, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->nidx, t->W, t->d_idx, t->d_pow64, t->d_pinv, t->d_P,
                                                     t->d_halfP, ctx->d_pc, mode, positive, logQ, d_out, nl_out);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -284,6 +294,8 @@ int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots
   if (mode != 0 && (logQ < 1 || logQ > 64 * (t->W - 1))) FHESI_FAIL("CRT: logQ=%d outside the range covered by the prime set", logQ);
   const int W = t->W;
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
+  // fully unrolled instantiation for the metric chain shape (fhe-si logQ = 512: 18 primes, 17-limb product)
+  if (t->nidx == 18 && W == 18) return launch_crt_t<18, 18, 18>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (W <= 4) return launch_crt_t<4>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (W <= 8) return launch_crt_t<8>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (W <= 12) return launch_crt_t<12>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
