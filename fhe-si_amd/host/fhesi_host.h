@@ -292,6 +292,42 @@ class DoubleCRT {
   DoubleCRT& operator/=(const ZZ& n) { return Op(n, OP_DIV); }   // :407-420
   DoubleCRT& operator/=(long n) { return Op(ZZ(n), OP_DIV); }
   void automorph(long k) { if (!context.zMstar.inZmStar((unsigned)k)) Error("DoubleCRT::automorph: k not in Zm*"); ck(fhesi_dcrt_automorph(h, k)); }   // :439-465
+  // BGV-style modulus switching (no callers in fhe-si, kept for the class surface): every heavy step is a C-ABI call
+  double addPrimesAndScale(const IndexSet& s1) {   // DoubleCRT.cpp:162-208
+    const ZZ p = context.ModulusP();
+    if (card(s1) == 0) return 0.0;
+    assert(p >= ZZ(2L)); assert(card(s1 & getIndexSet()) == 0);
+    ZZ factor(1L); double logFactor = 0.0;
+    for (long i = s1.first(); i <= s1.last(); i = s1.next(i)) { factor *= ZZ(context.ithPrime(i)); logFactor += std::log((double)context.ithPrime(i)); }
+    ZZ prodInv = InvModSmall(factor % p, p);
+    factor *= prodInv; logFactor += log(prodInv);
+    *this *= factor;                                  // scale existing rows by factor mod q_i
+    IndexSet old = getIndexSet();
+    DoubleCRT grown(context, old | s1);               // zero rows for the new primes, old rows copied in
+    { auto m = getMap(); for (auto& kv : m) grown.setRow(kv.first, kv.second); }
+    ck(fhesi_dcrt_free(h)); h = nullptr; alloc(old | s1); ck(fhesi_dcrt_copy(h, grown.h));
+    return logFactor;
+  }
+  void scaleDownToSet(const IndexSet& s) {   // DoubleCRT.cpp:518-558
+    IndexSet indexSet = getIndexSet(), intersect = s & indexSet, diff = indexSet / s;
+    assert(card(intersect) > 0); assert(card(diff) > 0);
+    ZZ diffProd = context.productOfPrimes(diff), p = context.ModulusP();
+    *this *= (diffProd % p);
+    ZZX delta; toPoly(delta, diff);
+    ZZ factor = diffProd * InvModSmall(diffProd % p, p);
+    for (auto& c : delta.rep) { ZZ d = c; c *= factor; c -= d; }
+    delta.normalize();
+    ZZ mod = diffProd * p, half = mod / ZZ(2L);
+    for (auto& c : delta.rep) { c %= mod; if (c > half) c -= mod; }     // ReduceCoefficientsSlow (Util.cpp:35-43)
+    delta.normalize();
+    removePrimes(diff);
+    *this += delta;
+    *this /= diffProd;
+  }
+  static ZZ InvModSmall(const ZZ& a, const ZZ& p) {   // a^-1 mod p for a word-size prime p
+    uint64_t pp = (uint64_t)p.to_long(), aa = (uint64_t)rem(a, (long)pp);
+    return ZZ((unsigned long)PowerMod(aa, pp - 2, pp));
+  }
   DoubleCRT& operator>>=(long k) { automorph(k); return *this; }
   const FHEcontext& getContext() const { return context; }
   IndexSet getIndexSet() const { int32_t n = 0; std::vector<int32_t> v(64); ck(fhesi_dcrt_index_set(h, v.data(), &n)); IndexSet s; for (int i = 0; i < n; ++i) s.insert(v[i]); return s; }

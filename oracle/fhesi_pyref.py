@@ -656,3 +656,42 @@ def key_switch_init_s2(ctx: Ctx, t: Sequence[int], rng: SplitMix64):
     tD = dcrt_from_poly(ctx, t)
     t2 = dcrt_to_poly(ctx, dcrt_op(ctx, tD, tD, "mul"))
     return key_switch_init(ctx, [one, list(t), t2], t, rng)
+
+
+# --------------------------------------------------------------------------------------------
+# BGV-style modulus switching (dead code in fhe-si -- no callers -- but part of the DoubleCRT surface)
+# --------------------------------------------------------------------------------------------
+def dcrt_add_primes_and_scale(ctx: Ctx, a: dict, s1: Sequence[int]) -> dict:
+    """DoubleCRT::addPrimesAndScale (DoubleCRT.cpp:162-208): scale the existing rows by F * (F^-1 mod p), F = product of the
+    added primes, and append zero rows for them."""
+    assert not set(s1) & set(a)
+    if not s1:
+        return dict(a)
+    factor = 1
+    for i in s1:
+        factor *= ctx.primes[i]
+    factor *= pow(factor % ctx.p, -1, ctx.p)
+    out = {i: [x * (factor % ctx.primes[i]) % ctx.primes[i] for x in row] for i, row in a.items()}
+    for i in s1:
+        out[i] = [0] * ctx.phim
+    return out
+
+
+def dcrt_scale_down_to_set(ctx: Ctx, a: dict, s: Sequence[int]) -> dict:
+    """DoubleCRT::scaleDownToSet (DoubleCRT.cpp:518-558)."""
+    keep = sorted(set(a) & set(s))
+    diff = sorted(set(a) - set(s))
+    assert keep and diff
+    D = 1
+    for i in diff:
+        D *= ctx.primes[i]
+    b = dcrt_op_scalar(ctx, a, D % ctx.p, "mul")                       # *this *= (diffProd % p)
+    delta = dcrt_to_poly(ctx, b, idxset=diff)                          # toPoly(delta, diff): centred modulo D
+    factor = D * pow(D % ctx.p, -1, ctx.p)
+    delta = [d * factor - d for d in delta]
+    mod = D * ctx.p
+    delta = [(d % mod) - (mod if (d % mod) > mod // 2 else 0) for d in delta]     # ReduceCoefficientsSlow (Util.cpp:35-43)
+    b = {i: b[i] for i in keep}                                        # removePrimes(diff)
+    dD = dcrt_from_poly(ctx, delta, keep)
+    b = dcrt_op(ctx, b, dD, "add")                                     # *this += delta
+    return dcrt_div_scalar(ctx, b, D)                                  # *this /= diffProd

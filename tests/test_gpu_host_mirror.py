@@ -41,3 +41,25 @@ def test_dump_matches_python_model_fixture():
     assert d["t"] == fx["t"]
     assert [d["c1_0"], d["c1_1"]] == fx["c1"] and [d["c2_0"], d["c2_1"]] == fx["c2"]
     assert [d["res_0"], d["res_1"]] == fx["result"]
+
+
+def test_modulus_switching_methods_match_python_model():
+    """addPrimesAndScale / scaleDownToSet (DoubleCRT.cpp:162-208, 518-558) on the mirrored DoubleCRT."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fhesi_pyref as R
+    build()
+    m, logQ, p = 64, 100, 23
+    r = subprocess.run([os.path.join(ROOT, "fhe-si_amd", "host", "test_modswitch"), str(m)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    _, phim = R.zms_idx(m)
+    primes = R.add_primes_by_size(m, R.si_context_size(logQ, p, phim))
+    ctx = R.Ctx(m, logQ, p, primes)
+    L = len(primes)
+    assert d["L"] == L and L >= 3
+    poly = [int(x) for x in d["poly"]]
+    grown = R.dcrt_add_primes_and_scale(ctx, R.dcrt_from_poly(ctx, poly, [0, 1]), list(range(2, L)))
+    assert {int(k): [int(x) for x in v] for k, v in d["grown"].items()} == grown
+    scaled = R.dcrt_scale_down_to_set(ctx, R.dcrt_from_poly(ctx, poly), [0, 1])
+    assert {int(k): [int(x) for x in v] for k, v in d["scaled"].items()} == scaled
