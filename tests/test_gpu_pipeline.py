@@ -77,3 +77,14 @@ def test_valid_keys_decrypt_to_product():
     parts = [O.limbs_to_ints(out[r]) for r in range(2)]
     assert parts == R.ct_mul_relin(rctx, ksm_py, c1, c2)
     assert R.decrypt(rctx, t, parts) == [c % p for c in R.poly_mul_mod_phi(rctx, m1, m2)]
+
+
+def test_stress_config_shape_single_ciphertext():
+    """configs[4] of BASELINE.json (stress): m = 2^16 (n = 2^15 > one LDS tile: generic multi-pass NTT), fhe-si logQ = 1024,
+    p = 65537  =>  35 primes, 43 digits; one ciphertext mult + relinearize, bit-exact against the oracle."""
+    m, logQ, p = 1 << 16, 1024, 65537
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 5, 1)
+    assert ctx.L == 35 and nd == 43
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert np.array_equal(got[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
