@@ -140,14 +140,14 @@ int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
 int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev = true);
 // digit-row forward NTT: source is the scaled-down part in limb-major layout, see kernels_crt.hip
 int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts_limbmajor, int nl, int logQ, int digit_bits, int nd, i64 npolys,
-                          u64* d_out_rows /* [npolys*nd][L][n] */);
+                          u64* d_out_rows /* [npolys*nd][L][n] */, int slot0 = 0, int nslot = 0 /* 0 = all primes */);
 
 // kernels_ew.hip
 int launch_ew_op(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 count, int nslots, const int* d_prime_of_slot, int op);
 int launch_ew_scalar(fhesi_ctx* ctx, u64* d_dst, const u64* d_scalars /* [nslots] residues */, i64 count, int nslots, const int* d_prime_of_slot, int op);
 int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a /* [count][2][L][n] */, const u64* d_b /* [count][2][L][n] */, u64* d_t /* [count][3][L][n] */, i64 count);
 int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key /* [2][ncol][L][n] */, const u64* d_dig /* [count][ncol][L][n] */, int ncol, i64 count,
-                     u64* d_out /* [count][2][L][n] */);
+                     u64* d_out /* [count][2][L][n] */, int slot0 = 0, int nslot = 0 /* 0 = all primes */);
 int launch_automorph(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 nrows, i64 k);
 int launch_rows_equal(fhesi_ctx* ctx, const u64* a, const u64* b, i64 nwords, int* equal);
 

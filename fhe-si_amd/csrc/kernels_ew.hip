@@ -96,9 +96,9 @@ __device__ __forceinline__ u64 acc_reduce(const Acc128& a, const PrimeConst& pc)
 }
 template <int CT_TILE>
 __global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ key, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
-                                                         u64* __restrict__ out, const PrimeConst* __restrict__ pcs) {
+                                                         u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int slot0) {
   const i64 ct0 = (i64)blockIdx.z * CT_TILE;
-  const int l = blockIdx.y;
+  const int l = blockIdx.y + slot0;
   const PrimeConst pc = pcs[l];
   const i64 rs = (i64)L * n;
   const u64* k0 = key + (i64)l * n;
@@ -199,8 +199,9 @@ int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a, const u64* d_b, u64* d_t, i
   return 0;
 }
 
-int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int ncol, i64 count, u64* d_out) {
+int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int ncol, i64 count, u64* d_out, int slot0, int nslot) {
   if (!count) return 0;
+  if (nslot <= 0) { slot0 = 0; nslot = ctx->L; }
   if (ctx->phim & 1) FHESI_FAIL("dot_accum: odd phi(m) not supported by the batched pipeline");
   // exact 128-bit accumulation needs ncol * q^2 < 2^128
   for (int l = 0; l < ctx->L; ++l) {
@@ -210,8 +211,8 @@ int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int nco
   }
   ProfScope prof(ctx, PROF_DOT, (double)count);
   constexpr int CT_TILE = 4;     // 8 measured slower on MI355X (register pressure outweighs the saved key reads)
-  dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ctx->L, (unsigned)((count + CT_TILE - 1) / CT_TILE));
-  dot_accum_kernel<CT_TILE><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc);
+  dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)nslot, (unsigned)((count + CT_TILE - 1) / CT_TILE));
+  dot_accum_kernel<CT_TILE><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -257,19 +257,20 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
 }
 
 // ByteDecomp fused into the forward transform: digit rows [npolys*nd][L][n] straight from the scaled-down parts.
-int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_out_rows) {
+int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_out_rows, int slot0, int nslot) {
+  if (nslot <= 0) { slot0 = 0; nslot = ctx->L; }
   if (!npolys) return 0;
   if (!ntt_tile_supported(ctx->logn) || digit_bits >= 32) {      // generic sizes: separate digit kernel, then the row transform
     FHESI_TRY(launch_digits(ctx, d_parts, nl, logQ, digit_bits, nd, npolys, d_out_rows));
     return launch_ntt_fwd(ctx, d_out_rows, npolys * nd, ctx->L, nullptr, true);
   }
-  ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * ctx->L));
-  const DigitSrc ds{d_parts, nl, digit_bits, nd};
+  ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * nslot));
+  const DigitSrc ds{d_parts, nl, digit_bits, nd, slot0};
   switch (ctx->logn) {
-    case 11: FHESI_TRY(launch_tile_digits<11>(ctx, ds, npolys * nd, d_out_rows)); break;
-    case 12: FHESI_TRY(launch_tile_digits<12>(ctx, ds, npolys * nd, d_out_rows)); break;
-    case 13: FHESI_TRY(launch_tile_digits<13>(ctx, ds, npolys * nd, d_out_rows)); break;
-    default: FHESI_TRY(launch_tile_digits<14>(ctx, ds, npolys * nd, d_out_rows)); break;
+    case 11: FHESI_TRY(launch_tile_digits<11>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
+    case 12: FHESI_TRY(launch_tile_digits<12>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
+    case 13: FHESI_TRY(launch_tile_digits<13>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
+    default: FHESI_TRY(launch_tile_digits<14>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
   }
   return 0;
 }
