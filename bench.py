@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="ciphertext mults per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (FHESI_LANES); 2 gives ~+5 %% throughput but "
+                    "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
     args = ap.parse_args()
 
@@ -145,6 +147,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
+    os.environ["FHESI_LANES"] = str(args.lanes)
     import torch
     import fhe_si_amd as F
     if not torch.cuda.is_available():
@@ -252,7 +255,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3",
-                       "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B,
+                       "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B, "lanes": args.lanes,
                        "fwd_row_ntts_per_mult": (4 + ncol) * L, "inv_row_ntts_per_mult": 5 * L,
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,

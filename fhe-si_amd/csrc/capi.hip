@@ -102,6 +102,10 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
   c->pow2 = (m & (m - 1)) == 0 && m >= 4;
   c->logn = c->pow2 ? hm::ilog2_ceil(c->phim) : 0;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
 
@@ -193,6 +197,12 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   bluestein_destroy(c);
   for (auto& kv : c->crt_cache) { hipFree(kv.second->d_blob); delete kv.second; }
   for (auto& kv : c->pow64_cache) hipFree(kv.second);
+  for (auto& kv : c->scalar_cache) hipFree(kv.second);
+  for (int i = 0; i < 10; ++i) if (c->lane_ws[i]) hipFree(c->lane_ws[i]);
+  if (c->lane_stream) hipStreamDestroy(c->lane_stream);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->ev_mid) hipEventDestroy(c->ev_mid);
   for (int i = 0; i < 10; ++i) if (c->ws[i]) hipFree(c->ws[i]);
   hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv);
   hipFree(c->d_zms_idx); hipFree(c->d_zms_list);
@@ -727,6 +737,7 @@ extern "C" int fhesi_apply_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
     FHESI_TRY(launch_digits(c, (const u64*)d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
     FHESI_TRY(row_fwd(c, (u64*)d_dig, count * ncol, L, nullptr, all.data()));
   }
+  if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
   // DotProduct with both key rows (FHE-SI.cpp:251-254)
   FHESI_TRY(launch_dot_accum(c, k->d_rows, (const u64*)d_dig, ncol, count, (u64*)d_t));
   // toPoly + ReduceCoefficients (FHE-SI.cpp:255-256)
@@ -744,12 +755,8 @@ static i64 batch_chunk(const fhesi_ctx* c, int ncol) {
   return ch < 1 ? 1 : ch;
 }
 
-extern "C" int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a,
-                                            const uint64_t* b, uint64_t* out, int32_t nlimbs, int64_t count) {
-  CHECK_CTX(c);
-  if (!k || k->ctx != c) FHESI_FAIL("KeySwitchSI: context mismatch");
-  if (k->ncomp != 3) FHESI_FAIL("ct_mul_relin needs the s^2 -> s matrix (3 source components), got %d", k->ncomp);
-  if (nlimbs * 64 < logQ) FHESI_FAIL("coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a, const uint64_t* b,
+                            uint64_t* out, int32_t nlimbs, int64_t count) {
   const i64 n = c->phim;
   const int L = c->L;
   const i64 chunk = batch_chunk(c, 3 * k->ndigits);
@@ -762,6 +769,41 @@ extern "C" int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* c, const fhesi_ksk* k, in
     FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_tp, cnt, out + off, nlimbs));
   }
   return 0;
+}
+static void swap_lane(fhesi_ctx* c) {
+  std::swap(c->stream, c->lane_stream);
+  for (int i = 0; i < 10; ++i) { std::swap(c->ws[i], c->lane_ws[i]); std::swap(c->ws_bytes[i], c->lane_ws_bytes[i]); }
+}
+
+extern "C" int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a,
+                                            const uint64_t* b, uint64_t* out, int32_t nlimbs, int64_t count) {
+  CHECK_CTX(c);
+  if (!k || k->ctx != c) FHESI_FAIL("KeySwitchSI: context mismatch");
+  if (k->ncomp != 3) FHESI_FAIL("ct_mul_relin needs the s^2 -> s matrix (3 source components), got %d", k->ncomp);
+  if (nlimbs * 64 < logQ) FHESI_FAIL("coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  static const int lanes = getenv("FHESI_LANES") ? atoi(getenv("FHESI_LANES")) : 1;    // 2: two concurrent half-batches (+5 % throughput on MI355X; kernels of the halves time-share the GPU)
+  if (lanes < 2 || count < 8) return mul_relin_chunks(c, k, logQ, p, decomp_bytes, a, b, out, nlimbs, count);
+  // two lanes: the second half of the batch runs on a second stream with its own workspace.  Ciphertexts are independent, so
+  // the halves never touch the same memory; the fork / join events keep the call's stream semantics (work is ordered after
+  // what was enqueued on the context's stream before the call, and fhesi_ctx_sync covers both halves afterwards).
+  const int64_t h0 = (count + 1) / 2, h1 = count - h0;
+  const size_t off = (size_t)h0 * 2 * c->phim * nlimbs;
+  static const int stagger = getenv("FHESI_STAGGER") ? atoi(getenv("FHESI_STAGGER")) : 0;   // measured slower than starting both lanes together
+  HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->lane_stream, c->ev_fork, 0));
+  c->mark_mid = stagger != 0;
+  int r = mul_relin_chunks(c, k, logQ, p, decomp_bytes, a, b, out, nlimbs, h0);
+  if (!r) {
+    // stagger: the second lane starts when the first lane's digit NTT (VALU-bound) has been issued, so that its own NTT
+    // runs against the first lane's HBM-bound dot product / CRT tail instead of in lockstep with its NTT
+    if (stagger) HIP_TRY(hipStreamWaitEvent(c->lane_stream, c->ev_mid, 0));
+    swap_lane(c);
+    r = mul_relin_chunks(c, k, logQ, p, decomp_bytes, a + off, b + off, out + off, nlimbs, h1);
+    hipEventRecord(c->ev_join, c->stream);        // (c->stream is the lane stream here)
+    swap_lane(c);
+    if (!r) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  }
+  return r;
 }
 
 extern "C" int fhesi_ct_mul_relin_batch(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a,

@@ -80,6 +80,14 @@ struct fhesi_ctx {
   BluesteinTables* blue = nullptr;
   std::map<std::vector<int>, CrtTables*> crt_cache;
   std::map<int, Shoup2*> pow64_cache;  // nlimbs -> device [L][nlimbs+1] table for rns_reduce
+  std::map<std::vector<u64>, u64*> scalar_cache;   // rns_reduce lift scalars (per-slot residues), keyed by the scalar list
+  // second "lane" (stream + workspace): the batched ciphertext pipeline runs two half-batches concurrently so that one
+  // half's HBM-bound kernels (dot, CRT loads) overlap the other half's VALU-bound NTTs
+  hipStream_t lane_stream = nullptr;
+  void* lane_ws[10] = {};
+  size_t lane_ws_bytes[10] = {};
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+  bool mark_mid = false;               // record ev_mid right after the next digit-NTT launch (staggers the second lane)
   bool prof_on = false;
   std::vector<ProfRec> prof;
   // grow-only workspace

@@ -70,17 +70,21 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pow64_cache[nlimbs] = d_pow;
   } else d_pow = it->second;
-  // per-(poly, slot) scalar residues
+  // per-(poly, slot) scalar residues, cached on the device (no host synchronisation in the steady state)
   u64* d_sc = nullptr;
   if (scalar_mul) {
-    std::vector<u64> h((size_t)npoly * nslots, 0);
-    std::vector<int> pos(nslots);
     if (d_prime_of_slot) FHESI_FAIL("rns_reduce: scalar lift only supported on the full prime set");
-    for (int p = 0; p < npoly; ++p)
-      for (int s = 0; s < nslots; ++s) h[(size_t)p * nslots + s] = scalar_mul[p] ? scalar_mul[p] % ctx->q[s] : 0;
-    FHESI_TRY(ws_reserve(ctx, 4, h.size() * 8 + 64, (void**)&d_sc));
-    HIP_TRY(hipMemcpyAsync(d_sc, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // h goes out of scope
+    std::vector<u64> key(scalar_mul, scalar_mul + npoly);
+    key.push_back((u64)nslots);
+    auto sit = ctx->scalar_cache.find(key);
+    if (sit == ctx->scalar_cache.end()) {
+      std::vector<u64> h((size_t)npoly * nslots, 0);
+      for (int p = 0; p < npoly; ++p)
+        for (int s = 0; s < nslots; ++s) h[(size_t)p * nslots + s] = scalar_mul[p] ? scalar_mul[p] % ctx->q[s] : 0;
+      HIP_TRY(hipMalloc(&d_sc, h.size() * 8));
+      HIP_TRY(hipMemcpy(d_sc, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+      ctx->scalar_cache[key] = d_sc;
+    } else d_sc = sit->second;
   }
   const i64 n = ctx->phim;
   ProfScope prof(ctx, PROF_RNS, (double)(count * npoly));
