@@ -247,7 +247,7 @@ def main():
         value = total_mults / dt
         breakdown = {k: round(v[2] / args.steps, 3) for k, v in prof.items() if v[0] and k != "ntt_fwd_digits_main"}
         cpu = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:       # CPU baseline on rank 0 at N=1 only
             cpu = cpu_baseline(primes, roots, ksm_host, a_host, b_host, min(args.cpu_sample, B))
         line = {
             "metric": "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^14, logQ=512",
