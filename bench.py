@@ -138,11 +138,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (FHESI_LANES); 2 gives ~+5 %% throughput but "
                     "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 plumbing)")
+    ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -156,7 +158,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     n = M_RING // 2
     primes = prime_chain(M_RING, LOGQ, P_PLAIN, n)
