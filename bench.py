@@ -138,11 +138,16 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (FHESI_LANES); 2 gives ~+5 %% throughput but "
                     "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
+    ap.add_argument("--workload", default="metric", choices=["metric", "stress"], help="metric = configs[2] (default, the contract line); "
+                    "stress = configs[4]: m=2^16 (n=2^15), logQ=1024, p=65537 (35 primes, 43 digits) -- reporting only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 plumbing)")
     ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
     args = ap.parse_args()
 
+    global M_RING, LOGQ, P_PLAIN
+    if args.workload == "stress":
+        M_RING, LOGQ, P_PLAIN = 1 << 16, 1024, 65537
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,11 +260,13 @@ def main():
         if args.cpu_sample > 0 and world == 1:       # CPU baseline on rank 0 at N=1 only
             cpu = cpu_baseline(primes, roots, ksm_host, a_host, b_host, min(args.cpu_sample, B))
         line = {
-            "metric": "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^14, logQ=512",
+            "metric": "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^14, logQ=512" if args.workload == "metric"
+                      else "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^15, logQ=1024 (stress shape)",
             "value": round(value, 2), "unit": "ciphertext-mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3",
+            "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
+                       if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
                        "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B, "lanes": args.lanes,
                        "fwd_row_ntts_per_mult": (4 + ncol) * L, "inv_row_ntts_per_mult": 5 * L,
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
