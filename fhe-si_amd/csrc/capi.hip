@@ -172,6 +172,47 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
       HIP_TRY(hipMemcpy(c->d_twt_fwd, all_f.data(), tb, hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy(c->d_twt_inv, all_i.data(), tb, hipMemcpyHostToDevice));
     }
+    if (lg >= 15 && lg <= 17) {      // two-pass transforms (TileBig in ntt_tile.inc, ntt_*_tail in kernels_ntt.hip)
+      const int s0 = lg - 14, nsub = 1 << s0;
+      const i64 n1 = 1 << 14;
+      std::vector<Shoup2> all_f((size_t)nprimes * n1), all_i((size_t)nprimes * n), tail((size_t)nprimes * n, Shoup2{0, 0}), fold((size_t)nprimes * nsub), one(n1), tmp;
+      for (int i = 0; i < nprimes; ++i) {
+        const u64 Q = q[i];
+        // forward sub-transforms: ring of 2^14 points with root psi^nsub = the first 2^14 entries of the bit-reversed table
+        one.assign(twf.begin() + (size_t)i * n, twf.begin() + (size_t)i * n + n1);
+        build_tile_order(one, 14, tmp);
+        to_q63(tmp, Q);
+        std::copy(tmp.begin(), tmp.end(), all_f.begin() + (size_t)i * n1);
+        // inverse sub-transform `sub`: stage s0+u of the row, block (sub << u) + b
+        for (int sub = 0; sub < nsub; ++sub) {
+          one[0] = Shoup2{0, 0};
+          for (int u = 0; u < 14; ++u)
+            for (i64 b = 0; b < (1ll << u); ++b) one[(1ll << u) + b] = twi[(size_t)i * n + (1ll << (s0 + u)) + ((i64)sub << u) + b];
+          build_tile_order(one, 14, tmp);
+          to_q63(tmp, Q);
+          std::copy(tmp.begin(), tmp.end(), all_i.begin() + ((size_t)i * nsub + sub) * n1);
+          const u64 f = hm::mulmod(c->pc[i].ninv, twi[(size_t)i * n + nsub + sub].w, Q);
+          fold[(size_t)i * nsub + sub] = Shoup2{f, hm::shoup63(f, Q)};
+        }
+        // forward tail: stage s builds M = 2^(14+s) points, entry j = psi^((n/M)(2j+1)), j < M/2
+        const u64 psi = hm::mulmod(root[i], root[i], Q);
+        for (int s = 1; s <= s0; ++s) {
+          const i64 half = n1 << (s - 1);
+          const u64 base = hm::powmod(psi, (u64)(n / (2 * half)), Q), step = hm::mulmod(base, base, Q);
+          u64 w = base;
+          Shoup2* dst = tail.data() + (size_t)i * n + n1 * ((1ll << (s - 1)) - 1);
+          for (i64 j = 0; j < half; ++j) { dst[j] = Shoup2{w, hm::shoup(w, Q)}; w = hm::mulmod(w, step, Q); }
+        }
+      }
+      HIP_TRY(hipMalloc(&c->d_twt_fwd, all_f.size() * sizeof(Shoup2)));
+      HIP_TRY(hipMalloc(&c->d_twt_inv, all_i.size() * sizeof(Shoup2)));
+      HIP_TRY(hipMalloc(&c->d_tail_fwd, tail.size() * sizeof(Shoup2)));
+      HIP_TRY(hipMalloc(&c->d_sub_fold, fold.size() * sizeof(Shoup2)));
+      HIP_TRY(hipMemcpy(c->d_twt_fwd, all_f.data(), all_f.size() * sizeof(Shoup2), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(c->d_twt_inv, all_i.data(), all_i.size() * sizeof(Shoup2), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(c->d_tail_fwd, tail.data(), tail.size() * sizeof(Shoup2), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(c->d_sub_fold, fold.data(), fold.size() * sizeof(Shoup2), hipMemcpyHostToDevice));
+    }
   }
   HIP_TRY(hipMalloc(&c->d_pc, sizeof(PrimeConst) * nprimes));
   HIP_TRY(hipMemcpy(c->d_pc, c->pc.data(), sizeof(PrimeConst) * nprimes, hipMemcpyHostToDevice));
@@ -204,7 +245,7 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_mid) hipEventDestroy(c->ev_mid);
   for (int i = 0; i < 10; ++i) if (c->ws[i]) hipFree(c->ws[i]);
-  hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv);
+  hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv); hipFree(c->d_tail_fwd); hipFree(c->d_sub_fold);
   hipFree(c->d_zms_idx); hipFree(c->d_zms_list);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);

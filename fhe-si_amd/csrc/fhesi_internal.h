@@ -75,6 +75,11 @@ struct fhesi_ctx {
   Shoup2* d_tw_inv = nullptr;          // [L][phim]  psi^-brv(i)    (pow2)
   Shoup2* d_twt_fwd = nullptr;         // [L][phim]  same values in the tile kernel's permuted order (ntt_tile.inc), logn 11..14
   Shoup2* d_twt_inv = nullptr;
+  // two-pass transforms, logn 15..17 (s0 = logn-14): d_twt_fwd = [L][2^14] table of the ring with root psi^(2^s0),
+  // d_twt_inv = [L][2^s0][2^14] per-sub-transform slices, d_tail_fwd = [L][phim] twiddles of ntt_fwd_tail,
+  // d_sub_fold = [L][2^s0] {1/n * inverse twiddle of stage s0, 63-bit quotient}
+  Shoup2* d_tail_fwd = nullptr;
+  Shoup2* d_sub_fold = nullptr;
   int* d_zms_idx = nullptr;            // [m]
   int* d_zms_list = nullptr;           // [phim] ascending elements of Z_m^*
   BluesteinTables* blue = nullptr;

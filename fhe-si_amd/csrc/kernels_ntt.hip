@@ -11,8 +11,10 @@
 //   * ntt_*_tile: the tuned path, n = 2^11..2^14.  One workgroup per row, n/32 threads, 32 residues per thread in
 //     registers, radix-32 register passes (5+5+rest stages) separated by two LDS exchanges; coalesced row loads/stores,
 //     the bit-reversal permutation is absorbed by the exchange addressing.
-//   * ntt_*_lds: generic radix-2 LDS path for every other power of two (n = 2 .. 2^14 per block); rows larger than 2^14
-//     run their outer stages through global-memory stage kernels first (n = 2^15, 2^16, 2^17: Bluestein sizes, stress config).
+//   * n = 2^15..2^17 (stress config, Bluestein convolution sizes): two passes, 2^(logn-14) tile sub-transforms per row and a
+//     tail kernel for the remaining stages (ntt_*_tail below, TileBig in ntt_tile.inc).
+//   * ntt_*_lds: generic radix-2 LDS path for every other power of two (up to 2^14 residues per block; rows above 2^17 run
+//     their outer stages through global-memory stage kernels first).
 #include "fhesi_internal.h"
 
 #define NTT_LDS_MAX_LOG 14
@@ -185,6 +187,106 @@ __global__ void __launch_bounds__(256) bitrev_rows(const u64* __restrict__ src, 
 // ------------------------------------------------------------------------------------------ tuned register-tile kernels
 #include "ntt_tile.inc"
 
+// ------------------------------------------------------------------------------------------ tails of the two-pass transforms
+// Rows of n = 2^(14+S0): the S0 stages the 2^14-point tile sub-transforms leave over.  One thread owns the 2^S0 residues
+// {j1 + 2^14 h}; loads and stores are contiguous across j1, rows are taken prime-major so the tail twiddles stay in L2.
+//
+// Forward (decimation in time).  F(M,c) = negacyclic transform of a[i*(n/M)+c] with root psi^(n/M):
+//   F(M,c)[j]       = F(M/2,c)[j] + psi_M^(2j+1) F(M/2,c+n/M)[j]
+//   F(M,c)[j + M/2] = F(M/2,c)[j] - psi_M^(2j+1) F(M/2,c+n/M)[j]          j < M/2
+// src holds F(2^14,k2) at [row][k2][j1]; stage s = 1..S0 builds M = 2^(14+s).  tail_tw: per prime, stage s at offset
+// 2^14 (2^(s-1) - 1), entry j = psi_M^(2j+1), j < M/2.  src == dst is allowed (a thread reads what it writes).
+template <int S0>
+__global__ void __launch_bounds__(256) ntt_fwd_tail(const u64* src, u64* dst, i64 count, int nslots, int slot0,
+                                                    const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs,
+                                                    const Shoup2* __restrict__ tail_tw) {
+  constexpr int N2 = 1 << S0, LOGN = 14 + S0;
+  const u32 rb = blockIdx.x >> 6;
+  const u32 j1 = ((blockIdx.x & 63) << 8) | threadIdx.x;
+  const int slot = (int)(rb / (u32)count) + slot0;
+  const i64 row = (i64)(rb % (u32)count) * nslots + slot;
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const u64 q = pcs[prime].q, two_q = pcs[prime].two_q;
+  const Shoup2* __restrict__ tw = tail_tw + ((i64)prime << LOGN) + j1;
+  const i64 base = (row << LOGN) + j1;
+  u64 v[N2];
+#pragma unroll
+  for (int k = 0; k < N2; ++k) v[k] = src[base + ((i64)k << 14)];
+#pragma unroll
+  for (int s = 1; s <= S0; ++s) {
+    const int C = 1 << (S0 - s + 1), H = 1 << (s - 1);     // v[h*C + c] = F(2^(13+s), c)[j1 + 2^14 h]
+    u64 nv[N2];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const Shoup2 w = tw[(i64)(H - 1 + h) << 14];
+#pragma unroll
+      for (int c = 0; c < C / 2; ++c) {
+        u64 X = v[h * C + c], Y = v[h * C + c + C / 2];
+        bfly_fwd(X, Y, w.w, w.wp, q, two_q);
+        nv[h * (C / 2) + c] = X;
+        nv[(h + H) * (C / 2) + c] = Y;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N2; ++k) v[k] = nv[k];
+  }
+#pragma unroll
+  for (int h = 0; h < N2; ++h) dst[base + ((i64)h << 14)] = norm4(v[h], q, two_q);
+}
+
+// Inverse: stages S0-1 .. 0 of the Gentleman-Sande network (partner distance 2^(14+S0-1-s), twiddle tw_inv[2^s + block],
+// uniform per thread); the 1/n scaling was folded into the sub-transforms' last stage.
+template <int S0>
+__global__ void __launch_bounds__(256) ntt_inv_tail(const u64* src, u64* dst, i64 count, int nslots,
+                                                    const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs,
+                                                    const Shoup2* __restrict__ tw_all) {
+  constexpr int N2 = 1 << S0, LOGN = 14 + S0;
+  const u32 rb = blockIdx.x >> 6;
+  const u32 j1 = ((blockIdx.x & 63) << 8) | threadIdx.x;
+  const int slot = (int)(rb / (u32)count);
+  const i64 row = (i64)(rb % (u32)count) * nslots + slot;
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const u64 q = pcs[prime].q, two_q = pcs[prime].two_q;
+  const Shoup2* __restrict__ tw = tw_all + ((i64)prime << LOGN);
+  const i64 base = (row << LOGN) + j1;
+  u64 v[N2];
+#pragma unroll
+  for (int h = 0; h < N2; ++h) v[h] = src[base + ((i64)h << 14)];
+#pragma unroll
+  for (int s = S0 - 1; s >= 0; --s) {
+    const int dist = 1 << (S0 - 1 - s);
+#pragma unroll
+    for (int h = 0; h < N2; ++h) {
+      if (h & dist) continue;
+      const Shoup2 w = tw[(1 << s) + (h >> (S0 - s))];
+      bfly_inv(v[h], v[h + dist], w.w, w.wp, q, two_q);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < N2; ++h) dst[base + ((i64)h << 14)] = norm2(v[h], q);
+}
+
+static int launch_fwd_tail(fhesi_ctx* ctx, const u64* src, u64* dst, i64 count, int nslots, int slot0, int nslot_launch, const int* d_pos) {
+  const unsigned grid = (unsigned)(count * nslot_launch) << 6;
+  switch (ctx->logn - 14) {
+    case 1: ntt_fwd_tail<1><<<grid, 256, 0, ctx->stream>>>(src, dst, count, nslots, slot0, d_pos, ctx->d_pc, ctx->d_tail_fwd); break;
+    case 2: ntt_fwd_tail<2><<<grid, 256, 0, ctx->stream>>>(src, dst, count, nslots, slot0, d_pos, ctx->d_pc, ctx->d_tail_fwd); break;
+    default: ntt_fwd_tail<3><<<grid, 256, 0, ctx->stream>>>(src, dst, count, nslots, slot0, d_pos, ctx->d_pc, ctx->d_tail_fwd); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static int launch_inv_tail(fhesi_ctx* ctx, const u64* src, u64* dst, i64 count, int nslots, const int* d_pos) {
+  const unsigned grid = (unsigned)(count * nslots) << 6;
+  switch (ctx->logn - 14) {
+    case 1: ntt_inv_tail<1><<<grid, 256, 0, ctx->stream>>>(src, dst, count, nslots, d_pos, ctx->d_pc, ctx->d_tw_inv); break;
+    case 2: ntt_inv_tail<2><<<grid, 256, 0, ctx->stream>>>(src, dst, count, nslots, d_pos, ctx->d_pc, ctx->d_tw_inv); break;
+    default: ntt_inv_tail<3><<<grid, 256, 0, ctx->stream>>>(src, dst, count, nslots, d_pos, ctx->d_pc, ctx->d_tw_inv); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 static int lds_threads(int logb) { int t = 1 << (logb > 0 ? logb - 1 : 0); return t > 1024 ? 1024 : (t < 64 ? 64 : t); }
 
@@ -196,6 +298,12 @@ int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   u64 skip_q = 0;
   if (bitrev && ntt_tile_supported(logn)) {
     return launch_ntt_fwd_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);     // (rows of small primes: its EXACT instantiation)
+  }
+  if (bitrev && ntt_tile2_supported(logn)) {
+    void* tmp;
+    FHESI_TRY(ws_reserve(ctx, 6, (size_t)nrows << (logn + 3), &tmp));
+    FHESI_TRY(launch_tile_big(ctx, true, d_rows, (u64*)tmp, nrows, nslots, d_prime_of_slot));
+    return launch_fwd_tail(ctx, (const u64*)tmp, d_rows, count, nslots, 0, nslots, d_prime_of_slot);
   }
   const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
   for (int st = 0; st < logn - logb; ++st) {
@@ -231,6 +339,12 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   if (bitrev && ntt_tile_supported(logn)) {
     return launch_ntt_inv_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
   }
+  if (bitrev && ntt_tile2_supported(logn)) {
+    void* tmp;
+    FHESI_TRY(ws_reserve(ctx, 6, (size_t)nrows << (logn + 3), &tmp));
+    FHESI_TRY(launch_tile_big(ctx, false, d_rows, (u64*)tmp, nrows, nslots, d_prime_of_slot));
+    return launch_inv_tail(ctx, (const u64*)tmp, d_rows, count, nslots, d_prime_of_slot);
+  }
   const int logb = logn > NTT_LDS_MAX_LOG ? NTT_LDS_MAX_LOG : logn;
   const size_t shmem = sizeof(u64) << logb;
   const unsigned grid = (unsigned)(nrows << (logn - logb));
@@ -260,12 +374,17 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
 int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_out_rows, int slot0, int nslot) {
   if (nslot <= 0) { slot0 = 0; nslot = ctx->L; }
   if (!npolys) return 0;
-  if (!ntt_tile_supported(ctx->logn) || digit_bits >= 32) {      // generic sizes: separate digit kernel, then the row transform
+  const bool two_pass = ntt_tile2_supported(ctx->logn);
+  if (!(ntt_tile_supported(ctx->logn) || two_pass) || digit_bits >= 32) {      // generic sizes: separate digit kernel, then the row transform
     FHESI_TRY(launch_digits(ctx, d_parts, nl, logQ, digit_bits, nd, npolys, d_out_rows));
     return launch_ntt_fwd(ctx, d_out_rows, npolys * nd, ctx->L, nullptr, true);
   }
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * nslot));
   const DigitSrc ds{d_parts, nl, digit_bits, nd, slot0};
+  if (two_pass) {      // sub-transforms straight from the parts into the rows, tail in place
+    FHESI_TRY(launch_tile_big_digits(ctx, ds, npolys * nd, d_out_rows, nslot));
+    return launch_fwd_tail(ctx, d_out_rows, d_out_rows, npolys * nd, ctx->L, slot0, nslot, nullptr);
+  }
   switch (ctx->logn) {
     case 11: FHESI_TRY(launch_tile_digits<11>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
     case 12: FHESI_TRY(launch_tile_digits<12>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;

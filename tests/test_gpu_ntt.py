@@ -9,14 +9,14 @@ import params as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("logn", [1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("logn", [1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_rows_fwd_inv_vs_oracle(logn):
     n = 1 << logn
     m = 2 * n
-    L = 3 if logn < 15 else 2
+    L = 3 if logn < 18 else 2
     primes, roots = P.first_primes(m, L)
-    if logn <= 12:     # also a small / odd-sized prime, like the last prime of a chain (FHEContext.cpp:101-107)
-        small, sroots = P.first_primes(m, 1, sp_nbits=max(20, logn + 4))
+    if logn <= 12 or 15 <= logn <= 17:     # also a small / odd-sized prime, like the last prime of a chain (FHEContext.cpp:101-107)
+        small, sroots = P.first_primes(m, 1, sp_nbits=max(20, logn + (4 if logn <= 12 else 8)))
         primes, roots = primes[:2] + small, roots[:2] + sroots
     ctx = F.Context(m, primes, roots)
     orc = O.Oracle(m, primes, roots)
