@@ -371,3 +371,40 @@ void orc_ct_mul_relin(const orc_ctx* c, const u64* ksm, const u64* a, const u64*
   orc_apply_key_switch(c, ksm, tprod, 3, logQ, decomp_bytes, out, nlimbs);
   free(tprod);
 }
+
+/* ------------------------------------------------------------------ ciphertext algebra used by Matrix<Ciphertext> / Regression */
+/* Ciphertext::operator+= on unscaled ciphertexts (Ciphertext.cpp:123-134): parts add + ReduceCoefficients.  a, b: [nparts][phim][nlimbs] */
+void orc_ct_add(const orc_ctx* c, u64* a, const u64* b, int nparts, int nlimbs, int logQ) {
+  i64 n = c->phim; int W = nlimbs + 1; u64 x[W], y[W];
+  for (i64 j = 0; j < (i64)nparts * n; j++) { bn_copy_ext(x, W, a + j * nlimbs, nlimbs); bn_copy_ext(y, W, b + j * nlimbs, nlimbs); bn_add(x, y, W); reduce_logq(x, W, logQ, 0); memcpy(a + j * nlimbs, x, 8 * nlimbs); }
+}
+/* Ciphertext::operator*=(long) on an unscaled ciphertext (Ciphertext.cpp:232-237, CiphertextPart::operator*= :21-27) */
+void orc_ct_mul_long(const orc_ctx* c, u64* a, i64 l, int nparts, int nlimbs, int logQ) {
+  i64 n = c->phim; int W = nlimbs + 2; u64 x[W]; u64 mag = l < 0 ? (u64)(-(l + 1)) + 1 : (u64)l;
+  for (i64 j = 0; j < (i64)nparts * n; j++) { bn_copy_ext(x, W, a + j * nlimbs, nlimbs); int s = bn_sign(x, W); if (s) bn_neg(x, W); bn_mul_u64(x, mag, W); if (s != (l < 0)) bn_neg(x, W);
+    reduce_logq(x, W, logQ, 0); memcpy(a + j * nlimbs, x, 8 * nlimbs); }
+}
+/* Ciphertext::operator>>= on an unscaled ciphertext (Ciphertext.cpp:264-269; CiphertextPart::operator>>= :54-59):
+ * DoubleCRT(poly) >>= k; toPoly.  in: [nparts][phim][nlimbs], out: [nparts][phim][nlimbs_out] (centred modulo the chain) */
+int orc_ct_automorph(const orc_ctx* c, const u64* in, i64 k, int nparts, int nlimbs, u64* out, int nlimbs_out) {
+  i64 n = c->phim; i64 rs = (i64)c->L * n; u64* rows = malloc(8 * rs); int rc = 0;
+  for (int i = 0; i < nparts && !rc; i++) { orc_dcrt_from_poly(c, in + (i64)i * n * nlimbs, nlimbs, n, rows); rc = orc_dcrt_automorph(c, rows, k);
+    if (!rc) orc_dcrt_to_poly(c, rows, NULL, 0, 0, out + (i64)i * n * nlimbs_out, nlimbs_out); }
+  free(rows); return rc;
+}
+/* KeySwitchSI::ApplyKeySwitch (FHE-SI.cpp:241-260) on an UNSCALED ciphertext of ncomp parts: ScaleDown returns at once
+ * (Ciphertext.cpp:195), ByteDecomp takes the positive residue mod 2^logQ (:94).  parts: [ncomp][phim][nlimbs_in] */
+void orc_apply_key_switch_parts(const orc_ctx* c, const u64* ksm, const u64* parts, int ncomp, int nlimbs_in, int logQ, int decomp_bytes, u64* out, int nlimbs) {
+  i64 n = c->phim; i64 rs = (i64)c->L * n; int nd = (logQ + 8 * decomp_bytes - 1) / (8 * decomp_bytes); int ncol = ncomp * nd;
+  u64* dig = malloc(8 * (i64)ncol * n); u64* bd = malloc(8 * (i64)ncol * rs); u64* acc = malloc(8 * rs); u64* tmp = malloc(8 * rs);
+  for (int i = 0; i < ncomp; i++) orc_byte_decomp_part(parts + (i64)i * n * nlimbs_in, n, nlimbs_in, logQ, nd, decomp_bytes, dig + (i64)i * nd * n);
+  for (int k = 0; k < ncol; k++) orc_dcrt_from_poly(c, dig + (i64)k * n, 1, n, bd + (i64)k * rs);
+  int W = c->L + 3; u64* big = malloc(8 * n * W);
+  for (int r = 0; r < 2; r++) { const u64* key = ksm + (i64)r * ncol * rs;
+    memcpy(acc, key, 8 * rs); orc_dcrt_op(c, acc, bd, 2);
+    for (int k = 1; k < ncol; k++) { memcpy(tmp, key + (i64)k * rs, 8 * rs); orc_dcrt_op(c, tmp, bd + (i64)k * rs, 2); orc_dcrt_op(c, acc, tmp, 0); }
+    orc_dcrt_to_poly(c, acc, NULL, 0, 0, big, W);
+    for (i64 j = 0; j < n; j++) { reduce_logq(big + j * W, W, logQ, 0); bn_copy_ext(out + ((i64)r * n + j) * nlimbs, nlimbs, big + j * W, W); }
+  }
+  free(dig); free(bd); free(acc); free(tmp); free(big);
+}

@@ -659,6 +659,103 @@ def key_switch_init_s2(ctx: Ctx, t: Sequence[int], rng: SplitMix64):
 
 
 # --------------------------------------------------------------------------------------------
+# Ciphertext algebra used by Matrix<Ciphertext> / Regression
+# --------------------------------------------------------------------------------------------
+def ct_add(ctx: Ctx, a_parts: Sequence[Sequence[int]], b_parts: Sequence[Sequence[int]]) -> List[List[int]]:
+    """Ciphertext::operator+= on unscaled ciphertexts (Ciphertext.cpp:123-134): parts add + ReduceCoefficients; extra parts of
+    the right operand are appended."""
+    out = []
+    for i in range(max(len(a_parts), len(b_parts))):
+        if i < len(a_parts) and i < len(b_parts):
+            out.append([reduce_logq(x + y, ctx.logQ) for x, y in zip(a_parts[i], b_parts[i])])
+        else:
+            out.append(list(a_parts[i] if i < len(a_parts) else b_parts[i]))
+    return out
+
+
+def ct_mul_long(ctx: Ctx, parts: Sequence[Sequence[int]], l: int) -> List[List[int]]:
+    """Ciphertext::operator*=(long) on an unscaled ciphertext (Ciphertext.cpp:232-237 -> CiphertextPart::operator*= :21-27)."""
+    return [[reduce_logq(c * l, ctx.logQ) for c in part] for part in parts]
+
+
+def tprod_mul_long(ctx: Ctx, tprod: Sequence[dict], l: int) -> List[dict]:
+    """Ciphertext::operator*=(long) on a scaled-up ciphertext (Ciphertext.cpp:238-241): DoubleCRT *= long."""
+    return [dcrt_op_scalar(ctx, t, l, "mul") for t in tprod]
+
+
+def tprod_add(ctx: Ctx, a: Sequence[dict], b: Sequence[dict]) -> List[dict]:
+    """Ciphertext::operator+= on scaled-up ciphertexts (Ciphertext.cpp:135-142)."""
+    return [dcrt_op(ctx, x, y, "add") for x, y in zip(a, b)]
+
+
+def ct_automorph(ctx: Ctx, parts: Sequence[Sequence[int]], k: int) -> List[List[int]]:
+    """Ciphertext::operator>>= on an unscaled ciphertext (Ciphertext.cpp:264-269): per part DoubleCRT(poly) >>= k; toPoly
+    (CiphertextPart::operator>>=, :54-59).  Coefficients come back centred modulo the whole chain, NOT reduced mod 2^logQ."""
+    return [dcrt_to_poly(ctx, dcrt_automorph(ctx, dcrt_from_poly(ctx, part), k)) for part in parts]
+
+
+def apply_key_switch_parts(ctx: Ctx, ksm: Sequence[Sequence[dict]], parts: Sequence[Sequence[int]]) -> List[List[int]]:
+    """KeySwitchSI::ApplyKeySwitch (FHE-SI.cpp:241-260) on an UNSCALED ciphertext: ScaleDown returns at once
+    (Ciphertext.cpp:195), ByteDecomp takes the positive residue mod 2^logQ of every coefficient (:94)."""
+    digits = byte_decomp(parts, ctx.logQ, ctx.ndigits, ctx.decomp_size)
+    bd = [dcrt_from_poly(ctx, d) for d in digits]
+    out = []
+    for r in range(len(ksm)):
+        dp = dot_product(ctx, ksm[r], bd)
+        out.append([reduce_logq(c, ctx.logQ) for c in dcrt_to_poly(ctx, dp)])
+    return out
+
+
+def key_switch_init_automorph(ctx: Ctx, t: Sequence[int], k: int, rng: SplitMix64):
+    """KeySwitchSI::InitAutomorph (FHE-SI.cpp:229-239): source key (1, t(X^k)), target key t."""
+    sample_hwt(rng, 64, ctx.phim)      # `FHESISecKey automorphedKey(context)` (:233) samples and discards a key, as in InitS2
+    one = [1] + [0] * (ctx.phim - 1)
+    src = []
+    for s in (one, list(t)):
+        src.append(dcrt_to_poly(ctx, dcrt_automorph(ctx, dcrt_from_poly(ctx, s), k)))
+    return key_switch_init(ctx, src, t, rng)
+
+
+def automorph_generators(m: int, g: int, nslots_usable: int) -> List[int]:
+    """The k sequence of Regression::Regression / SumBatchedData (Regression.h:71-80,166-178): g, g^2, g^4, ... mod m,
+    one per halving of the usable slot count."""
+    ks, k = [], g
+    while nslots_usable > 1:
+        ks.append(k)
+        nslots_usable >>= 1
+        k = (k * k) % m
+    return ks
+
+
+def sum_batched_data(ctx: Ctx, auto_ksms, ks: Sequence[int], parts: Sequence[Sequence[int]]) -> List[List[int]]:
+    """Regression::SumBatchedData (Regression.h:166-178): ct += KeySwitch_k(ct >>= k) for k = g, g^2, g^4, ..."""
+    cur = [list(part) for part in parts]
+    for ksm, k in zip(auto_ksms, ks):
+        tmp = apply_key_switch_parts(ctx, ksm, ct_automorph(ctx, cur, k))
+        cur = ct_add(ctx, cur, tmp)
+    return cur
+
+
+def total_slots(m: int, p: int) -> int:
+    """PlaintextSpace::GetTotalSlots (PlaintextSpace.cpp:29-31): number of irreducible factors of Phi_m mod p = phi(m)/ord_m(p)."""
+    phim = zms_idx(m)[1]
+    d, x = 1, p % m
+    while x != 1:
+        x = (x * p) % m
+        d += 1
+    return phim // d
+
+
+def usable_slots(m: int, p: int) -> int:
+    """PlaintextSpace::GetUsableSlots (PlaintextSpace.cpp:38-43): largest power of two <= total slots."""
+    u, t = 1, total_slots(m, p)
+    while t > 1:
+        u <<= 1
+        t >>= 1
+    return u
+
+
+# --------------------------------------------------------------------------------------------
 # BGV-style modulus switching (dead code in fhe-si -- no callers -- but part of the DoubleCRT surface, SURVEY.md a12)
 # --------------------------------------------------------------------------------------------
 def dcrt_add_primes_and_scale(ctx: Ctx, a: dict, s1: Sequence[int]) -> dict:

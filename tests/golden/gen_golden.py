@@ -170,7 +170,58 @@ def gen_ciphertext():
     dump("ciphertext.json", out)
 
 
+def gen_regression():
+    """Ciphertext algebra of Matrix<Ciphertext> / Regression (Ciphertext.cpp:21-27,54-59,123-145,232-243,264-275;
+    FHE-SI.cpp:229-260; Regression.h:166-178) with valid keys, plus the decrypt predicates that pin the semantics."""
+    cases = []
+    for m, logQ, p, g, seed in [(22, 80, 23, 7, 11), (32, 80, 17, 3, 12)]:
+        primes, roots = chain(m, logQ, p)
+        ctx = R.Ctx(m, logQ, p, primes, roots)
+        prng = R.SplitMix64(seed)
+        t, pk = R.keygen(ctx, prng)
+        n = ctx.phim
+        # (Z/32)^* is not cyclic, so the k sequence is just a few odd exponents there; for m = 22 it is Regression's own
+        ks = R.automorph_generators(m, g, R.usable_slots(m, p)) if m == 22 else [3, 9, 17]
+        auto = [R.key_switch_init_automorph(ctx, t, k, prng) for k in ks]
+        m1 = [prng.bnd(p) for _ in range(n)]
+        m2 = [prng.bnd(p) for _ in range(n)]
+        c1, c2 = R.encrypt(ctx, pk, m1, prng), R.encrypt(ctx, pk, m2, prng)
+        c1[0][0] = -(1 << (logQ - 1))          # the one value whose negation wraps (Reduce, Util.cpp:3-26)
+        added = R.ct_add(ctx, c1, c2)
+        neg = R.ct_mul_long(ctx, c1, -1)
+        tripled = R.ct_mul_long(ctx, c2, 3)
+        assert R.decrypt(ctx, t, tripled) == [(3 * x) % p for x in m2]
+        rot = R.ct_automorph(ctx, c2, ks[0])
+        sw = R.apply_key_switch_parts(ctx, auto[0], rot)
+        summed = R.sum_batched_data(ctx, auto, ks, c2)
+
+        def pt_auto(msg, k):
+            big = [0] * m
+            for i, c in enumerate(msg):
+                big[(i * k) % m] = (big[(i * k) % m] + c) % p
+            f, df = ctx.phi, len(ctx.phi) - 1
+            for i in range(m - 1, df - 1, -1):
+                c = big[i]
+                if c:
+                    for j in range(df + 1):
+                        big[i - df + j] = (big[i - df + j] - c * f[j]) % p
+            return [x % p for x in big[:df]]
+        assert R.decrypt(ctx, t, sw) == pt_auto(m2, ks[0])
+        cur = list(m2)
+        for k in ks:
+            cur = [(x + y) % p for x, y in zip(cur, pt_auto(cur, k))]
+        assert R.decrypt(ctx, t, summed) == cur
+        cases.append({"m": m, "logQ": logQ, "p": p, "g": g, "seed": seed, "primes": S(primes), "roots": S(roots), "t": S(t), "ks": ks,
+                      "m2": m2, "c1": [S(c) for c in c1], "c2": [S(c) for c in c2],
+                      "auto_ksm": [[[[S(d[i]) for i in range(ctx.L)] for d in a[r]] for r in range(2)] for a in auto],
+                      "added": [S(x) for x in added], "negated": [S(x) for x in neg], "tripled": [S(x) for x in tripled],
+                      "rotated": [S(x) for x in rot], "switched": [S(x) for x in sw], "summed": [S(x) for x in summed],
+                      "summed_plain": cur})
+    dump("regression.json", {"ct_algebra": cases})
+
+
 if __name__ == "__main__":
     gen_transforms()
     gen_dcrt()
     gen_ciphertext()
+    gen_regression()

@@ -52,6 +52,11 @@ def lib():
         _lib.orc_ct_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
         _lib.orc_apply_key_switch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _lib.orc_ct_mul_relin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+        _lib.orc_ct_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _lib.orc_ct_mul_long.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
+        _lib.orc_ct_automorph.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _lib.orc_ct_automorph.restype = C.c_int
+        _lib.orc_apply_key_switch_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     return _lib
 
 
@@ -188,6 +193,32 @@ class Oracle:
         tprod = np.ascontiguousarray(tprod, dtype=np.uint64)
         out = np.zeros((2, self.phim, nlimbs), dtype=np.uint64)
         lib().orc_apply_key_switch(self.h, _p(ksm), _p(tprod), tprod.shape[0], logQ, decomp_bytes, _p(out), nlimbs)
+        return out
+
+    # ---- ciphertext algebra of Matrix<Ciphertext> / Regression: parts are [nparts][phim][nlimbs]
+    def ct_add(self, a: np.ndarray, b: np.ndarray, logQ: int) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64, copy=True)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        lib().orc_ct_add(self.h, _p(a), _p(b), a.shape[0], a.shape[-1], logQ)
+        return a
+
+    def ct_mul_long(self, a: np.ndarray, l: int, logQ: int) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64, copy=True)
+        lib().orc_ct_mul_long(self.h, _p(a), l, a.shape[0], a.shape[-1], logQ)
+        return a
+
+    def ct_automorph(self, a: np.ndarray, k: int, nlimbs_out: int) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        out = np.zeros((a.shape[0], self.phim, nlimbs_out), dtype=np.uint64)
+        if lib().orc_ct_automorph(self.h, _p(a), k, a.shape[0], a.shape[-1], _p(out), nlimbs_out) != 0:
+            raise ValueError("k not in Zm*")
+        return out
+
+    def apply_key_switch_parts(self, ksm: np.ndarray, parts: np.ndarray, logQ: int, nlimbs: int, decomp_bytes: int = 3):
+        ksm = np.ascontiguousarray(ksm, dtype=np.uint64)
+        parts = np.ascontiguousarray(parts, dtype=np.uint64)
+        out = np.zeros((2, self.phim, nlimbs), dtype=np.uint64)
+        lib().orc_apply_key_switch_parts(self.h, _p(ksm), _p(parts), parts.shape[0], parts.shape[-1], logQ, decomp_bytes, _p(out), nlimbs)
         return out
 
     def ct_mul_relin(self, ksm: np.ndarray, a: np.ndarray, b: np.ndarray, logQ: int, p: int, decomp_bytes: int = 3):
