@@ -29,6 +29,8 @@ ABI_SYMBOLS = [
     "fhesi_ksk_upload", "fhesi_ksk_device_ptr", "fhesi_ksk_bytes", "fhesi_ct_mul_relin_batch", "fhesi_ct_mul_relin_batch_dev",
     "fhesi_ct_mul_dev", "fhesi_apply_key_switch_dev", "fhesi_dev_alloc", "fhesi_dev_free", "fhesi_dev_upload", "fhesi_dev_download",
     "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
+    "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
+    "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -101,6 +103,13 @@ def _load():
         "fhesi_ct_mul_relin_batch_dev": [_vp, _vp, _i32, _u64, _i32, _vp, _vp, _vp, _i32, _i64],
         "fhesi_ct_mul_dev": [_vp, _u64, _vp, _vp, _i32, _i64, _vp],
         "fhesi_apply_key_switch_dev": [_vp, _vp, _i32, _i32, _vp, _i64, _vp, _i32],
+        "fhesi_ct_add_dev": [_vp, _i32, _vp, _vp, _i32, _i32, _i64],
+        "fhesi_ct_mul_long_dev": [_vp, _i32, _vp, _i64, _i32, _i32, _i64],
+        "fhesi_rows_mul_long_dev": [_vp, _vp, _i64, _i64],
+        "fhesi_ct_automorph_dev": [_vp, _i64, _vp, _i32, _i32, _i64, _vp, _i32],
+        "fhesi_ct_automorph_key_switch_dev": [_vp, _vp, _i32, _i32, _i64, _vp, _i32, _i64, _vp, _i32],
+        "fhesi_ct_gather_dev": [_vp, _vp, _vp, _i64, _i64, _vp],
+        "fhesi_ct_mul_sum_relin_dev": [_vp, _vp, _i32, _u64, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp],
         "fhesi_dev_alloc": [_vp, C.c_size_t, _vp],
         "fhesi_dev_free": [_vp, _vp],
         "fhesi_dev_upload": [_vp, _vp, _vp, C.c_size_t],
@@ -271,6 +280,35 @@ class Context:
 
     def apply_key_switch_dev(self, ksk: "KeySwitchMatrix", logQ: int, tprod: DevBuf, count: int, out: DevBuf, nlimbs: int, decomp_bytes: int = 3):
         _ck(_load().fhesi_apply_key_switch_dev(self.h, ksk.h, logQ, decomp_bytes, tprod.ptr, count, out.ptr, nlimbs))
+
+    # ---- ciphertext algebra between multiplications (Matrix<Ciphertext> / Regression), batches resident in HBM
+    def ct_add_dev(self, logQ: int, dst: DevBuf, src: DevBuf, nparts: int, nlimbs: int, count: int):
+        _ck(_load().fhesi_ct_add_dev(self.h, logQ, dst.ptr, src.ptr, nparts, nlimbs, count))
+
+    def ct_mul_long_dev(self, logQ: int, ct: DevBuf, l: int, nparts: int, nlimbs: int, count: int):
+        _ck(_load().fhesi_ct_mul_long_dev(self.h, logQ, ct.ptr, l, nparts, nlimbs, count))
+
+    def rows_mul_long_dev(self, rows: DevBuf, l: int, count: int):
+        _ck(_load().fhesi_rows_mul_long_dev(self.h, rows.ptr, l, count))
+
+    def ct_automorph_dev(self, k: int, src: DevBuf, nparts: int, nlimbs_in: int, count: int, out: DevBuf, nlimbs_out: int):
+        _ck(_load().fhesi_ct_automorph_dev(self.h, k, src.ptr, nparts, nlimbs_in, count, out.ptr, nlimbs_out))
+
+    def ct_automorph_key_switch_dev(self, ksk: "KeySwitchMatrix", logQ: int, k: int, src: DevBuf, nlimbs_in: int, count: int, out: DevBuf,
+                                    nlimbs: int, decomp_bytes: int = 3):
+        _ck(_load().fhesi_ct_automorph_key_switch_dev(self.h, ksk.h, logQ, decomp_bytes, k, src.ptr, nlimbs_in, count, out.ptr, nlimbs))
+
+    def ct_gather_dev(self, pool: DevBuf, idx, words: int, out: DevBuf):
+        ia = np.ascontiguousarray(idx, dtype=np.int32)
+        _ck(_load().fhesi_ct_gather_dev(self.h, pool.ptr, _p(ia), len(ia), words, out.ptr))
+
+    def ct_mul_sum_relin_dev(self, ksk: "KeySwitchMatrix", logQ: int, p: int, pool: DevBuf, nlimbs: int, a_idx, b_idx, seg, out: DevBuf,
+                             decomp_bytes: int = 3):
+        """out[g] = KeySwitch(sum_{t in [seg[g], seg[g+1])} pool[a_idx[t]] * pool[b_idx[t]]): one wave of Matrix<Ciphertext> products."""
+        ia, ib = np.ascontiguousarray(a_idx, dtype=np.int32), np.ascontiguousarray(b_idx, dtype=np.int32)
+        sg = np.ascontiguousarray(seg, dtype=np.int32)
+        assert len(ia) == len(ib) == int(sg[-1]) and sg[0] == 0
+        _ck(_load().fhesi_ct_mul_sum_relin_dev(self.h, ksk.h, logQ, p, decomp_bytes, pool.ptr, nlimbs, _p(ia), _p(ib), _p(sg), len(sg) - 1, out.ptr))
 
     def ct_mul_relin_dev(self, ksk: "KeySwitchMatrix", logQ: int, p: int, a: DevBuf, b: DevBuf, out: DevBuf, nlimbs: int, count: int, decomp_bytes: int = 3):
         _ck(_load().fhesi_ct_mul_relin_batch_dev(self.h, ksk.h, logQ, p, decomp_bytes, a.ptr, b.ptr, out.ptr, nlimbs, count))

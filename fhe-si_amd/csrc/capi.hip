@@ -726,6 +726,7 @@ extern "C" void* fhesi_ksk_device_ptr(fhesi_ksk* k) { return k ? k->d_rows : nul
 extern "C" size_t fhesi_ksk_bytes(const fhesi_ksk* k) { return k ? k->bytes : 0; }
 
 // --------------------------------------------------------------------------------------------- ciphertext pipeline
+static i64 batch_chunk(const fhesi_ctx* c, int ncol);
 static std::vector<int> full_set(const fhesi_ctx* c) { std::vector<int> v(c->L); for (int i = 0; i < c->L; ++i) v[i] = i; return v; }
 
 extern "C" int fhesi_ct_mul_dev(fhesi_ctx* c, uint64_t p, const uint64_t* a, const uint64_t* b, int32_t nlimbs, int64_t count, uint64_t* tprod) {
@@ -748,42 +749,205 @@ extern "C" int fhesi_ct_mul_dev(fhesi_ctx* c, uint64_t p, const uint64_t* a, con
   return 0;
 }
 
-extern "C" int fhesi_apply_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, const uint64_t* tprod, int64_t count,
-                                          uint64_t* out, int32_t nlimbs) {
-  CHECK_CTX(c);
+// ByteDecomp + DoubleCRT(digit polys) + DotProduct + toPoly + ReduceCoefficients (FHE-SI.cpp:244-256) from parts that are already
+// positive residues mod 2^logQ in limb-major layout [count*ncomp][nlq][n].  d_t: scratch for count*2 DoubleCRTs.
+static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, const u64* d_parts, int64_t count, u64* d_t,
+                           uint64_t* out, int32_t nlimbs) {
+  const i64 n = c->phim;
+  const int L = c->L, ncomp = k->ncomp, nd = k->ndigits, ncol = ncomp * nd, nlq = (logQ + 63) / 64;
+  const std::vector<int> all = full_set(c);
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, all, &t));
+  // ByteDecomp + DoubleCRT(digit polys)   (Ciphertext.cpp:82-121, FHE-SI.cpp:244-249)
+  void* d_dig;
+  FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * L * n * 8, &d_dig));
+  if (c->pow2) FHESI_TRY(launch_ntt_fwd_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
+  else {
+    FHESI_TRY(launch_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
+    FHESI_TRY(row_fwd(c, (u64*)d_dig, count * ncol, L, nullptr, all.data()));
+  }
+  if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
+  // DotProduct with both key rows (FHE-SI.cpp:251-254)
+  FHESI_TRY(launch_dot_accum(c, k->d_rows, (const u64*)d_dig, ncol, count, d_t));
+  // toPoly + ReduceCoefficients (FHE-SI.cpp:255-256)
+  FHESI_TRY(row_inv(c, d_t, count * 2, L, nullptr, all.data()));
+  FHESI_TRY(launch_crt(c, t, d_t, L, nullptr, count * 2, 2, 0, logQ, (u64*)out, nlimbs));
+  return 0;
+}
+
+static int key_switch_args(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, int32_t nlimbs) {
   if (!k || k->ctx != c) FHESI_FAIL("KeySwitchSI: context mismatch");            // FHE-SI.cpp:279-281
   if (decomp_bytes < 1 || decomp_bytes > 7) FHESI_FAIL("decompSize %d not supported", decomp_bytes);
   const int nd = (logQ + 8 * decomp_bytes - 1) / (8 * decomp_bytes);            // FHEContext.h:115
   if (nd != k->ndigits) FHESI_FAIL("KeySwitchSI: matrix has %d digits per component, context needs %d", k->ndigits, nd);
   if (nlimbs * 64 < logQ) FHESI_FAIL("output coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  return 0;
+}
+
+extern "C" int fhesi_apply_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, const uint64_t* tprod, int64_t count,
+                                          uint64_t* out, int32_t nlimbs) {
+  CHECK_CTX(c);
+  FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
   if (!count) return 0;
   const i64 n = c->phim;
-  const int L = c->L, ncomp = k->ncomp, ncol = ncomp * nd, nlq = (logQ + 63) / 64;
+  const int L = c->L, ncomp = k->ncomp, nlq = (logQ + 63) / 64;
   const std::vector<int> all = full_set(c);
   CrtTables* t;
   FHESI_TRY(get_crt_tables(c, all, &t));
   // ScaleDown (Ciphertext.cpp:194-218): toPoly + round(x/q) + Reduce, kept as positive residues for ByteDecomp
   void* d_t;
-  FHESI_TRY(ws_reserve(c, 1, (size_t)count * ncomp * L * n * 8, &d_t));
+  FHESI_TRY(ws_reserve(c, 1, (size_t)count * (ncomp > 2 ? ncomp : 2) * L * n * 8, &d_t));
   HIP_TRY(hipMemcpyAsync(d_t, tprod, (size_t)count * ncomp * L * n * 8, hipMemcpyDeviceToDevice, c->stream));
   FHESI_TRY(row_inv(c, (u64*)d_t, count * ncomp, L, nullptr, all.data()));
   void* d_parts;
   FHESI_TRY(ws_reserve(c, 2, (size_t)count * ncomp * nlq * n * 8, &d_parts));
   FHESI_TRY(launch_crt(c, t, (const u64*)d_t, L, nullptr, count * ncomp, 1, 0, logQ, (u64*)d_parts, nlq));
-  // ByteDecomp + DoubleCRT(digit polys)   (Ciphertext.cpp:82-121, FHE-SI.cpp:244-249)
-  void* d_dig;
-  FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * L * n * 8, &d_dig));
-  if (c->pow2) FHESI_TRY(launch_ntt_fwd_digits(c, (const u64*)d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
-  else {
-    FHESI_TRY(launch_digits(c, (const u64*)d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
-    FHESI_TRY(row_fwd(c, (u64*)d_dig, count * ncol, L, nullptr, all.data()));
+  return key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, count, (u64*)d_t, out, nlimbs);
+}
+
+// Ciphertext::operator>>= (Ciphertext.cpp:264-269 -> CiphertextPart::operator>>= :54-59: DoubleCRT(poly) >>= k; toPoly) for a batch
+// of unscaled ciphertexts, rows left in d_rows [count*nparts][L][n] in coefficient (post-iFFT) form ready for the CRT.
+static int automorph_rows(fhesi_ctx* c, int64_t kk, const uint64_t* in, int32_t nparts, int32_t nlimbs_in, int64_t count, u64** d_rows_out) {
+  const i64 n = c->phim, m = c->m;
+  if (kk <= 0 || kk >= m || c->zms_idx[kk] < 0) FHESI_FAIL("automorph: k=%lld is not in Zm*", (long long)kk);     // DoubleCRT.cpp:442-443
+  const int L = c->L;
+  const std::vector<int> all = full_set(c);
+  const i64 nrows = count * nparts * L;
+  void *d_a, *d_b;
+  FHESI_TRY(ws_reserve(c, 3, (size_t)nrows * n * 8, &d_a));
+  FHESI_TRY(ws_reserve(c, 1, (size_t)(nrows > count * 2 * L ? nrows : count * 2 * L) * n * 8, &d_b));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)in, nlimbs_in, n, count, nparts, nullptr, (u64*)d_a, L, nullptr));
+  FHESI_TRY(row_fwd(c, (u64*)d_a, count * nparts, L, nullptr, all.data()));
+  FHESI_TRY(launch_automorph(c, (u64*)d_b, (const u64*)d_a, nrows, kk));
+  FHESI_TRY(row_inv(c, (u64*)d_b, count * nparts, L, nullptr, all.data()));
+  *d_rows_out = (u64*)d_b;
+  return 0;
+}
+
+extern "C" int fhesi_ct_automorph_dev(fhesi_ctx* c, int64_t kk, const uint64_t* in, int32_t nparts, int32_t nlimbs_in, int64_t count, uint64_t* out,
+                                      int32_t nlimbs_out) {
+  CHECK_CTX(c);
+  if (nparts < 1 || nlimbs_in < 1 || nlimbs_out < 1) FHESI_FAIL("Ciphertext >>= : bad shape");
+  if (!count) return 0;
+  u64* d_rows;
+  FHESI_TRY(automorph_rows(c, kk, in, nparts, nlimbs_in, count, &d_rows));
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, full_set(c), &t));
+  return launch_crt(c, t, d_rows, c->L, nullptr, count * nparts, 0, 0, 0, (u64*)out, nlimbs_out);
+}
+
+extern "C" int fhesi_ct_automorph_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, int64_t kk, const uint64_t* in,
+                                                 int32_t nlimbs_in, int64_t count, uint64_t* out, int32_t nlimbs) {
+  CHECK_CTX(c);
+  FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
+  if (nlimbs_in < 1) FHESI_FAIL("Ciphertext >>= : bad shape");
+  if (!count) return 0;
+  const i64 n = c->phim;
+  const int ncomp = k->ncomp, nlq = (logQ + 63) / 64;
+  void* d_parts;
+  FHESI_TRY(ws_reserve(c, 2, (size_t)count * ncomp * nlq * n * 8, &d_parts));
+  u64* d_rows;
+  if (kk == 1) {
+    // no automorphism: ApplyKeySwitch on the unscaled ciphertext as it is; ByteDecomp needs the positive residues limb-major
+    FHESI_TRY(automorph_rows(c, 1, in, ncomp, nlimbs_in, count, &d_rows));
+  } else {
+    FHESI_TRY(automorph_rows(c, kk, in, ncomp, nlimbs_in, count, &d_rows));
   }
-  if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
-  // DotProduct with both key rows (FHE-SI.cpp:251-254)
-  FHESI_TRY(launch_dot_accum(c, k->d_rows, (const u64*)d_dig, ncol, count, (u64*)d_t));
-  // toPoly + ReduceCoefficients (FHE-SI.cpp:255-256)
-  FHESI_TRY(row_inv(c, (u64*)d_t, count * 2, L, nullptr, all.data()));
-  FHESI_TRY(launch_crt(c, t, (const u64*)d_t, L, nullptr, count * 2, 2, 0, logQ, (u64*)out, nlimbs));
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, full_set(c), &t));
+  // toPoly (centred modulo the whole chain), then Reduce(..., positive) of ByteDecompPart (Ciphertext.cpp:94)
+  FHESI_TRY(launch_crt(c, t, d_rows, c->L, nullptr, count * ncomp, 3, 0, logQ, (u64*)d_parts, nlq));
+  return key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, count, d_rows, out, nlimbs);
+}
+
+// ---- coefficient-domain ciphertext algebra on device batches (kernels_ct.hip)
+extern "C" int fhesi_ct_add_dev(fhesi_ctx* c, int32_t logQ, uint64_t* dst, const uint64_t* src, int32_t nparts, int32_t nlimbs, int64_t count) {
+  CHECK_CTX(c);
+  if (nparts < 1 || nlimbs < 1 || logQ < 1 || nlimbs * 64 < logQ) FHESI_FAIL("Ciphertext += : coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  return launch_ct_add(c, (u64*)dst, (const u64*)src, count * nparts * c->phim, nlimbs, logQ);
+}
+extern "C" int fhesi_ct_mul_long_dev(fhesi_ctx* c, int32_t logQ, uint64_t* ct, int64_t l, int32_t nparts, int32_t nlimbs, int64_t count) {
+  CHECK_CTX(c);
+  if (nparts < 1 || nlimbs < 1 || logQ < 1 || nlimbs * 64 < logQ) FHESI_FAIL("Ciphertext *= long: coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  return launch_ct_mul_long(c, (u64*)ct, count * nparts * c->phim, nlimbs, logQ, l);
+}
+extern "C" int fhesi_rows_mul_long_dev(fhesi_ctx* c, uint64_t* rows, int64_t l, int64_t count) {
+  CHECK_CTX(c);
+  if (!count) return 0;
+  std::vector<u64> sc(c->L);
+  for (int i = 0; i < c->L; ++i) { const u64 q = c->q[i]; sc[i] = l >= 0 ? (u64)l % q : (q - ((u64)(-(l + 1)) + 1) % q) % q; }
+  void* d_sc;
+  FHESI_TRY(ws_reserve(c, 9, sizeof(u64) * 64, &d_sc));
+  HIP_TRY(hipMemcpyAsync(d_sc, sc.data(), sizeof(u64) * c->L, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));        // sc lives on this stack frame
+  return launch_ew_scalar(c, (u64*)rows, (const u64*)d_sc, count, c->L, nullptr, FHESI_OP_MUL);
+}
+extern "C" int fhesi_ct_gather_dev(fhesi_ctx* c, const uint64_t* pool, const int32_t* idx_host, int64_t count, int64_t words, uint64_t* out) {
+  CHECK_CTX(c);
+  if (!count) return 0;
+  void* d_idx;
+  FHESI_TRY(ws_reserve(c, 8, sizeof(int) * (size_t)count, &d_idx));
+  HIP_TRY(hipMemcpyAsync(d_idx, idx_host, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));        // the caller's index array may be reused as soon as we return
+  return launch_gather(c, (const u64*)pool, (const int*)d_idx, count, words, (u64*)out);
+}
+
+// One wave of Matrix<Ciphertext> arithmetic followed by the key switch (see include/fhesi_hip.h)
+extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* pool,
+                                          int32_t nlimbs, const int32_t* a_idx, const int32_t* b_idx, const int32_t* seg, int64_t ngroups, uint64_t* out) {
+  CHECK_CTX(c);
+  FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
+  if (k->ncomp != 3) FHESI_FAIL("ct_mul_sum_relin needs the s^2 -> s matrix (3 source components), got %d", k->ncomp);
+  if (!ngroups) return 0;
+  for (i64 g = 0; g < ngroups; ++g) if (seg[g + 1] <= seg[g]) FHESI_FAIL("ct_mul_sum_relin: group %lld is empty", (long long)g);
+  const i64 n = c->phim;
+  const int L = c->L;
+  const i64 ct_words = (i64)2 * n * nlimbs, tp_words = (i64)3 * L * n;
+  const i64 chunk = batch_chunk(c, 3 * k->ndigits);           // ciphertexts per key-switch call / products per tensor call
+  std::vector<int> lseg;
+  i64 g = 0;
+  while (g < ngroups) {
+    // groups g..g2-1 whose products fit one tensor call; a single larger group is accumulated piecewise
+    i64 g2 = g, terms = 0;
+    while (g2 < ngroups && g2 - g < chunk && (g2 == g || terms + (seg[g2 + 1] - seg[g2]) <= chunk)) { terms += seg[g2 + 1] - seg[g2]; ++g2; }
+    const i64 ng = g2 - g;
+    void *d_ab, *d_tp, *d_sum, *d_seg;
+    FHESI_TRY(ws_reserve(c, 4, (size_t)(ng + 1) * tp_words * 8, &d_sum));     // (+1: partial sum of an oversized group)
+    const i64 t0 = seg[g], t1 = seg[g2];
+    for (i64 done = t0; done < t1; done += chunk) {
+      const i64 cnt = std::min(chunk, t1 - done);
+      FHESI_TRY(ws_reserve(c, 7, (size_t)cnt * ct_words * 16, &d_ab));
+      FHESI_TRY(ws_reserve(c, 5, (size_t)cnt * tp_words * 8, &d_tp));
+      uint64_t* d_a = (uint64_t*)d_ab;
+      uint64_t* d_b = d_a + (size_t)cnt * ct_words;
+      FHESI_TRY(fhesi_ct_gather_dev(c, pool, a_idx + done, cnt, ct_words, d_a));
+      FHESI_TRY(fhesi_ct_gather_dev(c, pool, b_idx + done, cnt, ct_words, d_b));
+      FHESI_TRY(fhesi_ct_mul_dev(c, p, d_a, d_b, nlimbs, cnt, (uint64_t*)d_tp));
+      if (t1 - t0 <= chunk) {
+        // tProd sums of the groups (Ciphertext::operator+= on scaled-up ciphertexts, Ciphertext.cpp:135-142)
+        lseg.resize(ng + 1);
+        for (i64 i = 0; i <= ng; ++i) lseg[i] = seg[g + i] - (int)t0;
+        FHESI_TRY(ws_reserve(c, 8, sizeof(int) * (size_t)(ng + 1), &d_seg));
+        HIP_TRY(hipMemcpyAsync(d_seg, lseg.data(), sizeof(int) * (size_t)(ng + 1), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        FHESI_TRY(launch_segment_sum(c, (const u64*)d_tp, (const int*)d_seg, ng, 3, (u64*)d_sum));
+      } else {
+        // one group with more products than a call holds: partial sums accumulate into d_sum
+        lseg = {0, (int)cnt};
+        FHESI_TRY(ws_reserve(c, 8, sizeof(int) * 2, &d_seg));
+        HIP_TRY(hipMemcpyAsync(d_seg, lseg.data(), sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (done == t0) FHESI_TRY(launch_segment_sum(c, (const u64*)d_tp, (const int*)d_seg, 1, 3, (u64*)d_sum));
+        else {
+          u64* d_part = (u64*)d_sum + (size_t)ng * tp_words;
+          FHESI_TRY(launch_segment_sum(c, (const u64*)d_tp, (const int*)d_seg, 1, 3, d_part));
+          FHESI_TRY(launch_ew_op(c, (u64*)d_sum, d_part, 3, L, nullptr, FHESI_OP_ADD));
+        }
+      }
+    }
+    FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_sum, ng, out + (size_t)g * ct_words, nlimbs));
+    g = g2;
+  }
   return 0;
 }
 

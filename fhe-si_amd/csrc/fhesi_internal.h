@@ -164,6 +164,12 @@ int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key /* [2][ncol][L][n] */, con
 int launch_automorph(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 nrows, i64 k);
 int launch_rows_equal(fhesi_ctx* ctx, const u64* a, const u64* b, i64 nwords, int* equal);
 
+// kernels_ct.hip : coefficient-domain ciphertext algebra on device batches
+int launch_ct_add(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 ncoeffs, int nl, int logQ);
+int launch_ct_mul_long(fhesi_ctx* ctx, u64* d_ct, i64 ncoeffs, int nl, int logQ, i64 l);
+int launch_gather(fhesi_ctx* ctx, const u64* d_pool, const int* d_idx, i64 count, i64 words, u64* d_out);
+int launch_segment_sum(fhesi_ctx* ctx, const u64* d_in, const int* d_seg, i64 ngroups, int ncomp, u64* d_out);
+
 // kernels_crt.hip
 int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out);
 // big-int coefficients [count][npoly][n][nlimbs] -> residue rows [count][npoly][L][n]; scalar_mul[poly] (0 = none) multiplies

@@ -4,6 +4,7 @@
 //   crt          DoubleCRT::toPoly (DoubleCRT.cpp:349-398) = incremental intVecCRT (NumbTh.cpp:307-335), fused with
 //                  mode 1: Ciphertext::ScaleDown rounding (Ciphertext.cpp:205-213) + positive Reduce (Util.cpp:3-26, Ciphertext.cpp:94)
 //                  mode 2: ReduceCoefficients centered mod 2^logQ (Util.cpp:28-33; FHE-SI.cpp:256)
+//                  mode 3: positive residue mod 2^logQ (Reduce(...,true), Ciphertext.cpp:94), limb-major like mode 1
 //   digits       Ciphertext::ByteDecompPart (Ciphertext.cpp:82-105) + conv of the digit polys (FHE-SI.cpp:246-249)
 //
 // The reference's intVecCRT keeps a centred accumulator at every step; the final value is the unique symmetric
@@ -260,6 +261,16 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
       u64 val = b ? ((lo >> b) | (hi << (64 - b))) : lo;
       val += carry;
       carry = (carry && val == 0);
+      const int bits_left = logQ - 64 * i;
+      if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << bits_left) - 1);
+      o[(i64)i * n] = val;
+    }
+  } else if (mode == 3) {
+    // positive residue mod 2^logQ of the value itself, limb-major [nl_out][n]: what ByteDecompPart (Ciphertext.cpp:94) takes of
+    // an unscaled part (the key switch after Ciphertext::operator>>=, Regression.h:171-172)
+    u64* o = out + poly * nl_out * n + j;
+    for (int i = 0; i < nl_out; ++i) {
+      u64 val = X(i);
       const int bits_left = logQ - 64 * i;
       if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << bits_left) - 1);
       o[(i64)i * n] = val;

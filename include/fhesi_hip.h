@@ -121,6 +121,32 @@ int fhesi_ct_mul_dev(fhesi_ctx* ctx, uint64_t p, const uint64_t* a_dev, const ui
 int fhesi_apply_key_switch_dev(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes,
                                const uint64_t* tprod_dev, int64_t count, uint64_t* out_dev, int32_t nlimbs);   /* ApplyKeySwitch */
 
+/* ---- ciphertext algebra between multiplications, on batches resident in HBM: what Matrix<Ciphertext> (Matrix.cpp:57-98,
+ * 150-174,182-263) and Regression::Regress / SumBatchedData (Regression.h:102-149,166-178) call on Ciphertext objects.
+ * Unscaled ciphertexts: [count][nparts][phi(m)][nlimbs] two's complement; scaled-up ones (tProd): [count][3][L][phi(m)] rows. */
+int fhesi_ct_add_dev(fhesi_ctx* ctx, int32_t logQ, uint64_t* dst_dev, const uint64_t* src_dev, int32_t nparts, int32_t nlimbs, int64_t count);
+                                                                                     /* Ciphertext::operator+= unscaled: Ciphertext.cpp:123-134 (scaled-up: fhesi_rows_op_dev) */
+int fhesi_ct_mul_long_dev(fhesi_ctx* ctx, int32_t logQ, uint64_t* ct_dev, int64_t l, int32_t nparts, int32_t nlimbs, int64_t count);
+                                                                                     /* Ciphertext::operator*=(long) unscaled: Ciphertext.cpp:232-237 -> :21-27 */
+int fhesi_rows_mul_long_dev(fhesi_ctx* ctx, uint64_t* rows_dev, int64_t l, int64_t count);   /* ... scaled-up: Ciphertext.cpp:238-241 (DoubleCRT *= long); count DoubleCRTs */
+int fhesi_ct_automorph_dev(fhesi_ctx* ctx, int64_t k, const uint64_t* in_dev, int32_t nparts, int32_t nlimbs_in, int64_t count,
+                           uint64_t* out_dev, int32_t nlimbs_out);                   /* Ciphertext::operator>>= unscaled: Ciphertext.cpp:264-269 -> :54-59; the result is
+                                                                                        centred modulo the prime chain, not modulo 2^logQ; error if k not in Zm* */
+/* (ctxt >>= k) followed by KeySwitchSI::ApplyKeySwitch with the matrix of KeySwitchSI(secretKey, k) (FHE-SI.cpp:229-260): one
+ * step of Regression::SumBatchedData (Regression.h:170-172).  k = 1 applies the key switch to the unscaled ciphertext as it is.
+ * in: [count][ncomp][phi(m)][nlimbs_in], ncomp = the matrix's source components; out: [count][2][phi(m)][nlimbs] */
+int fhesi_ct_automorph_key_switch_dev(fhesi_ctx* ctx, const fhesi_ksk* k_matrix, int32_t logQ, int32_t decomp_bytes, int64_t k,
+                                      const uint64_t* in_dev, int32_t nlimbs_in, int64_t count, uint64_t* out_dev, int32_t nlimbs);
+/* out[i] = pool[idx[i]] for elements of `words` uint64 each (operands of one wave of products) */
+int fhesi_ct_gather_dev(fhesi_ctx* ctx, const uint64_t* pool_dev, const int32_t* idx_host, int64_t count, int64_t words, uint64_t* out_dev);
+/* One wave of Matrix<Ciphertext> arithmetic: for every group g
+ *     out[g] = ApplyKeySwitch( sum_{t in [seg[g], seg[g+1])}  pool[a_idx[t]] *= pool[b_idx[t]] )
+ * i.e. the inner loops of Matrix::operator*= (Matrix.cpp:57-79), MultByTranspose (:150-174) and Determinant (:227-263) -- products of
+ * unscaled ciphertexts (Ciphertext.cpp:167-192) summed while scaled up (:135-142) -- followed by the `reduce` / MapAll key switch
+ * (Regression.h:112-115,127-134).  pool: unscaled 2-part ciphertexts [npool][2][phi(m)][nlimbs]; a_idx, b_idx, seg: host arrays. */
+int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* pool_dev,
+                               int32_t nlimbs, const int32_t* a_idx, const int32_t* b_idx, const int32_t* seg, int64_t ngroups, uint64_t* out_dev);
+
 /* plain device-memory helpers so C callers need no HIP headers */
 int fhesi_dev_alloc(fhesi_ctx* ctx, size_t bytes, void** out_dev);
 int fhesi_dev_free(fhesi_ctx* ctx, void* dev);

@@ -1,0 +1,164 @@
+"""GPU parity: the ciphertext algebra Matrix<Ciphertext> / Regression run between multiplications -- Ciphertext += , *= long,
+>>= k, ApplyKeySwitch on unscaled parts (SumBatchedData, Regression.h:166-178) and the fused wave
+sum-of-products + key switch (Matrix.cpp:57-79,150-174,227-263) -- through the C ABI vs the golden fixtures and the C oracle.
+Bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fhe_si_amd as F
+import fhesi_pyref as R
+import oracle_lib as O
+import params as P
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def I(v):
+    return [int(x) for x in v]
+
+
+def as_ints(a):
+    return [O.limbs_to_ints(a[r]) for r in range(a.shape[0])]
+
+
+def test_fixtures_add_mul_long_automorph_sum_batched():
+    with open(os.path.join(G, "regression.json")) as f:
+        cases = json.load(f)["ct_algebra"]
+    for c in cases:           # m = 22 (Bluestein rows) and m = 32 (power-of-two rows)
+        m, logQ = c["m"], c["logQ"]
+        primes, roots = I(c["primes"]), I(c["roots"])
+        ctx = F.Context(m, primes, roots)
+        n, L, nd, nl = ctx.phim, len(primes), R.ndigits(logQ), (logQ + 63) // 64
+        c1 = np.stack([O.ints_to_limbs(I(x), nl) for x in c["c1"]])
+        c2 = np.stack([O.ints_to_limbs(I(x), nl) for x in c["c2"]])
+        d1, d2 = ctx.upload(c1), ctx.upload(c2)
+        acc = ctx.upload(c1)
+        ctx.ct_add_dev(logQ, acc, d2, 2, nl, 1)
+        assert as_ints(acc.download((2, n, nl))) == [I(x) for x in c["added"]]
+        neg = ctx.upload(c1)
+        ctx.ct_mul_long_dev(logQ, neg, -1, 2, nl, 1)
+        assert as_ints(neg.download((2, n, nl))) == [I(x) for x in c["negated"]]
+        tri = ctx.upload(c2)
+        ctx.ct_mul_long_dev(logQ, tri, 3, 2, nl, 1)
+        assert as_ints(tri.download((2, n, nl))) == [I(x) for x in c["tripled"]]
+        ks = c["ks"]
+        rot = ctx.alloc(2 * n * (nl + 1) * 8)
+        ctx.ct_automorph_dev(ks[0], d2, 2, nl, 1, rot, nl + 1)
+        assert as_ints(rot.download((2, n, nl + 1))) == [I(x) for x in c["rotated"]]
+        ksks = [F.KeySwitchMatrix(ctx, 2, nd).upload(np.array([[[I(row) for row in col] for col in a[r]] for r in range(2)], dtype=np.uint64))
+                for a in c["auto_ksm"]]
+        sw = ctx.alloc(2 * n * nl * 8)
+        ctx.ct_automorph_key_switch_dev(ksks[0], logQ, ks[0], d2, nl, 1, sw, nl)
+        assert as_ints(sw.download((2, n, nl))) == [I(x) for x in c["switched"]]
+        # k = 1: key switch of the already rotated ciphertext (its coefficients are centred modulo the chain, nl+1 limbs)
+        sw1 = ctx.alloc(2 * n * nl * 8)
+        ctx.ct_automorph_key_switch_dev(ksks[0], logQ, 1, rot, nl + 1, 1, sw1, nl)
+        assert as_ints(sw1.download((2, n, nl))) == [I(x) for x in c["switched"]]
+        # Regression::SumBatchedData
+        cur, tmp = ctx.upload(c2), ctx.alloc(2 * n * nl * 8)
+        for ksk, k in zip(ksks, ks):
+            ctx.ct_automorph_key_switch_dev(ksk, logQ, k, cur, nl, 1, tmp, nl)
+            ctx.ct_add_dev(logQ, cur, tmp, 2, nl, 1)
+        parts = as_ints(cur.download((2, n, nl)))
+        assert parts == [I(x) for x in c["summed"]]
+        rctx = R.Ctx(m, logQ, c["p"], primes, roots)
+        assert R.decrypt(rctx, I(c["t"]), parts) == c["summed_plain"]
+        with pytest.raises(F.FhesiError):
+            ctx.ct_automorph_dev(2, d2, 2, nl, 1, rot, nl + 1)         # not in Zm* (DoubleCRT.cpp:442-443)
+
+
+@pytest.mark.parametrize("m,logQ,p", [(2048, 128, 23), (46, 90, 47), (4096, 300, 65537)])
+def test_batches_vs_oracle(m, logQ, p):
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, L, nd, nl = ctx.phim, len(primes), R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(m + logQ)
+    count = 3
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    a[0, 0, 0] = O.ints_to_limbs([-(1 << (logQ - 1))], nl)[0]
+    a[0, 0, 1] = O.ints_to_limbs([(1 << (logQ - 1)) - 1], nl)[0]
+    b[0, 0, 0] = a[0, 0, 0]
+    b[0, 0, 1] = a[0, 0, 1]
+    da, db = ctx.upload(a), ctx.upload(b)
+    acc = ctx.upload(a)
+    ctx.ct_add_dev(logQ, acc, db, 2, nl, count)
+    got = acc.download(a.shape)
+    for c in range(count):
+        assert np.array_equal(got[c], orc.ct_add(a[c], b[c], logQ)), c
+    for l in (-1, 3, -(1 << 40) - 12345, (1 << 62) + 7):
+        t = ctx.upload(a)
+        ctx.ct_mul_long_dev(logQ, t, l, 2, nl, count)
+        got = t.download(a.shape)
+        for c in range(count):
+            assert np.array_equal(got[c], orc.ct_mul_long(a[c], l, logQ)), (l, c)
+    # Ciphertext >>= k and the automorphism key switch with a random matrix (timing and parity do not depend on key validity)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 2 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 2, nd).upload(ksm)
+    ks = [3, m - 1] if m % 2 == 0 else [2, m - 1]
+    for k in ks:
+        rot = ctx.alloc(count * 2 * n * (nl + 1) * 8)
+        ctx.ct_automorph_dev(k, da, 2, nl, count, rot, nl + 1)
+        got = rot.download((count, 2, n, nl + 1))
+        exp = [orc.ct_automorph(a[c], k, nl + 1) for c in range(count)]
+        for c in range(count):
+            assert np.array_equal(got[c], exp[c]), (k, c)
+        out = ctx.alloc(count * 2 * n * nl * 8)
+        ctx.ct_automorph_key_switch_dev(ksk, logQ, k, da, nl, count, out, nl)
+        got = out.download((count, 2, n, nl))
+        for c in range(count):
+            assert np.array_equal(got[c], orc.apply_key_switch_parts(ksm, exp[c], logQ, nl)), (k, c)
+    # scaled-up *= long
+    tp = ctx.alloc(count * 3 * L * n * 8)
+    ctx.ct_mul_dev(p, da, db, nl, count, tp)
+    before = tp.download((count * 3, L, n))
+    ctx.rows_mul_long_dev(tp, -1, count * 3)
+    after = tp.download((count * 3, L, n))
+    for i, q in enumerate(primes):
+        assert np.array_equal(after[:, i, :], (np.uint64(q) - before[:, i, :]) % np.uint64(q))
+
+
+@pytest.mark.parametrize("chunk", [None, "2"])
+def test_wave_of_products_sum_and_key_switch(chunk, monkeypatch):
+    """out[g] = KeySwitch(sum_t pool[a_t] * pool[b_t]) (fhesi_ct_mul_sum_relin_dev) vs the oracle composed the way Matrix.cpp does:
+    operator*= per product, += on the scaled-up ciphertexts, then ApplyKeySwitch.  chunk=2 forces the piecewise accumulation."""
+    if chunk:
+        monkeypatch.setenv("FHESI_BATCH_CHUNK", chunk)
+    m, logQ, p = 1024, 128, 23
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, L, nd, nl = ctx.phim, len(primes), R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(99)
+    npool = 6
+    pool = P.rand_limbs(rng, (npool, 2, n), nl, logQ)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    groups = [[(0, 1)], [(2, 3), (4, 5), (1, 1)], [(5, 0), (3, 2)], [(0, 0), (1, 2), (3, 4), (5, 5), (2, 2)], [(4, 1)]]
+    a_idx = [x for g in groups for x, _ in g]
+    b_idx = [y for g in groups for _, y in g]
+    seg = np.cumsum([0] + [len(g) for g in groups])
+    dpool = ctx.upload(pool)
+    out = ctx.alloc(len(groups) * 2 * n * nl * 8)
+    ctx.ct_mul_sum_relin_dev(ksk, logQ, p, dpool, nl, a_idx, b_idx, seg, out)
+    got = out.download((len(groups), 2, n, nl))
+    for gi, g in enumerate(groups):
+        tp = None
+        for x, y in g:
+            t = orc.ct_mul(pool[x], pool[y], p)
+            if tp is None:
+                tp = t
+            else:
+                for comp in range(3):
+                    for i, q in enumerate(primes):
+                        tp[comp][i] = (tp[comp][i] + t[comp][i]) % np.uint64(q)
+        assert np.array_equal(got[gi], orc.apply_key_switch(ksm, tp, logQ, nl)), gi
+    # the gather alone
+    g_out = ctx.alloc(3 * 2 * n * nl * 8)
+    ctx.ct_gather_dev(dpool, [5, 0, 5], 2 * n * nl, g_out)
+    assert np.array_equal(g_out.download((3, 2, n, nl)), pool[[5, 0, 5]])
