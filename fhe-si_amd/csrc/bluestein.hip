@@ -242,12 +242,46 @@ void bluestein_destroy(fhesi_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------------------ launch
+// One chunk of `count` DoubleCRTs (R = count * nslots rows).  Everything is enqueued on the caller's stream: the auxiliary
+// convolution context borrows it for the duration of the call, so no host synchronisation is needed between the stages.
+static int blue_chunk(fhesi_ctx* c, u64* d_rows, i64 count, int nslots, const int* d_pos, bool inv, u64* X, u64* dF) {
+  BluesteinTables* B = c->blue;
+  const i64 R = count * nslots, N = B->N, m = c->m, phim = c->phim;
+  dim3 gpre((unsigned)((N + 255) / 256), (unsigned)R);
+  if (!inv) blue_pre<false><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
+  else blue_pre<true><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
+  HIP_TRY(hipGetLastError());
+  FHESI_TRY(launch_ntt_fwd(B->aux, X, R, 3, nullptr, true));
+  unsigned gx = (unsigned)((N + 255) / 256);
+  if (gx > 64) gx = 64;
+  blue_mul<<<dim3(gx, (unsigned)(R * 3)), 256, 0, c->stream>>>(X, N, nslots, d_pos, inv ? 1 : 0, B->d_bhat, B->aux->d_pc);
+  HIP_TRY(hipGetLastError());
+  FHESI_TRY(launch_ntt_inv(B->aux, X, R, 3, nullptr, true));
+  dim3 gpost((unsigned)((m + 255) / 256), (unsigned)R);
+  if (!inv) {
+    blue_post<false><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, d_rows);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  blue_post<true><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, dF);
+  HIP_TRY(hipGetLastError());
+  if (B->phi_kind) {
+    blue_phi_fast<<<dim3((unsigned)((phim + 255) / 256), (unsigned)R), 256, 0, c->stream>>>((const u64*)dF, phim, m, B->phi_kind, nslots, d_pos, c->d_pc, d_rows);
+  } else {
+    const size_t shmem = (size_t)m * 8;
+    HIP_TRY(hipFuncSetAttribute((const void*)blue_phi_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    blue_phi_generic<<<(unsigned)R, 256, shmem, c->stream>>>((const u64*)dF, phim, m, B->d_phi, nslots, d_pos, c->d_pc, d_rows);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int blue_run(fhesi_ctx* c, u64* d_rows, i64 count, int nslots, const int* prime_of_slot_host, bool inv) {
   BluesteinTables* B = c->blue;
   if (!B) FHESI_FAIL("Bluestein tables missing");
-  const i64 R = count * nslots, N = B->N, m = c->m, phim = c->phim;
-  if (!R) return 0;
-  ProfScope prof(c, inv ? PROF_NTT_INV : PROF_NTT_FWD, (double)R);
+  const i64 N = B->N, m = c->m, phim = c->phim;
+  if (!count || !nslots) return 0;
+  ProfScope prof(c, inv ? PROF_NTT_INV : PROF_NTT_FWD, (double)(count * nslots));
   // device copy of the slot -> prime map unless it is the identity over all primes
   int* d_pos = nullptr;
   bool identity = nslots == c->L;
@@ -259,41 +293,22 @@ static int blue_run(fhesi_ctx* c, u64* d_rows, i64 count, int nslots, const int*
     HIP_TRY(hipStreamSynchronize(c->stream));
     d_pos = (int*)p;
   }
-  void* dX;
-  FHESI_TRY(ws_reserve(c, 8, (size_t)R * 3 * N * 8, &dX));
-  u64* X = (u64*)dX;
-  dim3 gpre((unsigned)((N + 255) / 256), (unsigned)R);
-  if (!inv) blue_pre<false><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
-  else blue_pre<true><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
-  HIP_TRY(hipGetLastError());
-  // the auxiliary context runs on its own stream: order it after the pre kernel and before the post kernel
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  FHESI_TRY(launch_ntt_fwd(B->aux, X, R, 3, nullptr, true));
-  unsigned gx = (unsigned)((N + 255) / 256);
-  if (gx > 64) gx = 64;
-  blue_mul<<<dim3(gx, (unsigned)(R * 3)), 256, 0, B->aux->stream>>>(X, N, nslots, d_pos, inv ? 1 : 0, B->d_bhat, B->aux->d_pc);
-  HIP_TRY(hipGetLastError());
-  FHESI_TRY(launch_ntt_inv(B->aux, X, R, 3, nullptr, true));
-  HIP_TRY(hipStreamSynchronize(B->aux->stream));
-  dim3 gpost((unsigned)((m + 255) / 256), (unsigned)R);
-  if (!inv) {
-    blue_post<false><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, d_rows);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  void* dF;
-  FHESI_TRY(ws_reserve(c, 9, (size_t)R * m * 8, &dF));
-  blue_post<true><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, (u64*)dF);
-  HIP_TRY(hipGetLastError());
-  if (B->phi_kind) {
-    blue_phi_fast<<<dim3((unsigned)((phim + 255) / 256), (unsigned)R), 256, 0, c->stream>>>((const u64*)dF, phim, m, B->phi_kind, nslots, d_pos, c->d_pc, d_rows);
-  } else {
-    const size_t shmem = (size_t)m * 8;
-    HIP_TRY(hipFuncSetAttribute((const void*)blue_phi_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    blue_phi_generic<<<(unsigned)R, 256, shmem, c->stream>>>((const u64*)dF, phim, m, B->d_phi, nslots, d_pos, c->d_pc, d_rows);
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
+  // the convolution buffer holds 3 auxiliary-prime rows of N words per row: bound it (and the auxiliary transform's scratch of
+  // the same size) to about 2 GiB per chunk -- thousands of rows, far more than the 512 workgroups the chip holds
+  i64 chunk = (i64)((2ull << 30) / ((u64)nslots * 3 * N * 8));
+  if (chunk > 21845 / nslots) chunk = 21845 / nslots;      // grid.y of blue_mul is 3 * rows <= 65535
+  if (chunk < 1) chunk = 1;
+  if (chunk > count) chunk = count;
+  void *dX, *dF = nullptr;
+  FHESI_TRY(ws_reserve(c, 8, (size_t)chunk * nslots * 3 * N * 8, &dX));
+  if (inv) FHESI_TRY(ws_reserve(c, 9, (size_t)chunk * nslots * m * 8, &dF));
+  hipStream_t aux_stream = B->aux->stream;
+  B->aux->stream = c->stream;
+  int rc = 0;
+  for (i64 done = 0; done < count && !rc; done += chunk)
+    rc = blue_chunk(c, d_rows + done * nslots * phim, std::min(chunk, count - done), nslots, d_pos, inv, (u64*)dX, (u64*)dF);
+  B->aux->stream = aux_stream;
+  return rc;
 }
 
 int launch_bluestein_fwd(fhesi_ctx* c, u64* d_rows, i64 count, int nslots, const int* prime_of_slot_host) { return blue_run(c, d_rows, count, nslots, prime_of_slot_host, false); }

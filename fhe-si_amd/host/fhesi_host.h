@@ -548,6 +548,14 @@ class KeySwitchSI {
     FHESISecKey tensored(s.GetContext()); tensored.UpdateRepresentation(tKeys);
     Init(tensored, s);
   }
+  KeySwitchSI(const FHESISecKey& s, unsigned k) : context(s.GetContext()) { InitAutomorph(s, k); }     // FHE-SI.h: key for X -> X^k
+  void InitAutomorph(const FHESISecKey& s, unsigned k) {   // FHE-SI.cpp:229-239
+    std::vector<DoubleCRT> sKeys = s.GetRepresentation();
+    FHESISecKey automorphedKey(s.GetContext());           // (its constructor draws a key that is replaced below, as in the reference)
+    for (auto& sk : sKeys) sk.automorph((long)k);
+    automorphedKey.UpdateRepresentation(sKeys);
+    Init(automorphedKey, s);
+  }
   void ApplyKeySwitch(Ciphertext& ctxt) const {   // FHE-SI.cpp:241-260
     ctxt.ScaleDown(); ctxt.ByteDecomp();
     std::vector<DoubleCRT> bd; for (auto& p : ctxt.parts) bd.push_back(DoubleCRT(p.poly, context));

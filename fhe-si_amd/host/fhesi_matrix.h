@@ -1,0 +1,408 @@
+// fhesi_matrix.h -- mirror of Matrix<T> (Matrix.h:16-83, Matrix.cpp) and of Regression (Regression.h:68-191) on the classes of
+// fhesi_host.h, plus the batched evaluator that SURVEY.md 8(f) ranks next after the multiplication path:
+//
+//   * Matrix<T>            same member names, argument meaning and evaluation order as the reference template, so it can be
+//                          instantiated with Ciphertext (object-at-a-time, every operation a C-ABI call) or with a plaintext ring type.
+//   * CtPool / ProductWave device-resident unscaled ciphertexts addressed by index; one ProductWave = many independent
+//                          "sum of products, then key switch" groups submitted as ONE fhesi_ct_mul_sum_relin_dev call.
+//   * Regression           Regress() walks the reference's control flow literally; RegressBatched() evaluates the same
+//                          expression DAG level by level (inner products -> SumBatchedData -> minors of growing size ->
+//                          determinant -> adj * last) in waves.  Every ciphertext operation is deterministic, so equal minors
+//                          the Laplace recursion of Matrix.cpp:227-263 recomputes are evaluated once; results are bit-identical.
+// Slot packing (PlaintextSpace.cpp) is outside the hot-path scope: plaintexts are coefficient vectors and only the slot COUNT
+// (Regression.h:72-79) is mirrored.  GenerateNoise (Regression.h:180-191) needs EmbedInSlots and is therefore not applied;
+// both evaluators return the unmasked theta / det.
+#pragma once
+#include <functional>
+#include <map>
+
+#include "fhesi_host.h"
+
+namespace fhesi {
+
+// ---------------------------------------------------------------- Matrix<T> (Matrix.h / Matrix.cpp)
+template <class T>
+class Matrix {
+  T dummy;
+  std::vector<std::vector<T>> mat;      // storage rows; `transpose` swaps the roles of the two indices (Matrix.cpp:144-152)
+  bool transpose = false;
+
+  T& ElemAt(unsigned r, unsigned c) { return transpose ? mat[c][r] : mat[r][c]; }
+  const T& ElemAt(unsigned r, unsigned c) const { return transpose ? mat[c][r] : mat[r][c]; }
+
+  // Laplace expansion along the first unused row (Matrix.cpp:227-263); `reduce` runs on every partial determinant of size >= 2
+  void Determinant(T& det, std::vector<bool>& usedRows, std::vector<bool>& usedCols, unsigned dim, std::function<void(T&)> reduce) const {
+    const unsigned matDim = NumRows();
+    unsigned row = 0;
+    while (usedRows[row]) ++row;
+    bool negative = false, first = true;
+    for (unsigned col = 0; col < matDim; ++col) {
+      if (usedCols[col]) continue;
+      if (dim == 1) { det = ElemAt(row, col); return; }
+      T term = ElemAt(row, col);
+      if (negative) term *= -1;
+      negative = !negative;
+      usedRows[row] = usedCols[col] = true;
+      T minor(dummy);
+      Determinant(minor, usedRows, usedCols, dim - 1, reduce);
+      usedRows[row] = usedCols[col] = false;
+      term *= minor;
+      if (first) { det = term; first = false; } else det += term;
+    }
+    if (reduce) reduce(det);
+  }
+
+ public:
+  Matrix() : dummy(T()) {}
+  Matrix(const T& d) : dummy(d) {}
+  Matrix(unsigned nRows, unsigned nCols, const T& d) : dummy(d) { Resize(nRows, nCols); }
+  Matrix(unsigned nRows, unsigned nCols) : dummy(T()) { Resize(nRows, nCols); }
+
+  unsigned NumRows() const { return mat.empty() ? 0 : (unsigned)(transpose ? mat[0].size() : mat.size()); }
+  unsigned NumCols() const { return mat.empty() ? 0 : (unsigned)(transpose ? mat.size() : mat[0].size()); }
+  void Resize(unsigned nRows, unsigned nCols) { Clear(); transpose = false; mat.assign(nRows, std::vector<T>(nCols, dummy)); }
+  void Clear() { mat.clear(); }
+  void Transpose() { transpose = !transpose; }
+  void AddRow(std::vector<T>& row) { if (!transpose) mat.push_back(row); }                 // no support on a transposed matrix (Matrix.cpp:293-297)
+  void Concatenate(Matrix<T>& o) { if (!transpose) mat.insert(mat.end(), o.mat.begin(), o.mat.end()); }
+  void MapAll(std::function<void(T&)> func) { for (auto& r : mat) for (auto& e : r) func(e); }   // storage order (Matrix.cpp:306-312)
+
+  T& operator()(unsigned r, unsigned c) { return ElemAt(r, c); }
+  const T& operator()(unsigned r, unsigned c) const { return ElemAt(r, c); }
+  std::vector<T>& operator[](unsigned r) { return mat[r]; }
+  const std::vector<T>& operator[](unsigned r) const { return mat[r]; }
+  Matrix& operator=(const Matrix& o) { mat = o.mat; transpose = o.transpose; dummy = o.dummy; return *this; }
+
+  Matrix& operator+=(const Matrix& o) { for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) ElemAt(i, j) += o(i, j); return *this; }
+  Matrix operator+(const Matrix& o) const { Matrix r = *this; r += o; return r; }
+  Matrix& operator-=(const Matrix& o) {                                                    // Matrix.cpp:30-40
+    for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) { T t = o(i, j); t *= -1; ElemAt(i, j) += t; }
+    return *this;
+  }
+  Matrix operator-(const Matrix& o) const { Matrix r = *this; r -= o; return r; }
+
+  Matrix& operator*=(Matrix& o) {                                                          // Matrix.cpp:57-79
+    if (mat.empty()) return *this;
+    Matrix prod(NumRows(), o.NumCols(), dummy);
+    for (unsigned i = 0; i < NumRows(); ++i)
+      for (unsigned j = 0; j < o.NumCols(); ++j) {
+        prod(i, j) = ElemAt(i, 0);
+        prod(i, j) *= o(0, j);
+        for (unsigned k = 1; k < NumCols(); ++k) { T t = ElemAt(i, k); t *= o(k, j); prod(i, j) += t; }
+      }
+    std::swap(prod.mat, mat);
+    transpose = false;
+    return *this;
+  }
+  Matrix& operator*=(std::vector<T>& v) {                                                  // Matrix.cpp:81-98 (the entries are multiplied in place first)
+    if (mat.empty()) return *this;
+    Matrix prod(NumRows(), 1, dummy);
+    for (unsigned i = 0; i < NumRows(); ++i) {
+      ElemAt(i, 0) *= v[0];
+      prod(i, 0) = ElemAt(i, 0);
+      for (unsigned j = 1; j < NumCols(); ++j) { ElemAt(i, j) *= v[j]; prod(i, 0) += ElemAt(i, j); }
+    }
+    std::swap(mat, prod.mat);
+    transpose = false;
+    return *this;
+  }
+  Matrix& operator*=(T& s) { for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) ElemAt(i, j) *= s; return *this; }
+  Matrix operator*(Matrix& o) const { Matrix r = *this; r *= o; return r; }
+  Matrix operator*(std::vector<T>& v) const { Matrix r = *this; r *= v; return r; }
+
+  void MultByTranspose() {                                                                 // Matrix.cpp:150-174: upper triangle, mirrored
+    if (mat.empty()) return;
+    Matrix prod(NumRows(), NumRows(), dummy);
+    for (unsigned i = 0; i < NumRows(); ++i)
+      for (unsigned j = i; j < NumRows(); ++j) {
+        prod(i, j) = ElemAt(i, 0);
+        prod(i, j) *= ElemAt(j, 0);
+        for (unsigned k = 1; k < NumCols(); ++k) { T t = ElemAt(i, k); t *= ElemAt(j, k); prod(i, j) += t; }
+        if (i != j) prod(j, i) = prod(i, j);
+      }
+    std::swap(prod.mat, mat);
+    transpose = false;
+  }
+  void Determinant(T& det, std::function<void(T&)> reduce = nullptr) const {
+    std::vector<bool> usedRows(NumRows()), usedCols(NumRows());
+    Determinant(det, usedRows, usedCols, NumRows(), reduce);
+  }
+  void Invert(T& det, std::function<void(T&)> reduce = nullptr) {                          // Matrix.cpp:182-216: adjugate, then det from its first column
+    const unsigned dim = NumRows();
+    Matrix adj(dim, dim, dummy);
+    std::vector<bool> usedRows(dim), usedCols(dim);
+    for (unsigned i = 0; i < dim; ++i)
+      for (unsigned j = 0; j < dim; ++j) {
+        usedRows[i] = usedCols[j] = true;
+        Determinant(adj(j, i), usedRows, usedCols, dim - 1, reduce);
+        usedRows[i] = usedCols[j] = false;
+        if ((i + j) % 2 == 1) adj(j, i) *= -1;
+      }
+    det = ElemAt(0, 0);
+    det *= adj(0, 0);
+    for (unsigned i = 1; i < dim; ++i) { T t = ElemAt(0, i); t *= adj(i, 0); det += t; }
+    if (reduce) reduce(det);
+    std::swap(adj.mat, mat);
+    transpose = false;
+  }
+};
+
+// ---------------------------------------------------------------- slot counts (PlaintextSpace.cpp:29-43): factors of Phi_m mod p
+inline unsigned TotalSlots(unsigned m, unsigned long p, unsigned phim) { unsigned d = 1; unsigned long x = p % m; while (x != 1) { x = (x * (p % m)) % m; ++d; } return phim / d; }
+inline unsigned UsableSlots(unsigned m, unsigned long p, unsigned phim) { unsigned u = 1, t = TotalSlots(m, p, phim); while (t > 1) { u <<= 1; t >>= 1; } return u; }
+
+// ---------------------------------------------------------------- device-resident ciphertext pool
+// Unscaled 2-part ciphertexts [capacity][2][phi(m)][nl] in HBM, addressed by index.  Entries are written once and never
+// modified afterwards, so indices can be shared freely (a symmetric matrix stores one entry for (i,j) and (j,i)).
+class CtPool {
+  const FHEcontext& context;
+  fhesi_ctx* h;
+  uint64_t* d = nullptr;
+  long cap = 0, used = 0;
+ public:
+  const int nl;
+  const long n, words;        // words per ciphertext
+  CtPool(const FHEcontext& c, long capacity = 64) : context(c), h(c.handle()), nl((int)((c.logQ + 63) / 64)), n(c.zMstar.phiM()), words(2 * n * nl) { reserve(capacity); }
+  ~CtPool() { if (d) fhesi_dev_free(h, d); }
+  CtPool(const CtPool&) = delete;
+  long size() const { return used; }
+  uint64_t* base() const { return d; }
+  uint64_t* ptr(long idx) const { return d + idx * words; }
+  void reserve(long want) {
+    if (want <= cap) return;
+    long ncap = std::max(want, cap * 2);
+    void* nd; ck(fhesi_dev_alloc(h, (size_t)ncap * words * 8, &nd));
+    if (d) { ck(fhesi_dev_copy(h, nd, d, (size_t)used * words * 8)); ck(fhesi_dev_free(h, d)); }
+    d = (uint64_t*)nd; cap = ncap;
+  }
+  long alloc(long count) { reserve(used + count); long first = used; used += count; return first; }      // `count` consecutive new entries
+  long add(const Ciphertext& ct) {
+    if (ct.isScaledUp() || ct.parts.size() != 2) Error("CtPool::add: expects an unscaled 2-part ciphertext");
+    std::vector<uint64_t> v(words);
+    for (int part = 0; part < 2; ++part) for (long i = 0; i < n; ++i) coeff(ct.parts[part].poly, i).to_limbs(&v[(part * n + i) * nl], nl);
+    long idx = alloc(1);
+    ck(fhesi_dev_upload(h, ptr(idx), v.data(), (size_t)words * 8));
+    return idx;
+  }
+  void get(long idx, Ciphertext& ct) const {
+    std::vector<uint64_t> v(words);
+    ck(fhesi_dev_download(h, v.data(), ptr(idx), (size_t)words * 8));
+    ct.Initialize(2, context);
+    for (int part = 0; part < 2; ++part) { ZZX p; p.rep.resize(n); for (long i = 0; i < n; ++i) p.rep[i] = ZZ::from_limbs(&v[(part * n + i) * nl], nl); p.normalize(); ct[part].poly = p; }
+  }
+  // new entries = -1 * the given ones (Ciphertext::operator*=(long), Ciphertext.cpp:232-237)
+  long negated(const std::vector<int32_t>& idx) {
+    if (idx.empty()) return used;
+    long first = alloc((long)idx.size());
+    ck(fhesi_ct_gather_dev(h, d, idx.data(), (int64_t)idx.size(), words, ptr(first)));
+    ck(fhesi_ct_mul_long_dev(h, (int32_t)context.logQ, ptr(first), -1, 2, nl, (int64_t)idx.size()));
+    return first;
+  }
+};
+
+// One KeySwitchSI matrix copied into a fhesi_ksk (device to device: the DoubleCRT rows already live in HBM)
+class DeviceKeySwitch {
+  fhesi_ksk* k = nullptr;
+ public:
+  DeviceKeySwitch(const FHEcontext& c, const KeySwitchSI& ks) {
+    const auto& M = ks.GetRepresentation();
+    const long ncol = (long)M[0].size(), rowWords = (long)c.numPrimes() * c.zMstar.phiM();
+    ck(fhesi_ksk_create(c.handle(), (int32_t)(ncol / c.ndigits), (int32_t)c.ndigits, &k));
+    uint64_t* dst = (uint64_t*)fhesi_ksk_device_ptr(k);
+    for (int r = 0; r < 2; ++r)
+      for (long col = 0; col < ncol; ++col) ck(fhesi_dev_copy(c.handle(), dst + (r * ncol + col) * rowWords, fhesi_dcrt_device_ptr(M[r][col].handle()), (size_t)rowWords * 8));
+    ck(fhesi_ctx_sync(c.handle()));
+  }
+  ~DeviceKeySwitch() { if (k) fhesi_ksk_free(k); }
+  DeviceKeySwitch(const DeviceKeySwitch&) = delete;
+  const fhesi_ksk* handle() const { return k; }
+};
+
+// A set of independent groups  out[g] = KeySwitch(sum_t a_t * b_t)  over pool indices
+struct ProductWave {
+  std::vector<int32_t> a, b, seg{0};
+  void product(long ai, long bi) { a.push_back((int32_t)ai); b.push_back((int32_t)bi); }
+  long end_group() { seg.push_back((int32_t)a.size()); return (long)seg.size() - 2; }     // returns the group's position in the wave
+  long groups() const { return (long)seg.size() - 1; }
+};
+
+// ---------------------------------------------------------------- Regression (Regression.h:68-191)
+class Regression {
+  const FHEcontext& context;
+  FHESISecKey secretKey;
+  FHESIPubKey publicKey;
+  KeySwitchSI keySwitch;
+  std::vector<KeySwitchSI> autoKeySwitch;
+  std::vector<unsigned> autoK;                                   // k = g, g^2, g^4, ... mod m (Regression.h:71-80)
+  Matrix<Ciphertext> data;
+  // device copies of the key-switch matrices, created on the first batched call
+  std::unique_ptr<DeviceKeySwitch> dKeySwitch;
+  std::vector<std::unique_ptr<DeviceKeySwitch>> dAuto;
+
+  void SumBatchedData(Ciphertext& batched) const {               // Regression.h:166-178
+    for (size_t i = 0; i < autoKeySwitch.size(); ++i) {
+      Ciphertext tmp = batched;
+      tmp >>= (long)autoK[i];
+      autoKeySwitch[i].ApplyKeySwitch(tmp);
+      batched += tmp;
+    }
+  }
+  void ensure_device_keys() {
+    if (dKeySwitch) return;
+    dKeySwitch.reset(new DeviceKeySwitch(context, keySwitch));
+    for (auto& a : autoKeySwitch) dAuto.emplace_back(new DeviceKeySwitch(context, a));
+  }
+  // runs a wave; returns the pool index of group 0 (groups are stored consecutively)
+  long run(CtPool& pool, const ProductWave& w) {
+    if (!w.groups()) return pool.size();
+    long first = pool.alloc(w.groups());
+    ck(fhesi_ct_mul_sum_relin_dev(context.handle(), dKeySwitch->handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), (int32_t)context.decompSize,
+                                  pool.base(), pool.nl, w.a.data(), w.b.data(), w.seg.data(), w.groups(), pool.ptr(first)));
+    return first;
+  }
+  // SumBatchedData on `count` consecutive pool entries, in place (they are not shared yet)
+  void sum_batched(CtPool& pool, long first, long count) {
+    if (!count || autoKeySwitch.empty()) return;
+    void* tmp; ck(fhesi_dev_alloc(context.handle(), (size_t)count * pool.words * 8, &tmp));
+    for (size_t i = 0; i < autoKeySwitch.size(); ++i) {
+      ck(fhesi_ct_automorph_key_switch_dev(context.handle(), dAuto[i]->handle(), (int32_t)context.logQ, (int32_t)context.decompSize, (int64_t)autoK[i], pool.ptr(first), pool.nl,
+                                           count, (uint64_t*)tmp, pool.nl));
+      ck(fhesi_ct_add_dev(context.handle(), (int32_t)context.logQ, pool.ptr(first), (const uint64_t*)tmp, 2, pool.nl, count));
+    }
+    ck(fhesi_dev_free(context.handle(), tmp));
+  }
+
+ public:
+  std::vector<Ciphertext> labels;
+  struct Stats { long products = 0, key_switches = 0, automorph_key_switches = 0, waves = 0; } stats;    // work submitted by the last RegressBatched
+
+  Regression(const FHEcontext& c) : context(c), secretKey(c), publicKey(secretKey), keySwitch(secretKey), data(Ciphertext(c)) {
+    unsigned k = c.Generator();
+    unsigned nSlots = UsableSlots(c.zMstar.M(), (unsigned long)c.ModulusP().to_long(), c.zMstar.phiM());
+    while (nSlots > 1) {
+      autoKeySwitch.push_back(KeySwitchSI(secretKey, k));
+      autoK.push_back(k);
+      nSlots >>= 1;
+      k = (unsigned)(((unsigned long)k * k) % c.zMstar.M());
+    }
+  }
+  FHESIPubKey& GetPublicKey() { return publicKey; }
+  FHESISecKey& GetSecretKey() { return secretKey; }
+  const std::vector<unsigned>& AutomorphismExponents() const { return autoK; }
+
+  void AddData(const std::vector<std::vector<Plaintext>>& ptxtData, const std::vector<Plaintext>& ptxtLabels) {   // Regression.h:83-95
+    for (size_t i = 0; i < ptxtData.size(); ++i) {
+      std::vector<Ciphertext> row(ptxtData[i].size(), Ciphertext(context));
+      for (size_t j = 0; j < ptxtData[i].size(); ++j) publicKey.Encrypt(row[j], ptxtData[i][j]);
+      Ciphertext lab(context);
+      publicKey.Encrypt(lab, ptxtLabels[i]);
+      data.AddRow(row);
+      labels.push_back(lab);
+    }
+  }
+  void Clear() { data.Clear(); labels.clear(); }
+
+  // The reference's control flow, one Ciphertext object at a time (Regression.h:102-149 without the GenerateNoise masking)
+  void Regress(std::vector<Ciphertext>& theta, Ciphertext& det) const {
+    Matrix<Ciphertext> dataCopy = data;
+    std::vector<Ciphertext> lab = labels;
+    dataCopy.Transpose();
+    Matrix<Ciphertext> last = dataCopy * lab;
+    dataCopy.MultByTranspose();
+    auto processFunc = [this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); SumBatchedData(ct); };
+    last.MapAll(processFunc);
+    dataCopy.MapAll(processFunc);
+    if (data.NumCols() == 1) { det = dataCopy(0, 0); theta.assign(1, last(0, 0)); return; }
+    dataCopy.Invert(det, [this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); });
+    dataCopy *= last;
+    dataCopy.MapAll([this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); });
+    theta.assign(dataCopy.NumRows(), Ciphertext(context));
+    for (unsigned i = 0; i < dataCopy.NumRows(); ++i) theta[i] = dataCopy(i, 0);
+  }
+
+  // The same expression DAG in waves on the device
+  void RegressBatched(std::vector<Ciphertext>& theta, Ciphertext& det) {
+    ensure_device_keys();
+    stats = Stats();
+    const unsigned N = data.NumRows(), d = data.NumCols();
+    if (!N || !d) Error("Regression: no data");
+    CtPool pool(context, (long)N * (d + 1) + 4L * d * d + 64);
+    std::vector<std::vector<long>> X(N, std::vector<long>(d));
+    std::vector<long> y(N);
+    for (unsigned i = 0; i < N; ++i) { for (unsigned j = 0; j < d; ++j) X[i][j] = pool.add(data(i, j)); y[i] = pool.add(labels[i]); }
+    // wave 1: last = X^T y (Matrix.cpp:81-98) and the upper triangle of X^T X (Matrix.cpp:150-174), then key switch
+    ProductWave w1;
+    for (unsigned j = 0; j < d; ++j) { for (unsigned i = 0; i < N; ++i) w1.product(X[i][j], y[i]); w1.end_group(); }
+    std::vector<std::vector<long>> A(d, std::vector<long>(d, -1));
+    for (unsigned i = 0; i < d; ++i) for (unsigned j = i; j < d; ++j) { for (unsigned k = 0; k < N; ++k) w1.product(X[k][i], X[k][j]); w1.end_group(); }
+    const long first1 = run(pool, w1);
+    note(w1);
+    sum_batched(pool, first1, w1.groups());                       // processFunc: ApplyKeySwitch + SumBatchedData (Regression.h:112-117)
+    stats.automorph_key_switches += w1.groups() * (long)autoKeySwitch.size();
+    std::vector<long> last(d);
+    for (unsigned j = 0; j < d; ++j) last[j] = first1 + j;
+    { long g = d; for (unsigned i = 0; i < d; ++i) for (unsigned j = i; j < d; ++j) { A[i][j] = A[j][i] = first1 + g; ++g; } }
+    if (d == 1) { pool.get(A[0][0], det); theta.assign(1, Ciphertext(context)); pool.get(last[0], theta[0]); return; }
+    // negated copies of the matrix entries: the `tmp *= -1` of the expansion (Matrix.cpp:245) acts on the unscaled entry
+    std::vector<int32_t> flat;
+    for (unsigned i = 0; i < d; ++i) for (unsigned j = 0; j < d; ++j) flat.push_back((int32_t)A[i][j]);
+    const long negA = pool.negated(flat);
+    auto entry = [&](unsigned r, unsigned c, bool neg) { return neg ? negA + (long)r * d + c : A[r][c]; };
+    // minors needed by Invert (Matrix.cpp:182-200): Determinant with row i and column j struck out, dim d-1, memoised on
+    // (used rows, used columns); level s holds the partial determinants of size s
+    typedef std::pair<unsigned, unsigned> Key;
+    std::vector<std::map<Key, long>> level(d);
+    std::function<void(unsigned, unsigned, unsigned)> need = [&](unsigned R, unsigned C, unsigned dim) {
+      if (level[dim].count(Key(R, C))) return;
+      level[dim][Key(R, C)] = -1;
+      if (dim == 1) return;
+      unsigned row = 0; while (R >> row & 1) ++row;
+      for (unsigned col = 0; col < d; ++col) if (!(C >> col & 1)) need(R | 1u << row, C | 1u << col, dim - 1);
+    };
+    for (unsigned i = 0; i < d; ++i) for (unsigned j = 0; j < d; ++j) need(1u << i, 1u << j, d - 1);
+    for (auto& kv : level[1]) {                                   // size 1: the entry itself, no reduce (Matrix.cpp:238-241)
+      unsigned row = 0; while (kv.first.first >> row & 1) ++row;
+      unsigned col = 0; while (kv.first.second >> col & 1) ++col;
+      kv.second = A[row][col];
+    }
+    for (unsigned s = 2; s + 1 <= d; ++s) {
+      ProductWave w;
+      std::vector<Key> order;
+      for (auto& kv : level[s]) {
+        const unsigned R = kv.first.first, C = kv.first.second;
+        unsigned row = 0; while (R >> row & 1) ++row;
+        bool negative = false;
+        for (unsigned col = 0; col < d; ++col) {
+          if (C >> col & 1) continue;
+          w.product(entry(row, col, negative), level[s - 1][Key(R | 1u << row, C | 1u << col)]);
+          negative = !negative;
+        }
+        w.end_group();
+        order.push_back(kv.first);
+      }
+      const long first = run(pool, w);
+      note(w);
+      for (size_t g = 0; g < order.size(); ++g) level[s][order[g]] = first + (long)g;
+    }
+    // adjugate: adj(j,i) = (-1)^(i+j) * minor(i,j)  (Matrix.cpp:192-199; the sign acts on the reduced, unscaled minor)
+    std::vector<std::vector<long>> adj(d, std::vector<long>(d));
+    std::vector<int32_t> toNeg;
+    for (unsigned i = 0; i < d; ++i) for (unsigned j = 0; j < d; ++j) { adj[j][i] = level[d - 1][Key(1u << i, 1u << j)]; if ((i + j) % 2 == 1) toNeg.push_back((int32_t)adj[j][i]); }
+    { const long firstNeg = pool.negated(toNeg); long g = 0; for (unsigned i = 0; i < d; ++i) for (unsigned j = 0; j < d; ++j) if ((i + j) % 2 == 1) adj[j][i] = firstNeg + g++; }
+    // det = sum_i A(0,i) adj(i,0) (Matrix.cpp:202-212), and theta = adj * last (Matrix.cpp:57-79 + MapAll key switch, Regression.h:131-134)
+    ProductWave wf;
+    for (unsigned i = 0; i < d; ++i) wf.product(A[0][i], adj[i][0]);
+    wf.end_group();
+    for (unsigned i = 0; i < d; ++i) { for (unsigned k = 0; k < d; ++k) wf.product(adj[i][k], last[k]); wf.end_group(); }
+    const long firstF = run(pool, wf);
+    note(wf);
+    pool.get(firstF, det);
+    theta.assign(d, Ciphertext(context));
+    for (unsigned i = 0; i < d; ++i) pool.get(firstF + 1 + i, theta[i]);
+  }
+
+ private:
+  void note(const ProductWave& w) { stats.products += (long)w.a.size(); stats.key_switches += w.groups(); stats.waves += 1; }
+};
+
+}  // namespace fhesi

@@ -63,3 +63,19 @@ def test_modulus_switching_methods_match_python_model():
     assert {int(k): [int(x) for x in v] for k, v in d["grown"].items()} == grown
     scaled = R.dcrt_scale_down_to_set(ctx, R.dcrt_from_poly(ctx, poly), [0, 1])
     assert {int(k): [int(x) for x in v] for k, v in d["scaled"].items()} == scaled
+
+
+REG = os.path.join(ROOT, "fhe-si_amd", "host", "test_regression")
+
+
+@pytest.mark.parametrize("p,g,dim,rows,seed", [(23, 7, 1, 2, 5), (23, 7, 2, 2, 1), (23, 7, 3, 2, 2), (17, 3, 3, 3, 3), (257, 3, 2, 2, 4), (47, 5, 4, 1, 6)])
+def test_regression_object_path_equals_batched_waves(p, g, dim, rows, seed):
+    """Regression::Regress (Regression.h:102-149) three ways -- Matrix<Ciphertext> object at a time (the reference's control flow),
+    device waves (RegressBatched), plaintext ring -- see fhe-si_amd/host/test_regression.cpp.  m = 22 and 46 run Bluestein rows,
+    m = 16 and 256 the power-of-two NTT."""
+    build()
+    r = subprocess.run([REG, str(p), str(g), str(dim), str(rows), str(seed)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ciphertexts of both evaluators bit-identical: yes" in r.stdout
+    assert r.stdout.count("decrypts to the plaintext regression: yes") == 2
+    assert "Test SUCCEEDED" in r.stdout
