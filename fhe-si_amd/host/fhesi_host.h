@@ -337,6 +337,12 @@ class DoubleCRT {
     for (long i = s.first(); i <= s.last(); i = s.next(i)) { ck(fhesi_dcrt_download_row(h, (int32_t)i, row.data())); m[i] = vec_long(row.begin(), row.end()); }
     return m;
   }
+  void setMap(const std::map<long, vec_long>& m) {   // DoubleCRT.h: replace index set and rows (Import, Serialization.cpp:67-81)
+    IndexSet s; for (auto& kv : m) s.insert(kv.first);
+    if (h) { ck(fhesi_dcrt_free(h)); h = nullptr; }
+    alloc(s);
+    for (auto& kv : m) { if ((long)kv.second.size() != (long)context.zMstar.phiM()) Error("DoubleCRT::setMap: bad row length"); setRow(kv.first, kv.second); }
+  }
   void setRow(long i, const vec_long& r) { std::vector<uint64_t> v(r.begin(), r.end()); ck(fhesi_dcrt_upload_row(h, (int32_t)i, v.data())); }
   fhesi_dcrt* handle() const { return h; }
   void randomize() { IndexSet s = getIndexSet(); long n = context.zMstar.phiM(); for (long i = s.first(); i <= s.last(); i = s.next(i)) { vec_long r(n); for (long j = 0; j < n; ++j) r[j] = RandomBnd(context.ithPrime(i)); setRow(i, r); } }   // :468-481
@@ -414,6 +420,7 @@ class Ciphertext {
   CiphertextPart& operator[](unsigned i) { return parts[i]; }
   CiphertextPart GetPart(unsigned i) const { return parts[i]; }
   bool isScaledUp() const { return scaledUp; }
+  void Clear() { tProd.clear(); scaledUp = false; parts.clear(); }     // Ciphertext.cpp:160-165
 
   Ciphertext& operator+=(const Ciphertext& o) {   // Ciphertext.cpp:123-145
     assert(scaledUp == o.scaledUp);
@@ -495,6 +502,8 @@ class FHESIPubKey {
  public:
   FHESIPubKey(const FHESISecKey& sk) : context(sk.GetContext()) { Init(sk); }
   const FHEcontext& GetContext() const { return context; }
+  const std::vector<DoubleCRT>& GetRepresentation() const { return publicKey; }
+  void UpdateRepresentation(const std::vector<DoubleCRT>& r) { publicKey = r; }
   void Init(const FHESISecKey& sk) {   // FHE-SI.cpp:42-63
     ZZX c0, c1; sampleGaussian(c0, context.zMstar.phiM(), context.stdev); SampleRandom(c1, context.modulusQ, context.zMstar.phiM());
     ZZX tmp; sk.GetRepresentation()[1].toPoly(tmp); tmp = mul(tmp, c1);
@@ -523,6 +532,8 @@ class KeySwitchSI {
   KeySwitchSI(const FHESISecKey& s) : context(s.GetContext()) { InitS2(s); }
   KeySwitchSI(const FHESISecKey& src, const FHESISecKey& dst) : context(src.GetContext()) { Init(src, dst); }
   const std::vector<std::vector<DoubleCRT>>& GetRepresentation() const { return keySwitchMatrix; }
+  void UpdateRepresentation(const std::vector<std::vector<DoubleCRT>>& rep) { keySwitchMatrix = rep; }
+  const FHEcontext& GetContext() const { return context; }
   void Init(const FHESISecKey& src, const FHESISecKey& dst) {   // FHE-SI.cpp:153-209
     std::vector<DoubleCRT> s = src.GetRepresentation(); std::vector<ZZX> sCoeff(s.size());
     for (size_t i = 0; i < s.size(); ++i) s[i].toPoly(sCoeff[i]);

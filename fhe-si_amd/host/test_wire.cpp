@@ -1,0 +1,97 @@
+// test_wire.cpp -- the reference's binary wire format (fhesi_serialization.h) on the mirrored classes.
+//
+//   test_wire logQ p generator seed outdir
+//
+// Same key / plaintext / ciphertext sequence as test_addmul's runTest (Test_AddMul.cpp:15-60) from the documented PRNG, then
+//   outdir/context.bin  FHEcontext::ExportSIContext            outdir/sk.bin   FHESISecKey::Export
+//   outdir/pk.bin       FHESIPubKey::Export                    outdir/ksk.bin  KeySwitchSI::Export (s^2 -> s matrix)
+//   outdir/c1.bin       Export(Ciphertext) of a fresh ciphertext
+//   outdir/prod.bin     Export(Ciphertext) of the scaled-up product c1 * c2 (Serialization.cpp:109-114 scales it down first)
+// The parity test compares these files byte for byte with the Python model's rendering of the same objects.  The program then
+// imports everything into a second context built by ImportSIContext and checks that the imported keys decrypt the imported
+// ciphertexts and that the imported key-switch matrix relinearises the product.  Exit code 0 on success.
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "fhesi_serialization.h"
+
+using namespace fhesi;
+namespace fhesi { FHEcontext* activeContext = nullptr; }
+
+static std::vector<long> mul_mod_phi(const std::vector<long>& a, const std::vector<long>& b, const FHEcontext& c, long p) {
+  ZZX x, y; for (size_t i = 0; i < a.size(); ++i) SetCoeff(x, (long)i, a[i]); for (size_t i = 0; i < b.size(); ++i) SetCoeff(y, (long)i, b[i]);
+  ZZX r = mul(x, y); rem(r, r, c.zMstar.PhimX());
+  std::vector<long> out(c.zMstar.phiM(), 0); for (long i = 0; i <= deg(r); ++i) out[i] = rem(r.rep[i], p);
+  return out;
+}
+
+int main(int argc, char* argv[]) {
+  if (argc < 6) { std::cout << "usage: test_wire logQ p generator seed outdir" << std::endl; return 1; }
+  const unsigned logQ = atoi(argv[1]), p = atoi(argv[2]), g = atoi(argv[3]);
+  const long long seed = atoll(argv[4]);
+  const std::string dir = argv[5];
+  auto path = [&](const char* f) { return dir + "/" + f; };
+  std::vector<long> m1, m2;
+  {
+    FHEcontext context(p - 1, logQ, p, g, 3);
+    activeContext = &context;
+    context.SetUpSIContext();
+    SetSeed((uint64_t)seed);
+    FHESISecKey secretKey(context);
+    FHESIPubKey publicKey(secretKey);
+    const long phim = context.zMstar.phiM();
+    Plaintext ptxt1, ptxt2; ptxt1.message.resize(phim); ptxt2.message.resize(phim);
+    for (long i = 0; i < phim; ++i) ptxt1.message[i] = RandomBnd((long)p);
+    for (long i = 0; i < phim; ++i) ptxt2.message[i] = RandomBnd((long)p);
+    m1 = ptxt1.message; m2 = ptxt2.message;
+    Ciphertext c1(context), c2(context);
+    publicKey.Encrypt(c1, ptxt1); publicKey.Encrypt(c2, ptxt2);
+    KeySwitchSI keySwitch(secretKey);
+    Ciphertext prod = c1; prod *= c2;
+    { std::ofstream f(path("context.bin"), std::ios::binary); ExportSIContext(context, f); }
+    { std::ofstream f(path("sk.bin"), std::ios::binary); Export(f, secretKey); }
+    { std::ofstream f(path("pk.bin"), std::ios::binary); Export(f, publicKey); }
+    { std::ofstream f(path("ksk.bin"), std::ios::binary); Export(f, keySwitch); }
+    { std::ofstream f(path("c1.bin"), std::ios::binary); Export(f, c1); }
+    { std::ofstream f(path("c2.bin"), std::ios::binary); Export(f, c2); }
+    { std::ofstream f(path("prod.bin"), std::ios::binary); Export(f, prod); }
+    activeContext = nullptr;
+  }
+  // ---- import side: nothing survives from above except the files
+  std::ifstream fc(path("context.bin"), std::ios::binary);
+  std::unique_ptr<FHEcontext> ctx2 = ImportSIContext(fc);
+  activeContext = ctx2.get();
+  SetSeed(12345);
+  FHESISecKey sk2(*ctx2);                 // freshly drawn keys, replaced by the imported representation
+  FHESIPubKey pk2(sk2);
+  KeySwitchSI ks2(sk2);
+  { std::ifstream f(path("sk.bin"), std::ios::binary); Import(f, sk2); }
+  { std::ifstream f(path("pk.bin"), std::ios::binary); Import(f, pk2); }
+  { std::ifstream f(path("ksk.bin"), std::ios::binary); Import(f, ks2); }
+  Ciphertext c1(*ctx2), c2(*ctx2), prod(*ctx2);
+  { std::ifstream f(path("c1.bin"), std::ios::binary); Import(f, c1); }
+  { std::ifstream f(path("c2.bin"), std::ios::binary); Import(f, c2); }
+  { std::ifstream f(path("prod.bin"), std::ios::binary); Import(f, prod); }
+  int failures = 0;
+  Plaintext res;
+  sk2.Decrypt(res, c1);
+  if (res.message != m1) { std::cout << "imported key does not decrypt imported ciphertext 1" << std::endl; ++failures; }
+  sk2.Decrypt(res, c2);
+  if (res.message != m2) { std::cout << "imported key does not decrypt imported ciphertext 2" << std::endl; ++failures; }
+  // a fresh encryption under the imported public key
+  Plaintext pt; pt.message = m2; Ciphertext fresh(*ctx2); pk2.Encrypt(fresh, pt);
+  sk2.Decrypt(res, fresh);
+  if (res.message != m2) { std::cout << "imported public key does not encrypt for the imported secret key" << std::endl; ++failures; }
+  // the imported product has 3 parts (it was scaled down on export): relinearise it with the imported matrix
+  if (prod.parts.size() != 3) { std::cout << "imported product has " << prod.parts.size() << " parts" << std::endl; ++failures; }
+  ks2.ApplyKeySwitch(prod);
+  sk2.Decrypt(res, prod);
+  if (res.message != mul_mod_phi(m1, m2, *ctx2, (long)p)) { std::cout << "imported key-switch matrix does not relinearise the imported product" << std::endl; ++failures; }
+  // re-export equals the file
+  { std::ostringstream os; Export(os, ks2); std::ifstream f(path("ksk.bin"), std::ios::binary); std::string orig((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (os.str() != orig) { std::cout << "re-export of the key-switch matrix differs" << std::endl; ++failures; } }
+  std::cout << (failures ? "wire roundtrip FAILED" : "wire roundtrip ok") << std::endl;
+  activeContext = nullptr;
+  return failures;
+}

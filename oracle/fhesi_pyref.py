@@ -756,6 +756,105 @@ def usable_slots(m: int, p: int) -> int:
 
 
 # --------------------------------------------------------------------------------------------
+# Wire format (Serialization.h:29-85, Serialization.cpp:3-119, FHEContext.cpp:45-81, FHE-SI.cpp:72-78,137-143,270-276), LP64:
+# `unsigned`/uint32_t/int32_t = 4 bytes, `long` = 8 bytes, bool = 1 byte, all little endian (x86-64 raw struct writes).
+# --------------------------------------------------------------------------------------------
+import struct
+
+
+def wire_zz(v: int) -> bytes:
+    """Export(ofstream&, const ZZ&) (Serialization.cpp:3-13): uint32 NumBytes, bool neg, magnitude bytes little endian
+    (NTL: NumBytes(0) == 0; BytesFromZZ writes |val|)."""
+    mag = abs(v)
+    nb = (mag.bit_length() + 7) // 8
+    return struct.pack("<I?", nb, v < 0) + mag.to_bytes(nb, "little")
+
+
+def wire_zzx(poly: Sequence[int]) -> bytes:
+    """Export(ofstream&, const ZZX&) (Serialization.cpp:29-36): int32 degree (-1 for the zero polynomial), coefficients 0..deg."""
+    deg = len(poly) - 1
+    while deg >= 0 and poly[deg] == 0:
+        deg -= 1
+    return struct.pack("<i", deg) + b"".join(wire_zz(poly[i]) for i in range(deg + 1))
+
+
+def wire_vec_long(row: Sequence[int]) -> bytes:
+    """Export(ofstream&, const vec_long&) (Serialization.cpp:83-89)."""
+    return struct.pack("<I", len(row)) + struct.pack("<%dq" % len(row), *row)
+
+
+def wire_dcrt(a: dict) -> bytes:
+    """Export(ofstream&, const DoubleCRT&) (Serialization.cpp:56-65): uint32 card, then (long index, vec_long row) ascending."""
+    return struct.pack("<I", len(a)) + b"".join(struct.pack("<q", i) + wire_vec_long(a[i]) for i in sorted(a))
+
+
+def wire_vector(items, item_fn) -> bytes:
+    """Export(ofstream&, const vector<T>&) (Serialization.h:41-48)."""
+    return struct.pack("<I", len(items)) + b"".join(item_fn(x) for x in items)
+
+
+def wire_ciphertext(parts: Sequence[Sequence[int]]) -> bytes:
+    """Export(ofstream&, const Ciphertext&) (Serialization.cpp:109-114) of an unscaled ciphertext: vector<CiphertextPart>."""
+    return wire_vector(parts, wire_zzx)
+
+
+def wire_key_switch(ksm) -> bytes:
+    """KeySwitchSI::Export (FHE-SI.cpp:270-272): vector<vector<DoubleCRT>>."""
+    return wire_vector(ksm, lambda row: wire_vector(row, wire_dcrt))
+
+
+def wire_context(ctx: "Ctx", generator: int) -> bytes:
+    """FHEcontext::ExportSIContext (FHEContext.cpp:45-60)."""
+    out = struct.pack("<II", ctx.m, ctx.logQ) + wire_zz(ctx.p) + struct.pack("<II", generator, ctx.decomp_size)
+    out += struct.pack("<I", ctx.L)
+    for q, r in zip(ctx.primes, ctx.roots):
+        out += struct.pack("<qq", q, r)
+    return out
+
+
+class WireReader:
+    """Import side of the same format."""
+
+    def __init__(self, data: bytes):
+        self.d, self.o = data, 0
+
+    def take(self, fmt: str):
+        v = struct.unpack_from(fmt, self.d, self.o)
+        self.o += struct.calcsize(fmt)
+        return v if len(v) > 1 else v[0]
+
+    def zz(self) -> int:
+        nb, neg = self.take("<I?")
+        v = int.from_bytes(self.d[self.o:self.o + nb], "little")
+        self.o += nb
+        return -v if neg else v
+
+    def zzx(self, n: int = 0) -> List[int]:
+        deg = self.take("<i")
+        poly = [self.zz() for _ in range(deg + 1)]
+        return poly + [0] * max(0, n - len(poly))
+
+    def vec_long(self) -> List[int]:
+        n = self.take("<I")
+        v = list(struct.unpack_from("<%dq" % n, self.d, self.o))
+        self.o += 8 * n
+        return v
+
+    def dcrt(self) -> dict:
+        out = {}
+        for _ in range(self.take("<I")):
+            i = self.take("<q")
+            out[i] = self.vec_long()
+        return out
+
+    def vector(self, item_fn):
+        return [item_fn() for _ in range(self.take("<I"))]
+
+    def done(self) -> bool:
+        return self.o == len(self.d)
+
+
+# --------------------------------------------------------------------------------------------
 # BGV-style modulus switching (dead code in fhe-si -- no callers -- but part of the DoubleCRT surface, SURVEY.md a12)
 # --------------------------------------------------------------------------------------------
 def dcrt_add_primes_and_scale(ctx: Ctx, a: dict, s1: Sequence[int]) -> dict:

@@ -79,3 +79,33 @@ def test_regression_object_path_equals_batched_waves(p, g, dim, rows, seed):
     assert "ciphertexts of both evaluators bit-identical: yes" in r.stdout
     assert r.stdout.count("decrypts to the plaintext regression: yes") == 2
     assert "Test SUCCEEDED" in r.stdout
+
+
+def test_wire_format_bytes_match_python_model(tmp_path):
+    """ExportSIContext / key Export / Ciphertext Export (FHEContext.cpp:45-60, FHE-SI.cpp:72-74,137-139,270-272, Serialization.cpp)
+    written by the C++ mirror == the Python model's rendering of the same objects, byte for byte; then the import round trip."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fhesi_pyref as R
+    build()
+    fx = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "ciphertext.json")))["mul_relin"] if c["m"] == 22][0]
+    m, logQ, p, seed = fx["m"], fx["logQ"], fx["p"], fx["seed"]
+    r = subprocess.run([os.path.join(ROOT, "fhe-si_amd", "host", "test_wire"), str(logQ), str(p), "7", str(seed), str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "wire roundtrip ok" in r.stdout
+    I = lambda v: [int(x) for x in v]
+    primes, roots = I(fx["primes"]), I(fx["roots"])
+    ctx = R.Ctx(m, logQ, p, primes, roots)
+    rd = lambda name: open(os.path.join(str(tmp_path), name), "rb").read()
+    assert rd("context.bin") == R.wire_context(ctx, 7)
+    t, pk = R.keygen(ctx, R.SplitMix64(seed))
+    assert [str(x) for x in t] == fx["t"]
+    one = [1] + [0] * (ctx.phim - 1)
+    assert rd("sk.bin") == R.wire_vector([R.dcrt_from_poly(ctx, one), R.dcrt_from_poly(ctx, t)], R.wire_dcrt)
+    assert rd("pk.bin") == R.wire_vector([R.dcrt_from_poly(ctx, c) for c in pk], R.wire_dcrt)
+    ksm = [[{i: I(d[i]) for i in range(ctx.L)} for d in fx["ksm"][r]] for r in range(2)]
+    assert rd("ksk.bin") == R.wire_key_switch(ksm)
+    assert rd("c1.bin") == R.wire_ciphertext([I(x) for x in fx["c1"]])
+    assert rd("c2.bin") == R.wire_ciphertext([I(x) for x in fx["c2"]])
+    assert rd("prod.bin") == R.wire_ciphertext([I(x) for x in fx["scaled"]])        # Export scales the product down first

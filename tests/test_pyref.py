@@ -57,3 +57,19 @@ def test_addmul_sequence(seed):
     nine = R.apply_key_switch(ctx, ksm, acc)
     quad = R.ct_mul_relin(ctx, ksm, nine, prod2)
     assert R.decrypt(ctx, t, quad) == [9 * c % p for c in mulp(e_prod2, e_prod2)]
+
+
+def test_wire_format_round_trip():
+    """Serialization.cpp:3-119 restated: what wire_* writes, WireReader reads back; known byte strings of the small cases."""
+    import random
+    rng = random.Random(1)
+    assert R.wire_zz(0) == bytes.fromhex("0000000000")                     # NumBytes(0) = 0, not negative
+    assert R.wire_zz(-258) == bytes.fromhex("02000000010201")              # 2 bytes, negative, magnitude little endian
+    assert R.wire_zzx([0, 0]) == bytes.fromhex("ffffffff")                 # zero polynomial: degree -1
+    poly = [rng.randrange(-(1 << 90), 1 << 90) for _ in range(10)] + [0, 0]
+    rd = R.WireReader(R.wire_zzx(poly))
+    assert rd.zzx(12) == poly and rd.done()
+    d = {0: [1, 2, 3], 2: [4, 5, (1 << 60) - 1]}
+    rd = R.WireReader(R.wire_key_switch([[d, d], [d]]))
+    assert rd.vector(lambda: rd.vector(rd.dcrt)) == [[d, d], [d]] and rd.done()
+    assert R.wire_vec_long([7]) == bytes.fromhex("01000000" + "0700000000000000")
