@@ -246,7 +246,11 @@ def main():
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "ntt_fwd_tile<14, true, false>" if not args.ntt_rows else "ntt_fwd_tile<14, false, false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    if args.workload != "metric" or args.ntt_rows:
+        traffic = None          # the PMC passes in profiles/ were taken on the metric workload's launch shape
+    big = "true" if ctx.phim > (1 << 14) else "false"       # rows above 2^14: tile pass of the two-pass transform
+    kname = "ntt_fwd_tile<14, %s, false, %s>" % ("false" if args.ntt_rows else "true", big)
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
                 "rows_per_launch": round(rows / launches, 1) if launches else None,
