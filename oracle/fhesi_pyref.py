@@ -756,6 +756,116 @@ def usable_slots(m: int, p: int) -> int:
 
 
 # --------------------------------------------------------------------------------------------
+# Matrix<Ciphertext> (Matrix.cpp) and Regression::Regress (Regression.h:102-134), literal control flow.
+# A ciphertext value is ("parts", [poly, poly, ...]) when unscaled or ("tprod", [dcrt, dcrt, dcrt]) when scaled up.
+# --------------------------------------------------------------------------------------------
+def _cv_mul(ctx: Ctx, a, b):
+    """Ciphertext::operator*=(Ciphertext) (Ciphertext.cpp:167-192); both operands unscaled in every caller."""
+    assert a[0] == "parts" and b[0] == "parts"
+    return ("tprod", ct_mul(ctx, a[1], b[1]))
+
+
+def _cv_add(ctx: Ctx, a, b):
+    """Ciphertext::operator+= (Ciphertext.cpp:123-145); asserts equal scaling like the reference (:124)."""
+    assert a[0] == b[0]
+    return ("parts", ct_add(ctx, a[1], b[1])) if a[0] == "parts" else ("tprod", tprod_add(ctx, a[1], b[1]))
+
+
+def _cv_neg(ctx: Ctx, a):
+    """`x *= -1` (Ciphertext.cpp:232-243)."""
+    return ("parts", ct_mul_long(ctx, a[1], -1)) if a[0] == "parts" else ("tprod", tprod_mul_long(ctx, a[1], -1))
+
+
+def matrix_determinant(ctx: Ctx, A, used_rows: List[bool], used_cols: List[bool], dim: int, reduce):
+    """Matrix<T>::Determinant (Matrix.cpp:227-263): Laplace expansion along the first unused row; `reduce` on every partial
+    determinant of size >= 2; size 1 returns the entry itself."""
+    d = len(A)
+    row = used_rows.index(False)
+    negative, det = False, None
+    for col in range(d):
+        if used_cols[col]:
+            continue
+        if dim == 1:
+            return A[row][col]
+        tmp = A[row][col]
+        if negative:
+            tmp = _cv_neg(ctx, tmp)
+        negative = not negative
+        used_rows[row] = used_cols[col] = True
+        tmp2 = matrix_determinant(ctx, A, used_rows, used_cols, dim - 1, reduce)
+        used_rows[row] = used_cols[col] = False
+        tmp = _cv_mul(ctx, tmp, tmp2)
+        det = tmp if det is None else _cv_add(ctx, det, tmp)
+    return reduce(det) if reduce else det
+
+
+def matrix_invert(ctx: Ctx, A, reduce):
+    """Matrix<T>::Invert (Matrix.cpp:182-216): returns (adjugate, det)."""
+    d = len(A)
+    adj = [[None] * d for _ in range(d)]
+    used_rows, used_cols = [False] * d, [False] * d
+    for i in range(d):
+        for j in range(d):
+            used_rows[i] = used_cols[j] = True
+            adj[j][i] = matrix_determinant(ctx, A, used_rows, used_cols, d - 1, reduce)
+            used_rows[i] = used_cols[j] = False
+            if (i + j) % 2 == 1:
+                adj[j][i] = _cv_neg(ctx, adj[j][i])
+    det = _cv_mul(ctx, A[0][0], adj[0][0])
+    for i in range(1, d):
+        det = _cv_add(ctx, det, _cv_mul(ctx, A[0][i], adj[i][0]))
+    return adj, (reduce(det) if reduce else det)
+
+
+def regress(ctx: Ctx, ksm, auto_ksms, ks: Sequence[int], X, y):
+    """Regression::Regress (Regression.h:102-134) without the GenerateNoise masking (:136-148).  X: N rows of d unscaled
+    ciphertexts (lists of parts), y: N unscaled ciphertexts.  Returns (theta parts list, det parts)."""
+    N, d = len(X), len(X[0])
+    P = lambda parts: ("parts", [list(q) for q in parts])
+
+    def key_switch(c):
+        return ("parts", apply_key_switch(ctx, ksm, c[1])) if c[0] == "tprod" else ("parts", apply_key_switch_parts(ctx, ksm, c[1]))
+
+    def process(c):                                                   # processFunc (:112-115)
+        c = key_switch(c)
+        return ("parts", sum_batched_data(ctx, auto_ksms, ks, c[1]))
+
+    # last = dataCopy^T * labels  (Matrix::operator*=(vector&), Matrix.cpp:81-98)
+    last = []
+    for i in range(d):
+        acc = _cv_mul(ctx, P(X[0][i]), P(y[0]))
+        for j in range(1, N):
+            acc = _cv_add(ctx, acc, _cv_mul(ctx, P(X[j][i]), P(y[j])))
+        last.append(acc)
+    # MultByTranspose (Matrix.cpp:150-174)
+    A = [[None] * d for _ in range(d)]
+    for i in range(d):
+        for j in range(i, d):
+            acc = _cv_mul(ctx, P(X[0][i]), P(X[0][j]))
+            for k in range(1, N):
+                acc = _cv_add(ctx, acc, _cv_mul(ctx, P(X[k][i]), P(X[k][j])))
+            A[i][j] = A[j][i] = acc
+    last = [process(c) for c in last]
+    done = {}
+    for i in range(d):                                                # MapAll visits both copies of a symmetric entry; same value
+        for j in range(d):
+            key = (min(i, j), max(i, j))
+            if key not in done:
+                done[key] = process(A[i][j])
+            A[i][j] = done[key]
+    if d == 1:
+        return [last[0][1]], A[0][0][1]
+    adj, det = matrix_invert(ctx, A, key_switch)
+    theta = []
+    for i in range(d):                                                # dataCopy *= last (Matrix.cpp:57-79), then MapAll key switch
+        acc = _cv_mul(ctx, adj[i][0], last[0])
+        for k in range(1, d):
+            acc = _cv_add(ctx, acc, _cv_mul(ctx, adj[i][k], last[k]))
+        theta.append(key_switch(acc)[1])
+    return theta, det[1]
+
+
+# --------------------------------------------------------------------------------------------
 # Wire format (Serialization.h:29-85, Serialization.cpp:3-119, FHEContext.cpp:45-81, FHE-SI.cpp:72-78,137-143,270-276), LP64:
 # `unsigned`/uint32_t/int32_t = 4 bytes, `long` = 8 bytes, bool = 1 byte, all little endian (x86-64 raw struct writes).
 # --------------------------------------------------------------------------------------------
