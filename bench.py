@@ -129,6 +129,107 @@ def cpu_baseline(primes, roots, ksm, a, b, n_sample):
                       f"with the C oracle's direct negacyclic NTT (optimistic vs the reference's Bluestein over NTL), {dt:.1f} s"}
 
 
+class _CountingBackend:
+    """dry run of the wave schedule: how many pool entries one Regress needs"""
+    auto_ks = ()
+
+    def __init__(self, used):
+        self.used = used
+
+    def run_wave(self, w):
+        first = self.used
+        self.used += w.groups
+        return first
+
+    def sum_batched(self, first, count):
+        pass
+
+    def negated(self, idx):
+        first = self.used
+        self.used += len(idx)
+        return first
+
+
+def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, dist, torch, F, chain_bits):
+    """configs[3] (Test_Regression d=8) replayed at the metric ring: one step = one Regression::Regress
+    (Regression.h:102-134) evaluated in waves (fhe-si_amd/regression.py); the groups of every wave are sharded over the ranks
+    and the wave's outputs exchanged (RCCL broadcast per producing rank), so total work is fixed: strong scaling."""
+    from fhe_si_amd import regression as G, shard
+    d, N, L = args.reg_dim, args.reg_rows, len(primes)
+    dev = f"cuda:{local_rank}"
+    ks = G.automorphism_exponents(M_RING, 7, P_PLAIN, n)
+    autos = []
+    for i in range(len(ks)):             # KeySwitchSI(secretKey, k) matrices (2 source components), broadcast like the main one
+        a = F.KeySwitchMatrix(ctx, 2, nd)
+        host = rand_residue_rows(np.random.default_rng(100 + i), primes, (2, 2 * nd), n) if rank == 0 else None
+        if world > 1:
+            stage = shard.broadcast_key_matrix(host, a.nbytes, dist, device=dev)
+            torch.cuda.synchronize()
+            ctx.dev_copy(a.device_ptr, stage.data_ptr(), a.nbytes)
+            del stage
+        else:
+            a.upload(host)
+        autos.append(a)
+    nin = N * (d + 1)
+    X = [[i * d + j for j in range(d)] for i in range(N)]
+    y = [N * d + i for i in range(N)]
+    counter = _CountingBackend(nin)
+    G.regress_waves(counter, X, y)
+    pool = G.ShardedPool(2 * n * nl, counter.used + 8, device=dev, dist=dist)
+    be = G.DeviceBackend(ctx, LOGQ, P_PLAIN, ksk, autos, ks, pool, DECOMP)
+    first = be.upload(rand_coeffs(np.random.default_rng(7), (nin, 2, n), nl))      # same inputs on every rank
+    assert first == 0
+    mark = pool.used
+    stats = {}
+
+    def step():
+        pool.used = mark
+        stats.update(G.regress_waves(be, X, y)[2])
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = {k: ctx.prof_read(k) for k in F.binding.PROF_CLASSES}
+    ctx.prof_enable(False)
+    launches, rows, ms = prof["ntt_fwd_digits_main"]
+    achieved = rows * 2 * n * 8 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    if rank == 0:
+        ksw = stats["key_switches"] + stats["automorph_key_switches"]
+        line = {
+            "metric": "key-switched ciphertext products/sec inside Regression::Regress (wave-scheduled) at n=2^14, logQ=512",
+            "value": round(ksw * args.steps / dt, 2), "unit": "key-switches/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"configs[3] replay: Regression::Regress d={d}, {N} data block(s), m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3",
+                       "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "automorphism_keys": len(ks), "waves": stats["waves"],
+                       "products_per_regress": stats["products"], "key_switches_per_regress": stats["key_switches"],
+                       "automorph_key_switches_per_regress": stats["automorph_key_switches"], "regress_per_s": round(args.steps / dt, 3),
+                       "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_tile<14, true, false, false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches,
+                         "avg_launch_ms": round(ms / launches, 4) if launches else None},
+            "cpu_baseline": None,
+            "kernel_ms_per_step": {k: round(v[2] / args.steps, 3) for k, v in prof.items() if v[0] and k != "ntt_fwd_digits_main"},
+        }
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,8 +239,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (FHESI_LANES); 2 gives ~+5 %% throughput but "
                     "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
-    ap.add_argument("--workload", default="metric", choices=["metric", "stress"], help="metric = configs[2] (default, the contract line); "
-                    "stress = configs[4]: m=2^16 (n=2^15), logQ=1024, p=65537 (35 primes, 43 digits) -- reporting only")
+    ap.add_argument("--workload", default="metric", choices=["metric", "stress", "regression"], help="metric = configs[2] (default, the contract line); "
+                    "stress = configs[4]: m=2^16 (n=2^15), logQ=1024, p=65537 (35 primes, 43 digits) -- reporting only; "
+                    "regression = configs[3] replayed at the metric ring: Regression::Regress (d = --reg-dim, --reg-rows data blocks) in waves, "
+                    "every wave's groups sharded over the ranks (strong scaling)")
+    ap.add_argument("--reg-dim", type=int, default=8)
+    ap.add_argument("--reg-rows", type=int, default=1)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 plumbing)")
     ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
@@ -193,6 +298,13 @@ def main():
         del stage
     else:
         ksk.upload(ksm_host)
+
+    if args.workload == "regression":
+        run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, dist, torch, F, chain_bits)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     rng = np.random.default_rng(7 + rank)
     a_host = rand_coeffs(rng, (B, 2, n), nl)
