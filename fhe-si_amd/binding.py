@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "fhesi_ct_mul_dev", "fhesi_apply_key_switch_dev", "fhesi_dev_alloc", "fhesi_dev_free", "fhesi_dev_upload", "fhesi_dev_download",
     "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
     "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
-    "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev",
+    "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -110,6 +110,8 @@ def _load():
         "fhesi_ct_automorph_key_switch_dev": [_vp, _vp, _i32, _i32, _i64, _vp, _i32, _i64, _vp, _i32],
         "fhesi_ct_gather_dev": [_vp, _vp, _vp, _i64, _i64, _vp],
         "fhesi_ct_mul_sum_relin_dev": [_vp, _vp, _i32, _u64, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp],
+        "fhesi_encrypt_batch": [_vp, _vp, _vp, _i32, _u64, _vp, _vp, _i64, _vp, _i32],
+        "fhesi_decrypt_batch": [_vp, _vp, _i32, _u64, _vp, _i32, _i64, _vp],
         "fhesi_dev_alloc": [_vp, C.c_size_t, _vp],
         "fhesi_dev_free": [_vp, _vp],
         "fhesi_dev_upload": [_vp, _vp, _vp, C.c_size_t],
@@ -280,6 +282,19 @@ class Context:
 
     def apply_key_switch_dev(self, ksk: "KeySwitchMatrix", logQ: int, tprod: DevBuf, count: int, out: DevBuf, nlimbs: int, decomp_bytes: int = 3):
         _ck(_load().fhesi_apply_key_switch_dev(self.h, ksk.h, logQ, decomp_bytes, tprod.ptr, count, out.ptr, nlimbs))
+
+    # ---- Encrypt / Decrypt batches (FHE-SI.cpp:10-36, 93-119); randomness supplied by the caller
+    def encrypt_batch(self, pk0: "DoubleCRT", pk1: "DoubleCRT", logQ: int, p: int, rand: np.ndarray, msg: np.ndarray, out: DevBuf, nlimbs: int):
+        """rand: [count][3][phim] int64 = (r, e0, e1); msg: [count][phim] int64; out: device [count][2][phim][nlimbs]."""
+        rand = np.ascontiguousarray(rand, dtype=np.int64)
+        msg = np.ascontiguousarray(msg, dtype=np.int64)
+        assert rand.shape[0] == msg.shape[0] and rand.shape[1] == 3
+        _ck(_load().fhesi_encrypt_batch(self.h, pk0.h, pk1.h, logQ, p, _p(rand), _p(msg), msg.shape[0], out.ptr, nlimbs))
+
+    def decrypt_batch(self, sk1: "DoubleCRT", logQ: int, p: int, ct: DevBuf, nlimbs: int, count: int) -> np.ndarray:
+        msg = np.zeros((count, self.phim), dtype=np.int64)
+        _ck(_load().fhesi_decrypt_batch(self.h, sk1.h, logQ, p, ct.ptr, nlimbs, count, _p(msg)))
+        return msg
 
     # ---- ciphertext algebra between multiplications (Matrix<Ciphertext> / Regression), batches resident in HBM
     def ct_add_dev(self, logQ: int, dst: DevBuf, src: DevBuf, nparts: int, nlimbs: int, count: int):

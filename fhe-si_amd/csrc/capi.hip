@@ -892,6 +892,80 @@ extern "C" int fhesi_ct_gather_dev(fhesi_ctx* c, const uint64_t* pool, const int
   return launch_gather(c, (const u64*)pool, (const int*)d_idx, count, words, (u64*)out);
 }
 
+// --------------------------------------------------------------------------------------------- Encrypt / Decrypt batches
+// FHESIPubKey::Encrypt (FHE-SI.cpp:10-36) for `count` plaintexts; the randomness is the caller's (the reference draws it from NTL's
+// PRNG): rand_host = [count][3][phi(m)] int64 = (r binary, e0, e1 Gaussian samples before the multiplication by p)
+extern "C" int fhesi_encrypt_batch(fhesi_ctx* c, const fhesi_dcrt* pk0, const fhesi_dcrt* pk1, int32_t logQ, uint64_t p, const int64_t* rand_host,
+                                   const int64_t* msg_host, int64_t count, uint64_t* out_dev, int32_t nlimbs) {
+  CHECK_CTX(c);
+  if (!pk0 || !pk1 || pk0->ctx != c || pk1->ctx != c) FHESI_FAIL("Encrypt: public key belongs to another context");
+  if ((int)pk0->idx.size() != c->L || (int)pk1->idx.size() != c->L) FHESI_FAIL("Encrypt: public key must be defined over all primes");
+  if (logQ < 1 || nlimbs * 64 < logQ) FHESI_FAIL("Encrypt: coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  if (p < 2) FHESI_FAIL("Encrypt: plaintext modulus must be at least 2");
+  if (!count) return 0;
+  const i64 n = c->phim;
+  const int L = c->L;
+  const std::vector<int> all = full_set(c);
+  void *d_small, *d_rows, *d_ct, *d_pk, *d_msg, *d_delta;
+  FHESI_TRY(ws_reserve(c, 2, (size_t)count * 3 * n * 8, &d_small));
+  FHESI_TRY(ws_reserve(c, 0, (size_t)count * 3 * L * n * 8, &d_rows));
+  FHESI_TRY(ws_reserve(c, 1, (size_t)count * 2 * L * n * 8, &d_ct));
+  FHESI_TRY(ws_reserve(c, 3, (size_t)2 * L * n * 8, &d_pk));
+  FHESI_TRY(ws_reserve(c, 5, (size_t)count * n * 8, &d_msg));
+  FHESI_TRY(ws_reserve(c, 4, (size_t)(nlimbs + 1) * 8, &d_delta));
+  // delta = floor(2^logQ / p) (FHE-SI.cpp:31), nlimbs limbs
+  std::vector<u64> delta(nlimbs, 0);
+  { u128 rem = 0; for (int i = nlimbs - 1; i >= 0; --i) { const u64 limb = (i == logQ / 64) ? (1ull << (logQ % 64)) : 0; const u128 cur = (rem << 64) | limb; delta[i] = (u64)(cur / p); rem = cur % p; }
+    if (logQ == 64 * nlimbs) { /* 2^logQ needs limb nlimbs: redo with the extra limb */ rem = 1; for (int i = nlimbs - 1; i >= 0; --i) { const u128 cur = rem << 64; delta[i] = (u64)(cur / p); rem = cur % p; } } }
+  HIP_TRY(hipMemcpyAsync(d_small, rand_host, (size_t)count * 3 * n * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_msg, msg_host, (size_t)count * n * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_delta, delta.data(), (size_t)nlimbs * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_pk, pk0->d_rows, (size_t)L * n * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync((u64*)d_pk + (size_t)L * n, pk1->d_rows, (size_t)L * n * 8, hipMemcpyDeviceToDevice, c->stream));
+  // DoubleCRT(r), DoubleCRT(e_i) * p: one-limb signed coefficients, the noise lifted by p (FHE-SI.cpp:19-25)
+  const u64 lift[3] = {0, p, p};
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)d_small, 1, n, count, 3, lift, (u64*)d_rows, L, nullptr));
+  FHESI_TRY(row_fwd(c, (u64*)d_rows, count * 3, L, nullptr, all.data()));
+  FHESI_TRY(launch_encrypt_combine(c, (const u64*)d_rows, (const u64*)d_pk, count, (u64*)d_ct));          // ct[i] = pk[i]*r + e_i (:26-27)
+  FHESI_TRY(row_inv(c, (u64*)d_ct, count * 2, L, nullptr, all.data()));                                    // toPoly (:28)
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, all, &t));
+  FHESI_TRY(launch_crt(c, t, (const u64*)d_ct, L, nullptr, count * 2, 2, 0, logQ, (u64*)out_dev, nlimbs));
+  FHESI_TRY(launch_add_scaled_msg(c, (u64*)out_dev, (const i64*)d_msg, (const u64*)d_delta, count, nlimbs, logQ));   // += delta*msg, Reduce (:31-35)
+  HIP_TRY(hipStreamSynchronize(c->stream));      // the host arrays may be released on return
+  return 0;
+}
+
+// FHESISecKey::Decrypt (FHE-SI.cpp:93-119) of `count` unscaled 2-part ciphertexts [count][2][phi(m)][nlimbs] in HBM
+extern "C" int fhesi_decrypt_batch(fhesi_ctx* c, const fhesi_dcrt* sk1, int32_t logQ, uint64_t p, const uint64_t* ct_dev, int32_t nlimbs, int64_t count,
+                                   int64_t* msg_host) {
+  CHECK_CTX(c);
+  if (!sk1 || sk1->ctx != c) FHESI_FAIL("Decrypt: secret key belongs to another context");
+  if ((int)sk1->idx.size() != c->L) FHESI_FAIL("Decrypt: secret key must be defined over all primes");
+  if (logQ < 1 || nlimbs < 1) FHESI_FAIL("Decrypt: bad shape");
+  if (p < 2 || p >= (1ull << 62)) FHESI_FAIL("Decrypt: plaintext modulus out of range");
+  if (!count) return 0;
+  const i64 n = c->phim;
+  const int L = c->L, nw = (logQ + 1 + 63) / 64;
+  const std::vector<int> all = full_set(c);
+  void *d_rows, *d_z, *d_big, *d_msg;
+  FHESI_TRY(ws_reserve(c, 0, (size_t)count * 2 * L * n * 8, &d_rows));
+  FHESI_TRY(ws_reserve(c, 1, (size_t)count * L * n * 8, &d_z));
+  FHESI_TRY(ws_reserve(c, 2, (size_t)count * n * nw * 8, &d_big));
+  FHESI_TRY(ws_reserve(c, 5, (size_t)count * n * 8, &d_msg));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)ct_dev, nlimbs, n, count, 2, nullptr, (u64*)d_rows, L, nullptr));     // DoubleCRT(parts[i]) (:98-101)
+  FHESI_TRY(row_fwd(c, (u64*)d_rows, count * 2, L, nullptr, all.data()));
+  FHESI_TRY(launch_decrypt_dot(c, (const u64*)d_rows, sk1->d_rows, count, (u64*)d_z));                              // DotProduct with (1, t) (:105-107)
+  FHESI_TRY(row_inv(c, (u64*)d_z, count, L, nullptr, all.data()));
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, all, &t));
+  FHESI_TRY(launch_crt(c, t, (const u64*)d_z, L, nullptr, count, 0, 0, 0, (u64*)d_big, nw));                         // toPoly, low logQ+1 bits kept
+  FHESI_TRY(launch_decrypt_round(c, (const u64*)d_big, count * n, nw, logQ, p, (i64*)d_msg));                        // round(p z / q) mod p (:110-116)
+  HIP_TRY(hipMemcpyAsync(msg_host, d_msg, (size_t)count * n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // One wave of Matrix<Ciphertext> arithmetic followed by the key switch (see include/fhesi_hip.h)
 extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* pool,
                                           int32_t nlimbs, const int32_t* a_idx, const int32_t* b_idx, const int32_t* seg, int64_t ngroups, uint64_t* out) {

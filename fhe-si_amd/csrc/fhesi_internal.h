@@ -95,7 +95,12 @@ struct fhesi_ctx {
   bool mark_mid = false;               // record ev_mid right after the next digit-NTT launch (staggers the second lane)
   bool prof_on = false;
   std::vector<ProfRec> prof;
-  // grow-only workspace
+  // grow-only workspace.  Slot owners (a slot may be reused by another owner only when the first one's data is dead):
+  //   0 digit rows / product operands / encrypt rows    1 inverse-transform scratch (tProd copy, dot output, automorph rows)
+  //   2 limb-major parts / small-coefficient staging    3 automorph source rows / encrypt public key
+  //   4 wave sums, per-call constants                    5 tProd of a chunk / message staging
+  //   6 row transforms above 2^14 (two-pass, bit reversal)   7 Bluestein slot map / wave operands
+  //   8 Bluestein convolution buffer, index lists        9 Bluestein inverse output, scalar lists (no Bluestein call in between)
   void* ws[10] = {};
   size_t ws_bytes[10] = {};
 };
@@ -169,6 +174,10 @@ int launch_ct_add(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 ncoeffs, int
 int launch_ct_mul_long(fhesi_ctx* ctx, u64* d_ct, i64 ncoeffs, int nl, int logQ, i64 l);
 int launch_gather(fhesi_ctx* ctx, const u64* d_pool, const int* d_idx, i64 count, i64 words, u64* d_out);
 int launch_segment_sum(fhesi_ctx* ctx, const u64* d_in, const int* d_seg, i64 ngroups, int ncomp, u64* d_out);
+int launch_encrypt_combine(fhesi_ctx* ctx, const u64* d_rows /* [count][3][L][n] */, const u64* d_pk /* [2][L][n] */, i64 count, u64* d_out /* [count][2][L][n] */);
+int launch_add_scaled_msg(fhesi_ctx* ctx, u64* d_ct, const i64* d_msg, const u64* d_delta, i64 count, int nl, int logQ);
+int launch_decrypt_dot(fhesi_ctx* ctx, const u64* d_rows /* [count][2][L][n] */, const u64* d_t /* [L][n] */, i64 count, u64* d_out /* [count][L][n] */);
+int launch_decrypt_round(fhesi_ctx* ctx, const u64* d_z, i64 total, int nw, int logQ, u64 p, i64* d_out);
 
 // kernels_crt.hip
 int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out);

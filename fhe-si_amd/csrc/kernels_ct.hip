@@ -142,3 +142,154 @@ int launch_segment_sum(fhesi_ctx* ctx, const u64* d_in, const int* d_seg, i64 ng
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ---- FHESIPubKey::Encrypt (FHE-SI.cpp:26-27): ct[i] = pk[i] * r + e[i]  for i = 0,1, all in evaluation form.
+// rows: [count][3][L][n] = (r, e0*p, e1*p); pk: [2][L][n]; out: [count][2][L][n]
+__global__ void __launch_bounds__(256) encrypt_combine_kernel(const u64* __restrict__ rows, const u64* __restrict__ pk, u64* __restrict__ out, int L, i64 n,
+                                                              const PrimeConst* __restrict__ pcs) {
+  const i64 c = blockIdx.z;
+  const int l = blockIdx.y;
+  const PrimeConst pc = pcs[l];
+  const u64* r = rows + ((c * 3 + 0) * L + l) * n;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    const u64 rv = r[j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const u64 e = rows[((c * 3 + 1 + i) * L + l) * n + j];
+      out[((c * 2 + i) * L + l) * n + j] = d_addmod(d_mulmod(pk[((i64)i * L + l) * n + j], rv, pc), e, pc.q);
+    }
+  }
+}
+int launch_encrypt_combine(fhesi_ctx* ctx, const u64* d_rows, const u64* d_pk, i64 count, u64* d_out) {
+  if (!count) return 0;
+  unsigned gx = (unsigned)((ctx->phim + 255) / 256);
+  if (gx > 64) gx = 64;
+  for (i64 done = 0; done < count; done += 65535) {
+    const i64 cnt = count - done < 65535 ? count - done : 65535;
+    encrypt_combine_kernel<<<dim3(gx, (unsigned)ctx->L, (unsigned)cnt), 256, 0, ctx->stream>>>(d_rows + done * 3 * ctx->L * ctx->phim, d_pk, d_out + done * 2 * ctx->L * ctx->phim,
+                                                                                              ctx->L, ctx->phim, ctx->d_pc);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- ctxt[0] += delta * msg; ReduceCoefficients (FHE-SI.cpp:31-35).  ct: [count][2][n][nl]; msg: [count][n] small non-negative;
+// delta = floor(2^logQ / p) as nl limbs.  The product is taken modulo 2^(64 nl), exact modulo 2^logQ.
+template <int MAXNL>
+__global__ void __launch_bounds__(256) add_scaled_msg_kernel(u64* __restrict__ ct, const i64* __restrict__ msg, const u64* __restrict__ delta, i64 n, int nl, int logQ) {
+  const i64 c = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const u64 mv = (u64)msg[c * n + j];
+  u64* x = ct + ((c * 2) * n + j) * nl;
+  u64 v[MAXNL];
+  u64 mc = 0, ac = 0;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i < nl) {
+      const u64 dl = delta[i];
+      const u64 lo = dl * mv, hi = d_mulhi(dl, mv);
+      const u64 pr = lo + mc;
+      mc = hi + (pr < lo);
+      const u64 a = x[i], s = a + pr, s2 = s + ac;
+      ac = (s < a) | (s2 < s);
+      v[i] = s2;
+    }
+  u64 sb = 0;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i == (logQ - 1) >> 6) sb = (v[i] >> ((logQ - 1) & 63)) & 1;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i < nl) x[i] = reduce_limb(v[i], i, logQ, sb);
+}
+int launch_add_scaled_msg(fhesi_ctx* ctx, u64* d_ct, const i64* d_msg, const u64* d_delta, i64 count, int nl, int logQ) {
+  if (!count) return 0;
+  if (nl > 32) FHESI_FAIL("ciphertext coefficients of %d limbs exceed the supported 32", nl);
+  const dim3 grid((unsigned)((ctx->phim + 255) / 256), (unsigned)count);
+  if (count > 65535) FHESI_FAIL("Encrypt: more than 65535 plaintexts per call");
+  if (nl <= 2) add_scaled_msg_kernel<2><<<grid, 256, 0, ctx->stream>>>(d_ct, d_msg, d_delta, ctx->phim, nl, logQ);
+  else if (nl <= 8) add_scaled_msg_kernel<8><<<grid, 256, 0, ctx->stream>>>(d_ct, d_msg, d_delta, ctx->phim, nl, logQ);
+  else if (nl <= 16) add_scaled_msg_kernel<16><<<grid, 256, 0, ctx->stream>>>(d_ct, d_msg, d_delta, ctx->phim, nl, logQ);
+  else add_scaled_msg_kernel<32><<<grid, 256, 0, ctx->stream>>>(d_ct, d_msg, d_delta, ctx->phim, nl, logQ);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- FHESISecKey::Decrypt (FHE-SI.cpp:105-107): z = c0 + c1 * t in evaluation form.  rows: [count][2][L][n]; t: [L][n]; out [count][L][n]
+__global__ void __launch_bounds__(256) decrypt_dot_kernel(const u64* __restrict__ rows, const u64* __restrict__ t, u64* __restrict__ out, int L, i64 n,
+                                                          const PrimeConst* __restrict__ pcs) {
+  const i64 c = blockIdx.z;
+  const int l = blockIdx.y;
+  const PrimeConst pc = pcs[l];
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x)
+    out[(c * L + l) * n + j] = d_addmod(rows[((c * 2) * L + l) * n + j], d_mulmod(rows[((c * 2 + 1) * L + l) * n + j], t[(i64)l * n + j], pc), pc.q);
+}
+int launch_decrypt_dot(fhesi_ctx* ctx, const u64* d_rows, const u64* d_t, i64 count, u64* d_out) {
+  if (!count) return 0;
+  unsigned gx = (unsigned)((ctx->phim + 255) / 256);
+  if (gx > 64) gx = 64;
+  for (i64 done = 0; done < count; done += 65535) {
+    const i64 cnt = count - done < 65535 ? count - done : 65535;
+    decrypt_dot_kernel<<<dim3(gx, (unsigned)ctx->L, (unsigned)cnt), 256, 0, ctx->stream>>>(d_rows + done * 2 * ctx->L * ctx->phim, d_t, d_out + done * ctx->L * ctx->phim, ctx->L,
+                                                                                          ctx->phim, ctx->d_pc);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- the rounding of Decrypt (FHE-SI.cpp:110-116): m = floor((2 p z + q) / (2 q)) mod p, q = 2^logQ.
+// Writing z = zh * 2q + zl with zl = z mod 2q in [0, 2q) gives floor(...) = 2 p zh + floor((2 p zl + q) / 2q), and the first
+// term vanishes modulo p: only the low logQ+1 bits of z matter, and the quotient is at most 2p.
+// z: [npolys][n][nw] two's complement truncated to nw = ceil((logQ+1)/64) limbs; out: [npolys][n]
+template <int MAXNL>
+__global__ void __launch_bounds__(256) decrypt_round_kernel(const u64* __restrict__ z, i64 total, int nw, int logQ, u64 p, i64* __restrict__ out) {
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= total) return;
+  const int top_bits = logQ + 1 - 64 * (nw - 1);                  // bits of zl in its top limb (1..64)
+  const u64 twop = 2 * p;
+  u64 P[MAXNL + 1];
+  u64 carry = 0;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i) {
+    P[i] = 0;
+    if (i < nw) {
+      u64 xi = z[j * nw + i];
+      if (i == nw - 1 && top_bits < 64) xi &= (1ull << top_bits) - 1;
+      const u64 lo = xi * twop, hi = d_mulhi(xi, twop);
+      const u64 s = lo + carry;
+      carry = hi + (s < lo);
+      P[i] = s;
+    }
+  }
+  // limb nw of the product is `carry`; add q = 2^logQ with carry propagation
+  const int wq = logQ >> 6;
+  u64 add = 1ull << (logQ & 63);
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i < nw && i >= wq) { const u64 s = P[i] + add; add = s < add; P[i] = s; }
+  carry += add;
+  // bits from logQ+1 upward: at most 2p, fits one word
+  const int ws = (logQ + 1) >> 6, bs = (logQ + 1) & 63;
+  u64 lo = 0, hi = 0;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i) {
+    if (i == ws) lo = (i < nw) ? P[i] : carry;
+    if (i == ws + 1) hi = (i < nw) ? P[i] : (i == nw ? carry : 0);
+  }
+  if (ws == MAXNL) lo = carry;
+  if (ws + 1 == MAXNL) hi = (nw == MAXNL) ? carry : hi;
+  const u64 t = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+  out[j] = (i64)(t % p);
+}
+int launch_decrypt_round(fhesi_ctx* ctx, const u64* d_z, i64 total, int nw, int logQ, u64 p, i64* d_out) {
+  if (!total) return 0;
+  if (nw > 32) FHESI_FAIL("Decrypt: logQ=%d exceeds the supported 2047 bits", logQ);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (nw <= 2) decrypt_round_kernel<2><<<grid, 256, 0, ctx->stream>>>(d_z, total, nw, logQ, p, d_out);
+  else if (nw <= 9) decrypt_round_kernel<9><<<grid, 256, 0, ctx->stream>>>(d_z, total, nw, logQ, p, d_out);
+  else if (nw <= 17) decrypt_round_kernel<17><<<grid, 256, 0, ctx->stream>>>(d_z, total, nw, logQ, p, d_out);
+  else decrypt_round_kernel<32><<<grid, 256, 0, ctx->stream>>>(d_z, total, nw, logQ, p, d_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -486,6 +486,18 @@ class FHESISecKey {
   void UpdateRepresentation(const std::vector<DoubleCRT>& r) { sKeys = r; }
   const FHEcontext& GetContext() const { return context; }
   size_t GetSize() const { return sKeys.size(); }
+  // Decrypt for many unscaled 2-part ciphertexts in one device call (fhesi_decrypt_batch); same values as repeated Decrypt calls
+  void DecryptBatch(std::vector<Plaintext>& ptxts, const std::vector<Ciphertext>& ctxts) const {
+    const long n = context.zMstar.phiM(), count = (long)ctxts.size(); const int nl = (int)((context.logQ + 63) / 64);
+    std::vector<uint64_t> host((size_t)count * 2 * n * nl);
+    for (long c = 0; c < count; ++c) for (int part = 0; part < 2; ++part) for (long j = 0; j < n; ++j) coeff(ctxts[c].GetPart((unsigned)part).poly, j).to_limbs(&host[((c * 2 + part) * n + j) * nl], nl);
+    void* dev; ck(fhesi_dev_alloc(context.handle(), host.size() * 8, &dev)); ck(fhesi_dev_upload(context.handle(), dev, host.data(), host.size() * 8));
+    std::vector<int64_t> msg((size_t)count * n);
+    ck(fhesi_decrypt_batch(context.handle(), sKeys[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), (const uint64_t*)dev, nl, count, msg.data()));
+    ck(fhesi_dev_free(context.handle(), dev));
+    ptxts.assign(count, Plaintext());
+    for (long c = 0; c < count; ++c) ptxts[c].message.assign(msg.begin() + c * n, msg.begin() + (c + 1) * n);
+  }
   void Decrypt(Plaintext& ptxt, const Ciphertext& ctxt) const {   // FHE-SI.cpp:93-119
     std::vector<DoubleCRT> cp, sp;
     for (size_t i = 0; i < sKeys.size(); ++i) { cp.push_back(DoubleCRT(ctxt.GetPart((unsigned)i).poly, context)); sp.push_back(sKeys[i]); }
@@ -510,6 +522,27 @@ class FHESIPubKey {
     c0 += tmp; rem(c0, c0, context.zMstar.PhimX()); c1 *= ZZ(-1L);
     ReduceCoefficients(c0, context.logQ); ReduceCoefficients(c1, context.logQ);
     publicKey.clear(); publicKey.push_back(DoubleCRT(c0, context)); publicKey.push_back(DoubleCRT(c1, context));
+  }
+  // Encrypt for many plaintexts in one device call (fhesi_encrypt_batch).  The randomness is drawn here, per plaintext, in the
+  // order Encrypt draws it (r, noise of part 0, noise of part 1), so the ciphertexts equal those of repeated Encrypt calls.
+  void EncryptBatch(std::vector<Ciphertext>& ctxts, const std::vector<Plaintext>& ptxts) const {
+    const long n = context.zMstar.phiM(), count = (long)ptxts.size(); const int nl = (int)((context.logQ + 63) / 64);
+    std::vector<int64_t> rnd((size_t)count * 3 * n), msg((size_t)count * n, 0);
+    for (long c = 0; c < count; ++c) {
+      for (long j = 0; j < n; ++j) rnd[(c * 3) * n + j] = RandomBnd(2L);
+      for (int i = 0; i < 2; ++i) { ZZX e; sampleGaussian(e, n, context.stdev); for (long j = 0; j < n; ++j) rnd[(c * 3 + 1 + i) * n + j] = coeff(e, j).to_long(); }
+      for (size_t k = 0; k < ptxts[c].message.size() && (long)k < n; ++k) msg[c * n + k] = ptxts[c].message[k];
+    }
+    void* dev; ck(fhesi_dev_alloc(context.handle(), (size_t)count * 2 * n * nl * 8, &dev));
+    ck(fhesi_encrypt_batch(context.handle(), publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), rnd.data(), msg.data(),
+                           count, (uint64_t*)dev, nl));
+    std::vector<uint64_t> host((size_t)count * 2 * n * nl);
+    ck(fhesi_dev_download(context.handle(), host.data(), dev, host.size() * 8)); ck(fhesi_dev_free(context.handle(), dev));
+    ctxts.assign(count, Ciphertext(context));
+    for (long c = 0; c < count; ++c) {
+      ctxts[c].Initialize(2, context);
+      for (int part = 0; part < 2; ++part) { ZZX poly; poly.rep.resize(n); for (long j = 0; j < n; ++j) poly.rep[j] = ZZ::from_limbs(&host[((c * 2 + part) * n + j) * nl], nl); poly.normalize(); ctxts[c][part].poly = poly; }
+    }
   }
   void Encrypt(Ciphertext& ctxt, const Plaintext& ptxt) const {   // FHE-SI.cpp:10-36
     ctxt.Initialize(2, context);

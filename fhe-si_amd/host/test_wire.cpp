@@ -83,6 +83,16 @@ int main(int argc, char* argv[]) {
   Plaintext pt; pt.message = m2; Ciphertext fresh(*ctx2); pk2.Encrypt(fresh, pt);
   sk2.Decrypt(res, fresh);
   if (res.message != m2) { std::cout << "imported public key does not encrypt for the imported secret key" << std::endl; ++failures; }
+  // batched Encrypt / Decrypt on the device give what the per-object methods give from the same PRNG state
+  {
+    std::vector<Plaintext> pts(3); pts[0].message = m1; pts[1].message = m2; pts[2].message = m1;
+    SetSeed(777); std::vector<Ciphertext> one(3, Ciphertext(*ctx2)); for (int i = 0; i < 3; ++i) pk2.Encrypt(one[i], pts[i]);
+    SetSeed(777); std::vector<Ciphertext> many; pk2.EncryptBatch(many, pts);
+    bool same = many.size() == 3; for (int i = 0; same && i < 3; ++i) same = one[i][0] == many[i][0] && one[i][1] == many[i][1];
+    if (!same) { std::cout << "EncryptBatch differs from Encrypt" << std::endl; ++failures; }
+    std::vector<Plaintext> dec; sk2.DecryptBatch(dec, many);
+    if (dec.size() != 3 || dec[0].message != m1 || dec[1].message != m2 || dec[2].message != m1) { std::cout << "DecryptBatch does not invert EncryptBatch" << std::endl; ++failures; }
+  }
   // the imported product has 3 parts (it was scaled down on export): relinearise it with the imported matrix
   if (prod.parts.size() != 3) { std::cout << "imported product has " << prod.parts.size() << " parts" << std::endl; ++failures; }
   ks2.ApplyKeySwitch(prod);

@@ -147,6 +147,18 @@ int fhesi_ct_gather_dev(fhesi_ctx* ctx, const uint64_t* pool_dev, const int32_t*
 int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* pool_dev,
                                int32_t nlimbs, const int32_t* a_idx, const int32_t* b_idx, const int32_t* seg, int64_t ngroups, uint64_t* out_dev);
 
+/* ---- Encrypt / Decrypt in batches.  The polynomial arithmetic runs on the device; the randomness stays the
+ * caller's (the reference draws it from NTL's PRNG, FHE-SI.cpp:14-25), which keeps results reproducible bit for bit.
+ * FHESIPubKey::Encrypt (FHE-SI.cpp:10-36): pk0, pk1 = publicKey[0..1] over all primes;
+ *   rand_host [count][3][phi(m)] int64 = (r: binary polynomial, e0, e1: Gaussian samples BEFORE the multiplication by p);
+ *   msg_host [count][phi(m)] int64 in [0,p) (coefficient form);  out_dev [count][2][phi(m)][nlimbs] centred mod 2^logQ. */
+int fhesi_encrypt_batch(fhesi_ctx* ctx, const fhesi_dcrt* pk0, const fhesi_dcrt* pk1, int32_t logQ, uint64_t p, const int64_t* rand_host,
+                        const int64_t* msg_host, int64_t count, uint64_t* out_dev, int32_t nlimbs);
+/* FHESISecKey::Decrypt (FHE-SI.cpp:93-119) of unscaled 2-part ciphertexts: sk1 = sKeys[1] (sKeys[0] = 1);
+ *   msg_host [count][phi(m)] = round(p * (c0 + c1 t) / 2^logQ) mod p, floor((2 p z + q) / (2 q)) as in the reference. */
+int fhesi_decrypt_batch(fhesi_ctx* ctx, const fhesi_dcrt* sk1, int32_t logQ, uint64_t p, const uint64_t* ct_dev, int32_t nlimbs, int64_t count,
+                        int64_t* msg_host);
+
 /* plain device-memory helpers so C callers need no HIP headers */
 int fhesi_dev_alloc(fhesi_ctx* ctx, size_t bytes, void** out_dev);
 int fhesi_dev_free(fhesi_ctx* ctx, void* dev);

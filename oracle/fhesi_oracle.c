@@ -408,3 +408,36 @@ void orc_apply_key_switch_parts(const orc_ctx* c, const u64* ksm, const u64* par
   }
   free(dig); free(bd); free(acc); free(tmp); free(big);
 }
+
+/* ------------------------------------------------------------------ Encrypt / Decrypt with explicit randomness */
+/* FHESIPubKey::Encrypt (FHE-SI.cpp:10-36).  pk: [2][L][phim] rows; small: the binary polynomial r (:14-18); noise: [2][phim]
+ * Gaussian samples before the multiplication by p (:24-25); msg: [phim] in [0,p).  out: [2][phim][nlimbs] */
+void orc_encrypt(const orc_ctx* c, const u64* pk, const i64* small, const i64* noise, const i64* msg, int logQ, u64 p, u64* out, int nlimbs) {
+  i64 n = c->phim; i64 rs = (i64)c->L * n; u64* r = malloc(8 * rs); u64* e = malloc(8 * rs); u64* ct = malloc(8 * rs); u64 pl[1] = {p};
+  int W = c->L + 3; u64* big = malloc(8 * n * W);
+  orc_dcrt_from_poly(c, (const u64*)small, 1, n, r);
+  /* delta = floor(2^logQ / p) (:31) as a W-limb integer: schoolbook division of 2^logQ by the word p */
+  u64 delta[W]; memset(delta, 0, sizeof(delta)); { u128 rem = 0; for (int i = W - 1; i >= 0; i--) { u64 limb = (i == logQ / 64) ? (1ull << (logQ % 64)) : 0; u128 cur = (rem << 64) | limb; delta[i] = (u64)(cur / p); rem = cur % p; } }
+  for (int i = 0; i < 2; i++) {
+    orc_dcrt_from_poly(c, (const u64*)(noise + (i64)i * n), 1, n, e); orc_dcrt_op_scalar(c, e, pl, 1, 2);                 /* e *= p */
+    memcpy(ct, pk + (i64)i * rs, 8 * rs); orc_dcrt_op(c, ct, r, 2); orc_dcrt_op(c, ct, e, 0);                              /* pk[i]*r + e (:26-27) */
+    orc_dcrt_to_poly(c, ct, NULL, 0, 0, big, W);
+    for (i64 j = 0; j < n; j++) { u64* v = big + j * W;
+      if (i == 0) bn_addmul_i64(v, delta, msg[j], W);                                                                      /* += delta * msg (:32-33) */
+      reduce_logq(v, W, logQ, 0); bn_copy_ext(out + ((i64)i * n + j) * nlimbs, nlimbs, v, W); }
+  }
+  free(r); free(e); free(ct); free(big);
+}
+/* FHESISecKey::Decrypt (FHE-SI.cpp:93-119) of a 2-part ciphertext: z = c0 + c1*t, m = round(p z / q) mod p with
+ * floor((2 p z + q) / (2 q)).  t_rows: [L][phim] = sKeys[1]; parts: [2][phim][nlimbs]; msg_out: [phim] in [0,p) */
+void orc_decrypt(const orc_ctx* c, const u64* t_rows, const u64* parts, int nlimbs, int logQ, u64 p, i64* msg_out) {
+  i64 n = c->phim; i64 rs = (i64)c->L * n; u64* c0 = malloc(8 * rs); u64* c1 = malloc(8 * rs);
+  orc_dcrt_from_poly(c, parts, nlimbs, n, c0); orc_dcrt_from_poly(c, parts + n * nlimbs, nlimbs, n, c1);
+  orc_dcrt_op(c, c1, t_rows, 2); orc_dcrt_op(c, c0, c1, 0);                  /* DotProduct with (1, t) (:105-107) */
+  int W = c->L + 4; u64* big = malloc(8 * n * W); orc_dcrt_to_poly(c, c0, NULL, 0, 0, big, W);
+  u64 q[W]; memset(q, 0, sizeof(q)); q[logQ / 64] = 1ull << (logQ % 64);
+  for (i64 j = 0; j < n; j++) { u64* v = big + j * W; int s = bn_sign(v, W); if (s) bn_neg(v, W); bn_mul_u64(v, 2 * p, W); if (s) bn_neg(v, W);   /* 2 p z */
+    bn_add(v, q, W); bn_sar(v, W, logQ + 1);                                 /* floor((2pz + q) / 2q) */
+    msg_out[j] = (i64)bn_mod_u64(v, W, p); }
+  free(c0); free(c1); free(big);
+}

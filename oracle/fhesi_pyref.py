@@ -603,19 +603,27 @@ def keygen(ctx: Ctx, rng: SplitMix64):
     return t, [c0, c1]
 
 
-def encrypt(ctx: Ctx, pk, msg: Sequence[int], rng: SplitMix64) -> List[List[int]]:
-    """FHESIPubKey::Encrypt (FHE-SI.cpp:10-36)."""
-    n, Q = ctx.phim, 1 << ctx.logQ
-    small = [rng.bnd(2) for _ in range(n)]
+def encrypt_with(ctx: Ctx, pk, msg: Sequence[int], small: Sequence[int], noise: Sequence[Sequence[int]]) -> List[List[int]]:
+    """FHESIPubKey::Encrypt (FHE-SI.cpp:10-36) with the randomness made explicit: `small` = the binary polynomial r (:14-18),
+    noise[i] = the Gaussian sample of part i before the multiplication by p (:24-25)."""
+    Q = 1 << ctx.logQ
     r = dcrt_from_poly(ctx, small)
     parts = []
     for i in range(2):
-        e = dcrt_op_scalar(ctx, dcrt_from_poly(ctx, sample_gaussian(rng, n)), ctx.p, "mul")
+        e = dcrt_op_scalar(ctx, dcrt_from_poly(ctx, noise[i]), ctx.p, "mul")
         c = dcrt_op(ctx, dcrt_op(ctx, dcrt_from_poly(ctx, pk[i]), r, "mul"), e, "add")
         parts.append(dcrt_to_poly(ctx, c))
     delta = Q // ctx.p
     parts[0] = [c + delta * (msg[k] if k < len(msg) else 0) for k, c in enumerate(parts[0])]
     return [[reduce_logq(c, ctx.logQ) for c in part] for part in parts]
+
+
+def encrypt(ctx: Ctx, pk, msg: Sequence[int], rng: SplitMix64) -> List[List[int]]:
+    """FHESIPubKey::Encrypt (FHE-SI.cpp:10-36); draw order: r, then the noise of part 0, then of part 1."""
+    n = ctx.phim
+    small = [rng.bnd(2) for _ in range(n)]
+    noise = [sample_gaussian(rng, n), sample_gaussian(rng, n)]
+    return encrypt_with(ctx, pk, msg, small, noise)
 
 
 def decrypt(ctx: Ctx, t: Sequence[int], parts: Sequence[Sequence[int]]) -> List[int]:

@@ -52,6 +52,8 @@ def lib():
         _lib.orc_ct_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
         _lib.orc_apply_key_switch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _lib.orc_ct_mul_relin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+        _lib.orc_encrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]
+        _lib.orc_decrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         _lib.orc_ct_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib.orc_ct_mul_long.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
         _lib.orc_ct_automorph.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -193,6 +195,23 @@ class Oracle:
         tprod = np.ascontiguousarray(tprod, dtype=np.uint64)
         out = np.zeros((2, self.phim, nlimbs), dtype=np.uint64)
         lib().orc_apply_key_switch(self.h, _p(ksm), _p(tprod), tprod.shape[0], logQ, decomp_bytes, _p(out), nlimbs)
+        return out
+
+    # ---- Encrypt / Decrypt with explicit randomness (FHE-SI.cpp:10-36, 93-119)
+    def encrypt(self, pk_rows: np.ndarray, small, noise, msg, logQ: int, p: int, nlimbs: int) -> np.ndarray:
+        pk_rows = np.ascontiguousarray(pk_rows, dtype=np.uint64)
+        small = np.ascontiguousarray(small, dtype=np.int64)
+        noise = np.ascontiguousarray(noise, dtype=np.int64)
+        msg = np.ascontiguousarray(msg, dtype=np.int64)
+        out = np.zeros((2, self.phim, nlimbs), dtype=np.uint64)
+        lib().orc_encrypt(self.h, _p(pk_rows), _p(small), _p(noise), _p(msg), logQ, p, _p(out), nlimbs)
+        return out
+
+    def decrypt(self, t_rows: np.ndarray, parts: np.ndarray, logQ: int, p: int) -> np.ndarray:
+        t_rows = np.ascontiguousarray(t_rows, dtype=np.uint64)
+        parts = np.ascontiguousarray(parts, dtype=np.uint64)
+        out = np.zeros(self.phim, dtype=np.int64)
+        lib().orc_decrypt(self.h, _p(t_rows), _p(parts), parts.shape[-1], logQ, p, _p(out))
         return out
 
     # ---- ciphertext algebra of Matrix<Ciphertext> / Regression: parts are [nparts][phim][nlimbs]
