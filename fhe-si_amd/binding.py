@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -63,6 +64,15 @@ def _load():
         return _lib
     if not os.path.exists(_SO):
         raise FhesiError(f"HIP extension not built: {_SO} is missing (run __graft_entry__.build())")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64, the library links /opt/rocm's.  Whichever is loaded first
+    # serves both (same soname); loading ours first and torch afterwards leaves torch without a device ("No HIP GPUs are
+    # available").  So when torch is installed it is imported first -- it is only ever used for pool memory and collectives
+    # (fhe-si_amd/regression.py, bench.py), never for compute.  FHESI_NO_TORCH_PRELOAD=1 skips this.
+    if "torch" not in sys.modules and not os.environ.get("FHESI_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(_SO)
     lib.fhesi_last_error.restype = C.c_char_p
     sig = {

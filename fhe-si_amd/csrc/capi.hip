@@ -3,6 +3,8 @@
 // fails with an error string if HIP is unavailable.
 #include "../../include/fhesi_hip.h"
 #include "fhesi_internal.h"
+#include <map>
+#include <set>
 
 #include <algorithm>
 #include <cstdlib>
@@ -966,7 +968,9 @@ extern "C" int fhesi_decrypt_batch(fhesi_ctx* c, const fhesi_dcrt* sk1, int32_t 
   return 0;
 }
 
-// One wave of Matrix<Ciphertext> arithmetic followed by the key switch (see include/fhesi_hip.h)
+// One wave of Matrix<Ciphertext> arithmetic followed by the key switch (see include/fhesi_hip.h).
+// Every distinct operand of a chunk is brought to evaluation form ONCE (a matrix entry or a minor typically feeds many products),
+// the products are formed and summed per group in one pass (tensor_sum_kernel), then the groups are key-switched together.
 extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* pool,
                                           int32_t nlimbs, const int32_t* a_idx, const int32_t* b_idx, const int32_t* seg, int64_t ngroups, uint64_t* out) {
   CHECK_CTX(c);
@@ -977,47 +981,78 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
   const i64 n = c->phim;
   const int L = c->L;
   const i64 ct_words = (i64)2 * n * nlimbs, tp_words = (i64)3 * L * n;
-  const i64 chunk = batch_chunk(c, 3 * k->ndigits);           // ciphertexts per key-switch call / products per tensor call
-  std::vector<int> lseg;
+  const std::vector<int> all = full_set(c);
+  const i64 chunk = batch_chunk(c, 3 * k->ndigits);           // groups per key-switch call
+  // distinct operands per pass: bound their evaluation-form rows (2 L n words each) to about 4 GiB
+  i64 ucap = (i64)(4.0 * 1024 * 1024 * 1024 / ((double)2 * L * n * 8));
+  if (const char* e = getenv("FHESI_WAVE_OPERANDS")) if (atoll(e) > 1) ucap = atoll(e);
+  if (ucap < 2) ucap = 2;
+  const u64 lift[2] = {p, p};
+  std::vector<int> ua, ub, sa, sb, lseg, host_idx;
+  std::map<int, int> ma, mb;
+  // one pass: terms [t0, t1) of the groups [g, g2) (group boundaries in gseg, relative to t0), summed into d_sum[0 .. g2-g)
+  auto pass = [&](i64 t0, i64 t1, const std::vector<int>& gseg, bool accumulate, u64* d_sum) -> int {
+    ua.clear(); ub.clear(); ma.clear(); mb.clear();
+    sa.resize(t1 - t0); sb.resize(t1 - t0);
+    for (i64 t = t0; t < t1; ++t) {
+      auto ia = ma.find(a_idx[t]); if (ia == ma.end()) { ia = ma.emplace(a_idx[t], (int)ua.size()).first; ua.push_back(a_idx[t]); }
+      auto ib = mb.find(b_idx[t]); if (ib == mb.end()) { ib = mb.emplace(b_idx[t], (int)ub.size()).first; ub.push_back(b_idx[t]); }
+      sa[t - t0] = ia->second; sb[t - t0] = ib->second;
+    }
+    const i64 nua = (i64)ua.size(), nub = (i64)ub.size(), nt = t1 - t0, ng = (i64)gseg.size() - 1;
+    void *d_ops, *d_rows, *d_ix;
+    FHESI_TRY(ws_reserve(c, 7, (size_t)(nua + nub) * ct_words * 8, &d_ops));
+    FHESI_TRY(ws_reserve(c, 0, (size_t)(nua + nub) * 2 * L * n * 8, &d_rows));
+    FHESI_TRY(ws_reserve(c, 5, sizeof(int) * (size_t)(nua + nub + 2 * nt + ng + 1), &d_ix));
+    host_idx.clear();
+    host_idx.insert(host_idx.end(), ua.begin(), ua.end());
+    host_idx.insert(host_idx.end(), ub.begin(), ub.end());
+    host_idx.insert(host_idx.end(), sa.begin(), sa.end());
+    host_idx.insert(host_idx.end(), sb.begin(), sb.end());
+    host_idx.insert(host_idx.end(), gseg.begin(), gseg.end());
+    HIP_TRY(hipMemcpyAsync(d_ix, host_idx.data(), sizeof(int) * host_idx.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                 // host_idx is reused by the next pass
+    const int* dix = (const int*)d_ix;
+    u64* d_a = (u64*)d_ops;
+    u64* d_b = d_a + (size_t)nua * ct_words;
+    u64* ca = (u64*)d_rows;
+    u64* cb = ca + (size_t)nua * 2 * L * n;
+    FHESI_TRY(launch_gather(c, (const u64*)pool, dix, nua + nub, ct_words, d_a));
+    // c1 = DoubleCRT(parts * p), c2 = DoubleCRT(other.parts)   (Ciphertext.cpp:169-176)
+    FHESI_TRY(launch_rns_reduce(c, d_a, nlimbs, n, nua, 2, lift, ca, L, nullptr));
+    FHESI_TRY(launch_rns_reduce(c, d_b, nlimbs, n, nub, 2, nullptr, cb, L, nullptr));
+    FHESI_TRY(row_fwd(c, ca, (nua + nub) * 2, L, nullptr, all.data()));
+    return launch_tensor_sum(c, ca, cb, dix + nua + nub, dix + nua + nub + nt, dix + nua + nub + 2 * nt, ng, accumulate, d_sum, (double)nt);
+  };
+  std::vector<int> gseg;
+  std::set<int> seen_a, seen_b;
   i64 g = 0;
   while (g < ngroups) {
-    // groups g..g2-1 whose products fit one tensor call; a single larger group is accumulated piecewise
-    i64 g2 = g, terms = 0;
-    while (g2 < ngroups && g2 - g < chunk && (g2 == g || terms + (seg[g2 + 1] - seg[g2]) <= chunk)) { terms += seg[g2 + 1] - seg[g2]; ++g2; }
+    // groups g..g2-1: at most `chunk` of them and at most `ucap` distinct operands (one group is always taken)
+    seen_a.clear(); seen_b.clear();
+    i64 g2 = g;
+    while (g2 < ngroups && g2 - g < chunk) {
+      std::set<int> na = seen_a, nb = seen_b;
+      for (i64 t = seg[g2]; t < seg[g2 + 1]; ++t) { na.insert(a_idx[t]); nb.insert(b_idx[t]); }
+      if (g2 > g && (i64)(na.size() + nb.size()) > ucap) break;
+      seen_a.swap(na); seen_b.swap(nb);
+      ++g2;
+    }
     const i64 ng = g2 - g;
-    void *d_ab, *d_tp, *d_sum, *d_seg;
-    FHESI_TRY(ws_reserve(c, 4, (size_t)(ng + 1) * tp_words * 8, &d_sum));     // (+1: partial sum of an oversized group)
-    const i64 t0 = seg[g], t1 = seg[g2];
-    for (i64 done = t0; done < t1; done += chunk) {
-      const i64 cnt = std::min(chunk, t1 - done);
-      FHESI_TRY(ws_reserve(c, 7, (size_t)cnt * ct_words * 16, &d_ab));
-      FHESI_TRY(ws_reserve(c, 5, (size_t)cnt * tp_words * 8, &d_tp));
-      uint64_t* d_a = (uint64_t*)d_ab;
-      uint64_t* d_b = d_a + (size_t)cnt * ct_words;
-      FHESI_TRY(fhesi_ct_gather_dev(c, pool, a_idx + done, cnt, ct_words, d_a));
-      FHESI_TRY(fhesi_ct_gather_dev(c, pool, b_idx + done, cnt, ct_words, d_b));
-      FHESI_TRY(fhesi_ct_mul_dev(c, p, d_a, d_b, nlimbs, cnt, (uint64_t*)d_tp));
-      if (t1 - t0 <= chunk) {
-        // tProd sums of the groups (Ciphertext::operator+= on scaled-up ciphertexts, Ciphertext.cpp:135-142)
-        lseg.resize(ng + 1);
-        for (i64 i = 0; i <= ng; ++i) lseg[i] = seg[g + i] - (int)t0;
-        FHESI_TRY(ws_reserve(c, 8, sizeof(int) * (size_t)(ng + 1), &d_seg));
-        HIP_TRY(hipMemcpyAsync(d_seg, lseg.data(), sizeof(int) * (size_t)(ng + 1), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        FHESI_TRY(launch_segment_sum(c, (const u64*)d_tp, (const int*)d_seg, ng, 3, (u64*)d_sum));
-      } else {
-        // one group with more products than a call holds: partial sums accumulate into d_sum
-        lseg = {0, (int)cnt};
-        FHESI_TRY(ws_reserve(c, 8, sizeof(int) * 2, &d_seg));
-        HIP_TRY(hipMemcpyAsync(d_seg, lseg.data(), sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (done == t0) FHESI_TRY(launch_segment_sum(c, (const u64*)d_tp, (const int*)d_seg, 1, 3, (u64*)d_sum));
-        else {
-          u64* d_part = (u64*)d_sum + (size_t)ng * tp_words;
-          FHESI_TRY(launch_segment_sum(c, (const u64*)d_tp, (const int*)d_seg, 1, 3, d_part));
-          FHESI_TRY(launch_ew_op(c, (u64*)d_sum, d_part, 3, L, nullptr, FHESI_OP_ADD));
-        }
+    void* d_sum;
+    FHESI_TRY(ws_reserve(c, 4, (size_t)ng * tp_words * 8, &d_sum));
+    if (ng == 1 && (i64)(seen_a.size() + seen_b.size()) > ucap) {
+      // one group with more distinct operands than a pass holds: its terms are summed piecewise into the same accumulator
+      const i64 step = ucap / 2;
+      for (i64 t0 = seg[g]; t0 < seg[g + 1]; t0 += step) {
+        const i64 t1 = std::min<i64>(t0 + step, seg[g + 1]);
+        gseg = {0, (int)(t1 - t0)};
+        FHESI_TRY(pass(t0, t1, gseg, t0 != seg[g], (u64*)d_sum));
       }
+    } else {
+      gseg.resize(ng + 1);
+      for (i64 i = 0; i <= ng; ++i) gseg[i] = seg[g + i] - seg[g];
+      FHESI_TRY(pass(seg[g], seg[g2], gseg, false, (u64*)d_sum));
     }
     FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_sum, ng, out + (size_t)g * ct_words, nlimbs));
     g = g2;

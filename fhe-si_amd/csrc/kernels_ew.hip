@@ -236,3 +236,49 @@ int launch_rows_equal(fhesi_ctx* ctx, const u64* a, const u64* b, i64 nwords, in
   *equal = !h;
   return 0;
 }
+
+// ---- sum of tensor products over index lists: the `newMatrix(i,j) += tmp` loops of Matrix.cpp:62-72,157-167,243 with
+// tmp = a *= b (Ciphertext.cpp:167-192) and += on scaled-up ciphertexts (:135-142), fused:
+//   out[g][0..2] = sum_{t in [seg[g], seg[g+1])} (a0 b0, a0 b1 + a1 b0, a1 b1)   with a = ca[slot_a[t]], b = cb[slot_b[t]]
+// ca: [nua][2][L][n] = evaluation form of the p-lifted left operands, cb: [nub][2][L][n] right operands; every distinct operand is
+// transformed once however many products use it.  Exact 128-bit accumulation, folded every 32 terms (64 products of < 2^122).
+__global__ void __launch_bounds__(256) tensor_sum_kernel(const u64* __restrict__ ca, const u64* __restrict__ cb, const int* __restrict__ slot_a,
+                                                         const int* __restrict__ slot_b, const int* __restrict__ seg, int accumulate, u64* __restrict__ out,
+                                                         i64 n, int L, const PrimeConst* __restrict__ pcs) {
+  const int g = blockIdx.z, l = blockIdx.y;
+  const PrimeConst pc = pcs[l];
+  const i64 rs = (i64)L * n;
+  u64* o0 = out + (((i64)g * 3 + 0) * L + l) * n;
+  const int t0 = seg[g], t1 = seg[g + 1];
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    Acc128 r0{0, 0}, r1{0, 0}, r2{0, 0};
+    if (accumulate) { r0.lo = o0[j]; r1.lo = o0[rs + j]; r2.lo = o0[2 * rs + j]; }
+    for (int t = t0; t < t1; ++t) {
+      const u64* a = ca + (((i64)slot_a[t] * 2) * L + l) * n + j;
+      const u64* b = cb + (((i64)slot_b[t] * 2) * L + l) * n + j;
+      const u64 a0 = a[0], a1 = a[rs], b0 = b[0], b1 = b[rs];
+      acc_mad(r0, a0, b0);
+      acc_mad(r1, a0, b1);
+      acc_mad(r1, a1, b0);
+      acc_mad(r2, a1, b1);
+      if (((t - t0) & 31) == 31) { r0 = Acc128{acc_reduce(r0, pc), 0}; r1 = Acc128{acc_reduce(r1, pc), 0}; r2 = Acc128{acc_reduce(r2, pc), 0}; }
+    }
+    o0[j] = acc_reduce(r0, pc);
+    o0[rs + j] = acc_reduce(r1, pc);
+    o0[2 * rs + j] = acc_reduce(r2, pc);
+  }
+}
+int launch_tensor_sum(fhesi_ctx* ctx, const u64* d_ca, const u64* d_cb, const int* d_slot_a, const int* d_slot_b, const int* d_seg, i64 ngroups, bool accumulate,
+                      u64* d_out, double nproducts) {
+  if (!ngroups) return 0;
+  for (int l = 0; l < ctx->L; ++l) if (ctx->pc[l].bar_k > 61) FHESI_FAIL("tensor_sum: %u-bit residues overflow the 128-bit accumulator", ctx->pc[l].bar_k);
+  ProfScope prof(ctx, PROF_TENSOR, nproducts);
+  for (i64 done = 0; done < ngroups; done += 65535) {
+    const i64 cnt = ngroups - done < 65535 ? ngroups - done : 65535;
+    dim3 grid(grid_x_for(ctx->phim), (unsigned)ctx->L, (unsigned)cnt);
+    tensor_sum_kernel<<<grid, 256, 0, ctx->stream>>>(d_ca, d_cb, d_slot_a, d_slot_b, d_seg + done, accumulate ? 1 : 0, d_out + done * 3 * ctx->L * ctx->phim, ctx->phim, ctx->L,
+                                                     ctx->d_pc);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

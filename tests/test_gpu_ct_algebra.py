@@ -123,12 +123,15 @@ def test_batches_vs_oracle(m, logQ, p):
         assert np.array_equal(after[:, i, :], (np.uint64(q) - before[:, i, :]) % np.uint64(q))
 
 
-@pytest.mark.parametrize("chunk", [None, "2"])
-def test_wave_of_products_sum_and_key_switch(chunk, monkeypatch):
+@pytest.mark.parametrize("chunk,operands", [(None, None), ("2", None), (None, "4"), ("1", "2")])
+def test_wave_of_products_sum_and_key_switch(chunk, operands, monkeypatch):
     """out[g] = KeySwitch(sum_t pool[a_t] * pool[b_t]) (fhesi_ct_mul_sum_relin_dev) vs the oracle composed the way Matrix.cpp does:
-    operator*= per product, += on the scaled-up ciphertexts, then ApplyKeySwitch.  chunk=2 forces the piecewise accumulation."""
+    operator*= per product, += on the scaled-up ciphertexts, then ApplyKeySwitch.  chunk bounds the groups per key-switch call,
+    operands the distinct ciphertexts transformed per pass (small values force the piecewise accumulation of one group)."""
     if chunk:
         monkeypatch.setenv("FHESI_BATCH_CHUNK", chunk)
+    if operands:
+        monkeypatch.setenv("FHESI_WAVE_OPERANDS", operands)
     m, logQ, p = 1024, 128, 23
     primes, roots = P.chain_for(m, logQ, p)
     ctx = F.Context(m, primes, roots)
