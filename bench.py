@@ -127,7 +127,7 @@ def cpu_baseline(primes, roots, ksm, a, b, n_sample):
     # the same oracle on all host cores: independent ciphertexts, one per thread (ctypes releases the GIL; the oracle keeps no
     # shared mutable state).  The reference itself is single-threaded; this is the generous CPU figure.
     from concurrent.futures import ThreadPoolExecutor
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = max(1, min(os.cpu_count() or 1, 32))          # (each oracle call holds ~0.4 GB of digit rows)
     t1 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(lambda i: orc.ct_mul_relin(ksm, a[i % n_sample], b[i % n_sample], LOGQ, P_PLAIN, DECOMP), range(cores)))
@@ -240,6 +240,87 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
         print(json.dumps(line), flush=True)
 
 
+def run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F):
+    """configs[1]: m = 2^14 (n = 8192), the first 8 primes = 1 mod 2^15 descending from 2^60, B DoubleCRTs of
+    uniform residues per GPU; one step = forward + inverse transform of the whole batch (2 B L row transforms); the round trip must
+    reproduce the input bit for bit, and one DoubleCRT is checked against the C oracle in both directions."""
+    m, n, L = 1 << 14, 1 << 13, 8
+    B = args.batch if args.batch != 32 else 1024
+    primes, q = [], (1 << 60) - 1
+    q -= q % (2 * m)
+    q += 2 * m + 1
+    while len(primes) < L:
+        q -= 2 * m
+        if _is_prime(q):
+            primes.append(q)
+    roots = [root_2m(q, m) for q in primes]
+    ctx = F.Context(m, primes, roots, device=local_rank)
+    host = rand_residue_rows(np.random.default_rng(42 + rank), primes, (B,), n)
+    buf = ctx.upload(host)
+
+    def step():
+        ctx.rows_ntt_fwd(buf, B)
+        ctx.rows_ntt_inv(buf, B)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    ctx.sync()
+    if dist:
+        dist.barrier()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fl, frows, fms = ctx.prof_read("ntt_fwd")
+    il, irows, ims = ctx.prof_read("ntt_inv")
+    ctx.prof_enable(False)
+    identity = bool(np.array_equal(buf.download(host.shape), host))
+    cpu = None
+    oracle_ok = None
+    if rank == 0 and args.cpu_sample > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        orc = O.Oracle(m, primes, roots)
+        one = ctx.upload(host[:1])
+        ctx.rows_ntt_fwd(one, 1)
+        ev = one.download((1, L, n))
+        t1 = time.perf_counter()
+        exp = np.stack([orc.fft_residues(i, host[0, i]) for i in range(L)])
+        back = np.stack([orc.cmod_ifft(i, exp[i]) for i in range(L)])
+        cdt = time.perf_counter() - t1
+        oracle_ok = bool(np.array_equal(ev[0], exp) and np.array_equal(back, host[0]))
+        cpu = {"value": 1.0 / cdt, "unit": "DoubleCRT round trips/s", "cores": 1, "kind": "port",
+               "sample": f"1 DoubleCRT (8 rows of n=2^13) forward + inverse with the C oracle's direct negacyclic NTT, {cdt * 1e3:.1f} ms"}
+    if rank == 0:
+        row_bytes = 2 * n * 8
+        ach = frows * row_bytes / (fms * 1e-3) / 1e9 if fms > 0 else 0.0
+        line = {
+            "metric": "DoubleCRT forward+inverse NTT round trips/sec at n=2^13, 8 primes", "value": round(B * args.steps * world / dt, 1),
+            "unit": "DoubleCRT round trips/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[1]: DoubleCRT NTT round trip, m=2^14 n=2^13, 8 primes of 60 bits", "L": L, "batch_per_gpu": B,
+                       "round_trip_is_identity": identity, "matches_oracle": oracle_ok},
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_tile<13, false, false, false>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": fl, "avg_launch_ms": round(fms / fl, 4) if fl else None,
+                         "row_ntts_per_s": round(frows / (fms * 1e-3), 1) if fms > 0 else None,
+                         "inverse": {"kernel": "ntt_inv_tile<13, false, false>", "achieved": round(irows * row_bytes / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
+                                     "row_ntts_per_s": round(irows / (ims * 1e-3), 1) if ims > 0 else None}},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+        if not identity or oracle_ok is False:
+            raise SystemExit("NTT round trip / oracle parity failed")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,7 +330,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (FHESI_LANES); 2 gives ~+5 %% throughput but "
                     "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
-    ap.add_argument("--workload", default="metric", choices=["metric", "stress", "regression"], help="metric = configs[2] (default, the contract line); "
+    ap.add_argument("--workload", default="metric", choices=["metric", "stress", "regression", "ntt"], help="metric = configs[2] (default, the contract line); "
+                    "ntt = configs[1]: DoubleCRT forward+inverse round trips at n=2^13, 8 primes, --batch DoubleCRTs per GPU (default there: 1024); "
                     "stress = configs[4]: m=2^16 (n=2^15), logQ=1024, p=65537 (35 primes, 43 digits) -- reporting only; "
                     "regression = configs[3] replayed at the metric ring: Regression::Regress (d = --reg-dim, --reg-rows data blocks) in waves, "
                     "every wave's groups sharded over the ranks (strong scaling)")
@@ -282,6 +364,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+
+    if args.workload == "ntt":
+        run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     n = M_RING // 2
     primes = prime_chain(M_RING, LOGQ, P_PLAIN, n)
