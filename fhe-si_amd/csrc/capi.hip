@@ -67,7 +67,7 @@ static void build_tile_order(const std::vector<Shoup2>& tw, int logn, std::vecto
     for (int x = 0; x < (1 << u); ++x)
       for (int jl = 0; jl < 1024; ++jl) twt[1024 + (i64)((1 << u) - 1 + x) * 1024 + jl] = tw[(1 << (10 + u)) + ((i64)hm::brv(jl, 10) << u) + x];
 }
-// the tile kernels use quotients scaled by 2^63 (modarith63.h)
+// the tile kernels use quotients scaled by 2^63 (modarith63.h), relative to the modulus they compute with (q_tile)
 static void to_q63(std::vector<Shoup2>& t, u64 q) {
   for (auto& e : t) e.wp = hm::shoup63(e.w, q);
 }
@@ -125,7 +125,9 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
     pc.r64 = (u64)(((u128)1 << 64) % Q);
     pc.r64_sh = hm::shoup(pc.r64, Q);
     pc.one_sh = hm::shoup(1, Q);
-    pc.one_q63 = hm::shoup63(1, Q);
+    // modulus of the tile kernels: q itself, or for small primes the largest multiple of q below 2^60 (ntt_tile.inc)
+    pc.q_tile = Q >= (1ull << 48) ? Q : Q * (((1ull << 60) - 1) / Q);
+    pc.one_q63 = hm::shoup63(1, pc.q_tile);
     if (Q < (1ull << 48)) c->has_small_prime = true; else c->n_big_primes++;
     pc.ninv = pc.ninv_sh = pc.ninv_w = pc.ninv_w_sh = 0;
   }
@@ -149,8 +151,8 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
       pc.ninv_sh = hm::shoup(pc.ninv, Q);
       pc.ninv_w = hm::mulmod(pc.ninv, n > 1 ? twi[(size_t)i * n + 1].w : 1, Q);
       pc.ninv_w_sh = hm::shoup(pc.ninv_w, Q);
-      pc.ninv_q63 = hm::shoup63(pc.ninv, Q);
-      pc.ninv_w_q63 = hm::shoup63(pc.ninv_w, Q);
+      pc.ninv_q63 = hm::shoup63(pc.ninv, pc.q_tile);
+      pc.ninv_w_q63 = hm::shoup63(pc.ninv_w, pc.q_tile);
     }
     const size_t tb = twf.size() * sizeof(Shoup2);
     HIP_TRY(hipMalloc(&c->d_tw_fwd, tb));
@@ -162,11 +164,11 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
       for (int i = 0; i < nprimes; ++i) {
         one.assign(twf.begin() + (size_t)i * n, twf.begin() + (size_t)(i + 1) * n);
         build_tile_order(one, lg, tmp);
-        to_q63(tmp, q[i]);
+        to_q63(tmp, c->pc[i].q_tile);
         std::copy(tmp.begin(), tmp.end(), all_f.begin() + (size_t)i * n);
         one.assign(twi.begin() + (size_t)i * n, twi.begin() + (size_t)(i + 1) * n);
         build_tile_order(one, lg, tmp);
-        to_q63(tmp, q[i]);
+        to_q63(tmp, c->pc[i].q_tile);
         std::copy(tmp.begin(), tmp.end(), all_i.begin() + (size_t)i * n);
       }
       HIP_TRY(hipMalloc(&c->d_twt_fwd, tb));
@@ -183,7 +185,7 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
         // forward sub-transforms: ring of 2^14 points with root psi^nsub = the first 2^14 entries of the bit-reversed table
         one.assign(twf.begin() + (size_t)i * n, twf.begin() + (size_t)i * n + n1);
         build_tile_order(one, 14, tmp);
-        to_q63(tmp, Q);
+        to_q63(tmp, c->pc[i].q_tile);
         std::copy(tmp.begin(), tmp.end(), all_f.begin() + (size_t)i * n1);
         // inverse sub-transform `sub`: stage s0+u of the row, block (sub << u) + b
         for (int sub = 0; sub < nsub; ++sub) {
@@ -191,10 +193,10 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
           for (int u = 0; u < 14; ++u)
             for (i64 b = 0; b < (1ll << u); ++b) one[(1ll << u) + b] = twi[(size_t)i * n + (1ll << (s0 + u)) + ((i64)sub << u) + b];
           build_tile_order(one, 14, tmp);
-          to_q63(tmp, Q);
+          to_q63(tmp, c->pc[i].q_tile);
           std::copy(tmp.begin(), tmp.end(), all_i.begin() + ((size_t)i * nsub + sub) * n1);
           const u64 f = hm::mulmod(c->pc[i].ninv, twi[(size_t)i * n + nsub + sub].w, Q);
-          fold[(size_t)i * nsub + sub] = Shoup2{f, hm::shoup63(f, Q)};
+          fold[(size_t)i * nsub + sub] = Shoup2{f, hm::shoup63(f, c->pc[i].q_tile)};
         }
         // forward tail: stage s builds M = 2^(14+s) points, entry j = psi^((n/M)(2j+1)), j < M/2
         const u64 psi = hm::mulmod(root[i], root[i], Q);

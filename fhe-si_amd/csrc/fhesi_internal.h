@@ -31,8 +31,9 @@ struct PrimeConst {
   u64 ninv, ninv_sh;        // phi(m)^-1 mod q and its Shoup quotient (power-of-two m: the /m of CModulus.cpp:125 folded with X^n=-1)
   u64 ninv_w, ninv_w_sh;    // ninv * psi^-brv(1) (last inverse stage twiddle folded with the scaling)
   u64 r64, r64_sh;          // 2^64 mod q (Horner step of the big-int -> residue reduction, CModulus.cpp:96 conv)
-  u64 one_q63;              // floor(2^63/q)
-  u64 ninv_q63, ninv_w_q63; // floor(ninv 2^63/q), floor(ninv_w 2^63/q): quotients in the tile kernels' 63-bit convention (modarith63.h)
+  u64 one_q63;              // floor(2^63/q_tile)
+  u64 ninv_q63, ninv_w_q63; // floor(ninv 2^63/q_tile), floor(ninv_w 2^63/q_tile): quotients in the tile kernels' 63-bit convention (modarith63.h)
+  u64 q_tile;               // modulus the tile kernels compute with: q, or the largest multiple of q below 2^60 when q < 2^48 (ntt_tile.inc)
 };
 
 struct Shoup2 { u64 w, wp; };   // constant multiplier and floor(w*2^64/q)
@@ -63,8 +64,8 @@ struct fhesi_ctx {
   i64 m = 0, phim = 0;
   int L = 0;
   bool pow2 = false;
-  int n_big_primes = 0;                // chain primes >= 2^48 (rows handled by the asm tile kernels)
-  bool has_small_prime = false;        // some chain prime is below the tile kernels' 2^48 bound (ntt_tile.inc)
+  int n_big_primes = 0;                // chain primes >= 2^48
+  bool has_small_prime = false;        // some chain prime is below 2^48: the tile kernels transform its rows modulo q_tile (ntt_tile.inc)
   int logn = 0;                        // log2(phim) when pow2
   std::vector<u64> q, root;
   std::vector<int> zms_idx;            // PAlgebra::zmsIdx (PAlgebra.cpp:50-52)
