@@ -1,0 +1,26 @@
+#!/bin/bash
+# Profiles of one round, run ON THE GPU BOX (via gpurun): kernel-trace statistics of the bench workloads and two separate PMC
+# passes (FETCH_SIZE, WRITE_SIZE) of the metric workload.  Results land in gpurun_out/prof_$1/ and are copied into profiles/ by hand.
+set -u
+TAG=${1:-round}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+run() {   # name, then bench.py arguments
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$name" -o "$name" -- python3 "$R/bench.py" "$@" > "$O/${name}_bench.json" 2> "$O/${name}.log"
+  cp "$O/$name"/*/"${name}_kernel_stats.csv" "$O/${name}_kernel_stats.csv" 2>/dev/null || cp "$O/$name/${name}_kernel_stats.csv" "$O/${name}_kernel_stats.csv" 2>/dev/null
+  tail -1 "$O/${name}_bench.json" | cut -c1-400
+}
+run metric --steps 5 --warmup 2
+run stress --workload stress --batch 8 --steps 3 --warmup 1 --cpu-sample 0
+run regression --workload regression --steps 3 --warmup 1
+run ntt --workload ntt --steps 10 --warmup 2
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 > /dev/null 2> "$O/pmc_$c.log"
+  f=$(find "$O/pmc_$c" -name '*counter_collection.csv' | head -1)
+  python3 "$R/tools/pmc_summary.py" "$f" "ntt_fwd_tile<14, true, false>" | tee "$O/pmc_$c.txt"
+done
+find "$O" -name '*.db' -delete; find "$O" -name '*agent_info.csv' -delete; find "$O" -name '*kernel_trace.csv' -delete; find "$O" -name '*counter_collection.csv' -delete
+ls -la "$O"
