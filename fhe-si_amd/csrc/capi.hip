@@ -81,7 +81,9 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
   if (nprimes < 1 || nprimes > 64) FHESI_FAIL("FHEcontext: number of primes %d outside [1,64]", nprimes);
   for (int i = 0; i < nprimes; ++i) {
     // FHEContext.cpp:31-34: assert( ProbPrime(p) && p % twoM == 1 && !inChain(p) )
-    if (q[i] >= (1ull << 62)) FHESI_FAIL("AddPrime: prime %d does not fit 62 bits", i);
+    // single-precision moduli of the reference are below 2^NTL_SP_NBITS (60 in NTL >= 10: zz_p::init rejects larger ones), and
+    // every lazy range of the kernels (4q + 2^32 < 2^63, 8 products of < 2^124 in a 128-bit sum, ...) is sized for that
+    if (q[i] >= (1ull << 60)) FHESI_FAIL("AddPrime: prime %d does not fit 60 bits (NTL_SP_NBITS)", i);
     if (!hm::is_prime(q[i])) FHESI_FAIL("AddPrime: modulus %d (%llu) is not prime", i, (unsigned long long)q[i]);
     if (q[i] % (2 * (u64)m) != 1) FHESI_FAIL("AddPrime: prime %d (%llu) is not 1 mod 2m", i, (unsigned long long)q[i]);
     for (int j = 0; j < i; ++j)

@@ -160,7 +160,20 @@ int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out)
 // needs run-time limb indices (shift by logQ).
 // KFIX / WFIX > 0: the prime count and limb count are compile-time constants, so the triangular recurrence unrolls
 // completely (no uniform branches, constants hoisted); 0 = run-time values.
-template <int MAXW, int KFIX, int WFIX>
+// 128-bit value -> [0,q): hi * (2^64 mod q) + lo, each reduced by a Shoup step
+__device__ __forceinline__ u64 crt_fold128(u128 a, const PrimeConst& pc) {
+  const u64 q = pc.q, lo = (u64)a, hi = (u64)(a >> 64);
+  const u64 h = d_shoup(hi, 1, pc.one_sh, q);                 // hi mod q
+  const u64 t = d_shoup_lazy(h, pc.r64, pc.r64_sh, q);        // hi * 2^64 mod q, in [0,2q)
+  const u64 l = d_shoup_lazy(lo, 1, pc.one_sh, q);            // lo mod q, in [0,2q)
+  u64 r = t + l;
+  if (r >= pc.two_q) r -= pc.two_q;
+  if (r >= q) r -= q;
+  return r;
+}
+// LQFIX > 0 (with KFIX, WFIX): logQ is a compile-time constant too, so the epilogue indexes the limb registers statically and
+// the LDS staging (and its cap on resident workgroups) disappears; modes 1-3 only.
+template <int MAXW, int KFIX, int WFIX, int LQFIX = 0>
 __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, i64 n, int nslots_layout, const int* __restrict__ slot_of /* [K] or null */,
                                                   int K_rt, int W_rt, const int* __restrict__ idx, const Shoup2* __restrict__ pow64,
                                                   const Shoup2* __restrict__ pinv, const u64* __restrict__ Ptab, const u64* __restrict__ halfP,
@@ -183,16 +196,20 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
       const u64 q = pc.q, two_q = pc.two_q;
       const u64 rk = base[(i64)(slot_of ? slot_of[k] : idx[k]) * n + j];
       // t = x mod q_k   (x < P_k < 2^(64k): k limbs)
-      u64 t = 0;
+      // as one exact 128-bit sum of products x_i * (2^(64 i) mod q_k), folded every 8 limbs (q_k < 2^60: 8 products of
+      // < 2^124 plus a residue fit 128 bits) -- 4 multiplies per limb instead of the 10 of a Shoup product per limb
       const Shoup2* pw = pow64 + (i64)k * W;      // wave-uniform scalar loads (an LDS copy of the tables measured slower)
+      u128 acc = 0;
+      constexpr int fold_mask = 7;
 #pragma unroll
       for (int i = 0; i < MAXW; ++i) {
         if (i < k && i < W) {
-          t += d_shoup_lazy(x[i], pw[i].w, pw[i].wp, q);
-          if (t >= two_q) t -= two_q;
+          acc += (u128)x[i] * pw[i].w;
+          if ((i & fold_mask) == fold_mask) acc = crt_fold128(acc, pc);
         }
       }
-      if (t >= q) t -= q;
+      u64 t = crt_fold128(acc, pc);
+      (void)two_q;
       // v = (r_k - t) * P_k^-1 mod q_k   (NumbTh.cpp:314-317 without the centring, see file header)
       const u64 v = d_shoup(d_submod(rk, t, q), pinv[k].w, pinv[k].wp, q);
       // x += v * P_k
@@ -201,14 +218,9 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
 #pragma unroll
       for (int i = 0; i < MAXW; ++i) {
         if (i <= k && i < W) {
-          const u64 p = Pk[i];
-          const u64 lo = v * p, hi = d_mulhi(v, p);
-          u64 s = x[i] + lo;
-          u64 c1 = s < lo;
-          s += carry;
-          c1 += s < carry;
-          x[i] = s;
-          carry = hi + c1;
+          const u128 s = (u128)v * Pk[i] + x[i] + carry;      // < 2^128: (2^64-1)^2 + 2 (2^64-1)
+          x[i] = (u64)s;
+          carry = (u64)(s >> 64);
         }
       }
     }
@@ -239,6 +251,58 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
         }
       }
     }
+  }
+  if constexpr (LQFIX > 0) {
+    static_assert(WFIX > 0 && WFIX <= MAXW, "static epilogue needs a compile-time limb count");
+    if (!active) return;
+    constexpr int LQ = LQFIX, w = LQ >> 6, b = LQ & 63, sw = (LQ - 1) >> 6, sb = (LQ - 1) & 63;
+    const u64 sf = (x[WFIX - 1] >> 63) ? ~0ull : 0ull;
+#define XS(i) ((i) < WFIX ? x[(i) < WFIX ? (i) : 0] : sf)
+    const u64 hbit = (XS(sw) >> sb) & 1;           // bit logQ-1: the rounding carry (mode 1) / the sign of the centred residue (mode 2)
+    if (mode == 1) {
+      u64 carry = hbit;
+      u64* o = out + poly * nl_out * n + j;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i < nl_out) {
+          const u64 lo = XS(i + w), hi = XS(i + w + 1);
+          u64 val = b ? ((lo >> b) | (hi << ((64 - b) & 63))) : lo;
+          val += carry;
+          carry = (carry && val == 0);
+          const int bits_left = LQ - 64 * i;
+          if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << (bits_left & 63)) - 1);
+          o[(i64)i * n] = val;
+        }
+      }
+      for (int i = MAXW; i < nl_out; ++i) o[(i64)i * n] = 0;
+    } else if (mode == 3) {
+      u64* o = out + poly * nl_out * n + j;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i < nl_out) {
+          u64 val = XS(i);
+          const int bits_left = LQ - 64 * i;
+          if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << (bits_left & 63)) - 1);
+          o[(i64)i * n] = val;
+        }
+      }
+      for (int i = MAXW; i < nl_out; ++i) o[(i64)i * n] = 0;
+    } else {
+      u64* o = out + (poly * n + j) * nl_out;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i < nl_out) {
+          u64 val = XS(i);
+          const int bits_left = LQ - 64 * i;
+          if (bits_left <= 0) val = hbit ? ~0ull : 0ull;
+          else if (bits_left < 64) { const u64 mask = (1ull << (bits_left & 63)) - 1; val = hbit ? (val | ~mask) : (val & mask); }
+          o[i] = val;
+        }
+      }
+      for (int i = MAXW; i < nl_out; ++i) o[i] = hbit ? ~0ull : 0ull;
+    }
+#undef XS
+    return;
   }
 #pragma unroll
   for (int i = 0; i < MAXW; ++i)
@@ -289,15 +353,15 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
   }
 }
 
-template <int MAXW, int KFIX = 0, int WFIX = 0>
+template <int MAXW, int KFIX = 0, int WFIX = 0, int LQFIX = 0>
 static int launch_crt_t(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode,
                         int positive, int logQ, u64* d_out, int nl_out) {
   const int TB = 128;
-  const size_t shmem = (size_t)t->W * TB * sizeof(u64);
+  const size_t shmem = LQFIX ? 0 : (size_t)t->W * TB * sizeof(u64);
   static unsigned long long attr_done = 0;     // one bit per device: the attribute is per device
-  if (!(attr_done >> ctx->device & 1)) { HIP_TRY(hipFuncSetAttribute((const void*)crt_kernel<MAXW, KFIX, WFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, MAXW * TB * 8)); attr_done |= 1ull << ctx->device; }
+  if (!LQFIX && !(attr_done >> ctx->device & 1)) { HIP_TRY(hipFuncSetAttribute((const void*)crt_kernel<MAXW, KFIX, WFIX, LQFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, MAXW * TB * 8)); attr_done |= 1ull << ctx->device; }
   dim3 grid((unsigned)((ctx->phim + TB - 1) / TB), (unsigned)npolys);
-  crt_kernel<MAXW, KFIX, WFIX><<<grid, TB, shmem, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->nidx, t->W, t->d_idx, t->d_pow64, t->d_pinv, t->d_P,
+  crt_kernel<MAXW, KFIX, WFIX, LQFIX><<<grid, TB, shmem, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->nidx, t->W, t->d_idx, t->d_pow64, t->d_pinv, t->d_P,
                                                     t->d_halfP, ctx->d_pc, mode, positive, logQ, d_out, nl_out);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -310,6 +374,7 @@ int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots
   const int W = t->W;
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
   // fully unrolled instantiation for the metric chain shape (fhe-si logQ = 512: 18 primes, 17-limb product)
+  if (t->nidx == 18 && W == 18 && logQ == 512 && mode != 0) return launch_crt_t<18, 18, 18, 512>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (t->nidx == 18 && W == 18) return launch_crt_t<18, 18, 18>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (W <= 4) return launch_crt_t<4>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (W <= 8) return launch_crt_t<8>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);

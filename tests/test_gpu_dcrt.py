@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import fhe_si_amd as F
+import fhesi_pyref as R
 import oracle_lib as O
 import params as P
 
@@ -143,6 +144,9 @@ def test_context_rejects_bad_primes():
         F.Context(m, [primes[0], primes[0]], [roots[0], roots[0]])
     with pytest.raises(F.FhesiError, match="root"):
         F.Context(m, [primes[0]], [1])
+    big = next(q for q in range((1 << 60) + 1, (1 << 60) + (1 << 20), 64) if R.is_prime(q))      # = 1 mod 2m but wider than NTL_SP_NBITS
+    with pytest.raises(F.FhesiError, match="60 bits"):
+        F.Context(m, [big], [R.find_root_2m(big, m)])
     ctx = F.Context(m, primes, roots)
     orc = O.Oracle(m, primes, roots)
     z, phi = orc.tables()
