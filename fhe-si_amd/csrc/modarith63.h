@@ -96,13 +96,19 @@ __device__ __forceinline__ u64 mulmod63(u64 y, const Tw63& t, const Mod63& m) {
 #undef BFLY_INV_NAME
 #undef BFLY_TWC
 
-// exact normalisations on store
+// exact normalisations on store.  Conditional subtraction without compares: values stay below 2^63, so the sign of v - c
+// tells whether to add c back (5 VALU instructions per step instead of a compare / select / borrow chain with VCC wait states)
+__device__ __forceinline__ u64 csub63(u64 v, u64 c) {                 // v < 2^63, c < 2^62:  v >= c ? v - c : v
+  const u64 d = v - c;
+  u32 mask;                                                   // (asm: keeps the compiler from turning this back into cmp + select)
+  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mask) : "v"((u32)(d >> 32)));
+  return d + (((u64)(mask & (u32)(c >> 32)) << 32) | (mask & (u32)c));
+}
 __device__ __forceinline__ u64 norm_fwd63(u64 v, const Mod63& m) {   // v < 4q + 2^32  ->  [0,q)
-  if (v >= m.twoq) v -= m.twoq;
-  if (v >= m.q) v -= m.q;
-  if (v >= m.q) v -= m.q;
-  return v;
+  v = csub63(v, m.twoq);
+  v = csub63(v, m.q);
+  return csub63(v, m.q);
 }
 __device__ __forceinline__ u64 norm_inv63(u64 v, const Mod63& m) {   // v < 2q  ->  [0,q)   (outputs of mulmod63)
-  return v >= m.q ? v - m.q : v;
+  return csub63(v, m.q);
 }
