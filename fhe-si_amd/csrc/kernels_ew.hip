@@ -80,9 +80,9 @@ __global__ void __launch_bounds__(256) tensor2x2_kernel(const u64* __restrict__ 
 // accumulated as exact 128-bit integers (ncol * q^2 < 2^128, checked by the launcher) and reduced once at the end.
 struct Acc128 { u64 lo, hi; };
 __device__ __forceinline__ void acc_mad(Acc128& a, u64 x, u64 y) {
-  const u64 pl = x * y, ph = d_mulhi(x, y);
-  a.lo += pl;
-  a.hi += ph + (a.lo < pl);
+  const u128 s = ((u128)a.hi << 64 | a.lo) + (u128)x * y;      // one 64x64->128 multiply-add: 4 v_mad_u64_u32
+  a.lo = (u64)s;
+  a.hi = (u64)(s >> 64);
 }
 __device__ __forceinline__ u64 acc_reduce(const Acc128& a, const PrimeConst& pc) {
   const u64 q = pc.q;
