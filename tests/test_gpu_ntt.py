@@ -15,7 +15,8 @@ def test_rows_fwd_inv_vs_oracle(logn):
     m = 2 * n
     L = 3 if logn < 18 else 2
     primes, roots = P.first_primes(m, L)
-    if logn <= 12 or 15 <= logn <= 17:     # also a small / odd-sized prime, like the last prime of a chain (FHEContext.cpp:101-107)
+    if logn <= 17:     # also a small / odd-sized prime, like the last prime of a chain (FHEContext.cpp:101-107): the tile kernels
+        # (logn 11..17) transform its rows modulo a 60-bit multiple of it
         small, sroots = P.first_primes(m, 1, sp_nbits=max(20, logn + (4 if logn <= 12 else 8)))
         primes, roots = primes[:2] + small, roots[:2] + sroots
     ctx = F.Context(m, primes, roots)

@@ -27,7 +27,8 @@ def setup(m, logQ, p, seed, count):
 
 @pytest.mark.parametrize("m,logQ,p,count", [(32, 80, 23, 3), (256, 120, 2027, 2), (4096, 128, 23, 2), (16384, 200, 65537, 1),
                                             (64, 512, 23, 2),      # the metric chain shape: 18 primes, 17-limb product (unrolled CRT instantiation)
-                                            (4096, 512, 23, 1)])
+                                            (4096, 512, 23, 1),
+                                            (32768, 512, 23, 1)])   # BASELINE.json's metric configuration itself: n = 2^14, 17 x 60-bit + one 37-bit prime
 def test_mul_relin_stages_and_end_to_end(m, logQ, p, count):
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, m + logQ, count)
     n, L = ctx.phim, ctx.L
