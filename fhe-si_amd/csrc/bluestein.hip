@@ -27,11 +27,17 @@ struct BluesteinTables {
   u64* d_garner = nullptr;        // [2] : P0^-1 mod P1, (P0 P1)^-1 mod P2
   i64* d_phi = nullptr;           // [phim+1] Phi_m coefficients
   int phi_kind = 0;               // 0 generic long division, 1 m prime, 2 m = 2 * odd prime
+  // N = 2^15 .. 2^17: the auxiliary transforms run order-free (head stages + in-place sub-transforms; sub-transforms + tail
+  // stages), the chirp transform is stored in that order.  N = 2^15 additionally fuses the single head stage into blue_pre
+  // (its partner words are zero: m <= N/2) and the single tail stage into blue_post.
+  bool orderfree = false, fused = false;
 };
 
 // ------------------------------------------------------------------------------------------------ kernels
 // a -> X_j[k] = (a[k] * powers[k] mod q) mod P_j  for k < m, 0 above.  grid: (ceil(N/256), rows)
-template <bool INV>
+// DUP: the first Cooley-Tukey stage of the size-N transform pairs word k with word k + N/2, which is zero (m <= N/2), so both
+// outputs equal word k: write it twice and let the transform start at stage 1.  grid.x then covers N/2 words.
+template <bool INV, bool DUP = false>
 __global__ void __launch_bounds__(256) blue_pre(const u64* __restrict__ rows, i64 phim, i64 m, i64 N, int nslots, const int* __restrict__ prime_of_slot,
                                                 const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ pow_all, const int* __restrict__ zms_idx,
                                                 u64 P0, u64 P1, u64 P2, u64* __restrict__ X) {
@@ -41,7 +47,7 @@ __global__ void __launch_bounds__(256) blue_pre(const u64* __restrict__ rows, i6
   const u64 q = pcs[prime].q;
   const Shoup2* pw = pow_all + ((i64)prime * 2 + (INV ? 1 : 0)) * m;
   const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= N) return;
+  if (k >= (DUP ? N / 2 : N)) return;
   u64 t = 0;
   if (k < m) {
     u64 a = 0;
@@ -50,9 +56,15 @@ __global__ void __launch_bounds__(256) blue_pre(const u64* __restrict__ rows, i6
     t = d_shoup(a, pw[k].w, pw[k].wp, q);
   }
   u64* x = X + r * 3 * N;
-  x[k] = t >= P0 ? t % P0 : t;
-  x[N + k] = t >= P1 ? t % P1 : t;
-  x[2 * N + k] = t >= P2 ? t % P2 : t;
+  const u64 t0 = t >= P0 ? t % P0 : t, t1 = t >= P1 ? t % P1 : t, t2 = t >= P2 ? t % P2 : t;
+  x[k] = t0;
+  x[N + k] = t1;
+  x[2 * N + k] = t2;
+  if (DUP) {
+    x[k + N / 2] = t0;
+    x[N + k + N / 2] = t1;
+    x[2 * N + k + N / 2] = t2;
+  }
 }
 
 // X[r][j][:] *= bhat[prime][dir][j][:]  mod P_j   (aux PrimeConst table: index j)
@@ -69,11 +81,13 @@ __global__ void __launch_bounds__(256) blue_mul(u64* __restrict__ X, i64 N, int 
 }
 
 // window m-1..2m-2 of the convolution: Garner CRT -> mod q -> * powers[k]; FFT keeps Z_m^*, iFFT multiplies by m^-1.
-template <bool INV>
+// FUSED (N = 2^15): X holds the output of the inverse sub-transforms; the last Gentleman-Sande stage (partner distance N/2,
+// twiddle aux_tw_inv[1]) is applied here to the one word of each pair that the window needs.
+template <bool INV, bool FUSED = false>
 __global__ void __launch_bounds__(256) blue_post(const u64* __restrict__ X, i64 phim, i64 m, i64 N, int nslots, const int* __restrict__ prime_of_slot,
                                                  const PrimeConst* __restrict__ pcs, const PrimeConst* __restrict__ aux_pcs, const Shoup2* __restrict__ pow_all,
                                                  const int* __restrict__ zms_idx, const u64* __restrict__ crt, const u64* __restrict__ garner,
-                                                 u64* __restrict__ out /* FFT: rows [R][phim]; iFFT: full [R][m] */) {
+                                                 u64* __restrict__ out /* FFT: rows [R][phim]; iFFT: full [R][m] */, const Shoup2* __restrict__ aux_tw_inv) {
   const i64 r = blockIdx.y;
   const int slot = (int)(r % nslots);
   const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
@@ -82,9 +96,23 @@ __global__ void __launch_bounds__(256) blue_post(const u64* __restrict__ X, i64 
   if (k >= m) return;
   const int z = zms_idx[k];
   if (!INV && z < 0) return;
-  const u64* x = X + r * 3 * N + (m - 1 + k);
-  const u64 c0 = x[0], c1 = x[N], c2 = x[2 * N];
   const PrimeConst a1 = aux_pcs[1], a2 = aux_pcs[2];
+  u64 c0, c1, c2;
+  if (!FUSED) {
+    const u64* x = X + r * 3 * N + (m - 1 + k);
+    c0 = x[0]; c1 = x[N]; c2 = x[2 * N];
+  } else {
+    const i64 w = m - 1 + k, h = N / 2;
+    const u64* x = X + r * 3 * N + (w < h ? w : w - h);
+    const PrimeConst a0 = aux_pcs[0];
+    if (w < h) {        // X' = X + Y
+      c0 = d_addmod(x[0], x[h], a0.q); c1 = d_addmod(x[N], x[N + h], a1.q); c2 = d_addmod(x[2 * N], x[2 * N + h], a2.q);
+    } else {            // Y' = (X - Y) * psi^-brv(1)
+      c0 = d_mulmod(d_submod(x[0], x[h], a0.q), aux_tw_inv[1].w, a0);
+      c1 = d_mulmod(d_submod(x[N], x[N + h], a1.q), aux_tw_inv[N + 1].w, a1);
+      c2 = d_mulmod(d_submod(x[2 * N], x[2 * N + h], a2.q), aux_tw_inv[2 * N + 1].w, a2);
+    }
+  }
   // mixed radix digits: value = v0 + v1 P0 + v2 P0 P1
   const u64 v0 = c0;
   const u64 v1 = d_mulmod(d_submod(c1, v0 >= a1.q ? v0 % a1.q : v0, a1.q), garner[0], a1);
@@ -222,7 +250,9 @@ int bluestein_init(fhesi_ctx* c) {
   HIP_TRY(hipMalloc(&B->d_phi, c->phi.size() * 8));
   HIP_TRY(hipMemcpy(B->d_phi, c->phi.data(), c->phi.size() * 8, hipMemcpyHostToDevice));
   // transform the chirps once (role of the cached Rb, bluestein.cpp:121-136): layout [L*2][3][N] = 2L "DoubleCRTs" of the aux context
-  FHESI_TRY(launch_ntt_fwd(B->aux, B->d_bhat, (i64)L * 2, 3, nullptr, true));
+  B->orderfree = ntt_orderfree_two_pass(B->aux);
+  B->fused = B->orderfree && k == 15;
+  FHESI_TRY(launch_ntt_fwd(B->aux, B->d_bhat, (i64)L * 2, 3, nullptr, !B->orderfree));
   HIP_TRY(hipStreamSynchronize(B->aux->stream));
   // shape of m for the reduction modulo Phi_m
   if (hm::is_prime((u64)m)) B->phi_kind = 1;
@@ -247,23 +277,33 @@ void bluestein_destroy(fhesi_ctx* c) {
 static int blue_chunk(fhesi_ctx* c, u64* d_rows, i64 count, int nslots, const int* d_pos, bool inv, u64* X, u64* dF) {
   BluesteinTables* B = c->blue;
   const i64 R = count * nslots, N = B->N, m = c->m, phim = c->phim;
-  dim3 gpre((unsigned)((N + 255) / 256), (unsigned)R);
-  if (!inv) blue_pre<false><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
-  else blue_pre<true><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
+  dim3 gpre((unsigned)(((B->fused ? N / 2 : N) + 255) / 256), (unsigned)R);
+  if (B->fused) {
+    if (!inv) blue_pre<false, true><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
+    else blue_pre<true, true><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
+  } else {
+    if (!inv) blue_pre<false><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
+    else blue_pre<true><<<gpre, 256, 0, c->stream>>>(d_rows, phim, m, N, nslots, d_pos, c->d_pc, B->d_pow, c->d_zms_idx, B->P[0], B->P[1], B->P[2], X);
+  }
   HIP_TRY(hipGetLastError());
-  FHESI_TRY(launch_ntt_fwd(B->aux, X, R, 3, nullptr, true));
+  if (B->fused) FHESI_TRY(launch_ntt_sub(B->aux, true, X, R, 3, nullptr));
+  else FHESI_TRY(launch_ntt_fwd(B->aux, X, R, 3, nullptr, !B->orderfree));
   unsigned gx = (unsigned)((N + 255) / 256);
   if (gx > 64) gx = 64;
   blue_mul<<<dim3(gx, (unsigned)(R * 3)), 256, 0, c->stream>>>(X, N, nslots, d_pos, inv ? 1 : 0, B->d_bhat, B->aux->d_pc);
   HIP_TRY(hipGetLastError());
-  FHESI_TRY(launch_ntt_inv(B->aux, X, R, 3, nullptr, true));
+  if (B->fused) FHESI_TRY(launch_ntt_sub(B->aux, false, X, R, 3, nullptr));
+  else FHESI_TRY(launch_ntt_inv(B->aux, X, R, 3, nullptr, !B->orderfree));
   dim3 gpost((unsigned)((m + 255) / 256), (unsigned)R);
+  const Shoup2* atw = B->aux->d_tw_inv;
   if (!inv) {
-    blue_post<false><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, d_rows);
+    if (B->fused) blue_post<false, true><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, d_rows, atw);
+    else blue_post<false><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, d_rows, atw);
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  blue_post<true><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, dF);
+  if (B->fused) blue_post<true, true><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, dF, atw);
+  else blue_post<true><<<gpost, 256, 0, c->stream>>>(X, phim, m, N, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_pow, c->d_zms_idx, B->d_crt, B->d_garner, dF, atw);
   HIP_TRY(hipGetLastError());
   if (B->phi_kind) {
     blue_phi_fast<<<dim3((unsigned)((phim + 255) / 256), (unsigned)R), 256, 0, c->stream>>>((const u64*)dF, phim, m, B->phi_kind, nslots, d_pos, c->d_pc, d_rows);

@@ -181,7 +181,8 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
     if (lg >= 15 && lg <= 17) {      // two-pass transforms (TileBig in ntt_tile.inc, ntt_*_tail in kernels_ntt.hip)
       const int s0 = lg - 14, nsub = 1 << s0;
       const i64 n1 = 1 << 14;
-      std::vector<Shoup2> all_f((size_t)nprimes * n1), all_i((size_t)nprimes * n), tail((size_t)nprimes * n, Shoup2{0, 0}), fold((size_t)nprimes * nsub), one(n1), tmp;
+      std::vector<Shoup2> all_f((size_t)nprimes * n1), all_i((size_t)nprimes * n), all_fs((size_t)nprimes * n), tail((size_t)nprimes * n, Shoup2{0, 0}),
+          fold((size_t)nprimes * nsub), one(n1), tmp;
       for (int i = 0; i < nprimes; ++i) {
         const u64 Q = q[i];
         // forward sub-transforms: ring of 2^14 points with root psi^nsub = the first 2^14 entries of the bit-reversed table
@@ -197,6 +198,12 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
           build_tile_order(one, 14, tmp);
           to_q63(tmp, c->pc[i].q_tile);
           std::copy(tmp.begin(), tmp.end(), all_i.begin() + ((size_t)i * nsub + sub) * n1);
+          // forward slice of the same sub-block (order-free sub-transforms)
+          for (int u = 0; u < 14; ++u)
+            for (i64 b = 0; b < (1ll << u); ++b) one[(1ll << u) + b] = twf[(size_t)i * n + (1ll << (s0 + u)) + ((i64)sub << u) + b];
+          build_tile_order(one, 14, tmp);
+          to_q63(tmp, c->pc[i].q_tile);
+          std::copy(tmp.begin(), tmp.end(), all_fs.begin() + ((size_t)i * nsub + sub) * n1);
           const u64 f = hm::mulmod(c->pc[i].ninv, twi[(size_t)i * n + nsub + sub].w, Q);
           fold[(size_t)i * nsub + sub] = Shoup2{f, hm::shoup63(f, c->pc[i].q_tile)};
         }
@@ -212,6 +219,8 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
       }
       HIP_TRY(hipMalloc(&c->d_twt_fwd, all_f.size() * sizeof(Shoup2)));
       HIP_TRY(hipMalloc(&c->d_twt_inv, all_i.size() * sizeof(Shoup2)));
+      HIP_TRY(hipMalloc(&c->d_twt_fwd_sub, all_fs.size() * sizeof(Shoup2)));
+      HIP_TRY(hipMemcpy(c->d_twt_fwd_sub, all_fs.data(), all_fs.size() * sizeof(Shoup2), hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(&c->d_tail_fwd, tail.size() * sizeof(Shoup2)));
       HIP_TRY(hipMalloc(&c->d_sub_fold, fold.size() * sizeof(Shoup2)));
       HIP_TRY(hipMemcpy(c->d_twt_fwd, all_f.data(), all_f.size() * sizeof(Shoup2), hipMemcpyHostToDevice));
@@ -251,7 +260,7 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_mid) hipEventDestroy(c->ev_mid);
   for (int i = 0; i < 10; ++i) if (c->ws[i]) hipFree(c->ws[i]);
-  hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv); hipFree(c->d_tail_fwd); hipFree(c->d_sub_fold);
+  hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv); hipFree(c->d_tail_fwd); hipFree(c->d_sub_fold); hipFree(c->d_twt_fwd_sub);
   hipFree(c->d_zms_idx); hipFree(c->d_zms_list);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);

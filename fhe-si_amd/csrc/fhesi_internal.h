@@ -79,6 +79,7 @@ struct fhesi_ctx {
   // two-pass transforms, logn 15..17 (s0 = logn-14): d_twt_fwd = [L][2^14] table of the ring with root psi^(2^s0),
   // d_twt_inv = [L][2^s0][2^14] per-sub-transform slices, d_tail_fwd = [L][phim] twiddles of ntt_fwd_tail,
   // d_sub_fold = [L][2^s0] {1/n * inverse twiddle of stage s0, 63-bit quotient}
+  Shoup2* d_twt_fwd_sub = nullptr;     // [L][2^s0][2^14] forward twiddle slices of the order-free sub-transforms (convolutions)
   Shoup2* d_tail_fwd = nullptr;
   Shoup2* d_sub_fold = nullptr;
   int* d_zms_idx = nullptr;            // [m]
@@ -157,6 +158,12 @@ std::vector<u64> bn_mul_small(const std::vector<u64>& a, u64 b);   // non-negati
 // bit-reversed order (used by the Bluestein convolution engine).
 int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev = true);
 int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot, bool bitrev = true);
+// order-free transforms of rows of 2^15..2^17 points in two stages each, for callers that fuse the cheap stage themselves
+// (bluestein.hip): forward = head stages (ntt_fwd_head) + sub-transforms, inverse = sub-transforms + tail stages (ntt_inv_tail)
+bool ntt_orderfree_two_pass(const fhesi_ctx* ctx);
+int launch_ntt_fwd_head(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot);
+int launch_ntt_sub(fhesi_ctx* ctx, bool fwd, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot);
+int launch_ntt_inv_tail_inplace(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot);
 // digit-row forward NTT: source is the scaled-down part in limb-major layout, see kernels_crt.hip
 int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts_limbmajor, int nl, int logQ, int digit_bits, int nd, i64 npolys,
                           u64* d_out_rows /* [npolys*nd][L][n] */, int slot0 = 0, int nslot = 0 /* 0 = all primes */);

@@ -266,6 +266,56 @@ __global__ void __launch_bounds__(256) ntt_inv_tail(const u64* src, u64* dst, i6
   for (int h = 0; h < N2; ++h) dst[base + ((i64)h << 14)] = norm2(v[h], q);
 }
 
+// Head of the order-free forward transform: stages 0 .. S0-1 of the Cooley-Tukey network on the natural-order row (partner
+// distance 2^(14+S0-1-s), twiddle tw_fwd[2^s + block], uniform per thread), in place; values stay lazy in [0,4q) for the
+// sub-transforms.  Mirror image of ntt_inv_tail.
+template <int S0>
+__global__ void __launch_bounds__(256) ntt_fwd_head(u64* rows, i64 count, int nslots, const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs,
+                                                    const Shoup2* __restrict__ tw_all) {
+  constexpr int N2 = 1 << S0, LOGN = 14 + S0;
+  const u32 rb = blockIdx.x >> 6;
+  const u32 j1 = ((blockIdx.x & 63) << 8) | threadIdx.x;
+  const int slot = (int)(rb / (u32)count);
+  const i64 row = (i64)(rb % (u32)count) * nslots + slot;
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const u64 q = pcs[prime].q, two_q = pcs[prime].two_q;
+  const Shoup2* __restrict__ tw = tw_all + ((i64)prime << LOGN);
+  const i64 base = (row << LOGN) + j1;
+  u64 v[N2];
+#pragma unroll
+  for (int h = 0; h < N2; ++h) v[h] = rows[base + ((i64)h << 14)];
+#pragma unroll
+  for (int s = 0; s < S0; ++s) {
+    const int dist = 1 << (S0 - 1 - s);
+#pragma unroll
+    for (int h = 0; h < N2; ++h) {
+      if (h & dist) continue;
+      const Shoup2 w = tw[(1 << s) + (h >> (S0 - s))];
+      bfly_fwd(v[h], v[h + dist], w.w, w.wp, q, two_q);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < N2; ++h) rows[base + ((i64)h << 14)] = v[h];
+}
+
+bool ntt_orderfree_two_pass(const fhesi_ctx* ctx) { return ctx->pow2 && ntt_tile2_supported(ctx->logn); }
+int launch_ntt_fwd_head(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_pos) {
+  const unsigned grid = (unsigned)(count * nslots) << 6;
+  if (!grid) return 0;
+  switch (ctx->logn - 14) {
+    case 1: ntt_fwd_head<1><<<grid, 256, 0, ctx->stream>>>(d_rows, count, nslots, d_pos, ctx->d_pc, ctx->d_tw_fwd); break;
+    case 2: ntt_fwd_head<2><<<grid, 256, 0, ctx->stream>>>(d_rows, count, nslots, d_pos, ctx->d_pc, ctx->d_tw_fwd); break;
+    default: ntt_fwd_head<3><<<grid, 256, 0, ctx->stream>>>(d_rows, count, nslots, d_pos, ctx->d_pc, ctx->d_tw_fwd); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int launch_ntt_sub(fhesi_ctx* ctx, bool fwd, u64* d_rows, i64 count, int nslots, const int* d_pos) {
+  if (!(count * nslots)) return 0;
+  ProfScope prof(ctx, fwd ? PROF_NTT_FWD : PROF_NTT_INV, (double)(count * nslots));
+  return launch_tile_sub(ctx, fwd, d_rows, count * nslots, nslots, d_pos);
+}
+
 static int launch_fwd_tail(fhesi_ctx* ctx, const u64* src, u64* dst, i64 count, int nslots, int slot0, int nslot_launch, const int* d_pos) {
   const unsigned grid = (unsigned)(count * nslot_launch) << 6;
   switch (ctx->logn - 14) {
@@ -287,6 +337,11 @@ static int launch_inv_tail(fhesi_ctx* ctx, const u64* src, u64* dst, i64 count, 
   return 0;
 }
 
+int launch_ntt_inv_tail_inplace(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_pos) {
+  if (!(count * nslots)) return 0;
+  return launch_inv_tail(ctx, d_rows, d_rows, count, nslots, d_pos);
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 static int lds_threads(int logb) { int t = 1 << (logb > 0 ? logb - 1 : 0); return t > 1024 ? 1024 : (t < 64 ? 64 : t); }
 
@@ -298,6 +353,10 @@ int launch_ntt_fwd(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   u64 skip_q = 0;
   if (bitrev && ntt_tile_supported(logn)) {
     return launch_ntt_fwd_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);     // (rows of small primes: its EXACT instantiation)
+  }
+  if (!bitrev && ntt_tile2_supported(logn)) {      // order-free (convolutions): head stages, then in-place sub-transforms
+    FHESI_TRY(launch_ntt_fwd_head(ctx, d_rows, count, nslots, d_prime_of_slot));
+    return launch_tile_sub(ctx, true, d_rows, nrows, nslots, d_prime_of_slot);
   }
   if (bitrev && ntt_tile2_supported(logn)) {
     void* tmp;
@@ -338,6 +397,10 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
   u64 skip_q = 0;
   if (bitrev && ntt_tile_supported(logn)) {
     return launch_ntt_inv_tile(ctx, d_rows, nrows, nslots, d_prime_of_slot);
+  }
+  if (!bitrev && ntt_tile2_supported(logn)) {      // order-free: in-place sub-transforms, then the tail stages
+    FHESI_TRY(launch_tile_sub(ctx, false, d_rows, nrows, nslots, d_prime_of_slot));
+    return launch_inv_tail(ctx, d_rows, d_rows, count, nslots, d_prime_of_slot);
   }
   if (bitrev && ntt_tile2_supported(logn)) {
     void* tmp;

@@ -38,9 +38,11 @@ def test_rows_general_m(m):
         assert np.array_equal(g2[0, i], orc.cmod_ifft(i, ev[0, i])), (m, i)
 
 
-def test_large_safe_prime_ring_single_rows():
-    """config 4a of SURVEY.md section 8d: p = 8423, m = 8422 (Bluestein size 2^15)."""
-    m = 8422
+@pytest.mark.parametrize("m", [8422, 16411, 32771])
+def test_large_safe_prime_ring_single_rows(m):
+    """m = 8422: config 4a of SURVEY.md section 8d (p = 8423; convolution size N = 2^15: order-free transforms with the head stage
+    fused into the pre-multiplication and the tail stage into the post-processing); m = 16411 and 32771 (primes): N = 2^16 and
+    2^17, order-free transforms with 2 and 3 separate head / tail stages."""
     primes, roots = P.first_primes(m, 2)
     ctx = F.Context(m, primes, roots)
     orc = O.Oracle(m, primes, roots)
@@ -52,6 +54,10 @@ def test_large_safe_prime_ring_single_rows():
     assert np.array_equal(got[0, 0], orc.fft_residues(0, rows[0, 0]))
     ctx.rows_ntt_inv(buf, 1)
     assert np.array_equal(buf.download(rows.shape), rows)
+    ev = P.rand_rows(rng, primes, ctx.phim, 1)
+    b2 = ctx.upload(ev)
+    ctx.rows_ntt_inv(b2, 1)
+    assert np.array_equal(b2.download(ev.shape)[0, 1], orc.cmod_ifft(1, ev[0, 1]))
 
 
 @pytest.mark.parametrize("m,logQ,p", [(22, 80, 23), (46, 90, 47), (166, 120, 167)])
