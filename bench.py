@@ -231,7 +231,7 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
                        "products_per_regress": stats["products"], "key_switches_per_regress": stats["key_switches"],
                        "automorph_key_switches_per_regress": stats["automorph_key_switches"], "regress_per_s": round(args.steps / dt, 3),
                        "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_tile<14, true, false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_tile<14, true, 0, false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches,
                          "avg_launch_ms": round(ms / launches, 4) if launches else None},
             "cpu_baseline": None,
@@ -309,10 +309,10 @@ def run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[1]: DoubleCRT NTT round trip, m=2^14 n=2^13, 8 primes of 60 bits", "L": L, "batch_per_gpu": B,
                        "round_trip_is_identity": identity, "matches_oracle": oracle_ok},
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_tile<13, false, false>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_tile<13, false, 0, false>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": fl, "avg_launch_ms": round(fms / fl, 4) if fl else None,
                          "row_ntts_per_s": round(frows / (fms * 1e-3), 1) if fms > 0 else None,
-                         "inverse": {"kernel": "ntt_inv_tile<13, false>", "achieved": round(irows * row_bytes / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
+                         "inverse": {"kernel": "ntt_inv_tile<13, 0, false>", "achieved": round(irows * row_bytes / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
                                      "row_ntts_per_s": round(irows / (ims * 1e-3), 1) if ims > 0 else None}},
             "cpu_baseline": cpu,
         }
@@ -459,8 +459,11 @@ def main():
             traffic = None
     if args.workload != "metric" or args.ntt_rows:
         traffic = None          # the PMC passes in profiles/ were taken on the metric workload's launch shape
-    big = "true" if ctx.phim > (1 << 14) else "false"       # rows above 2^14: tile pass of the two-pass transform
-    kname = "ntt_fwd_tile<14, %s, %s>" % ("false" if args.ntt_rows else "true", big)
+    # template parameters <LOGN, DIGITS, S0, CONTIG>; rows of 2^15 points: the head-fused sub-transform kernel (S0 = 1, CONTIG)
+    if ctx.phim > (1 << 14):
+        kname = "ntt_fwd_tile<14, false, 1, false>" if args.ntt_rows else "ntt_fwd_tile<14, true, 1, true>"
+    else:
+        kname = "ntt_fwd_tile<14, %s, 0, false>" % ("false" if args.ntt_rows else "true")
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,

@@ -219,6 +219,12 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
       }
       HIP_TRY(hipMalloc(&c->d_twt_fwd, all_f.size() * sizeof(Shoup2)));
       HIP_TRY(hipMalloc(&c->d_twt_inv, all_i.size() * sizeof(Shoup2)));
+      {
+        std::vector<Shoup2> head(nprimes);
+        for (int i = 0; i < nprimes; ++i) { const u64 w = twf[(size_t)i * n + 1].w; head[i] = Shoup2{w, hm::shoup63(w, c->pc[i].q_tile)}; }
+        HIP_TRY(hipMalloc(&c->d_head_tw, head.size() * sizeof(Shoup2)));
+        HIP_TRY(hipMemcpy(c->d_head_tw, head.data(), head.size() * sizeof(Shoup2), hipMemcpyHostToDevice));
+      }
       HIP_TRY(hipMalloc(&c->d_twt_fwd_sub, all_fs.size() * sizeof(Shoup2)));
       HIP_TRY(hipMemcpy(c->d_twt_fwd_sub, all_fs.data(), all_fs.size() * sizeof(Shoup2), hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(&c->d_tail_fwd, tail.size() * sizeof(Shoup2)));
@@ -260,7 +266,7 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_mid) hipEventDestroy(c->ev_mid);
   for (int i = 0; i < 10; ++i) if (c->ws[i]) hipFree(c->ws[i]);
-  hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv); hipFree(c->d_tail_fwd); hipFree(c->d_sub_fold); hipFree(c->d_twt_fwd_sub);
+  hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv); hipFree(c->d_tail_fwd); hipFree(c->d_sub_fold); hipFree(c->d_twt_fwd_sub); hipFree(c->d_head_tw);
   hipFree(c->d_zms_idx); hipFree(c->d_zms_list);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -783,7 +789,7 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
   }
   if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
   // DotProduct with both key rows (FHE-SI.cpp:251-254)
-  FHESI_TRY(launch_dot_accum(c, k->d_rows, (const u64*)d_dig, ncol, count, d_t));
+  FHESI_TRY(launch_dot_accum(c, k->d_rows, (const u64*)d_dig, ncol, count, d_t, 0, 0, c->pow2 && ntt_digits_suborder(c, 8 * decomp_bytes)));
   // toPoly + ReduceCoefficients (FHE-SI.cpp:255-256)
   FHESI_TRY(row_inv(c, d_t, count * 2, L, nullptr, all.data()));
   FHESI_TRY(launch_crt(c, t, d_t, L, nullptr, count * 2, 2, 0, logQ, (u64*)out, nlimbs));

@@ -80,6 +80,7 @@ struct fhesi_ctx {
   // d_twt_inv = [L][2^s0][2^14] per-sub-transform slices, d_tail_fwd = [L][phim] twiddles of ntt_fwd_tail,
   // d_sub_fold = [L][2^s0] {1/n * inverse twiddle of stage s0, 63-bit quotient}
   Shoup2* d_twt_fwd_sub = nullptr;     // [L][2^s0][2^14] forward twiddle slices of the order-free sub-transforms (convolutions)
+  Shoup2* d_head_tw = nullptr;         // [L] {psi^brv(1), 63-bit quotient}: the head stage fused into the digit loader at n = 2^15
   Shoup2* d_tail_fwd = nullptr;
   Shoup2* d_sub_fold = nullptr;
   int* d_zms_idx = nullptr;            // [m]
@@ -173,7 +174,9 @@ int launch_ew_op(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 count, int ns
 int launch_ew_scalar(fhesi_ctx* ctx, u64* d_dst, const u64* d_scalars /* [nslots] residues */, i64 count, int nslots, const int* d_prime_of_slot, int op);
 int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a /* [count][2][L][n] */, const u64* d_b /* [count][2][L][n] */, u64* d_t /* [count][3][L][n] */, i64 count);
 int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key /* [2][ncol][L][n] */, const u64* d_dig /* [count][ncol][L][n] */, int ncol, i64 count,
-                     u64* d_out /* [count][2][L][n] */, int slot0 = 0, int nslot = 0 /* 0 = all primes */);
+                     u64* d_out /* [count][2][L][n] */, int slot0 = 0, int nslot = 0 /* 0 = all primes */, bool dig_suborder = false);
+// true when launch_ntt_fwd_digits leaves its rows in sub-block order (n = 2^15): evaluation 2j + sub at [sub][j]
+bool ntt_digits_suborder(const fhesi_ctx* ctx, int digit_bits);
 int launch_tensor_sum(fhesi_ctx* ctx, const u64* d_ca, const u64* d_cb, const int* d_slot_a, const int* d_slot_b, const int* d_seg, i64 ngroups, bool accumulate,
                       u64* d_out /* [ngroups][3][L][n] */, double nproducts);
 int launch_automorph(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 nrows, i64 k);

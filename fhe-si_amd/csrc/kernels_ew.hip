@@ -94,7 +94,9 @@ __device__ __forceinline__ u64 acc_reduce(const Acc128& a, const PrimeConst& pc)
   if (r >= q) r -= q;
   return r;
 }
-template <int CT_TILE>
+// SUBORDER: the digit rows are in the sub-block order the head-fused transform of n = 2^15 leaves them in (evaluation 2j + sub at
+// [sub][j]): the two evaluations a lane works on come from the two halves of the row instead of from adjacent words.
+template <int CT_TILE, bool SUBORDER = false>
 __global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ key, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
                                                          u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int slot0) {
   // prime-major block order (blockIdx.z = prime): all ciphertext tiles of one prime run back to back, so that prime's 2*ncol key
@@ -118,7 +120,10 @@ __global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ 
 #pragma unroll
       for (int c = 0; c < CT_TILE; ++c) {
         if (ct0 + c < count) {
-          const u64x2 d = __builtin_nontemporal_load(&((const u64x2*)(dig + ((ct0 + c) * ncol + k) * rs + (i64)l * n))[i]);   // digit rows are read once
+          u64x2 d;
+          const u64* drow = dig + ((ct0 + c) * ncol + k) * rs + (i64)l * n;
+          if (SUBORDER) { d.x = __builtin_nontemporal_load(&drow[i]); d.y = __builtin_nontemporal_load(&drow[n2 + i]); }
+          else d = __builtin_nontemporal_load(&((const u64x2*)drow)[i]);   // digit rows are read once
           acc_mad(acc[c][0], a.x, d.x);
           acc_mad(acc[c][1], a.y, d.y);
           acc_mad(acc[c][2], b.x, d.x);
@@ -201,7 +206,7 @@ int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a, const u64* d_b, u64* d_t, i
   return 0;
 }
 
-int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int ncol, i64 count, u64* d_out, int slot0, int nslot) {
+int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int ncol, i64 count, u64* d_out, int slot0, int nslot, bool dig_suborder) {
   if (!count) return 0;
   if (nslot <= 0) { slot0 = 0; nslot = ctx->L; }
   if (ctx->phim & 1) FHESI_FAIL("dot_accum: odd phi(m) not supported by the batched pipeline");
@@ -216,7 +221,8 @@ int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int nco
   const i64 ntiles = (count + CT_TILE - 1) / CT_TILE;
   if (ntiles > 65535) FHESI_FAIL("dot_accum: more than %d ciphertexts per call", 65535 * CT_TILE);
   dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ntiles, (unsigned)nslot);
-  dot_accum_kernel<CT_TILE><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0);
+  if (dig_suborder) dot_accum_kernel<CT_TILE, true><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0);
+  else dot_accum_kernel<CT_TILE><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0);
   HIP_TRY(hipGetLastError());
   return 0;
 }

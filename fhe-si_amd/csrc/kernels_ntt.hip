@@ -298,6 +298,7 @@ __global__ void __launch_bounds__(256) ntt_fwd_head(u64* rows, i64 count, int ns
   for (int h = 0; h < N2; ++h) rows[base + ((i64)h << 14)] = v[h];
 }
 
+bool ntt_digits_suborder(const fhesi_ctx* ctx, int digit_bits) { return ctx->pow2 && ctx->logn == 15 && digit_bits < 32; }
 bool ntt_orderfree_two_pass(const fhesi_ctx* ctx) { return ctx->pow2 && ntt_tile2_supported(ctx->logn); }
 int launch_ntt_fwd_head(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_pos) {
   const unsigned grid = (unsigned)(count * nslots) << 6;
@@ -444,9 +445,10 @@ int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, 
   }
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * nslot));
   const DigitSrc ds{d_parts, nl, digit_bits, nd, slot0};
-  if (two_pass) {      // sub-transforms straight from the parts into the rows, tail in place
+  if (two_pass) {      // sub-transforms straight from the parts into the rows
     FHESI_TRY(launch_tile_big_digits(ctx, ds, npolys * nd, d_out_rows, nslot));
-    return launch_fwd_tail(ctx, d_out_rows, d_out_rows, npolys * nd, ctx->L, slot0, nslot, nullptr);
+    if (ntt_digits_suborder(ctx, digit_bits)) return 0;                     // n = 2^15: head stage fused into the loader, no tail (sub-block order)
+    return launch_fwd_tail(ctx, d_out_rows, d_out_rows, npolys * nd, ctx->L, slot0, nslot, nullptr);     // tail in place
   }
   switch (ctx->logn) {
     case 11: FHESI_TRY(launch_tile_digits<11>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;

@@ -10,4 +10,4 @@ def summarise(path, needle):
         print(k, {c: (len(x), sum(x) / len(x)) for c, x in v.items()})
 if __name__ == "__main__":
     for f in glob.glob(sys.argv[1]):
-        summarise(f, sys.argv[2] if len(sys.argv) > 2 else "ntt_fwd_tile<14, true, false>")
+        summarise(f, sys.argv[2] if len(sys.argv) > 2 else "ntt_fwd_tile<14, true, 0, false>")

@@ -20,7 +20,7 @@ run ntt --workload ntt --steps 10 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 > /dev/null 2> "$O/pmc_$c.log"
   f=$(find "$O/pmc_$c" -name '*counter_collection.csv' | head -1)
-  python3 "$R/tools/pmc_summary.py" "$f" "ntt_fwd_tile<14, true, false>" | tee "$O/pmc_$c.txt"
+  python3 "$R/tools/pmc_summary.py" "$f" "ntt_fwd_tile<14, true, 0, false>" | tee "$O/pmc_$c.txt"
 done
 find "$O" -name '*.db' -delete; find "$O" -name '*agent_info.csv' -delete; find "$O" -name '*kernel_trace.csv' -delete; find "$O" -name '*counter_collection.csv' -delete
 ls -la "$O"
