@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "fhesi_ct_mul_dev", "fhesi_apply_key_switch_dev", "fhesi_dev_alloc", "fhesi_dev_free", "fhesi_dev_upload", "fhesi_dev_download",
     "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
     "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
-    "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch",
+    "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -99,6 +99,7 @@ def _load():
         "fhesi_dcrt_op": [_vp, _vp, _i32],
         "fhesi_dcrt_op_scalar": [_vp, _vp, _i32, _i32],
         "fhesi_dcrt_automorph": [_vp, _i64],
+        "fhesi_dcrt_exp": [_vp, _i64],
         "fhesi_dcrt_add_primes": [_vp, _vp, _i32],
         "fhesi_dcrt_remove_primes": [_vp, _vp, _i32],
         "fhesi_dcrt_from_scrt": [_vp, _vp],
@@ -429,6 +430,11 @@ class DoubleCRT:
 
     def automorph(self, k: int):
         _ck(_load().fhesi_dcrt_automorph(self.h, k))
+        return self
+
+    def exp(self, e: int):
+        """DoubleCRT::Exp (DoubleCRT.cpp:423-434): element-wise PowerMod."""
+        _ck(_load().fhesi_dcrt_exp(self.h, e))
         return self
 
     def add_primes(self, idx):

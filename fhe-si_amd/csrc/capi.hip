@@ -593,6 +593,37 @@ extern "C" int fhesi_dcrt_op_scalar(fhesi_dcrt* d, const uint64_t* num, int32_t 
   return launch_ew_scalar(c, d->d_rows, (const u64*)d_sc, 1, K, d_pos, op);
 }
 
+extern "C" int fhesi_dcrt_exp(fhesi_dcrt* d, int64_t e) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  const int K = (int)d->idx.size();
+  if (!K) return 0;
+  // PowerMod(a, e, q) with e < 0 is (a^-1)^|e| = a^((q-1) - |e| mod (q-1)) for a != 0, and NTL's InvMod error for a = 0
+  std::vector<u64> ex(K);
+  for (int s = 0; s < K; ++s) {
+    const u64 ord = c->q[d->idx[s]] - 1;
+    if (e >= 0) ex[s] = (u64)e;
+    else { const u64 r = (0 - (u64)e) % ord; ex[s] = r ? ord - r : 0; }
+  }
+  void* d_ex;
+  FHESI_TRY(ws_reserve(c, 4, K * 8 + 64, &d_ex));
+  unsigned* d_flag = (unsigned*)((u64*)d_ex + K);
+  HIP_TRY(hipMemcpyAsync(d_ex, ex.data(), K * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(d_flag, 0, 4, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, d->idx, &d_pos));
+  if (e < 0) {
+    FHESI_TRY(launch_ew_exp(c, d->d_rows, (const u64*)d_ex, 1, K, d_pos, d_flag));
+    unsigned flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flag) FHESI_FAIL("DoubleCRT::Exp: negative exponent of a zero element (InvMod: inverse undefined)");
+  }
+  return launch_ew_exp(c, d->d_rows, (const u64*)d_ex, 1, K, d_pos, nullptr);
+}
+
 extern "C" int fhesi_dcrt_automorph(fhesi_dcrt* d, int64_t k) {
   if (!d) FHESI_FAIL("null DoubleCRT");
   fhesi_ctx* c = d->ctx;

@@ -171,6 +171,7 @@ int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts_limbmajor, int nl, 
 
 // kernels_ew.hip
 int launch_ew_op(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 count, int nslots, const int* d_prime_of_slot, int op);
+int launch_ew_exp(fhesi_ctx* ctx, u64* d_dst, const u64* d_exps /* [nslots] */, i64 count, int nslots, const int* d_prime_of_slot, unsigned* d_zero_flag /* non-null: only flag zero elements */);
 int launch_ew_scalar(fhesi_ctx* ctx, u64* d_dst, const u64* d_scalars /* [nslots] residues */, i64 count, int nslots, const int* d_prime_of_slot, int op);
 int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a /* [count][2][L][n] */, const u64* d_b /* [count][2][L][n] */, u64* d_t /* [count][3][L][n] */, i64 count);
 int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key /* [2][ncol][L][n] */, const u64* d_dig /* [count][ncol][L][n] */, int ncol, i64 count,

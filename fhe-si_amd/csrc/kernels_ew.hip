@@ -50,6 +50,27 @@ __global__ void __launch_bounds__(256) ew_scalar_kernel(u64* __restrict__ dst, c
   }
 }
 
+// DoubleCRT::Exp (DoubleCRT.cpp:423-434): d[i] <- d[i]^e mod q, exps[slot] = the (per-prime, non-negative) exponent.
+// CHECK: only count zero elements into *flag (the inverse of 0 is NTL's InvMod error for negative exponents).
+template <bool CHECK>
+__global__ void __launch_bounds__(256) ew_exp_kernel(u64* __restrict__ dst, const u64* __restrict__ exps, i64 n, int nslots,
+                                                      const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs, unsigned* __restrict__ flag) {
+  const i64 row = blockIdx.y;
+  const int slot = (int)(row % nslots);
+  const PrimeConst pc = pcs[prime_of_slot ? prime_of_slot[slot] : slot];
+  const u64 e = exps[slot];
+  u64* d = dst + row * n;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    if (CHECK) { if (d[i] == 0) atomicOr(flag, 1u); continue; }
+    u64 base = d[i], r = 1;
+    for (u64 k = e; k; k >>= 1) {           // e is wave-uniform: no divergence
+      if (k & 1) r = d_mulmod(r, base, pc);
+      base = d_mulmod(base, base, pc);
+    }
+    d[i] = r;
+  }
+}
+
 // ca: [count][2][L][n] = NTT(a0*p), NTT(a1*p);  cb: [count][2][L][n] = NTT(b0), NTT(b1);  t: [count][3][L][n]
 __global__ void __launch_bounds__(256) tensor2x2_kernel(const u64* __restrict__ ca, const u64* __restrict__ cb, u64* __restrict__ t, i64 n, int L, const PrimeConst* __restrict__ pcs) {
   const i64 ct = blockIdx.z;
@@ -192,6 +213,16 @@ int launch_ew_scalar(fhesi_ctx* ctx, u64* d_dst, const u64* d_scalars, i64 count
     case 4: ew_scalar_kernel<FHESI_OP_SET_><<<grid, 256, 0, ctx->stream>>>(d_dst, d_scalars, n, nslots, d_prime_of_slot, ctx->d_pc); break;
     default: FHESI_FAIL("DoubleCRT scalar op: unknown operation %d", op);
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_ew_exp(fhesi_ctx* ctx, u64* d_dst, const u64* d_exps, i64 count, int nslots, const int* d_prime_of_slot, unsigned* d_zero_flag) {
+  const i64 n = ctx->phim, nrows = count * nslots;
+  if (!nrows) return 0;
+  dim3 grid(grid_x_for(n), (unsigned)nrows);
+  if (d_zero_flag) ew_exp_kernel<true><<<grid, 256, 0, ctx->stream>>>(d_dst, d_exps, n, nslots, d_prime_of_slot, ctx->d_pc, d_zero_flag);
+  else ew_exp_kernel<false><<<grid, 256, 0, ctx->stream>>>(d_dst, d_exps, n, nslots, d_prime_of_slot, ctx->d_pc, nullptr);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -291,6 +291,7 @@ class DoubleCRT {
   void Mul(const DoubleCRT& o, bool match = true) { Op(o, OP_MUL, match); }
   DoubleCRT& operator/=(const ZZ& n) { return Op(n, OP_DIV); }   // :407-420
   DoubleCRT& operator/=(long n) { return Op(ZZ(n), OP_DIV); }
+  void Exp(long e) { ck(fhesi_dcrt_exp(h, e)); }   // :423-434
   void automorph(long k) { if (!context.zMstar.inZmStar((unsigned)k)) Error("DoubleCRT::automorph: k not in Zm*"); ck(fhesi_dcrt_automorph(h, k)); }   // :439-465
   // BGV-style modulus switching (no callers in fhe-si, kept for the class surface): every heavy step is a C-ABI call
   double addPrimesAndScale(const IndexSet& s1) {   // DoubleCRT.cpp:162-208

@@ -86,6 +86,7 @@ int fhesi_dcrt_to_poly(const fhesi_dcrt* d, const int32_t* prime_idx, int32_t ni
 int fhesi_dcrt_op(fhesi_dcrt* dst, const fhesi_dcrt* src, int32_t op);              /* Op(DoubleCRT): DoubleCRT.cpp:79-113 (equal index sets; ADD/SUB/MUL) */
 int fhesi_dcrt_op_scalar(fhesi_dcrt* d, const uint64_t* num_limbs, int32_t nlimbs, int32_t op);
                                                                                      /* Op(ZZ) :115-129, operator/= :407-420, operator=(ZZ) :333-347 */
+int fhesi_dcrt_exp(fhesi_dcrt* d, int64_t e);                                       /* Exp: DoubleCRT.cpp:423-434 (PowerMod per element; e < 0 needs every element invertible) */
 int fhesi_dcrt_automorph(fhesi_dcrt* d, int64_t k);                                 /* automorph: DoubleCRT.cpp:439-465; error if k not in Zm* */
 int fhesi_dcrt_add_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx);   /* addPrimes: DoubleCRT.cpp:142-156 */
 int fhesi_dcrt_remove_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx);/* removePrimes: DoubleCRT.h:197-199 */

@@ -271,6 +271,13 @@ void orc_dcrt_op_scalar(const orc_ctx* c, u64* a, const u64* num, int nlimbs, in
   for (int i = 0; i < c->L; i++) { u64 q = c->pr[i].q; u64 s = bn_mod_u64(num, nlimbs, q); if (op == 3) s = invmod(s, q); u64* ra = a + (i64)i * c->phim;
     for (i64 j = 0; j < c->phim; j++) ra[j] = op == 0 ? addmod(ra[j], s, q) : op == 1 ? submod(ra[j], s, q) : op == 4 ? s : mulmod(ra[j], s, q); }
 }
+/* DoubleCRT::Exp (DoubleCRT.cpp:423-434): PowerMod per element; e < 0 inverts first, -1 if some element is 0 (NTL InvMod error) */
+int orc_dcrt_exp(const orc_ctx* c, u64* a, i64 e) {
+  if (e < 0) for (i64 j = 0; j < (i64)c->L * c->phim; j++) if (a[j] == 0) return -1;
+  for (int i = 0; i < c->L; i++) { u64 q = c->pr[i].q; u64* ra = a + (i64)i * c->phim;
+    for (i64 j = 0; j < c->phim; j++) { u64 b = e < 0 ? invmod(ra[j], q) : ra[j]; ra[j] = powmod(b, e < 0 ? 0 - (u64)e : (u64)e, q); } }
+  return 0;
+}
 /* DoubleCRT::automorph (DoubleCRT.cpp:439-465); returns -1 if k not in Zm* (:442-443) */
 int orc_dcrt_automorph(const orc_ctx* c, u64* a, i64 k) {
   i64 m = c->m; if (k <= 0 || k >= m || c->zms_idx[k] < 0) return -1;

@@ -416,6 +416,12 @@ def dcrt_op_scalar(ctx: Ctx, a: dict, num: int, op: str) -> dict:
     return {i: [f(x, num % ctx.primes[i], ctx.primes[i]) for x in a[i]] for i in a}
 
 
+def dcrt_exp(ctx: Ctx, a: dict, e: int) -> dict:
+    """DoubleCRT::Exp (DoubleCRT.cpp:423-434): row[j] = PowerMod(row[j], e, q_i); a negative exponent inverts first
+    (NTL PowerMod), which is an error for a zero element."""
+    return {i: [pow(x, e, ctx.primes[i]) for x in a[i]] for i in a}
+
+
 def dcrt_div_scalar(ctx: Ctx, a: dict, num: int) -> dict:
     """DoubleCRT::operator/=(ZZ) (DoubleCRT.cpp:407-420)."""
     return {i: [x * pow(num % ctx.primes[i], -1, ctx.primes[i]) % ctx.primes[i] for x in a[i]] for i in a}

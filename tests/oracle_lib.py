@@ -155,6 +155,13 @@ class Oracle:
         lib().orc_dcrt_op_scalar(self.h, _p(a), _p(s), nlimbs, op)
         return a
 
+    def dcrt_exp(self, a: np.ndarray, e: int) -> np.ndarray:
+        a = np.array(a, dtype=np.uint64, copy=True)
+        lib().orc_dcrt_exp.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        if lib().orc_dcrt_exp(self.h, _p(a), e) != 0:
+            raise ValueError("inverse undefined")
+        return a
+
     def dcrt_automorph(self, a: np.ndarray, k: int) -> np.ndarray:
         a = np.array(a, dtype=np.uint64, copy=True)
         if lib().orc_dcrt_automorph(self.h, _p(a), k) != 0:

@@ -79,6 +79,17 @@ def test_ops_scalar_automorph(m):
     assert np.array_equal(a.rows(), orc.dcrt_op_scalar(ra, 23, 3))
     with pytest.raises(F.FhesiError):       # divisor = 0 mod q_0
         dev(ra).op_scalar(primes[0], F.OP_DIV)
+    # Exp (DoubleCRT.cpp:423-434): PowerMod per element, negative exponents invert, 0^-1 is an error
+    for e in (0, 1, 2, 3, 65537, -1, -5):
+        a = dev(ra)
+        a.exp(e)
+        assert np.array_equal(a.rows(), orc.dcrt_exp(ra, e)), e
+    rz = ra.copy()
+    rz[1, 7] = 0
+    assert np.array_equal(dev(rz).exp(3).rows(), orc.dcrt_exp(rz, 3))
+    assert np.array_equal(dev(rz).exp(0).rows(), np.ones_like(rz))       # PowerMod(0, 0) = 1
+    with pytest.raises(F.FhesiError, match="inverse undefined"):
+        dev(rz).exp(-2)
     for k in (3, 5, m - 1):
         a = dev(ra)
         a.automorph(k)
