@@ -98,7 +98,9 @@ __global__ void __launch_bounds__(256) tensor2x2_kernel(const u64* __restrict__ 
 
 // out[ct][r][l][:] = sum_k key[r][k][l][:] * dig[ct][k][l][:]   (r = 0,1)
 // One block column handles CT_TILE ciphertexts so that every key element is loaded once per CT_TILE uses; products are
-// accumulated as exact 128-bit integers (ncol * q^2 < 2^128, checked by the launcher) and reduced once at the end.
+// accumulated as exact 128-bit integers and reduced once at the end.  The digit values may be lazy representatives (anything
+// below 2 q_tile + 2^32 < 2^62, which is what the fused digit transform stores): the launcher derives from that bound after how many
+// columns the accumulators have to be folded (never at the metric config: 66 * 2^62 * 2^60 < 2^128).
 struct Acc128 { u64 lo, hi; };
 __device__ __forceinline__ void acc_mad(Acc128& a, u64 x, u64 y) {
   const u128 s = ((u128)a.hi << 64 | a.lo) + (u128)x * y;      // one 64x64->128 multiply-add: 4 v_mad_u64_u32
@@ -119,7 +121,7 @@ __device__ __forceinline__ u64 acc_reduce(const Acc128& a, const PrimeConst& pc)
 // [sub][j]): the two evaluations a lane works on come from the two halves of the row instead of from adjacent words.
 template <int CT_TILE, bool SUBORDER = false>
 __global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ key, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
-                                                         u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int slot0) {
+                                                         u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int slot0, int fold_every) {
   // prime-major block order (blockIdx.z = prime): all ciphertext tiles of one prime run back to back, so that prime's 2*ncol key
   // rows (17 MiB at the metric config) are re-read from the Infinity Cache instead of HBM by every tile after the first
   const i64 ct0 = (i64)blockIdx.y * CT_TILE;
@@ -135,7 +137,15 @@ __global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ 
     for (int c = 0; c < CT_TILE; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[c][e] = Acc128{0, 0};
+    int until_fold = fold_every;
     for (int k = 0; k < ncol; ++k) {
+      if (fold_every && until_fold-- == 0) {        // uniform; only for very wide key-switch matrices
+        until_fold = fold_every - 1;
+#pragma unroll
+        for (int c = 0; c < CT_TILE; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[c][e] = Acc128{acc_reduce(acc[c][e], pc), 0};
+      }
       const u64x2 a = ((const u64x2*)(k0 + k * rs))[i];
       const u64x2 b = ((const u64x2*)(k1 + k * rs))[i];
 #pragma unroll
@@ -241,19 +251,21 @@ int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int nco
   if (!count) return 0;
   if (nslot <= 0) { slot0 = 0; nslot = ctx->L; }
   if (ctx->phim & 1) FHESI_FAIL("dot_accum: odd phi(m) not supported by the batched pipeline");
-  // exact 128-bit accumulation needs ncol * q^2 < 2^128
+  // exact 128-bit accumulation: F columns of (digit < 2 q_tile + 2^32) * (key < q) on top of a folded value below q must stay below 2^128
+  int fold_every = 0;
   for (int l = 0; l < ctx->L; ++l) {
-    const int k = (int)ctx->pc[l].bar_k;
-    int lg = 0; while ((1 << lg) < ncol) ++lg;
-    if (2 * k + lg > 128) FHESI_FAIL("dot_accum: %d columns of %d-bit residues overflow the 128-bit accumulator", ncol, k);
+    const u128 term = (u128)(2 * ctx->pc[l].q_tile + ((u64)1 << 32)) * ctx->pc[l].q;
+    const u128 F = (~(u128)0 - ctx->pc[l].q) / term;
+    if (F < 2) FHESI_FAIL("dot_accum: residues of prime %d overflow the 128-bit accumulator", l);
+    if (F < (u128)ncol && (fold_every == 0 || (int)F < fold_every)) fold_every = (int)F;
   }
   ProfScope prof(ctx, PROF_DOT, (double)count);
   constexpr int CT_TILE = 2;     // with prime-major blocks the key rows come from the Infinity Cache: 2 measured best on MI355X (1: +20 %, 4: +8 %, 8: +22 % time)
   const i64 ntiles = (count + CT_TILE - 1) / CT_TILE;
   if (ntiles > 65535) FHESI_FAIL("dot_accum: more than %d ciphertexts per call", 65535 * CT_TILE);
   dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ntiles, (unsigned)nslot);
-  if (dig_suborder) dot_accum_kernel<CT_TILE, true><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0);
-  else dot_accum_kernel<CT_TILE><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0);
+  if (dig_suborder) dot_accum_kernel<CT_TILE, true><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0, fold_every);
+  else dot_accum_kernel<CT_TILE><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0, fold_every);
   HIP_TRY(hipGetLastError());
   return 0;
 }
