@@ -99,8 +99,8 @@ __global__ void __launch_bounds__(256) tensor2x2_kernel(const u64* __restrict__ 
 // out[ct][r][l][:] = sum_k key[r][k][l][:] * dig[ct][k][l][:]   (r = 0,1)
 // One block column handles CT_TILE ciphertexts so that every key element is loaded once per CT_TILE uses; products are
 // accumulated as exact 128-bit integers and reduced once at the end.  The digit values may be lazy representatives (anything
-// below 2 q_tile + 2^32 < 2^62, which is what the fused digit transform stores): the launcher derives from that bound after how many
-// columns the accumulators have to be folded (never at the metric config: 66 * 2^62 * 2^60 < 2^128).
+// below 4 q_tile + 2^32 < 2^63, which is what the fused digit transform stores): the launcher derives from that bound after how many
+// columns the accumulators have to be folded (every 63 columns for 60-bit primes: once per sum at the metric config's 66 columns).
 struct Acc128 { u64 lo, hi; };
 __device__ __forceinline__ void acc_mad(Acc128& a, u64 x, u64 y) {
   const u128 s = ((u128)a.hi << 64 | a.lo) + (u128)x * y;      // one 64x64->128 multiply-add: 4 v_mad_u64_u32
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) dot_accum_kernel(const u64* __restrict__ 
       for (int e = 0; e < 4; ++e) acc[c][e] = Acc128{0, 0};
     int until_fold = fold_every;
     for (int k = 0; k < ncol; ++k) {
-      if (fold_every && until_fold-- == 0) {        // uniform; only for very wide key-switch matrices
+      if (fold_every && until_fold-- == 0) {        // uniform
         until_fold = fold_every - 1;
 #pragma unroll
         for (int c = 0; c < CT_TILE; ++c)
@@ -251,10 +251,10 @@ int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int nco
   if (!count) return 0;
   if (nslot <= 0) { slot0 = 0; nslot = ctx->L; }
   if (ctx->phim & 1) FHESI_FAIL("dot_accum: odd phi(m) not supported by the batched pipeline");
-  // exact 128-bit accumulation: F columns of (digit < 2 q_tile + 2^32) * (key < q) on top of a folded value below q must stay below 2^128
+  // exact 128-bit accumulation: F columns of (digit < 4 q_tile + 2^32) * (key < q) on top of a folded value below q must stay below 2^128
   int fold_every = 0;
   for (int l = 0; l < ctx->L; ++l) {
-    const u128 term = (u128)(2 * ctx->pc[l].q_tile + ((u64)1 << 32)) * ctx->pc[l].q;
+    const u128 term = (u128)(4 * ctx->pc[l].q_tile + ((u64)1 << 32)) * ctx->pc[l].q;
     const u128 F = (~(u128)0 - ctx->pc[l].q) / term;
     if (F < 2) FHESI_FAIL("dot_accum: residues of prime %d overflow the 128-bit accumulator", l);
     if (F < (u128)ncol && (fold_every == 0 || (int)F < fold_every)) fold_every = (int)F;

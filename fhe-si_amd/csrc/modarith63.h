@@ -104,12 +104,6 @@ __device__ __forceinline__ u64 csub63(u64 v, u64 c) {                 // v < 2^6
   asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mask) : "v"((u32)(d >> 32)));
   return d + (((u64)(mask & (u32)(c >> 32)) << 32) | (mask & (u32)c));
 }
-// v < 4q + 2^32  ->  congruent value below 2q + 2^32: the butterflies' own range step (compare HIGH words only), as a sign mask
-__device__ __forceinline__ u64 lazy_out63(u64 v, const Mod63& m) {
-  u32 mask;
-  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mask) : "v"(m.twoq_hi - (u32)(v >> 32)));      // all ones iff v.hi > (2q).hi  (both below 2^31)
-  return v + (((u64)(mask & m.m2q_hi) << 32) | (mask & m.m2q_lo));
-}
 __device__ __forceinline__ u64 norm_fwd63(u64 v, const Mod63& m) {   // v < 4q + 2^32  ->  [0,q)
   v = csub63(v, m.twoq);
   v = csub63(v, m.q);
