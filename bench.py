@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="ciphertext mults per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="ciphertext mults per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (FHESI_LANES); 2 gives ~+5 %% throughput but "
                     "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")

@@ -1113,9 +1113,13 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
 static i64 batch_chunk(const fhesi_ctx* c, int ncol) {
   const char* e = getenv("FHESI_BATCH_CHUNK");
   if (e && atoll(e) > 0) return atoll(e);
-  // bound the digit-row working set (count * ncol * L * n * 8 bytes) to about 6 GiB
-  const double per = (double)ncol * c->L * c->phim * 8.0;
-  i64 ch = (i64)(6.0 * 1024 * 1024 * 1024 / per);
+  // about 75k digit rows per chunk (150 rounds of the transform's 512 resident workgroups): measured best on MI355X at both the
+  // metric ring (64 mults, 9.3 GiB of digit rows) and the stress ring (16-17 mults, 18 GiB) -- smaller chunks pay launch tails in
+  // every stage, larger ones push the key rows out of the Infinity Cache during the dot product.  Capped at 32 GiB of digit rows.
+  const double rows_per = (double)ncol * c->L, bytes_per = rows_per * c->phim * 8.0;
+  i64 ch = (i64)(76800.0 / rows_per);
+  const i64 cap = (i64)(32.0 * 1024 * 1024 * 1024 / bytes_per);
+  if (ch > cap) ch = cap;
   return ch < 1 ? 1 : ch;
 }
 
