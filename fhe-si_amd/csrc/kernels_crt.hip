@@ -12,6 +12,18 @@
 // (x stays in [0, P_k) ) and centres once at the end -- same value, no signed big-int arithmetic per step.
 #include "fhesi_internal.h"
 
+// 128-bit value -> [0,q): hi * (2^64 mod q) + lo, each reduced by a Shoup step
+__device__ __forceinline__ u64 crt_fold128(u128 a, const PrimeConst& pc) {
+  const u64 q = pc.q, lo = (u64)a, hi = (u64)(a >> 64);
+  const u64 h = d_shoup(hi, 1, pc.one_sh, q);                 // hi mod q
+  const u64 t = d_shoup_lazy(h, pc.r64, pc.r64_sh, q);        // hi * 2^64 mod q, in [0,2q)
+  const u64 l = d_shoup_lazy(lo, 1, pc.one_sh, q);            // lo mod q, in [0,2q)
+  u64 r = t + l;
+  if (r >= pc.two_q) r -= pc.two_q;
+  if (r >= q) r -= q;
+  return r;
+}
+
 // ----------------------------------------------------------------------------------------- rns_reduce
 // limbs: [npolys_total][n][nlimbs] two's complement.  rows: [npolys_total][nslots][n].  pow64: [L][nlimbs+1].
 // One block stages 256 coefficients (all limbs, coalesced) in LDS, limb-major, and then produces their residues for every
@@ -52,6 +64,54 @@ __global__ void __launch_bounds__(256) rns_reduce_kernel(const u64* __restrict__
   }
 }
 
+// The same for a compile-time limb count (the usual coefficient widths): the limbs of a coefficient sit in registers across the
+// prime loop, and the residue is ONE exact 128-bit sum of x_k * (2^(64k) mod q) (4 word multiplies per limb instead of a Shoup
+// step's 10), folded every 8 limbs when the sum could overflow and reduced once.
+template <int NL>
+__global__ void __launch_bounds__(256) rns_reduce_kernel_t(const u64* __restrict__ limbs, i64 ncoeffs, i64 n, int npoly_mod, const u64* __restrict__ scalar_res,
+                                                            u64* __restrict__ rows, int nslots, const int* __restrict__ prime_of_slot,
+                                                            const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ pow64) {
+  __shared__ __attribute__((aligned(16))) u64 sl[NL * 256];       // [NL][256]
+  const i64 poly = blockIdx.y;
+  const i64 j0 = (i64)blockIdx.x * 256;
+  const int tid = threadIdx.x;
+  const u64* src = limbs + poly * ncoeffs * NL;
+  const i64 navail = ncoeffs - j0 < 256 ? (ncoeffs - j0 < 0 ? 0 : ncoeffs - j0) : 256;
+  const int nwords = (int)navail * NL;
+#pragma unroll
+  for (int it = 0; it < NL; ++it) {
+    const int e = it * 256 + tid;
+    sl[(e % NL) * 256 + e / NL] = e < nwords ? src[j0 * NL + e] : 0;
+  }
+  __syncthreads();
+  const i64 j = j0 + tid;
+  if (j >= n) return;
+  u64 x[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) x[k] = sl[k * 256 + tid];
+  const bool neg = (x[NL - 1] >> 63) != 0;
+  for (int slot = 0; slot < nslots; ++slot) {
+    const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+    const PrimeConst pc = pcs[prime];
+    const Shoup2* pw = pow64 + (i64)prime * (NL + 1);
+    u128 acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      acc += (u128)x[k] * pw[k].w;
+      if (NL > 15 && (k & 7) == 7 && k + 1 < NL) acc = crt_fold128(acc, pc);      // 8 more terms below 2^124 on top of a value below q
+    }
+    u64 r = crt_fold128(acc, pc);
+    if (neg) r = d_submod(r, pw[NL].w, pc.q);
+    if (scalar_res) { const u64 sc = scalar_res[(poly % npoly_mod) * nslots + slot]; if (sc) r = d_mulmod(r, sc, pc); }
+    rows[(poly * nslots + slot) * n + j] = r;
+  }
+}
+template <int NL>
+static void launch_rns_t(fhesi_ctx* ctx, dim3 grid, const u64* d_limbs, i64 ncoeffs, i64 n, int npoly, const u64* d_sc, u64* d_rows, int nslots,
+                         const int* d_prime_of_slot, const Shoup2* d_pow) {
+  rns_reduce_kernel_t<NL><<<grid, 256, 0, ctx->stream>>>(d_limbs, ncoeffs, n, npoly, d_sc, d_rows, nslots, d_prime_of_slot, ctx->d_pc, d_pow);
+}
+
 int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeffs, i64 count, int npoly, const u64* scalar_mul,
                       u64* d_rows, int nslots, const int* d_prime_of_slot) {
   if (!count || !npoly) return 0;
@@ -90,6 +150,14 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
   const i64 n = ctx->phim;
   ProfScope prof(ctx, PROF_RNS, (double)(count * npoly));
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)(count * npoly));
+  const i64 nc = ncoeffs < n ? ncoeffs : n;
+#define RNS_CASE(NL) case NL: launch_rns_t<NL>(ctx, grid, d_limbs, nc, n, npoly, d_sc, d_rows, nslots, d_prime_of_slot, d_pow); HIP_TRY(hipGetLastError()); return 0;
+  switch (nlimbs) {
+    RNS_CASE(1) RNS_CASE(2) RNS_CASE(3) RNS_CASE(4) RNS_CASE(5) RNS_CASE(6) RNS_CASE(7) RNS_CASE(8) RNS_CASE(9) RNS_CASE(10)
+    RNS_CASE(11) RNS_CASE(12) RNS_CASE(13) RNS_CASE(14) RNS_CASE(15) RNS_CASE(16) RNS_CASE(17) RNS_CASE(18) RNS_CASE(19) RNS_CASE(20)
+    default: break;
+  }
+#undef RNS_CASE
   const size_t shmem = (size_t)nlimbs * 256 * sizeof(u64);
   if (shmem > 160 * 1024) FHESI_FAIL("rns_reduce: coefficients of %d limbs are too wide", nlimbs);
   HIP_TRY(hipFuncSetAttribute((const void*)rns_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -160,17 +228,6 @@ int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out)
 // needs run-time limb indices (shift by logQ).
 // KFIX / WFIX > 0: the prime count and limb count are compile-time constants, so the triangular recurrence unrolls
 // completely (no uniform branches, constants hoisted); 0 = run-time values.
-// 128-bit value -> [0,q): hi * (2^64 mod q) + lo, each reduced by a Shoup step
-__device__ __forceinline__ u64 crt_fold128(u128 a, const PrimeConst& pc) {
-  const u64 q = pc.q, lo = (u64)a, hi = (u64)(a >> 64);
-  const u64 h = d_shoup(hi, 1, pc.one_sh, q);                 // hi mod q
-  const u64 t = d_shoup_lazy(h, pc.r64, pc.r64_sh, q);        // hi * 2^64 mod q, in [0,2q)
-  const u64 l = d_shoup_lazy(lo, 1, pc.one_sh, q);            // lo mod q, in [0,2q)
-  u64 r = t + l;
-  if (r >= pc.two_q) r -= pc.two_q;
-  if (r >= q) r -= q;
-  return r;
-}
 // LQFIX > 0 (with KFIX, WFIX): logQ is a compile-time constant too, so the epilogue indexes the limb registers statically and
 // the LDS staging (and its cap on resident workgroups) disappears; modes 1-3 only.
 template <int MAXW, int KFIX, int WFIX, int LQFIX = 0>
