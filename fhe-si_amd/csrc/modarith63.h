@@ -96,6 +96,57 @@ __device__ __forceinline__ u64 mulmod63(u64 y, const Tw63& t, const Mod63& m) {
 #undef BFLY_INV_NAME
 #undef BFLY_TWC
 
+// ---- the first two forward stages of a DIGIT row (phase A, SGPR twiddles).  The loader hands over values below 2^32, so
+//  stage 0: y1 = 0 -- the quotient chain loses three multiplies and the shift of y1 -- and X needs no range step
+//           (X' = X + T < 2q + 2^32,  Y' = X + 2q - T < 2q + 2^32);
+//  stage 1: inputs below 2q + 2^32 need no range step either (outputs below 4q + 2^32, the invariant of the later stages).
+#define MULMOD63_SMALL_ASM(b0, b1, b2, b3, b4, b5, Y0, W0, W1, P0, P1)                         \
+  "v_mul_hi_u32 " VR_(b0) ", " Y0 ", " P0 "\n\t"                                               \
+  "v_mov_b32 " VR_(b1) ", 0\n\t"                                                               \
+  "v_mad_u64_u32 " VP_(b2, b3) ", %[cy], " Y0 ", " W1 ", 0\n\t"                                \
+  "v_mad_u64_u32 " VP_(b0, b1) ", %[cy], " Y0 ", " P1 ", " VP_(b0, b1) "\n\t"                  \
+  "v_mad_u64_u32 " VP_(b4, b5) ", %[cy], " Y0 ", " W0 ", 0\n\t"                                \
+  "v_lshrrev_b64 " VP_(b0, b1) ", 31, " VP_(b0, b1) "\n\t"                                     \
+  "v_mad_u64_u32 " VP_(b2, b3) ", %[cy], " VR_(b0) ", %[nq1], " VP_(b2, b3) "\n\t"             \
+  "v_mad_u64_u32 " VP_(b4, b5) ", %[cy], " VR_(b0) ", %[nq0], " VP_(b4, b5) "\n\t"             \
+  "v_mad_u64_u32 " VP_(b2, b3) ", %[cy], " VR_(b1) ", %[nq0], " VP_(b2, b3) "\n\t"             \
+  "v_add_u32 " VR_(b5) ", " VR_(b5) ", " VR_(b2) "\n\t"
+// X' = X + T,  Y' = X + (2q + 1) + ~T   (T in v[b4:b5]; b6,b7: ~T; b8,b9: X + 2q + 1)
+#define BFLY_NC_TAIL(X, YN, b4, b5, b6, b7, b8, b9)                                             \
+  "v_not_b32 " VR_(b6) ", " VR_(b4) "\n\t"                                                     \
+  "v_not_b32 " VR_(b7) ", " VR_(b5) "\n\t"                                                     \
+  "v_lshl_add_u64 " VP_(b8, b9) ", " X ", 0, %[twoq1]\n\t"                                     \
+  "v_lshl_add_u64 " X ", " X ", 0, " VP_(b4, b5) "\n\t"                                        \
+  "v_lshl_add_u64 " YN ", " VP_(b8, b9) ", 0, " VP_(b6, b7) "\n\t"
+__device__ __forceinline__ void bfly_fwd63_x2_s_small(u64& Xa, u64& Ya, const Tw63& ta, u64& Xb, u64& Yb, const Tw63& tb, const Mod63& m) {
+  u64 cy, ya_new, yb_new;
+  asm(MULMOD63_SMALL_ASM(104, 105, 106, 107, 108, 109, "%[ya0]", "%[wa0]", "%[wa1]", "%[pa0]", "%[pa1]")
+      MULMOD63_SMALL_ASM(116, 117, 118, 119, 120, 121, "%[yb0]", "%[wb0]", "%[wb1]", "%[pb0]", "%[pb1]")
+      BFLY_NC_TAIL("%[xa]", "%[yan]", 108, 109, 110, 111, 112, 113)
+      BFLY_NC_TAIL("%[xb]", "%[ybn]", 120, 121, 122, 123, 124, 125)
+      : [xa] "+v"(Xa), [xb] "+v"(Xb), [yan] "=&v"(ya_new), [ybn] "=&v"(yb_new), [cy] "=&s"(cy)
+      : [ya0] "v"((u32)Ya), [yb0] "v"((u32)Yb), [wa0] "s"(ta.w0), [wa1] "s"(ta.w1), [pa0] "s"(ta.p0), [pa1] "s"(ta.p1), [wb0] "s"(tb.w0), [wb1] "s"(tb.w1),
+        [pb0] "s"(tb.p0), [pb1] "s"(tb.p1), [nq0] "s"(m.nq0), [nq1] "s"(m.nq1), [twoq1] "s"(m.twoq1)
+      : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+        "v124", "v125");
+  Ya = ya_new;
+  Yb = yb_new;
+}
+__device__ __forceinline__ void bfly_fwd63_x2_s_nc(u64& Xa, u64& Ya, const Tw63& ta, u64& Xb, u64& Yb, const Tw63& tb, const Mod63& m) {
+  u64 cy, ya_new, yb_new;
+  asm(MULMOD63_ASM(104, 105, 106, 107, 108, 109, 110, "%[ya0]", "%[ya1]", "%[wa0]", "%[wa1]", "%[pa0]", "%[pa1]")
+      MULMOD63_ASM(116, 117, 118, 119, 120, 121, 122, "%[yb0]", "%[yb1]", "%[wb0]", "%[wb1]", "%[pb0]", "%[pb1]")
+      BFLY_NC_TAIL("%[xa]", "%[yan]", 108, 109, 110, 111, 112, 113)
+      BFLY_NC_TAIL("%[xb]", "%[ybn]", 120, 121, 122, 123, 124, 125)
+      : [xa] "+v"(Xa), [xb] "+v"(Xb), [yan] "=&v"(ya_new), [ybn] "=&v"(yb_new), [cy] "=&s"(cy)
+      : [ya0] "v"((u32)Ya), [ya1] "v"((u32)(Ya >> 32)), [yb0] "v"((u32)Yb), [yb1] "v"((u32)(Yb >> 32)), [wa0] "s"(ta.w0), [wa1] "s"(ta.w1), [pa0] "s"(ta.p0),
+        [pa1] "s"(ta.p1), [wb0] "s"(tb.w0), [wb1] "s"(tb.w1), [pb0] "s"(tb.p0), [pb1] "s"(tb.p1), [nq0] "s"(m.nq0), [nq1] "s"(m.nq1), [twoq1] "s"(m.twoq1)
+      : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+        "v124", "v125");
+  Ya = ya_new;
+  Yb = yb_new;
+}
+
 // exact normalisations on store.  Conditional subtraction without compares: values stay below 2^63, so the sign of v - c
 // tells whether to add c back (5 VALU instructions per step instead of a compare / select / borrow chain with VCC wait states)
 __device__ __forceinline__ u64 csub63(u64 v, u64 c) {                 // v < 2^63, c < 2^62:  v >= c ? v - c : v
