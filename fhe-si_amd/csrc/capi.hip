@@ -257,7 +257,7 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   bluestein_destroy(c);
-  for (auto& kv : c->crt_cache) { hipFree(kv.second->d_blob); delete kv.second; }
+  for (auto& kv : c->crt_cache) { hipFree(kv.second->d_blob); if (kv.second->d_flags) hipFree(kv.second->d_flags); delete kv.second; }
   for (auto& kv : c->pow64_cache) hipFree(kv.second);
   for (auto& kv : c->scalar_cache) hipFree(kv.second);
   for (int i = 0; i < 10; ++i) if (c->lane_ws[i]) hipFree(c->lane_ws[i]);

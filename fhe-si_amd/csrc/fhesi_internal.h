@@ -49,6 +49,11 @@ struct CrtTables {
   Shoup2* d_pinv = nullptr;            // [nidx]      (q_0...q_{k-1})^-1 mod q_k
   u64* d_P = nullptr;                  // [nidx+1][W] partial products P_k = q_0...q_{k-1}; row nidx = full product
   u64* d_halfP = nullptr;              // [W]         (P-1)/2
+  // tables of the sum form x = sum_i y_i M_i - kappa P (crt_sum_kernel): M_i = P / q_i, y_i = r_i c_i mod q_i, c_i = M_i^-1 mod q_i
+  u64* d_M = nullptr;                  // [nidx][W]
+  u64* d_cinv = nullptr;               // [nidx][3]   c_i, floor(c_i 2^128 / q_i) as (hi, lo)
+  mutable unsigned char* d_flags = nullptr;   // per-workgroup "recompute exactly" flags of the last launch (grow-only)
+  mutable size_t flags_cap = 0;
 };
 
 struct BluesteinTables;                // general-m path, defined in bluestein.hip

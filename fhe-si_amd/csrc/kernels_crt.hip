@@ -179,9 +179,9 @@ int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out)
   const int W = (int)P[K].size() + 1;   // one spare limb for the sign / rounding carry
   CrtTables* t = new CrtTables();
   t->nidx = K; t->W = W; t->idx = idx;
-  // blob layout (u64 words): idx[K] (as u64) | pow64[K][W] (2 words each) | pinv[K] (2 words) | P[K+1][W] | halfP[W]
-  const size_t n_idx = K, n_pow = (size_t)K * W * 2, n_pinv = (size_t)K * 2, n_P = (size_t)(K + 1) * W, n_half = W;
-  std::vector<u64> blob(n_idx + n_pow + n_pinv + n_P + n_half, 0);
+  // blob layout (u64 words): idx[K] (as u64) | pow64[K][W] (2 words each) | pinv[K] (2 words) | P[K+1][W] | halfP[W] | M[K][W] | cinv[K][3]
+  const size_t n_idx = K, n_pow = (size_t)K * W * 2, n_pinv = (size_t)K * 2, n_P = (size_t)(K + 1) * W, n_half = W, n_M = (size_t)K * W, n_cinv = (size_t)K * 3;
+  std::vector<u64> blob(n_idx + n_pow + n_pinv + n_P + n_half + n_M + n_cinv, 0);
   u64* b_idx = blob.data();
   u64* b_pow = b_idx + n_idx;
   u64* b_pinv = b_pow + n_pow;
@@ -209,6 +209,23 @@ int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out)
     for (int j = 0; j < W; ++j) h[j] = (h[j] >> 1) | (j + 1 < W ? h[j + 1] << 63 : 0);
     for (int j = 0; j < W; ++j) b_half[j] = h[j];
   }
+  // sum-form tables
+  {
+    u64* b_M = b_half + n_half;
+    u64* b_c = b_M + n_M;
+    for (int i = 0; i < K; ++i) {
+      const u64 q = ctx->q[idx[i]];
+      std::vector<u64> M{1};
+      for (int k = 0; k < K; ++k) if (k != i) M = hm::bn_mul_small(M, ctx->q[idx[k]]);
+      u64 mi = 0;
+      for (int j = (int)M.size() - 1; j >= 0; --j) mi = (u64)((((u128)mi << 64) | M[j]) % q);
+      const u64 c = hm::invmod(mi, q);
+      for (size_t j = 0; j < M.size(); ++j) b_M[(size_t)i * W + j] = M[j];
+      const u128 num = (u128)c << 64;
+      const u64 hi = (u64)(num / q), rem = (u64)(num % q);
+      b_c[i * 3] = c; b_c[i * 3 + 1] = hi; b_c[i * 3 + 2] = (u64)(((u128)rem << 64) / q);
+    }
+  }
   HIP_TRY(hipMalloc(&t->d_blob, blob.size() * 8));
   HIP_TRY(hipMemcpyAsync(t->d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -217,12 +234,68 @@ int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out)
   t->d_pinv = (Shoup2*)(t->d_blob + n_idx + n_pow);
   t->d_P = t->d_blob + n_idx + n_pow + n_pinv;
   t->d_halfP = t->d_P + n_P;
+  t->d_M = t->d_halfP + n_half;
+  t->d_cinv = t->d_M + n_M;
   ctx->crt_cache[idx] = t;
   *out = t;
   return 0;
 }
 
 // ----------------------------------------------------------------------------------------- CRT kernel
+// Mode-dependent store of a finished W-limb two's-complement value whose limb count and logQ are compile-time constants
+// (static register indices).  Mode 1 reads the limbs from bit logQ - 1 upwards only, modes 2 and 3 the limbs below bit logQ only.
+template <int MAXW, int WFIX, int LQFIX>
+__device__ __forceinline__ void crt_store_fixed(const u64 (&x)[MAXW], int mode, u64* __restrict__ out, i64 poly, i64 n, i64 j, int nl_out) {
+  static_assert(WFIX > 0 && WFIX <= MAXW, "static epilogue needs a compile-time limb count");
+    constexpr int LQ = LQFIX, w = LQ >> 6, b = LQ & 63, sw = (LQ - 1) >> 6, sb = (LQ - 1) & 63;
+    const u64 sf = (x[WFIX - 1] >> 63) ? ~0ull : 0ull;
+#define XS(i) ((i) < WFIX ? x[(i) < WFIX ? (i) : 0] : sf)
+    const u64 hbit = (XS(sw) >> sb) & 1;           // bit logQ-1: the rounding carry (mode 1) / the sign of the centred residue (mode 2)
+    if (mode == 1) {
+      u64 carry = hbit;
+      u64* o = out + poly * nl_out * n + j;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i < nl_out) {
+          const u64 lo = XS(i + w), hi = XS(i + w + 1);
+          u64 val = b ? ((lo >> b) | (hi << ((64 - b) & 63))) : lo;
+          val += carry;
+          carry = (carry && val == 0);
+          const int bits_left = LQ - 64 * i;
+          if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << (bits_left & 63)) - 1);
+          o[(i64)i * n] = val;
+        }
+      }
+      for (int i = MAXW; i < nl_out; ++i) o[(i64)i * n] = 0;
+    } else if (mode == 3) {
+      u64* o = out + poly * nl_out * n + j;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i < nl_out) {
+          u64 val = XS(i);
+          const int bits_left = LQ - 64 * i;
+          if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << (bits_left & 63)) - 1);
+          o[(i64)i * n] = val;
+        }
+      }
+      for (int i = MAXW; i < nl_out; ++i) o[(i64)i * n] = 0;
+    } else {
+      u64* o = out + (poly * n + j) * nl_out;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i < nl_out) {
+          u64 val = XS(i);
+          const int bits_left = LQ - 64 * i;
+          if (bits_left <= 0) val = hbit ? ~0ull : 0ull;
+          else if (bits_left < 64) { const u64 mask = (1ull << (bits_left & 63)) - 1; val = hbit ? (val | ~mask) : (val & mask); }
+          o[i] = val;
+        }
+      }
+      for (int i = MAXW; i < nl_out; ++i) o[i] = hbit ? ~0ull : 0ull;
+    }
+#undef XS
+}
+
 // One thread per coefficient.  MAXW = compile-time bound on the limb count (register array, static indices only);
 // the finished W-limb integer is staged in LDS (limb-major, conflict-free) for the mode-dependent epilogue that
 // needs run-time limb indices (shift by logQ).
@@ -235,8 +308,10 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
                                                   int K_rt, int W_rt, const int* __restrict__ idx, const Shoup2* __restrict__ pow64,
                                                   const Shoup2* __restrict__ pinv, const u64* __restrict__ Ptab, const u64* __restrict__ halfP,
                                                   const PrimeConst* __restrict__ pcs, int mode, int positive, int logQ,
-                                                  u64* __restrict__ out, int nl_out) {
+                                                  u64* __restrict__ out, int nl_out, const unsigned char* __restrict__ block_flags) {
   extern __shared__ __attribute__((aligned(16))) u64 sx[];   // [W][blockDim.x]
+  // clean-up pass behind crt_sum_kernel: only the workgroups it flagged recompute (and overwrite) their coefficients
+  if (block_flags && !block_flags[(size_t)blockIdx.y * gridDim.x + blockIdx.x]) return;
   const i64 poly = blockIdx.y;
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = j < n;
@@ -310,55 +385,8 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
     }
   }
   if constexpr (LQFIX > 0) {
-    static_assert(WFIX > 0 && WFIX <= MAXW, "static epilogue needs a compile-time limb count");
     if (!active) return;
-    constexpr int LQ = LQFIX, w = LQ >> 6, b = LQ & 63, sw = (LQ - 1) >> 6, sb = (LQ - 1) & 63;
-    const u64 sf = (x[WFIX - 1] >> 63) ? ~0ull : 0ull;
-#define XS(i) ((i) < WFIX ? x[(i) < WFIX ? (i) : 0] : sf)
-    const u64 hbit = (XS(sw) >> sb) & 1;           // bit logQ-1: the rounding carry (mode 1) / the sign of the centred residue (mode 2)
-    if (mode == 1) {
-      u64 carry = hbit;
-      u64* o = out + poly * nl_out * n + j;
-#pragma unroll
-      for (int i = 0; i < MAXW; ++i) {
-        if (i < nl_out) {
-          const u64 lo = XS(i + w), hi = XS(i + w + 1);
-          u64 val = b ? ((lo >> b) | (hi << ((64 - b) & 63))) : lo;
-          val += carry;
-          carry = (carry && val == 0);
-          const int bits_left = LQ - 64 * i;
-          if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << (bits_left & 63)) - 1);
-          o[(i64)i * n] = val;
-        }
-      }
-      for (int i = MAXW; i < nl_out; ++i) o[(i64)i * n] = 0;
-    } else if (mode == 3) {
-      u64* o = out + poly * nl_out * n + j;
-#pragma unroll
-      for (int i = 0; i < MAXW; ++i) {
-        if (i < nl_out) {
-          u64 val = XS(i);
-          const int bits_left = LQ - 64 * i;
-          if (bits_left < 64) val &= (bits_left <= 0) ? 0ull : ((1ull << (bits_left & 63)) - 1);
-          o[(i64)i * n] = val;
-        }
-      }
-      for (int i = MAXW; i < nl_out; ++i) o[(i64)i * n] = 0;
-    } else {
-      u64* o = out + (poly * n + j) * nl_out;
-#pragma unroll
-      for (int i = 0; i < MAXW; ++i) {
-        if (i < nl_out) {
-          u64 val = XS(i);
-          const int bits_left = LQ - 64 * i;
-          if (bits_left <= 0) val = hbit ? ~0ull : 0ull;
-          else if (bits_left < 64) { const u64 mask = (1ull << (bits_left & 63)) - 1; val = hbit ? (val | ~mask) : (val & mask); }
-          o[i] = val;
-        }
-      }
-      for (int i = MAXW; i < nl_out; ++i) o[i] = hbit ? ~0ull : 0ull;
-    }
-#undef XS
+    crt_store_fixed<MAXW, WFIX, LQFIX>(x, mode, out, poly, n, j, nl_out);
     return;
   }
 #pragma unroll
@@ -412,16 +440,118 @@ __global__ void __launch_bounds__(128) crt_kernel(const u64* __restrict__ rows, 
 
 template <int MAXW, int KFIX = 0, int WFIX = 0, int LQFIX = 0>
 static int launch_crt_t(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode,
-                        int positive, int logQ, u64* d_out, int nl_out) {
+                        int positive, int logQ, u64* d_out, int nl_out, const unsigned char* d_block_flags = nullptr) {
   const int TB = 128;
   const size_t shmem = LQFIX ? 0 : (size_t)t->W * TB * sizeof(u64);
   static unsigned long long attr_done = 0;     // one bit per device: the attribute is per device
   if (!LQFIX && !(attr_done >> ctx->device & 1)) { HIP_TRY(hipFuncSetAttribute((const void*)crt_kernel<MAXW, KFIX, WFIX, LQFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, MAXW * TB * 8)); attr_done |= 1ull << ctx->device; }
   dim3 grid((unsigned)((ctx->phim + TB - 1) / TB), (unsigned)npolys);
   crt_kernel<MAXW, KFIX, WFIX, LQFIX><<<grid, TB, shmem, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->nidx, t->W, t->d_idx, t->d_pow64, t->d_pinv, t->d_P,
-                                                    t->d_halfP, ctx->d_pc, mode, positive, logQ, d_out, nl_out);
+                                                    t->d_halfP, ctx->d_pc, mode, positive, logQ, d_out, nl_out, d_block_flags);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+// ----------------------------------------------------------------------------------------- CRT, sum form
+// The pipeline's conversions (modes 1-3, centred, compile-time prime count / limb count / logQ) do not need the whole integer:
+//   x = sum_i y_i M_i - kappa P,   M_i = P/q_i,   y_i = r_i (M_i^-1) mod q_i,   kappa = floor(sum_i y_i/q_i + 1/2)   (centred x)
+// and mode 1 (ScaleDown) only reads the bits from logQ-1 upwards, modes 2/3 only the bits below logQ.  So
+//   * kappa comes from a 128-bit fixed-point sum of frac(r_i c_i / q_i), each term taken from r_i * floor(c_i 2^128 / q_i) and
+//     under-estimated by less than 2^-68: the sum is low by less than 2^-63, and only a fraction within 2^-62 below 1/2 leaves
+//     kappa undecided;
+//   * modes 2/3 accumulate only the limbs below logQ of y_i M_i and kappa P -- exact, low limbs do not depend on high ones;
+//   * mode 1 accumulates the limbs from two below the one holding bit logQ-1: dropping the lower limbs of every product costs less
+//     than 2 units of that limb, which can change the rounded quotient only if (x + 2^(logQ-1)) mod 2^logQ is within a few units
+//     of wrapping around.
+// A workgroup that meets an undecided coefficient (probability ~2^-60 per coefficient on real data; certain for crafted values such
+// as +-P/2) sets its flag, and the exact mixed-radix kernel, launched right behind with the flag array, redoes just those
+// workgroups.  Result: identical bits, 18 x 8 (or 18 x 12) limb products instead of the recurrence's 2 x 153 + folds.
+template <int K, int W, int LQ, bool HIGH>
+__global__ void __launch_bounds__(128) crt_sum_kernel(const u64* __restrict__ rows, i64 n, int nslots_layout, const int* __restrict__ slot_of,
+                                                      const int* __restrict__ idx, const u64* __restrict__ Mtab, const u64* __restrict__ cinv,
+                                                      const u64* __restrict__ Pfull, const PrimeConst* __restrict__ pcs, int mode,
+                                                      u64* __restrict__ out, int nl_out, unsigned char* __restrict__ block_flags) {
+  constexpr int w = LQ >> 6, sw = (LQ - 1) >> 6;
+  static_assert((LQ & 63) == 0 && w >= 2 && w + 1 < W, "sum-form CRT: logQ a multiple of 64 inside the product");
+  constexpr int J0 = HIGH ? sw - 1 : 0, J1 = HIGH ? W : w;          // limbs [J0, J1) are accumulated
+  const i64 poly = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < n;
+  const u64* base = rows + poly * nslots_layout * n;
+  u64 x[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) x[i] = 0;
+  int undecided = 0;
+  if (active) {
+    u64 f_lo = 0, f_hi = 0;        // fractional part of sum y_i/q_i, 128-bit fixed point
+    u32 kint = 0;                  // its integer part
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const PrimeConst pc = pcs[idx[i]];
+      const u64 q = pc.q;
+      const u64 r = base[(i64)(slot_of ? slot_of[i] : idx[i]) * n + j];
+      const u64 c = cinv[i * 3], ch = cinv[i * 3 + 1], cl = cinv[i * 3 + 2];
+      const u64 y = d_shoup(r, c, ch, q);
+      // low 128 bits of r * (ch:cl)
+      const u128 pl = (u128)r * cl;
+      const u64 t_lo = (u64)pl, t_hi = (u64)(pl >> 64) + r * ch;
+      const u128 fs = ((u128)f_hi << 64 | f_lo) + ((u128)t_hi << 64 | t_lo);
+      kint += (fs < ((u128)t_hi << 64 | t_lo)) ? 1u : 0u;
+      f_lo = (u64)fs; f_hi = (u64)(fs >> 64);
+      // x[J0..J1) += y * M_i[J0..J1)
+      const u64* Mi = Mtab + (i64)i * W;
+      u64 carry = 0;
+#pragma unroll
+      for (int l = J0; l < J1; ++l) {
+        const u128 s = (u128)y * Mi[l] + x[l] + carry;
+        x[l] = (u64)s;
+        carry = (u64)(s >> 64);
+      }
+    }
+    // centred: kappa = floor(phi + 1/2); the computed fraction is low by less than 2^-63
+    const u32 kappa = kint + (u32)(f_hi >> 63);
+    undecided |= (f_hi >= 0x7ffffffffffffffcull && f_hi < 0x8000000000000000ull) ? 1 : 0;
+    // x[J0..J1) -= kappa * P[J0..J1)
+    u64 carry = 0, borrow = 0;
+#pragma unroll
+    for (int l = J0; l < J1; ++l) {
+      const u128 t = (u128)kappa * Pfull[l] + carry;
+      carry = (u64)(t >> 64);
+      const u64 tl = (u64)t, d = x[l] - tl, b1 = x[l] < tl, d2 = d - borrow, b2 = d < borrow;
+      x[l] = d2;
+      borrow = b1 | b2;
+    }
+    if (HIGH) {
+      // limbs below J0 were dropped: the limb holding bit logQ-1 may be off by a few units
+      const u64 u = x[sw] + ((u64)1 << 63);
+      undecided |= (u + 8 < 16) ? 1 : 0;
+    }
+    crt_store_fixed<W, W, LQ>(x, mode, out, poly, n, j, nl_out);
+  }
+  const int any = __syncthreads_or(undecided);
+  if (threadIdx.x == 0) block_flags[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = any ? 1 : 0;
+}
+
+template <int K, int W, int LQ>
+static int launch_crt_sum(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode,
+                          u64* d_out, int nl_out) {
+  const int TB = 128;
+  dim3 grid((unsigned)((ctx->phim + TB - 1) / TB), (unsigned)npolys);
+  const size_t need = (size_t)grid.x * grid.y;
+  if (need > t->flags_cap) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (t->d_flags) HIP_TRY(hipFree(t->d_flags));
+    HIP_TRY(hipMalloc(&t->d_flags, need));
+    t->flags_cap = need;
+  }
+  if (mode == 1) crt_sum_kernel<K, W, LQ, true><<<grid, TB, 0, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->d_idx, t->d_M, t->d_cinv, t->d_P + (size_t)K * W,
+                                                                               ctx->d_pc, mode, d_out, nl_out, t->d_flags);
+  else crt_sum_kernel<K, W, LQ, false><<<grid, TB, 0, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->d_idx, t->d_M, t->d_cinv, t->d_P + (size_t)K * W,
+                                                                      ctx->d_pc, mode, d_out, nl_out, t->d_flags);
+  HIP_TRY(hipGetLastError());
+  // exact clean-up of the flagged workgroups (normally none: every workgroup of this launch returns at once)
+  if (getenv("FHESI_CRT_SKIP_CLEANUP")) return 0;      // test hook: shows that a crafted input really needs the clean-up
+  return launch_crt_t<K, K, W, LQ>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, 0, LQ, d_out, nl_out, t->d_flags);
 }
 
 int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode, int positive,
@@ -431,6 +561,12 @@ int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots
   const int W = t->W;
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
   // fully unrolled instantiation for the metric chain shape (fhe-si logQ = 512: 18 primes, 17-limb product)
+  // sum form for the chain shapes of the metric ring (logQ = 512: 18 primes, 17-limb product) and of the stress ring (logQ = 1024: 35 primes,
+  // 33-limb product); FHESI_CRT_EXACT=1 keeps the mixed-radix kernel (A/B measurements)
+  if (mode != 0 && !positive && !getenv("FHESI_CRT_EXACT")) {
+    if (t->nidx == 18 && W == 18 && logQ == 512) return launch_crt_sum<18, 18, 512>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, d_out, nl_out);
+    if (t->nidx == 35 && W == 34 && logQ == 1024) return launch_crt_sum<35, 34, 1024>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, d_out, nl_out);
+  }
   if (t->nidx == 18 && W == 18 && logQ == 512 && mode != 0) return launch_crt_t<18, 18, 18, 512>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (t->nidx == 18 && W == 18) return launch_crt_t<18, 18, 18>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);
   if (W <= 4) return launch_crt_t<4>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, positive, logQ, d_out, nl_out);

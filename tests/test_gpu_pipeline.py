@@ -89,3 +89,63 @@ def test_stress_config_shape_single_ciphertext():
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     assert np.array_equal(got[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
+
+
+def test_sum_form_crt_undecided_coefficients(monkeypatch):
+    """The metric chain shape converts through the sum-form CRT kernel (kernels_crt.hip), which hands coefficients it cannot decide
+    to the exact mixed-radix kernel: values whose rounding in ScaleDown (Ciphertext.cpp:205-213) sits on the edge, and values at
+    +-P/2 in toPoly's centring (DoubleCRT.cpp:375-376).  Crafted inputs put such values at known positions; the result must still
+    equal the oracle's, and must NOT when the clean-up pass is switched off (so the inputs really exercise it)."""
+    m, logQ, p, count = 64, 512, 23, 1
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 99, count)
+    n, L = ctx.phim, ctx.L
+    primes = [int(q) for q in ctx.primes]
+    Pprod = 1
+    for q in primes:
+        Pprod *= q
+    mod = 1 << logQ
+    inv_p = pow(p, -1, mod)
+
+    def centred(v):
+        v %= mod
+        return v - mod if v >= mod // 2 else v
+
+    # --- ScaleDown edge: x = p * A with (x + 2^(logQ-1)) mod 2^logQ = delta, delta around 0
+    deltas = [0, 1, -1, 2, -2, 3, -3, 5, -5, 7, -7, 8, -8, 100, -100]
+    A = [centred((d - (mod >> 1)) * inv_p) for d in deltas]
+    a0 = A + [0] * (n - len(A))
+    a[0, 0] = O.ints_to_limbs(a0, nl)
+    a[0, 1] = 0
+    b[0, 0] = O.ints_to_limbs([1] + [0] * (n - 1), nl)
+    b[0, 1] = 0
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    want = orc.ct_mul_relin(ksm, a[0], b[0], logQ, p)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
+    monkeypatch.setenv("FHESI_CRT_SKIP_CLEANUP", "1")
+    assert not np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
+    monkeypatch.delenv("FHESI_CRT_SKIP_CLEANUP")
+
+    # --- centring edge: make the key-switch dot product return chosen polynomials.  Scaled-down parts = (1, 0, 0), so only digit 0
+    # of part 0 is non-zero (the constant 1, whose transform is the all-ones row) and the dot product is key row (r, 0) itself.
+    W = L + 2
+    one = O.ints_to_limbs([mod] + [0] * (n - 1), W)           # x / 2^logQ = 1 exactly
+    tp = np.zeros((1, 3, L, n), dtype=np.uint64)
+    tp[0, 0] = orc.dcrt_from_poly(one)
+    h = (Pprod - 1) // 2
+    edge = [h, -h, h + 1, h - 1, -h + 1, 0, 1, -1, Pprod - 1, h + 2, -h - 2, 12345, -(1 << 600)]
+    ksm2 = ksm.copy()
+    for r in range(2):
+        e = edge[r:] + edge[:r] + [0] * (n - len(edge))
+        ksm2[r, 0] = orc.dcrt_from_poly(O.ints_to_limbs(e, W))
+    ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm2)
+    dtp = ctx.upload(tp)
+    out = ctx.alloc(2 * n * nl * 8)
+    ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
+    want2 = orc.apply_key_switch(ksm2, tp[0], logQ, nl)
+    assert np.array_equal(out.download((2, n, nl)), want2)
+    got_int = O.limbs_to_ints(out.download((2, n, nl))[0])
+    assert got_int[0] == centred(h) and got_int[1] == centred(-h) and got_int[2] == centred(-h)      # (P+1)/2 wraps to -(P-1)/2
+    monkeypatch.setenv("FHESI_CRT_SKIP_CLEANUP", "1")
+    ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
+    assert not np.array_equal(out.download((2, n, nl)), want2)
+    monkeypatch.delenv("FHESI_CRT_SKIP_CLEANUP")
