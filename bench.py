@@ -245,7 +245,7 @@ def run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F):
     uniform residues per GPU; one step = forward + inverse transform of the whole batch (2 B L row transforms); the round trip must
     reproduce the input bit for bit, and one DoubleCRT is checked against the C oracle in both directions."""
     m, n, L = 1 << 14, 1 << 13, 8
-    B = args.batch if args.batch != 32 else 1024
+    B = args.batch if args.batch else 1024
     primes, q = [], (1 << 60) - 1
     q -= q % (2 * m)
     q += 2 * m + 1
@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="ciphertext mults per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="ciphertext mults per GPU per step (default 64 = one chunk of the library; ntt workload: DoubleCRTs per step, default 1024)")
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (FHESI_LANES); 2 gives ~+5 %% throughput but "
                     "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
@@ -380,7 +380,7 @@ def main():
     nl = (LOGQ + 63) // 64
     ncol = 3 * nd
     chain_bits = sum(math.log2(q) for q in primes)
-    B = args.batch
+    B = args.batch if args.batch else (16 if args.workload == "stress" else 64)      # one chunk of the library (about 75k digit rows)
 
     ctx = F.Context(M_RING, primes, roots, device=local_rank)
     ksk = F.KeySwitchMatrix(ctx, 3, nd)
@@ -454,7 +454,10 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_ntt_fwd.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get("hbm_bytes_per_launch")
+            if not launches or pmc.get("rows_per_launch") != round(rows / launches):
+                traffic = None      # the counters were collected on another launch shape (batch)
         except Exception:
             traffic = None
     if args.workload != "metric" or args.ntt_rows:

@@ -14,7 +14,7 @@ run() {   # name, then bench.py arguments
   tail -1 "$O/${name}_bench.json" | cut -c1-400
 }
 run metric --steps 5 --warmup 2
-run stress --workload stress --batch 8 --steps 3 --warmup 1 --cpu-sample 0
+run stress --workload stress --steps 3 --warmup 1 --cpu-sample 0
 run regression --workload regression --steps 3 --warmup 1
 run ntt --workload ntt --steps 10 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do
