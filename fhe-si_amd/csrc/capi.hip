@@ -260,12 +260,12 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   for (auto& kv : c->crt_cache) { hipFree(kv.second->d_blob); if (kv.second->d_flags) hipFree(kv.second->d_flags); delete kv.second; }
   for (auto& kv : c->pow64_cache) hipFree(kv.second);
   for (auto& kv : c->scalar_cache) hipFree(kv.second);
-  for (int i = 0; i < 10; ++i) if (c->lane_ws[i]) hipFree(c->lane_ws[i]);
+  for (int i = 0; i < FHESI_WS_SLOTS; ++i) if (c->lane_ws[i]) hipFree(c->lane_ws[i]);
   if (c->lane_stream) hipStreamDestroy(c->lane_stream);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_mid) hipEventDestroy(c->ev_mid);
-  for (int i = 0; i < 10; ++i) if (c->ws[i]) hipFree(c->ws[i]);
+  for (int i = 0; i < FHESI_WS_SLOTS; ++i) if (c->ws[i]) hipFree(c->ws[i]);
   hipFree(c->d_pc); hipFree(c->d_tw_fwd); hipFree(c->d_tw_inv); hipFree(c->d_twt_fwd); hipFree(c->d_twt_inv); hipFree(c->d_tail_fwd); hipFree(c->d_sub_fold); hipFree(c->d_twt_fwd_sub); hipFree(c->d_head_tw);
   hipFree(c->d_zms_idx); hipFree(c->d_zms_list);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -764,6 +764,8 @@ extern "C" int fhesi_ksk_free(fhesi_ksk* k) {
   hipSetDevice(k->ctx->device);
   hipStreamSynchronize(k->ctx->stream);
   hipFree(k->d_rows);
+  if (k->d_aux) hipFree(k->d_aux);
+  if (k->d_aux_consts) hipFree(k->d_aux_consts);
   delete k;
   return 0;
 }
@@ -772,9 +774,12 @@ extern "C" int fhesi_ksk_upload(fhesi_ksk* k, const uint64_t* rows_host) {
   CHECK_CTX(k->ctx);
   HIP_TRY(hipMemcpyAsync(k->d_rows, rows_host, k->bytes, hipMemcpyHostToDevice, k->ctx->stream));
   HIP_TRY(hipStreamSynchronize(k->ctx->stream));
+  k->aux_valid = false;
   return 0;
 }
-extern "C" void* fhesi_ksk_device_ptr(fhesi_ksk* k) { return k ? k->d_rows : nullptr; }
+// Handing out the row pointer invalidates the derived table: whoever writes the rows directly (the RCCL key broadcast) fetches the
+// pointer first, and the next key switch rebuilds the table from the new rows.
+extern "C" void* fhesi_ksk_device_ptr(fhesi_ksk* k) { if (k) k->aux_valid = false; return k ? k->d_rows : nullptr; }
 extern "C" size_t fhesi_ksk_bytes(const fhesi_ksk* k) { return k ? k->bytes : 0; }
 
 // --------------------------------------------------------------------------------------------- ciphertext pipeline
@@ -810,6 +815,21 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
   const std::vector<int> all = full_set(c);
   CrtTables* t;
   FHESI_TRY(get_crt_tables(c, all, &t));
+  // Dot product through the two largest chain primes (kernels_ksaux.hip): 2 transforms per digit polynomial instead of L.
+  // FHESI_KS_DIRECT=1 keeps the per-prime dot product below (A/B measurements; also the path of every shape the other does not cover).
+  if (ksaux_supported(c, ncol, 8 * decomp_bytes) && !getenv("FHESI_KS_DIRECT")) {
+    fhesi_ksk* km = const_cast<fhesi_ksk*>(k);
+    if (!k->aux_valid || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes)) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes));
+    void *d_dig, *d_o;
+    FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * 2 * n * 8, &d_dig));
+    FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * L * 2 * n * 8, &d_o));
+    FHESI_TRY(launch_ntt_fwd_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig, 0, 2, 2));
+    if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
+    FHESI_TRY(launch_dot_aux(c, k, (const u64*)d_dig, ncol, count, (u64*)d_o));
+    FHESI_TRY(launch_ntt_inv(c, (u64*)d_o, count * 2 * L, 2, (const int*)(k->d_aux_consts + L), !k->aux_suborder));
+    FHESI_TRY(launch_aux_crt(c, k, (const u64*)d_o, d_t, count * 2 * L));
+    return launch_crt(c, t, d_t, L, nullptr, count * 2, 2, 0, logQ, (u64*)out, nlimbs);
+  }
   // ByteDecomp + DoubleCRT(digit polys)   (Ciphertext.cpp:82-121, FHE-SI.cpp:244-249)
   void* d_dig;
   FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * L * n * 8, &d_dig));
@@ -1140,7 +1160,7 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
 }
 static void swap_lane(fhesi_ctx* c) {
   std::swap(c->stream, c->lane_stream);
-  for (int i = 0; i < 10; ++i) { std::swap(c->ws[i], c->lane_ws[i]); std::swap(c->ws_bytes[i], c->lane_ws_bytes[i]); }
+  for (int i = 0; i < FHESI_WS_SLOTS; ++i) { std::swap(c->ws[i], c->lane_ws[i]); std::swap(c->ws_bytes[i], c->lane_ws_bytes[i]); }
 }
 
 extern "C" int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a,

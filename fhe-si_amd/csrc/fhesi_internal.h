@@ -17,6 +17,7 @@ void fhesi_set_error(const char* fmt, ...);
 #define FHESI_FAIL(...) do { fhesi_set_error(__VA_ARGS__); return 1; } while (0)
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fhesi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return 1; } } while (0)
 #define FHESI_OP_SET_ 4
+#define FHESI_WS_SLOTS 12
 #define FHESI_TRY(expr) do { int r__ = (expr); if (r__) return r__; } while (0)
 
 // --------------------------------------------------------------------------------- per-prime device constants
@@ -97,8 +98,8 @@ struct fhesi_ctx {
   // second "lane" (stream + workspace): the batched ciphertext pipeline runs two half-batches concurrently so that one
   // half's HBM-bound kernels (dot, CRT loads) overlap the other half's VALU-bound NTTs
   hipStream_t lane_stream = nullptr;
-  void* lane_ws[10] = {};
-  size_t lane_ws_bytes[10] = {};
+  void* lane_ws[FHESI_WS_SLOTS] = {};
+  size_t lane_ws_bytes[FHESI_WS_SLOTS] = {};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
   bool mark_mid = false;               // record ev_mid right after the next digit-NTT launch (staggers the second lane)
   bool prof_on = false;
@@ -109,8 +110,9 @@ struct fhesi_ctx {
   //   4 wave sums, per-call constants                    5 tProd of a chunk / message staging
   //   6 row transforms above 2^14 (two-pass, bit reversal)   7 Bluestein slot map / wave operands
   //   8 Bluestein convolution buffer, index lists        9 Bluestein inverse output, scalar lists (no Bluestein call in between)
-  void* ws[10] = {};
-  size_t ws_bytes[10] = {};
+  //   10 auxiliary-prime dot product output (kernels_ksaux.hip)
+  void* ws[FHESI_WS_SLOTS] = {};
+  size_t ws_bytes[FHESI_WS_SLOTS] = {};
 };
 
 struct fhesi_dcrt {
@@ -124,7 +126,15 @@ struct fhesi_ksk {
   int ncomp = 0, ndigits = 0;
   u64* d_rows = nullptr;               // [2][ncomp*ndigits][L][phim]
   size_t bytes = 0;
+  // derived table of the two-auxiliary-prime dot product (kernels_ksaux.hip), rebuilt on the device when the rows changed
+  u64* d_aux = nullptr;                // [2 aux][L][2][ncomp*ndigits][phim]
+  u64* d_aux_consts = nullptr;         // [L] q_0 q_1 mod q_i, then the int pair {0, 1} (prime_of_slot of auxiliary rows)
+  bool aux_valid = false, aux_suborder = false;
 };
+bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits);
+int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits);
+int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig /* [count*ncol][2][n] */, int ncol, i64 count, u64* d_out /* [count][2][L][2][n] */);
+int launch_aux_crt(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_o /* [nrows][2][n] */, u64* d_dst /* [nrows][n] */, i64 nrows);
 
 int ws_reserve(fhesi_ctx* ctx, int slot, size_t bytes, void** out);
 
@@ -172,7 +182,7 @@ int launch_ntt_sub(fhesi_ctx* ctx, bool fwd, u64* d_rows, i64 count, int nslots,
 int launch_ntt_inv_tail_inplace(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int* d_prime_of_slot);
 // digit-row forward NTT: source is the scaled-down part in limb-major layout, see kernels_crt.hip
 int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts_limbmajor, int nl, int logQ, int digit_bits, int nd, i64 npolys,
-                          u64* d_out_rows /* [npolys*nd][L][n] */, int slot0 = 0, int nslot = 0 /* 0 = all primes */);
+                          u64* d_out_rows /* [npolys*nd][L][n] */, int slot0 = 0, int nslot = 0 /* 0 = all primes */, int layout_slots = 0 /* 0 = L */);
 
 // kernels_ew.hip
 int launch_ew_op(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 count, int nslots, const int* d_prime_of_slot, int op);

@@ -1,0 +1,223 @@
+// kernels_ksaux.hip -- the key-switch dot product through two auxiliary primes.
+//
+// KeySwitchSI::ApplyKeySwitch (FHE-SI.cpp:241-260) computes, for every chain prime q_i and both key rows r,
+//     out[r] = sum_k  DoubleCRT(digit_k) * key[r][k]        (DotProduct, Util.h:79-98)
+// which costs one forward transform of every digit polynomial PER CHAIN PRIME (3 nd L row transforms per ciphertext, 93 % of
+// all transforms of a multiplication).  The digit polynomials have tiny coefficients (below 2^(8 decompSize)), so the negacyclic
+// product  V[r][i] = sum_k digit_k (*) keycoef[r][k][i]  with the key taken as its coefficient vector in [0, q_i)  is an INTEGER
+// polynomial whose coefficients are bounded by  ncol * n * 2^digit_bits * q_i  <  2^106 -- far below the product of two 60-bit
+// primes.  It is therefore computed exactly modulo the two largest chain primes a in {0, 1} only:
+//     digits:  2 transforms per digit polynomial instead of L            (launch_ntt_fwd_digits, slots 0..1, compact layout)
+//     keys:    K2[a][i][r][k] = NTT_a( iNTT_i(key[r][k][i]) mod q_a )    built once per matrix (ksaux_build)
+//     dot:     O[ct][r][i][a] = sum_k D[ct][k][a] * K2[a][i][r][k]  mod q_a                       (dot_aux_kernel)
+//     back:    iNTT_a, then V = CRT(O[..][0], O[..][1]) centred modulo q_0 q_1, then V mod q_i    (aux_crt_kernel)
+// and V mod q_i is, coefficient by coefficient, exactly what toPoly of the reference's dot product holds modulo q_i -- the rows the
+// final intVecCRT (kernels_crt.hip) takes.  Same bits, 2 (nd ncomp) + 2 L 2 row transforms instead of (nd ncomp) L + 2 L.
+#include "fhesi_internal.h"
+#include <cmath>
+
+// 128-bit value -> [0,q)
+__device__ __forceinline__ u64 aux_fold128(u128 a, const PrimeConst& pc) {
+  const u64 q = pc.q, lo = (u64)a, hi = (u64)(a >> 64);
+  const u64 h = d_shoup(hi, 1, pc.one_sh, q);
+  const u64 t = d_shoup_lazy(h, pc.r64, pc.r64_sh, q);
+  const u64 l = d_shoup_lazy(lo, 1, pc.one_sh, q);
+  u64 r = t + l;
+  if (r >= pc.two_q) r -= pc.two_q;
+  if (r >= q) r -= q;
+  return r;
+}
+
+// coefficient rows of the key [2*ncol][L][n] (values in [0, q_i)) -> K2[a][i][r][k][n] reduced modulo q_a (q_a > 2^59: one step)
+__global__ void __launch_bounds__(256) ksaux_scatter_kernel(const u64* __restrict__ coef, u64* __restrict__ k2, int ncol, int L, i64 n, u64 q0, u64 q1) {
+  const i64 row = blockIdx.y;                 // (r * ncol + k) * L + i
+  const int i = (int)(row % L);
+  const i64 rk = row / L;
+  const int k = (int)(rk % ncol), r = (int)(rk / ncol);
+  const u64* src = coef + row * n;
+  u64* d0 = k2 + ((((i64)0 * L + i) * 2 + r) * ncol + k) * n;
+  u64* d1 = k2 + ((((i64)1 * L + i) * 2 + r) * ncol + k) * n;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    const u64 c = src[j];
+    d0[j] = c >= q0 ? c - q0 : c;
+    d1[j] = c >= q1 ? c - q1 : c;
+  }
+}
+
+// O[ct][r][i][a][slice] = sum_k D[ct][k][a][slice] * K2[a][i][r][k][slice]  mod q_a.
+// One workgroup = one 64-element slice of CT ciphertexts for one auxiliary prime: their ncol x CT digit slices sit in LDS and every
+// wave walks its share of the chain primes, streaming that prime's 2 ncol key slices (L2-resident across the ciphertext tiles that
+// follow on the same XCD, see the block order in the launcher).  Digit values may be the lazy representatives the fused digit
+// transform stores (below 4 q_a + 2^32): products are accumulated as exact 128-bit integers and folded every `fold_every` columns.
+template <int CT, int NW>
+__global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict__ k2, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
+                                                          u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int fold_every, int ntiles, int nsl8) {
+  extern __shared__ __attribute__((aligned(16))) u64 dl[];        // [ncol][CT][64]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // block order: 8 consecutive slices (one per XCD), then the ciphertext tiles, then the slice groups, then the auxiliary prime
+  u32 b = blockIdx.x;
+  const u32 s_lo = b & 7; b >>= 3;
+  const u32 tile = b % (u32)ntiles; b /= (u32)ntiles;
+  const u32 s_hi = b % (u32)nsl8;
+  const int a = (int)(b / (u32)nsl8);
+  const i64 off = (i64)(s_hi * 8 + s_lo) * 64 + lane;
+  const i64 ct0 = (i64)tile * CT;
+  for (int e = w; e < ncol * CT; e += NW) {
+    const int k = e / CT, c = e % CT;
+    const i64 ct = ct0 + c;
+    dl[e * 64 + lane] = ct < count ? __builtin_nontemporal_load(&dig[((ct * ncol + k) * 2 + a) * n + off]) : 0;
+  }
+  __syncthreads();
+  const PrimeConst pc = pcs[a];
+  for (int i = w; i < L; i += NW) {
+    const u64* k0 = k2 + ((((i64)a * L + i) * 2 + 0) * ncol) * n + off;
+    const u64* k1 = k0 + (i64)ncol * n;
+    u128 acc[CT][2];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { acc[c][0] = 0; acc[c][1] = 0; }
+    int until_fold = fold_every;
+#pragma unroll 6
+    for (int k = 0; k < ncol; ++k) {
+      if (fold_every && until_fold-- == 0) {
+        until_fold = fold_every - 1;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { acc[c][0] = aux_fold128(acc[c][0], pc); acc[c][1] = aux_fold128(acc[c][1], pc); }
+      }
+      const u64 x0 = k0[(i64)k * n], x1 = k1[(i64)k * n];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const u64 d = dl[(k * CT + c) * 64 + lane];
+        acc[c][0] += (u128)x0 * d;
+        acc[c][1] += (u128)x1 * d;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      if (ct0 + c < count) {
+        out[((((ct0 + c) * 2 + 0) * L + i) * 2 + a) * n + off] = aux_fold128(acc[c][0], pc);
+        out[((((ct0 + c) * 2 + 1) * L + i) * 2 + a) * n + off] = aux_fold128(acc[c][1], pc);
+      }
+    }
+  }
+}
+
+// o: [rows][2][n] coefficient residues modulo (q_0, q_1) of an integer V with |V| < q_0 q_1 / 2;  dst[row][j] = V mod q_i, i = row % L.
+__global__ void __launch_bounds__(256) aux_crt_kernel(const u64* __restrict__ o, u64* __restrict__ dst, i64 n, int L, const PrimeConst* __restrict__ pcs,
+                                                      u64 q0, u64 q1, u64 q0inv, u64 q0inv_sh, const u64* __restrict__ a_mod /* [L]: q_0 q_1 mod q_i */,
+                                                      u64 half_hi, u64 half_lo) {
+  const i64 row = blockIdx.y;
+  const int i = (int)(row % L);
+  const PrimeConst pc = pcs[i];
+  const u64 am = a_mod[i];
+  const u64* v0p = o + (row * 2 + 0) * n;
+  const u64* v1p = o + (row * 2 + 1) * n;
+  const u128 half = ((u128)half_hi << 64) | half_lo;            // (q_0 q_1 - 1) / 2
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    const u64 v0 = v0p[j], v1 = v1p[j];
+    const u64 v0r = v0 >= q1 ? v0 - q1 : v0;                    // q_1 < q_0 < 2 q_1
+    const u64 t = d_shoup(d_submod(v1, v0r, q1), q0inv, q0inv_sh, q1);
+    const u128 V = (u128)q0 * t + v0;                           // in [0, q_0 q_1)
+    u64 r = aux_fold128(V, pc);
+    if (V > half) r = d_submod(r, am, pc.q);                    // centred value V - q_0 q_1
+    dst[row * n + j] = r;
+  }
+}
+
+static int aux_dot_ct() {
+  const char* e = getenv("FHESI_DOTAUX_CT");
+  return e ? atoi(e) : 0;
+}
+
+bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits) {
+  if (!ctx->pow2 || ctx->L < 2 || digit_bits >= 32) return false;
+  if (!((ctx->logn >= 11 && ctx->logn <= 14) || ntt_digits_suborder(ctx, digit_bits))) return false;      // single-pass digit transforms
+  const u64 q0 = ctx->q[0], q1 = ctx->q[1];
+  if (q0 <= q1 || q1 < (1ull << 59)) return false;             // the chain is descending from 2^60 (FHEContext.cpp:92-108)
+  for (int i = 2; i < ctx->L; ++i) if (ctx->q[i] >= q1) return false;
+  // |V| <= ncol * n * 2^digit_bits * q_0  must stay below q_0 q_1 / 2
+  const double lg = std::log2((double)ncol) + (double)ctx->logn + digit_bits + 60.0;
+  return lg + 2.0 < std::log2((double)q0) + std::log2((double)q1);
+}
+
+// builds k->d_aux from k->d_rows (device work only; the caller holds the context's stream)
+int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
+  const i64 n = ctx->phim;
+  const int L = ctx->L, ncol = k->ncomp * k->ndigits;
+  const bool suborder = ntt_digits_suborder(ctx, digit_bits);
+  if (!k->d_aux) {
+    HIP_TRY(hipMalloc(&k->d_aux, 2 * k->bytes));
+    HIP_TRY(hipMalloc(&k->d_aux_consts, (size_t)(L + 2) * 8));
+    std::vector<u64> h(L + 2, 0);
+    const u128 A = (u128)ctx->q[0] * ctx->q[1];
+    for (int i = 0; i < L; ++i) h[i] = (u64)(A % ctx->q[i]);
+    ((int*)&h[L])[0] = 0; ((int*)&h[L])[1] = 1;                  // prime_of_slot of the auxiliary rows
+    HIP_TRY(hipMemcpyAsync(k->d_aux_consts, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  void* tmp;
+  FHESI_TRY(ws_reserve(ctx, 0, k->bytes, &tmp));
+  HIP_TRY(hipMemcpyAsync(tmp, k->d_rows, k->bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  FHESI_TRY(launch_ntt_inv(ctx, (u64*)tmp, 2 * ncol, L, nullptr, true));
+  dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)(2 * ncol * L));
+  ksaux_scatter_kernel<<<grid, 256, 0, ctx->stream>>>((const u64*)tmp, k->d_aux, ncol, L, n, ctx->q[0], ctx->q[1]);
+  HIP_TRY(hipGetLastError());
+  const int* d_slot = (const int*)(k->d_aux_consts + L);
+  const i64 rows_per_a = (i64)L * 2 * ncol;
+  for (int a = 0; a < 2; ++a) FHESI_TRY(launch_ntt_fwd(ctx, k->d_aux + (i64)a * rows_per_a * n, rows_per_a, 1, d_slot + a, !suborder));
+  k->aux_suborder = suborder;
+  k->aux_valid = true;
+  return 0;
+}
+
+template <int CT, int NW>
+static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int ncol, i64 count, u64* d_out, int fold_every) {
+  const i64 n = ctx->phim;
+  const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(n / 64 / 8);
+  const size_t shmem = (size_t)ncol * CT * 64 * 8;
+  static unsigned long long attr_done = 0;
+  if (!(attr_done >> ctx->device & 1)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)dot_aux_kernel<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done |= 1ull << ctx->device;
+  }
+  const i64 blocks = (i64)8 * ntiles * nsl8 * 2;
+  if (blocks > 0x7fffffff) FHESI_FAIL("dot_aux: too many ciphertexts per call");
+  dot_aux_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>(k->d_aux, d_dig, ncol, n, ctx->L, count, d_out, ctx->d_pc, fold_every, ntiles, nsl8);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// d_dig: [count*ncol][2][n] (compact, auxiliary primes 0 and 1); d_out: [count][2][L][2][n]
+int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int ncol, i64 count, u64* d_out) {
+  if (!count) return 0;
+  if (ctx->phim % 512) FHESI_FAIL("dot_aux: phi(m) must be a multiple of 512");
+  int fold_every = 0;
+  for (int a = 0; a < 2; ++a) {
+    const u128 term = (u128)(4 * ctx->pc[a].q_tile + ((u64)1 << 32)) * ctx->pc[a].q;
+    const u128 F = (~(u128)0 - ctx->pc[a].q) / term;
+    if (F < 2) FHESI_FAIL("dot_aux: residues of prime %d overflow the 128-bit accumulator", a);
+    if (F < (u128)ncol && (fold_every == 0 || (int)F < fold_every)) fold_every = (int)F;
+  }
+  ProfScope prof(ctx, PROF_DOT, (double)count);
+  int ct = aux_dot_ct();
+  if (!ct) ct = ((size_t)ncol * 4 * 512 <= 150 * 1024) ? 4 : (((size_t)ncol * 2 * 512 <= 150 * 1024) ? 2 : 1);
+  if ((size_t)ncol * ct * 512 > 160 * 1024) FHESI_FAIL("dot_aux: %d columns do not fit the LDS tile", ncol);
+  switch (ct) {
+    case 4: return launch_dot_aux_t<4, 6>(ctx, k, d_dig, ncol, count, d_out, fold_every);
+    case 2: return launch_dot_aux_t<2, 6>(ctx, k, d_dig, ncol, count, d_out, fold_every);
+    default: return launch_dot_aux_t<1, 6>(ctx, k, d_dig, ncol, count, d_out, fold_every);
+  }
+}
+
+// d_o: [nrows][2][n] after the inverse transforms; d_dst: [nrows][n], row r belongs to chain prime r % L
+int launch_aux_crt(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_o, u64* d_dst, i64 nrows) {
+  if (!nrows) return 0;
+  const i64 n = ctx->phim;
+  const u64 q0 = ctx->q[0], q1 = ctx->q[1];
+  const u64 inv = hm::invmod(q0 % q1, q1);
+  const u128 half = ((u128)q0 * q1 - 1) / 2;
+  ProfScope prof(ctx, PROF_EW, (double)nrows);
+  dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)nrows);
+  aux_crt_kernel<<<grid, 256, 0, ctx->stream>>>(d_o, d_dst, n, ctx->L, ctx->d_pc, q0, q1, inv, hm::shoup(inv, q1), k->d_aux_consts, (u64)(half >> 64), (u64)half);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

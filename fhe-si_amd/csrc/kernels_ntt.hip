@@ -435,26 +435,31 @@ int launch_ntt_inv(fhesi_ctx* ctx, u64* d_rows, i64 count, int nslots, const int
 }
 
 // ByteDecomp fused into the forward transform: digit rows [npolys*nd][L][n] straight from the scaled-down parts.
-int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_out_rows, int slot0, int nslot) {
+// layout_slots: slots per DoubleCRT in d_out_rows (0 = L); a compact layout (layout_slots = nslot, slot0 = 0) holds only the computed rows.
+int launch_ntt_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_out_rows, int slot0, int nslot, int layout_slots) {
   if (nslot <= 0) { slot0 = 0; nslot = ctx->L; }
+  if (layout_slots <= 0) layout_slots = ctx->L;
+  if (slot0 + nslot > layout_slots) FHESI_FAIL("digit transform: slots %d..%d outside a layout of %d", slot0, slot0 + nslot - 1, layout_slots);
   if (!npolys) return 0;
   const bool two_pass = ntt_tile2_supported(ctx->logn);
   if (!(ntt_tile_supported(ctx->logn) || two_pass) || digit_bits >= 32) {      // generic sizes: separate digit kernel, then the row transform
+    if (layout_slots != ctx->L) FHESI_FAIL("digit transform: compact layouts need a tile size");
     FHESI_TRY(launch_digits(ctx, d_parts, nl, logQ, digit_bits, nd, npolys, d_out_rows));
     return launch_ntt_fwd(ctx, d_out_rows, npolys * nd, ctx->L, nullptr, true);
   }
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * nslot));
   const DigitSrc ds{d_parts, nl, digit_bits, nd, slot0};
   if (two_pass) {      // sub-transforms straight from the parts into the rows
-    FHESI_TRY(launch_tile_big_digits(ctx, ds, npolys * nd, d_out_rows, nslot));
+    if (layout_slots != ctx->L && !ntt_digits_suborder(ctx, digit_bits)) FHESI_FAIL("digit transform: compact layouts need a single-pass size");
+    FHESI_TRY(launch_tile_big_digits(ctx, ds, npolys * nd, d_out_rows, nslot, layout_slots));
     if (ntt_digits_suborder(ctx, digit_bits)) return 0;                     // n = 2^15: head stage fused into the loader, no tail (sub-block order)
     return launch_fwd_tail(ctx, d_out_rows, d_out_rows, npolys * nd, ctx->L, slot0, nslot, nullptr);     // tail in place
   }
   switch (ctx->logn) {
-    case 11: FHESI_TRY(launch_tile_digits<11>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
-    case 12: FHESI_TRY(launch_tile_digits<12>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
-    case 13: FHESI_TRY(launch_tile_digits<13>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
-    default: FHESI_TRY(launch_tile_digits<14>(ctx, ds, npolys * nd, d_out_rows, nslot)); break;
+    case 11: FHESI_TRY(launch_tile_digits<11>(ctx, ds, npolys * nd, d_out_rows, nslot, layout_slots)); break;
+    case 12: FHESI_TRY(launch_tile_digits<12>(ctx, ds, npolys * nd, d_out_rows, nslot, layout_slots)); break;
+    case 13: FHESI_TRY(launch_tile_digits<13>(ctx, ds, npolys * nd, d_out_rows, nslot, layout_slots)); break;
+    default: FHESI_TRY(launch_tile_digits<14>(ctx, ds, npolys * nd, d_out_rows, nslot, layout_slots)); break;
   }
   return 0;
 }
