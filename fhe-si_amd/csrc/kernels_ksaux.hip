@@ -44,15 +44,23 @@ __global__ void __launch_bounds__(256) ksaux_scatter_kernel(const u64* __restric
   }
 }
 
+// Split representation of a residue v < 2^60 for the dot product: low 30 bits in the low dword, high 30 bits in the high dword.
+// The four partial products of two such values are below 2^60 each, so they accumulate in plain 64-bit v_mad_u64_u32 chains --
+// no carries, no 128-bit additions -- for 8 columns (the two middle products share one accumulator) before they are gathered.
+__device__ __forceinline__ u64 pack30(u64 v) { return (v & 0x3fffffffull) | ((v >> 30) << 32); }
+__global__ void __launch_bounds__(256) ksaux_pack_kernel(u64* __restrict__ rows, i64 nwords) {
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < nwords; j += (i64)gridDim.x * blockDim.x) rows[j] = pack30(rows[j]);
+}
+
 // O[ct][r][i][a][slice] = sum_k D[ct][k][a][slice] * K2[a][i][r][k][slice]  mod q_a.
-// One workgroup = one 64-element slice of CT ciphertexts for one auxiliary prime: their ncol x CT digit slices sit in LDS and every
-// wave walks its share of the chain primes, streaming that prime's 2 ncol key slices (L2-resident across the ciphertext tiles that
-// follow on the same XCD, see the block order in the launcher).  Digit values may be the lazy representatives the fused digit
-// transform stores (below 4 q_a + 2^32): products are accumulated as exact 128-bit integers and folded every `fold_every` columns.
+// One workgroup = one 64-element slice of CT ciphertexts for one auxiliary prime: their ncol x CT digit slices sit in LDS (reduced
+// modulo q_a -- the fused digit transform stores lazy representatives -- and split) and every wave walks its share of the chain
+// primes, streaming that prime's 2 ncol key slices (stored split; L2-resident across the ciphertext tiles that follow on the same
+// XCD, see the block order in the launcher), 16 key loads in flight per wave.
 template <int CT, int NW>
 __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict__ k2, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
-                                                          u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int fold_every, int ntiles, int nsl8) {
-  extern __shared__ __attribute__((aligned(16))) u64 dl[];        // [ncol][CT][64]
+                                                          u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int ntiles, int nsl8) {
+  extern __shared__ __attribute__((aligned(16))) u64 dl[];        // [ncol][64][CT]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // block order: 8 consecutive slices (one per XCD), then the ciphertext tiles, then the slice groups, then the auxiliary prime
   u32 b = blockIdx.x;
@@ -60,42 +68,63 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
   const u32 tile = b % (u32)ntiles; b /= (u32)ntiles;
   const u32 s_hi = b % (u32)nsl8;
   const int a = (int)(b / (u32)nsl8);
-  const i64 off = (i64)(s_hi * 8 + s_lo) * 64 + lane;
+  const i64 soff = (i64)(s_hi * 8 + s_lo) * 64;                   // uniform: first element of the slice
   const i64 ct0 = (i64)tile * CT;
+  const PrimeConst pc = pcs[a];
   for (int e = w; e < ncol * CT; e += NW) {
     const int k = e / CT, c = e % CT;
     const i64 ct = ct0 + c;
-    dl[e * 64 + lane] = ct < count ? __builtin_nontemporal_load(&dig[((ct * ncol + k) * 2 + a) * n + off]) : 0;
+    u64 v = 0;
+    if (ct < count) v = d_shoup(__builtin_nontemporal_load(&(dig + ((ct * ncol + k) * 2 + a) * n + soff)[lane]), 1, pc.one_sh, pc.q);
+    dl[(k * 64 + lane) * CT + c] = pack30(v);
   }
   __syncthreads();
-  const PrimeConst pc = pcs[a];
   for (int i = w; i < L; i += NW) {
-    const u64* k0 = k2 + ((((i64)a * L + i) * 2 + 0) * ncol) * n + off;
+    const u64* k0 = k2 + ((((i64)a * L + i) * 2 + 0) * ncol) * n + soff;      // uniform row pointers; the lane offset stays a 32-bit index
     const u64* k1 = k0 + (i64)ncol * n;
-    u128 acc[CT][2];
+    u128 tot[CT][2];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) { acc[c][0] = 0; acc[c][1] = 0; }
-    int until_fold = fold_every;
-#pragma unroll 6
-    for (int k = 0; k < ncol; ++k) {
-      if (fold_every && until_fold-- == 0) {
-        until_fold = fold_every - 1;
+    for (int c = 0; c < CT; ++c) { tot[c][0] = 0; tot[c][1] = 0; }
+    for (int kb = 0; kb < ncol; kb += 8) {
+      u64 ll[CT][2], mid[CT][2], hh[CT][2];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { acc[c][0] = aux_fold128(acc[c][0], pc); acc[c][1] = aux_fold128(acc[c][1], pc); }
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { ll[c][r] = 0; mid[c][r] = 0; hh[c][r] = 0; }
+      auto column = [&](u64 x0, u64 x1, int k) {
+        const u32 xa[2][2] = {{(u32)x0, (u32)(x0 >> 32)}, {(u32)x1, (u32)(x1 >> 32)}};
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const u64 d = dl[(k * 64 + lane) * CT + c];
+          const u32 d0 = (u32)d, d1 = (u32)(d >> 32);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            ll[c][r] += (u64)xa[r][0] * d0;
+            mid[c][r] += (u64)xa[r][0] * d1;
+            mid[c][r] += (u64)xa[r][1] * d0;
+            hh[c][r] += (u64)xa[r][1] * d1;
+          }
+        }
+      };
+      if (kb + 8 <= ncol) {
+        u64 x0[8], x1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x0[u] = (k0 + (i64)(kb + u) * n)[lane]; x1[u] = (k1 + (i64)(kb + u) * n)[lane]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) column(x0[u], x1[u], kb + u);
+      } else {
+        for (int k = kb; k < ncol; ++k) column((k0 + (i64)k * n)[lane], (k1 + (i64)k * n)[lane], k);
       }
-      const u64 x0 = k0[(i64)k * n], x1 = k1[(i64)k * n];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        const u64 d = dl[(k * CT + c) * 64 + lane];
-        acc[c][0] += (u128)x0 * d;
-        acc[c][1] += (u128)x1 * d;
-      }
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) tot[c][r] += (u128)ll[c][r] + ((u128)mid[c][r] << 30) + ((u128)hh[c][r] << 60);
     }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       if (ct0 + c < count) {
-        out[((((ct0 + c) * 2 + 0) * L + i) * 2 + a) * n + off] = aux_fold128(acc[c][0], pc);
-        out[((((ct0 + c) * 2 + 1) * L + i) * 2 + a) * n + off] = aux_fold128(acc[c][1], pc);
+        (out + ((((ct0 + c) * 2 + 0) * L + i) * 2 + a) * n + soff)[lane] = aux_fold128(tot[c][0], pc);
+        (out + ((((ct0 + c) * 2 + 1) * L + i) * 2 + a) * n + soff)[lane] = aux_fold128(tot[c][1], pc);
       }
     }
   }
@@ -164,13 +193,15 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
   const int* d_slot = (const int*)(k->d_aux_consts + L);
   const i64 rows_per_a = (i64)L * 2 * ncol;
   for (int a = 0; a < 2; ++a) FHESI_TRY(launch_ntt_fwd(ctx, k->d_aux + (i64)a * rows_per_a * n, rows_per_a, 1, d_slot + a, !suborder));
+  ksaux_pack_kernel<<<4096, 256, 0, ctx->stream>>>(k->d_aux, 2 * rows_per_a * n);
+  HIP_TRY(hipGetLastError());
   k->aux_suborder = suborder;
   k->aux_valid = true;
   return 0;
 }
 
 template <int CT, int NW>
-static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int ncol, i64 count, u64* d_out, int fold_every) {
+static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int ncol, i64 count, u64* d_out) {
   const i64 n = ctx->phim;
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(n / 64 / 8);
   const size_t shmem = (size_t)ncol * CT * 64 * 8;
@@ -181,7 +212,7 @@ static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig
   }
   const i64 blocks = (i64)8 * ntiles * nsl8 * 2;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot_aux: too many ciphertexts per call");
-  dot_aux_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>(k->d_aux, d_dig, ncol, n, ctx->L, count, d_out, ctx->d_pc, fold_every, ntiles, nsl8);
+  dot_aux_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>(k->d_aux, d_dig, ncol, n, ctx->L, count, d_out, ctx->d_pc, ntiles, nsl8);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -190,21 +221,16 @@ static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig
 int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int ncol, i64 count, u64* d_out) {
   if (!count) return 0;
   if (ctx->phim % 512) FHESI_FAIL("dot_aux: phi(m) must be a multiple of 512");
-  int fold_every = 0;
-  for (int a = 0; a < 2; ++a) {
-    const u128 term = (u128)(4 * ctx->pc[a].q_tile + ((u64)1 << 32)) * ctx->pc[a].q;
-    const u128 F = (~(u128)0 - ctx->pc[a].q) / term;
-    if (F < 2) FHESI_FAIL("dot_aux: residues of prime %d overflow the 128-bit accumulator", a);
-    if (F < (u128)ncol && (fold_every == 0 || (int)F < fold_every)) fold_every = (int)F;
-  }
+  // every product of two residues below 2^60 is below 2^120: up to 255 columns fit the 128-bit total
+  if (ncol > 255) FHESI_FAIL("dot_aux: %d columns overflow the 128-bit sum", ncol);
   ProfScope prof(ctx, PROF_DOT, (double)count);
   int ct = aux_dot_ct();
   if (!ct) ct = ((size_t)ncol * 4 * 512 <= 150 * 1024) ? 4 : (((size_t)ncol * 2 * 512 <= 150 * 1024) ? 2 : 1);
   if ((size_t)ncol * ct * 512 > 160 * 1024) FHESI_FAIL("dot_aux: %d columns do not fit the LDS tile", ncol);
   switch (ct) {
-    case 4: return launch_dot_aux_t<4, 6>(ctx, k, d_dig, ncol, count, d_out, fold_every);
-    case 2: return launch_dot_aux_t<2, 6>(ctx, k, d_dig, ncol, count, d_out, fold_every);
-    default: return launch_dot_aux_t<1, 6>(ctx, k, d_dig, ncol, count, d_out, fold_every);
+    case 4: return launch_dot_aux_t<4, 6>(ctx, k, d_dig, ncol, count, d_out);
+    case 2: return launch_dot_aux_t<2, 6>(ctx, k, d_dig, ncol, count, d_out);
+    default: return launch_dot_aux_t<1, 6>(ctx, k, d_dig, ncol, count, d_out);
   }
 }
 
