@@ -152,11 +152,6 @@ __global__ void __launch_bounds__(256) aux_crt_kernel(const u64* __restrict__ o,
   }
 }
 
-static int aux_dot_ct() {
-  const char* e = getenv("FHESI_DOTAUX_CT");
-  return e ? atoi(e) : 0;
-}
-
 bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits) {
   if (!ctx->pow2 || ctx->L < 2 || digit_bits >= 32) return false;
   if (!((ctx->logn >= 11 && ctx->logn <= 14) || ntt_digits_suborder(ctx, digit_bits))) return false;      // single-pass digit transforms
@@ -224,14 +219,11 @@ int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int nco
   // every product of two residues below 2^60 is below 2^120: up to 255 columns fit the 128-bit total
   if (ncol > 255) FHESI_FAIL("dot_aux: %d columns overflow the 128-bit sum", ncol);
   ProfScope prof(ctx, PROF_DOT, (double)count);
-  int ct = aux_dot_ct();
-  if (!ct) ct = ((size_t)ncol * 4 * 512 <= 150 * 1024) ? 4 : (((size_t)ncol * 2 * 512 <= 150 * 1024) ? 2 : 1);
-  if ((size_t)ncol * ct * 512 > 160 * 1024) FHESI_FAIL("dot_aux: %d columns do not fit the LDS tile", ncol);
-  switch (ct) {
-    case 4: return launch_dot_aux_t<4, 6>(ctx, k, d_dig, ncol, count, d_out);
-    case 2: return launch_dot_aux_t<2, 6>(ctx, k, d_dig, ncol, count, d_out);
-    default: return launch_dot_aux_t<1, 6>(ctx, k, d_dig, ncol, count, d_out);
-  }
+  // 2 ciphertexts per tile and 16 waves per workgroup measured best at both rings (1 ciphertext: twice the key traffic from L2;
+  // 4: one workgroup per CU and 150+ VGPRs; 6 waves: 2.25 instead of 2.12 ms at the metric ring, 5.4 instead of 3.7 at the stress ring)
+  if ((size_t)ncol * 2 * 512 <= 150 * 1024) return launch_dot_aux_t<2, 16>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 512 > 160 * 1024) FHESI_FAIL("dot_aux: %d columns do not fit the LDS tile", ncol);
+  return launch_dot_aux_t<1, 16>(ctx, k, d_dig, ncol, count, d_out);
 }
 
 // d_o: [nrows][2][n] after the inverse transforms; d_dst: [nrows][n], row r belongs to chain prime r % L
