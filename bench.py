@@ -467,11 +467,39 @@ def main():
         kname = "ntt_fwd_tile<14, false, 1, false>" if args.ntt_rows else "ntt_fwd_tile<14, true, 1, true>"
     else:
         kname = "ntt_fwd_tile<14, %s, 0, false>" % ("false" if args.ntt_rows else "true")
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
-                "rows_per_launch": round(rows / launches, 1) if launches else None,
-                "row_ntts_per_s": round(rows / (ms * 1e-3), 1) if ms > 0 else None}
+    roofline_ntt = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
+                    "rows_per_launch": round(rows / launches, 1) if launches else None,
+                    "row_ntts_per_s": round(rows / (ms * 1e-3), 1) if ms > 0 else None}
+    # The dominant kernel of the pipeline is the key-switch dot product through the two auxiliary primes (kernels_ksaux.hip):
+    # algorithmic bytes per launch of c ciphertexts = (digit rows c*ncol*2 + key rows 2*L*2*ncol + output rows c*2*L*2) * n * 8
+    # (DESIGN.md section 6); it is bound by the VALU (64-bit multiply-adds) and the L2, not by HBM -- the contract's roof is HBM.
+    aux = "FHESI_KS_DIRECT" not in os.environ      # the library's A/B switch back to the per-prime dot product
+    dl, dunits, dms = prof["dot"]
+    if aux:
+        dbytes = (dunits * (ncol * 2 + 2 * L * 2) + dl * (2 * L * 2 * ncol)) * n * 8
+        dname = "dot_aux_kernel<2, 16>"
+    else:
+        dbytes = (dunits * (ncol + 2) * L + dl * (2 * ncol * L)) * n * 8
+        dname = "dot_accum_kernel<2, %s>" % ("true" if ctx.phim > (1 << 14) else "false")
+    dach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+    dtraffic = None
+    dpmc_path = os.path.join(ROOT, "profiles", "pmc_dot_aux.json")
+    if aux and args.workload == "metric" and os.path.exists(dpmc_path):
+        try:
+            dp = json.load(open(dpmc_path))
+            if dl and dp.get("ciphertexts_per_launch") == round(dunits / dl):
+                dtraffic = dp.get("hbm_bytes_per_launch")
+        except Exception:
+            dtraffic = None
+    roofline_dot = {"bound": "hbm", "kernel": dname, "achieved": round(dach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": dtraffic, "launches": dl,
+                    "avg_launch_ms": round(dms / dl, 4) if dl else None, "ciphertexts_per_launch": round(dunits / dl, 1) if dl else None,
+                    "note": "VALU- and L2-bound integer multiply-accumulate (keys are re-read from L2, 89 % hit rate); see roofline_ntt for the "
+                            "DoubleCRT transform the metric's GB/s figure refers to"}
+    # `roofline` is the kernel with the largest share of the step
+    roofline = roofline_dot if dms >= ms else roofline_ntt
 
     if rank == 0:
         total_mults = B * args.steps * world
@@ -489,9 +517,10 @@ def main():
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
                        if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
                        "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B, "lanes": args.lanes,
-                       "fwd_row_ntts_per_mult": (4 + ncol) * L, "inv_row_ntts_per_mult": 5 * L,
+                       "fwd_row_ntts_per_mult": (4 * L + 2 * ncol) if aux else (4 + ncol) * L,
+                       "inv_row_ntts_per_mult": (3 * L + 4 * L) if aux else 5 * L,
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
+            "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_dot": roofline_dot, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
         }
         print(json.dumps(line), flush=True)
     if dist:
