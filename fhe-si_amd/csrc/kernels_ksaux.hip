@@ -8,7 +8,7 @@
 // polynomial whose coefficients are bounded by  ncol * n * 2^digit_bits * q_i  <  2^106 -- far below the product of two 60-bit
 // primes.  It is therefore computed exactly modulo the two largest chain primes a in {0, 1} only:
 //     digits:  2 transforms per digit polynomial instead of L            (launch_ntt_fwd_digits, slots 0..1, compact layout)
-//     keys:    K2[a][i][r][k] = NTT_a( iNTT_i(key[r][k][i]) mod q_a )    built once per matrix (ksaux_build)
+//     keys:    K2[a][i][r][k] = NTT_a( iNTT_i(key[r][k][i]) mod q_a )    built once per matrix (ksaux_build), stored tiled by 64-element slices
 //     dot:     O[ct][r][i][a] = sum_k D[ct][k][a] * K2[a][i][r][k]  mod q_a                       (dot_aux_kernel)
 //     back:    iNTT_a, then V = CRT(O[..][0], O[..][1]) centred modulo q_0 q_1, then V mod q_i    (aux_crt_kernel)
 // and V mod q_i is, coefficient by coefficient, exactly what toPoly of the reference's dot product holds modulo q_i -- the rows the
@@ -48,8 +48,18 @@ __global__ void __launch_bounds__(256) ksaux_scatter_kernel(const u64* __restric
 // The four partial products of two such values are below 2^60 each, so they accumulate in plain 64-bit v_mad_u64_u32 chains --
 // no carries, no 128-bit additions -- for 8 columns (the two middle products share one accumulator) before they are gathered.
 __device__ __forceinline__ u64 pack30(u64 v) { return (v & 0x3fffffffull) | ((v >> 30) << 32); }
-__global__ void __launch_bounds__(256) ksaux_pack_kernel(u64* __restrict__ rows, i64 nwords) {
-  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < nwords; j += (i64)gridDim.x * blockDim.x) rows[j] = pack30(rows[j]);
+// rows of one auxiliary prime, [i][r][k][n] after the transforms  ->  tiled and split: [i][slice][r][k][64], so that the 2 ncol key
+// slices a wave streams for one (chain prime, slice) are one contiguous block and consecutive columns are 512 bytes apart
+// (immediate offsets in the loads instead of 64-bit address arithmetic)
+__global__ void __launch_bounds__(256) ksaux_retile_kernel(const u64* __restrict__ src, u64* __restrict__ dst, int ncol, i64 n) {
+  const i64 row = blockIdx.y;                 // (i * 2 + r) * ncol + k
+  const int k = (int)(row % ncol);
+  const i64 ir = row / ncol;
+  const int r = (int)(ir & 1);
+  const i64 i = ir >> 1;
+  const i64 nsl = n >> 6;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x)
+    dst[((((i * nsl + (j >> 6)) * 2 + r) * ncol + k) << 6) + (j & 63)] = pack30(src[row * n + j]);
 }
 
 // O[ct][r][i][a][slice] = sum_k D[ct][k][a][slice] * K2[a][i][r][k][slice]  mod q_a.
@@ -61,7 +71,8 @@ template <int CT, int NW>
 __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict__ k2, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
                                                           u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int ntiles, int nsl8) {
   extern __shared__ __attribute__((aligned(16))) u64 dl[];        // [ncol][64][CT]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const u32 lane = threadIdx.x & 63;       // unsigned: the lane offset of a load is a zero-extended 32-bit index next to a scalar base
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index as a scalar: the key row pointers stay in SGPRs
   // block order: 8 consecutive slices (one per XCD), then the ciphertext tiles, then the slice groups, then the auxiliary prime
   u32 b = blockIdx.x;
   const u32 s_lo = b & 7; b >>= 3;
@@ -80,11 +91,19 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
   }
   __syncthreads();
   for (int i = w; i < L; i += NW) {
-    const u64* k0 = k2 + ((((i64)a * L + i) * 2 + 0) * ncol) * n + soff;      // uniform row pointers; the lane offset stays a 32-bit index
-    const u64* k1 = k0 + (i64)ncol * n;
-    u128 tot[CT][2];
+    // this wave's two key streams (r = 0, 1): contiguous [r][k][64] block of the tiled table
+    const u64* k0 = k2 + (((((i64)a * L + i) * (n >> 6) + (soff >> 6)) * 2) * ncol << 6) + lane;
+    const u64* k1 = k0 + ((i64)ncol << 6);
+    // second level: the three partial-product sums of every 8-column group are added into 96-bit totals (64-bit low word + a
+    // carry counter) and combined once per chain prime -- no 128-bit shifts and additions inside the column loop
+    u64 tl[CT][2][3];
+    u32 th[CT][2][3];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) { tot[c][0] = 0; tot[c][1] = 0; }
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { tl[c][r][p] = 0; th[c][r][p] = 0; }
     for (int kb = 0; kb < ncol; kb += 8) {
       u64 ll[CT][2], mid[CT][2], hh[CT][2];
 #pragma unroll
@@ -108,18 +127,30 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
       };
       if (kb + 8 <= ncol) {
         u64 x0[8], x1[8];
+        const u64* p0 = k0 + (kb << 6);
+        const u64* p1 = k1 + (kb << 6);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { x0[u] = (k0 + (i64)(kb + u) * n)[lane]; x1[u] = (k1 + (i64)(kb + u) * n)[lane]; }
+        for (int u = 0; u < 8; ++u) { x0[u] = p0[u << 6]; x1[u] = p1[u << 6]; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) column(x0[u], x1[u], kb + u);
       } else {
-        for (int k = kb; k < ncol; ++k) column((k0 + (i64)k * n)[lane], (k1 + (i64)k * n)[lane], k);
+        for (int k = kb; k < ncol; ++k) column(k0[k << 6], k1[k << 6], k);
       }
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) tot[c][r] += (u128)ll[c][r] + ((u128)mid[c][r] << 30) + ((u128)hh[c][r] << 60);
+        for (int r = 0; r < 2; ++r) {
+          const u64 part[3] = {ll[c][r], mid[c][r], hh[c][r]};
+#pragma unroll
+          for (int p = 0; p < 3; ++p) { const u64 t = tl[c][r][p] + part[p]; th[c][r][p] += t < part[p] ? 1u : 0u; tl[c][r][p] = t; }
+        }
     }
+    u128 tot[CT][2];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        tot[c][r] = (((u128)th[c][r][0] << 64) | tl[c][r][0]) + ((((u128)th[c][r][1] << 64) | tl[c][r][1]) << 30) + ((((u128)th[c][r][2] << 64) | tl[c][r][2]) << 60);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       if (ct0 + c < count) {
@@ -188,8 +219,13 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
   const int* d_slot = (const int*)(k->d_aux_consts + L);
   const i64 rows_per_a = (i64)L * 2 * ncol;
   for (int a = 0; a < 2; ++a) FHESI_TRY(launch_ntt_fwd(ctx, k->d_aux + (i64)a * rows_per_a * n, rows_per_a, 1, d_slot + a, !suborder));
-  ksaux_pack_kernel<<<4096, 256, 0, ctx->stream>>>(k->d_aux, 2 * rows_per_a * n);
-  HIP_TRY(hipGetLastError());
+  for (int a = 0; a < 2; ++a) {               // tmp (the matrix's own size) takes one auxiliary prime's rows at a time
+    u64* half = k->d_aux + (i64)a * rows_per_a * n;
+    HIP_TRY(hipMemcpyAsync(tmp, half, (size_t)rows_per_a * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    dim3 g2((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)rows_per_a);
+    ksaux_retile_kernel<<<g2, 256, 0, ctx->stream>>>((const u64*)tmp, half, ncol, n);
+    HIP_TRY(hipGetLastError());
+  }
   k->aux_suborder = suborder;
   k->aux_valid = true;
   return 0;
