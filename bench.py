@@ -479,7 +479,7 @@ def main():
     dl, dunits, dms = prof["dot"]
     if aux:
         dbytes = (dunits * (ncol * 2 + 2 * L * 2) + dl * (2 * L * 2 * ncol)) * n * 8
-        dname = "dot_aux_kernel<2, 16>"
+        dname = "dot_aux_kernel<4, 16, 1>" if ncol * 4 * 512 <= 150 * 1024 else "dot_aux_kernel<2, 16, 2>"
     else:
         dbytes = (dunits * (ncol + 2) * L + dl * (2 * ncol * L)) * n * 8
         dname = "dot_accum_kernel<2, %s>" % ("true" if ctx.phim > (1 << 14) else "false")

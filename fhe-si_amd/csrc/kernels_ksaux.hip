@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) ksaux_retile_kernel(const u64* __restrict
 // modulo q_a -- the fused digit transform stores lazy representatives -- and split) and every wave walks its share of the chain
 // primes, streaming that prime's 2 ncol key slices (stored split; L2-resident across the ciphertext tiles that follow on the same
 // XCD, see the block order in the launcher), 16 key loads in flight per wave.
-template <int CT, int NW>
+template <int CT, int NW, int R>
 __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict__ k2, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
                                                           u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int ntiles, int nsl8) {
   extern __shared__ __attribute__((aligned(16))) u64 dl[];        // [ncol][64][CT]
@@ -90,26 +90,29 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
     dl[(k * 64 + lane) * CT + c] = pack30(v);
   }
   __syncthreads();
-  for (int i = w; i < L; i += NW) {
-    // this wave's two key streams (r = 0, 1): contiguous [r][k][64] block of the tiled table
-    const u64* k0 = k2 + (((((i64)a * L + i) * (n >> 6) + (soff >> 6)) * 2) * ncol << 6) + lane;
+  // R = 2: a wave takes both key rows of a chain prime for its CT ciphertexts; R = 1: one key row, so that a key load feeds CT
+  // multiply-adds with the same number of accumulators (half the L2 traffic per multiply-add when CT is doubled)
+  for (int pr = w; pr < L * (2 / R); pr += NW) {
+    const int i = R == 2 ? pr : pr >> 1, r0 = R == 2 ? 0 : pr & 1;
+    // this wave's key streams: contiguous [r][k][64] block of the tiled table
+    const u64* k0 = k2 + ((((((i64)a * L + i) * (n >> 6) + (soff >> 6)) * 2 + r0) * ncol) << 6) + lane;
     const u64* k1 = k0 + ((i64)ncol << 6);
     // second level: the three partial-product sums of every 8-column group are added into 96-bit totals (64-bit low word + a
     // carry counter) and combined once per chain prime -- no 128-bit shifts and additions inside the column loop
-    u64 tl[CT][2][3];
-    u32 th[CT][2][3];
+    u64 tl[CT][R][3];
+    u32 th[CT][R][3];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int p = 0; p < 3; ++p) { tl[c][r][p] = 0; th[c][r][p] = 0; }
     for (int kb = 0; kb < ncol; kb += 8) {
-      u64 ll[CT][2], mid[CT][2], hh[CT][2];
+      u64 ll[CT][R], mid[CT][R], hh[CT][R];
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) { ll[c][r] = 0; mid[c][r] = 0; hh[c][r] = 0; }
+        for (int r = 0; r < R; ++r) { ll[c][r] = 0; mid[c][r] = 0; hh[c][r] = 0; }
       auto column = [&](u64 x0, u64 x1, int k) {
         const u32 xa[2][2] = {{(u32)x0, (u32)(x0 >> 32)}, {(u32)x1, (u32)(x1 >> 32)}};
 #pragma unroll
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
           const u64 d = dl[(k * 64 + lane) * CT + c];
           const u32 d0 = (u32)d, d1 = (u32)(d >> 32);
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
+          for (int r = 0; r < R; ++r) {
             ll[c][r] += (u64)xa[r][0] * d0;
             mid[c][r] += (u64)xa[r][0] * d1;
             mid[c][r] += (u64)xa[r][1] * d0;
@@ -130,32 +133,32 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
         const u64* p0 = k0 + (kb << 6);
         const u64* p1 = k1 + (kb << 6);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { x0[u] = p0[u << 6]; x1[u] = p1[u << 6]; }
+        for (int u = 0; u < 8; ++u) { x0[u] = p0[u << 6]; x1[u] = R == 2 ? p1[u << 6] : 0; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) column(x0[u], x1[u], kb + u);
       } else {
-        for (int k = kb; k < ncol; ++k) column(k0[k << 6], k1[k << 6], k);
+        for (int k = kb; k < ncol; ++k) column(k0[k << 6], R == 2 ? k1[k << 6] : 0, k);
       }
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
           const u64 part[3] = {ll[c][r], mid[c][r], hh[c][r]};
 #pragma unroll
           for (int p = 0; p < 3; ++p) { const u64 t = tl[c][r][p] + part[p]; th[c][r][p] += t < part[p] ? 1u : 0u; tl[c][r][p] = t; }
         }
     }
-    u128 tot[CT][2];
+    u128 tot[CT][R];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < R; ++r)
         tot[c][r] = (((u128)th[c][r][0] << 64) | tl[c][r][0]) + ((((u128)th[c][r][1] << 64) | tl[c][r][1]) << 30) + ((((u128)th[c][r][2] << 64) | tl[c][r][2]) << 60);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       if (ct0 + c < count) {
-        (out + ((((ct0 + c) * 2 + 0) * L + i) * 2 + a) * n + soff)[lane] = aux_fold128(tot[c][0], pc);
-        (out + ((((ct0 + c) * 2 + 1) * L + i) * 2 + a) * n + soff)[lane] = aux_fold128(tot[c][1], pc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) (out + ((((ct0 + c) * 2 + r0 + r) * L + i) * 2 + a) * n + soff)[lane] = aux_fold128(tot[c][r], pc);
       }
     }
   }
@@ -231,19 +234,19 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
   return 0;
 }
 
-template <int CT, int NW>
+template <int CT, int NW, int R>
 static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int ncol, i64 count, u64* d_out) {
   const i64 n = ctx->phim;
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(n / 64 / 8);
   const size_t shmem = (size_t)ncol * CT * 64 * 8;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot_aux_kernel<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot_aux_kernel<CT, NW, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done |= 1ull << ctx->device;
   }
   const i64 blocks = (i64)8 * ntiles * nsl8 * 2;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot_aux: too many ciphertexts per call");
-  dot_aux_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>(k->d_aux, d_dig, ncol, n, ctx->L, count, d_out, ctx->d_pc, ntiles, nsl8);
+  dot_aux_kernel<CT, NW, R><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>(k->d_aux, d_dig, ncol, n, ctx->L, count, d_out, ctx->d_pc, ntiles, nsl8);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -255,11 +258,12 @@ int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int nco
   // every product of two residues below 2^60 is below 2^120: up to 255 columns fit the 128-bit total
   if (ncol > 255) FHESI_FAIL("dot_aux: %d columns overflow the 128-bit sum", ncol);
   ProfScope prof(ctx, PROF_DOT, (double)count);
-  // 2 ciphertexts per tile and 16 waves per workgroup measured best at both rings (1 ciphertext: twice the key traffic from L2;
-  // 4: one workgroup per CU and 150+ VGPRs; 6 waves: 2.25 instead of 2.12 ms at the metric ring, 5.4 instead of 3.7 at the stress ring)
-  if ((size_t)ncol * 2 * 512 <= 150 * 1024) return launch_dot_aux_t<2, 16>(ctx, k, d_dig, ncol, count, d_out);
+  // Measured at the metric ring (66 columns): 4 ciphertexts per tile with one key row per wave 1.76 ms, 2 ciphertexts with both key
+  // rows per wave 2.05 ms, 6 waves instead of 16 per workgroup 2.25 ms.  The LDS tile decides what fits (stress ring, 129 columns: 2).
+  if ((size_t)ncol * 4 * 512 <= 150 * 1024) return launch_dot_aux_t<4, 16, 1>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 2 * 512 <= 150 * 1024) return launch_dot_aux_t<2, 16, 2>(ctx, k, d_dig, ncol, count, d_out);
   if ((size_t)ncol * 512 > 160 * 1024) FHESI_FAIL("dot_aux: %d columns do not fit the LDS tile", ncol);
-  return launch_dot_aux_t<1, 16>(ctx, k, d_dig, ncol, count, d_out);
+  return launch_dot_aux_t<1, 16, 2>(ctx, k, d_dig, ncol, count, d_out);
 }
 
 // d_o: [nrows][2][n] after the inverse transforms; d_dst: [nrows][n], row r belongs to chain prime r % L
