@@ -856,25 +856,33 @@ static int key_switch_args(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
   return 0;
 }
 
-extern "C" int fhesi_apply_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, const uint64_t* tprod, int64_t count,
-                                          uint64_t* out, int32_t nlimbs) {
-  CHECK_CTX(c);
-  FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
-  if (!count) return 0;
+// d_t: the scaled-up ciphertexts [count][ncomp][L][n], with room for max(ncomp, 2) parts per ciphertext; consumed (transformed in place,
+// then reused for the dot product's rows)
+static int apply_key_switch_consume(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, u64* d_t, int64_t count, uint64_t* out, int32_t nlimbs) {
   const i64 n = c->phim;
   const int L = c->L, ncomp = k->ncomp, nlq = (logQ + 63) / 64;
   const std::vector<int> all = full_set(c);
   CrtTables* t;
   FHESI_TRY(get_crt_tables(c, all, &t));
   // ScaleDown (Ciphertext.cpp:194-218): toPoly + round(x/q) + Reduce, kept as positive residues for ByteDecomp
-  void* d_t;
-  FHESI_TRY(ws_reserve(c, 1, (size_t)count * (ncomp > 2 ? ncomp : 2) * L * n * 8, &d_t));
-  HIP_TRY(hipMemcpyAsync(d_t, tprod, (size_t)count * ncomp * L * n * 8, hipMemcpyDeviceToDevice, c->stream));
-  FHESI_TRY(row_inv(c, (u64*)d_t, count * ncomp, L, nullptr, all.data()));
+  FHESI_TRY(row_inv(c, d_t, count * ncomp, L, nullptr, all.data()));
   void* d_parts;
   FHESI_TRY(ws_reserve(c, 2, (size_t)count * ncomp * nlq * n * 8, &d_parts));
   FHESI_TRY(launch_crt(c, t, (const u64*)d_t, L, nullptr, count * ncomp, 1, 0, logQ, (u64*)d_parts, nlq));
-  return key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, count, (u64*)d_t, out, nlimbs);
+  return key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, count, d_t, out, nlimbs);
+}
+
+extern "C" int fhesi_apply_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, const uint64_t* tprod, int64_t count,
+                                          uint64_t* out, int32_t nlimbs) {
+  CHECK_CTX(c);
+  FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
+  if (!count) return 0;
+  const i64 n = c->phim;
+  const int L = c->L, ncomp = k->ncomp;
+  void* d_t;
+  FHESI_TRY(ws_reserve(c, 1, (size_t)count * (ncomp > 2 ? ncomp : 2) * L * n * 8, &d_t));
+  HIP_TRY(hipMemcpyAsync(d_t, tprod, (size_t)count * ncomp * L * n * 8, hipMemcpyDeviceToDevice, c->stream));      // the caller keeps its tProd
+  return apply_key_switch_consume(c, k, logQ, decomp_bytes, (u64*)d_t, count, out, nlimbs);
 }
 
 // Ciphertext::operator>>= (Ciphertext.cpp:264-269 -> CiphertextPart::operator>>= :54-59: DoubleCRT(poly) >>= k; toPoly) for a batch
@@ -1154,7 +1162,8 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
     FHESI_TRY(ws_reserve(c, 5, (size_t)cnt * 3 * L * n * 8, &d_tp));
     const size_t off = (size_t)done * 2 * n * nlimbs;
     FHESI_TRY(fhesi_ct_mul_dev(c, p, a + off, b + off, nlimbs, cnt, (uint64_t*)d_tp));
-    FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_tp, cnt, out + off, nlimbs));
+    FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
+    FHESI_TRY(apply_key_switch_consume(c, k, logQ, decomp_bytes, (u64*)d_tp, cnt, out + off, nlimbs));      // the chunk's tProd is ours: no copy
   }
   return 0;
 }
