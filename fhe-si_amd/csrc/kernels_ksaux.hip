@@ -229,6 +229,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
     ksaux_retile_kernel<<<g2, 256, 0, ctx->stream>>>((const u64*)tmp, half, ncol, n);
     HIP_TRY(hipGetLastError());
   }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));       // one-off: another lane's stream may use the table right away
   k->aux_suborder = suborder;
   k->aux_valid = true;
   return 0;

@@ -149,3 +149,24 @@ def test_sum_form_crt_undecided_coefficients(monkeypatch):
     ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
     assert not np.array_equal(out.download((2, n, nl)), want2)
     monkeypatch.delenv("FHESI_CRT_SKIP_CLEANUP")
+
+
+@pytest.mark.parametrize("m,logQ,p", [(4096, 128, 23), (32768, 512, 23), (1 << 16, 200, 23)])
+def test_key_switch_paths_agree(m, logQ, p, monkeypatch):
+    """The key switch has two device paths: the dot product through the two largest chain primes (kernels_ksaux.hip, default for
+    n = 2^11 .. 2^15) and the per-prime dot product of the reference's own structure (FHE-SI.cpp:251-254; FHESI_KS_DIRECT=1, and every
+    shape the first does not cover).  Both must give the oracle's bits -- including after the key rows are rewritten in place
+    through the device pointer (the RCCL broadcast path), which has to rebuild the derived key table."""
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 31 + m, 1)
+    want = orc.ct_mul_relin(ksm, a[0], b[0], logQ, p)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
+    monkeypatch.setenv("FHESI_KS_DIRECT", "1")
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
+    monkeypatch.delenv("FHESI_KS_DIRECT")
+    # new key rows written straight into HBM
+    rng = np.random.default_rng(m)
+    ksm2 = np.stack([P.rand_rows(rng, [int(q) for q in ctx.primes], ctx.phim, 3 * nd) for _ in range(2)])
+    stage = ctx.upload(ksm2)
+    ctx.dev_copy(ksk.device_ptr, stage.ptr.value, ksm2.nbytes)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], orc.ct_mul_relin(ksm2, a[0], b[0], logQ, p))
