@@ -70,7 +70,10 @@ __global__ void __launch_bounds__(256) ksaux_retile_kernel(const u64* __restrict
 template <int CT, int NW, int R>
 __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict__ k2, const u64* __restrict__ dig, int ncol, i64 n, int L, i64 count,
                                                           u64* __restrict__ out, const PrimeConst* __restrict__ pcs, int ntiles, int nsl8) {
-  extern __shared__ __attribute__((aligned(16))) u64 dl[];        // [ncol][64][CT]
+  // digit tile [ncol][CT/2][64 lanes][2]: a lane's 16-byte reads are 16 bytes apart (conflict-free ds_read_b128)
+  extern __shared__ __attribute__((aligned(16))) u64 dl[];
+  constexpr int PW = CT >= 2 ? 2 : 1, CH = CT / PW;
+#define DL_IDX(k, c) ((((k) * CH + ((c) / PW)) * 64 + lane) * PW + ((c) % PW))
   const u32 lane = threadIdx.x & 63;       // unsigned: the lane offset of a load is a zero-extended 32-bit index next to a scalar base
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index as a scalar: the key row pointers stay in SGPRs
   // block order: 8 consecutive slices (one per XCD), then the ciphertext tiles, then the slice groups, then the auxiliary prime
@@ -87,7 +90,7 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
     const i64 ct = ct0 + c;
     u64 v = 0;
     if (ct < count) v = d_shoup(__builtin_nontemporal_load(&(dig + ((ct * ncol + k) * 2 + a) * n + soff)[lane]), 1, pc.one_sh, pc.q);
-    dl[(k * 64 + lane) * CT + c] = pack30(v);
+    dl[DL_IDX(k, c)] = pack30(v);
   }
   __syncthreads();
   // R = 2: a wave takes both key rows of a chain prime for its CT ciphertexts; R = 1: one key row, so that a key load feeds CT
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
         const u32 xa[2][2] = {{(u32)x0, (u32)(x0 >> 32)}, {(u32)x1, (u32)(x1 >> 32)}};
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const u64 d = dl[(k * 64 + lane) * CT + c];
+          const u64 d = dl[DL_IDX(k, c)];
           const u32 d0 = (u32)d, d1 = (u32)(d >> 32);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
@@ -235,6 +238,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
   return 0;
 }
 
+#undef DL_IDX
 template <int CT, int NW, int R>
 static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig, int ncol, i64 count, u64* d_out) {
   const i64 n = ctx->phim;

@@ -104,7 +104,11 @@ int fhesi_rows_op_dev(fhesi_ctx* ctx, uint64_t* dst_dev, const uint64_t* src_dev
 int fhesi_ksk_create(fhesi_ctx* ctx, int32_t ncomp, int32_t ndigits, fhesi_ksk** out);
 int fhesi_ksk_free(fhesi_ksk* k);
 int fhesi_ksk_upload(fhesi_ksk* k, const uint64_t* rows_host);                       /* whole matrix, host layout as above */
-void* fhesi_ksk_device_ptr(fhesi_ksk* k);                                            /* HBM buffer (target of the RCCL broadcast) */
+void* fhesi_ksk_device_ptr(fhesi_ksk* k);                                            /* HBM buffer (target of the RCCL broadcast).  The library keeps a
+                                                                                        table derived from these rows (the key's coefficient vectors
+                                                                                        transformed modulo the two largest chain primes); asking for the
+                                                                                        pointer marks it stale, so fetch the pointer BEFORE every direct
+                                                                                        write into the rows (or use fhesi_ksk_upload) */
 size_t fhesi_ksk_bytes(const fhesi_ksk* k);
 
 /* ---- the metric's unit of work, batched: Ciphertext::operator*= (Ciphertext.cpp:167-192) followed by
