@@ -85,12 +85,20 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
   const i64 soff = (i64)(s_hi * 8 + s_lo) * 64;                   // uniform: first element of the slice
   const i64 ct0 = (i64)tile * CT;
   const PrimeConst pc = pcs[a];
-  for (int e = w; e < ncol * CT; e += NW) {
-    const int k = e / CT, c = e % CT;
-    const i64 ct = ct0 + c;
-    u64 v = 0;
-    if (ct < count) v = d_shoup(__builtin_nontemporal_load(&(dig + ((ct * ncol + k) * 2 + a) * n + soff)[lane]), 1, pc.one_sh, pc.q);
-    dl[DL_IDX(k, c)] = pack30(v);
+  // tile load, 8 row slices per wave in flight (one at a time would pay the HBM latency ncol CT / NW times per workgroup)
+  for (int e0 = w; e0 < ncol * CT; e0 += 8 * NW) {
+    u64 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * NW, k = e / CT, c = e % CT;
+      const i64 ct = ct0 + c;
+      v[u] = (e < ncol * CT && ct < count) ? __builtin_nontemporal_load(&(dig + ((ct * ncol + k) * 2 + a) * n + soff)[lane]) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * NW, k = e / CT, c = e % CT;
+      if (e < ncol * CT) dl[DL_IDX(k, c)] = pack30(d_shoup(v[u], 1, pc.one_sh, pc.q));
+    }
   }
   __syncthreads();
   // R = 2: a wave takes both key rows of a chain prime for its CT ciphertexts; R = 1: one key row, so that a key load feeds CT
@@ -110,38 +118,8 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int p = 0; p < 3; ++p) { tl[c][r][p] = 0; th[c][r][p] = 0; }
-    for (int kb = 0; kb < ncol; kb += 8) {
-      u64 ll[CT][R], mid[CT][R], hh[CT][R];
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int r = 0; r < R; ++r) { ll[c][r] = 0; mid[c][r] = 0; hh[c][r] = 0; }
-      auto column = [&](u64 x0, u64 x1, int k) {
-        const u32 xa[2][2] = {{(u32)x0, (u32)(x0 >> 32)}, {(u32)x1, (u32)(x1 >> 32)}};
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const u64 d = dl[DL_IDX(k, c)];
-          const u32 d0 = (u32)d, d1 = (u32)(d >> 32);
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            ll[c][r] += (u64)xa[r][0] * d0;
-            mid[c][r] += (u64)xa[r][0] * d1;
-            mid[c][r] += (u64)xa[r][1] * d0;
-            hh[c][r] += (u64)xa[r][1] * d1;
-          }
-        }
-      };
-      if (kb + 8 <= ncol) {
-        u64 x0[8], x1[8];
-        const u64* p0 = k0 + (kb << 6);
-        const u64* p1 = k1 + (kb << 6);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { x0[u] = p0[u << 6]; x1[u] = R == 2 ? p1[u << 6] : 0; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) column(x0[u], x1[u], kb + u);
-      } else {
-        for (int k = kb; k < ncol; ++k) column(k0[k << 6], R == 2 ? k1[k << 6] : 0, k);
-      }
+    // columns in groups of 8, software-pipelined: the key loads of group g + 1 are issued before group g is multiplied
+    auto gather = [&](const u64 (&ll)[CT][R], const u64 (&mid)[CT][R], const u64 (&hh)[CT][R]) {
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -150,6 +128,63 @@ __global__ void __launch_bounds__(NW * 64) dot_aux_kernel(const u64* __restrict_
 #pragma unroll
           for (int p = 0; p < 3; ++p) { const u64 t = tl[c][r][p] + part[p]; th[c][r][p] += t < part[p] ? 1u : 0u; tl[c][r][p] = t; }
         }
+    };
+    auto column = [&](u64 (&ll)[CT][R], u64 (&mid)[CT][R], u64 (&hh)[CT][R], u64 x0, u64 x1, int k) {
+      const u32 xa[2][2] = {{(u32)x0, (u32)(x0 >> 32)}, {(u32)x1, (u32)(x1 >> 32)}};
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const u64 d = dl[DL_IDX(k, c)];
+        const u32 d0 = (u32)d, d1 = (u32)(d >> 32);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          ll[c][r] += (u64)xa[r][0] * d0;
+          mid[c][r] += (u64)xa[r][0] * d1;
+          mid[c][r] += (u64)xa[r][1] * d0;
+          hh[c][r] += (u64)xa[r][1] * d1;
+        }
+      }
+    };
+    const int nfull = ncol & ~7;
+    constexpr bool PF = R == 1;          // (with both key rows per wave the second register set spills)
+    u64 xc[R][8], xn[R][8];
+    if (PF && nfull) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { xc[0][u] = k0[u << 6]; if (R == 2) xc[R - 1][u] = k1[u << 6]; }
+    }
+    for (int kb = 0; kb < nfull; kb += 8) {
+      if (PF) {
+        if (kb + 8 < nfull) {
+          const u64* p0 = k0 + ((kb + 8) << 6);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) xn[0][u] = p0[u << 6];
+        }
+      } else {
+        const u64* p0 = k0 + (kb << 6);
+        const u64* p1 = k1 + (kb << 6);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { xc[0][u] = p0[u << 6]; if (R == 2) xc[R - 1][u] = p1[u << 6]; }
+      }
+      u64 ll[CT][R], mid[CT][R], hh[CT][R];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ll[c][r] = 0; mid[c][r] = 0; hh[c][r] = 0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) column(ll, mid, hh, xc[0][u], R == 2 ? xc[R - 1][u] : 0, kb + u);
+      gather(ll, mid, hh);
+      if (PF) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xc[0][u] = xn[0][u];
+      }
+    }
+    if (nfull < ncol) {       // the last ncol mod 8 columns
+      u64 ll[CT][R], mid[CT][R], hh[CT][R];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ll[c][r] = 0; mid[c][r] = 0; hh[c][r] = 0; }
+      for (int k = nfull; k < ncol; ++k) column(ll, mid, hh, k0[k << 6], R == 2 ? k1[k << 6] : 0, k);
+      gather(ll, mid, hh);
     }
     u128 tot[CT][R];
 #pragma unroll
