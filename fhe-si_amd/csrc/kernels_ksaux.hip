@@ -240,8 +240,8 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
   const i64 n = ctx->phim;
   const int L = ctx->L, ncol = k->ncomp * k->ndigits;
   const bool suborder = ntt_digits_suborder(ctx, digit_bits);
-  if (!k->d_aux) {
-    HIP_TRY(hipMalloc(&k->d_aux, 2 * k->bytes));
+  if (!k->d_aux) HIP_TRY(hipMalloc(&k->d_aux, 2 * k->bytes));
+  if (!k->d_aux_consts) {
     HIP_TRY(hipMalloc(&k->d_aux_consts, (size_t)(L + 2) * 8));
     std::vector<u64> h(L + 2, 0);
     const u128 A = (u128)ctx->q[0] * ctx->q[1];
