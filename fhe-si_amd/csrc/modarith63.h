@@ -147,6 +147,21 @@ __device__ __forceinline__ void bfly_fwd63_x2_s_nc(u64& Xa, u64& Ya, const Tw63&
   Yb = yb_new;
 }
 
+// two independent multiplications by wave-uniform constants (the last inverse stage: sum * 1/n and difference * w/n); results below 2q
+__device__ __forceinline__ void mulmod63_x2_s(u64& Ya, const Tw63& ta, u64& Yb, const Tw63& tb, const Mod63& m) {
+  u64 cy, ra, rb;
+  asm(MULMOD63_ASM(104, 105, 106, 107, 108, 109, 110, "%[ya0]", "%[ya1]", "%[wa0]", "%[wa1]", "%[pa0]", "%[pa1]")
+      MULMOD63_ASM(116, 117, 118, 119, 120, 121, 122, "%[yb0]", "%[yb1]", "%[wb0]", "%[wb1]", "%[pb0]", "%[pb1]")
+      "v_lshl_add_u64 %[ra], v[108:109], 0, 0\n\t"
+      "v_lshl_add_u64 %[rb], v[120:121], 0, 0\n\t"
+      : [ra] "=&v"(ra), [rb] "=&v"(rb), [cy] "=&s"(cy)
+      : [ya0] "v"((u32)Ya), [ya1] "v"((u32)(Ya >> 32)), [yb0] "v"((u32)Yb), [yb1] "v"((u32)(Yb >> 32)), [wa0] "s"(ta.w0), [wa1] "s"(ta.w1), [pa0] "s"(ta.p0),
+        [pa1] "s"(ta.p1), [wb0] "s"(tb.w0), [wb1] "s"(tb.w1), [pb0] "s"(tb.p0), [pb1] "s"(tb.p1), [nq0] "s"(m.nq0), [nq1] "s"(m.nq1)
+      : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v116", "v117", "v118", "v119", "v120", "v121", "v122");
+  Ya = ra;
+  Yb = rb;
+}
+
 // exact normalisations on store.  Conditional subtraction without compares: values stay below 2^63, so the sign of v - c
 // tells whether to add c back (5 VALU instructions per step instead of a compare / select / borrow chain with VCC wait states)
 __device__ __forceinline__ u64 csub63(u64 v, u64 c) {                 // v < 2^63, c < 2^62:  v >= c ? v - c : v
