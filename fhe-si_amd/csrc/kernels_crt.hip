@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(128) crt_sum_kernel(const u64* __restrict__ ro
   if (active) {
     u64 f_lo = 0, f_hi = 0;        // fractional part of sum y_i/q_i, 128-bit fixed point
     u32 kint = 0;                  // its integer part
-#pragma unroll
+#pragma unroll 2
     for (int i = 0; i < K; ++i) {
       const PrimeConst pc = pcs[idx[i]];
       const u64 q = pc.q;
