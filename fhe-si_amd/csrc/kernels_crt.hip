@@ -68,9 +68,9 @@ __global__ void __launch_bounds__(256) rns_reduce_kernel(const u64* __restrict__
 // prime loop, and the residue is ONE exact 128-bit sum of x_k * (2^(64k) mod q) (4 word multiplies per limb instead of a Shoup
 // step's 10), folded every 8 limbs when the sum could overflow and reduced once.
 template <int NL>
-__global__ void __launch_bounds__(256) rns_reduce_kernel_t(const u64* __restrict__ limbs, i64 ncoeffs, i64 n, int npoly_mod, const u64* __restrict__ scalar_res,
+__global__ void __launch_bounds__(256) rns_reduce_kernel_t(const u64* __restrict__ limbs, i64 ncoeffs, i64 n, int npoly_mod, i64 pow_poly_stride,
                                                             u64* __restrict__ rows, int nslots, const int* __restrict__ prime_of_slot,
-                                                            const PrimeConst* __restrict__ pcs, const Shoup2* __restrict__ pow64) {
+                                                            const PrimeConst* __restrict__ pcs, const u64* __restrict__ pows, int L) {
   __shared__ __attribute__((aligned(16))) u64 sl[NL * 256];       // [NL][256]
   const i64 poly = blockIdx.y;
   const i64 j0 = (i64)blockIdx.x * 256;
@@ -93,23 +93,23 @@ __global__ void __launch_bounds__(256) rns_reduce_kernel_t(const u64* __restrict
   for (int slot = 0; slot < nslots; ++slot) {
     const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
     const PrimeConst pc = pcs[prime];
-    const Shoup2* pw = pow64 + (i64)prime * (NL + 1);
+    // pows[class][prime][k] = s * 2^(64k) mod q: the word scalar s of the polynomial's class (the `poly * p` lift) is folded into the table
+    const u64* pw = pows + (poly % npoly_mod) * pow_poly_stride + (i64)prime * (NL + 1);
     u128 acc = 0;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-      acc += (u128)x[k] * pw[k].w;
+      acc += (u128)x[k] * pw[k];
       if (NL > 15 && (k & 7) == 7 && k + 1 < NL) acc = crt_fold128(acc, pc);      // 8 more terms below 2^124 on top of a value below q
     }
     u64 r = crt_fold128(acc, pc);
-    if (neg) r = d_submod(r, pw[NL].w, pc.q);
-    if (scalar_res) { const u64 sc = scalar_res[(poly % npoly_mod) * nslots + slot]; if (sc) r = d_mulmod(r, sc, pc); }
+    if (neg) r = d_submod(r, pw[NL], pc.q);
     rows[(poly * nslots + slot) * n + j] = r;
   }
 }
 template <int NL>
-static void launch_rns_t(fhesi_ctx* ctx, dim3 grid, const u64* d_limbs, i64 ncoeffs, i64 n, int npoly, const u64* d_sc, u64* d_rows, int nslots,
-                         const int* d_prime_of_slot, const Shoup2* d_pow) {
-  rns_reduce_kernel_t<NL><<<grid, 256, 0, ctx->stream>>>(d_limbs, ncoeffs, n, npoly, d_sc, d_rows, nslots, d_prime_of_slot, ctx->d_pc, d_pow);
+static void launch_rns_t(fhesi_ctx* ctx, dim3 grid, const u64* d_limbs, i64 ncoeffs, i64 n, int npoly, i64 pow_poly_stride, u64* d_rows, int nslots,
+                         const int* d_prime_of_slot, const u64* d_pows) {
+  rns_reduce_kernel_t<NL><<<grid, 256, 0, ctx->stream>>>(d_limbs, ncoeffs, n, npoly, pow_poly_stride, d_rows, nslots, d_prime_of_slot, ctx->d_pc, d_pows, ctx->L);
 }
 
 int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeffs, i64 count, int npoly, const u64* scalar_mul,
@@ -151,7 +151,31 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
   ProfScope prof(ctx, PROF_RNS, (double)(count * npoly));
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)(count * npoly));
   const i64 nc = ncoeffs < n ? ncoeffs : n;
-#define RNS_CASE(NL) case NL: launch_rns_t<NL>(ctx, grid, d_limbs, nc, n, npoly, d_sc, d_rows, nslots, d_prime_of_slot, d_pow); HIP_TRY(hipGetLastError()); return 0;
+  // table of the compile-time-width kernel: s * 2^(64k) mod q per (class, prime, k), s = the class's word scalar (1 without a lift)
+  u64* d_pows = nullptr;
+  const i64 pow_stride = (i64)ctx->L * (nlimbs + 1);
+  if (nlimbs <= 20) {
+    std::vector<u64> key;
+    if (scalar_mul) key.assign(scalar_mul, scalar_mul + npoly); else key.assign(1, 0);
+    key.push_back(0x7461626c65000000ull | (u64)nlimbs);          // tag: scaled power table of this limb count
+    auto pit = ctx->scalar_cache.find(key);
+    if (pit == ctx->scalar_cache.end()) {
+      const int ncls = scalar_mul ? npoly : 1;
+      std::vector<u64> h((size_t)ncls * pow_stride);
+      for (int p = 0; p < ncls; ++p)
+        for (int l = 0; l < ctx->L; ++l) {
+          const u64 q = ctx->q[l];
+          const u64 b = (u64)(((u128)1 << 64) % q);
+          u64 cur = (scalar_mul && scalar_mul[p]) ? scalar_mul[p] % q : 1 % q;
+          for (int k = 0; k <= nlimbs; ++k) { h[(size_t)p * pow_stride + (size_t)l * (nlimbs + 1) + k] = cur; cur = hm::mulmod(cur, b, q); }
+        }
+      HIP_TRY(hipMalloc(&d_pows, h.size() * 8));
+      HIP_TRY(hipMemcpy(d_pows, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+      ctx->scalar_cache[key] = d_pows;
+    } else d_pows = pit->second;
+  }
+  const int npoly_cls = scalar_mul ? npoly : 1;
+#define RNS_CASE(NL) case NL: launch_rns_t<NL>(ctx, grid, d_limbs, nc, n, npoly_cls, pow_stride, d_rows, nslots, d_prime_of_slot, d_pows); HIP_TRY(hipGetLastError()); return 0;
   switch (nlimbs) {
     RNS_CASE(1) RNS_CASE(2) RNS_CASE(3) RNS_CASE(4) RNS_CASE(5) RNS_CASE(6) RNS_CASE(7) RNS_CASE(8) RNS_CASE(9) RNS_CASE(10)
     RNS_CASE(11) RNS_CASE(12) RNS_CASE(13) RNS_CASE(14) RNS_CASE(15) RNS_CASE(16) RNS_CASE(17) RNS_CASE(18) RNS_CASE(19) RNS_CASE(20)
