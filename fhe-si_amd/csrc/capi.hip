@@ -766,6 +766,7 @@ extern "C" int fhesi_ksk_free(fhesi_ksk* k) {
   hipFree(k->d_rows);
   if (k->d_aux) hipFree(k->d_aux);
   if (k->d_aux_consts) hipFree(k->d_aux_consts);
+  if (k->d_limb_consts) hipFree(k->d_limb_consts);
   delete k;
   return 0;
 }
@@ -819,14 +820,16 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
   // FHESI_KS_DIRECT=1 keeps the per-prime dot product below (A/B measurements; also the path of every shape the other does not cover).
   if (ksaux_supported(c, ncol, 8 * decomp_bytes) && !getenv("FHESI_KS_DIRECT")) {
     fhesi_ksk* km = const_cast<fhesi_ksk*>(k);
-    if (!k->aux_valid || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes)) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes));
+    if (!k->aux_valid || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ));
+    const int R = k->aux_rows;        // L chain-prime residues, or the limbs of the key's integer coefficients (limb mode)
     void *d_dig, *d_o;
     FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * 2 * n * 8, &d_dig));
-    FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * L * 2 * n * 8, &d_o));
+    FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * R * 2 * n * 8, &d_o));
     FHESI_TRY(launch_ntt_fwd_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig, 0, 2, 2));
     if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
     FHESI_TRY(launch_dot_aux(c, k, (const u64*)d_dig, ncol, count, (u64*)d_o));
-    FHESI_TRY(launch_ntt_inv(c, (u64*)d_o, count * 2 * L, 2, (const int*)(k->d_aux_consts + L), !k->aux_suborder));
+    FHESI_TRY(launch_ntt_inv(c, (u64*)d_o, count * 2 * R, 2, (const int*)(k->d_aux_consts + L), !k->aux_suborder));
+    if (k->aux_limb_bits) return launch_ks_recombine(c, t, k, (const u64*)d_o, count * 2, (u64*)out, nlimbs);
     FHESI_TRY(launch_aux_crt(c, k, (const u64*)d_o, d_t, count * 2 * L));
     return launch_crt(c, t, d_t, L, nullptr, count * 2, 2, 0, logQ, (u64*)out, nlimbs);
   }

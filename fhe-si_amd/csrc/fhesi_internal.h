@@ -130,9 +130,16 @@ struct fhesi_ksk {
   u64* d_aux = nullptr;                // [2 aux][L][2][ncomp*ndigits][phim]
   u64* d_aux_consts = nullptr;         // [L] q_0 q_1 mod q_i, then the int pair {0, 1} (prime_of_slot of auxiliary rows)
   bool aux_valid = false, aux_suborder = false;
+  // limb mode (kernels_ksaux.hip): the table is built from the key polynomial's INTEGER coefficients (toPoly over the chain) cut into
+  // aux_rows limbs of aux_limb_bits bits instead of from its aux_rows = L chain-prime residues; 0 = residue mode
+  int aux_rows = 0, aux_limb_bits = 0, aux_logQ = 0;
+  u64* d_limb_consts = nullptr;        // [W+1] offset constant D, [2] floor(2^(64(W-2)+128) / P), then the quotient bound's bit count
 };
+struct KsLimbPlan { int W = 0, LQ = 0, B = 0, NLB = 0, mbits = 0; };
+bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan);
+int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o /* [npolys][aux_rows][2][n] */, i64 npolys, u64* d_out, int nl_out);
 bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits);
-int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits);
+int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ);
 int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig /* [count*ncol][2][n] */, int ncol, i64 count, u64* d_out /* [count][2][L][2][n] */);
 int launch_aux_crt(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_o /* [nrows][2][n] */, u64* d_dst /* [nrows][n] */, i64 nrows);
 

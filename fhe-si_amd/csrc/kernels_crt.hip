@@ -578,6 +578,112 @@ static int launch_crt_sum(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows,
   return launch_crt_t<K, K, W, LQ>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, 0, LQ, d_out, nl_out, t->d_flags);
 }
 
+// ----------------------------------------------------------------------------------------- key switch, limb mode: recombination
+// The auxiliary-prime dot product in limb mode (kernels_ksaux.hip) returns, per output coefficient, NLB pairs of residues of the
+// integers V_l = sum_k digit_k (*) K_{k,l}, where K_{k,l} is limb l (B bits) of the key polynomial's integer coefficient in [0, P).
+// So S = sum_l V_l 2^(B l) = sum_k digit_k (*) K_k is the dot product as an integer, and ApplyKeySwitch's result
+// (toPoly of the dot product, then ReduceCoefficients: FHE-SI.cpp:255-256) is the centred residue of S modulo P, reduced modulo 2^logQ.
+//   V_l: Garner from the two residues, centred modulo q_0 q_1 (|V_l| < q_0 q_1 / 2 by the plan's bound), made non-negative by +2^119;
+//   x = D + sum_l (V_l + 2^119) 2^(B l)  with  D = 2^m P - sum_l 2^(119 + B l)  (host constant), so x = S + 2^m P in (0, 2^(m+1) P);
+//   quotient estimate from the top two limbs and floor(2^(64(W-2)+128) / P) (never above, at most 2 below), remainder, at most two
+//   corrections, centring -- all exact integer arithmetic on W + 1 limbs -- then the mode-2 store of the sum-form kernel.
+template <int W, int LQ, int B, int NLB>
+__global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict__ o, i64 n, u64 q0, u64 q1, u64 q0inv, u64 q0inv_sh, u64 half_hi, u64 half_lo,
+                                                           u64 a_hi, u64 a_lo, const u64* __restrict__ consts /* D[W+1], pinv lo, hi */,
+                                                           const u64* __restrict__ Pfull, const u64* __restrict__ halfP, u64* __restrict__ out, int nl_out) {
+  const i64 poly = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  u64 x[W + 1];
+#pragma unroll
+  for (int i = 0; i <= W; ++i) x[i] = consts[i];
+  const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
+  const u64* base = o + poly * NLB * 2 * n + j;
+#pragma unroll
+  for (int l = 0; l < NLB; ++l) {
+    const u64 v0 = base[(i64)(l * 2 + 0) * n], v1 = base[(i64)(l * 2 + 1) * n];
+    const u64 v0r = v0 >= q1 ? v0 - q1 : v0;
+    const u64 t = d_shoup(d_submod(v1, v0r, q1), q0inv, q0inv_sh, q1);
+    u128 V = (u128)q0 * t + v0;                                  // in [0, q_0 q_1)
+    if (V > half) V -= A;                                        // centred (two's complement in 128 bits)
+    V += (u128)1 << 119;                                         // non-negative, below 2^120
+    const int s = B * l, wd = s >> 6, bt = s & 63;               // compile-time after unrolling
+    const u64 lo = (u64)V, hi = (u64)(V >> 64);
+    const u64 p0 = lo << bt, p1 = bt ? ((lo >> ((64 - bt) & 63)) | (hi << bt)) : hi, p2 = bt ? (hi >> ((64 - bt) & 63)) : 0;
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i <= W; ++i) {
+      if (i >= wd) {
+        const u64 add = i == wd ? p0 : (i == wd + 1 ? p1 : (i == wd + 2 ? p2 : 0));
+        const u128 sum = (u128)x[i] + add + carry;
+        x[i] = (u64)sum;
+        carry = (u64)(sum >> 64);
+      }
+    }
+  }
+  // x = S + 2^m P, below 2^(64 (W-1) + 63): x[W] = 0
+  const u64 t0 = x[W - 2], t1 = x[W - 1], p0 = consts[W + 1], p1 = consts[W + 2];
+  u128 mid = (u128)t1 * p0 + (u64)(((u128)t0 * p0) >> 64);
+  const u128 add = (u128)t0 * p1;
+  const u128 mid2 = mid + add;
+  u128 qh = (u128)t1 * p1 + (mid2 >> 64) + ((mid2 < add) ? ((u128)1 << 64) : 0);
+  const u64 qhat = (u64)qh;                                      // below 2^(m+1) < 2^63
+  {
+    u64 carry = 0, borrow = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      const u128 t = (u128)qhat * Pfull[i] + carry;
+      carry = (u64)(t >> 64);
+      const u64 tl = (u64)t, d = x[i] - tl, b1 = x[i] < tl, d2 = d - borrow, b2 = d < borrow;
+      x[i] = d2;
+      borrow = b1 | b2;
+    }
+  }
+  auto ge = [&](const u64* __restrict__ c) -> bool {             // x[0..W) >= c[0..W)
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int i = W - 1; i >= 0; --i) { const u64 h = c[i]; if (!decided && x[i] != h) { gt = x[i] > h; decided = true; } }
+    return gt || !decided;
+  };
+  auto subP = [&]() {
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) { const u64 p = Pfull[i], d = x[i] - p, b1 = x[i] < p, d2 = d - borrow, b2 = d < borrow; x[i] = d2; borrow = b1 | b2; }
+  };
+  if (ge(Pfull)) subP();
+  if (ge(Pfull)) subP();
+  // centre: x > (P-1)/2  ->  x - P   (DoubleCRT.cpp:375-376)
+  {
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int i = W - 1; i >= 0; --i) { const u64 h = halfP[i]; if (!decided && x[i] != h) { gt = x[i] > h; decided = true; } }
+    if (gt) subP();
+  }
+  u64 y[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) y[i] = x[i];
+  crt_store_fixed<W, W, LQ>(y, 2, out, poly, n, j, nl_out);
+}
+
+template <int W, int LQ, int B, int NLB>
+static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
+  const u64 q0 = ctx->q[0], q1 = ctx->q[1];
+  const u64 inv = hm::invmod(q0 % q1, q1);
+  const u128 A = (u128)q0 * q1, half = (A - 1) / 2;
+  dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
+  ks_recombine_kernel<W, LQ, B, NLB><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, q0, q1, inv, hm::shoup(inv, q1), (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A,
+                                                                     k->d_limb_consts, t->d_P + (size_t)t->nidx * t->W, t->d_halfP, d_out, nl_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
+  if (!npolys) return 0;
+  ProfScope prof(ctx, PROF_CRT, (double)npolys);
+  if (t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15>(ctx, t, k, d_o, npolys, d_out, nl_out);
+  if (t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30) return launch_ks_recombine_t<34, 1024, 72, 30>(ctx, t, k, d_o, npolys, d_out, nl_out);
+  FHESI_FAIL("key switch, limb mode: no recombination kernel for W=%d logQ=%d B=%d rows=%d", t->W, k->aux_logQ, k->aux_limb_bits, k->aux_rows);
+}
+
 int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode, int positive,
                int logQ, u64* d_out, int nl_out) {
   if (!npolys) return 0;

@@ -44,6 +44,30 @@ __global__ void __launch_bounds__(256) ksaux_scatter_kernel(const u64* __restric
   }
 }
 
+// Limb mode: kint [2*ncol][n][W] = the key polynomial's integer coefficients in [0, P) (toPoly over the whole chain);
+// K2[a][l][r][k][n] = (limb l of B bits) mod q_a.  Build-time only.
+__global__ void __launch_bounds__(256) ks_limb_scatter_kernel(const u64* __restrict__ kint, u64* __restrict__ k2, int ncol, int NLB, int B, int W, i64 n,
+                                                              u64 q0, u64 q1) {
+  const i64 row = blockIdx.y;                 // (r * ncol + k) * NLB + l
+  const int l = (int)(row % NLB);
+  const i64 rk = row / NLB;
+  const int k = (int)(rk % ncol), r = (int)(rk / ncol);
+  const int s = B * l, wd = s >> 6, bt = s & 63;
+  u64* d0 = k2 + ((((i64)0 * NLB + l) * 2 + r) * ncol + k) * n;
+  u64* d1 = k2 + ((((i64)1 * NLB + l) * 2 + r) * ncol + k) * n;
+  const u64 r64_0 = (u64)(((u128)1 << 64) % q0), r64_1 = (u64)(((u128)1 << 64) % q1);
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    const u64* x = kint + (rk * n + j) * W;
+    auto word = [&](int i) -> u64 { return i < W ? x[i] : 0; };
+    const u64 w0 = word(wd), w1 = word(wd + 1), w2 = word(wd + 2);
+    const u64 lo = bt ? ((w0 >> bt) | (w1 << (64 - bt))) : w0;
+    u64 hi = bt ? ((w1 >> bt) | (w2 << (64 - bt))) : w1;
+    hi &= ((u64)1 << (B - 64)) - 1;                                  // B in (64, 128)
+    d0[j] = (u64)(((u128)(lo % q0) + (u128)hi * r64_0) % q0);
+    d1[j] = (u64)(((u128)(lo % q1) + (u128)hi * r64_1) % q1);
+  }
+}
+
 // Split representation of a residue v < 2^60 for the dot product: low 30 bits in the low dword, high 30 bits in the high dword.
 // The four partial products of two such values are below 2^60 each, so they accumulate in plain 64-bit v_mad_u64_u32 chains --
 // no carries, no 128-bit additions -- for 8 columns (the two middle products share one accumulator) before they are gathered.
@@ -235,11 +259,65 @@ bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits) {
   return lg + 2.0 < std::log2((double)q0) + std::log2((double)q1);
 }
 
+// Limb mode is used where a recombination kernel is compiled (launch_ks_recombine): the metric chain shape (17-limb product,
+// logQ = 512: 15 limbs of 74 bits instead of 18 residues) and the stress shape (33-limb product, logQ = 1024: 30 limbs of 72 bits
+// instead of 35 residues).  Conditions: every limb product sum stays below q_0 q_1 / 2, the limbs cover P, and |S| < 2^m P.
+bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan) {
+  if (getenv("FHESI_KS_RESIDUES")) return false;               // A/B switch: residue mode
+  KsLimbPlan p;
+  if (t->W == 18 && logQ == 512) { p.W = 18; p.LQ = 512; p.B = 74; p.NLB = 15; }
+  else if (t->W == 34 && logQ == 1024) { p.W = 34; p.LQ = 1024; p.B = 72; p.NLB = 30; }
+  else return false;
+  if (t->nidx != ctx->L) return false;
+  std::vector<u64> P{1};
+  for (int i = 0; i < ctx->L; ++i) P = hm::bn_mul_small(P, ctx->q[i]);
+  int pbits = (int)(P.size() - 1) * 64;
+  for (u64 top = P.back(); top; top >>= 1) ++pbits;
+  if (p.NLB * p.B < pbits || (p.NLB - 1) * p.B + 120 > 64 * (p.W + 1)) return false;
+  const u128 A = (u128)ctx->q[0] * ctx->q[1];
+  if (A >> 119 > 1) return false;                               // the +2^119 offset needs q_0 q_1 < 2^120
+  const u128 terms = (u128)ncol * (u128)ctx->phim << digit_bits;      // ncol * n * 2^digit_bits
+  if (terms >> 50) return false;
+  if (((A / 2) >> p.B) <= terms) return false;                  // |V_l| <= terms * 2^B < q_0 q_1 / 2
+  int m = 0;
+  while (((u128)1 << m) <= terms) ++m;
+  p.mbits = m + 1;                                              // |S| < terms * P < 2^(mbits-1) P
+  if (p.mbits > 60) return false;
+  *plan = p;
+  return true;
+}
+
+// host big integers (little-endian u64 limbs, fixed width) for the limb mode's constants
+static void bn_shl(std::vector<u64>& a, int sh) {
+  const int n = (int)a.size(), w = sh >> 6, b = sh & 63;
+  std::vector<u64> r(n, 0);
+  for (int i = n - 1; i >= w; --i) r[i] = (a[i - w] << b) | ((b && i - w - 1 >= 0) ? (a[i - w - 1] >> (64 - b)) : 0);
+  a.swap(r);
+}
+static void bn_sub(std::vector<u64>& a, const std::vector<u64>& b) {          // a -= b  (mod 2^(64 n))
+  u64 borrow = 0;
+  for (size_t i = 0; i < a.size(); ++i) {
+    const u64 bi = i < b.size() ? b[i] : 0, d = a[i] - bi, b1 = a[i] < bi, d2 = d - borrow, b2 = d < borrow;
+    a[i] = d2; borrow = b1 | b2;
+  }
+}
+static bool bn_ge(const std::vector<u64>& a, const std::vector<u64>& b) {
+  for (int i = (int)a.size() - 1; i >= 0; --i) { const u64 bi = i < (int)b.size() ? b[i] : 0; if (a[i] != bi) return a[i] > bi; }
+  return true;
+}
+
 // builds k->d_aux from k->d_rows (device work only; the caller holds the context's stream)
-int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
+int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
   const i64 n = ctx->phim;
   const int L = ctx->L, ncol = k->ncomp * k->ndigits;
   const bool suborder = ntt_digits_suborder(ctx, digit_bits);
+  std::vector<int> all(L);
+  for (int i = 0; i < L; ++i) all[i] = i;
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(ctx, all, &t));
+  KsLimbPlan plan;
+  const bool limb = ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan);
+  const int R = limb ? plan.NLB : L;                          // output rows per (ciphertext, key row, auxiliary prime)
   if (!k->d_aux) HIP_TRY(hipMalloc(&k->d_aux, 2 * k->bytes));
   if (!k->d_aux_consts) {
     HIP_TRY(hipMalloc(&k->d_aux_consts, (size_t)(L + 2) * 8));
@@ -254,11 +332,48 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
   FHESI_TRY(ws_reserve(ctx, 0, k->bytes, &tmp));
   HIP_TRY(hipMemcpyAsync(tmp, k->d_rows, k->bytes, hipMemcpyDeviceToDevice, ctx->stream));
   FHESI_TRY(launch_ntt_inv(ctx, (u64*)tmp, 2 * ncol, L, nullptr, true));
-  dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)(2 * ncol * L));
-  ksaux_scatter_kernel<<<grid, 256, 0, ctx->stream>>>((const u64*)tmp, k->d_aux, ncol, L, n, ctx->q[0], ctx->q[1]);
-  HIP_TRY(hipGetLastError());
+  if (limb) {
+    const int W = t->W;
+    u64* kint = nullptr;                                        // the key's integer coefficients: one-off scratch
+    HIP_TRY(hipMalloc(&kint, (size_t)2 * ncol * n * W * 8));
+    int rc = launch_crt(ctx, t, (const u64*)tmp, L, nullptr, 2 * ncol, 0, 1, 0, kint, W);
+    if (!rc) {
+      dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)(2 * ncol * R));
+      ks_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(kint, k->d_aux, ncol, R, plan.B, W, n, ctx->q[0], ctx->q[1]);
+      if (hipGetLastError() != hipSuccess) rc = 1;
+    }
+    hipStreamSynchronize(ctx->stream);
+    hipFree(kint);
+    if (rc) FHESI_FAIL("key switch, limb mode: building the limb table failed");
+    // constants of the recombination kernel: D = 2^(mbits-1) P - sum_l 2^(119 + B l)  (W+1 limbs), floor(2^(64(W-2)+128) / P)
+    std::vector<u64> P{1};
+    for (int i = 0; i < L; ++i) P = hm::bn_mul_small(P, ctx->q[i]);
+    std::vector<u64> D(W + 1, 0);
+    for (size_t i = 0; i < P.size(); ++i) D[i] = P[i];
+    bn_shl(D, plan.mbits - 1);
+    for (int l = 0; l < R; ++l) { std::vector<u64> o(W + 1, 0); const int bit = 119 + plan.B * l; o[bit >> 6] = (u64)1 << (bit & 63); bn_sub(D, o); }
+    // restoring division of 2^e by P, e = 64 (W-2) + 128
+    const int e = 64 * (W - 2) + 128;
+    std::vector<u64> rem(W + 1, 0), Pw(W + 1, 0), quo(3, 0);
+    for (size_t i = 0; i < P.size(); ++i) Pw[i] = P[i];
+    for (int bit = e; bit >= 0; --bit) {
+      bn_shl(rem, 1);
+      if (bit == e) rem[0] |= 1;
+      quo[2] = (quo[2] << 1) | (quo[1] >> 63); quo[1] = (quo[1] << 1) | (quo[0] >> 63); quo[0] <<= 1;
+      if (bn_ge(rem, Pw)) { bn_sub(rem, Pw); quo[0] |= 1; }
+    }
+    if (quo[2]) FHESI_FAIL("key switch, limb mode: reciprocal of the chain product does not fit 128 bits");
+    std::vector<u64> h(D);
+    h.push_back(quo[0]); h.push_back(quo[1]);
+    if (!k->d_limb_consts) HIP_TRY(hipMalloc(&k->d_limb_consts, (size_t)(L + 8) * 8));
+    HIP_TRY(hipMemcpy(k->d_limb_consts, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+  } else {
+    dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)(2 * ncol * L));
+    ksaux_scatter_kernel<<<grid, 256, 0, ctx->stream>>>((const u64*)tmp, k->d_aux, ncol, L, n, ctx->q[0], ctx->q[1]);
+    HIP_TRY(hipGetLastError());
+  }
   const int* d_slot = (const int*)(k->d_aux_consts + L);
-  const i64 rows_per_a = (i64)L * 2 * ncol;
+  const i64 rows_per_a = (i64)R * 2 * ncol;
   for (int a = 0; a < 2; ++a) FHESI_TRY(launch_ntt_fwd(ctx, k->d_aux + (i64)a * rows_per_a * n, rows_per_a, 1, d_slot + a, !suborder));
   for (int a = 0; a < 2; ++a) {               // tmp (the matrix's own size) takes one auxiliary prime's rows at a time
     u64* half = k->d_aux + (i64)a * rows_per_a * n;
@@ -269,6 +384,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits) {
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));       // one-off: another lane's stream may use the table right away
   k->aux_suborder = suborder;
+  k->aux_rows = R; k->aux_limb_bits = limb ? plan.B : 0; k->aux_logQ = logQ;
   k->aux_valid = true;
   return 0;
 }
@@ -286,7 +402,7 @@ static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig
   }
   const i64 blocks = (i64)8 * ntiles * nsl8 * 2;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot_aux: too many ciphertexts per call");
-  dot_aux_kernel<CT, NW, R><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>(k->d_aux, d_dig, ncol, n, ctx->L, count, d_out, ctx->d_pc, ntiles, nsl8);
+  dot_aux_kernel<CT, NW, R><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>(k->d_aux, d_dig, ncol, n, k->aux_rows, count, d_out, ctx->d_pc, ntiles, nsl8);
   HIP_TRY(hipGetLastError());
   return 0;
 }
