@@ -170,3 +170,37 @@ def test_key_switch_paths_agree(m, logQ, p, monkeypatch):
     stage = ctx.upload(ksm2)
     ctx.dev_copy(ksk.device_ptr, stage.ptr.value, ksm2.nbytes)
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], orc.ct_mul_relin(ksm2, a[0], b[0], logQ, p))
+
+
+@pytest.mark.parametrize("m", [4096, 8192])
+def test_key_switch_limb_mode_edge_values(m):
+    """At n >= 2^11 with the metric chain shape the key switch runs in limb mode (kernels_ksaux.hip + ks_recombine_kernel): the dot
+    product is recombined as an integer and reduced modulo the chain product P exactly.  Crafted key rows make that integer hit the
+    edges of the reduction: 0, +-1, +-(P-1)/2, (P+1)/2 (wraps), P-1, values just inside and outside the centring threshold, and a
+    large multiple pattern; the result must equal the oracle's (toPoly + ReduceCoefficients, FHE-SI.cpp:255-256)."""
+    logQ, p = 512, 23
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 7 + m, 1)
+    n, L = ctx.phim, ctx.L
+    assert L == 18
+    primes = [int(q) for q in ctx.primes]
+    Pprod = 1
+    for q in primes:
+        Pprod *= q
+    mod = 1 << logQ
+    W = L + 2
+    h = (Pprod - 1) // 2
+    edge = [h, -h, h + 1, h - 1, -h + 1, 0, 1, -1, Pprod - 1, h + 2, -h - 2, 12345, -(1 << 600), (1 << 1000) + 17, -(1 << 1050) + 3]
+    # scaled-down parts = (digit value d at coefficient 0, 0, 0): only digit 0 of part 0 is non-zero, so the dot product is d * key row (r, 0)
+    # (at position n-1 the negacyclic wrap turns the products negative: S = -d * e_j)
+    for d, pos in ((1, 0), ((1 << 24) - 1, 0), ((1 << 24) - 1, n - 1), (1, n - 1)):
+        tp = np.zeros((1, 3, L, n), dtype=np.uint64)
+        tp[0, 0] = orc.dcrt_from_poly(O.ints_to_limbs([0] * pos + [d * mod] + [0] * (n - 1 - pos), W))
+        ksm2 = ksm.copy()
+        for r in range(2):
+            e = edge[r:] + edge[:r] + [0] * (n - len(edge))
+            ksm2[r, 0] = orc.dcrt_from_poly(O.ints_to_limbs(e, W))
+        ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm2)
+        dtp = ctx.upload(tp)
+        out = ctx.alloc(2 * n * nl * 8)
+        ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
+        assert np.array_equal(out.download((2, n, nl)), orc.apply_key_switch(ksm2, tp[0], logQ, nl)), (d, pos)
