@@ -473,12 +473,15 @@ def main():
                     "rows_per_launch": round(rows / launches, 1) if launches else None,
                     "row_ntts_per_s": round(rows / (ms * 1e-3), 1) if ms > 0 else None}
     # The dominant kernel of the pipeline is the key-switch dot product through the two auxiliary primes (kernels_ksaux.hip):
-    # algorithmic bytes per launch of c ciphertexts = (digit rows c*ncol*2 + key rows 2*L*2*ncol + output rows c*2*L*2) * n * 8
+    # algorithmic bytes per launch of c ciphertexts = (digit rows c*ncol*2 + key rows 2*R*2*ncol + output rows c*2*R*2) * n * 8
     # (DESIGN.md section 6); it is bound by the VALU (64-bit multiply-adds) and the L2, not by HBM -- the contract's roof is HBM.
     aux = "FHESI_KS_DIRECT" not in os.environ      # the library's A/B switch back to the per-prime dot product
     dl, dunits, dms = prof["dot"]
+    # output rows per (ciphertext, key row, auxiliary prime): the limbs of the key's integer coefficients where the library runs the
+    # key switch in limb mode (ks_limb_plan: 15 at the metric chain shape, 30 at the stress shape), the L residues otherwise
+    R = L if "FHESI_KS_RESIDUES" in os.environ else {(18, 512): 15, (35, 1024): 30}.get((L, LOGQ), L)
     if aux:
-        dbytes = (dunits * (ncol * 2 + 2 * L * 2) + dl * (2 * L * 2 * ncol)) * n * 8
+        dbytes = (dunits * (ncol * 2 + 2 * R * 2) + dl * (2 * R * 2 * ncol)) * n * 8
         dname = "dot_aux_kernel<4, 16, 1>" if ncol * 4 * 512 <= 150 * 1024 else "dot_aux_kernel<2, 16, 2>"
     else:
         dbytes = (dunits * (ncol + 2) * L + dl * (2 * ncol * L)) * n * 8
@@ -518,7 +521,7 @@ def main():
                        if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
                        "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B, "lanes": args.lanes,
                        "fwd_row_ntts_per_mult": (4 * L + 2 * ncol) if aux else (4 + ncol) * L,
-                       "inv_row_ntts_per_mult": (3 * L + 4 * L) if aux else 5 * L,
+                       "inv_row_ntts_per_mult": (3 * L + 4 * R) if aux else 5 * L,
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
             "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_dot": roofline_dot, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
         }
