@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "fhesi_ct_mul_dev", "fhesi_apply_key_switch_dev", "fhesi_dev_alloc", "fhesi_dev_free", "fhesi_dev_upload", "fhesi_dev_download",
     "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
     "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
-    "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp",
+    "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -100,6 +100,7 @@ def _load():
         "fhesi_dcrt_op_scalar": [_vp, _vp, _i32, _i32],
         "fhesi_dcrt_automorph": [_vp, _i64],
         "fhesi_dcrt_exp": [_vp, _i64],
+        "fhesi_selftest_aux32": [_vp],
         "fhesi_dcrt_add_primes": [_vp, _vp, _i32],
         "fhesi_dcrt_remove_primes": [_vp, _vp, _i32],
         "fhesi_dcrt_from_scrt": [_vp, _vp],
@@ -254,6 +255,10 @@ class Context:
         n, u, ms = _i64(0), C.c_double(0), C.c_double(0)
         _ck(_load().fhesi_prof_read(self.h, PROF_CLASSES[cls], C.byref(n), C.byref(u), C.byref(ms)))
         return n.value, u.value, ms.value
+
+    def selftest_aux32(self):
+        """Diagnostic of the 32-bit auxiliary transforms of the key switch (n = 2^14): raises FhesiError on failure."""
+        _ck(_load().fhesi_selftest_aux32(self.h))
 
     def dev_copy(self, dst_ptr: int, src_ptr: int, nbytes: int):
         _ck(_load().fhesi_dev_copy(self.h, _vp(dst_ptr), _vp(src_ptr), nbytes))

@@ -260,6 +260,7 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   for (auto& kv : c->crt_cache) { hipFree(kv.second->d_blob); if (kv.second->d_flags) hipFree(kv.second->d_flags); delete kv.second; }
   for (auto& kv : c->pow64_cache) hipFree(kv.second);
   for (auto& kv : c->scalar_cache) hipFree(kv.second);
+  aux32_free(c);
   for (int i = 0; i < FHESI_WS_SLOTS; ++i) if (c->lane_ws[i]) hipFree(c->lane_ws[i]);
   if (c->lane_stream) hipStreamDestroy(c->lane_stream);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);

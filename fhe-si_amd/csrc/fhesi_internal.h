@@ -58,6 +58,7 @@ struct CrtTables {
 };
 
 struct BluesteinTables;                // general-m path, defined in bluestein.hip
+struct fhesi_aux32;                    // four 30-bit auxiliary primes of the key switch (kernels_aux32.hip), built on first use
 
 // per-kernel-class HIP-event stopwatch (bench.py's live kernel timing; off by default)
 enum { PROF_NTT_FWD = 0, PROF_NTT_INV = 1, PROF_RNS = 2, PROF_TENSOR = 3, PROF_CRT = 4, PROF_DIGITS = 5, PROF_DOT = 6, PROF_EW = 7, PROF_NTT_FWD_DIGITS_MAIN = 8, PROF_NCLASS = 9 };
@@ -92,6 +93,7 @@ struct fhesi_ctx {
   int* d_zms_idx = nullptr;            // [m]
   int* d_zms_list = nullptr;           // [phim] ascending elements of Z_m^*
   BluesteinTables* blue = nullptr;
+  fhesi_aux32* aux32 = nullptr;
   std::map<std::vector<int>, CrtTables*> crt_cache;
   std::map<int, Shoup2*> pow64_cache;  // nlimbs -> device [L][nlimbs+1] table for rns_reduce
   std::map<std::vector<u64>, u64*> scalar_cache;   // rns_reduce lift scalars (per-slot residues), keyed by the scalar list
@@ -138,6 +140,11 @@ struct fhesi_ksk {
 struct KsLimbPlan { int W = 0, LQ = 0, B = 0, NLB = 0, mbits = 0; };
 bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan);
 int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o /* [npolys][aux_rows][2][n] */, i64 npolys, u64* d_out, int nl_out);
+void aux32_free(fhesi_ctx* ctx);
+const u32* aux32_primes(fhesi_ctx* ctx);          // the four primes (host array), nullptr on error
+int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
+int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
+int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* [npolys*nd][4][n] */);
 bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits);
 int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ);
 int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig /* [count*ncol][2][n] */, int ncol, i64 count, u64* d_out /* [count][2][L][2][n] */);

@@ -111,6 +111,9 @@ void* fhesi_ksk_device_ptr(fhesi_ksk* k);                                       
                                                                                         write into the rows (or use fhesi_ksk_upload) */
 size_t fhesi_ksk_bytes(const fhesi_ksk* k);
 
+int fhesi_selftest_aux32(fhesi_ctx* c);                                              /* diagnostic: checks the 32-bit auxiliary transforms of the key switch
+                                                                                        (n = 2^14 only) as a ring isomorphism; 0 = ok */
+
 /* ---- the metric's unit of work, batched: Ciphertext::operator*= (Ciphertext.cpp:167-192) followed by
  * KeySwitchSI::ApplyKeySwitch (FHE-SI.cpp:241-260) = ScaleDown (Ciphertext.cpp:194-218) + ByteDecomp (:82-121)
  * + DotProduct (Util.h:79-98) + toPoly + ReduceCoefficients (Util.cpp:3-33).
