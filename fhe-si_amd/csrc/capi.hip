@@ -826,6 +826,13 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
     void *d_dig, *d_o;
     FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * 2 * n * 8, &d_dig));
     FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * R * 2 * n * 8, &d_o));
+    if (k->aux32) {       // four 30-bit primes (kernels_aux32.hip): the same buffer sizes, u32 rows
+      FHESI_TRY(launch_ntt32_fwd_digits(c, d_parts, nlq, 8 * decomp_bytes, nd, count * ncomp, (u32*)d_dig));
+      if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
+      FHESI_TRY(launch_dot32(c, k, (const u32*)d_dig, ncol, count, (u32*)d_o));
+      FHESI_TRY(launch_ntt32_inv(c, (u32*)d_o, count * 2 * R, 4, 0));
+      return launch_ks_recombine(c, t, k, (const u64*)d_o, count * 2, (u64*)out, nlimbs);
+    }
     FHESI_TRY(launch_ntt_fwd_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig, 0, 2, 2));
     if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
     FHESI_TRY(launch_dot_aux(c, k, (const u64*)d_dig, ncol, count, (u64*)d_o));

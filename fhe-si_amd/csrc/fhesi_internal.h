@@ -135,16 +135,19 @@ struct fhesi_ksk {
   // limb mode (kernels_ksaux.hip): the table is built from the key polynomial's INTEGER coefficients (toPoly over the chain) cut into
   // aux_rows limbs of aux_limb_bits bits instead of from its aux_rows = L chain-prime residues; 0 = residue mode
   int aux_rows = 0, aux_limb_bits = 0, aux_logQ = 0;
+  bool aux32 = false;                  // the table holds residues modulo the four 30-bit primes of kernels_aux32.hip (u32, n = 2^14)
   u64* d_limb_consts = nullptr;        // [W+1] offset constant D, [2] floor(2^(64(W-2)+128) / P), then the quotient bound's bit count
 };
-struct KsLimbPlan { int W = 0, LQ = 0, B = 0, NLB = 0, mbits = 0; };
-bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan);
+struct KsLimbPlan { int W = 0, LQ = 0, B = 0, NLB = 0, mbits = 0; bool a32 = false; };
+bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan, const u32* p32 /* the 30-bit primes, or null */);
 int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o /* [npolys][aux_rows][2][n] */, i64 npolys, u64* d_out, int nl_out);
 void aux32_free(fhesi_ctx* ctx);
 const u32* aux32_primes(fhesi_ctx* ctx);          // the four primes (host array), nullptr on error
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* [npolys*nd][4][n] */);
+int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */);
+int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig /* [count*ncol][4][n] */, int ncol, i64 count, u32* d_out /* [count*2*rows][4][n] */);
 bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits);
 int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ);
 int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig /* [count*ncol][2][n] */, int ncol, i64 count, u64* d_out /* [count][2][L][2][n] */);

@@ -91,22 +91,40 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ r
       a32_ct(r[k], r[k + h], tab[(1 << s) + (k >> (5 - s))], p);
     }
   }
+  const u32 kq = tid >> 4, lo = tid & 15;          // sub-problem and position inside a group of 16 (after the first exchange)
+  // The twiddles of phases B and C differ per lane (2^u of them per thread in stage u).  They are fetched ahead of the exchanges and of
+  // the stages before them, so that no stage waits for an L2 round trip.
+  Tw32 tb[31];                                     // stage u at [2^u - 1, 2^(u+1) - 1)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int i = 0; i < (1 << u); ++i) tb[(1 << u) - 1 + i] = tab[(32 << u) + (kq << u) + i];
 #pragma unroll
   for (int k = 0; k < 32; ++k) lds[k * A32_P + a32_f(tid)] = r[k];
   __syncthreads();
-  const u32 kq = tid >> 4, lo = tid & 15;          // sub-problem and position inside a group of 16
 #pragma unroll
   for (int k2 = 0; k2 < 32; ++k2) r[k2] = lds[kq * A32_P + a32_f(k2 * 16 + lo)];
   // phase B: sub-problem kq (512 elements t = k2 * 16 + lo); distances 16 .. 1 in k2
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
     const int h = 16 >> u;
+    if (u == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tb[15 + i] = tab[(32 << 4) + (kq << 4) + i];
+    }
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
       const int k2 = a32_bfly_k(b, h);
-      a32_ct(r[k2], r[k2 + h], tab[(32 << u) + (kq << u) + (k2 >> (5 - u))], p);
+      a32_ct(r[k2], r[k2 + h], tb[(1 << u) - 1 + (k2 >> (5 - u))], p);
     }
   }
+  Tw32 tc[2][15];                                  // per group: stage v at [2^v - 1, 2^(v+1) - 1)
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int i = 0; i < (1 << v); ++i) tc[gq][(1 << v) - 1 + i] = tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i];
   __syncthreads();
 #pragma unroll
   for (int k2 = 0; k2 < 32; ++k2) lds[kq * A32_P + a32_f(k2 * 16 + lo)] = r[k2];
@@ -117,16 +135,24 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ r
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int h = 8 >> v;
+    if (v == 1) {
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tc[gq][7 + i] = tab[(1024 << 3) + ((kq * 32 + 2 * lo + gq) << 3) + i];
+    }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         const int x = a32_bfly_k(b, h);
-        a32_ct(r[gq * 16 + x], r[gq * 16 + x + h], tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + (x >> (4 - v))], p);
+        a32_ct(r[gq * 16 + x], r[gq * 16 + x + h], tc[gq][(1 << v) - 1 + (x >> (4 - v))], p);
       }
     }
   }
-  u32* __restrict__ o = g + kq * 512 + lo * 32;
+  // digit rows are stored tiled, [prime][64-element slice][unit][64], so that the dot product's tile (one slice of one prime, a run of
+  // units) is one contiguous block; plain rows in place
+  u32* __restrict__ o = DIGITS ? rows + ((((i64)a << (A32_LOGN - 6)) + (kq * 8 + (lo >> 1))) * count + c) * 64 + (lo & 1) * 32 : g + kq * 512 + lo * 32;
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
     u32 v = r[i];
@@ -149,18 +175,38 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_inv_kernel(u32* __restrict__ r
   const u32* __restrict__ in = g + kq * 512 + lo * 32;
 #pragma unroll
   for (int i = 0; i < 32; ++i) r[i] = in[i];
+  Tw32 tc[2][15];                                  // the per-lane twiddles are fetched ahead (see the forward kernel)
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int v = 2; v < 4; ++v)
+#pragma unroll
+      for (int i = 0; i < (1 << v); ++i) tc[gq][(1 << v) - 1 + i] = tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i];
 #pragma unroll
   for (int v = 3; v >= 0; --v) {
     const int h = 8 >> v;
+    if (v == 2) {
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int vv = 0; vv < 2; ++vv)
+#pragma unroll
+          for (int i = 0; i < (1 << vv); ++i) tc[gq][(1 << vv) - 1 + i] = tab[(1024 << vv) + ((kq * 32 + 2 * lo + gq) << vv) + i];
+    }
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         const int x = a32_bfly_k(b, h);
-        a32_gs(r[gq * 16 + x], r[gq * 16 + x + h], tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + (x >> (4 - v))], p);
+        a32_gs(r[gq * 16 + x], r[gq * 16 + x + h], tc[gq][(1 << v) - 1 + (x >> (4 - v))], p);
       }
     }
   }
+  Tw32 tb[31];
+#pragma unroll
+  for (int u = 3; u < 5; ++u)
+#pragma unroll
+    for (int i = 0; i < (1 << u); ++i) tb[(1 << u) - 1 + i] = tab[(32 << u) + (kq << u) + i];
 #pragma unroll
   for (int i = 0; i < 32; ++i) lds[kq * A32_P + lo * 36 + i] = r[i];
   __syncthreads();
@@ -169,10 +215,16 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_inv_kernel(u32* __restrict__ r
 #pragma unroll
   for (int u = 4; u >= 0; --u) {
     const int h = 16 >> u;
+    if (u == 3) {
+#pragma unroll
+      for (int uu = 0; uu < 3; ++uu)
+#pragma unroll
+        for (int i = 0; i < (1 << uu); ++i) tb[(1 << uu) - 1 + i] = tab[(32 << uu) + (kq << uu) + i];
+    }
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
       const int k2 = a32_bfly_k(b, h);
-      a32_gs(r[k2], r[k2 + h], tab[(32 << u) + (kq << u) + (k2 >> (5 - u))], p);
+      a32_gs(r[k2], r[k2 + h], tb[(1 << u) - 1 + (k2 >> (5 - u))], p);
     }
   }
   __syncthreads();
@@ -259,7 +311,7 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
   HIP_TRY(hipGetLastError());
   return 0;
 }
-// digit rows [npolys * nd][4][n] u32 straight from the scaled-down parts
+// digit rows, tiled [4][n/64][npolys * nd][64] u32, straight from the scaled-down parts
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out) {
   FHESI_TRY(aux32_init(ctx));
   if (!npolys) return 0;
@@ -270,6 +322,181 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   return 0;
 }
 const u32* aux32_primes(fhesi_ctx* ctx) { return aux32_init(ctx) ? nullptr : ctx->aux32->pr.p; }
+
+// ---------------------------------------------------------------------------------------------- key table and dot product
+// kint [2*ncol][n][W]: the key's integer coefficients;  rows32[a][(l*2 + r)*ncol + k][n] = (limb l of B bits) mod p_a
+__global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __restrict__ kint, u32* __restrict__ rows32, int ncol, int NLB, int B, int W, Aux32Primes pr) {
+  const i64 row = blockIdx.y;                 // (r * ncol + k) * NLB + l
+  const int l = (int)(row % NLB);
+  const i64 rk = row / NLB;
+  const int k = (int)(rk % ncol), r = (int)(rk / ncol);
+  const int s = B * l, wd = s >> 6, bt = s & 63;
+  const i64 rows_per_a = (i64)NLB * 2 * ncol;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < A32_N; j += (i64)gridDim.x * blockDim.x) {
+    const u64* x = kint + (rk * A32_N + j) * W;
+    auto word = [&](int i) -> u64 { return i < W ? x[i] : 0; };
+    const u64 w0 = word(wd), w1 = word(wd + 1), w2 = word(wd + 2);
+    const u64 lo = bt ? ((w0 >> bt) | (w1 << (64 - bt))) : w0;
+    u64 hi = bt ? ((w1 >> bt) | (w2 << (64 - bt))) : w1;
+    hi &= ((u64)1 << (B - 64)) - 1;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const u64 p = pr.p[a];
+      const u64 r64 = (u64)(((u128)1 << 64) % p);
+      rows32[((i64)a * rows_per_a + ((i64)l * 2 + r) * ncol + k) * A32_N + j] = (u32)((lo % p + (hi % p) * r64) % p);
+    }
+  }
+}
+// rows of one prime [(l*2 + r)*ncol + k][n]  ->  tiled [l][slice][r][k][64]
+__global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict__ src, u32* __restrict__ dst, int ncol) {
+  const i64 row = blockIdx.y;
+  const int k = (int)(row % ncol);
+  const i64 lr = row / ncol;
+  const int r = (int)(lr & 1);
+  const i64 l = lr >> 1;
+  const i64 nsl = A32_N >> 6;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < A32_N; j += (i64)gridDim.x * blockDim.x)
+    dst[((((l * nsl + (j >> 6)) * 2 + r) * ncol + k) << 6) + (j & 63)] = src[row * A32_N + j];
+}
+
+// O[ct][r][l][a][slice] = sum_k D[ct][k][a][slice] * K[a][l][r][k][slice]  mod p_a.   One workgroup = a 64-element slice of CT
+// ciphertexts for one prime; the digit slices (reduced below p) sit in LDS, every wave walks its share of the (limb, key row)
+// pairs.  Products are below 2^60: 16 columns accumulate in a plain 64-bit v_mad_u64_u32 chain, groups are added into a 64-bit
+// total with a carry counter, one reduction per output.
+template <int CT, int NW>
+__global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
+                                                        u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8) {
+  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
+  static_assert(CT % 4 == 0, "ciphertexts per tile in fours (16-byte LDS reads)");
+  const u32 lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32 b = blockIdx.x;
+  const u32 s_lo = b & 7; b >>= 3;
+  const u32 tile = b % (u32)ntiles; b /= (u32)ntiles;
+  const u32 s_hi = b % (u32)nsl8;
+  const int a = (int)(b / (u32)nsl8);
+  const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64;
+  const i64 ct0 = (i64)tile * CT;
+  const u32 p = pr.p[a], twop = 2 * p;
+#define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
+  // tile load: the CT ciphertexts' ncol digit slices are one contiguous run of the tiled digit rows; CT wave-loads in flight per wave
+  const u32* dtile = dig + ((((i64)a << (A32_LOGN - 6)) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
+  for (int k = w; k < ncol; k += NW) {            // (no division by the run-time column count in this loop: it would be scalar code per element)
+    u32 v[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) v[c] = ct0 + c < count ? __builtin_nontemporal_load(&dtile[((i64)c * ncol + k) << 6]) : 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      u32 x = v[c];
+      x = x >= twop ? x - twop : x;
+      x = x >= p ? x - p : x;
+      dl32[DL32(k, c)] = x;
+    }
+  }
+  __syncthreads();
+  const u64 pinv = ~(u64)0 / p;                      // floor((2^64 - 1) / p)
+  const u64 r64 = (u64)(((u128)1 << 64) % p);
+  // one (limb, key row) pair per wave and pass; the 16 key words of the next column group are fetched while this one is multiplied
+  for (int pr_i = w; pr_i < NLB * 2; pr_i += NW) {
+    const int l = pr_i >> 1, r = pr_i & 1;
+    const u32* kp = k32 + ((((((i64)a * NLB + l) * (A32_N >> 6) + slice) * 2 + r) * ncol) << 6) + lane;
+    u64 tl[CT];
+    u32 th[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { tl[c] = 0; th[c] = 0; }
+    const int nfull = ncol & ~15;
+    u32 xc[16], xn[16];
+    if (nfull) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) xc[u] = kp[u << 6];
+    }
+    for (int kb = 0; kb < nfull; kb += 16) {
+      if (kb + 16 < nfull) {
+        const u32* pk = kp + ((kb + 16) << 6);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xn[u] = pk[u << 6];
+      }
+      u64 acc[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[c] = 0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] += (u64)xc[u] * dl32[DL32(kb + u, c)];
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) { const u64 t = tl[c] + acc[c]; th[c] += t < acc[c] ? 1u : 0u; tl[c] = t; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) xc[u] = xn[u];
+    }
+    if (nfull < ncol) {
+      u64 acc[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[c] = 0;
+      for (int k = nfull; k < ncol; ++k) {
+        const u32 x = kp[k << 6];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] += (u64)x * dl32[DL32(k, c)];
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) { const u64 t = tl[c] + acc[c]; th[c] += t < acc[c] ? 1u : 0u; tl[c] = t; }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      if (ct0 + c < count) {
+        // (th 2^64 + tl) mod p
+        u64 v = tl[c] - __umul64hi(tl[c], pinv) * p;          // below 2p + small
+        v += (u64)th[c] * r64;                                // th < 2^5, r64 < 2^30
+        v = v - __umul64hi(v, pinv) * p;
+        u32 o = (u32)v;
+        o = o >= twop ? o - twop : o;
+        o = o >= p ? o - p : o;
+        (out + ((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) * A32_N + soff)[lane] = o;
+      }
+    }
+  }
+#undef DL32
+}
+
+int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp) {
+  FHESI_TRY(aux32_init(ctx));
+  const int ncol = k->ncomp * k->ndigits;
+  const i64 rows_per_a = (i64)NLB * 2 * ncol;
+  u32* rows32 = (u32*)k->d_aux;
+  if ((size_t)4 * rows_per_a * A32_N * 4 > 2 * k->bytes) FHESI_FAIL("aux32: key table does not fit");
+  dim3 grid(64, (unsigned)(2 * ncol * NLB));
+  ks32_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(d_kint, rows32, ncol, NLB, B, W, ctx->aux32->pr);
+  HIP_TRY(hipGetLastError());
+  for (int a = 0; a < 4; ++a) FHESI_TRY(launch_ntt32_fwd(ctx, rows32 + (i64)a * rows_per_a * A32_N, rows_per_a, 1, a));
+  for (int a = 0; a < 4; ++a) {
+    u32* q = rows32 + (i64)a * rows_per_a * A32_N;
+    HIP_TRY(hipMemcpyAsync(d_tmp, q, (size_t)rows_per_a * A32_N * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    dim3 g2(64, (unsigned)rows_per_a);
+    ks32_retile_kernel<<<g2, 256, 0, ctx->stream>>>((const u32*)d_tmp, q, ncol);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+// d_dig: tiled [4][n/64][count*ncol][64] u32; d_out: [count*2*NLB][4][n] u32
+int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
+  if (!count) return 0;
+  if (ncol > 255) FHESI_FAIL("dot32: %d columns", ncol);
+  ProfScope prof(ctx, PROF_DOT, (double)count);
+  constexpr int CT = 8, NW = 16;
+  const size_t shmem = (size_t)ncol * CT * 64 * 4;
+  if (shmem > 160 * 1024) FHESI_FAIL("dot32: %d columns do not fit the LDS tile", ncol);
+  static unsigned long long attr_done = 0;
+  if (!(attr_done >> ctx->device & 1)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done |= 1ull << ctx->device;
+  }
+  const int ntiles = (int)((count + CT - 1) / CT), nsl8 = A32_N / 64 / 8;
+  const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
+  dot32_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 
 // Self-test (tests/test_gpu_ntt.py): the transform pair is a ring isomorphism of Z_p[X]/(X^n + 1) -- it is linear by construction, so
 // checking that monomials multiply like monomials (X^i X^j = +-X^(i+j mod n)) and that inverse(forward(x)) = x pins it.

@@ -587,10 +587,15 @@ static int launch_crt_sum(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows,
 //   x = D + sum_l (V_l + 2^119) 2^(B l)  with  D = 2^m P - sum_l 2^(119 + B l)  (host constant), so x = S + 2^m P in (0, 2^(m+1) P);
 //   quotient estimate from the top two limbs and floor(2^(64(W-2)+128) / P) (never above, at most 2 below), remainder, at most two
 //   corrections, centring -- all exact integer arithmetic on W + 1 limbs -- then the mode-2 store of the sum-form kernel.
-template <int W, int LQ, int B, int NLB>
+// A32: the residues are those of the four 30-bit auxiliary primes (kernels_aux32.hip), [poly][NLB][4][n] u32, recombined by Garner's
+// mixed radix with the constants of Garner32; otherwise the two 60-bit chain primes, [poly][NLB][2][n] u64.
+struct Garner32 { u32 p[4]; u32 c[6], cp[6]; };      // c = {p0^-1 mod p1, p0^-1 mod p2, p1^-1 mod p2, p0^-1 mod p3, p1^-1 mod p3, p2^-1 mod p3} and floor(c 2^32 / p_j)
+__device__ __forceinline__ u32 g32_mul(u32 y, u32 c, u32 cp, u32 p) { const u32 r = y * c - __umulhi(y, cp) * p; return r >= p ? r - p : r; }     // y any u32 -> [0, p)
+__device__ __forceinline__ u32 g32_sub(u32 a, u32 b, u32 p) { b = b >= p ? b - p : b; return a >= b ? a - b : a + p - b; }                     // a in [0, p), b below 2p
+template <int W, int LQ, int B, int NLB, bool A32>
 __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict__ o, i64 n, u64 q0, u64 q1, u64 q0inv, u64 q0inv_sh, u64 half_hi, u64 half_lo,
                                                            u64 a_hi, u64 a_lo, const u64* __restrict__ consts /* D[W+1], pinv lo, hi */,
-                                                           const u64* __restrict__ Pfull, const u64* __restrict__ halfP, u64* __restrict__ out, int nl_out) {
+                                                           const u64* __restrict__ Pfull, const u64* __restrict__ halfP, u64* __restrict__ out, int nl_out, Garner32 gc) {
   const i64 poly = blockIdx.y;
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -599,12 +604,25 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
   for (int i = 0; i <= W; ++i) x[i] = consts[i];
   const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
   const u64* base = o + poly * NLB * 2 * n + j;
+  const u32* base32 = reinterpret_cast<const u32*>(o) + poly * NLB * 4 * n + j;
 #pragma unroll
   for (int l = 0; l < NLB; ++l) {
+    u128 V;
+    if (A32) {
+      const u32 v0 = base32[(i64)(l * 4 + 0) * n], v1 = base32[(i64)(l * 4 + 1) * n], v2 = base32[(i64)(l * 4 + 2) * n], v3 = base32[(i64)(l * 4 + 3) * n];
+      const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
+      const u32 x1 = v0;                                                        // all four primes lie in (2^29, 2^30): a residue of one is below twice any other
+      const u32 x2 = g32_mul(g32_sub(v1, x1, p1), gc.c[0], gc.cp[0], p1);
+      const u32 x3 = g32_mul(g32_sub(g32_mul(g32_sub(v2, x1, p2), gc.c[1], gc.cp[1], p2), x2, p2), gc.c[2], gc.cp[2], p2);
+      const u32 x4 = g32_mul(g32_sub(g32_mul(g32_sub(g32_mul(g32_sub(v3, x1, p3), gc.c[3], gc.cp[3], p3), x2, p3), gc.c[4], gc.cp[4], p3), x3, p3),
+                             gc.c[5], gc.cp[5], p3);
+      V = (u128)((u64)x3 + (u64)p2 * x4) * ((u64)p0 * p1) + ((u64)x1 + (u64)p0 * x2);       // x1 + p0 (x2 + p1 (x3 + p2 x4)), below p0 p1 p2 p3
+    } else {
     const u64 v0 = base[(i64)(l * 2 + 0) * n], v1 = base[(i64)(l * 2 + 1) * n];
     const u64 v0r = v0 >= q1 ? v0 - q1 : v0;
     const u64 t = d_shoup(d_submod(v1, v0r, q1), q0inv, q0inv_sh, q1);
-    u128 V = (u128)q0 * t + v0;                                  // in [0, q_0 q_1)
+    V = (u128)q0 * t + v0;                                       // in [0, q_0 q_1)
+    }
     if (V > half) V -= A;                                        // centred (two's complement in 128 bits)
     V += (u128)1 << 119;                                         // non-negative, below 2^120
     const int s = B * l, wd = s >> 6, bt = s & 63;               // compile-time after unrolling
@@ -665,22 +683,36 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
   crt_store_fixed<W, W, LQ>(y, 2, out, poly, n, j, nl_out);
 }
 
-template <int W, int LQ, int B, int NLB>
+template <int W, int LQ, int B, int NLB, bool A32>
 static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
   const u64 q0 = ctx->q[0], q1 = ctx->q[1];
   const u64 inv = hm::invmod(q0 % q1, q1);
-  const u128 A = (u128)q0 * q1, half = (A - 1) / 2;
+  u128 A = (u128)q0 * q1;
+  Garner32 gc{};
+  if (A32) {
+    const u32* p = aux32_primes(ctx);
+    if (!p) return 1;
+    for (int i = 0; i < 4; ++i) gc.p[i] = p[i];
+    const int pairs[6][2] = {{0, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {2, 3}};
+    for (int e = 0; e < 6; ++e) {
+      const u64 pj = p[pairs[e][1]], c = hm::invmod(p[pairs[e][0]] % pj, pj);
+      gc.c[e] = (u32)c; gc.cp[e] = (u32)((c << 32) / pj);
+    }
+    A = (u128)((u64)p[0] * p[1]) * ((u64)p[2] * p[3]);
+  }
+  const u128 half = (A - 1) / 2;
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
-  ks_recombine_kernel<W, LQ, B, NLB><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, q0, q1, inv, hm::shoup(inv, q1), (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A,
-                                                                     k->d_limb_consts, t->d_P + (size_t)t->nidx * t->W, t->d_halfP, d_out, nl_out);
+  ks_recombine_kernel<W, LQ, B, NLB, A32><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, q0, q1, inv, hm::shoup(inv, q1), (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A,
+                                                                          k->d_limb_consts, t->d_P + (size_t)t->nidx * t->W, t->d_halfP, d_out, nl_out, gc);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
   if (!npolys) return 0;
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
-  if (t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15>(ctx, t, k, d_o, npolys, d_out, nl_out);
-  if (t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30) return launch_ks_recombine_t<34, 1024, 72, 30>(ctx, t, k, d_o, npolys, d_out, nl_out);
+  if (k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 73 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 73, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
+  if (!k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, false>(ctx, t, k, d_o, npolys, d_out, nl_out);
+  if (!k->aux32 && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30) return launch_ks_recombine_t<34, 1024, 72, 30, false>(ctx, t, k, d_o, npolys, d_out, nl_out);
   FHESI_FAIL("key switch, limb mode: no recombination kernel for W=%d logQ=%d B=%d rows=%d", t->W, k->aux_logQ, k->aux_limb_bits, k->aux_rows);
 }
 

@@ -262,10 +262,16 @@ bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits) {
 // Limb mode is used where a recombination kernel is compiled (launch_ks_recombine): the metric chain shape (17-limb product,
 // logQ = 512: 15 limbs of 74 bits instead of 18 residues) and the stress shape (33-limb product, logQ = 1024: 30 limbs of 72 bits
 // instead of 35 residues).  Conditions: every limb product sum stays below q_0 q_1 / 2, the limbs cover P, and |S| < 2^m P.
-bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan) {
+bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan, const u32* p32) {
   if (getenv("FHESI_KS_RESIDUES")) return false;               // A/B switch: residue mode
   KsLimbPlan p;
-  if (t->W == 18 && logQ == 512) { p.W = 18; p.LQ = 512; p.B = 74; p.NLB = 15; }
+  u128 A = (u128)ctx->q[0] * ctx->q[1];
+  // n = 2^14 at the metric chain shape: the four 30-bit primes of kernels_aux32.hip carry the limb products (FHESI_KS_AUX60=1: A/B switch)
+  if (p32 && ctx->logn == 14 && t->W == 18 && logQ == 512 && !getenv("FHESI_KS_AUX60")) {
+    p.W = 18; p.LQ = 512; p.B = 73; p.NLB = 15; p.a32 = true;
+    A = (u128)((u64)p32[0] * p32[1]) * ((u64)p32[2] * p32[3]);
+  }
+  else if (t->W == 18 && logQ == 512) { p.W = 18; p.LQ = 512; p.B = 74; p.NLB = 15; }
   else if (t->W == 34 && logQ == 1024) { p.W = 34; p.LQ = 1024; p.B = 72; p.NLB = 30; }
   else return false;
   if (t->nidx != ctx->L) return false;
@@ -274,8 +280,7 @@ bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_
   int pbits = (int)(P.size() - 1) * 64;
   for (u64 top = P.back(); top; top >>= 1) ++pbits;
   if (p.NLB * p.B < pbits || (p.NLB - 1) * p.B + 120 > 64 * (p.W + 1)) return false;
-  const u128 A = (u128)ctx->q[0] * ctx->q[1];
-  if (A >> 119 > 1) return false;                               // the +2^119 offset needs q_0 q_1 < 2^120
+  if (A >> 119 > 1) return false;                               // the +2^119 offset needs the auxiliary modulus below 2^120
   const u128 terms = (u128)ncol * (u128)ctx->phim << digit_bits;      // ncol * n * 2^digit_bits
   if (terms >> 50) return false;
   if (((A / 2) >> p.B) <= terms) return false;                  // |V_l| <= terms * 2^B < q_0 q_1 / 2
@@ -316,7 +321,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
   CrtTables* t;
   FHESI_TRY(get_crt_tables(ctx, all, &t));
   KsLimbPlan plan;
-  const bool limb = ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan);
+  const bool limb = ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, ctx->logn == 14 ? aux32_primes(ctx) : nullptr);
   const int R = limb ? plan.NLB : L;                          // output rows per (ciphertext, key row, auxiliary prime)
   if (!k->d_aux) HIP_TRY(hipMalloc(&k->d_aux, 2 * k->bytes));
   if (!k->d_aux_consts) {
@@ -337,7 +342,8 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
     u64* kint = nullptr;                                        // the key's integer coefficients: one-off scratch
     HIP_TRY(hipMalloc(&kint, (size_t)2 * ncol * n * W * 8));
     int rc = launch_crt(ctx, t, (const u64*)tmp, L, nullptr, 2 * ncol, 0, 1, 0, kint, W);
-    if (!rc) {
+    if (!rc && plan.a32) rc = ks32_build(ctx, k, kint, W, plan.B, R, tmp);
+    else if (!rc) {
       dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)(2 * ncol * R));
       ks_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(kint, k->d_aux, ncol, R, plan.B, W, n, ctx->q[0], ctx->q[1]);
       if (hipGetLastError() != hipSuccess) rc = 1;
@@ -372,10 +378,12 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
     ksaux_scatter_kernel<<<grid, 256, 0, ctx->stream>>>((const u64*)tmp, k->d_aux, ncol, L, n, ctx->q[0], ctx->q[1]);
     HIP_TRY(hipGetLastError());
   }
+  k->aux32 = limb && plan.a32;
   const int* d_slot = (const int*)(k->d_aux_consts + L);
   const i64 rows_per_a = (i64)R * 2 * ncol;
+  if (!k->aux32)
   for (int a = 0; a < 2; ++a) FHESI_TRY(launch_ntt_fwd(ctx, k->d_aux + (i64)a * rows_per_a * n, rows_per_a, 1, d_slot + a, !suborder));
-  for (int a = 0; a < 2; ++a) {               // tmp (the matrix's own size) takes one auxiliary prime's rows at a time
+  for (int a = 0; a < 2 && !k->aux32; ++a) {   // tmp (the matrix's own size) takes one auxiliary prime's rows at a time
     u64* half = k->d_aux + (i64)a * rows_per_a * n;
     HIP_TRY(hipMemcpyAsync(tmp, half, (size_t)rows_per_a * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     dim3 g2((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)rows_per_a);

@@ -172,7 +172,7 @@ def test_key_switch_paths_agree(m, logQ, p, monkeypatch):
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], orc.ct_mul_relin(ksm2, a[0], b[0], logQ, p))
 
 
-@pytest.mark.parametrize("m", [4096, 8192])
+@pytest.mark.parametrize("m", [4096, 8192, 32768])       # 32768: n = 2^14, the four 30-bit auxiliary primes (kernels_aux32.hip)
 def test_key_switch_limb_mode_edge_values(m):
     """At n >= 2^11 with the metric chain shape the key switch runs in limb mode (kernels_ksaux.hip + ks_recombine_kernel): the dot
     product is recombined as an integer and reduced modulo the chain product P exactly.  Crafted key rows make that integer hit the
