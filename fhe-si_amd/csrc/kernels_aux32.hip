@@ -16,7 +16,7 @@
 #include "fhesi_internal.h"
 
 struct Tw32 { u32 w, wp; };          // constant and floor(w 2^32 / p)
-struct Aux32Primes { u32 p[4]; u32 ninv[4], ninv_p[4]; };
+struct Aux32Primes { u32 p[4]; u32 ninv[4], ninv_p[4]; u64 pinv64[4] /* floor((2^64 - 1) / p) */, r64[4] /* 2^64 mod p */; };
 
 struct fhesi_aux32 {
   Aux32Primes pr;
@@ -282,6 +282,8 @@ static int aux32_init(fhesi_ctx* ctx) {
     const u64 ninv = hm::invmod(A32_N % p, p);
     x->pr.ninv[a] = (u32)ninv;
     x->pr.ninv_p[a] = (u32)((ninv << 32) / p);
+    x->pr.pinv64[a] = ~(u64)0 / p;
+    x->pr.r64[a] = (u64)(((u128)1 << 64) % p);
   }
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
   HIP_TRY(hipMemcpy(x->d_fwd, hf.data(), hf.size() * sizeof(Tw32), hipMemcpyHostToDevice));
@@ -394,8 +396,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ 
     }
   }
   __syncthreads();
-  const u64 pinv = ~(u64)0 / p;                      // floor((2^64 - 1) / p)
-  const u64 r64 = (u64)(((u128)1 << 64) % p);
+  const u64 pinv = pr.pinv64[a], r64 = pr.r64[a];   // (host constants: a 128-bit division here would be hundreds of scalar instructions per wave)
   // one (limb, key row) pair per wave and pass; the 16 key words of the next column group are fetched while this one is multiplied
   for (int pr_i = w; pr_i < NLB * 2; pr_i += NW) {
     const int l = pr_i >> 1, r = pr_i & 1;
