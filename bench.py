@@ -437,8 +437,11 @@ def main():
     # live per-kernel timing of the timed region (HIP events on the context's stream)
     prof = {k: ctx.prof_read(k) for k in F.binding.PROF_CLASSES}
     ctx.prof_enable(False)
-    launches, rows, ms = prof["ntt_fwd_digits_main"]       # the dominant kernel: fused ByteDecomp + forward NTT, rows of the 60-bit primes
-    row_bytes = 2 * n * 8                                   # row read once + written once
+    launches, rows, ms = prof["ntt_fwd_digits_main"]       # fused ByteDecomp + forward NTT of the digit polynomials
+    # n = 2^14 at the metric chain shape: the digit rows are transformed modulo four 30-bit primes (kernels_aux32.hip): 4-byte residues
+    aux32 = (n == (1 << 14) and L == 18 and LOGQ == 512 and not args.ntt_rows
+             and not any(v in os.environ for v in ("FHESI_KS_DIRECT", "FHESI_KS_RESIDUES", "FHESI_KS_AUX60")))
+    row_bytes = 2 * n * (4 if aux32 else 8)                 # row read once + written once
     if args.ntt_rows:
         # optional standalone measurement on a fixed row count
         cnt = max(1, args.ntt_rows // L)
@@ -463,14 +466,16 @@ def main():
     if args.workload != "metric" or args.ntt_rows:
         traffic = None          # the PMC passes in profiles/ were taken on the metric workload's launch shape
     # template parameters <LOGN, DIGITS, S0, CONTIG>; rows of 2^15 points: the head-fused sub-transform kernel (S0 = 1, CONTIG)
-    if ctx.phim > (1 << 14):
+    if aux32:
+        kname = "ntt32_fwd_kernel<true>"
+    elif ctx.phim > (1 << 14):
         kname = "ntt_fwd_tile<14, false, 1, false>" if args.ntt_rows else "ntt_fwd_tile<14, true, 1, true>"
     else:
         kname = "ntt_fwd_tile<14, %s, 0, false>" % ("false" if args.ntt_rows else "true")
     roofline_ntt = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
-                    "rows_per_launch": round(rows / launches, 1) if launches else None,
+                    "rows_per_launch": round(rows / launches, 1) if launches else None, "row_bytes": row_bytes // 2,
                     "row_ntts_per_s": round(rows / (ms * 1e-3), 1) if ms > 0 else None}
     # The dominant kernel of the pipeline is the key-switch dot product through the two auxiliary primes (kernels_ksaux.hip):
     # algorithmic bytes per launch of c ciphertexts = (digit rows c*ncol*2 + key rows 2*R*2*ncol + output rows c*2*R*2) * n * 8
@@ -482,7 +487,7 @@ def main():
     R = L if "FHESI_KS_RESIDUES" in os.environ else {(18, 512): 15, (35, 1024): 30}.get((L, LOGQ), L)
     if aux:
         dbytes = (dunits * (ncol * 2 + 2 * R * 2) + dl * (2 * R * 2 * ncol)) * n * 8
-        dname = "dot_aux_kernel<4, 16, 1>" if ncol * 4 * 512 <= 150 * 1024 else "dot_aux_kernel<2, 16, 2>"
+        dname = "dot32_kernel<8, 16>" if aux32 else ("dot_aux_kernel<4, 16, 1>" if ncol * 4 * 512 <= 150 * 1024 else "dot_aux_kernel<2, 16, 2>")
     else:
         dbytes = (dunits * (ncol + 2) * L + dl * (2 * ncol * L)) * n * 8
         dname = "dot_accum_kernel<2, %s>" % ("true" if ctx.phim > (1 << 14) else "false")
@@ -520,8 +525,9 @@ def main():
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
                        if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
                        "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B, "lanes": args.lanes,
-                       "fwd_row_ntts_per_mult": (4 * L + 2 * ncol) if aux else (4 + ncol) * L,
-                       "inv_row_ntts_per_mult": (3 * L + 4 * R) if aux else 5 * L,
+                       "fwd_row_ntts_per_mult": (4 * L + (4 if aux32 else 2) * ncol) if aux else (4 + ncol) * L,
+                       "inv_row_ntts_per_mult": (3 * L + (8 if aux32 else 4) * R) if aux else 5 * L,
+                       "key_switch": ("4 x 30-bit auxiliary primes, 15 limbs" if aux32 else "2 x 60-bit auxiliary primes") if aux else "per chain prime",
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
             "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_dot": roofline_dot, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
         }
