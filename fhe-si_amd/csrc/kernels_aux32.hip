@@ -54,8 +54,17 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ r
                                                              Dig32Src ds) {
   __shared__ u32 lds[32 * A32_P];
   const u32 tid = threadIdx.x;
-  const i64 c = blockIdx.x % count;
-  const int slot = (int)(blockIdx.x / count), a = a0 + slot;
+  i64 c = blockIdx.x % count;
+  int slot = (int)(blockIdx.x / count);
+  if (DIGITS) {
+    // the four transforms of a digit polynomial read the same source words: keep them on one XCD (block ids 8 apart) and close in
+    // time, so that the source leaves HBM once instead of once per prime (the four twiddle tables, 512 KiB, fit every L2)
+    const u32 bid = blockIdx.x;
+    slot = (int)((bid >> 3) & 3);
+    c = (i64)(bid >> 5) * 8 + (bid & 7);
+    if (c >= count) return;
+  }
+  const int a = a0 + slot;
   const u32 p = pr.p[a];
   const Tw32* __restrict__ tab = tabs + (i64)a * A32_N;
   u32* __restrict__ g = rows + (c * nslots + slot) * A32_N;
@@ -319,7 +328,8 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   if (!npolys) return 0;
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * 4));
   ProfScope main_prof(ctx, PROF_NTT_FWD_DIGITS_MAIN, (double)(npolys * nd * 4));
-  ntt32_fwd_kernel<true><<<(unsigned)(npolys * nd * 4), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd});
+  const i64 units = npolys * nd;
+  ntt32_fwd_kernel<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd});
   HIP_TRY(hipGetLastError());
   return 0;
 }
