@@ -129,7 +129,7 @@ struct fhesi_ksk {
   u64* d_rows = nullptr;               // [2][ncomp*ndigits][L][phim]
   size_t bytes = 0;
   // derived table of the two-auxiliary-prime dot product (kernels_ksaux.hip), rebuilt on the device when the rows changed
-  u64* d_aux = nullptr;                // [2 aux][L][2][ncomp*ndigits][phim]
+  u64* d_aux = nullptr;                // [2 aux][aux_rows][n/64][2][ncomp*ndigits][64] split 60-bit words, or (aux32) [4][aux_rows][n/64][2][ncol][64] u32
   u64* d_aux_consts = nullptr;         // [L] q_0 q_1 mod q_i, then the int pair {0, 1} (prime_of_slot of auxiliary rows)
   bool aux_valid = false, aux_suborder = false;
   // limb mode (kernels_ksaux.hip): the table is built from the key polynomial's INTEGER coefficients (toPoly over the chain) cut into

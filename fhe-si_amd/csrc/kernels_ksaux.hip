@@ -13,6 +13,13 @@
 //     back:    iNTT_a, then V = CRT(O[..][0], O[..][1]) centred modulo q_0 q_1, then V mod q_i    (aux_crt_kernel)
 // and V mod q_i is, coefficient by coefficient, exactly what toPoly of the reference's dot product holds modulo q_i -- the rows the
 // final intVecCRT (kernels_crt.hip) takes.  Same bits, 2 (nd ncomp) + 2 L 2 row transforms instead of (nd ncomp) L + 2 L.
+//
+// That is the RESIDUE mode (index i = chain prime).  In LIMB mode (ks_limb_plan: the metric and stress chain shapes) the table is
+// built from the key polynomial's integer coefficients in [0, P) instead (toPoly over the chain, once per matrix), cut into limbs of
+// B bits: index i = limb, 15 x 74 bits instead of 18 residues at the metric ring, and the closing step is ks_recombine_kernel
+// (kernels_crt.hip): S = sum_l V_l 2^(B l), reduced modulo P exactly.  At n = 2^14 the limb products are carried by four 30-bit
+// primes instead of q_0, q_1 (kernels_aux32.hip: own 32-bit transforms, one multiply per multiply-add); this file then only plans
+// and builds.  Switches for A/B runs: FHESI_KS_DIRECT (per-prime dot product), FHESI_KS_RESIDUES, FHESI_KS_AUX60.
 #include "fhesi_internal.h"
 #include <cmath>
 
