@@ -204,3 +204,20 @@ def test_key_switch_limb_mode_edge_values(m):
         out = ctx.alloc(2 * n * nl * 8)
         ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
         assert np.array_equal(out.download((2, n, nl)), orc.apply_key_switch(ksm2, tp[0], logQ, nl)), (d, pos)
+
+
+def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
+    """BASELINE.json's metric configuration at the bench's batch size: the three device forms of the key switch -- four 30-bit auxiliary
+    primes (default at n = 2^14), two 60-bit auxiliary primes in limb mode, and the per-prime dot product of the reference's structure --
+    must produce the same 2 x 64 x 16384 coefficients (the oracle is too slow for 64 ciphertexts; one of them is checked against it in
+    test_mul_relin_stages_and_end_to_end)."""
+    m, logQ, p, count = 32768, 512, 23, 64
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 4242, count)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    ref = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    for env in ("FHESI_KS_AUX60", "FHESI_KS_RESIDUES", "FHESI_KS_DIRECT"):
+        monkeypatch.setenv(env, "1")
+        ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)        # a fresh matrix: the derived table is built for the selected form
+        assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), env
+        monkeypatch.delenv(env)
+    assert np.array_equal(ref[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
