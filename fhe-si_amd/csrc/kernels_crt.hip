@@ -94,14 +94,21 @@ __global__ void __launch_bounds__(256) rns_reduce_kernel_t(const u64* __restrict
     const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
     const PrimeConst pc = pcs[prime];
     // pows[class][prime][k] = s * 2^(64k) mod q: the word scalar s of the polynomial's class (the `poly * p` lift) is folded into the table
-    const u64* pw = pows + (poly % npoly_mod) * pow_poly_stride + (i64)prime * (NL + 1);
+    const u64* pw = pows + (poly % npoly_mod) * pow_poly_stride + (i64)prime * (NL + 3);
     u128 acc = 0;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       acc += (u128)x[k] * pw[k];
       if (NL > 15 && (k & 7) == 7 && k + 1 < NL) acc = crt_fold128(acc, pc);      // 8 more terms below 2^124 on top of a value below q
     }
-    u64 r = crt_fold128(acc, pc);
+    // acc < 2^127 -> [0, q): quotient by mu = floor(2^128 / q) = pw[NL+2]:pw[NL+1], low 64 bits only (all the remainder needs),
+    // taken from the three high partial products (at most 3 below the true one), then up to three subtractions of q < 2^60
+    const u64 a0 = (u64)acc, a1 = (u64)(acc >> 64), m0 = pw[NL + 1], m1 = pw[NL + 2];
+    const u64 qh = a1 * m1 + __umul64hi(a1, m0) + __umul64hi(a0, m1);
+    u64 r = a0 - qh * pc.q;
+    if (r >= pc.two_q) r -= pc.two_q;
+    if (r >= pc.two_q) r -= pc.two_q;
+    if (r >= pc.q) r -= pc.q;
     if (neg) r = d_submod(r, pw[NL], pc.q);
     rows[(poly * nslots + slot) * n + j] = r;
   }
@@ -153,11 +160,11 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
   const i64 nc = ncoeffs < n ? ncoeffs : n;
   // table of the compile-time-width kernel: s * 2^(64k) mod q per (class, prime, k), s = the class's word scalar (1 without a lift)
   u64* d_pows = nullptr;
-  const i64 pow_stride = (i64)ctx->L * (nlimbs + 1);
+  const i64 pow_stride = (i64)ctx->L * (nlimbs + 3);
   if (nlimbs <= 20) {
     std::vector<u64> key;
     if (scalar_mul) key.assign(scalar_mul, scalar_mul + npoly); else key.assign(1, 0);
-    key.push_back(0x7461626c65000000ull | (u64)nlimbs);          // tag: scaled power table of this limb count
+    key.push_back(0x7461626c65320000ull | (u64)nlimbs);          // tag: scaled power table (+ Barrett constant) of this limb count
     auto pit = ctx->scalar_cache.find(key);
     if (pit == ctx->scalar_cache.end()) {
       const int ncls = scalar_mul ? npoly : 1;
@@ -167,7 +174,11 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
           const u64 q = ctx->q[l];
           const u64 b = (u64)(((u128)1 << 64) % q);
           u64 cur = (scalar_mul && scalar_mul[p]) ? scalar_mul[p] % q : 1 % q;
-          for (int k = 0; k <= nlimbs; ++k) { h[(size_t)p * pow_stride + (size_t)l * (nlimbs + 1) + k] = cur; cur = hm::mulmod(cur, b, q); }
+          u64* e = &h[(size_t)p * pow_stride + (size_t)l * (nlimbs + 3)];
+          for (int k = 0; k <= nlimbs; ++k) { e[k] = cur; cur = hm::mulmod(cur, b, q); }
+          // floor(2^128 / q) = floor((2^128 - 1) / q) for odd q > 1
+          const u128 mu = ~(u128)0 / q;
+          e[nlimbs + 1] = (u64)mu; e[nlimbs + 2] = (u64)(mu >> 64);
         }
       HIP_TRY(hipMalloc(&d_pows, h.size() * 8));
       HIP_TRY(hipMemcpy(d_pows, h.data(), h.size() * 8, hipMemcpyHostToDevice));
