@@ -504,7 +504,7 @@ def main():
     roofline_dot = {"bound": "hbm", "kernel": dname, "achieved": round(dach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": dtraffic, "launches": dl,
                     "avg_launch_ms": round(dms / dl, 4) if dl else None, "ciphertexts_per_launch": round(dunits / dl, 1) if dl else None,
-                    "note": "VALU- and L2-bound integer multiply-accumulate (the key slices are re-read from L2); see roofline_ntt for the "
+                    "note": "integer multiply-accumulate bound by the LDS pipe and the VALU (the key slices are re-read from L2), not by HBM; see roofline_ntt for the "
                             "DoubleCRT transform the metric's GB/s figure refers to"}
     # `roofline` is the kernel with the largest share of the step
     roofline = roofline_dot if dms >= ms else roofline_ntt
