@@ -8,9 +8,17 @@ Inputs are synthetic (uniform coefficients in [-2^511, 2^511), uniform key-switc
 timed region.  N > 1: one process per GPU, ciphertext batches sharded (each rank its own B), key-switch matrix generated
 on rank 0 and broadcast with RCCL; no collective inside the timed loop (weak scaling).
 
+`python bench.py --gpus N` with N > 1 and no RANK in the environment launches the N ranks itself (torch.distributed.run as a child
+process, started before anything in this process touches the GPU) and relays rank 0's line; under an external launcher (RANK set) it
+is one of the ranks.
+
 Prints ONE JSON line on rank 0 (contract in the task description) including
-  roofline     -- forward-NTT kernel: algorithmic bytes (2*n*8 per row) / HIP-event time of its launches, vs 8 TB/s
-  cpu_baseline -- the C oracle (oracle/fhesi_oracle.c, single thread) on a bounded sample of the same workload
+  roofline       -- the kernel with the largest share of the step: algorithmic bytes / HIP-event time of its launches, vs 8 TB/s;
+                    kernel names are read back from the library (fhesi_prof_kernel_name), not written here
+  roofline_ntt   -- the same for the transform of the digit polynomials (fused ByteDecomp + forward NTT)
+  cpu_baseline   -- the C oracle (oracle/fhesi_oracle.c) on a bounded sample of the same workload, one thread, all cores, and in the
+                    reference's own Bluestein-over-FFT-primes structure (like for like)
+  matches_oracle -- the first cpu-sample outputs of the timed buffer compared bit for bit with the oracle's (exit code 1 otherwise)
 """
 import argparse
 import ctypes
@@ -111,32 +119,108 @@ def rand_coeffs(rng, shape, nlimbs):
     return hi * np.uint64(2) + lo
 
 
-def cpu_baseline(primes, roots, ksm, a, b, n_sample):
-    """Oracle (single-thread C restatement) timed on the host cores: the reported CPU figure, never the product path."""
+def host_cpu_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable}
+
+
+def cpu_baseline(primes, roots, ksm, a, b, n_sample, bluestein_sample=1):
+    """Oracle (C restatement) timed on the host cores: the reported CPU figure, never the product path.  Returns (record, outputs)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     orc = O.Oracle(M_RING, primes, roots)
+    info = host_cpu_info()
     t0 = time.perf_counter()
-    done = 0
+    outs = []
     for i in range(n_sample):
-        orc.ct_mul_relin(ksm, a[i], b[i], LOGQ, P_PLAIN, DECOMP)
-        done += 1
+        outs.append(orc.ct_mul_relin(ksm, a[i], b[i], LOGQ, P_PLAIN, DECOMP))
         if time.perf_counter() - t0 > 30.0:
             break
+    done = len(outs)
     dt = time.perf_counter() - t0
     # the same oracle on all host cores: independent ciphertexts, one per thread (ctypes releases the GIL; the oracle keeps no
     # shared mutable state).  The reference itself is single-threaded; this is the generous CPU figure.
     from concurrent.futures import ThreadPoolExecutor
-    cores = max(1, min(os.cpu_count() or 1, 32))          # (each oracle call holds ~0.4 GB of digit rows)
+    threads = max(1, min(info["usable_cpus"], 64))        # (each oracle call holds ~0.4 GB of digit rows)
     t1 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(lambda i: orc.ct_mul_relin(ksm, a[i % n_sample], b[i % n_sample], LOGQ, P_PLAIN, DECOMP), range(cores)))
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda i: orc.ct_mul_relin(ksm, a[i % n_sample], b[i % n_sample], LOGQ, P_PLAIN, DECOMP), range(threads)))
     dt_all = time.perf_counter() - t1
-    return {"value": done / dt, "unit": "ciphertext-mults/s", "cores": 1, "kind": "port",
-            "sample": f"{done} ciphertext mult+relin at the bench config (n=2^14, L={len(primes)}, ndigits={ksm.shape[1] // 3}) "
-                      f"with the C oracle's direct negacyclic NTT (optimistic vs the reference's Bluestein over NTL), {dt:.1f} s",
-            "all_cores": {"value": cores / dt_all, "unit": "ciphertext-mults/s", "cores": cores,
-                          "sample": f"{cores} mults, one per thread, {dt_all:.1f} s"}}
+    rec = {"value": done / dt, "unit": "ciphertext-mults/s", "cores": 1, "kind": "port",
+           "sample": f"{done} ciphertext mult+relin at the bench config (n=2^{M_RING.bit_length() - 2}, L={len(primes)}, ndigits={ksm.shape[1] // 3}) "
+                     f"with the C oracle's direct negacyclic NTT (optimistic vs the reference's Bluestein over NTL), {dt:.1f} s",
+           "host": info,
+           "all_cores": {"value": threads / dt_all, "unit": "ciphertext-mults/s", "cores": threads,
+                         "sample": f"{threads} mults, one per thread on {info['usable_cpus']} usable logical CPUs, {dt_all:.1f} s"}}
+    if bluestein_sample > 0:
+        # like for like: the reference evaluates every transform (power-of-two m too) as Bluestein with an N = 2^16-point cyclic
+        # product through NTL's FFT primes (bluestein.cpp:116-139); the oracle's bluestein_fft mode has that structure
+        orc.set_bluestein_fft(True)
+        t2 = time.perf_counter()
+        o = orc.ct_mul_relin(ksm, a[0], b[0], LOGQ, P_PLAIN, DECOMP)
+        dt_b = time.perf_counter() - t2
+        orc.set_bluestein_fft(False)
+        rec["bluestein_mode"] = {"value": 1.0 / dt_b, "unit": "ciphertext-mults/s", "cores": 1, "kind": "port",
+                                 "same_result": bool(np.array_equal(o, outs[0])),
+                                 "sample": f"1 mult+relin with every row transform as Bluestein + 3-prime FFT convolution of 2^{(2 * M_RING - 1).bit_length()} points "
+                                           f"(the reference's algorithm, bluestein.cpp:93-144), {dt_b:.1f} s"}
+    return rec, np.stack(outs)
+
+
+class SclkSampler:
+    """Observed shader clock during the timed region: polls the current sclk level in sysfs (readable without privileges)."""
+
+    def __init__(self, card_index=0, period=0.02):
+        import glob
+        import threading
+        paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = paths[min(card_index, len(paths) - 1)] if paths else None
+        self.samples, self.period = [], period
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True) if self.path else None
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+        except (OSError, ValueError, IndexError):
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self._th:
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        return {"min": min(self.samples), "mean": round(sum(self.samples) / len(self.samples), 1), "max": max(self.samples), "samples": len(self.samples),
+                "source": "pp_dpm_sclk (current DPM level)"}
 
 
 class _CountingBackend:
@@ -175,7 +259,7 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
         if world > 1:
             stage = shard.broadcast_key_matrix(host, a.nbytes, dist, device=dev)
             torch.cuda.synchronize()
-            ctx.dev_copy(a.device_ptr, stage.data_ptr(), a.nbytes)
+            a.upload_dev(stage.data_ptr())
             del stage
         else:
             a.upload(host)
@@ -216,9 +300,10 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = {k: ctx.prof_read(k) for k in F.binding.PROF_CLASSES}
+    kname = ctx.prof_kernel_name("ntt_fwd_digits_main")
     ctx.prof_enable(False)
     launches, rows, ms = prof["ntt_fwd_digits_main"]
-    achieved = rows * 2 * n * 8 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    achieved = rows * 2 * n * (4 if kname.startswith("ntt32_") else 8) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     if rank == 0:
         ksw = stats["key_switches"] + stats["automorph_key_switches"]
         line = {
@@ -231,7 +316,7 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
                        "products_per_regress": stats["products"], "key_switches_per_regress": stats["key_switches"],
                        "automorph_key_switches_per_regress": stats["automorph_key_switches"], "regress_per_s": round(args.steps / dt, 3),
                        "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_tile<14, true, 0, false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches,
                          "avg_launch_ms": round(ms / launches, 4) if launches else None},
             "cpu_baseline": None,
@@ -282,6 +367,7 @@ def run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F):
         dt = float(tt.item())
     fl, frows, fms = ctx.prof_read("ntt_fwd")
     il, irows, ims = ctx.prof_read("ntt_inv")
+    fname, iname = ctx.prof_kernel_name("ntt_fwd"), ctx.prof_kernel_name("ntt_inv")
     ctx.prof_enable(False)
     identity = bool(np.array_equal(buf.download(host.shape), host))
     cpu = None
@@ -309,10 +395,10 @@ def run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[1]: DoubleCRT NTT round trip, m=2^14 n=2^13, 8 primes of 60 bits", "L": L, "batch_per_gpu": B,
                        "round_trip_is_identity": identity, "matches_oracle": oracle_ok},
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd_tile<13, false, 0, false>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": fname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": fl, "avg_launch_ms": round(fms / fl, 4) if fl else None,
                          "row_ntts_per_s": round(frows / (fms * 1e-3), 1) if fms > 0 else None,
-                         "inverse": {"kernel": "ntt_inv_tile<13, 0, false>", "achieved": round(irows * row_bytes / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
+                         "inverse": {"kernel": iname, "achieved": round(irows * row_bytes / (ims * 1e-3) / 1e9, 1) if ims > 0 else None,
                                      "row_ntts_per_s": round(irows / (ims * 1e-3), 1) if ims > 0 else None}},
             "cpu_baseline": cpu,
         }
@@ -321,14 +407,32 @@ def run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F):
             raise SystemExit("NTT round trip / oracle parity failed")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without an external launcher: start the N ranks as a child torch.distributed.run (one process per GPU),
+    wait, relay its output and exit code.  Nothing in THIS process has touched the GPU (no torch / library import yet), and the child
+    is a subprocess, never an exec of this one."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="ciphertext mults per GPU per step (default 64 = one chunk of the library; ntt workload: DoubleCRTs per step, default 1024)")
-    ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (FHESI_LANES); 2 gives ~+5 %% throughput but "
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="ciphertext mults per GPU per step (default 1024 = 16 chunks of the library, so that 20 steps time more than "
+                    "a second; stress: 64; ntt workload: DoubleCRTs per step, default 1024)")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline and compared with the timed output buffer (0 = skip)")
+    ap.add_argument("--no-bluestein-cpu", action="store_true", help="skip the like-for-like (Bluestein-mode) CPU timing, about 20 s")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (option lanes); 2 gives ~+5 %% throughput but "
                     "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
     ap.add_argument("--workload", default="metric", choices=["metric", "stress", "regression", "ntt"], help="metric = configs[2] (default, the contract line); "
                     "ntt = configs[1]: DoubleCRT forward+inverse round trips at n=2^13, 8 primes, --batch DoubleCRTs per GPU (default there: 1024); "
@@ -340,18 +444,20 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 plumbing)")
     ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="library option (fhesi_ctx_set_option), e.g. ks_direct=1, tensor32=0")
     args = ap.parse_args()
 
     global M_RING, LOGQ, P_PLAIN
     if args.workload == "stress":
         M_RING, LOGQ, P_PLAIN = 1 << 16, 1024, 65537
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    os.environ["FHESI_LANES"] = str(args.lanes)
     import torch
     import fhe_si_amd as F
     if not torch.cuda.is_available():
@@ -364,6 +470,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+    options = {"lanes": args.lanes}
+    for kv in args.option:
+        k, _, v = kv.partition("=")
+        options[k] = int(v)
 
     if args.workload == "ntt":
         run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F)
@@ -380,9 +490,11 @@ def main():
     nl = (LOGQ + 63) // 64
     ncol = 3 * nd
     chain_bits = sum(math.log2(q) for q in primes)
-    B = args.batch if args.batch else (16 if args.workload == "stress" else 64)      # one chunk of the library (about 75k digit rows)
+    B = args.batch if args.batch else (64 if args.workload == "stress" else 1024)
 
     ctx = F.Context(M_RING, primes, roots, device=local_rank)
+    for k, v in options.items():
+        ctx.set_option(k, v)
     ksk = F.KeySwitchMatrix(ctx, 3, nd)
 
     # key-switch matrix: generated on rank 0, RCCL-broadcast over xGMI into every rank's HBM copy
@@ -393,7 +505,7 @@ def main():
         from fhe_si_amd import shard
         stage = shard.broadcast_key_matrix(ksm_host, ksk.nbytes, dist, device=f"cuda:{local_rank}")   # one RCCL broadcast
         torch.cuda.synchronize()
-        ctx.dev_copy(ksk.device_ptr, stage.data_ptr(), ksk.nbytes)
+        ksk.upload_dev(stage.data_ptr())
         del stage
     else:
         ksk.upload(ksm_host)
@@ -405,42 +517,54 @@ def main():
             dist.destroy_process_group()
         return
 
+    # synthetic inputs: `uniq` distinct random ciphertext pairs per GPU, repeated to fill the batch (every pair is an independent
+    # multiplication; repeating keeps host generation and upload of multi-GiB batches short without making the data any less random)
     rng = np.random.default_rng(7 + rank)
-    a_host = rand_coeffs(rng, (B, 2, n), nl)
-    b_host = rand_coeffs(rng, (B, 2, n), nl)
-    da, db = ctx.upload(a_host), ctx.upload(b_host)
-    dout = ctx.alloc(a_host.nbytes)
+    uniq = min(B, 64)
+    a_host = rand_coeffs(rng, (uniq, 2, n), nl)
+    b_host = rand_coeffs(rng, (uniq, 2, n), nl)
+    ct_bytes = a_host.nbytes // uniq
+    da, db, dout = ctx.alloc(ct_bytes * B), ctx.alloc(ct_bytes * B), ctx.alloc(ct_bytes * B)
+    da.upload(a_host)
+    db.upload(b_host)
+    done = uniq
+    while done < B:        # device-to-device replication
+        cnt = min(done, B - done)
+        ctx.dev_copy(da.ptr.value + done * ct_bytes, da.ptr.value, cnt * ct_bytes)
+        ctx.dev_copy(db.ptr.value + done * ct_bytes, db.ptr.value, cnt * ct_bytes)
+        done += cnt
 
     def step():
         ctx.ct_mul_relin_dev(ksk, LOGQ, P_PLAIN, da, db, dout, nl, B, DECOMP)
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         step()
     ctx.sync()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    with SclkSampler(local_rank) as sclk:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # live per-kernel timing of the timed region (HIP events on the context's stream)
+    # live per-kernel timing of the timed region (HIP events on the context's stream); kernel names as the library launched them
     prof = {k: ctx.prof_read(k) for k in F.binding.PROF_CLASSES}
+    names = {k: ctx.prof_kernel_name(k) for k in F.binding.PROF_CLASSES}
     ctx.prof_enable(False)
     launches, rows, ms = prof["ntt_fwd_digits_main"]       # fused ByteDecomp + forward NTT of the digit polynomials
-    # n = 2^14 at the metric chain shape: the digit rows are transformed modulo four 30-bit primes (kernels_aux32.hip): 4-byte residues
-    aux32 = (n == (1 << 14) and L == 18 and LOGQ == 512 and not args.ntt_rows
-             and not any(v in os.environ for v in ("FHESI_KS_DIRECT", "FHESI_KS_RESIDUES", "FHESI_KS_AUX60")))
+    kname = names["ntt_fwd_digits_main"]
+    aux32 = kname.startswith("ntt32_")                      # digit rows transformed modulo four 30-bit primes (kernels_aux32.hip): 4-byte residues
     row_bytes = 2 * n * (4 if aux32 else 8)                 # row read once + written once
     if args.ntt_rows:
         # optional standalone measurement on a fixed row count
@@ -451,90 +575,104 @@ def main():
         for _ in range(10):
             ctx.rows_ntt_fwd(buf, cnt)
         launches, rows, ms = ctx.prof_read("ntt_fwd")
+        kname = ctx.prof_kernel_name("ntt_fwd")
+        row_bytes = 2 * n * 8
         ctx.prof_enable(False)
     achieved = rows * row_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_ntt_fwd.json")
-    if os.path.exists(pmc_path):
+
+    def offline_traffic(fname, kernel, shape_key, shape_val):
+        """HBM bytes per launch from a committed `rocprofv3 --pmc` pass (collected offline as the microarch guide prescribes: separate
+        passes, FETCH_SIZE corrected); only when that pass was taken on the kernel and launch shape of THIS run."""
+        path = os.path.join(ROOT, "profiles", fname)
         try:
-            pmc = json.load(open(pmc_path))
-            traffic = pmc.get("hbm_bytes_per_launch")
-            if not launches or pmc.get("rows_per_launch") != round(rows / launches):
-                traffic = None      # the counters were collected on another launch shape (batch)
+            rec = json.load(open(path))
         except Exception:
-            traffic = None
-    if args.workload != "metric" or args.ntt_rows:
-        traffic = None          # the PMC passes in profiles/ were taken on the metric workload's launch shape
-    # template parameters <LOGN, DIGITS, S0, CONTIG>; rows of 2^15 points: the head-fused sub-transform kernel (S0 = 1, CONTIG)
-    if aux32:
-        kname = "ntt32_fwd_kernel<true>"
-    elif ctx.phim > (1 << 14):
-        kname = "ntt_fwd_tile<14, false, 1, false>" if args.ntt_rows else "ntt_fwd_tile<14, true, 1, true>"
-    else:
-        kname = "ntt_fwd_tile<14, %s, 0, false>" % ("false" if args.ntt_rows else "true")
+            return None, None
+        if rec.get("kernel") != kernel or rec.get(shape_key) != shape_val:
+            return None, None
+        return rec.get("hbm_bytes_per_launch"), f"profiles/{fname} (offline rocprofv3 --pmc passes on {rec.get('kernel')}, {shape_key}={shape_val})"
+
+    traffic, traffic_src = (None, None)
+    if args.workload == "metric" and not args.ntt_rows and launches:
+        traffic, traffic_src = offline_traffic("pmc_ntt_fwd.json", kname, "rows_per_launch", round(rows / launches))
     roofline_ntt = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "achieved_on_traffic": round(traffic * launches / (ms * 1e-3) / 1e9, 1) if traffic and ms > 0 else None,
                     "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
                     "rows_per_launch": round(rows / launches, 1) if launches else None, "row_bytes": row_bytes // 2,
                     "row_ntts_per_s": round(rows / (ms * 1e-3), 1) if ms > 0 else None}
-    # The dominant kernel of the pipeline is the key-switch dot product through the two auxiliary primes (kernels_ksaux.hip):
+    # The dominant kernel of the pipeline is the key-switch dot product through the auxiliary primes (kernels_ksaux.hip / kernels_aux32.hip):
     # algorithmic bytes per launch of c ciphertexts = (digit rows c*ncol*2 + key rows 2*R*2*ncol + output rows c*2*R*2) * n * 8
-    # (DESIGN.md section 6); it is bound by the VALU (64-bit multiply-adds) and the L2, not by HBM -- the contract's roof is HBM.
-    aux = "FHESI_KS_DIRECT" not in os.environ      # the library's A/B switch back to the per-prime dot product
+    # (DESIGN.md section 6); it is bound by the VALU (integer multiply-adds) and the LDS pipe, not by HBM -- the contract's roof is HBM.
+    dname = names["dot"]
+    aux = not dname.startswith("dot_accum")      # dot_accum_kernel = the per-chain-prime dot product (option ks_direct)
     dl, dunits, dms = prof["dot"]
     # output rows per (ciphertext, key row, auxiliary prime): the limbs of the key's integer coefficients where the library runs the
-    # key switch in limb mode (ks_limb_plan: 15 at the metric chain shape, 30 at the stress shape), the L residues otherwise
-    R = L if "FHESI_KS_RESIDUES" in os.environ else {(18, 512): 15, (35, 1024): 30}.get((L, LOGQ), L)
+    # key switch in limb mode (15 at the metric chain shape, 30 at the stress shape), the L residues otherwise
+    R = L if ctx.get_option("ks_residues") else {(18, 512): 15, (35, 1024): 30}.get((L, LOGQ), L)
     if aux:
         dbytes = (dunits * (ncol * 2 + 2 * R * 2) + dl * (2 * R * 2 * ncol)) * n * 8
-        dname = "dot32_kernel<8, 16>" if aux32 else ("dot_aux_kernel<4, 16, 1>" if ncol * 4 * 512 <= 150 * 1024 else "dot_aux_kernel<2, 16, 2>")
     else:
         dbytes = (dunits * (ncol + 2) * L + dl * (2 * ncol * L)) * n * 8
-        dname = "dot_accum_kernel<2, %s>" % ("true" if ctx.phim > (1 << 14) else "false")
     dach = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-    dtraffic = None
-    dpmc_path = os.path.join(ROOT, "profiles", "pmc_dot_aux.json")
-    if aux and args.workload == "metric" and os.path.exists(dpmc_path):
-        try:
-            dp = json.load(open(dpmc_path))
-            if dl and dp.get("ciphertexts_per_launch") == round(dunits / dl):
-                dtraffic = dp.get("hbm_bytes_per_launch")
-        except Exception:
-            dtraffic = None
+    dtraffic, dtraffic_src = (None, None)
+    if aux and args.workload == "metric" and dl:
+        dtraffic, dtraffic_src = offline_traffic("pmc_dot_aux.json", dname, "ciphertexts_per_launch", round(dunits / dl))
     roofline_dot = {"bound": "hbm", "kernel": dname, "achieved": round(dach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": dtraffic, "launches": dl,
+                    "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": dtraffic, "traffic_source": dtraffic_src, "launches": dl,
                     "avg_launch_ms": round(dms / dl, 4) if dl else None, "ciphertexts_per_launch": round(dunits / dl, 1) if dl else None,
                     "note": "integer multiply-accumulate bound by the LDS pipe and the VALU (the key slices are re-read from L2), not by HBM; see roofline_ntt for the "
                             "DoubleCRT transform the metric's GB/s figure refers to"}
     # `roofline` is the kernel with the largest share of the step
     roofline = roofline_dot if dms >= ms else roofline_ntt
 
+    ok = True
     if rank == 0:
         total_mults = B * args.steps * world
         value = total_mults / dt
         breakdown = {k: round(v[2] / args.steps, 3) for k, v in prof.items() if v[0] and k != "ntt_fwd_digits_main"}
-        cpu = None
-        if args.cpu_sample > 0 and world == 1:       # CPU baseline on rank 0 at N=1 only
-            cpu = cpu_baseline(primes, roots, ksm_host, a_host, b_host, min(args.cpu_sample, B))
+        cpu, matches = None, None
+        if args.cpu_sample > 0 and world == 1:       # CPU baseline on rank 0 at N=1 only; its outputs check the timed buffer
+            ns = min(args.cpu_sample, uniq)
+            cpu, want = cpu_baseline(primes, roots, ksm_host, a_host, b_host, ns, 0 if (args.no_bluestein_cpu or args.workload != "metric") else 1)
+            got = dout.download((want.shape[0], 2, n, nl))
+            last = np.frombuffer(ctx_download_tail(ctx, dout, B, ct_bytes), dtype=np.uint64).reshape(2, n, nl)
+            # the batch repeats the `uniq` pairs: the last ciphertext of the batch equals output (B-1) % uniq of the first chunk
+            first_chunk = dout.download((uniq, 2, n, nl))
+            matches = bool(np.array_equal(got, want)) and bool(np.array_equal(last, first_chunk[(B - 1) % uniq]))
+            ok = matches
         line = {
             "metric": "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^14, logQ=512" if args.workload == "metric"
                       else "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^15, logQ=1024 (stress shape)",
-            "value": round(value, 2), "unit": "ciphertext-mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "ciphertext-mults/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            "dtype": "u64 (chain-prime rows u64; key-switch rows u32 modulo four 30-bit primes)" if aux32 else "u64",
+            "data": f"synthetic ({uniq} distinct uniform ciphertext pairs per GPU repeated to the batch, uniform key rows)",
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
                        if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
-                       "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B, "lanes": args.lanes,
-                       "fwd_row_ntts_per_mult": (4 * L + (4 if aux32 else 2) * ncol) if aux else (4 + ncol) * L,
-                       "inv_row_ntts_per_mult": (3 * L + (8 if aux32 else 4) * R) if aux else 5 * L,
-                       "key_switch": ("4 x 30-bit auxiliary primes, 15 limbs" if aux32 else "2 x 60-bit auxiliary primes") if aux else "per chain prime",
+                       "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B, "options": {k: ctx.get_option(k) for k in ("lanes", "ks_direct", "ks_residues", "ks_aux60", "tensor32", "batch_chunk")},
+                       "timed_region_s": round(dt, 3),
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
+            "matches_oracle": matches,
+            "sclk_mhz_observed": sclk.summary(),
             "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_dot": roofline_dot, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
+            "kernels": {k: v for k, v in names.items() if v},
         }
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench: the timed output buffer differs from the oracle")
+
+
+def ctx_download_tail(ctx, buf, B, ct_bytes):
+    """bytes of the last ciphertext of a device batch"""
+    import ctypes as C
+    out = np.empty(ct_bytes, dtype=np.uint8)
+    from fhe_si_amd import binding as Bd
+    Bd._ck(Bd._load().fhesi_dev_download(ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(buf.ptr.value + (B - 1) * ct_bytes), ct_bytes))
+    return out.tobytes()
 
 
 if __name__ == "__main__":

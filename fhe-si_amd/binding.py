@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
     "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
     "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
+    "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -131,6 +132,11 @@ def _load():
         "fhesi_dev_copy": [_vp, _vp, _vp, C.c_size_t],
         "fhesi_prof_enable": [_vp, _i32],
         "fhesi_prof_read": [_vp, _i32, _vp, _vp, _vp],
+        "fhesi_prof_kernel_name": [_vp, _i32, _vp, C.c_size_t],
+        "fhesi_ctx_set_option": [_vp, C.c_char_p, _i64],
+        "fhesi_ctx_get_option": [_vp, C.c_char_p, _vp],
+        "fhesi_ksk_mark_dirty": [_vp],
+        "fhesi_ksk_upload_dev": [_vp, _vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -255,6 +261,20 @@ class Context:
         n, u, ms = _i64(0), C.c_double(0), C.c_double(0)
         _ck(_load().fhesi_prof_read(self.h, PROF_CLASSES[cls], C.byref(n), C.byref(u), C.byref(ms)))
         return n.value, u.value, ms.value
+
+    def prof_kernel_name(self, cls: str) -> str:
+        """Demangled name of the kernel the last profiled launch of that class ran ('' if none)."""
+        buf = C.create_string_buffer(512)
+        _ck(_load().fhesi_prof_kernel_name(self.h, PROF_CLASSES[cls], buf, 512))
+        return buf.value.decode()
+
+    def set_option(self, name: str, value: int):
+        _ck(_load().fhesi_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = _i64(0)
+        _ck(_load().fhesi_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def selftest_aux32(self):
         """Diagnostic of the 32-bit auxiliary transforms of the key switch (n = 2^14): raises FhesiError on failure."""
@@ -486,6 +506,14 @@ class KeySwitchMatrix:
     @property
     def device_ptr(self) -> int:
         return _load().fhesi_ksk_device_ptr(self.h)
+
+    def mark_dirty(self):
+        """The rows were written through device_ptr (e.g. by a collective): derived tables are rebuilt at the next key switch."""
+        _ck(_load().fhesi_ksk_mark_dirty(self.h))
+
+    def upload_dev(self, src_ptr: int):
+        """Whole matrix from another HBM buffer of the same device (the staging tensor of an RCCL broadcast)."""
+        _ck(_load().fhesi_ksk_upload_dev(self.h, _vp(src_ptr)))
 
     def __del__(self):
         try:

@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <cxxabi.h>
+#include <string>
 
 // --------------------------------------------------------------------------------------------- helpers
 int ws_reserve(fhesi_ctx* ctx, int slot, size_t bytes, void** out) {
@@ -72,7 +74,39 @@ static void to_q63(std::vector<Shoup2>& t, u64 q) {
   for (auto& e : t) e.wp = hm::shoup63(e.w, q);
 }
 
-thread_local bool g_fhesi_internal_ctx = false;   // set by bluestein_init: its convolution context needs sizes up to 4m
+thread_local bool g_fhesi_internal_ctx = false;
+
+struct OptDesc { const char* name; const char* env; size_t off; bool wide; };
+static const OptDesc kOptions[] = {
+  {"ks_direct", "FHESI_KS_DIRECT", offsetof(CtxOptions, ks_direct), false},
+  {"ks_residues", "FHESI_KS_RESIDUES", offsetof(CtxOptions, ks_residues), false},
+  {"ks_aux60", "FHESI_KS_AUX60", offsetof(CtxOptions, ks_aux60), false},
+  {"crt_exact", "FHESI_CRT_EXACT", offsetof(CtxOptions, crt_exact), false},
+  {"crt_skip_cleanup", "FHESI_CRT_SKIP_CLEANUP", offsetof(CtxOptions, crt_skip_cleanup), false},
+  {"lanes", "FHESI_LANES", offsetof(CtxOptions, lanes), false},
+  {"stagger", "FHESI_STAGGER", offsetof(CtxOptions, stagger), false},
+  {"batch_chunk", "FHESI_BATCH_CHUNK", offsetof(CtxOptions, batch_chunk), true},
+  {"wave_operands", "FHESI_WAVE_OPERANDS", offsetof(CtxOptions, wave_operands), true},
+  {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
+};
+static void opt_store(CtxOptions* o, const OptDesc& d, long long v) {
+  if (d.wide) *(long long*)((char*)o + d.off) = v; else *(int*)((char*)o + d.off) = (int)v;
+}
+static long long opt_load(const CtxOptions* o, const OptDesc& d) {
+  return d.wide ? *(const long long*)((const char*)o + d.off) : (long long)*(const int*)((const char*)o + d.off);
+}
+extern "C" int fhesi_ctx_set_option(fhesi_ctx* c, const char* name, int64_t value) {
+  if (!c || !name) FHESI_FAIL("set_option: null argument");
+  for (const OptDesc& d : kOptions)
+    if (!strcmp(d.name, name)) { opt_store(&c->opt, d, value); return 0; }
+  FHESI_FAIL("set_option: unknown option '%s'", name);
+}
+extern "C" int fhesi_ctx_get_option(const fhesi_ctx* c, const char* name, int64_t* value) {
+  if (!c || !name || !value) FHESI_FAIL("get_option: null argument");
+  for (const OptDesc& d : kOptions)
+    if (!strcmp(d.name, name)) { *value = opt_load(&c->opt, d); return 0; }
+  FHESI_FAIL("get_option: unknown option '%s'", name);
+}   // set by bluestein_init: its convolution context needs sizes up to 4m
 
 extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, const uint64_t* q, const uint64_t* root, int32_t device) {
   if (!out) FHESI_FAIL("null output pointer");
@@ -96,6 +130,8 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
   HIP_TRY(hipSetDevice(device));
 
   fhesi_ctx* c = new fhesi_ctx();
+  for (const OptDesc& d : kOptions)          // initial values from the environment, read once per context
+    if (const char* e = getenv(d.env)) opt_store(&c->opt, d, atoll(e));
   c->device = device;
   c->m = m;
   c->L = nprimes;
@@ -254,8 +290,13 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
 
 extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   if (!c) return 0;
+  // DoubleCRT objects and key-switch matrices hold a pointer to their context (the reference's `const FHEcontext&`, DoubleCRT.h:84):
+  // the context must outlive them, so destroying it while handles are alive is refused instead of leaving them dangling
+  if (c->live_handles > 0) FHESI_FAIL("fhesi_ctx_destroy: %d DoubleCRT / key-switch handle(s) of this context are still alive", c->live_handles);
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto& r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  c->prof.clear();
   bluestein_destroy(c);
   for (auto& kv : c->crt_cache) { hipFree(kv.second->d_blob); if (kv.second->d_flags) hipFree(kv.second->d_flags); delete kv.second; }
   for (auto& kv : c->pow64_cache) hipFree(kv.second);
@@ -312,6 +353,7 @@ extern "C" int fhesi_prof_enable(fhesi_ctx* c, int32_t on) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (auto& r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   c->prof.clear();
+  if (on) for (auto& f : c->prof_fn) f = nullptr;
   c->prof_on = on != 0;
   return 0;
 }
@@ -327,6 +369,26 @@ extern "C" int fhesi_prof_read(fhesi_ctx* c, int32_t cls, int64_t* launches, dou
     ++n; u += r.units; ms += t;
   }
   *launches = n; *units = u; *total_ms = ms;
+  return 0;
+}
+
+extern "C" int fhesi_prof_kernel_name(fhesi_ctx* c, int32_t cls, char* out, size_t cap) {
+  CHECK_CTX(c);
+  if (cls < 0 || cls >= PROF_NCLASS || !out || !cap) FHESI_FAIL("prof_kernel_name: bad argument");
+  out[0] = 0;
+  if (!c->prof_fn[cls]) return 0;
+  const char* mangled = hipKernelNameRefByPtr(c->prof_fn[cls], c->stream);
+  if (!mangled) return 0;
+  int st = 0;
+  char* dm = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+  std::string name = (st == 0 && dm) ? dm : mangled;
+  free(dm);
+  // rocprofv3 prints "void kernel<args>(params)": keep "kernel<args>"
+  if (name.compare(0, 5, "void ") == 0) name.erase(0, 5);
+  int depth = 0; size_t cut = name.size();
+  for (size_t i = 0; i < name.size(); ++i) { const char ch = name[i]; if (ch == '<') ++depth; else if (ch == '>') --depth; else if (ch == '(' && depth == 0) { cut = i; break; } }
+  name.resize(cut);
+  snprintf(out, cap, "%s", name.c_str());
   return 0;
 }
 
@@ -421,6 +483,7 @@ extern "C" int fhesi_dcrt_alloc(fhesi_ctx* c, const int32_t* prime_idx, int32_t 
   const size_t bytes = d->idx.size() * c->phim * 8;
   HIP_TRY(hipMalloc(&d->d_rows, bytes ? bytes : 8));
   HIP_TRY(hipMemsetAsync(d->d_rows, 0, bytes, c->stream));
+  ++c->live_handles;
   *out = d;
   return 0;
 }
@@ -429,6 +492,7 @@ extern "C" int fhesi_dcrt_free(fhesi_dcrt* d) {
   hipSetDevice(d->ctx->device);
   hipStreamSynchronize(d->ctx->stream);
   hipFree(d->d_rows);
+  --d->ctx->live_handles;
   delete d;
   return 0;
 }
@@ -757,6 +821,7 @@ extern "C" int fhesi_ksk_create(fhesi_ctx* c, int32_t ncomp, int32_t ndigits, fh
   k->bytes = (size_t)2 * ncomp * ndigits * c->L * c->phim * 8;
   HIP_TRY(hipMalloc(&k->d_rows, k->bytes));
   HIP_TRY(hipMemsetAsync(k->d_rows, 0, k->bytes, c->stream));
+  ++c->live_handles;
   *out = k;
   return 0;
 }
@@ -768,6 +833,7 @@ extern "C" int fhesi_ksk_free(fhesi_ksk* k) {
   if (k->d_aux) hipFree(k->d_aux);
   if (k->d_aux_consts) hipFree(k->d_aux_consts);
   if (k->d_limb_consts) hipFree(k->d_limb_consts);
+  --k->ctx->live_handles;
   delete k;
   return 0;
 }
@@ -779,9 +845,22 @@ extern "C" int fhesi_ksk_upload(fhesi_ksk* k, const uint64_t* rows_host) {
   k->aux_valid = false;
   return 0;
 }
-// Handing out the row pointer invalidates the derived table: whoever writes the rows directly (the RCCL key broadcast) fetches the
-// pointer first, and the next key switch rebuilds the table from the new rows.
-extern "C" void* fhesi_ksk_device_ptr(fhesi_ksk* k) { if (k) k->aux_valid = false; return k ? k->d_rows : nullptr; }
+// The library keeps tables derived from the rows; whoever writes the rows directly (a collective receiving into them) says so with
+// fhesi_ksk_mark_dirty, and the next key switch rebuilds the tables.  The getter itself has no side effect.
+extern "C" void* fhesi_ksk_device_ptr(fhesi_ksk* k) { return k ? k->d_rows : nullptr; }
+extern "C" int fhesi_ksk_mark_dirty(fhesi_ksk* k) {
+  if (!k) FHESI_FAIL("null key-switch matrix");
+  k->aux_valid = false;
+  return 0;
+}
+extern "C" int fhesi_ksk_upload_dev(fhesi_ksk* k, const uint64_t* rows_dev) {
+  if (!k || !rows_dev) FHESI_FAIL("null key-switch matrix");
+  CHECK_CTX(k->ctx);
+  HIP_TRY(hipMemcpyAsync(k->d_rows, rows_dev, k->bytes, hipMemcpyDeviceToDevice, k->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(k->ctx->stream));
+  k->aux_valid = false;
+  return 0;
+}
 extern "C" size_t fhesi_ksk_bytes(const fhesi_ksk* k) { return k ? k->bytes : 0; }
 
 // --------------------------------------------------------------------------------------------- ciphertext pipeline
@@ -818,8 +897,8 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
   CrtTables* t;
   FHESI_TRY(get_crt_tables(c, all, &t));
   // Dot product through the two largest chain primes (kernels_ksaux.hip): 2 transforms per digit polynomial instead of L.
-  // FHESI_KS_DIRECT=1 keeps the per-prime dot product below (A/B measurements; also the path of every shape the other does not cover).
-  if (ksaux_supported(c, ncol, 8 * decomp_bytes) && !getenv("FHESI_KS_DIRECT")) {
+  // option ks_direct keeps the per-prime dot product below (A/B measurements; also the path of every shape the other does not cover).
+  if (ksaux_supported(c, ncol, 8 * decomp_bytes) && !c->opt.ks_direct) {
     fhesi_ksk* km = const_cast<fhesi_ksk*>(k);
     if (!k->aux_valid || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ));
     const int R = k->aux_rows;        // L chain-prime residues, or the limbs of the key's integer coefficients (limb mode)
@@ -1074,7 +1153,7 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
   const i64 chunk = batch_chunk(c, 3 * k->ndigits);           // groups per key-switch call
   // distinct operands per pass: bound their evaluation-form rows (2 L n words each) to about 4 GiB
   i64 ucap = (i64)(4.0 * 1024 * 1024 * 1024 / ((double)2 * L * n * 8));
-  if (const char* e = getenv("FHESI_WAVE_OPERANDS")) if (atoll(e) > 1) ucap = atoll(e);
+  if (c->opt.wave_operands > 1) ucap = c->opt.wave_operands;
   if (ucap < 2) ucap = 2;
   const u64 lift[2] = {p, p};
   std::vector<int> ua, ub, sa, sb, lseg, host_idx;
@@ -1150,8 +1229,7 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
 }
 
 static i64 batch_chunk(const fhesi_ctx* c, int ncol) {
-  const char* e = getenv("FHESI_BATCH_CHUNK");
-  if (e && atoll(e) > 0) return atoll(e);
+  if (c->opt.batch_chunk > 0) return c->opt.batch_chunk;
   // about 75k digit rows per chunk (150 rounds of the transform's 512 resident workgroups): measured best on MI355X at both the
   // metric ring (64 mults, 9.3 GiB of digit rows) and the stress ring (16-17 mults, 18 GiB) -- smaller chunks pay launch tails in
   // every stage, larger ones push the key rows out of the Infinity Cache during the dot product.  Capped at 32 GiB of digit rows.
@@ -1189,14 +1267,14 @@ extern "C" int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* c, const fhesi_ksk* k, in
   if (!k || k->ctx != c) FHESI_FAIL("KeySwitchSI: context mismatch");
   if (k->ncomp != 3) FHESI_FAIL("ct_mul_relin needs the s^2 -> s matrix (3 source components), got %d", k->ncomp);
   if (nlimbs * 64 < logQ) FHESI_FAIL("coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
-  static const int lanes = getenv("FHESI_LANES") ? atoi(getenv("FHESI_LANES")) : 1;    // 2: two concurrent half-batches (+5 % throughput on MI355X; kernels of the halves time-share the GPU)
+  const int lanes = c->opt.lanes;    // 2: two concurrent half-batches (+5 % throughput on MI355X; kernels of the halves time-share the GPU)
   if (lanes < 2 || count < 8 || !c->pow2) return mul_relin_chunks(c, k, logQ, p, decomp_bytes, a, b, out, nlimbs, count);
   // two lanes: the second half of the batch runs on a second stream with its own workspace.  Ciphertexts are independent, so
   // the halves never touch the same memory; the fork / join events keep the call's stream semantics (work is ordered after
   // what was enqueued on the context's stream before the call, and fhesi_ctx_sync covers both halves afterwards).
   const int64_t h0 = (count + 1) / 2, h1 = count - h0;
   const size_t off = (size_t)h0 * 2 * c->phim * nlimbs;
-  static const int stagger = getenv("FHESI_STAGGER") ? atoi(getenv("FHESI_STAGGER")) : 0;   // measured slower than starting both lanes together
+  const int stagger = c->opt.stagger;   // measured slower than starting both lanes together
   HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
   HIP_TRY(hipStreamWaitEvent(c->lane_stream, c->ev_fork, 0));
   c->mark_mid = stagger != 0;

@@ -64,7 +64,24 @@ struct fhesi_aux32;                    // four 30-bit auxiliary primes of the ke
 enum { PROF_NTT_FWD = 0, PROF_NTT_INV = 1, PROF_RNS = 2, PROF_TENSOR = 3, PROF_CRT = 4, PROF_DIGITS = 5, PROF_DOT = 6, PROF_EW = 7, PROF_NTT_FWD_DIGITS_MAIN = 8, PROF_NCLASS = 9 };
 struct ProfRec { int cls; double units; hipEvent_t e0, e1; };
 
+// Behaviour switches of one context (fhesi_ctx_set_option).  The FHESI_* environment variables of the same meaning are read ONCE, when
+// the context is created, as initial values -- never per call.
+struct CtxOptions {
+  int ks_direct = 0;        // 1: per-chain-prime key-switch dot product (the reference's structure) instead of the auxiliary-prime path
+  int ks_residues = 0;      // 1: auxiliary-prime key switch in residue mode (no limb mode)
+  int ks_aux60 = 0;         // 1: two 60-bit auxiliary primes even where the four 30-bit primes apply
+  int crt_exact = 0;        // 1: mixed-radix CRT kernel instead of the sum form
+  int crt_skip_cleanup = 0; // test hook: skip the exact clean-up pass of the sum-form CRT
+  int lanes = 1;            // 2: two concurrent half-batches on two streams in fhesi_ct_mul_relin_batch_dev
+  int stagger = 0;          // lanes = 2: start the second lane after the first lane's digit transform
+  long long batch_chunk = 0;      // ciphertexts per pipeline chunk (0 = derived from the ring)
+  long long wave_operands = 0;    // distinct operands per pass of fhesi_ct_mul_sum_relin_dev (0 = about 4 GiB of rows)
+  int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)
+};
+
 struct fhesi_ctx {
+  CtxOptions opt;
+  int live_handles = 0;                // DoubleCRT objects and key-switch matrices created on this context and not yet freed
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -106,6 +123,7 @@ struct fhesi_ctx {
   bool mark_mid = false;               // record ev_mid right after the next digit-NTT launch (staggers the second lane)
   bool prof_on = false;
   std::vector<ProfRec> prof;
+  const void* prof_fn[16] = {};        // host stub of the kernel the last profiled launch of each class ran (fhesi_prof_kernel_name)
   // grow-only workspace.  Slot owners (a slot may be reused by another owner only when the first one's data is dead):
   //   0 digit rows / product operands / encrypt rows    1 inverse-transform scratch (tProd copy, dot output, automorph rows)
   //   2 limb-major parts / small-coefficient staging    3 automorph source rows / encrypt public key
@@ -167,6 +185,10 @@ struct ProfScope {
   }
   ~ProfScope() { if (idx >= 0) hipEventRecord(c->prof[idx].e1, c->stream); }
 };
+
+// names the kernel of the launch that follows (only recorded while profiling is on)
+static inline void prof_kernel(fhesi_ctx* ctx, int cls, const void* host_stub) { if (ctx->prof_on) ctx->prof_fn[cls] = host_stub; }
+#define PROF_KERNEL(ctx, cls, ...) prof_kernel((ctx), (cls), (const void*)&__VA_ARGS__)
 
 // --------------------------------------------------------------------------------- host number theory (hostmath.cpp)
 namespace hm {

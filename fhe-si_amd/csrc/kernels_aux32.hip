@@ -310,6 +310,7 @@ void aux32_free(fhesi_ctx* ctx) {
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0) {
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
+  PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel<false>);
   ntt32_fwd_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{});
   HIP_TRY(hipGetLastError());
   return 0;
@@ -318,6 +319,7 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
   ProfScope prof(ctx, PROF_NTT_INV, (double)(count * nslots));
+  PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel);
   ntt32_inv_kernel<<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -329,6 +331,7 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * 4));
   ProfScope main_prof(ctx, PROF_NTT_FWD_DIGITS_MAIN, (double)(npolys * nd * 4));
   const i64 units = npolys * nd;
+  PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel<true>);
   ntt32_fwd_kernel<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd});
   HIP_TRY(hipGetLastError());
   return 0;
@@ -504,6 +507,7 @@ int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol,
   }
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = A32_N / 64 / 8;
   const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
+  PROF_KERNEL(ctx, PROF_DOT, dot32_kernel<CT, NW>);
   dot32_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
   HIP_TRY(hipGetLastError());
   return 0;

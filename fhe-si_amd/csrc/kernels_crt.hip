@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(256) rns_reduce_kernel_t(const u64* __restrict
 template <int NL>
 static void launch_rns_t(fhesi_ctx* ctx, dim3 grid, const u64* d_limbs, i64 ncoeffs, i64 n, int npoly, i64 pow_poly_stride, u64* d_rows, int nslots,
                          const int* d_prime_of_slot, const u64* d_pows) {
+  PROF_KERNEL(ctx, PROF_RNS, rns_reduce_kernel_t<NL>);
   rns_reduce_kernel_t<NL><<<grid, 256, 0, ctx->stream>>>(d_limbs, ncoeffs, n, npoly, pow_poly_stride, d_rows, nslots, d_prime_of_slot, ctx->d_pc, d_pows, ctx->L);
 }
 
@@ -579,13 +580,14 @@ static int launch_crt_sum(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows,
     HIP_TRY(hipMalloc(&t->d_flags, need));
     t->flags_cap = need;
   }
+  if (mode == 1) PROF_KERNEL(ctx, PROF_CRT, crt_sum_kernel<K, W, LQ, true>); else PROF_KERNEL(ctx, PROF_CRT, crt_sum_kernel<K, W, LQ, false>);
   if (mode == 1) crt_sum_kernel<K, W, LQ, true><<<grid, TB, 0, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->d_idx, t->d_M, t->d_cinv, t->d_P + (size_t)K * W,
                                                                                ctx->d_pc, mode, d_out, nl_out, t->d_flags);
   else crt_sum_kernel<K, W, LQ, false><<<grid, TB, 0, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->d_idx, t->d_M, t->d_cinv, t->d_P + (size_t)K * W,
                                                                       ctx->d_pc, mode, d_out, nl_out, t->d_flags);
   HIP_TRY(hipGetLastError());
   // exact clean-up of the flagged workgroups (normally none: every workgroup of this launch returns at once)
-  if (getenv("FHESI_CRT_SKIP_CLEANUP")) return 0;      // test hook: shows that a crafted input really needs the clean-up
+  if (ctx->opt.crt_skip_cleanup) return 0;      // test hook: shows that a crafted input really needs the clean-up
   return launch_crt_t<K, K, W, LQ>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, 0, LQ, d_out, nl_out, t->d_flags);
 }
 
@@ -736,7 +738,7 @@ int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots
   // fully unrolled instantiation for the metric chain shape (fhe-si logQ = 512: 18 primes, 17-limb product)
   // sum form for the chain shapes of the metric ring (logQ = 512: 18 primes, 17-limb product) and of the stress ring (logQ = 1024: 35 primes,
   // 33-limb product); FHESI_CRT_EXACT=1 keeps the mixed-radix kernel (A/B measurements)
-  if (mode != 0 && !positive && !getenv("FHESI_CRT_EXACT")) {
+  if (mode != 0 && !positive && !ctx->opt.crt_exact) {
     if (t->nidx == 18 && W == 18 && logQ == 512) return launch_crt_sum<18, 18, 512>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, d_out, nl_out);
     if (t->nidx == 35 && W == 34 && logQ == 1024) return launch_crt_sum<35, 34, 1024>(ctx, t, d_rows, nslots_layout, d_slot_of, npolys, mode, d_out, nl_out);
   }

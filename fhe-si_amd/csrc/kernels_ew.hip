@@ -242,6 +242,7 @@ int launch_tensor2x2(fhesi_ctx* ctx, const u64* d_a, const u64* d_b, u64* d_t, i
   if (ctx->phim & 1) FHESI_FAIL("tensor2x2: odd phi(m) not supported by the batched pipeline");
   ProfScope prof(ctx, PROF_TENSOR, (double)count);
   dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ctx->L, (unsigned)count);
+  PROF_KERNEL(ctx, PROF_TENSOR, tensor2x2_kernel);
   tensor2x2_kernel<<<grid, 256, 0, ctx->stream>>>(d_a, d_b, d_t, ctx->phim, ctx->L, ctx->d_pc);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -264,6 +265,7 @@ int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int nco
   const i64 ntiles = (count + CT_TILE - 1) / CT_TILE;
   if (ntiles > 65535) FHESI_FAIL("dot_accum: more than %d ciphertexts per call", 65535 * CT_TILE);
   dim3 grid(grid_x_for(ctx->phim / 2), (unsigned)ntiles, (unsigned)nslot);
+  if (dig_suborder) PROF_KERNEL(ctx, PROF_DOT, dot_accum_kernel<CT_TILE, true>); else PROF_KERNEL(ctx, PROF_DOT, dot_accum_kernel<CT_TILE>);
   if (dig_suborder) dot_accum_kernel<CT_TILE, true><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0, fold_every);
   else dot_accum_kernel<CT_TILE><<<grid, 256, 0, ctx->stream>>>(d_key, d_dig, ncol, ctx->phim, ctx->L, count, d_out, ctx->d_pc, slot0, fold_every);
   HIP_TRY(hipGetLastError());

@@ -270,11 +270,11 @@ bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits) {
 // logQ = 512: 15 limbs of 74 bits instead of 18 residues) and the stress shape (33-limb product, logQ = 1024: 30 limbs of 72 bits
 // instead of 35 residues).  Conditions: every limb product sum stays below q_0 q_1 / 2, the limbs cover P, and |S| < 2^m P.
 bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan, const u32* p32) {
-  if (getenv("FHESI_KS_RESIDUES")) return false;               // A/B switch: residue mode
+  if (ctx->opt.ks_residues) return false;               // A/B switch: residue mode
   KsLimbPlan p;
   u128 A = (u128)ctx->q[0] * ctx->q[1];
   // n = 2^14 at the metric chain shape: the four 30-bit primes of kernels_aux32.hip carry the limb products (FHESI_KS_AUX60=1: A/B switch)
-  if (p32 && ctx->logn == 14 && t->W == 18 && logQ == 512 && !getenv("FHESI_KS_AUX60")) {
+  if (p32 && ctx->logn == 14 && t->W == 18 && logQ == 512 && !ctx->opt.ks_aux60) {
     p.W = 18; p.LQ = 512; p.B = 73; p.NLB = 15; p.a32 = true;
     A = (u128)((u64)p32[0] * p32[1]) * ((u64)p32[2] * p32[3]);
   }
@@ -417,6 +417,7 @@ static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig
   }
   const i64 blocks = (i64)8 * ntiles * nsl8 * 2;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot_aux: too many ciphertexts per call");
+  PROF_KERNEL(ctx, PROF_DOT, dot_aux_kernel<CT, NW, R>);
   dot_aux_kernel<CT, NW, R><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>(k->d_aux, d_dig, ncol, n, k->aux_rows, count, d_out, ctx->d_pc, ntiles, nsl8);
   HIP_TRY(hipGetLastError());
   return 0;

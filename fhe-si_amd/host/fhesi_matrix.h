@@ -211,6 +211,7 @@ class DeviceKeySwitch {
     uint64_t* dst = (uint64_t*)fhesi_ksk_device_ptr(k);
     for (int r = 0; r < 2; ++r)
       for (long col = 0; col < ncol; ++col) ck(fhesi_dev_copy(c.handle(), dst + (r * ncol + col) * rowWords, fhesi_dcrt_device_ptr(M[r][col].handle()), (size_t)rowWords * 8));
+    ck(fhesi_ksk_mark_dirty(k));      // rows written through the pointer: derived tables are rebuilt at the first key switch
     ck(fhesi_ctx_sync(c.handle()));
   }
   ~DeviceKeySwitch() { if (k) fhesi_ksk_free(k); }

@@ -54,6 +54,13 @@ int fhesi_ctx_zms_idx(const fhesi_ctx* ctx, int32_t* out_m);                    
 int fhesi_ctx_phi_m(const fhesi_ctx* ctx, int64_t* out_phim_plus_1);                /* PAlgebra::PhimX coefficients */
 int fhesi_ctx_sync(fhesi_ctx* ctx);
 void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t all work of this context runs on */
+/* Behaviour switches of one context (A/B measurements, test hooks).  Names: "ks_direct" (1 = per-chain-prime key-switch dot product, the
+ * reference's own structure FHE-SI.cpp:251-254), "ks_residues", "ks_aux60", "crt_exact", "crt_skip_cleanup" (test hook), "lanes" (2 = two
+ * concurrent half-batches), "stagger", "batch_chunk", "wave_operands", "tensor32" (0 = the fused pipeline keeps the tensor product on the
+ * chain primes).  The FHESI_<NAME> environment variables give the initial values, read once in fhesi_ctx_create -- never per call.
+ * fhesi_ctx_destroy fails while DoubleCRT / key-switch handles of the context are alive (they hold the reference's `const FHEcontext&`). */
+int fhesi_ctx_set_option(fhesi_ctx* ctx, const char* name, int64_t value);
+int fhesi_ctx_get_option(const fhesi_ctx* ctx, const char* name, int64_t* value);
 /* HIP-event stopwatch on the context's stream (bench.py's per-kernel timing) */
 int fhesi_timer_start(fhesi_ctx* ctx);
 int fhesi_timer_stop(fhesi_ctx* ctx, float* elapsed_ms);
@@ -65,6 +72,9 @@ enum { FHESI_PROF_NTT_FWD = 0, FHESI_PROF_NTT_INV = 1, FHESI_PROF_RNS = 2, FHESI
        FHESI_PROF_NTT_FWD_DIGITS_MAIN = 8 /* the fused ByteDecomp + forward-NTT tile kernel alone; units = rows it transformed */ };
 int fhesi_prof_enable(fhesi_ctx* ctx, int32_t on);      /* also clears the records */
 int fhesi_prof_read(fhesi_ctx* ctx, int32_t kernel_class, int64_t* launches, double* units, double* total_ms);
+/* demangled name (as rocprofv3 prints it, without the argument list) of the kernel the most recent profiled launch of that class ran:
+ * the roofline line of bench.py names kernels by what the library launched, not by string literals */
+int fhesi_prof_kernel_name(fhesi_ctx* ctx, int32_t kernel_class, char* name_out, size_t name_cap);
 
 /* ---- Cmodulus::FFT / iFFT, one row (CModulus.h:165-166; CModulus.cpp:90-107, 110-132) */
 int fhesi_cmod_fft(fhesi_ctx* ctx, int32_t prime, const uint64_t* coeff_limbs, int32_t nlimbs, int64_t ncoeffs, uint64_t* y_out);
@@ -104,11 +114,11 @@ int fhesi_rows_op_dev(fhesi_ctx* ctx, uint64_t* dst_dev, const uint64_t* src_dev
 int fhesi_ksk_create(fhesi_ctx* ctx, int32_t ncomp, int32_t ndigits, fhesi_ksk** out);
 int fhesi_ksk_free(fhesi_ksk* k);
 int fhesi_ksk_upload(fhesi_ksk* k, const uint64_t* rows_host);                       /* whole matrix, host layout as above */
-void* fhesi_ksk_device_ptr(fhesi_ksk* k);                                            /* HBM buffer (target of the RCCL broadcast).  The library keeps a
-                                                                                        table derived from these rows (the key's coefficient vectors
-                                                                                        transformed modulo the two largest chain primes); asking for the
-                                                                                        pointer marks it stale, so fetch the pointer BEFORE every direct
-                                                                                        write into the rows (or use fhesi_ksk_upload) */
+void* fhesi_ksk_device_ptr(fhesi_ksk* k);                                            /* HBM buffer of the rows (pure getter) */
+int fhesi_ksk_mark_dirty(fhesi_ksk* k);                                              /* call after writing the rows through the pointer (a collective that
+                                                                                        received into them): the library keeps tables derived from the rows
+                                                                                        and rebuilds them at the next key switch */
+int fhesi_ksk_upload_dev(fhesi_ksk* k, const uint64_t* rows_dev);                    /* whole matrix from another HBM buffer (copies and invalidates) */
 size_t fhesi_ksk_bytes(const fhesi_ksk* k);
 
 int fhesi_selftest_aux32(fhesi_ctx* c);                                              /* diagnostic: checks the 32-bit auxiliary transforms of the key switch

@@ -95,7 +95,13 @@ typedef struct {
   u64 *psi, *psi_sh, *ipsi, *ipsi_sh; u64 ninv, ninv_sh;
   /* general m: Bluestein tables (bluestein.cpp:103-109,121-133) */
   u64 *powers, *b, *ipowers, *ib; u64 minv;
+  /* FFT form of Bluestein (orc_set_bluestein_fft): N-point cyclic transforms of b / ib modulo the three auxiliary primes
+   * (the reference's fftRep Rb, bluestein.cpp:121-136) */
+  u64 *Rb[3], *iRb[3];
 } orc_prime;
+
+/* one auxiliary FFT prime of the N-point cyclic convolution (role of NTL's FFT primes behind fftRep) */
+typedef struct { u64 p; u64 *w, *wsh, *iw, *iwsh; u64 ninv, ninv_sh; } orc_fftprime;
 
 typedef struct {
   i64 m, phim; int L;
@@ -103,6 +109,8 @@ typedef struct {
   i64* phi;                   /* Phi_m(X) coefficients, length phim+1 (PAlgebra.cpp:55) */
   orc_prime* pr;
   int use_slow_dft;           /* evaluate through the tDFT definition instead (bluestein.cpp:149-172) */
+  int use_bluestein_fft;      /* evaluate EVERY m the way the reference does: Bluestein + N-point cyclic convolution by multi-prime FFT + CRT */
+  i64 N; int logN; orc_fftprime fp[3];
 } orc_ctx;
 
 static int mobius_i(i64 n) { int mu = 1; for (i64 p = 2; p * p <= n; p++) if (n % p == 0) { n /= p; if (n % p == 0) return 0; mu = -mu; } if (n > 1) mu = -mu; return mu; }
@@ -133,7 +141,9 @@ const char* orc_last_error(void) { return orc_err; }
 
 void orc_ctx_destroy(orc_ctx* c) {
   if (!c) return;
-  for (int i = 0; i < c->L; i++) { orc_prime* p = &c->pr[i]; free(p->psi); free(p->psi_sh); free(p->ipsi); free(p->ipsi_sh); free(p->powers); free(p->b); free(p->ipowers); free(p->ib); }
+  for (int i = 0; i < c->L; i++) { orc_prime* p = &c->pr[i]; free(p->psi); free(p->psi_sh); free(p->ipsi); free(p->ipsi_sh); free(p->powers); free(p->b); free(p->ipowers); free(p->ib);
+    for (int a = 0; a < 3; a++) { free(p->Rb[a]); free(p->iRb[a]); } }
+  for (int a = 0; a < 3; a++) { free(c->fp[a].w); free(c->fp[a].wsh); free(c->fp[a].iw); free(c->fp[a].iwsh); }
   free(c->pr); free(c->zms_idx); free(c->phi); free(c);
 }
 
@@ -194,6 +204,82 @@ static void bluestein(u64* x, const u64* a, i64 n, const u64* powers, const u64*
   free(t);
 }
 
+/* ---- FFT form of tBluesteinFFT, the algorithm the reference really runs for EVERY m (bluestein.cpp:93-144): the N-point cyclic
+ * product of :138 (N = 2^ceil(log2(2m-1)), :117) through NTL's fftRep = forward FFTs modulo several word-size FFT primes, pointwise
+ * product with the precomputed transform Rb of the chirp (:121-136), inverse FFTs and CRT back to Z_q (:119,135,138-139).  NTL is
+ * absent here, so the FFT primes are three primes = 1 mod N just below 2^62 (their product exceeds the largest coefficient
+ * m * q^2 < 2^140 of the integer convolution, which is what makes the result exact for any choice).  Used as the like-for-like CPU
+ * baseline of bench.py and cross-checked against the direct evaluation in tests/test_oracle_golden.py. */
+static void cyc_ntt(u64* a, i64 N, int logN, const u64* w, const u64* wsh, u64 p) {   /* in-place, natural in / natural out */
+  for (i64 i = 0; i < N; i++) { i64 j = (i64)brv((u64)i, logN); if (j > i) { u64 t = a[i]; a[i] = a[j]; a[j] = t; } }
+  for (i64 len = 1; len < N; len <<= 1) { i64 step = N / (2 * len);
+    for (i64 i = 0; i < N; i += 2 * len) for (i64 j = 0; j < len; j++) {
+      u64 u = a[i + j], v = mulmod_shoup(a[i + j + len], w[j * step], wsh[j * step], p);
+      a[i + j] = addmod(u, v, p); a[i + j + len] = submod(u, v, p); } }
+}
+static int bluestein_fft_setup(orc_ctx* c) {
+  if (c->N) return 0;
+  i64 m = c->m; int lg = 0; while ((1ll << lg) < 2 * m - 1) lg++;
+  i64 N = 1ll << lg; c->N = N; c->logN = lg;
+  u64 cand = ((1ull << 62) / (u64)N) * (u64)N + 1;
+  for (int a = 0; a < 3; a++) {
+    do { cand -= (u64)N; } while (!is_prime_u64(cand));
+    orc_fftprime* f = &c->fp[a]; f->p = cand;
+    u64 g = 0; for (u64 s = 2; s < 1000 && !g; s++) { u64 r = powmod(s, (cand - 1) / (u64)N, cand); if (powmod(r, (u64)N / 2, cand) == cand - 1) g = r; }
+    if (!g) { snprintf(orc_err, 256, "no N-th root of unity for the auxiliary prime"); return 1; }
+    u64 gi = invmod(g, cand);
+    f->w = malloc(8 * (N / 2)); f->wsh = malloc(8 * (N / 2)); f->iw = malloc(8 * (N / 2)); f->iwsh = malloc(8 * (N / 2));
+    u64 x = 1, y = 1;
+    for (i64 j = 0; j < N / 2; j++) { f->w[j] = x; f->wsh[j] = shoup_pre(x, cand); f->iw[j] = y; f->iwsh[j] = shoup_pre(y, cand); x = mulmod(x, g, cand); y = mulmod(y, gi, cand); }
+    f->ninv = invmod((u64)N % cand, cand); f->ninv_sh = shoup_pre(f->ninv, cand);
+  }
+  for (int i = 0; i < c->L; i++) {
+    orc_prime* p = &c->pr[i]; u64 Q = p->q;
+    if (!p->powers) {      /* power-of-two m keeps only the negacyclic tables: build the chirp tables of bluestein.cpp:103-109,126-132 too */
+      p->powers = malloc(8 * m); p->ipowers = malloc(8 * m); p->b = calloc(2 * m, 8); p->ib = calloc(2 * m, 8);
+      for (i64 j = 0; j < m; j++) { u64 e = (u64)(((u128)j * j) % (2 * m)); p->powers[j] = powmod(p->root, e, Q); p->ipowers[j] = powmod(p->rinv, e, Q); }
+      for (i64 j = 0; j < m; j++) { p->b[m - 1 + j] = p->b[m - 1 - j] = p->ipowers[j]; p->ib[m - 1 + j] = p->ib[m - 1 - j] = p->powers[j]; }
+      p->minv = invmod(m % Q, Q);
+    }
+    for (int a = 0; a < 3; a++) {
+      const orc_fftprime* f = &c->fp[a];
+      p->Rb[a] = calloc(N, 8); p->iRb[a] = calloc(N, 8);
+      for (i64 j = 0; j < 2 * m - 1; j++) { p->Rb[a][j] = p->b[j] % f->p; p->iRb[a][j] = p->ib[j] % f->p; }
+      cyc_ntt(p->Rb[a], N, lg, f->w, f->wsh, f->p); cyc_ntt(p->iRb[a], N, lg, f->w, f->wsh, f->p);
+    }
+  }
+  return 0;
+}
+int orc_set_bluestein_fft(orc_ctx* c, int on) { c->use_bluestein_fft = on; return on ? bluestein_fft_setup(c) : 0; }
+static void bluestein_fft(const orc_ctx* c, u64* x, const u64* a, const u64* powers, u64* const Rb[3], u64 q) {
+  i64 n = c->m, N = c->N;
+  int zero = 1; for (i64 i = 0; i < n; i++) zero &= (a[i] == 0);
+  if (zero) { memset(x, 0, 8 * n); return; }                            /* bluestein.cpp:96-97 */
+  u64* t = malloc(8 * n); u64* r[3];
+  for (i64 i = 0; i < n; i++) t[i] = mulmod(a[i], powers[i], q);        /* :111-113 */
+  for (int k = 0; k < 3; k++) {
+    const orc_fftprime* f = &c->fp[k]; u64* v = calloc(N, 8); r[k] = v;
+    for (i64 i = 0; i < n; i++) v[i] = t[i] % f->p;                     /* TofftRep :119 */
+    cyc_ntt(v, N, c->logN, f->w, f->wsh, f->p);
+    for (i64 i = 0; i < N; i++) v[i] = mulmod(v[i], Rb[k][i], f->p);    /* mul(Ra, Ra, Rb) :138 */
+    cyc_ntt(v, N, c->logN, f->iw, f->iwsh, f->p);                       /* FromfftRep :139 (window n-1 .. 2n-2) */
+    for (i64 i = n - 1; i < 2 * n - 1; i++) v[i] = mulmod_shoup(v[i], f->ninv, f->ninv_sh, f->p);
+  }
+  /* CRT of the three residues (Garner), reduced modulo q on the way: value = r0 + p0 (d1 + p1 d2) */
+  u64 p0 = c->fp[0].p, p1 = c->fp[1].p, p2 = c->fp[2].p;
+  u64 i01 = invmod(p0 % p1, p1), i012 = invmod(mulmod(p0 % p2, p1 % p2, p2), p2);
+  for (i64 k = 0; k < n; k++) {
+    u64 r0 = r[0][n - 1 + k], r1 = r[1][n - 1 + k], r2 = r[2][n - 1 + k];
+    u64 d1 = mulmod(submod(r1 % p1, r0 % p1, p1), i01, p1);
+    u64 v01 = addmod(r0 % p2, mulmod(p0 % p2, d1 % p2, p2), p2);
+    u64 d2 = mulmod(submod(r2, v01, p2), i012, p2);
+    u64 acc = addmod(d1 % q, mulmod(p1 % q, d2 % q, q), q);
+    acc = addmod(r0 % q, mulmod(p0 % q, acc, q), q);
+    x[k] = mulmod(acc, powers[k], q);                                   /* :140-142 */
+  }
+  free(t); for (int k = 0; k < 3; k++) free(r[k]);
+}
+
 /* negacyclic NTT, natural-order in and out (power-of-two m): y[j] = sum_k a_k psi^{(2j+1)k} */
 static void ntt_pow2_fwd(u64* y, const u64* a_in, i64 n, const orc_prime* p) {
   u64 q = p->q; int lg = ilog2(n); u64* a = malloc(8 * n); memcpy(a, a_in, 8 * n);
@@ -219,6 +305,13 @@ static void ntt_pow2_inv(u64* x, const u64* y, i64 n, const orc_prime* p) {
 /* Cmod::FFT on residues (CModulus.cpp:90-107 after conv :96): xres has ncoeffs entries in [0,q) */
 void orc_fft_residues(const orc_ctx* c, int i, const u64* xres, i64 ncoeffs, u64* y) {
   const orc_prime* p = &c->pr[i]; i64 m = c->m; u64 q = p->q;
+  if (c->use_bluestein_fft) {
+    u64* in = calloc(m, 8); u64* out = malloc(8 * m);
+    for (i64 k = 0; k < ncoeffs && k < m; k++) in[k] = xres[k];
+    bluestein_fft(c, out, in, p->powers, p->Rb, q);
+    for (i64 k = 0, j = 0; k < m; k++) if (c->zms_idx[k] >= 0) y[j++] = out[k];
+    free(in); free(out); return;
+  }
   if (p->pow2 && !c->use_slow_dft) {
     i64 n = m / 2; u64* a = calloc(n, 8);
     /* degree >= m ignored (bluestein.cpp:111-113); X^n = -1 at primitive m-th roots folds n..m-1 */
@@ -243,11 +336,12 @@ void orc_cmod_fft(const orc_ctx* c, int i, const u64* limbs, int nlimbs, i64 nco
 /* Cmod::iFFT (CModulus.cpp:110-132): returns phim coefficients in [0,q) */
 void orc_cmod_ifft(const orc_ctx* c, int i, const u64* y, u64* x) {
   const orc_prime* p = &c->pr[i]; i64 m = c->m, phim = c->phim; u64 q = p->q;
-  if (p->pow2 && !c->use_slow_dft) { ntt_pow2_inv(x, y, phim, p); return; }
+  if (p->pow2 && !c->use_slow_dft && !c->use_bluestein_fft) { ntt_pow2_inv(x, y, phim, p); return; }
   u64* in = calloc(m, 8); u64* out = malloc(8 * m);
   for (i64 k = 0, j = 0; k < m; k++) if (c->zms_idx[k] >= 0) in[k] = y[j++];      /* :117-121 */
   u64 minv = p->pow2 ? invmod(m % q, q) : p->minv;
-  if (c->use_slow_dft || p->pow2) { u64 w = mulmod(p->rinv, p->rinv, q); int zero = 1; for (i64 k = 0; k < m; k++) zero &= !in[k]; if (zero) memset(out, 0, 8 * m); else tdft(out, in, m, w, q); }
+  if (c->use_bluestein_fft) bluestein_fft(c, out, in, p->ipowers, p->iRb, q);
+  else if (c->use_slow_dft || p->pow2) { u64 w = mulmod(p->rinv, p->rinv, q); int zero = 1; for (i64 k = 0; k < m; k++) zero &= !in[k]; if (zero) memset(out, 0, 8 * m); else tdft(out, in, m, w, q); }
   else bluestein(out, in, m, p->ipowers, p->ib, q);                                /* :124 */
   for (i64 k = 0; k < m; k++) out[k] = mulmod(out[k], minv, q);                    /* :125 */
   /* rem(out, out, Phi_m) over Z_q (:128-129), Phi_m monic */

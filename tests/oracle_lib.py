@@ -36,6 +36,8 @@ def lib():
         _lib.orc_phim.argtypes = [C.c_void_p]
         _lib.orc_last_error.restype = C.c_char_p
         _lib.orc_set_slow_dft.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_set_bluestein_fft.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_set_bluestein_fft.restype = C.c_int
         _lib.orc_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_fft_residues.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         _lib.orc_cmod_fft.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
@@ -112,6 +114,12 @@ class Oracle:
 
     def set_slow_dft(self, on: bool):
         lib().orc_set_slow_dft(self.h, int(on))
+
+    def set_bluestein_fft(self, on: bool):
+        """Evaluate every transform the way the reference does for every m: Bluestein + N-point cyclic convolution by multi-prime FFT
+        (bluestein.cpp:116-139) -- the like-for-like CPU baseline; same results as the default mode."""
+        if lib().orc_set_bluestein_fft(self.h, int(on)) != 0:
+            raise ValueError(lib().orc_last_error().decode())
 
     def tables(self):
         z = np.zeros(self.m, dtype=np.int32)

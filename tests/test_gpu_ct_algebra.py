@@ -128,13 +128,13 @@ def test_wave_of_products_sum_and_key_switch(chunk, operands, monkeypatch):
     """out[g] = KeySwitch(sum_t pool[a_t] * pool[b_t]) (fhesi_ct_mul_sum_relin_dev) vs the oracle composed the way Matrix.cpp does:
     operator*= per product, += on the scaled-up ciphertexts, then ApplyKeySwitch.  chunk bounds the groups per key-switch call,
     operands the distinct ciphertexts transformed per pass (small values force the piecewise accumulation of one group)."""
-    if chunk:
-        monkeypatch.setenv("FHESI_BATCH_CHUNK", chunk)
-    if operands:
-        monkeypatch.setenv("FHESI_WAVE_OPERANDS", operands)
     m, logQ, p = 1024, 128, 23
     primes, roots = P.chain_for(m, logQ, p)
     ctx = F.Context(m, primes, roots)
+    if chunk:
+        ctx.set_option("batch_chunk", int(chunk))
+    if operands:
+        ctx.set_option("wave_operands", int(operands))
     orc = O.Oracle(m, primes, roots)
     n, L, nd, nl = ctx.phim, len(primes), R.ndigits(logQ), (logQ + 63) // 64
     rng = np.random.default_rng(99)

@@ -121,9 +121,9 @@ def test_sum_form_crt_undecided_coefficients(monkeypatch):
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     want = orc.ct_mul_relin(ksm, a[0], b[0], logQ, p)
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
-    monkeypatch.setenv("FHESI_CRT_SKIP_CLEANUP", "1")
+    ctx.set_option("crt_skip_cleanup", 1)
     assert not np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
-    monkeypatch.delenv("FHESI_CRT_SKIP_CLEANUP")
+    ctx.set_option("crt_skip_cleanup", 0)
 
     # --- centring edge: make the key-switch dot product return chosen polynomials.  Scaled-down parts = (1, 0, 0), so only digit 0
     # of part 0 is non-zero (the constant 1, whose transform is the all-ones row) and the dot product is key row (r, 0) itself.
@@ -145,10 +145,10 @@ def test_sum_form_crt_undecided_coefficients(monkeypatch):
     assert np.array_equal(out.download((2, n, nl)), want2)
     got_int = O.limbs_to_ints(out.download((2, n, nl))[0])
     assert got_int[0] == centred(h) and got_int[1] == centred(-h) and got_int[2] == centred(-h)      # (P+1)/2 wraps to -(P-1)/2
-    monkeypatch.setenv("FHESI_CRT_SKIP_CLEANUP", "1")
+    ctx.set_option("crt_skip_cleanup", 1)
     ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
     assert not np.array_equal(out.download((2, n, nl)), want2)
-    monkeypatch.delenv("FHESI_CRT_SKIP_CLEANUP")
+    ctx.set_option("crt_skip_cleanup", 0)
 
 
 @pytest.mark.parametrize("m,logQ,p", [(4096, 128, 23), (32768, 512, 23), (1 << 16, 200, 23)])
@@ -161,14 +161,15 @@ def test_key_switch_paths_agree(m, logQ, p, monkeypatch):
     want = orc.ct_mul_relin(ksm, a[0], b[0], logQ, p)
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
-    monkeypatch.setenv("FHESI_KS_DIRECT", "1")
+    ctx.set_option("ks_direct", 1)
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
-    monkeypatch.delenv("FHESI_KS_DIRECT")
+    ctx.set_option("ks_direct", 0)
     # new key rows written straight into HBM
     rng = np.random.default_rng(m)
     ksm2 = np.stack([P.rand_rows(rng, [int(q) for q in ctx.primes], ctx.phim, 3 * nd) for _ in range(2)])
     stage = ctx.upload(ksm2)
     ctx.dev_copy(ksk.device_ptr, stage.ptr.value, ksm2.nbytes)
+    ksk.mark_dirty()
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], orc.ct_mul_relin(ksm2, a[0], b[0], logQ, p))
 
 
@@ -215,9 +216,9 @@ def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 4242, count)
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     ref = ctx.ct_mul_relin(ksk, logQ, p, a, b)
-    for env in ("FHESI_KS_AUX60", "FHESI_KS_RESIDUES", "FHESI_KS_DIRECT"):
-        monkeypatch.setenv(env, "1")
+    for opt in ("ks_aux60", "ks_residues", "ks_direct"):
+        ctx.set_option(opt, 1)
         ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)        # a fresh matrix: the derived table is built for the selected form
-        assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), env
-        monkeypatch.delenv(env)
+        assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), opt
+        ctx.set_option(opt, 0)
     assert np.array_equal(ref[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
