@@ -1,14 +1,13 @@
 // fhesi_matrix.h -- mirror of Matrix<T> (Matrix.h:16-83, Matrix.cpp) and of Regression (Regression.h:68-191) on the classes of
 // fhesi_host.h, plus the batched evaluator that SURVEY.md 8(f) ranks next after the multiplication path:
 //
-//   * Matrix<T>            same member names, argument meaning and evaluation order as the reference template, so it can be
-//                          instantiated with Ciphertext (object-at-a-time, every operation a C-ABI call) or with a plaintext ring type.
+//   * Matrix<T>            the container only (storage, shape, element access, wire format).
 //   * CtPool / ProductWave device-resident unscaled ciphertexts addressed by index; one ProductWave = many independent
 //                          "sum of products, then key switch" groups submitted as ONE fhesi_ct_mul_sum_relin_dev call.
-//   * Regression           Regress() walks the reference's control flow literally; RegressBatched() evaluates the same
-//                          expression DAG level by level (inner products -> SumBatchedData -> minors of growing size ->
+//   * Regression           RegressBatched() evaluates the expression DAG of Regression::Regress (Regression.h:102-149) level by level (inner products -> SumBatchedData -> minors of growing size ->
 //                          determinant -> adj * last) in waves.  Every ciphertext operation is deterministic, so equal minors
-//                          the Laplace recursion of Matrix.cpp:227-263 recomputes are evaluated once; results are bit-identical.
+//                          the Laplace recursion of Matrix.cpp:227-263 recomputes are evaluated once; results are bit-identical to the
+//                          literal object-at-a-time control flow (tests/host/matrix_literal.h: RegressLiteral).
 // Slot packing (PlaintextSpace.cpp) is outside the hot-path scope: plaintexts are coefficient vectors and only the slot COUNT
 // (Regression.h:72-79) is mirrored.  GenerateNoise (Regression.h:180-191) needs EmbedInSlots and is therefore not applied;
 // both evaluators return the unmasked theta / det.
@@ -20,131 +19,37 @@
 
 namespace fhesi {
 
-// ---------------------------------------------------------------- Matrix<T> (Matrix.h / Matrix.cpp)
+// ---------------------------------------------------------------- Matrix<T> as a container (Matrix.h:16-83)
+// Storage, shape and element access only: what Regression keeps its encrypted data in and what the wire format of
+// Serialization.h:60-85 carries.  The reference's object-at-a-time matrix ARITHMETIC (Matrix.cpp:57-98,150-263) is not part of this
+// package -- the device evaluates those expressions in waves (RegressBatched below); a literal restatement of it lives in
+// tests/host/matrix_literal.h as the checker the waves are compared with.
 template <class T>
 class Matrix {
+ protected:
   T dummy;
   std::vector<std::vector<T>> mat;      // storage rows; `transpose` swaps the roles of the two indices (Matrix.cpp:144-152)
   bool transpose = false;
-
   T& ElemAt(unsigned r, unsigned c) { return transpose ? mat[c][r] : mat[r][c]; }
   const T& ElemAt(unsigned r, unsigned c) const { return transpose ? mat[c][r] : mat[r][c]; }
-
-  // Laplace expansion along the first unused row (Matrix.cpp:227-263); `reduce` runs on every partial determinant of size >= 2
-  void Determinant(T& det, std::vector<bool>& usedRows, std::vector<bool>& usedCols, unsigned dim, std::function<void(T&)> reduce) const {
-    const unsigned matDim = NumRows();
-    unsigned row = 0;
-    while (usedRows[row]) ++row;
-    bool negative = false, first = true;
-    for (unsigned col = 0; col < matDim; ++col) {
-      if (usedCols[col]) continue;
-      if (dim == 1) { det = ElemAt(row, col); return; }
-      T term = ElemAt(row, col);
-      if (negative) term *= -1;
-      negative = !negative;
-      usedRows[row] = usedCols[col] = true;
-      T minor(dummy);
-      Determinant(minor, usedRows, usedCols, dim - 1, reduce);
-      usedRows[row] = usedCols[col] = false;
-      term *= minor;
-      if (first) { det = term; first = false; } else det += term;
-    }
-    if (reduce) reduce(det);
-  }
 
  public:
   Matrix() : dummy(T()) {}
   Matrix(const T& d) : dummy(d) {}
   Matrix(unsigned nRows, unsigned nCols, const T& d) : dummy(d) { Resize(nRows, nCols); }
   Matrix(unsigned nRows, unsigned nCols) : dummy(T()) { Resize(nRows, nCols); }
-
   unsigned NumRows() const { return mat.empty() ? 0 : (unsigned)(transpose ? mat[0].size() : mat.size()); }
   unsigned NumCols() const { return mat.empty() ? 0 : (unsigned)(transpose ? mat.size() : mat[0].size()); }
   void Resize(unsigned nRows, unsigned nCols) { Clear(); transpose = false; mat.assign(nRows, std::vector<T>(nCols, dummy)); }
   void Clear() { mat.clear(); }
   void Transpose() { transpose = !transpose; }
   void AddRow(std::vector<T>& row) { if (!transpose) mat.push_back(row); }                 // no support on a transposed matrix (Matrix.cpp:293-297)
-  void Concatenate(Matrix<T>& o) { if (!transpose) mat.insert(mat.end(), o.mat.begin(), o.mat.end()); }
   void MapAll(std::function<void(T&)> func) { for (auto& r : mat) for (auto& e : r) func(e); }   // storage order (Matrix.cpp:306-312)
-
   T& operator()(unsigned r, unsigned c) { return ElemAt(r, c); }
   const T& operator()(unsigned r, unsigned c) const { return ElemAt(r, c); }
   std::vector<T>& operator[](unsigned r) { return mat[r]; }
   const std::vector<T>& operator[](unsigned r) const { return mat[r]; }
-  Matrix& operator=(const Matrix& o) { mat = o.mat; transpose = o.transpose; dummy = o.dummy; return *this; }
-
-  Matrix& operator+=(const Matrix& o) { for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) ElemAt(i, j) += o(i, j); return *this; }
-  Matrix operator+(const Matrix& o) const { Matrix r = *this; r += o; return r; }
-  Matrix& operator-=(const Matrix& o) {                                                    // Matrix.cpp:30-40
-    for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) { T t = o(i, j); t *= -1; ElemAt(i, j) += t; }
-    return *this;
-  }
-  Matrix operator-(const Matrix& o) const { Matrix r = *this; r -= o; return r; }
-
-  Matrix& operator*=(Matrix& o) {                                                          // Matrix.cpp:57-79
-    if (mat.empty()) return *this;
-    Matrix prod(NumRows(), o.NumCols(), dummy);
-    for (unsigned i = 0; i < NumRows(); ++i)
-      for (unsigned j = 0; j < o.NumCols(); ++j) {
-        prod(i, j) = ElemAt(i, 0);
-        prod(i, j) *= o(0, j);
-        for (unsigned k = 1; k < NumCols(); ++k) { T t = ElemAt(i, k); t *= o(k, j); prod(i, j) += t; }
-      }
-    std::swap(prod.mat, mat);
-    transpose = false;
-    return *this;
-  }
-  Matrix& operator*=(std::vector<T>& v) {                                                  // Matrix.cpp:81-98 (the entries are multiplied in place first)
-    if (mat.empty()) return *this;
-    Matrix prod(NumRows(), 1, dummy);
-    for (unsigned i = 0; i < NumRows(); ++i) {
-      ElemAt(i, 0) *= v[0];
-      prod(i, 0) = ElemAt(i, 0);
-      for (unsigned j = 1; j < NumCols(); ++j) { ElemAt(i, j) *= v[j]; prod(i, 0) += ElemAt(i, j); }
-    }
-    std::swap(mat, prod.mat);
-    transpose = false;
-    return *this;
-  }
-  Matrix& operator*=(T& s) { for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) ElemAt(i, j) *= s; return *this; }
-  Matrix operator*(Matrix& o) const { Matrix r = *this; r *= o; return r; }
-  Matrix operator*(std::vector<T>& v) const { Matrix r = *this; r *= v; return r; }
-
-  void MultByTranspose() {                                                                 // Matrix.cpp:150-174: upper triangle, mirrored
-    if (mat.empty()) return;
-    Matrix prod(NumRows(), NumRows(), dummy);
-    for (unsigned i = 0; i < NumRows(); ++i)
-      for (unsigned j = i; j < NumRows(); ++j) {
-        prod(i, j) = ElemAt(i, 0);
-        prod(i, j) *= ElemAt(j, 0);
-        for (unsigned k = 1; k < NumCols(); ++k) { T t = ElemAt(i, k); t *= ElemAt(j, k); prod(i, j) += t; }
-        if (i != j) prod(j, i) = prod(i, j);
-      }
-    std::swap(prod.mat, mat);
-    transpose = false;
-  }
-  void Determinant(T& det, std::function<void(T&)> reduce = nullptr) const {
-    std::vector<bool> usedRows(NumRows()), usedCols(NumRows());
-    Determinant(det, usedRows, usedCols, NumRows(), reduce);
-  }
-  void Invert(T& det, std::function<void(T&)> reduce = nullptr) {                          // Matrix.cpp:182-216: adjugate, then det from its first column
-    const unsigned dim = NumRows();
-    Matrix adj(dim, dim, dummy);
-    std::vector<bool> usedRows(dim), usedCols(dim);
-    for (unsigned i = 0; i < dim; ++i)
-      for (unsigned j = 0; j < dim; ++j) {
-        usedRows[i] = usedCols[j] = true;
-        Determinant(adj(j, i), usedRows, usedCols, dim - 1, reduce);
-        usedRows[i] = usedCols[j] = false;
-        if ((i + j) % 2 == 1) adj(j, i) *= -1;
-      }
-    det = ElemAt(0, 0);
-    det *= adj(0, 0);
-    for (unsigned i = 1; i < dim; ++i) { T t = ElemAt(0, i); t *= adj(i, 0); det += t; }
-    if (reduce) reduce(det);
-    std::swap(adj.mat, mat);
-    transpose = false;
-  }
+  const T& Dummy() const { return dummy; }
 };
 
 // ---------------------------------------------------------------- slot counts (PlaintextSpace.cpp:29-43): factors of Phi_m mod p
@@ -303,23 +208,11 @@ class Regression {
   }
   void Clear() { data.Clear(); labels.clear(); }
 
-  // The reference's control flow, one Ciphertext object at a time (Regression.h:102-149 without the GenerateNoise masking)
-  void Regress(std::vector<Ciphertext>& theta, Ciphertext& det) const {
-    Matrix<Ciphertext> dataCopy = data;
-    std::vector<Ciphertext> lab = labels;
-    dataCopy.Transpose();
-    Matrix<Ciphertext> last = dataCopy * lab;
-    dataCopy.MultByTranspose();
-    auto processFunc = [this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); SumBatchedData(ct); };
-    last.MapAll(processFunc);
-    dataCopy.MapAll(processFunc);
-    if (data.NumCols() == 1) { det = dataCopy(0, 0); theta.assign(1, last(0, 0)); return; }
-    dataCopy.Invert(det, [this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); });
-    dataCopy *= last;
-    dataCopy.MapAll([this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); });
-    theta.assign(dataCopy.NumRows(), Ciphertext(context));
-    for (unsigned i = 0; i < dataCopy.NumRows(); ++i) theta[i] = dataCopy(i, 0);
-  }
+  // access for the object-at-a-time checker (tests/host/matrix_literal.h)
+  const Matrix<Ciphertext>& Data() const { return data; }
+  const KeySwitchSI& KeySwitch() const { return keySwitch; }
+  const FHEcontext& Context() const { return context; }
+  void SumBatchedDataObject(Ciphertext& ct) const { SumBatchedData(ct); }
 
   // The same expression DAG in waves on the device
   void RegressBatched(std::vector<Ciphertext>& theta, Ciphertext& det) {

@@ -7,7 +7,7 @@
 #include <cstring>
 #include <iostream>
 
-#include "fhesi_host.h"
+#include "../../fhe-si_amd/host/fhesi_host.h"
 
 using namespace fhesi;
 namespace fhesi { FHEcontext* activeContext = nullptr; }

@@ -1,7 +1,7 @@
 // test_modswitch.cpp -- DoubleCRT::addPrimesAndScale / scaleDownToSet (DoubleCRT.cpp:162-208, 518-558) on the mirrored
 // class: prints the resulting rows as JSON; tests/test_gpu_host_mirror.py compares them with the Python model.
 #include <iostream>
-#include "fhesi_host.h"
+#include "../../fhe-si_amd/host/fhesi_host.h"
 using namespace fhesi;
 namespace fhesi { FHEcontext* activeContext = nullptr; }
 static void dump(const char* name, const DoubleCRT& d, bool last = false) {

@@ -1,13 +1,13 @@
 // test_regression.cpp -- counterpart of the reference's Test_Regression driver (Test_Regression.cpp:10-131) on the mirrored
-// classes, with coefficient-form plaintexts (slot packing is outside the hot-path scope, see fhesi_matrix.h).
+// classes, with coefficient-form plaintexts (slot packing is outside the hot-path scope, see fhe-si_amd/host/fhesi_matrix.h).
 //
 //   test_regression p generator dim nrows [seed] [--batched-only] [--check=ring|slots|none] [--m=M] [--logQ=B]
 //
 // Context as in Test_Regression.cpp:97-125: m = p-1, logQ from the same noise formula, SetUpSIContext(xi).  The data matrix
 // (nrows x dim) and the labels are random polynomials over Z_p; Regression::Regress is evaluated three ways
-//   (1) object at a time through Matrix<Ciphertext> -- the reference's control flow,
+//   (1) object at a time through LMatrix<Ciphertext> (matrix_literal.h) -- the reference's control flow,
 //   (2) in waves on the device (Regression::RegressBatched),
-//   (3) in the plaintext ring Z_p[X]/Phi_m with the same Matrix<T> template,
+//   (3) in the plaintext ring Z_p[X]/Phi_m with the same LMatrix<T> template,
 // and the run succeeds when (1) and (2) give bit-identical ciphertexts and both decrypt to (3).
 // --check=slots replaces (3) for sizes where ring arithmetic on the host is too slow (the reference's own d = 8, p = 8423
 // configuration): p = 1 mod m there, so Z_p[X]/Phi_m splits into phi(m) copies of Z_p (the plaintext slots of
@@ -19,7 +19,7 @@
 #include <iostream>
 #include <string>
 
-#include "fhesi_matrix.h"
+#include "matrix_literal.h"
 
 using namespace fhesi;
 namespace fhesi { FHEcontext* activeContext = nullptr; }
@@ -107,7 +107,7 @@ int main(int argc, char* argv[]) {
 
   std::vector<std::vector<Plaintext>> ptxtData(nrows, std::vector<Plaintext>(dim));
   std::vector<Plaintext> ptxtLabels(nrows);
-  Matrix<RingElem> plainX(nrows, dim);
+  LMatrix<RingElem> plainX(nrows, dim);
   std::vector<RingElem> plainY(nrows);
   for (unsigned i = 0; i < nrows; ++i) {
     for (unsigned j = 0; j < dim; ++j) { ptxtData[i][j].message.resize(phim); for (auto& v : ptxtData[i][j].message) v = RandomBnd((long)p); plainX(i, j).c = ptxtData[i][j].message; }
@@ -119,8 +119,8 @@ int main(int argc, char* argv[]) {
   // (3) plaintext ring, same template and the same sequence as Regression::Regress
   std::vector<RingElem> thetaP; RingElem detP;
   if (check == "ring") {
-    Matrix<RingElem> A = plainX; A.Transpose();
-    Matrix<RingElem> last = A * plainY;
+    LMatrix<RingElem> A = plainX; A.Transpose();
+    LMatrix<RingElem> last = A * plainY;
     A.MultByTranspose();
     auto sumBatched = [&](RingElem& e) { for (unsigned k : regress.AutomorphismExponents()) { RingElem t = e; t >>= (long)k; e += t; } };
     last.MapAll(sumBatched); A.MapAll(sumBatched);
@@ -137,7 +137,7 @@ int main(int argc, char* argv[]) {
     const size_t r = regress.AutomorphismExponents().size();
     for (long e : {1L, (long)g, (long)(m - 1)}) {
       slotE.push_back(e);
-      Matrix<ModP> A(dim, dim); std::vector<ModP> lastv(dim);
+      LMatrix<ModP> A(dim, dim); std::vector<ModP> lastv(dim);
       long ge = 1;                       // g^j mod m
       for (unsigned long j = 0; j < (1ul << r); ++j, ge = (long)(((unsigned long)ge * g) % m)) {
         const long x = (long)PowerMod(zeta, ((unsigned long)e * ge) % m, p);
@@ -150,7 +150,7 @@ int main(int argc, char* argv[]) {
       }
       ModP dS; std::vector<ModP> tS(dim);
       if (dim == 1) { dS = A(0, 0); tS[0] = lastv[0]; }
-      else { Matrix<ModP> last(dim, 1); for (unsigned a = 0; a < dim; ++a) last(a, 0) = lastv[a]; A.Invert(dS); A *= last; for (unsigned a = 0; a < dim; ++a) tS[a] = A(a, 0); }
+      else { LMatrix<ModP> last(dim, 1); for (unsigned a = 0; a < dim; ++a) last(a, 0) = lastv[a]; A.Invert(dS); A *= last; for (unsigned a = 0; a < dim; ++a) tS[a] = A(a, 0); }
       detS.push_back(dS); thetaS.push_back(tS);
     }
   }
@@ -190,7 +190,7 @@ int main(int argc, char* argv[]) {
   if (!batchedOnly) {
     std::vector<Ciphertext> thetaA; Ciphertext detA(context);
     t0 = now();
-    regress.Regress(thetaA, detA);
+    RegressLiteral(regress, thetaA, detA);
     double tA = now() - t0;
     std::cout << "object at a time: " << tA << " s" << std::endl;
     check_fn("object at a time", thetaA, detA);

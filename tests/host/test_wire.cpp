@@ -14,7 +14,7 @@
 #include <iostream>
 #include <sstream>
 
-#include "fhesi_serialization.h"
+#include "../../fhe-si_amd/host/fhesi_serialization.h"
 
 using namespace fhesi;
 namespace fhesi { FHEcontext* activeContext = nullptr; }

@@ -1,0 +1,101 @@
+"""GPU parity at the sizes BASELINE.json's `configs` state (configs[1], [3], [4] were only exercised at reduced
+sizes).  Each test names the config it covers; all comparisons are bit-exact against the oracle (or, for configs[3], against the
+plaintext regression the reference's own Test_Regression compares with, Regression.h:193-214)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fhe_si_amd as F
+import fhesi_pyref as R
+import oracle_lib as O
+import params as P
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config1_ntt_round_trip_n8192_eight_primes():
+    """configs[1]: single-GPU DoubleCRT NTT, n = 2^13, the exact chain of SURVEY 8(d) item 2 = the first 8 primes = 1 mod 2^15
+    descending from 2^60; forward vs oracle, inverse vs oracle, forward-then-inverse = identity, on a batch."""
+    m, n, L, B = 1 << 14, 1 << 13, 8, 33
+    primes, roots = P.first_primes(m, L)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    rng = np.random.default_rng(42)
+    rows = P.rand_rows(rng, primes, n, B)
+    rows[0, 0, :] = 0
+    rows[1, 3, :] = np.uint64(primes[3] - 1)
+    buf = ctx.upload(rows)
+    ctx.rows_ntt_fwd(buf, B)
+    got = buf.download(rows.shape)
+    for c in (0, 1, B - 1):                      # first, edge and last DoubleCRT of the batch, every prime
+        for i in range(L):
+            assert np.array_equal(got[c, i], orc.fft_residues(i, rows[c, i])), (c, i)
+    ctx.rows_ntt_inv(buf, B)
+    assert np.array_equal(buf.download(rows.shape), rows)
+    ev = P.rand_rows(rng, primes, n, 2)
+    b2 = ctx.upload(ev)
+    ctx.rows_ntt_inv(b2, 2)
+    back = b2.download(ev.shape)
+    for c in range(2):
+        for i in range(L):
+            assert np.array_equal(back[c, i], orc.cmod_ifft(i, ev[c, i])), (c, i)
+
+
+def test_config4_stress_ring_several_chunks():
+    """configs[4]: n = 2^15, logQ = 1024 (35 primes, 43 digits).  A batch of 35 multiplications = 3 chunks of the library at that ring
+    (16-17 ciphertexts each): ciphertext 0 and the last one are checked against the oracle, and every ciphertext against the same
+    pair multiplied alone (a chunk boundary must not change a result)."""
+    m, logQ, p, count = 1 << 16, 1024, 65537, 35
+    primes, roots = P.chain_for(m, logQ, p)
+    assert len(primes) == 35
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(9)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    a[count - 1, 0, 0] = O.ints_to_limbs([-(1 << (logQ - 1))], nl)[0]
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert ctx.get_option("batch_chunk") == 0        # the library's own chunking (about 16 ciphertexts per chunk at this ring)
+    for c in (0, count - 1):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    for c in (15, 16, 17, 33, 34):                   # around the chunk boundaries, each multiplied alone
+        assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[c:c + 1], b[c:c + 1])[0], got[c]), c
+
+
+def test_config2_metric_ring_several_chunks():
+    """configs[2] at a batch that spans three chunks of 64: first, last and chunk-boundary ciphertexts vs the oracle."""
+    m, logQ, p, count = 1 << 15, 512, 23, 130
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(2)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    for c in (0, 63, 64, 128, 129):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+
+
+def test_config3_regression_at_the_reference_size():
+    """configs[3] at its own parameters: Test_Regression's safe prime p = 8423 (m = 8422, phi(m) = 4210, Bluestein rows with N = 2^15),
+    d = 8, one data block of 4096 points (blockSize = usable slots = 4096, Test_Regression.cpp:111-121), logQ = 341 by the
+    reference's noise formula (Test_Regression.cpp:100-108) => 13 primes, 15 digits, 12 automorphism keys.  RegressBatched on the
+    device; theta and det decrypt to the plaintext regression (Regression.h:193-214), compared slot-wise over Z_p."""
+    host = os.path.join(ROOT, "tests", "host")
+    subprocess.check_call(["make", "-C", host], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(host, "test_regression"), "8423", "7", "8", "1", "1", "--batched-only", "--check=slots"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "phi(m)=4210 logQ=341 primes=13 ndigits=15 dim=8 rows=1" in r.stdout, r.stdout
+    assert "automorphism keys: 12" in r.stdout
+    assert "batched: decrypts to the plaintext regression: yes" in r.stdout
+    assert "Test SUCCEEDED" in r.stdout
