@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
     "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
     "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
+    "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -136,6 +137,8 @@ def _load():
         "fhesi_ctx_set_option": [_vp, C.c_char_p, _i64],
         "fhesi_ctx_get_option": [_vp, C.c_char_p, _vp],
         "fhesi_ksk_mark_dirty": [_vp],
+        "fhesi_dcrt_add_primes_and_scale": [_vp, _vp, _i32, _u64, _vp],
+        "fhesi_dcrt_scale_down_to_set": [_vp, _vp, _i32, _u64],
         "fhesi_ksk_upload_dev": [_vp, _vp],
     }
     for name, args in sig.items():
@@ -469,6 +472,18 @@ class DoubleCRT:
     def remove_primes(self, idx):
         ia = np.array(list(idx), dtype=np.int32)
         _ck(_load().fhesi_dcrt_remove_primes(self.h, _p(ia), len(ia)))
+
+    def add_primes_and_scale(self, idx, p: int) -> float:
+        """DoubleCRT::addPrimesAndScale (DoubleCRT.cpp:162-208); returns the logarithm of the scaling factor."""
+        ia = np.array(list(idx), dtype=np.int32)
+        lf = C.c_double(0.0)
+        _ck(_load().fhesi_dcrt_add_primes_and_scale(self.h, _p(ia), len(ia), p, C.byref(lf)))
+        return lf.value
+
+    def scale_down_to_set(self, idx, p: int):
+        """DoubleCRT::scaleDownToSet (DoubleCRT.cpp:518-558)."""
+        ia = np.array(list(idx), dtype=np.int32)
+        _ck(_load().fhesi_dcrt_scale_down_to_set(self.h, _p(ia), len(ia), p))
 
     def equals(self, other: "DoubleCRT") -> bool:
         eq = _i32(0)

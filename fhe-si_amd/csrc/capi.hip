@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <cxxabi.h>
 #include <string>
 
@@ -759,6 +760,144 @@ extern "C" int fhesi_dcrt_remove_primes(fhesi_dcrt* d, const int32_t* prime_idx,
   HIP_TRY(hipFree(d->d_rows));
   d->d_rows = d_new;
   d->idx = keep;
+  return 0;
+}
+
+// magnitude of a non-negative big integer modulo a word (host scalars of the modulus-switching methods)
+static u64 bn_mag_mod(const std::vector<u64>& a, u64 q) { u64 r = 0; for (size_t i = a.size(); i-- > 0;) r = (u64)((((u128)r << 64) | a[i]) % q); return r; }
+static u64 inv_mod_word(u64 a, u64 p) {      // a^-1 mod p for any p > 1 with gcd(a, p) = 1 (NTL InvMod); 0 if not invertible
+  __int128 t = 0, nt = 1, r = p, nr = a % p;
+  while (nr) { const __int128 qq = r / nr; __int128 tmp = t - qq * nt; t = nt; nt = tmp; tmp = r - qq * nr; r = nr; nr = tmp; }
+  if (r != 1) return 0;
+  if (t < 0) t += p;
+  return (u64)t;
+}
+
+// replaces the row storage of d by the rows of the ascending set `idx_new`: rows present in the old set are copied, the others zero-filled
+static int dcrt_reindex(fhesi_dcrt* d, const std::vector<int>& idx_new) {
+  fhesi_ctx* c = d->ctx;
+  const i64 n = c->phim;
+  u64* d_new;
+  HIP_TRY(hipMalloc(&d_new, std::max<size_t>(8, idx_new.size() * n * 8)));
+  for (size_t u = 0; u < idx_new.size(); ++u) {
+    const int so = slot_of(d, idx_new[u]);
+    if (so >= 0) HIP_TRY(hipMemcpyAsync(d_new + (i64)u * n, d->d_rows + (i64)so * n, n * 8, hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(hipMemsetAsync(d_new + (i64)u * n, 0, n * 8, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipFree(d->d_rows));
+  d->d_rows = d_new;
+  d->idx = idx_new;
+  return 0;
+}
+
+// rows of d (all slots) *= per-slot word scalars
+static int dcrt_scale_rows(fhesi_dcrt* d, const std::vector<u64>& sc) {
+  fhesi_ctx* c = d->ctx;
+  const int K = (int)d->idx.size();
+  void* d_sc;
+  FHESI_TRY(ws_reserve(c, 4, K * 8 + 64, &d_sc));
+  HIP_TRY(hipMemcpyAsync(d_sc, sc.data(), K * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, d->idx, &d_pos));
+  return launch_ew_scalar(c, d->d_rows, (const u64*)d_sc, 1, K, d_pos, FHESI_OP_MUL);
+}
+
+extern "C" int fhesi_dcrt_add_primes_and_scale(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, uint64_t p, double* log_factor_out) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  if (log_factor_out) *log_factor_out = 0.0;
+  if (nidx == 0) return 0;                                                                // DoubleCRT.cpp:165
+  if (p < 2) FHESI_FAIL("addPrimesAndScale: plaintext modulus must be at least 2");      // :166
+  std::vector<int> add(prime_idx, prime_idx + nidx);
+  std::sort(add.begin(), add.end());
+  for (size_t i = 0; i < add.size(); ++i) {
+    if (add[i] < 0 || add[i] >= c->L || (i && add[i] == add[i - 1])) FHESI_FAIL("addPrimesAndScale: prime index %d out of range or repeated", add[i]);
+    if (slot_of(d, add[i]) >= 0) FHESI_FAIL("addPrimesAndScale: index sets must be disjoint");   // :167
+  }
+  // factor = prod q_i * ((prod q_i)^-1 mod p)   (:170-182); only its residues modulo the existing primes reach the device
+  std::vector<u64> factor{1};
+  double lf = 0.0;
+  for (int i : add) { factor = hm::bn_mul_small(factor, c->q[i]); lf += std::log((double)c->q[i]); }
+  const u64 prodInv = inv_mod_word(bn_mag_mod(factor, p), p);
+  if (!prodInv) FHESI_FAIL("addPrimesAndScale: product of the added primes is not invertible modulo p (InvMod)");
+  factor = hm::bn_mul_small(factor, prodInv);
+  lf += std::log((double)prodInv);
+  if (!d->idx.empty()) {
+    std::vector<u64> sc(d->idx.size());
+    for (size_t s = 0; s < d->idx.size(); ++s) sc[s] = bn_mag_mod(factor, c->q[d->idx[s]]);    // f = factor % qi (:190)
+    FHESI_TRY(dcrt_scale_rows(d, sc));                                                     // MulModPrecon loop (:193-196)
+  }
+  std::vector<int> uni(d->idx);
+  uni.insert(uni.end(), add.begin(), add.end());
+  std::sort(uni.begin(), uni.end());
+  FHESI_TRY(dcrt_reindex(d, uni));                                                         // new rows filled with zeros (:200-205)
+  if (log_factor_out) *log_factor_out = lf;
+  return 0;
+}
+
+extern "C" int fhesi_dcrt_scale_down_to_set(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, uint64_t p) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  if (p < 2) FHESI_FAIL("scaleDownToSet: plaintext modulus must be at least 2");
+  std::vector<int> keep, diff;
+  for (int q : d->idx) (std::find(prime_idx, prime_idx + nidx, q) != prime_idx + nidx ? keep : diff).push_back(q);
+  if (keep.empty()) FHESI_FAIL("scaleDownToSet: the target set does not intersect the index set");      // assert(card(intersect) > 0), DoubleCRT.cpp:525
+  if (diff.empty()) FHESI_FAIL("scaleDownToSet: no prime to drop");                                       // assert(card(diff) > 0), :526
+  const i64 n = c->phim;
+  const int K = (int)d->idx.size(), Kd = (int)diff.size(), Kk = (int)keep.size();
+  // diffProd and the scalars derived from it (:528, :538)
+  std::vector<u64> D{1};
+  for (int i : diff) D = hm::bn_mul_small(D, c->q[i]);
+  const u64 dp = bn_mag_mod(D, p);
+  const u64 u = inv_mod_word(dp, p);
+  if (!u) FHESI_FAIL("scaleDownToSet: product of the dropped primes is not invertible modulo p (InvMod)");
+  // *this *= (diffProd % p)   (:529) -- every row, the dropped ones included
+  {
+    std::vector<u64> sc(K);
+    for (int s = 0; s < K; ++s) sc[s] = dp % c->q[d->idx[s]];
+    FHESI_TRY(dcrt_scale_rows(d, sc));
+  }
+  // toPoly(delta, diff)   (:531-532): inverse transforms of the dropped rows + CRT over them, centred modulo D
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, diff, &t));
+  const int W = t->W + 1;                      // room for D p and a sign
+  void *d_tmp, *d_delta, *d_e, *d_slots;
+  FHESI_TRY(ws_reserve(c, 0, (size_t)std::max(Kd, Kk) * n * 8, &d_tmp));
+  for (int k = 0; k < Kd; ++k)
+    HIP_TRY(hipMemcpyAsync((u64*)d_tmp + (i64)k * n, d->d_rows + (i64)slot_of(d, diff[k]) * n, n * 8, hipMemcpyDeviceToDevice, c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, diff, &d_pos));
+  FHESI_TRY(row_inv(c, (u64*)d_tmp, 1, Kd, d_pos, diff.data()));
+  std::vector<int> slots(Kd);
+  for (int k = 0; k < Kd; ++k) slots[k] = k;
+  FHESI_TRY(ws_reserve(c, 4, Kd * sizeof(int) + 64, &d_slots));
+  HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), Kd * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  FHESI_TRY(ws_reserve(c, 1, (size_t)n * W * 8, &d_delta));
+  FHESI_TRY(ws_reserve(c, 2, (size_t)n * W * 8, &d_e));
+  FHESI_TRY(launch_crt(c, t, (const u64*)d_tmp, Kd, (const int*)d_slots, 1, 0, 0, 0, (u64*)d_delta, W));
+  // delta <- delta * factor - delta, centred modulo D p   (:538-545) -- modswitch_delta_kernel
+  std::vector<u64> consts((size_t)3 * W, 0);
+  std::vector<u64> M = hm::bn_mul_small(D, p);
+  if ((int)M.size() > W || (M.size() == (size_t)W && (M.back() >> 63))) FHESI_FAIL("scaleDownToSet: D p does not fit %d limbs", W);
+  for (size_t i = 0; i < D.size(); ++i) consts[i] = D[i];
+  for (size_t i = 0; i < M.size(); ++i) consts[W + i] = M[i];
+  for (int i = 0; i < W; ++i) consts[2 * W + i] = (consts[W + i] >> 1) | (i + 1 < W ? consts[W + i + 1] << 63 : 0);
+  FHESI_TRY(launch_modswitch_delta(c, (const u64*)d_delta, W, consts.data(), p, u, (u64*)d_e));
+  // removePrimes(diff); *this += delta; *this /= diffProd   (:555-557)
+  FHESI_TRY(dcrt_reindex(d, keep));
+  FHESI_TRY(upload_idx(c, keep, &d_pos));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)d_e, W, n, 1, 1, nullptr, (u64*)d_tmp, Kk, d_pos));
+  FHESI_TRY(row_fwd(c, (u64*)d_tmp, 1, Kk, d_pos, keep.data()));
+  FHESI_TRY(launch_ew_op(c, d->d_rows, (const u64*)d_tmp, 1, Kk, d_pos, FHESI_OP_ADD));
+  std::vector<u64> sc(Kk);
+  for (int s = 0; s < Kk; ++s) { const u64 q = c->q[keep[s]]; sc[s] = hm::invmod(bn_mag_mod(D, q), q); }
+  FHESI_TRY(dcrt_scale_rows(d, sc));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 

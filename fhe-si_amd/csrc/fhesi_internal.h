@@ -260,6 +260,7 @@ int launch_rns_reduce(fhesi_ctx* ctx, const u64* d_limbs, int nlimbs, i64 ncoeff
 // d_slot_of: device [K] layout slot of the k-th prime of the subset (nullptr: slot = prime index); npolys = number of polynomials.
 int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode, int positive,
                int logQ, u64* d_out, int nl_out);
+int launch_modswitch_delta(fhesi_ctx* ctx, const u64* d_delta, int W, const u64* consts_host /* D, D p, floor(D p / 2): 3 W words */, u64 p, u64 u, u64* d_e);
 // ByteDecomp: parts limb-major [npolys][nl][n] -> digit residue rows [npolys][nd][L][n]
 int launch_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int logQ, int digit_bits, int nd, i64 npolys, u64* d_rows, u64 only_below_q = 0);
 

@@ -753,6 +753,64 @@ int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots
   FHESI_FAIL("CRT: prime-set product of %d limbs exceeds the supported 44", W);
 }
 
+// ----------------------------------------------------------------------------------------- modulus switching
+// DoubleCRT::scaleDownToSet (DoubleCRT.cpp:531-545): delta = toPoly over the dropped primes (centred modulo D = their product), then
+//   delta[i] = delta[i] * factor - delta[i],  factor = D * (D^-1 mod p),  reduced to the centred residue modulo D p (Util.cpp:35-43).
+// factor - 1 is -1 modulo D and 0 modulo p, so the result e is the one centred value with e = -delta (mod D), e = 0 (mod p):
+//   t0 = (delta mod p) * u mod p  (u = D^-1 mod p),  e0 = D t0 - delta in (-D/2, D p - D/2],  + D p when negative,  - D p when above
+//   floor(D p / 2) -- exact integer arithmetic on W limbs per coefficient, the same bits as the reference's big-integer loop.
+// consts: D[W], M = D p [W], floor(M / 2) [W].  delta / e: [n][W] two's complement, coefficient-major.
+template <int MAXW>
+__global__ void __launch_bounds__(128) modswitch_delta_kernel(const u64* __restrict__ delta, i64 n, int W, const u64* __restrict__ consts, u64 p, u64 u, u64* __restrict__ e) {
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  u64 d[MAXW], x[MAXW];
+  for (int i = 0; i < W; ++i) d[i] = delta[j * W + i];
+  const bool neg = (d[W - 1] >> 63) != 0;
+  // |delta| mod p by Horner, then the sign
+  u64 r = 0;
+  {
+    u64 c = 1;
+    for (int i = 0; i < W; ++i) { const u64 v = neg ? ~d[i] + c : d[i]; c = (neg && c && v == 0) ? 1 : 0; x[i] = v; }
+    for (int i = W - 1; i >= 0; --i) r = (u64)((((u128)r << 64) | x[i]) % p);
+    if (neg && r) r = p - r;
+  }
+  const u64 t0 = (u64)(((u128)r * u) % p);
+  // x = D t0 - delta
+  const u64* D = consts; const u64* M = consts + W; const u64* H = consts + 2 * W;
+  {
+    u64 c = 0, br = 0;
+    for (int i = 0; i < W; ++i) {
+      const u128 t = (u128)D[i] * t0 + c;
+      c = (u64)(t >> 64);
+      const u64 lo = (u64)t;
+      const u128 s = (u128)lo - d[i] - br;
+      x[i] = (u64)s; br = (u64)(s >> 64) & 1;
+    }
+  }
+  if (x[W - 1] >> 63) { u64 c = 0; for (int i = 0; i < W; ++i) { const u128 s = (u128)x[i] + M[i] + c; x[i] = (u64)s; c = (u64)(s >> 64); } }
+  // x in [0, M): subtract M when x > floor(M / 2)
+  int cmp = 0;
+  for (int i = W - 1; i >= 0 && !cmp; --i) if (x[i] != H[i]) cmp = x[i] < H[i] ? -1 : 1;
+  if (cmp > 0) { u64 br = 0; for (int i = 0; i < W; ++i) { const u128 s = (u128)x[i] - M[i] - br; x[i] = (u64)s; br = (u64)(s >> 64) & 1; } }
+  for (int i = 0; i < W; ++i) e[j * W + i] = x[i];
+}
+
+// d_delta, d_e: [n][W]; consts_host: 3 W words (D, D p, floor(D p / 2)), all below 2^(64 W - 1)
+int launch_modswitch_delta(fhesi_ctx* ctx, const u64* d_delta, int W, const u64* consts_host, u64 p, u64 u, u64* d_e) {
+  void* d_c;
+  FHESI_TRY(ws_reserve(ctx, 9, (size_t)3 * W * 8 + 64, &d_c));
+  HIP_TRY(hipMemcpyAsync(d_c, consts_host, (size_t)3 * W * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));            // the caller's constant array may go away
+  const unsigned grid = (unsigned)((ctx->phim + 127) / 128);
+  if (W <= 8) modswitch_delta_kernel<8><<<grid, 128, 0, ctx->stream>>>(d_delta, ctx->phim, W, (const u64*)d_c, p, u, d_e);
+  else if (W <= 24) modswitch_delta_kernel<24><<<grid, 128, 0, ctx->stream>>>(d_delta, ctx->phim, W, (const u64*)d_c, p, u, d_e);
+  else if (W <= 66) modswitch_delta_kernel<66><<<grid, 128, 0, ctx->stream>>>(d_delta, ctx->phim, W, (const u64*)d_c, p, u, d_e);
+  else FHESI_FAIL("scaleDownToSet: dropped-prime product of %d limbs is too wide", W);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ----------------------------------------------------------------------------------------- byte decomposition -> digit rows
 // parts: positive residues mod 2^logQ, limb-major [npolys][nl][n] (mode-1 output of crt_kernel).
 // rows out: [npolys][nd][L][n], digit d of coefficient j reduced mod q_l (digits < 2^digit_bits; Ciphertext.cpp:95-102,

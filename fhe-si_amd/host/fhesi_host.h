@@ -293,41 +293,16 @@ class DoubleCRT {
   DoubleCRT& operator/=(long n) { return Op(ZZ(n), OP_DIV); }
   void Exp(long e) { ck(fhesi_dcrt_exp(h, e)); }   // :423-434
   void automorph(long k) { if (!context.zMstar.inZmStar((unsigned)k)) Error("DoubleCRT::automorph: k not in Zm*"); ck(fhesi_dcrt_automorph(h, k)); }   // :439-465
-  // BGV-style modulus switching (no callers in fhe-si, kept for the class surface): every heavy step is a C-ABI call
+  // BGV-style modulus switching (no callers in fhe-si, kept for the class surface): device kernels behind the C ABI
   double addPrimesAndScale(const IndexSet& s1) {   // DoubleCRT.cpp:162-208
-    const ZZ p = context.ModulusP();
-    if (card(s1) == 0) return 0.0;
-    assert(p >= ZZ(2L)); assert(card(s1 & getIndexSet()) == 0);
-    ZZ factor(1L); double logFactor = 0.0;
-    for (long i = s1.first(); i <= s1.last(); i = s1.next(i)) { factor *= ZZ(context.ithPrime(i)); logFactor += std::log((double)context.ithPrime(i)); }
-    ZZ prodInv = InvModSmall(factor % p, p);
-    factor *= prodInv; logFactor += log(prodInv);
-    *this *= factor;                                  // scale existing rows by factor mod q_i
-    IndexSet old = getIndexSet();
-    DoubleCRT grown(context, old | s1);               // zero rows for the new primes, old rows copied in
-    { auto m = getMap(); for (auto& kv : m) grown.setRow(kv.first, kv.second); }
-    ck(fhesi_dcrt_free(h)); h = nullptr; alloc(old | s1); ck(fhesi_dcrt_copy(h, grown.h));
-    return logFactor;
+    std::vector<int32_t> v; for (long i = s1.first(); i <= s1.last(); i = s1.next(i)) v.push_back((int32_t)i);
+    double lf = 0.0;
+    ck(fhesi_dcrt_add_primes_and_scale(h, v.data(), (int32_t)v.size(), (uint64_t)context.ModulusP().to_long(), &lf));
+    return lf;
   }
   void scaleDownToSet(const IndexSet& s) {   // DoubleCRT.cpp:518-558
-    IndexSet indexSet = getIndexSet(), intersect = s & indexSet, diff = indexSet / s;
-    assert(card(intersect) > 0); assert(card(diff) > 0);
-    ZZ diffProd = context.productOfPrimes(diff), p = context.ModulusP();
-    *this *= (diffProd % p);
-    ZZX delta; toPoly(delta, diff);
-    ZZ factor = diffProd * InvModSmall(diffProd % p, p);
-    for (auto& c : delta.rep) { ZZ d = c; c *= factor; c -= d; }
-    delta.normalize();
-    ZZ mod = diffProd * p, half = mod / ZZ(2L);
-    for (auto& c : delta.rep) { c %= mod; if (c > half) c -= mod; }     // ReduceCoefficientsSlow (Util.cpp:35-43)
-    delta.normalize();
-    removePrimes(diff);
-    *this += delta;
-    *this /= diffProd;
-  }
-  static ZZ InvModSmall(const ZZ& a, const ZZ& p) {   // a^-1 mod p for a word-size prime p
-    uint64_t pp = (uint64_t)p.to_long(), aa = (uint64_t)rem(a, (long)pp);
-    return ZZ((unsigned long)PowerMod(aa, pp - 2, pp));
+    std::vector<int32_t> v; for (long i = s.first(); i <= s.last(); i = s.next(i)) v.push_back((int32_t)i);
+    ck(fhesi_dcrt_scale_down_to_set(h, v.data(), (int32_t)v.size(), (uint64_t)context.ModulusP().to_long()));
   }
   DoubleCRT& operator>>=(long k) { automorph(k); return *this; }
   const FHEcontext& getContext() const { return context; }

@@ -100,6 +100,13 @@ int fhesi_dcrt_exp(fhesi_dcrt* d, int64_t e);                                   
 int fhesi_dcrt_automorph(fhesi_dcrt* d, int64_t k);                                 /* automorph: DoubleCRT.cpp:439-465; error if k not in Zm* */
 int fhesi_dcrt_add_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx);   /* addPrimes: DoubleCRT.cpp:142-156 */
 int fhesi_dcrt_remove_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx);/* removePrimes: DoubleCRT.h:197-199 */
+/* BGV-style modulus switching (no caller inside fhe-si, part of the DoubleCRT surface); p = FHEcontext::ModulusP().
+ * addPrimesAndScale (DoubleCRT.cpp:162-208): existing rows *= F (F^-1 mod p), F = product of the added primes; the added rows are zero;
+ *   *log_factor_out (may be null) = log F + log(F^-1 mod p), the method's return value.  Errors: sets not disjoint, F not invertible mod p.
+ * scaleDownToSet (DoubleCRT.cpp:518-558): drop the primes outside `prime_idx`, dividing by their product D with the correction term
+ *   delta (D (D^-1 mod p) - 1) reduced modulo D p.  Errors mirror the asserts of :525-526 (empty intersection, nothing to drop). */
+int fhesi_dcrt_add_primes_and_scale(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, uint64_t p, double* log_factor_out);
+int fhesi_dcrt_scale_down_to_set(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, uint64_t p);
 /* SingleCRT <-> DoubleCRT (DoubleCRT.cpp:484-515): coefficient-domain residues per prime, [nidx][phi(m)] */
 int fhesi_dcrt_from_scrt(fhesi_dcrt* d, const uint64_t* coeff_rows);
 int fhesi_dcrt_to_scrt(const fhesi_dcrt* d, uint64_t* coeff_rows_out);

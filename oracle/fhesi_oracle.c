@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <math.h>
 
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
@@ -405,6 +406,73 @@ void orc_dcrt_to_poly(const orc_ctx* c, const u64* rows, const int* idx, int nid
     int_vec_crt(vp, P, W, cur, n, q); bn_mul_u64(P, q, W); }                        /* :381-388 */
   for (i64 j = 0; j < n; j++) { u64* v = vp + j * W; if (positive && bn_sign(v, W)) bn_add(v, P, W); bn_copy_ext(out + j * nlimbs, nlimbs, v, W); }
   free(vp); free(cur); free(P);
+}
+
+/* ------------------------------------------------------------------ BGV-style modulus switching (DoubleCRT.cpp:162-208, 518-558)
+ * Dead code in fhe-si (no callers) but part of the DoubleCRT surface.  Rows are in the full layout [L][phim];
+ * index sets are ascending lists of prime indices.  Big integers here are magnitudes in little-endian limbs. */
+static void bn_mul_mag(u64* out, const u64* a, int na, const u64* b, int nb) {       /* out[na+nb] = a * b */
+  memset(out, 0, 8 * (na + nb));
+  for (int i = 0; i < na; i++) { u64 c = 0; for (int j = 0; j < nb; j++) { u128 t = (u128)a[i] * b[j] + out[i + j] + c; out[i + j] = (u64)t; c = (u64)(t >> 64); } out[i + nb] = c; }
+}
+static int bn_cmp_mag(const u64* a, const u64* b, int n) { for (int i = n - 1; i >= 0; i--) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1; return 0; }
+static void bn_mod_mag(u64* r, int nr, const u64* a, int na, const u64* m) {            /* r[nr] = a mod m, m in nr limbs, m < 2^(64 nr - 1) */
+  memset(r, 0, 8 * nr);
+  for (int bit = 64 * na - 1; bit >= 0; bit--) {
+    u64 c = (a[bit / 64] >> (bit % 64)) & 1;
+    for (int i = 0; i < nr; i++) { u64 t = r[i]; r[i] = (t << 1) | c; c = t >> 63; }
+    if (bn_cmp_mag(r, m, nr) >= 0) bn_sub(r, m, nr);
+  }
+}
+static void prod_of_primes(const orc_ctx* c, const int* idx, int nidx, u64* out, int W) { memset(out, 0, 8 * W); out[0] = 1; for (int i = 0; i < nidx; i++) bn_mul_u64(out, c->pr[idx[i]].q, W); }
+
+/* DoubleCRT::addPrimesAndScale (DoubleCRT.cpp:162-208): scale the rows of cur_idx by factor = F * (F^-1 mod p), F = product of the
+ * added primes; rows of add_idx are zero-filled (:200-205).  Returns the logarithm of the factor (:172,182). */
+double orc_dcrt_add_primes_and_scale(const orc_ctx* c, u64* rows, const int* cur_idx, int ncur, const int* add_idx, int nadd, u64 p) {
+  if (nadd == 0) return 0.0;                                                          /* :165 */
+  i64 n = c->phim; int W = nadd + 2; u64 factor[W]; prod_of_primes(c, add_idx, nadd, factor, W);
+  double lf = 0.0; for (int i = 0; i < nadd; i++) lf += log((double)c->pr[add_idx[i]].q);
+  u64 prodInv = invmod(bn_mod_u64_mag(factor, W, p), p);                             /* :176-179 (p prime or at least coprime: InvMod) */
+  bn_mul_u64(factor, prodInv, W); lf += log((double)prodInv);                         /* :180-182 */
+  for (int t = 0; t < ncur; t++) { u64 q = c->pr[cur_idx[t]].q, f = bn_mod_u64_mag(factor, W, q); u64* row = rows + (i64)cur_idx[t] * n;
+    for (i64 j = 0; j < n; j++) row[j] = mulmod(row[j], f, q); }                      /* :188-197 */
+  for (int t = 0; t < nadd; t++) memset(rows + (i64)add_idx[t] * n, 0, 8 * n);        /* :200-205 */
+  return lf;
+}
+
+/* DoubleCRT::scaleDownToSet (DoubleCRT.cpp:518-558).  cur_idx: the object's index set, s_idx: the target set; on return the rows of
+ * (cur & s) hold the result (the other rows are no longer part of the object).  Returns 0, or 1 when an assertion of :525-526 fails. */
+int orc_dcrt_scale_down_to_set(const orc_ctx* c, u64* rows, const int* cur_idx, int ncur, const int* s_idx, int ns, u64 p) {
+  i64 n = c->phim; int keep[64], diff[64], nk = 0, nd = 0;
+  for (int t = 0; t < ncur; t++) { int in = 0; for (int u = 0; u < ns; u++) in |= (s_idx[u] == cur_idx[t]); if (in) keep[nk++] = cur_idx[t]; else diff[nd++] = cur_idx[t]; }
+  if (!nk || !nd) return 1;                                                           /* :525-526 */
+  int W = nd + 3; u64 D[W]; prod_of_primes(c, diff, nd, D, W);                        /* diffProd :528 */
+  u64 dp = bn_mod_u64_mag(D, W, p);
+  for (int t = 0; t < ncur; t++) { u64 q = c->pr[cur_idx[t]].q, f = dp % q; u64* row = rows + (i64)cur_idx[t] * n; for (i64 j = 0; j < n; j++) row[j] = mulmod(row[j], f, q); }   /* :529 */
+  u64* delta = malloc(8 * n * W); orc_dcrt_to_poly(c, rows, diff, nd, 0, delta, W);   /* :531-532 */
+  /* factor = diffProd * InvMod(diffProd % p, p) (:538); delta[i] = delta[i]*factor - delta[i] (:539-543), then ReduceCoefficientsSlow
+   * modulo diffProd * p (:545, Util.cpp:35-43: c %= mod -- NTL's remainder is non-negative for a positive modulus -- then c -= mod
+   * when c > mod/2) */
+  u64 fm1[W]; memcpy(fm1, D, 8 * W); bn_mul_u64(fm1, invmod(dp, p), W); { u64 one[W]; memset(one, 0, 8 * W); one[0] = 1; bn_sub(fm1, one, W); }   /* factor - 1 >= 0 */
+  u64 M[W]; memcpy(M, D, 8 * W); bn_mul_u64(M, p, W);
+  u64 halfM[W]; memcpy(halfM, M, 8 * W); for (int i = 0; i < W; i++) halfM[i] = (M[i] >> 1) | (i + 1 < W ? M[i + 1] << 63 : 0);
+  u64* e = malloc(8 * n * W); u64 mag[W], prod[2 * W], r[W];
+  for (i64 j = 0; j < n; j++) {
+    memcpy(mag, delta + j * W, 8 * W); int neg = bn_sign(mag, W); if (neg) bn_neg(mag, W);
+    bn_mul_mag(prod, mag, W, fm1, W); bn_mod_mag(r, W, prod, 2 * W, M);
+    int zero = 1; for (int i = 0; i < W; i++) zero &= !r[i];
+    if (neg && !zero) { u64 t[W]; memcpy(t, M, 8 * W); bn_sub(t, r, W); memcpy(r, t, 8 * W); }
+    if (bn_cmp_mag(r, halfM, W) > 0) bn_sub(r, M, W);                                 /* two's complement from here on */
+    memcpy(e + j * W, r, 8 * W);
+  }
+  /* removePrimes(diff); *this += delta; *this /= diffProd  (:555-557) */
+  u64* row_e = malloc(8 * n);
+  for (int t = 0; t < nk; t++) { int i = keep[t]; u64 q = c->pr[i].q; u64* row = rows + (i64)i * n;
+    orc_cmod_fft(c, i, e, W, n, row_e);
+    u64 dinv = invmod(bn_mod_u64_mag(D, W, q), q);
+    for (i64 j = 0; j < n; j++) row[j] = mulmod(addmod(row[j], row_e[j], q), dinv, q); }
+  free(delta); free(e); free(row_e);
+  return 0;
 }
 
 /* ------------------------------------------------------------------ Util.cpp / Ciphertext.cpp / FHE-SI.cpp */

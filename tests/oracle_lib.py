@@ -36,6 +36,10 @@ def lib():
         _lib.orc_phim.argtypes = [C.c_void_p]
         _lib.orc_last_error.restype = C.c_char_p
         _lib.orc_set_slow_dft.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_dcrt_add_primes_and_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint64]
+        _lib.orc_dcrt_add_primes_and_scale.restype = C.c_double
+        _lib.orc_dcrt_scale_down_to_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint64]
+        _lib.orc_dcrt_scale_down_to_set.restype = C.c_int
         _lib.orc_set_bluestein_fft.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_set_bluestein_fft.restype = C.c_int
         _lib.orc_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -185,6 +189,22 @@ class Oracle:
             ia = np.array(idx, dtype=np.int32)
             lib().orc_dcrt_to_poly(self.h, _p(rows), _p(ia), len(ia), int(positive), _p(out), nlimbs)
         return out
+
+    # ---- BGV-style modulus switching (DoubleCRT.cpp:162-208, 518-558); rows in the full layout [L][phim]
+    def dcrt_add_primes_and_scale(self, rows: np.ndarray, cur_idx, add_idx, p: int):
+        """-> (rows with the scaled old rows and zero rows for add_idx, log factor)"""
+        rows = np.array(rows, dtype=np.uint64, copy=True)
+        ci, ai = np.array(list(cur_idx), dtype=np.int32), np.array(list(add_idx), dtype=np.int32)
+        lf = lib().orc_dcrt_add_primes_and_scale(self.h, _p(rows), _p(ci), len(ci), _p(ai), len(ai), p)
+        return rows, lf
+
+    def dcrt_scale_down_to_set(self, rows: np.ndarray, cur_idx, s_idx, p: int) -> np.ndarray:
+        """-> rows [L][phim]; only the rows of (cur_idx & s_idx) are meaningful afterwards"""
+        rows = np.array(rows, dtype=np.uint64, copy=True)
+        ci, si = np.array(list(cur_idx), dtype=np.int32), np.array(list(s_idx), dtype=np.int32)
+        if lib().orc_dcrt_scale_down_to_set(self.h, _p(rows), _p(ci), len(ci), _p(si), len(si), p) != 0:
+            raise ValueError("scaleDownToSet: assertion failed (empty intersection or nothing to drop)")
+        return rows
 
     def scale_down(self, rows: np.ndarray, logQ: int, nlimbs: int) -> np.ndarray:
         rows = np.ascontiguousarray(rows, dtype=np.uint64)

@@ -162,3 +162,52 @@ def test_context_rejects_bad_primes():
     orc = O.Oracle(m, primes, roots)
     z, phi = orc.tables()
     assert np.array_equal(ctx.zms_idx(), z) and np.array_equal(ctx.phi_m(), phi)
+
+
+@pytest.mark.parametrize("m,logQ", [(64, 100), (22, 100), (4096, 200), (1006, 120)])
+def test_modulus_switching_vs_oracle(m, logQ):
+    """DoubleCRT::addPrimesAndScale / scaleDownToSet (DoubleCRT.cpp:162-208, 518-558; SURVEY a12, kernel K11) as device calls
+    (fhesi_dcrt_add_primes_and_scale / fhesi_dcrt_scale_down_to_set) against the C oracle: several target sets, coefficients at
+    +-(P-1)/2 and 0, power-of-two and Bluestein rings; the error paths of the reference's asserts."""
+    p = 23
+    primes, roots = P.chain_for(m, logQ, p)
+    L = len(primes)
+    assert L >= 3
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n = ctx.phim
+    rng = np.random.default_rng(m)
+    Pall = 1
+    for q in primes:
+        Pall *= q
+    W = L + 2
+    limbs = P.rand_limbs(rng, (n,), W, 60 * L - 3)
+    limbs[0] = O.ints_to_limbs([(Pall - 1) // 2], W)[0]
+    limbs[1] = O.ints_to_limbs([-((Pall - 1) // 2)], W)[0]
+    limbs[2] = 0
+    rows = orc.dcrt_from_poly(limbs)
+    for keep in ([0], [0, 1], list(range(L - 1)), [L - 1], [1, L - 1]):
+        d = F.DoubleCRT.from_poly(ctx, limbs)
+        d.scale_down_to_set(keep, p)
+        assert d.index_set() == sorted(keep)
+        want = orc.dcrt_scale_down_to_set(rows, range(L), keep, p)
+        got = d.rows()
+        for s, i in enumerate(sorted(keep)):
+            assert np.array_equal(got[s], want[i]), (keep, i)
+    for cur in ([0], [0, 1], [1]):
+        add = [i for i in range(L) if i not in cur]
+        d = F.DoubleCRT.from_poly(ctx, limbs, index_set=cur)
+        lf = d.add_primes_and_scale(add, p)
+        assert d.index_set() == list(range(L))
+        want, wlf = orc.dcrt_add_primes_and_scale(rows, cur, add, p)
+        assert np.array_equal(d.rows(), want)
+        assert abs(lf - wlf) < 1e-9 * max(1.0, abs(wlf))
+    d = F.DoubleCRT.from_poly(ctx, limbs)
+    with pytest.raises(F.FhesiError):
+        d.scale_down_to_set(range(L), p)                # nothing to drop (DoubleCRT.cpp:526)
+    with pytest.raises(F.FhesiError):
+        d.add_primes_and_scale([0], p)                  # not disjoint (DoubleCRT.cpp:167)
+    e = F.DoubleCRT.from_poly(ctx, limbs, index_set=[0, 1])
+    with pytest.raises(F.FhesiError):
+        e.scale_down_to_set([2], p)                     # empty intersection (DoubleCRT.cpp:525)
+    assert e.add_primes_and_scale([], p) == 0.0         # nothing to do (DoubleCRT.cpp:165)
