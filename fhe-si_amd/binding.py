@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
     "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
+    "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -137,6 +138,12 @@ def _load():
         "fhesi_ctx_set_option": [_vp, C.c_char_p, _i64],
         "fhesi_ctx_get_option": [_vp, C.c_char_p, _vp],
         "fhesi_ksk_mark_dirty": [_vp],
+        "fhesi_scrt_alloc": [_vp, _vp, _i32, _vp],
+        "fhesi_scrt_from_poly": [_vp, _vp, _i32, _i64],
+        "fhesi_scrt_to_poly": [_vp, _vp, _i32, _vp, _i32],
+        "fhesi_scrt_op_scalar": [_vp, _vp, _i32, _i32],
+        "fhesi_dcrt_assign_scrt": [_vp, _vp],
+        "fhesi_scrt_assign_dcrt": [_vp, _vp, _vp, _i32],
         "fhesi_dcrt_add_primes_and_scale": [_vp, _vp, _i32, _u64, _vp],
         "fhesi_dcrt_scale_down_to_set": [_vp, _vp, _i32, _u64],
         "fhesi_ksk_upload_dev": [_vp, _vp],
@@ -498,6 +505,85 @@ class DoubleCRT:
         out = np.zeros((len(self.index_set()), self.ctx.phim), dtype=np.uint64)
         _ck(_load().fhesi_dcrt_to_scrt(self.h, _p(out)))
         return out
+
+
+class SingleCRT:
+    """One SingleCRT object resident in HBM (SingleCRT.h:41-175 through the C ABI): coefficient residues per prime."""
+
+    def __init__(self, ctx: Context, index_set=None):
+        self.ctx = ctx
+        self.h = _vp()
+        if index_set is None:
+            _ck(_load().fhesi_scrt_alloc(ctx.h, None, 0, C.byref(self.h)))
+        else:
+            ia = np.array(list(index_set), dtype=np.int32)
+            if len(ia) == 0:
+                raise FhesiError("SingleCRT: empty index set")
+            _ck(_load().fhesi_scrt_alloc(ctx.h, _p(ia), len(ia), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _load().fhesi_dcrt_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    index_set = DoubleCRT.index_set
+    row = DoubleCRT.row
+    set_row = DoubleCRT.set_row
+    rows = DoubleCRT.rows
+    remove_primes = DoubleCRT.remove_primes
+
+    def assign_poly(self, limbs: np.ndarray):
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        _ck(_load().fhesi_scrt_from_poly(self.h, _p(limbs), limbs.shape[1], limbs.shape[0]))
+        return self
+
+    def to_poly(self, nlimbs: int, index_set=None) -> np.ndarray:
+        out = np.zeros((self.ctx.phim, nlimbs), dtype=np.uint64)
+        if index_set is None:
+            _ck(_load().fhesi_scrt_to_poly(self.h, None, 0, _p(out), nlimbs))
+        else:
+            ia = np.array(list(index_set), dtype=np.int32)
+            if len(ia) == 0:
+                return out
+            _ck(_load().fhesi_scrt_to_poly(self.h, _p(ia), len(ia), _p(out), nlimbs))
+        return out
+
+    def assign(self, other: "SingleCRT"):
+        _ck(_load().fhesi_dcrt_copy(self.h, other.h))
+
+    def op(self, other: "SingleCRT", op: int):
+        _ck(_load().fhesi_dcrt_op(self.h, other.h, op))
+        return self
+
+    def op_scalar(self, num: int, op: int, nlimbs: int = 4):
+        mod = 1 << (64 * nlimbs)
+        v = num % mod
+        s = np.array([(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(nlimbs)], dtype=np.uint64)
+        _ck(_load().fhesi_scrt_op_scalar(self.h, _p(s), nlimbs, op))
+        return self
+
+    def equals(self, other) -> bool:
+        eq = _i32(0)
+        _ck(_load().fhesi_dcrt_equal(self.h, other.h, C.byref(eq)))
+        return bool(eq.value)
+
+    def assign_dcrt(self, d: DoubleCRT, index_set=None):
+        """DoubleCRT::toSingleCRT (DoubleCRT.cpp:498-515)."""
+        if index_set is None:
+            _ck(_load().fhesi_scrt_assign_dcrt(self.h, d.h, None, 0))
+        else:
+            ia = np.array(list(index_set), dtype=np.int32)
+            _ck(_load().fhesi_scrt_assign_dcrt(self.h, d.h, _p(ia), len(ia)))
+        return self
+
+
+def dcrt_assign_scrt(d: DoubleCRT, s: SingleCRT):
+    """DoubleCRT::operator=(const SingleCRT&) (DoubleCRT.cpp:484-496)."""
+    _ck(_load().fhesi_dcrt_assign_scrt(d.h, s.h))
+    return d
 
 
 class KeySwitchMatrix:

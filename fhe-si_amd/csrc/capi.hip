@@ -508,7 +508,8 @@ static int dcrt_resize(fhesi_dcrt* d, const std::vector<int>& idx) {
 }
 extern "C" int fhesi_dcrt_copy(fhesi_dcrt* dst, const fhesi_dcrt* src) {
   if (!dst || !src) FHESI_FAIL("null DoubleCRT");
-  if (dst->ctx != src->ctx) FHESI_FAIL("DoubleCRT assigment: incompatible contexts");   // DoubleCRT.cpp:315-316
+  if (dst->ctx != src->ctx) FHESI_FAIL("DoubleCRT assigment: incompatible contexts");   // DoubleCRT.cpp:315-316 (SingleCRT.cpp:223-224)
+  if (dst->coeff_form != src->coeff_form) FHESI_FAIL("assignment between a DoubleCRT and a SingleCRT handle: use fhesi_dcrt_assign_scrt / fhesi_scrt_assign_dcrt");
   CHECK_CTX(dst->ctx);
   if (dst == src) return 0;
   FHESI_TRY(dcrt_resize(dst, src->idx));
@@ -524,7 +525,7 @@ extern "C" int fhesi_dcrt_index_set(const fhesi_dcrt* d, int32_t* idx_out, int32
 extern "C" int fhesi_dcrt_equal(const fhesi_dcrt* a, const fhesi_dcrt* b, int32_t* equal) {
   if (!a || !b) FHESI_FAIL("null DoubleCRT");
   *equal = 0;
-  if (a->ctx != b->ctx || a->idx != b->idx) return 0;    // DoubleCRT.h:167-169
+  if (a->ctx != b->ctx || a->idx != b->idx || a->coeff_form != b->coeff_form) return 0;    // DoubleCRT.h:167-169, SingleCRT.h:98-100
   CHECK_CTX(a->ctx);
   int eq = 0;
   FHESI_TRY(launch_rows_equal(a->ctx, a->d_rows, b->d_rows, (i64)a->idx.size() * a->ctx->phim, &eq));
@@ -557,6 +558,7 @@ extern "C" void* fhesi_dcrt_device_ptr(fhesi_dcrt* d) { return d ? d->d_rows : n
 
 extern "C" int fhesi_dcrt_from_poly(fhesi_dcrt* d, const uint64_t* limbs, int32_t nlimbs, int64_t ncoeffs) {
   if (!d) FHESI_FAIL("null DoubleCRT");
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT call on a SingleCRT handle");
   fhesi_ctx* c = d->ctx;
   CHECK_CTX(c);
   if (nlimbs < 1 || ncoeffs < 0) FHESI_FAIL("DoubleCRT(ZZX): bad coefficient shape");
@@ -586,6 +588,7 @@ extern "C" int fhesi_dcrt_from_poly(fhesi_dcrt* d, const uint64_t* limbs, int32_
 
 extern "C" int fhesi_dcrt_to_poly(const fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, int32_t positive, uint64_t* out, int32_t nlimbs) {
   if (!d) FHESI_FAIL("null DoubleCRT");
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT call on a SingleCRT handle");
   fhesi_ctx* c = d->ctx;
   CHECK_CTX(c);
   const i64 n = c->phim;
@@ -626,6 +629,8 @@ extern "C" int fhesi_dcrt_op(fhesi_dcrt* dst, const fhesi_dcrt* src, int32_t op)
   if (dst->ctx != src->ctx) FHESI_FAIL("DoubleCRT::Op: incompatible objects");           // DoubleCRT.cpp:82-83
   if (dst->idx != src->idx) FHESI_FAIL("DoubleCRT::Op: index sets differ (match them with add_primes first)");
   if (op < FHESI_OP_ADD || op > FHESI_OP_MUL) FHESI_FAIL("DoubleCRT::Op: unknown operation %d", op);
+  if (dst->coeff_form != src->coeff_form) FHESI_FAIL("Op between a DoubleCRT and a SingleCRT handle");
+  if (dst->coeff_form && op == FHESI_OP_MUL) FHESI_FAIL("SingleCRT::Op: only AddMod / SubMod exist (SingleCRT.h:127-133)");
   fhesi_ctx* c = dst->ctx;
   CHECK_CTX(c);
   int* d_pos;
@@ -635,6 +640,7 @@ extern "C" int fhesi_dcrt_op(fhesi_dcrt* dst, const fhesi_dcrt* src, int32_t op)
 
 extern "C" int fhesi_dcrt_op_scalar(fhesi_dcrt* d, const uint64_t* num, int32_t nlimbs, int32_t op) {
   if (!d) FHESI_FAIL("null DoubleCRT");
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT call on a SingleCRT handle");
   fhesi_ctx* c = d->ctx;
   CHECK_CTX(c);
   if (op < FHESI_OP_ADD || op > FHESI_OP_SET) FHESI_FAIL("DoubleCRT scalar op: unknown operation %d", op);
@@ -661,6 +667,7 @@ extern "C" int fhesi_dcrt_op_scalar(fhesi_dcrt* d, const uint64_t* num, int32_t 
 
 extern "C" int fhesi_dcrt_exp(fhesi_dcrt* d, int64_t e) {
   if (!d) FHESI_FAIL("null DoubleCRT");
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT call on a SingleCRT handle");
   fhesi_ctx* c = d->ctx;
   CHECK_CTX(c);
   const int K = (int)d->idx.size();
@@ -692,6 +699,7 @@ extern "C" int fhesi_dcrt_exp(fhesi_dcrt* d, int64_t e) {
 
 extern "C" int fhesi_dcrt_automorph(fhesi_dcrt* d, int64_t k) {
   if (!d) FHESI_FAIL("null DoubleCRT");
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT call on a SingleCRT handle");
   fhesi_ctx* c = d->ctx;
   CHECK_CTX(c);
   if (k <= 0 || k >= c->m || c->zms_idx[k] < 0) FHESI_FAIL("DoubleCRT::automorph: k not in Zm*");     // DoubleCRT.cpp:442-443
@@ -705,6 +713,7 @@ extern "C" int fhesi_dcrt_automorph(fhesi_dcrt* d, int64_t k) {
 
 extern "C" int fhesi_dcrt_add_primes(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx) {
   if (!d) FHESI_FAIL("null DoubleCRT");
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT call on a SingleCRT handle");
   fhesi_ctx* c = d->ctx;
   CHECK_CTX(c);
   if (nidx == 0) return 0;                                                               // DoubleCRT.cpp:144
@@ -806,6 +815,7 @@ static int dcrt_scale_rows(fhesi_dcrt* d, const std::vector<u64>& sc) {
 
 extern "C" int fhesi_dcrt_add_primes_and_scale(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, uint64_t p, double* log_factor_out) {
   if (!d) FHESI_FAIL("null DoubleCRT");
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT call on a SingleCRT handle");
   fhesi_ctx* c = d->ctx;
   CHECK_CTX(c);
   if (log_factor_out) *log_factor_out = 0.0;
@@ -840,6 +850,7 @@ extern "C" int fhesi_dcrt_add_primes_and_scale(fhesi_dcrt* d, const int32_t* pri
 
 extern "C" int fhesi_dcrt_scale_down_to_set(fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx, uint64_t p) {
   if (!d) FHESI_FAIL("null DoubleCRT");
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT call on a SingleCRT handle");
   fhesi_ctx* c = d->ctx;
   CHECK_CTX(c);
   if (p < 2) FHESI_FAIL("scaleDownToSet: plaintext modulus must be at least 2");
@@ -930,6 +941,125 @@ extern "C" int fhesi_dcrt_to_scrt(const fhesi_dcrt* d, uint64_t* out) {
   HIP_TRY(hipMemcpyAsync(out, tmp, (size_t)K * n * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
+}
+
+// --------------------------------------------------------------------------------------------- SingleCRT (SingleCRT.h:41-175)
+// A SingleCRT is the coefficient-domain RNS form: for every prime of its index set the polynomial's coefficients modulo that prime.
+// It shares the handle type (and the row storage) of a DoubleCRT; fhesi_scrt_alloc marks the handle as holding coefficient residues
+// and the entry points below refuse a handle of the wrong form.
+#define CHECK_SCRT(s) do { if (!(s)) FHESI_FAIL("null SingleCRT"); if (!(s)->coeff_form) FHESI_FAIL("SingleCRT call on a DoubleCRT handle"); } while (0)
+extern "C" int fhesi_scrt_alloc(fhesi_ctx* c, const int32_t* prime_idx, int32_t nidx, fhesi_dcrt** out) {
+  FHESI_TRY(fhesi_dcrt_alloc(c, prime_idx, nidx, out));
+  (*out)->coeff_form = true;
+  return 0;
+}
+// SingleCRT::operator=(const ZZX&) (SingleCRT.cpp:239-251): PolyRed(poly, p_i, abs = true) per prime = coefficient residues in [0, p_i)
+extern "C" int fhesi_scrt_from_poly(fhesi_dcrt* s, const uint64_t* limbs, int32_t nlimbs, int64_t ncoeffs) {
+  CHECK_SCRT(s);
+  fhesi_ctx* c = s->ctx;
+  CHECK_CTX(c);
+  const i64 n = c->phim;
+  if (nlimbs < 1 || ncoeffs < 0) FHESI_FAIL("SingleCRT = ZZX: bad coefficient shape");
+  if (ncoeffs > n) FHESI_FAIL("SingleCRT = ZZX: %lld coefficients, rows hold phi(m) = %lld", (long long)ncoeffs, (long long)n);
+  const int K = (int)s->idx.size();
+  if (!K) return 0;
+  void* d_l;
+  FHESI_TRY(ws_reserve(c, 0, std::max<size_t>(8, (size_t)ncoeffs * nlimbs * 8), &d_l));
+  HIP_TRY(hipMemcpyAsync(d_l, limbs, (size_t)ncoeffs * nlimbs * 8, hipMemcpyHostToDevice, c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, s->idx, &d_pos));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)d_l, nlimbs, ncoeffs, 1, 1, nullptr, s->d_rows, K, d_pos));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+// SingleCRT::toPoly (SingleCRT.cpp:299-334): the same incremental CRT as DoubleCRT::toPoly, without the inverse transforms
+extern "C" int fhesi_scrt_to_poly(const fhesi_dcrt* s, const int32_t* prime_idx, int32_t nidx, uint64_t* out, int32_t nlimbs) {
+  CHECK_SCRT(s);
+  fhesi_ctx* c = s->ctx;
+  CHECK_CTX(c);
+  const i64 n = c->phim;
+  std::vector<int> s1;
+  if (nidx == 0 && prime_idx == nullptr) s1 = s->idx;
+  else for (int i = 0; i < nidx; ++i) if (slot_of(s, prime_idx[i]) >= 0) s1.push_back(prime_idx[i]);
+  std::sort(s1.begin(), s1.end());
+  s1.erase(std::unique(s1.begin(), s1.end()), s1.end());
+  if (s1.empty()) { memset(out, 0, (size_t)n * nlimbs * 8); return 0; }             // :303-306
+  const int K = (int)s1.size();
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, s1, &t));
+  std::vector<int> slots(K);
+  for (int k = 0; k < K; ++k) slots[k] = slot_of(s, s1[k]);
+  void *d_slots, *d_out;
+  FHESI_TRY(ws_reserve(c, 4, K * sizeof(int) + 64, &d_slots));
+  HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  FHESI_TRY(ws_reserve(c, 1, (size_t)n * nlimbs * 8, &d_out));
+  FHESI_TRY(launch_crt(c, t, s->d_rows, (int)s->idx.size(), (const int*)d_slots, 1, 0, 0, 0, (u64*)d_out, nlimbs));
+  HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * nlimbs * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+// SingleCRT::Op(const ZZ&, add / sub / mul) (SingleCRT.cpp:137-153) and operator/= (:279-296).  NTL's add(ZZX, ZZX, ZZ) / sub touch the
+// CONSTANT coefficient only; mul and the division by a constant act on every coefficient.
+extern "C" int fhesi_scrt_op_scalar(fhesi_dcrt* s, const uint64_t* num, int32_t nlimbs, int32_t op) {
+  CHECK_SCRT(s);
+  fhesi_ctx* c = s->ctx;
+  CHECK_CTX(c);
+  if (op < FHESI_OP_ADD || op > FHESI_OP_DIV) FHESI_FAIL("SingleCRT scalar op: unknown operation %d", op);
+  const int K = (int)s->idx.size();
+  if (!K) return 0;
+  std::vector<u64> sc(K);
+  for (int k = 0; k < K; ++k) {
+    const u64 Q = c->q[s->idx[k]];
+    u64 v = hm::bn_mod((const u64*)num, nlimbs, Q);                 // rem(n, num, pi)  (:146, :287)
+    if (op == FHESI_OP_DIV) {
+      if (v == 0) FHESI_FAIL("SingleCRT::operator/=: divisor is zero modulo prime %d", s->idx[k]);   // InvMod error (:288)
+      v = hm::invmod(v, Q);
+    }
+    sc[k] = v;
+  }
+  void* d_sc;
+  FHESI_TRY(ws_reserve(c, 4, K * 8 + 64, &d_sc));
+  HIP_TRY(hipMemcpyAsync(d_sc, sc.data(), K * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, s->idx, &d_pos));
+  if (op == FHESI_OP_ADD || op == FHESI_OP_SUB) return launch_scrt_const(c, s->d_rows, (const u64*)d_sc, K, d_pos, op == FHESI_OP_ADD ? 0 : 1);
+  return launch_ew_scalar(c, s->d_rows, (const u64*)d_sc, 1, K, d_pos, FHESI_OP_MUL);
+}
+// DoubleCRT::operator=(const SingleCRT&) (DoubleCRT.cpp:484-496): index set of the SingleCRT, one forward transform per row, in HBM
+extern "C" int fhesi_dcrt_assign_scrt(fhesi_dcrt* d, const fhesi_dcrt* s) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  CHECK_SCRT(s);
+  if (d->coeff_form) FHESI_FAIL("DoubleCRT = SingleCRT: the target handle is a SingleCRT");
+  if (d->ctx != s->ctx) FHESI_FAIL("DoubleCRT=SingleCRT -- incompatible contexts");          // :486-487
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  FHESI_TRY(dcrt_resize(d, s->idx));
+  const int K = (int)d->idx.size();
+  HIP_TRY(hipMemcpyAsync(d->d_rows, s->d_rows, (size_t)K * c->phim * 8, hipMemcpyDeviceToDevice, c->stream));
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, d->idx, &d_pos));
+  return row_fwd(c, d->d_rows, 1, K, d_pos, d->idx.data());                                   // :493-494
+}
+// DoubleCRT::toSingleCRT(scrt, s) (DoubleCRT.cpp:498-515): index set = s & the DoubleCRT's, one inverse transform per row, in HBM
+extern "C" int fhesi_scrt_assign_dcrt(fhesi_dcrt* s, const fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx) {
+  CHECK_SCRT(s);
+  if (!d || d->coeff_form) FHESI_FAIL("toSingleCRT: the source is not a DoubleCRT");
+  if (d->ctx != s->ctx) FHESI_FAIL("DoubleCRT::toSingleCRT -- incompatible contexts");        // :500-501
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  std::vector<int> s1;
+  if (nidx == 0 && prime_idx == nullptr) s1 = d->idx;
+  else for (int q : d->idx) if (std::find(prime_idx, prime_idx + nidx, q) != prime_idx + nidx) s1.push_back(q);
+  FHESI_TRY(dcrt_resize(s, s1));
+  const i64 n = c->phim;
+  for (size_t k = 0; k < s1.size(); ++k)
+    HIP_TRY(hipMemcpyAsync(s->d_rows + (i64)k * n, d->d_rows + (i64)slot_of(d, s1[k]) * n, n * 8, hipMemcpyDeviceToDevice, c->stream));
+  if (s1.empty()) return 0;
+  int* d_pos;
+  FHESI_TRY(upload_idx(c, s1, &d_pos));
+  return row_inv(c, s->d_rows, 1, (int)s1.size(), d_pos, s1.data());                          // :508-509
 }
 
 // --------------------------------------------------------------------------------------------- batched row kernels

@@ -139,6 +139,7 @@ struct fhesi_dcrt {
   fhesi_ctx* ctx = nullptr;
   std::vector<int> idx;                // ascending prime indices (IndexSet, IndexSet.h)
   u64* d_rows = nullptr;               // [idx.size()][phim]
+  bool coeff_form = false;             // the rows hold COEFFICIENT residues: the object is a SingleCRT (SingleCRT.h:41-175)
 };
 
 struct fhesi_ksk {
@@ -234,6 +235,7 @@ int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key /* [2][ncol][L][n] */, con
 bool ntt_digits_suborder(const fhesi_ctx* ctx, int digit_bits);
 int launch_tensor_sum(fhesi_ctx* ctx, const u64* d_ca, const u64* d_cb, const int* d_slot_a, const int* d_slot_b, const int* d_seg, i64 ngroups, bool accumulate,
                       u64* d_out /* [ngroups][3][L][n] */, double nproducts);
+int launch_scrt_const(fhesi_ctx* ctx, u64* d_rows, const u64* d_scalars /* [nslots] */, int nslots, const int* d_prime_of_slot, int op /* 0 add, 1 sub */);
 int launch_automorph(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 nrows, i64 k);
 int launch_rows_equal(fhesi_ctx* ctx, const u64* a, const u64* b, i64 nwords, int* equal);
 

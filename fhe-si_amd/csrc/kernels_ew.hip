@@ -272,6 +272,20 @@ int launch_dot_accum(fhesi_ctx* ctx, const u64* d_key, const u64* d_dig, int nco
   return 0;
 }
 
+// SingleCRT += / -= ZZ (SingleCRT.cpp:137-153 with NTL::add / NTL::sub on a ZZX and a scalar): only the constant coefficient changes
+__global__ void scrt_const_kernel(u64* __restrict__ rows, i64 n, int nslots, const u64* __restrict__ scalars, const int* __restrict__ prime_of_slot, const PrimeConst* __restrict__ pcs, int op) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= nslots) return;
+  const u64 q = pcs[prime_of_slot ? prime_of_slot[s] : s].q;
+  u64* x = rows + (i64)s * n;
+  x[0] = op == 0 ? d_addmod(x[0], scalars[s], q) : d_submod(x[0], scalars[s], q);
+}
+int launch_scrt_const(fhesi_ctx* ctx, u64* d_rows, const u64* d_scalars, int nslots, const int* d_prime_of_slot, int op) {
+  scrt_const_kernel<<<(unsigned)((nslots + 63) / 64), 64, 0, ctx->stream>>>(d_rows, ctx->phim, nslots, d_scalars, d_prime_of_slot, ctx->d_pc, op);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int launch_automorph(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 nrows, i64 k) {
   if (!nrows) return 0;
   dim3 grid(grid_x_for(ctx->phim), (unsigned)nrows);

@@ -230,6 +230,7 @@ inline void Cmodulus::iFFT(ZZX& x, const vec_long& y) const {
 
 // ---------------------------------------------------------------- DoubleCRT (DoubleCRT.h:83-365, DoubleCRT.cpp)
 enum { OP_ADD = FHESI_OP_ADD, OP_SUB = FHESI_OP_SUB, OP_MUL = FHESI_OP_MUL, OP_DIV = FHESI_OP_DIV, OP_SET = FHESI_OP_SET };
+class SingleCRT;
 class DoubleCRT {
   const FHEcontext& context;
   fhesi_dcrt* h = nullptr;
@@ -258,6 +259,9 @@ class DoubleCRT {
   DoubleCRT& operator=(const ZZX& poly) { int nl = limbs_for(poly); auto v = to_limbs(poly, nl); ck(fhesi_dcrt_from_poly(h, v.data(), nl, (int64_t)poly.rep.size())); return *this; }   // :323-331
   DoubleCRT& operator=(const ZZ& num) { return Op(num, OP_SET); }   // :333-347
   DoubleCRT& operator=(long num) { return *this = ZZ(num); }
+  DoubleCRT& operator=(const SingleCRT& scrt);                                  // :484-496
+  void toSingleCRT(SingleCRT& scrt, const IndexSet& s) const;                    // :498-510
+  void toSingleCRT(SingleCRT& scrt) const;                                       // :512-515
 
   void toPoly(ZZX& p, const IndexSet& s, bool positive = false) const {   // :349-404
     IndexSet s1 = getIndexSet() & s;
@@ -327,6 +331,114 @@ class DoubleCRT {
   ZZ getCoefficientModulus() const { return context.productOfPrimes(); }
 };
 inline ZZX to_ZZX(const DoubleCRT& d) { ZZX p; d.toPoly(p); return p; }
+
+// ---------------------------------------------------------------- SingleCRT (SingleCRT.h:41-175, SingleCRT.cpp)
+// Coefficient-domain RNS form: per prime of the index set, the polynomial's coefficients modulo that prime, resident in HBM.
+// Same member names and argument meaning as the reference; every operation is a C-ABI call on device rows.  One deliberate
+// difference: the reference's SingleCRT::addPrimes stores the UNREDUCED polynomial in the new rows (`map[i] = poly;` instead of
+// `poly1`, SingleCRT.cpp:262-266), which its own verify() would reject; the mirror stores the reduced residues the comment there
+// describes.
+class SingleCRT {
+  const FHEcontext& context;
+  fhesi_dcrt* h = nullptr;
+  friend class DoubleCRT;
+  void alloc(const IndexSet& s) { auto v = s.vec(); if (v.empty()) Error("SingleCRT: empty index set"); ck(fhesi_scrt_alloc(context.handle(), v.data(), (int32_t)v.size(), &h)); }
+  void realloc(const IndexSet& s) { if (h) { ck(fhesi_dcrt_free(h)); h = nullptr; } alloc(s); }
+  SingleCRT& Op(const SingleCRT& other, int op, bool matchIndexSets = true) {   // SingleCRT.cpp:61-103
+    if (&context != &other.context) Error("SingleCRT::Op: incomopatible objects");
+    if (matchIndexSets && !(getIndexSet() >= other.getIndexSet())) addPrimes(other.getIndexSet() / getIndexSet());
+    if (getIndexSet() > other.getIndexSet()) { SingleCRT tmp(other); tmp.addPrimes(getIndexSet() / other.getIndexSet()); ck(fhesi_dcrt_op(h, tmp.h, op)); }
+    else if (getIndexSet() == other.getIndexSet()) ck(fhesi_dcrt_op(h, other.h, op));
+    else { SingleCRT tmp(other); tmp.removePrimes(other.getIndexSet() / getIndexSet()); ck(fhesi_dcrt_op(h, tmp.h, op)); }
+    return *this;
+  }
+  SingleCRT& Op(const ZZX& poly, int op) { SingleCRT other(poly, context, getIndexSet()); return Op(other, op); }   // :105-135: PolyRed per prime, then AddMod / SubMod
+  SingleCRT& Op(const ZZ& num, int op) { int nl = (int)(num.bits() / 64 + 2); std::vector<uint64_t> v(nl); num.to_limbs(v.data(), nl); ck(fhesi_scrt_op_scalar(h, v.data(), nl, op)); return *this; }   // :137-153
+ public:
+  SingleCRT(const ZZX& poly, const FHEcontext& c, const IndexSet& s) : context(c) { alloc(s); *this = poly; }
+  SingleCRT(const ZZX& poly, const FHEcontext& c) : context(c) { alloc(IndexSet(0, c.numPrimes() - 1)); *this = poly; }
+  explicit SingleCRT(const ZZX& poly) : context(*activeContext) { alloc(IndexSet(0, context.numPrimes() - 1)); *this = poly; }
+  SingleCRT(const FHEcontext& c, const IndexSet& s) : context(c) { alloc(s); }
+  explicit SingleCRT(const FHEcontext& c) : context(c) { alloc(IndexSet(0, c.numPrimes() - 1)); }
+  SingleCRT() : context(*activeContext) { alloc(IndexSet(0, context.numPrimes() - 1)); }
+  SingleCRT(const SingleCRT& o) : context(o.context) { alloc(o.getIndexSet()); ck(fhesi_dcrt_copy(h, o.h)); }
+  ~SingleCRT() { if (h) fhesi_dcrt_free(h); }
+
+  SingleCRT& operator=(const SingleCRT& o) { if (&context != &o.context) Error("SingleCRT assignment: context mismatch"); ck(fhesi_dcrt_copy(h, o.h)); return *this; }   // :219-228
+  SingleCRT& operator=(const DoubleCRT& d) { d.toSingleCRT(*this); return *this; }                                                                                 // :231-235
+  SingleCRT& operator=(const ZZX& poly) {                                                                                                                            // :239-251
+    ZZX p = poly; p.normalize();
+    if ((long)p.rep.size() > (long)context.zMstar.phiM()) Error("SingleCRT = ZZX: degree >= phi(m) is outside the device row layout");
+    int nl = limbs_for(p); auto v = to_limbs(p, nl);
+    ck(fhesi_scrt_from_poly(h, v.data(), nl, (int64_t)p.rep.size()));
+    return *this;
+  }
+  SingleCRT& operator=(const ZZ& num) { ZZX p; p.rep.assign(1, num); p.normalize(); return *this = p; }
+  SingleCRT& operator=(long num) { return *this = ZZ(num); }
+  bool operator==(const SingleCRT& o) const { if (&context != &o.context) return false; int32_t eq = 0; ck(fhesi_dcrt_equal(h, o.h, &eq)); return eq != 0; }
+  bool operator!=(const SingleCRT& o) const { return !(*this == o); }
+  SingleCRT& setZero() { return *this = ZZ(); }
+  SingleCRT& setOne() { return *this = 1L; }
+  void addPrimes(const IndexSet& s1) {                                                                                                                               // :254-268
+    assert(card(s1 & getIndexSet()) == 0);
+    if (card(s1) == 0) return;
+    ZZX poly; toPoly(poly);
+    IndexSet uni = getIndexSet() | s1;
+    SingleCRT grown(context, uni);
+    long n = context.zMstar.phiM(); std::vector<uint64_t> row(n);
+    IndexSet old = getIndexSet();
+    for (long i = old.first(); i <= old.last(); i = old.next(i)) { ck(fhesi_dcrt_download_row(h, (int32_t)i, row.data())); ck(fhesi_dcrt_upload_row(grown.h, (int32_t)i, row.data())); }
+    SingleCRT fresh(poly, context, s1);
+    for (long i = s1.first(); i <= s1.last(); i = s1.next(i)) { ck(fhesi_dcrt_download_row(fresh.h, (int32_t)i, row.data())); ck(fhesi_dcrt_upload_row(grown.h, (int32_t)i, row.data())); }
+    realloc(uni); ck(fhesi_dcrt_copy(h, grown.h));
+  }
+  void removePrimes(const IndexSet& s1) { auto v = s1.vec(); if (v.empty()) return; ck(fhesi_dcrt_remove_primes(h, v.data(), (int32_t)v.size())); }   // SingleCRT.h:117-119
+  SingleCRT& operator+=(const SingleCRT& o) { return Op(o, OP_ADD); }
+  SingleCRT& operator+=(const ZZX& p) { return Op(p, OP_ADD); }
+  SingleCRT& operator+=(const ZZ& n) { return Op(n, OP_ADD); }
+  SingleCRT& operator+=(long n) { return Op(ZZ(n), OP_ADD); }
+  SingleCRT& operator-=(const SingleCRT& o) { return Op(o, OP_SUB); }
+  SingleCRT& operator-=(const ZZX& p) { return Op(p, OP_SUB); }
+  SingleCRT& operator-=(const ZZ& n) { return Op(n, OP_SUB); }
+  SingleCRT& operator-=(long n) { return Op(ZZ(n), OP_SUB); }
+  void Add(const SingleCRT& o, bool match = true) { Op(o, OP_ADD, match); }
+  void Sub(const SingleCRT& o, bool match = true) { Op(o, OP_SUB, match); }
+  SingleCRT& operator++() { return *this += 1L; }
+  SingleCRT& operator--() { return *this -= 1L; }
+  void operator++(int) { *this += 1L; }
+  void operator--(int) { *this -= 1L; }
+  SingleCRT& operator*=(const ZZ& n) { return Op(n, OP_MUL); }
+  SingleCRT& operator*=(long n) { return Op(ZZ(n), OP_MUL); }
+  SingleCRT& operator/=(const ZZ& n) { return Op(n, OP_DIV); }                                                                                                       // :279-296
+  SingleCRT& operator/=(long n) { return Op(ZZ(n), OP_DIV); }
+  void toPoly(ZZX& p, const IndexSet& s) const {                                                                                                                     // :299-334
+    IndexSet s1 = getIndexSet() & s;
+    if (card(s1) == 0) { clear(p); return; }
+    int nl = (int)card(s1) + 2; long n = context.zMstar.phiM(); auto idx = s1.vec();
+    std::vector<uint64_t> out((size_t)n * nl);
+    ck(fhesi_scrt_to_poly(h, idx.data(), (int32_t)idx.size(), out.data(), nl));
+    p = from_limbs(out, n, nl);
+  }
+  void toPoly(ZZX& p) const { toPoly(p, getIndexSet()); }
+  const FHEcontext& getContext() const { return context; }
+  IndexSet getIndexSet() const { int32_t n = 0; std::vector<int32_t> v(64); ck(fhesi_dcrt_index_set(h, v.data(), &n)); IndexSet s; for (int i = 0; i < n; ++i) s.insert(v[i]); return s; }
+  fhesi_dcrt* handle() const { return h; }
+};
+inline void conv(SingleCRT& s, const ZZX& p) { s = p; }
+inline void conv(ZZX& p, const SingleCRT& s) { s.toPoly(p); }
+inline ZZX to_ZZX(const SingleCRT& s) { ZZX p; s.toPoly(p); return p; }
+inline DoubleCRT& DoubleCRT::operator=(const SingleCRT& scrt) {
+  if (&context != &scrt.getContext()) Error("DoubleCRT=SingleCRT -- incompatible contexts");
+  ck(fhesi_dcrt_assign_scrt(h, scrt.handle()));
+  return *this;
+}
+inline void DoubleCRT::toSingleCRT(SingleCRT& scrt, const IndexSet& s) const {
+  if (&context != &scrt.getContext()) Error("DoubleCRT::toSingleCRT -- incompatible contexts");
+  auto v = s.vec();
+  if (v.empty()) Error("DoubleCRT::toSingleCRT: empty index set");
+  ck(fhesi_scrt_assign_dcrt(scrt.handle(), h, v.data(), (int32_t)v.size()));
+}
+inline void DoubleCRT::toSingleCRT(SingleCRT& scrt) const { toSingleCRT(scrt, getIndexSet()); }
 
 // ---------------------------------------------------------------- samplers (NumbTh.cpp:340-404) on the documented PRNG
 inline void sampleHWt(ZZX& poly, long Hwt, long n) {

@@ -183,6 +183,7 @@ inline void SetCoeff(ZZX& a, long i, const ZZ& v) { if (i >= (long)a.rep.size())
 inline void SetCoeff(ZZX& a, long i, long v) { SetCoeff(a, i, ZZ(v)); }
 inline void clear(ZZX& a) { a.rep.clear(); }
 inline ZZX& operator+=(ZZX& a, const ZZX& b) { if (a.rep.size() < b.rep.size()) a.rep.resize(b.rep.size()); for (size_t i = 0; i < b.rep.size(); ++i) a.rep[i] += b.rep[i]; a.normalize(); return a; }
+inline ZZX& operator-=(ZZX& a, const ZZX& b) { if (a.rep.size() < b.rep.size()) a.rep.resize(b.rep.size()); for (size_t i = 0; i < b.rep.size(); ++i) a.rep[i] -= b.rep[i]; a.normalize(); return a; }
 inline ZZX& operator*=(ZZX& a, const ZZ& s) { for (auto& c : a.rep) c *= s; a.normalize(); return a; }
 inline ZZX operator*(ZZX a, const ZZ& s) { return a *= s; }
 inline ZZX operator*(const ZZ& s, ZZX a) { return a *= s; }

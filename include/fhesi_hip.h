@@ -111,6 +111,25 @@ int fhesi_dcrt_scale_down_to_set(fhesi_dcrt* d, const int32_t* prime_idx, int32_
 int fhesi_dcrt_from_scrt(fhesi_dcrt* d, const uint64_t* coeff_rows);
 int fhesi_dcrt_to_scrt(const fhesi_dcrt* d, uint64_t* coeff_rows_out);
 
+/* ---- SingleCRT (SingleCRT.h:41-175, SingleCRT.cpp): the coefficient-domain RNS form -- for every prime of the index set the
+ * polynomial's phi(m) coefficients modulo that prime.  It shares the DoubleCRT handle type and row storage; a handle made by
+ * fhesi_scrt_alloc holds coefficient residues, and calls of the other family on it fail.  Shared entry points: fhesi_dcrt_free,
+ * fhesi_dcrt_copy (operator=, SingleCRT.cpp:219-228), fhesi_dcrt_index_set, fhesi_dcrt_equal (SingleCRT.h:98-100),
+ * fhesi_dcrt_upload_row / download_row (getMap), fhesi_dcrt_op with ADD / SUB (Op(SingleCRT, AddMod / SubMod), SingleCRT.cpp:61-103),
+ * fhesi_dcrt_remove_primes (SingleCRT.h:117-119). */
+int fhesi_scrt_alloc(fhesi_ctx* ctx, const int32_t* prime_idx, int32_t nidx, fhesi_dcrt** out);     /* SingleCRT(context, s): zero polynomial (SingleCRT.cpp:188-203) */
+int fhesi_scrt_from_poly(fhesi_dcrt* s, const uint64_t* coeff_limbs, int32_t nlimbs, int64_t ncoeffs);   /* operator=(ZZX): PolyRed(poly, p_i, abs=true) per prime
+                                                                                        (SingleCRT.cpp:239-251, NumbTh.cpp:210-233); ncoeffs <= phi(m) */
+int fhesi_scrt_to_poly(const fhesi_dcrt* s, const int32_t* prime_idx, int32_t nidx, uint64_t* coeff_limbs_out, int32_t nlimbs);
+                                                                                     /* toPoly (SingleCRT.cpp:299-334): centred CRT over (index set & s) */
+int fhesi_scrt_op_scalar(fhesi_dcrt* s, const uint64_t* num_limbs, int32_t nlimbs, int32_t op);
+                                                                                     /* Op(ZZ, add / sub / mul) (SingleCRT.cpp:137-153) and operator/= (:279-296):
+                                                                                        ADD / SUB change the constant coefficient only (NTL add(ZZX, ZZX, ZZ)) */
+int fhesi_dcrt_assign_scrt(fhesi_dcrt* d, const fhesi_dcrt* s);                      /* DoubleCRT::operator=(SingleCRT): DoubleCRT.cpp:484-496, in HBM */
+int fhesi_scrt_assign_dcrt(fhesi_dcrt* s, const fhesi_dcrt* d, const int32_t* prime_idx, int32_t nidx);
+                                                                                     /* DoubleCRT::toSingleCRT(scrt, s) / SingleCRT::operator=(DoubleCRT):
+                                                                                        DoubleCRT.cpp:498-515, SingleCRT.cpp:231-235; nidx = 0 and null = all */
+
 /* ---- batched device-resident row kernels.  rows_dev: [count][L][phi(m)] uint64 in HBM, all L primes */
 int fhesi_rows_ntt_fwd_dev(fhesi_ctx* ctx, uint64_t* rows_dev, int64_t count);      /* coefficient residues -> evaluations, in place (Cmod::FFT after conv) */
 int fhesi_rows_ntt_inv_dev(fhesi_ctx* ctx, uint64_t* rows_dev, int64_t count);      /* evaluations -> coefficient residues, in place (Cmod::iFFT) */

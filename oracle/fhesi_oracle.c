@@ -408,6 +408,34 @@ void orc_dcrt_to_poly(const orc_ctx* c, const u64* rows, const int* idx, int nid
   free(vp); free(cur); free(P);
 }
 
+/* ------------------------------------------------------------------ SingleCRT (SingleCRT.cpp): rows [L][phim] of COEFFICIENT residues */
+/* SingleCRT::operator=(const ZZX&) (SingleCRT.cpp:239-251): PolyRed(poly, p_i, abs=true) per prime (NumbTh.cpp:210-233) */
+void orc_scrt_from_poly(const orc_ctx* c, const u64* limbs, int nlimbs, i64 ncoeffs, u64* rows) {
+  i64 n = c->phim; memset(rows, 0, 8 * n * c->L);
+  for (int i = 0; i < c->L; i++) for (i64 k = 0; k < ncoeffs && k < n; k++) rows[(i64)i * n + k] = bn_mod_u64(limbs + k * nlimbs, nlimbs, c->pr[i].q);
+}
+/* SingleCRT::toPoly (SingleCRT.cpp:299-334): first row centred (:320-321), then intVecCRT per further prime (:323-328) */
+void orc_scrt_to_poly(const orc_ctx* c, const u64* rows, const int* idx, int nidx, u64* out, int nlimbs) {
+  i64 n = c->phim; int all[64]; if (!idx) { nidx = c->L; for (int i = 0; i < nidx; i++) all[i] = i; idx = all; }
+  if (nidx == 0) { memset(out, 0, 8 * n * nlimbs); return; }
+  int W = nidx + 2; u64* vp = calloc(n * W, 8); u64* P = calloc(W, 8);
+  u64 p0 = c->pr[idx[0]].q; P[0] = p0; const u64* r0 = rows + (i64)idx[0] * n;
+  for (i64 j = 0; j < n; j++) { i64 v = r0[j] > p0 / 2 ? (i64)r0[j] - (i64)p0 : (i64)r0[j]; bn_set_i64(vp + j * W, v, W); }
+  for (int t = 1; t < nidx; t++) { u64 q = c->pr[idx[t]].q; int_vec_crt(vp, P, W, rows + (i64)idx[t] * n, n, q); bn_mul_u64(P, q, W); }
+  for (i64 j = 0; j < n; j++) bn_copy_ext(out + j * nlimbs, nlimbs, vp + j * W, W);
+  free(vp); free(P);
+}
+/* SingleCRT::Op(const ZZ&, NTL::add / sub / mul) (SingleCRT.cpp:137-153) and operator/= (:279-296); op: 0 add, 1 sub, 2 mul, 3 div.
+ * add / sub of a ZZX and a scalar change the constant coefficient only.  Returns 1 when the divisor is not invertible. */
+int orc_scrt_op_scalar(const orc_ctx* c, u64* rows, const u64* num, int nlimbs, int op) {
+  i64 n = c->phim;
+  for (int i = 0; i < c->L; i++) { u64 q = c->pr[i].q, v = bn_mod_u64(num, nlimbs, q); u64* r = rows + (i64)i * n;
+    if (op == 0) r[0] = addmod(r[0], v, q);
+    else if (op == 1) r[0] = submod(r[0], v, q);
+    else { if (op == 3) { if (!v) return 1; v = invmod(v, q); } for (i64 j = 0; j < n; j++) r[j] = mulmod(r[j], v, q); } }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ BGV-style modulus switching (DoubleCRT.cpp:162-208, 518-558)
  * Dead code in fhe-si (no callers) but part of the DoubleCRT surface.  Rows are in the full layout [L][phim];
  * index sets are ascending lists of prime indices.  Big integers here are magnitudes in little-endian limbs. */

@@ -40,6 +40,10 @@ def lib():
         _lib.orc_dcrt_add_primes_and_scale.restype = C.c_double
         _lib.orc_dcrt_scale_down_to_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint64]
         _lib.orc_dcrt_scale_down_to_set.restype = C.c_int
+        _lib.orc_scrt_from_poly.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+        _lib.orc_scrt_to_poly.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        _lib.orc_scrt_op_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _lib.orc_scrt_op_scalar.restype = C.c_int
         _lib.orc_set_bluestein_fft.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_set_bluestein_fft.restype = C.c_int
         _lib.orc_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -189,6 +193,30 @@ class Oracle:
             ia = np.array(idx, dtype=np.int32)
             lib().orc_dcrt_to_poly(self.h, _p(rows), _p(ia), len(ia), int(positive), _p(out), nlimbs)
         return out
+
+    # ---- SingleCRT (SingleCRT.cpp): rows [L][phim] of coefficient residues
+    def scrt_from_poly(self, limbs: np.ndarray) -> np.ndarray:
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        rows = np.zeros((self.L, self.phim), dtype=np.uint64)
+        lib().orc_scrt_from_poly(self.h, _p(limbs), limbs.shape[1], limbs.shape[0], _p(rows))
+        return rows
+
+    def scrt_to_poly(self, rows: np.ndarray, nlimbs: int, idx=None) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros((self.phim, nlimbs), dtype=np.uint64)
+        if idx is None:
+            lib().orc_scrt_to_poly(self.h, _p(rows), None, 0, _p(out), nlimbs)
+        else:
+            ia = np.array(idx, dtype=np.int32)
+            lib().orc_scrt_to_poly(self.h, _p(rows), _p(ia), len(ia), _p(out), nlimbs)
+        return out
+
+    def scrt_op_scalar(self, rows: np.ndarray, num: int, op: int, nlimbs: int = 4) -> np.ndarray:
+        rows = np.array(rows, dtype=np.uint64, copy=True)
+        s = ints_to_limbs([num], nlimbs)
+        if lib().orc_scrt_op_scalar(self.h, _p(rows), _p(s), nlimbs, op) != 0:
+            raise ValueError("inverse undefined")
+        return rows
 
     # ---- BGV-style modulus switching (DoubleCRT.cpp:162-208, 518-558); rows in the full layout [L][phim]
     def dcrt_add_primes_and_scale(self, rows: np.ndarray, cur_idx, add_idx, p: int):

@@ -211,3 +211,62 @@ def test_modulus_switching_vs_oracle(m, logQ):
     with pytest.raises(F.FhesiError):
         e.scale_down_to_set([2], p)                     # empty intersection (DoubleCRT.cpp:525)
     assert e.add_primes_and_scale([], p) == 0.0         # nothing to do (DoubleCRT.cpp:165)
+
+
+@pytest.mark.parametrize("m,logQ", [(64, 100), (22, 100), (4096, 200)])
+def test_single_crt_vs_oracle(m, logQ):
+    """class SingleCRT (SingleCRT.h:41-175) through the C ABI vs the C oracle: operator=(ZZX) = PolyRed per prime, toPoly over
+    the full set and over subsets (+-(P-1)/2 edges), Op(SingleCRT) add / sub, scalar add / sub (constant coefficient only), mul, /=,
+    and the device-to-device conversions DoubleCRT = SingleCRT and toSingleCRT (DoubleCRT.cpp:484-515)."""
+    primes, roots = P.chain_for(m, logQ, 23)
+    L = len(primes)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n = ctx.phim
+    rng = np.random.default_rng(m + 1)
+    Pall = 1
+    for q in primes:
+        Pall *= q
+    W = L + 2
+    la, lb = P.rand_limbs(rng, (n,), W, 60 * L - 3), P.rand_limbs(rng, (n,), W, 60 * L + 40)     # b exceeds P: reduced modulo each prime
+    la[0] = O.ints_to_limbs([(Pall - 1) // 2], W)[0]
+    la[1] = O.ints_to_limbs([-((Pall - 1) // 2)], W)[0]
+    la[2] = 0
+    sa, sb = F.SingleCRT(ctx).assign_poly(la), F.SingleCRT(ctx).assign_poly(lb)
+    ra, rb = orc.scrt_from_poly(la), orc.scrt_from_poly(lb)
+    assert np.array_equal(sa.rows(), ra) and np.array_equal(sb.rows(), rb)
+    short = F.SingleCRT(ctx).assign_poly(la[:5])                # fewer coefficients than phi(m): the rest is zero
+    assert np.array_equal(short.rows(), orc.scrt_from_poly(la[:5]))
+    assert np.array_equal(sa.to_poly(W), orc.scrt_to_poly(ra, W))
+    for idx in ([0], [1, L - 1], list(range(L - 1))):
+        assert np.array_equal(sb.to_poly(W, idx), orc.scrt_to_poly(rb, W, idx)), idx
+    assert not sa.to_poly(W, []).any()
+    # Op(SingleCRT, AddMod / SubMod) -- the same element-wise kernels as DoubleCRT::Op
+    c = F.SingleCRT(ctx)
+    c.assign(sa)
+    c.op(sb, F.OP_ADD)
+    assert np.array_equal(c.rows(), orc.dcrt_op(ra, rb, 0))
+    c.op(sb, F.OP_SUB)
+    assert c.equals(sa)
+    with pytest.raises(F.FhesiError):
+        c.op(sb, F.OP_MUL)                                      # no MulMod between SingleCRT objects (SingleCRT.h:127-133)
+    # scalars: add / sub on the constant coefficient, mul / div on all of them
+    k = (1 << 100) + 12345
+    for op in (0, 1, 2, 3):
+        c.assign(sa)
+        c.op_scalar(k, op)
+        assert np.array_equal(c.rows(), orc.scrt_op_scalar(ra, k, op)), op
+    with pytest.raises(F.FhesiError):
+        c.op_scalar(primes[0], 3)                               # InvMod of 0 (SingleCRT.cpp:288)
+    # conversions in HBM
+    d = F.DoubleCRT(ctx)
+    F.dcrt_assign_scrt(d, sa)
+    assert np.array_equal(d.rows(), orc.dcrt_from_poly(la))
+    back = F.SingleCRT(ctx).assign_dcrt(d)
+    assert back.equals(sa)
+    part = F.SingleCRT(ctx).assign_dcrt(d, [0, L - 1])
+    assert part.index_set() == [0, L - 1] and np.array_equal(part.rows(), ra[[0, L - 1]])
+    with pytest.raises(F.FhesiError):
+        d.op(sa, F.OP_ADD)                                      # mixing the two forms is an error
+    with pytest.raises(F.FhesiError):
+        sa.assign(d)

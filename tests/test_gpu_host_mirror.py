@@ -109,3 +109,13 @@ def test_wire_format_bytes_match_python_model(tmp_path):
     assert rd("c1.bin") == R.wire_ciphertext([I(x) for x in fx["c1"]])
     assert rd("c2.bin") == R.wire_ciphertext([I(x) for x in fx["c2"]])
     assert rd("prod.bin") == R.wire_ciphertext([I(x) for x in fx["scaled"]])        # Export scales the product down first
+
+
+@pytest.mark.parametrize("m", [64, 22, 1024])
+def test_single_crt_mirror_class(m):
+    """The mirrored SingleCRT class (fhe-si_amd/host/fhesi_host.h, SingleCRT.h:41-175): conversions, arithmetic and index-set handling
+    against big-integer arithmetic on the host and against the mirrored DoubleCRT (tests/host/test_scrt.cpp)."""
+    build()
+    r = subprocess.run([os.path.join(HOST, "test_scrt"), str(m)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Test SUCCEEDED" in r.stdout
