@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
     "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
-    "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
+    "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -138,6 +138,8 @@ def _load():
         "fhesi_ctx_set_option": [_vp, C.c_char_p, _i64],
         "fhesi_ctx_get_option": [_vp, C.c_char_p, _vp],
         "fhesi_ksk_mark_dirty": [_vp],
+        "fhesi_ksk_download": [_vp, _vp],
+        "fhesi_keyswitch_init_batch": [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp],
         "fhesi_scrt_alloc": [_vp, _vp, _i32, _vp],
         "fhesi_scrt_from_poly": [_vp, _vp, _i32, _i64],
         "fhesi_scrt_to_poly": [_vp, _vp, _i32, _vp, _i32],
@@ -607,6 +609,21 @@ class KeySwitchMatrix:
     @property
     def device_ptr(self) -> int:
         return _load().fhesi_ksk_device_ptr(self.h)
+
+    def download(self) -> np.ndarray:
+        out = np.zeros((2, self.ncomp * self.ndigits, self.ctx.L, self.ctx.phim), dtype=np.uint64)
+        _ck(_load().fhesi_ksk_download(self.h, _p(out)))
+        return out
+
+    def init_batch(self, src, dst_t: "DoubleCRT", logQ: int, a: np.ndarray, err: np.ndarray, decomp_bytes: int = 3):
+        """KeySwitchSI::Init (FHE-SI.cpp:153-209) for all columns at once: src = the source key's DoubleCRT components, a = the random
+        polynomials [ncol][phim][nlimbs], err = the Gaussian errors [ncol][phim], drawn by the caller in the reference's order."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        err = np.ascontiguousarray(err, dtype=np.int64)
+        assert a.shape[0] == err.shape[0] == self.ncomp * self.ndigits
+        hs = (_vp * len(src))(*[d.h for d in src])
+        _ck(_load().fhesi_keyswitch_init_batch(self.h, hs, len(src), dst_t.h, logQ, decomp_bytes, _p(a), a.shape[-1], _p(err)))
+        return self
 
     def mark_dirty(self):
         """The rows were written through device_ptr (e.g. by a collective): derived tables are rebuilt at the next key switch."""

@@ -1117,6 +1117,13 @@ extern "C" int fhesi_ksk_upload(fhesi_ksk* k, const uint64_t* rows_host) {
 // The library keeps tables derived from the rows; whoever writes the rows directly (a collective receiving into them) says so with
 // fhesi_ksk_mark_dirty, and the next key switch rebuilds the tables.  The getter itself has no side effect.
 extern "C" void* fhesi_ksk_device_ptr(fhesi_ksk* k) { return k ? k->d_rows : nullptr; }
+extern "C" int fhesi_ksk_download(const fhesi_ksk* k, uint64_t* rows_host) {
+  if (!k || !rows_host) FHESI_FAIL("null key-switch matrix");
+  CHECK_CTX(k->ctx);
+  HIP_TRY(hipMemcpyAsync(rows_host, k->d_rows, k->bytes, hipMemcpyDeviceToHost, k->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(k->ctx->stream));
+  return 0;
+}
 extern "C" int fhesi_ksk_mark_dirty(fhesi_ksk* k) {
   if (!k) FHESI_FAIL("null key-switch matrix");
   k->aux_valid = false;
@@ -1402,6 +1409,59 @@ extern "C" int fhesi_decrypt_batch(fhesi_ctx* c, const fhesi_dcrt* sk1, int32_t 
   FHESI_TRY(launch_decrypt_round(c, (const u64*)d_big, count * n, nw, logQ, p, (i64*)d_msg));                        // round(p z / q) mod p (:110-116)
   HIP_TRY(hipMemcpyAsync(msg_host, d_msg, (size_t)count * n * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// KeySwitchSI::Init (FHE-SI.cpp:153-209) for all columns of a matrix at once; the randomness is the caller's, in the reference's draw order
+extern "C" int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
+                                          const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host) {
+  if (!k) FHESI_FAIL("null key-switch matrix");
+  fhesi_ctx* c = k->ctx;
+  CHECK_CTX(c);
+  if (nsrc != k->ncomp) FHESI_FAIL("KeySwitchSI::Init: the source key has %d components, the matrix was created for %d", nsrc, k->ncomp);
+  if (decomp_bytes < 1 || decomp_bytes > 7) FHESI_FAIL("decompSize %d not supported", decomp_bytes);
+  const int nd = (logQ + 8 * decomp_bytes - 1) / (8 * decomp_bytes);
+  if (nd != k->ndigits) FHESI_FAIL("KeySwitchSI::Init: matrix has %d digits per component, context needs %d", k->ndigits, nd);
+  if (nlimbs < 1 || nlimbs * 64 < logQ) FHESI_FAIL("KeySwitchSI::Init: random coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  const int L = c->L;
+  if (!dst_t || dst_t->ctx != c || dst_t->coeff_form || (int)dst_t->idx.size() != L) FHESI_FAIL("KeySwitchSI::Init: the target key must be a DoubleCRT over all primes of this context");
+  for (int i = 0; i < nsrc; ++i)
+    if (!src[i] || src[i]->ctx != c || src[i]->coeff_form || (int)src[i]->idx.size() != L) FHESI_FAIL("KeySwitchSI::Init: source key component %d must be a DoubleCRT over all primes of this context", i);
+  const i64 n = c->phim, ncol = (i64)nsrc * nd;
+  const int nlq = (logQ + 63) / 64;
+  const std::vector<int> all = full_set(c);
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, all, &t));
+  const int W = t->W;
+  u64* d_b = k->d_rows;                                  // keySwitchMatrix[0] = b
+  u64* d_A = k->d_rows + (size_t)ncol * L * n;           // keySwitchMatrix[1] = A
+  // one-off call: its scratch is allocated here and released on return (the transforms below own the context's workspace slots)
+  struct Scratch { std::vector<void*> p; ~Scratch() { hipDeviceSynchronize(); for (void* q : p) hipFree(q); } int get(size_t bytes, void** out) { if (hipMalloc(out, bytes ? bytes : 8) != hipSuccess) return 1; p.push_back(*out); return 0; } } scratch;
+  void *d_s, *d_scoef, *d_in, *d_err, *d_bcoef, *d_comb;
+  if (scratch.get((size_t)nsrc * L * n * 8, &d_s) || scratch.get((size_t)nsrc * n * W * 8, &d_scoef) || scratch.get((size_t)ncol * n * std::max(nlimbs, W) * 8, &d_in) ||
+      scratch.get((size_t)ncol * n * 8, &d_err) || scratch.get((size_t)ncol * n * nlq * 8, &d_comb)) FHESI_FAIL("KeySwitchSI::Init: out of device memory");
+  // sCoeff[i] = toPoly(s[i])   (:163-166)
+  for (int i = 0; i < nsrc; ++i) HIP_TRY(hipMemcpyAsync((u64*)d_s + (size_t)i * L * n, src[i]->d_rows, (size_t)L * n * 8, hipMemcpyDeviceToDevice, c->stream));
+  FHESI_TRY(row_inv(c, (u64*)d_s, nsrc, L, nullptr, all.data()));
+  FHESI_TRY(launch_crt(c, t, (const u64*)d_s, L, nullptr, nsrc, 0, 0, 0, (u64*)d_scoef, W));
+  // A[ind] = DoubleCRT(poly)   (:176-179)
+  HIP_TRY(hipMemcpyAsync(d_in, a_host, (size_t)ncol * n * nlimbs * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_err, err_host, (size_t)ncol * n * 8, hipMemcpyHostToDevice, c->stream));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)d_in, nlimbs, n, ncol, 1, nullptr, d_A, L, nullptr));
+  FHESI_TRY(row_fwd(c, d_A, ncol, L, nullptr, all.data()));
+  // b[ind] = A[ind] * t; toPoly   (:180-187)
+  FHESI_TRY(launch_rows_mul_bcast(c, d_b, d_A, dst_t->d_rows, ncol));
+  FHESI_TRY(row_inv(c, d_b, ncol, L, nullptr, all.data()));
+  d_bcoef = d_in;                                        // (the random coefficients are consumed)
+  FHESI_TRY(launch_crt(c, t, d_b, L, nullptr, ncol, 0, 0, 0, (u64*)d_bcoef, W));
+  // bCoeff += err + sCoeff[i] << (8 decompSize j); ReduceCoefficients; b[ind] = DoubleCRT(bCoeff)   (:189-204)
+  FHESI_TRY(launch_keygen_combine(c, (const u64*)d_bcoef, W, (const u64*)d_scoef, W, (const i64*)d_err, ncol, nd, 8 * decomp_bytes, nlq, logQ, (u64*)d_comb));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)d_comb, nlq, n, ncol, 1, nullptr, d_b, L, nullptr));
+  FHESI_TRY(row_fwd(c, d_b, ncol, L, nullptr, all.data()));
+  // A[ind] *= -1   (:181)
+  FHESI_TRY(fhesi_rows_mul_long_dev(c, d_A, -1, ncol));
+  k->aux_valid = false;
+  HIP_TRY(hipStreamSynchronize(c->stream));             // the host arrays and the scratch may be released on return
   return 0;
 }
 

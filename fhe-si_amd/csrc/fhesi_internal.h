@@ -249,6 +249,9 @@ int launch_add_scaled_msg(fhesi_ctx* ctx, u64* d_ct, const i64* d_msg, const u64
 int launch_decrypt_dot(fhesi_ctx* ctx, const u64* d_rows /* [count][2][L][n] */, const u64* d_t /* [L][n] */, i64 count, u64* d_out /* [count][L][n] */);
 int launch_decrypt_round(fhesi_ctx* ctx, const u64* d_z, i64 total, int nw, int logQ, u64 p, i64* d_out);
 
+int launch_rows_mul_bcast(fhesi_ctx* ctx, u64* d_dst /* [ncols][L][n] */, const u64* d_a /* [ncols][L][n] */, const u64* d_t /* [L][n] */, i64 ncols);
+int launch_keygen_combine(fhesi_ctx* ctx, const u64* d_bcoef, int wb, const u64* d_scoef, int ws, const i64* d_err, i64 ncols, int nd, int digit_bits, int nl, int logQ, u64* d_out);
+
 // kernels_crt.hip
 int get_crt_tables(fhesi_ctx* ctx, const std::vector<int>& idx, CrtTables** out);
 // big-int coefficients [count][npoly][n][nlimbs] -> residue rows [count][npoly][L][n]; scalar_mul[poly] (0 = none) multiplies

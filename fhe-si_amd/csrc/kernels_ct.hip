@@ -293,3 +293,74 @@ int launch_decrypt_round(fhesi_ctx* ctx, const u64* d_z, i64 total, int nw, int 
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ---- KeySwitchSI::Init in batches (FHE-SI.cpp:153-209) -------------------------------------------------------------------------------
+// b = A * t for every column: dst[col][l][j] = a[col][l][j] * t[l][j] mod q_l   (`b[ind] = A[ind]; b[ind] *= t`, :180-184)
+__global__ void __launch_bounds__(256) rows_mul_bcast_kernel(u64* __restrict__ dst, const u64* __restrict__ a, const u64* __restrict__ t, int L, i64 n,
+                                                              const PrimeConst* __restrict__ pcs) {
+  const i64 col = blockIdx.z;
+  const int l = blockIdx.y;
+  const PrimeConst pc = pcs[l];
+  const u64* ar = a + (col * L + l) * n;
+  const u64* tr = t + (i64)l * n;
+  u64* dr = dst + (col * L + l) * n;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) dr[j] = d_mulmod(ar[j], tr[j], pc);
+}
+int launch_rows_mul_bcast(fhesi_ctx* ctx, u64* d_dst, const u64* d_a, const u64* d_t, i64 ncols) {
+  if (!ncols) return 0;
+  if (ncols > 65535) FHESI_FAIL("KeySwitchSI::Init: more than 65535 columns");
+  unsigned gx = (unsigned)((ctx->phim + 255) / 256);
+  if (gx > 64) gx = 64;
+  rows_mul_bcast_kernel<<<dim3(gx, (unsigned)ctx->L, (unsigned)ncols), 256, 0, ctx->stream>>>(d_dst, d_a, d_t, ctx->L, ctx->phim, ctx->d_pc);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// bCoeff += err; bCoeff += sCoeff[i] (already shifted left by digit_bits * j); ReduceCoefficients(bCoeff, logQ)   (:192-203)
+//   bcoef: [ncol][n][wb] two's complement (toPoly of b), scoef: [nsrc][n][ws] (toPoly of the source key components), err: [ncol][n];
+//   out: [ncol][n][nl] centred modulo 2^logQ.  Only the bits below logQ of every term matter, so all arithmetic is modulo 2^(64 nl).
+template <int MAXNL>
+__global__ void __launch_bounds__(256) keygen_combine_kernel(const u64* __restrict__ bcoef, int wb, const u64* __restrict__ scoef, int ws, const i64* __restrict__ err,
+                                                              i64 n, int nd, int digit_bits, int nl, int logQ, u64* __restrict__ out) {
+  const i64 col = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const i64 comp = col / nd;
+  const int sh = (int)(col % nd) * digit_bits, wsh = sh >> 6, bsh = sh & 63;
+  const u64* bx = bcoef + (col * n + j) * wb;
+  const u64* sx = scoef + (comp * n + j) * ws;
+  const i64 e = err[col * n + j];
+  const u64 bsign = (bx[wb - 1] >> 63) ? ~0ull : 0, ssign = (sx[ws - 1] >> 63) ? ~0ull : 0, esign = e < 0 ? ~0ull : 0;
+  u64 v[MAXNL];
+  u64 carry = 0;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i < nl) {
+      const u64 b = i < wb ? bx[i] : bsign;
+      const u64 ev = i == 0 ? (u64)e : esign;
+      // limb i of (s << sh): limbs i - wsh and i - wsh - 1 of the sign-extended s
+      auto slimb = [&](int k) -> u64 { return k < 0 ? 0 : (k < ws ? sx[k] : ssign); };
+      const u64 hi = slimb(i - wsh), lo = slimb(i - wsh - 1);
+      const u64 sv = bsh ? ((hi << bsh) | (lo >> (64 - bsh))) : hi;
+      const u128 t = (u128)b + ev + sv + carry;
+      v[i] = (u64)t; carry = (u64)(t >> 64);
+    }
+  u64 sb = 0;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i == (logQ - 1) >> 6) sb = (v[i] >> ((logQ - 1) & 63)) & 1;
+  u64* o = out + (col * n + j) * nl;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i < nl) o[i] = reduce_limb(v[i], i, logQ, sb);
+}
+int launch_keygen_combine(fhesi_ctx* ctx, const u64* d_bcoef, int wb, const u64* d_scoef, int ws, const i64* d_err, i64 ncols, int nd, int digit_bits, int nl, int logQ, u64* d_out) {
+  if (!ncols) return 0;
+  if (nl > 32) FHESI_FAIL("KeySwitchSI::Init: coefficients of %d limbs exceed the supported 32", nl);
+  const dim3 grid((unsigned)((ctx->phim + 255) / 256), (unsigned)ncols);
+  if (nl <= 2) keygen_combine_kernel<2><<<grid, 256, 0, ctx->stream>>>(d_bcoef, wb, d_scoef, ws, d_err, ctx->phim, nd, digit_bits, nl, logQ, d_out);
+  else if (nl <= 8) keygen_combine_kernel<8><<<grid, 256, 0, ctx->stream>>>(d_bcoef, wb, d_scoef, ws, d_err, ctx->phim, nd, digit_bits, nl, logQ, d_out);
+  else if (nl <= 16) keygen_combine_kernel<16><<<grid, 256, 0, ctx->stream>>>(d_bcoef, wb, d_scoef, ws, d_err, ctx->phim, nd, digit_bits, nl, logQ, d_out);
+  else keygen_combine_kernel<32><<<grid, 256, 0, ctx->stream>>>(d_bcoef, wb, d_scoef, ws, d_err, ctx->phim, nd, digit_bits, nl, logQ, d_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

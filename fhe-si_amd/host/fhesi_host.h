@@ -649,13 +649,47 @@ class FHESIPubKey {
 class KeySwitchSI {
   const FHEcontext& context;
   std::vector<std::vector<DoubleCRT>> keySwitchMatrix;
+  bool objectAtATime = false;          // checker mode: build the matrix with the reference's per-object loop (InitObjects)
+  void InitAny(const FHESISecKey& src, const FHESISecKey& dst) { if (objectAtATime) InitObjects(src, dst); else Init(src, dst); }
  public:
+  struct ObjectAtATime {};
+  KeySwitchSI(const FHESISecKey& s, ObjectAtATime) : context(s.GetContext()), objectAtATime(true) { InitS2(s); }
   KeySwitchSI(const FHESISecKey& s) : context(s.GetContext()) { InitS2(s); }
   KeySwitchSI(const FHESISecKey& src, const FHESISecKey& dst) : context(src.GetContext()) { Init(src, dst); }
   const std::vector<std::vector<DoubleCRT>>& GetRepresentation() const { return keySwitchMatrix; }
   void UpdateRepresentation(const std::vector<std::vector<DoubleCRT>>& rep) { keySwitchMatrix = rep; }
   const FHEcontext& GetContext() const { return context; }
-  void Init(const FHESISecKey& src, const FHESISecKey& dst) {   // FHE-SI.cpp:153-209
+  // FHE-SI.cpp:153-209.  The randomness is drawn here in the reference's order (per column: the SampleRandom polynomial, then the
+  // Gaussian error); the arithmetic of all columns -- 2 ncol L forward and ncol L inverse row transforms, products, CRT, the shifted
+  // key term and the reduction modulo 2^logQ -- is ONE device call (fhesi_keyswitch_init_batch).  InitObjects below is the same
+  // computation one DoubleCRT object at a time, as the reference writes it; both give identical matrices (tests/host/test_wire.cpp).
+  void Init(const FHESISecKey& src, const FHESISecKey& dst) {
+    const std::vector<DoubleCRT>& s = src.GetRepresentation();
+    const size_t n = src.GetSize(); const long phim = context.zMstar.phiM(), L = context.numPrimes();
+    const long ncol = (long)(context.ndigits * n); const int nl = (int)((context.logQ + 63) / 64);
+    std::vector<uint64_t> a((size_t)ncol * phim * nl); std::vector<int64_t> err((size_t)ncol * phim);
+    for (long ind = 0; ind < ncol; ++ind) {
+      ZZX poly; SampleRandom(poly, context.modulusQ, phim);
+      for (long k = 0; k < phim; ++k) coeff(poly, k).to_limbs(&a[((size_t)ind * phim + k) * nl], nl);
+      ZZX e; sampleGaussian(e, phim, context.stdev);
+      for (long k = 0; k < phim; ++k) err[(size_t)ind * phim + k] = coeff(e, k).to_long();
+    }
+    fhesi_ksk* k = nullptr;
+    ck(fhesi_ksk_create(context.handle(), (int32_t)n, (int32_t)context.ndigits, &k));
+    std::vector<const fhesi_dcrt*> hs; for (auto& d : s) hs.push_back(d.handle());
+    int rc = fhesi_keyswitch_init_batch(k, hs.data(), (int32_t)n, dst.GetRepresentation()[1].handle(), (int32_t)context.logQ, (int32_t)context.decompSize, a.data(), nl, err.data());
+    if (rc) { fhesi_ksk_free(k); ck(rc); }
+    const uint64_t* rows = (const uint64_t*)fhesi_ksk_device_ptr(k); const size_t rowWords = (size_t)L * phim;
+    keySwitchMatrix.assign(2, std::vector<DoubleCRT>());
+    for (int r = 0; r < 2; ++r)
+      for (long col = 0; col < ncol; ++col) {
+        DoubleCRT d(context);
+        ck(fhesi_dev_copy(context.handle(), fhesi_dcrt_device_ptr(d.handle()), rows + ((size_t)r * ncol + col) * rowWords, rowWords * 8));
+        keySwitchMatrix[r].push_back(d);
+      }
+    fhesi_ksk_free(k);
+  }
+  void InitObjects(const FHESISecKey& src, const FHESISecKey& dst) {   // the reference's loop, one object at a time
     std::vector<DoubleCRT> s = src.GetRepresentation(); std::vector<ZZX> sCoeff(s.size());
     for (size_t i = 0; i < s.size(); ++i) s[i].toPoly(sCoeff[i]);
     DoubleCRT t = dst.GetRepresentation()[1]; size_t n = src.GetSize();
@@ -678,7 +712,7 @@ class KeySwitchSI {
     tKeys[0] = sKeys[0];
     for (size_t i = 2; i < tKeys.size(); ++i) tKeys[i] *= tKeys[i - 1];
     FHESISecKey tensored(s.GetContext()); tensored.UpdateRepresentation(tKeys);
-    Init(tensored, s);
+    InitAny(tensored, s);
   }
   KeySwitchSI(const FHESISecKey& s, unsigned k) : context(s.GetContext()) { InitAutomorph(s, k); }     // FHE-SI.h: key for X -> X^k
   void InitAutomorph(const FHESISecKey& s, unsigned k) {   // FHE-SI.cpp:229-239
@@ -686,7 +720,7 @@ class KeySwitchSI {
     FHESISecKey automorphedKey(s.GetContext());           // (its constructor draws a key that is replaced below, as in the reference)
     for (auto& sk : sKeys) sk.automorph((long)k);
     automorphedKey.UpdateRepresentation(sKeys);
-    Init(automorphedKey, s);
+    InitAny(automorphedKey, s);
   }
   void ApplyKeySwitch(Ciphertext& ctxt) const {   // FHE-SI.cpp:241-260
     ctxt.ScaleDown(); ctxt.ByteDecomp();

@@ -203,6 +203,16 @@ int fhesi_encrypt_batch(fhesi_ctx* ctx, const fhesi_dcrt* pk0, const fhesi_dcrt*
 int fhesi_decrypt_batch(fhesi_ctx* ctx, const fhesi_dcrt* sk1, int32_t logQ, uint64_t p, const uint64_t* ct_dev, int32_t nlimbs, int64_t count,
                         int64_t* msg_host);
 
+/* KeySwitchSI::Init (FHE-SI.cpp:153-209) for every column of a matrix in one call: k = the matrix (ncomp = components of the source
+ * key: 3 for InitS2's (1, t, t^2), 2 for InitAutomorph), src[i] = the source key's DoubleCRT components, dst_t = dst[1].
+ *   a_host   [ncomp*ndigits][phi(m)][nlimbs]  the SampleRandom polynomials (:174-175), centred modulo 2^logQ, column i*ndigits+j
+ *   err_host [ncomp*ndigits][phi(m)] int64    the Gaussian errors (:189-190)
+ * drawn by the caller in the reference's order (poly, err per column).  Result: k[1][col] = -DoubleCRT(a), k[0][col] =
+ * DoubleCRT(Reduce(toPoly(a t) + err + (toPoly(s_i) << 8 decompSize j))), all transforms, products and conversions on the device. */
+int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
+                               const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host);
+int fhesi_ksk_download(const fhesi_ksk* k, uint64_t* rows_host);                         /* whole matrix to the host (Export, FHE-SI.cpp:270-272) */
+
 /* plain device-memory helpers so C callers need no HIP headers */
 int fhesi_dev_alloc(fhesi_ctx* ctx, size_t bytes, void** out_dev);
 int fhesi_dev_free(fhesi_ctx* ctx, void* dev);

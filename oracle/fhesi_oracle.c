@@ -638,3 +638,28 @@ void orc_decrypt(const orc_ctx* c, const u64* t_rows, const u64* parts, int nlim
     msg_out[j] = (i64)bn_mod_u64(v, W, p); }
   free(c0); free(c1); free(big);
 }
+
+/* KeySwitchSI::Init (FHE-SI.cpp:153-209) with the randomness made explicit.  src: [nsrc][L][phim] rows of the source key components,
+ * t_rows: rows of dst[1]; a: [ncol][phim][nlimbs] the SampleRandom polynomials (:174-175), err: [ncol][phim] the Gaussian errors
+ * (:189-190), column ind = i * ndigits + j.  ksm: [2][ncol][L][phim], ksm[0] = b, ksm[1] = A (:206-208). */
+void orc_keyswitch_init(const orc_ctx* c, const u64* src, int nsrc, const u64* t_rows, int logQ, int decomp_bytes, const u64* a, int nlimbs, const i64* err, u64* ksm) {
+  i64 n = c->phim; int L = c->L, nd = (logQ + 8 * decomp_bytes - 1) / (8 * decomp_bytes), ncol = nsrc * nd;
+  int W = L + 3 + (nd * 8 * decomp_bytes + 63) / 64;                 /* sCoeff grows by 8 decompSize bits per digit (:198-200) */
+  u64* sco = malloc(8 * n * W); u64* bco = malloc(8 * n * W); u64* tmp = malloc(8 * (i64)L * n); u64 e[W];
+  for (int i = 0; i < nsrc; i++) {
+    orc_dcrt_to_poly(c, src + (i64)i * L * n, NULL, 0, 0, sco, W);                                   /* s[i].toPoly(sCoeff[i]) :163-166 */
+    for (int j = 0; j < nd; j++) { int ind = i * nd + j;
+      u64* A = ksm + ((i64)ncol + ind) * L * n; u64* B = ksm + (i64)ind * L * n;
+      orc_dcrt_from_poly(c, a + (i64)ind * n * nlimbs, nlimbs, n, A);                                /* A[ind] = DoubleCRT(poly) :176-178 */
+      memcpy(tmp, A, 8 * (i64)L * n); orc_dcrt_op(c, tmp, t_rows, 2);                                /* b[ind] = A[ind]; b[ind] *= t :179,184 */
+      orc_dcrt_to_poly(c, tmp, NULL, 0, 0, bco, W);                                                  /* b[ind].toPoly(bCoeff) :186-187 */
+      for (i64 k = 0; k < n; k++) { u64* v = bco + k * W; bn_set_i64(e, err[(i64)ind * n + k], W); bn_add(v, e, W); bn_add(v, sco + k * W, W);    /* :192-194 */
+        bn_shl(sco + k * W, W, 8 * decomp_bytes);                                                    /* sCoeff[i].rep[k] <<= 8 decompSize :196-198 */
+        reduce_logq(v, W, logQ, 0); }                                                                /* ReduceCoefficients :200 */
+      orc_dcrt_from_poly(c, bco, W, n, B);                                                           /* b[ind] = DoubleCRT(bCoeff) :201 */
+      u64 m1[1] = {~0ull}; orc_dcrt_op_scalar(c, A, m1, 1, 2);                                       /* A[ind] *= -1 :181 */
+    }
+  }
+  free(sco); free(bco); free(tmp);
+}
+

@@ -93,6 +93,15 @@ int main(int argc, char* argv[]) {
     std::vector<Plaintext> dec; sk2.DecryptBatch(dec, many);
     if (dec.size() != 3 || dec[0].message != m1 || dec[1].message != m2 || dec[2].message != m1) { std::cout << "DecryptBatch does not invert EncryptBatch" << std::endl; ++failures; }
   }
+  // KeySwitchSI::Init as one device call (fhesi_keyswitch_init_batch) equals the reference's object-at-a-time loop from the same PRNG state
+  {
+    SetSeed(4242); KeySwitchSI kb(sk2);
+    SetSeed(4242); KeySwitchSI ko(sk2, KeySwitchSI::ObjectAtATime());
+    const auto &A = kb.GetRepresentation(), &B = ko.GetRepresentation();
+    bool same = A.size() == 2 && B.size() == 2 && A[0].size() == B[0].size() && A[1].size() == B[1].size();
+    for (int r = 0; same && r < 2; ++r) for (size_t c = 0; same && c < A[r].size(); ++c) same = A[r][c] == B[r][c];
+    if (!same) { std::cout << "batched KeySwitchSI::Init differs from the object-at-a-time loop" << std::endl; ++failures; }
+  }
   // the imported product has 3 parts (it was scaled down on export): relinearise it with the imported matrix
   if (prod.parts.size() != 3) { std::cout << "imported product has " << prod.parts.size() << " parts" << std::endl; ++failures; }
   ks2.ApplyKeySwitch(prod);

@@ -44,6 +44,7 @@ def lib():
         _lib.orc_scrt_to_poly.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         _lib.orc_scrt_op_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib.orc_scrt_op_scalar.restype = C.c_int
+        _lib.orc_keyswitch_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.orc_set_bluestein_fft.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_set_bluestein_fft.restype = C.c_int
         _lib.orc_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -193,6 +194,17 @@ class Oracle:
             ia = np.array(idx, dtype=np.int32)
             lib().orc_dcrt_to_poly(self.h, _p(rows), _p(ia), len(ia), int(positive), _p(out), nlimbs)
         return out
+
+    def keyswitch_init(self, src_rows: np.ndarray, t_rows: np.ndarray, logQ: int, a: np.ndarray, err: np.ndarray, decomp_bytes: int = 3) -> np.ndarray:
+        """KeySwitchSI::Init (FHE-SI.cpp:153-209) with explicit randomness -> [2][ncol][L][phim]."""
+        src_rows = np.ascontiguousarray(src_rows, dtype=np.uint64)
+        t_rows = np.ascontiguousarray(t_rows, dtype=np.uint64)
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        err = np.ascontiguousarray(err, dtype=np.int64)
+        ncol = a.shape[0]
+        ksm = np.zeros((2, ncol, self.L, self.phim), dtype=np.uint64)
+        lib().orc_keyswitch_init(self.h, _p(src_rows), src_rows.shape[0], _p(t_rows), logQ, decomp_bytes, _p(a), a.shape[-1], _p(err), _p(ksm))
+        return ksm
 
     # ---- SingleCRT (SingleCRT.cpp): rows [L][phim] of coefficient residues
     def scrt_from_poly(self, limbs: np.ndarray) -> np.ndarray:
