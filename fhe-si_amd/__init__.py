@@ -5,8 +5,8 @@ package is the thin ctypes binding used by tests/ and bench.py, plus the C++ mir
 surface under ``host/``.  The directory name carries a hyphen (it follows the reference's name), so import it
 through the repo-root shim:  ``import fhe_si_amd``.
 """
-from .binding import (Backend, Context, DoubleCRT, SingleCRT, dcrt_assign_scrt, KeySwitchMatrix, FhesiError, build_library, library_path,
+from .binding import (Backend, Context, DoubleCRT, SingleCRT, dcrt_assign_scrt, KeySwitchMatrix, Comm, FhesiError, build_library, library_path,
                       OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SET)
 
-__all__ = ["Backend", "Context", "DoubleCRT", "SingleCRT", "dcrt_assign_scrt", "KeySwitchMatrix", "FhesiError", "build_library", "library_path",
+__all__ = ["Backend", "Context", "DoubleCRT", "SingleCRT", "dcrt_assign_scrt", "KeySwitchMatrix", "Comm", "FhesiError", "build_library", "library_path",
            "OP_ADD", "OP_SUB", "OP_MUL", "OP_DIV", "OP_SET"]

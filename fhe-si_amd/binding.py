@@ -34,7 +34,8 @@ ABI_SYMBOLS = [
     "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
     "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
-    "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
+    "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_comm_init_all", "fhesi_comm_from_rccl", "fhesi_comm_destroy", "fhesi_comm_rank",
+    "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -138,6 +139,13 @@ def _load():
         "fhesi_ctx_set_option": [_vp, C.c_char_p, _i64],
         "fhesi_ctx_get_option": [_vp, C.c_char_p, _vp],
         "fhesi_ksk_mark_dirty": [_vp],
+        "fhesi_comm_init_all": [_i32, _vp, _vp],
+        "fhesi_comm_from_rccl": [_vp, _vp],
+        "fhesi_comm_destroy": [_vp],
+        "fhesi_ksk_broadcast": [_vp, _vp, _i32],
+        "fhesi_comm_broadcast_dev": [_vp, _vp, _vp, C.c_size_t, _i32],
+        "fhesi_comm_exchange": [_vp, _vp, _vp, _vp],
+        "fhesi_comm_allreduce_rows": [_vp, _vp, _vp, _i64],
         "fhesi_ksk_download": [_vp, _vp],
         "fhesi_keyswitch_init_batch": [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp],
         "fhesi_scrt_alloc": [_vp, _vp, _i32, _vp],
@@ -162,6 +170,9 @@ def _load():
     for name in ("fhesi_ctx_stream", "fhesi_dcrt_device_ptr", "fhesi_ksk_device_ptr"):
         getattr(lib, name).argtypes = [_vp]
         getattr(lib, name).restype = _vp
+    for name in ("fhesi_comm_rank", "fhesi_comm_size"):
+        getattr(lib, name).argtypes = [_vp]
+        getattr(lib, name).restype = _i32
     lib.fhesi_ksk_bytes.argtypes = [_vp]
     lib.fhesi_ksk_bytes.restype = C.c_size_t
     _lib = lib
@@ -586,6 +597,44 @@ def dcrt_assign_scrt(d: DoubleCRT, s: SingleCRT):
     """DoubleCRT::operator=(const SingleCRT&) (DoubleCRT.cpp:484-496)."""
     _ck(_load().fhesi_dcrt_assign_scrt(d.h, s.h))
     return d
+
+
+class Comm:
+    """One rank of a multi-GPU group (fhesi_comm: an RCCL communicator; a loopback group when ranks share a device).  Collective
+    methods must be called by every rank of the group concurrently (one host thread per rank; ctypes releases the GIL)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def init_all(devices):
+        devs = np.array(list(devices), dtype=np.int32)
+        hs = (_vp * len(devs))()
+        _ck(_load().fhesi_comm_init_all(len(devs), _p(devs), hs))
+        return [Comm(_vp(h)) for h in hs]
+
+    @property
+    def rank(self) -> int:
+        return _load().fhesi_comm_rank(self.h)
+
+    @property
+    def size(self) -> int:
+        return _load().fhesi_comm_size(self.h)
+
+    def ksk_broadcast(self, ksk: "KeySwitchMatrix", root: int = 0):
+        _ck(_load().fhesi_ksk_broadcast(ksk.h, self.h, root))
+
+    def exchange(self, ctx: Context, base: DevBuf, offsets_words):
+        off = np.ascontiguousarray(offsets_words, dtype=np.int64)
+        _ck(_load().fhesi_comm_exchange(ctx.h, self.h, base.ptr, _p(off)))
+
+    def allreduce_rows(self, ctx: Context, rows: DevBuf, count: int):
+        _ck(_load().fhesi_comm_allreduce_rows(ctx.h, self.h, rows.ptr, count))
+
+    def destroy(self):
+        if self.h:
+            _load().fhesi_comm_destroy(self.h)
+            self.h = None
 
 
 class KeySwitchMatrix:

@@ -1,0 +1,246 @@
+// comm.hip -- the multi-GPU side of the C ABI: RCCL collectives over xGMI on the library's own streams.
+//
+// The data-parallel model has ONE collective in its set-up (the key-switch matrix generated on one rank is broadcast into every rank's
+// HBM replica: KeySwitchSI::keySwitchMatrix, FHE-SI.cpp:206-208) and, for wave-scheduled Matrix<Ciphertext> arithmetic whose waves
+// are sharded over the ranks, one exchange of each wave's outputs (the next wave reads ciphertexts produced by every rank) plus the
+// optional all-reduce of partial scaled-up sums (Ciphertext.cpp:135-142: scaled-up addition is linear).  No torch here: librccl is
+// resolved at run time (dlopen) so that single-GPU users need no RCCL at all, and communicators are plain ncclComm_t values made by
+// the caller (process per GPU: ncclCommInitRank) or by fhesi_comm_init_all (one process, one host thread per GPU).
+//
+// "Loopback" groups exist for ONE purpose: ranks that share a device (RCCL refuses duplicate GPUs), i.e. exercising the N > 1 host
+// logic on a single-GPU box.  They move the same bytes with device-to-device copies between the ranks' buffers and host barriers.
+#include "../../include/fhesi_hip.h"
+#include "fhesi_internal.h"
+
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <mutex>
+
+namespace {
+
+typedef void* nccl_comm_t;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*CommCount)(nccl_comm_t, int*) = nullptr;
+  int (*CommUserRank)(nccl_comm_t, int*) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+const int kNcclUint64 = 5, kNcclSum = 0;     // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+RcclApi* rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) return;
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p) ok = false; return p; };
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+    api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
+    api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(api.lib); api.lib = nullptr; }
+  });
+  return api.lib ? &api : nullptr;
+}
+
+// ranks of one process that share a device: publish buffer pointers, meet at a host barrier, copy
+struct LoopGroup {
+  int nranks = 0, refs = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  std::vector<void*> ptr;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long gen = generation;
+    if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
+    else cv.wait(lk, [&] { return generation != gen; });
+  }
+};
+
+}  // namespace
+
+struct fhesi_comm {
+  int rank = 0, nranks = 1;
+  nccl_comm_t nccl = nullptr;          // RCCL communicator (owned when made by fhesi_comm_init_all)
+  bool owns_nccl = false;
+  LoopGroup* loop = nullptr;           // loopback group (ranks sharing a device)
+};
+
+#define RCCL_TRY(api, expr) do { int r__ = (expr); if (r__ != 0) { fhesi_set_error("%s failed: %s", #expr, (api)->GetErrorString ? (api)->GetErrorString(r__) : "RCCL error"); return 1; } } while (0)
+
+extern "C" int fhesi_comm_init_all(int32_t ndev, const int32_t* devices, fhesi_comm** comms_out) {
+  if (ndev < 1 || !devices || !comms_out) FHESI_FAIL("comm_init_all: bad arguments");
+  bool distinct = true;
+  for (int i = 0; i < ndev; ++i) for (int j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+  if (!distinct) {
+    // ranks sharing a device: RCCL rejects duplicate GPUs, so this group moves its bytes with device copies (plumbing checks on a 1-GPU box)
+    LoopGroup* g = new LoopGroup();
+    g->nranks = ndev; g->refs = ndev; g->ptr.assign(ndev, nullptr);
+    for (int i = 0; i < ndev; ++i) { fhesi_comm* c = new fhesi_comm(); c->rank = i; c->nranks = ndev; c->loop = g; comms_out[i] = c; }
+    return 0;
+  }
+  RcclApi* api = rccl();
+  if (!api) FHESI_FAIL("comm_init_all: librccl.so.1 could not be loaded");
+  std::vector<nccl_comm_t> cs(ndev);
+  std::vector<int> devs(devices, devices + ndev);
+  RCCL_TRY(api, api->CommInitAll(cs.data(), ndev, devs.data()));
+  for (int i = 0; i < ndev; ++i) { fhesi_comm* c = new fhesi_comm(); c->rank = i; c->nranks = ndev; c->nccl = cs[i]; c->owns_nccl = true; comms_out[i] = c; }
+  return 0;
+}
+
+extern "C" int fhesi_comm_from_rccl(void* nccl_comm, fhesi_comm** out) {
+  if (!nccl_comm || !out) FHESI_FAIL("comm_from_rccl: null argument");
+  RcclApi* api = rccl();
+  if (!api) FHESI_FAIL("comm_from_rccl: librccl.so.1 could not be loaded");
+  fhesi_comm* c = new fhesi_comm();
+  c->nccl = nccl_comm;
+  if (api->CommCount(nccl_comm, &c->nranks) != 0 || api->CommUserRank(nccl_comm, &c->rank) != 0) { delete c; FHESI_FAIL("comm_from_rccl: not a usable ncclComm_t"); }
+  *out = c;
+  return 0;
+}
+
+extern "C" int fhesi_comm_destroy(fhesi_comm* c) {
+  if (!c) return 0;
+  if (c->nccl && c->owns_nccl) { RcclApi* api = rccl(); if (api) api->CommDestroy(c->nccl); }
+  if (c->loop) { bool last; { std::lock_guard<std::mutex> lk(c->loop->mu); last = --c->loop->refs == 0; } if (last) delete c->loop; }
+  delete c;
+  return 0;
+}
+extern "C" int32_t fhesi_comm_rank(const fhesi_comm* c) { return c ? c->rank : -1; }
+extern "C" int32_t fhesi_comm_size(const fhesi_comm* c) { return c ? c->nranks : 0; }
+
+// buf (bytes) of rank `root` into every rank's buf, on the context's stream
+static int comm_broadcast(fhesi_ctx* ctx, fhesi_comm* c, void* buf, size_t bytes, int root) {
+  if (root < 0 || root >= c->nranks) FHESI_FAIL("broadcast: root %d outside the %d ranks", root, c->nranks);
+  if (c->nranks == 1 && !c->nccl) return 0;       // (a one-rank RCCL communicator still goes through RCCL)
+  if (c->loop) {
+    LoopGroup* g = c->loop;
+    g->ptr[c->rank] = buf;
+    g->barrier();
+    if (c->rank != root) HIP_TRY(hipMemcpyAsync(buf, g->ptr[root], bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    g->barrier();                              // the root's buffer stays untouched until every rank has read it
+    return 0;
+  }
+  RcclApi* api = rccl();
+  if (!api) FHESI_FAIL("broadcast: librccl.so.1 could not be loaded");
+  if (bytes % 8) FHESI_FAIL("broadcast: byte count must be a multiple of 8");
+  RCCL_TRY(api, api->Broadcast(buf, buf, bytes / 8, kNcclUint64, root, c->nccl, ctx->stream));
+  return 0;
+}
+
+// The set-up collective: rank `root`'s key-switch matrix into every rank's replica (KeySwitchSI::keySwitchMatrix rows, FHE-SI.cpp:206-208)
+extern "C" int fhesi_ksk_broadcast(fhesi_ksk* k, fhesi_comm* comm, int32_t root) {
+  if (!k || !comm) FHESI_FAIL("ksk_broadcast: null argument");
+  fhesi_ctx* ctx = k->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  FHESI_TRY(comm_broadcast(ctx, comm, k->d_rows, k->bytes, root));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (comm->rank != root) k->aux_valid = false;      // the rows changed: derived tables are rebuilt at the next key switch
+  return 0;
+}
+
+extern "C" int fhesi_comm_broadcast_dev(fhesi_ctx* ctx, fhesi_comm* comm, void* buf_dev, size_t bytes, int32_t root) {
+  if (!ctx || !comm) FHESI_FAIL("broadcast: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  FHESI_TRY(comm_broadcast(ctx, comm, buf_dev, bytes, root));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// Exchange of sharded results: rank r holds words [offsets[r], offsets[r+1]) of base_dev; afterwards every rank holds all of them.
+// One (grouped) broadcast per producing rank: shards differ in size and a wave has few of them, so this beats a padded all-gather.
+extern "C" int fhesi_comm_exchange(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* base_dev, const int64_t* offsets_words) {
+  if (!ctx || !comm || !offsets_words) FHESI_FAIL("exchange: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (comm->nranks == 1 && !comm->nccl) return 0;
+  if (comm->loop) {
+    LoopGroup* g = comm->loop;
+    g->ptr[comm->rank] = base_dev;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));       // my shard is complete before anyone reads it
+    g->barrier();
+    for (int r = 0; r < comm->nranks; ++r) {
+      const i64 lo = offsets_words[r], hi = offsets_words[r + 1];
+      if (r == comm->rank || hi <= lo) continue;
+      HIP_TRY(hipMemcpyAsync(base_dev + lo, (const u64*)g->ptr[r] + lo, (size_t)(hi - lo) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    g->barrier();
+    return 0;
+  }
+  RcclApi* api = rccl();
+  if (!api) FHESI_FAIL("exchange: librccl.so.1 could not be loaded");
+  RCCL_TRY(api, api->GroupStart());
+  for (int r = 0; r < comm->nranks; ++r) {
+    const i64 lo = offsets_words[r], hi = offsets_words[r + 1];
+    if (hi <= lo) continue;
+    RCCL_TRY(api, api->Broadcast(base_dev + lo, base_dev + lo, (size_t)(hi - lo), kNcclUint64, r, comm->nccl, ctx->stream));
+  }
+  RCCL_TRY(api, api->GroupEnd());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// rows_dev[i] <- (sum over ranks of rows_dev[i]) mod q_{slot(i)}: the exact accumulator of partial scaled-up sums held by the ranks
+// (Ciphertext.cpp:135-142).  Residues are below 2^60, so the sum of up to 16 ranks fits a word before the reduction.
+__global__ void __launch_bounds__(256) reduce_after_sum_kernel(u64* __restrict__ rows, i64 n, int L, const PrimeConst* __restrict__ pcs) {
+  const i64 row = blockIdx.y;
+  const PrimeConst pc = pcs[row % L];
+  u64* x = rows + row * n;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    const u64 v = x[j];
+    x[j] = d_shoup(v, 1, pc.one_sh, pc.q);
+  }
+}
+extern "C" int fhesi_comm_allreduce_rows(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* rows_dev, int64_t count) {
+  if (!ctx || !comm) FHESI_FAIL("allreduce: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if ((comm->nranks == 1 && !comm->nccl) || !count) return 0;
+  if (comm->nranks > 16) FHESI_FAIL("allreduce: more than 16 ranks would overflow the 64-bit partial sums");
+  const i64 n = ctx->phim, words = count * ctx->L * n;
+  if (comm->loop) {
+    // sum through a staging copy of every other rank's rows (plumbing path: ranks share the device)
+    LoopGroup* g = comm->loop;
+    void* stage;
+    HIP_TRY(hipMalloc(&stage, (size_t)words * 8));
+    HIP_TRY(hipMemcpyAsync(stage, rows_dev, (size_t)words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    g->ptr[comm->rank] = stage;
+    g->barrier();
+    for (int r = 0; r < comm->nranks; ++r) {
+      if (r == comm->rank) continue;
+      if (launch_ew_op(ctx, rows_dev, (const u64*)g->ptr[r], count, ctx->L, nullptr, FHESI_OP_ADD)) { hipFree(stage); return 1; }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    g->barrier();
+    HIP_TRY(hipFree(stage));
+    return 0;
+  }
+  RcclApi* api = rccl();
+  if (!api) FHESI_FAIL("allreduce: librccl.so.1 could not be loaded");
+  RCCL_TRY(api, api->AllReduce(rows_dev, rows_dev, (size_t)words, kNcclUint64, kNcclSum, comm->nccl, ctx->stream));
+  unsigned gx = (unsigned)((n + 255) / 256);
+  if (gx > 64) gx = 64;
+  reduce_after_sum_kernel<<<dim3(gx, (unsigned)(count * ctx->L)), 256, 0, ctx->stream>>>(rows_dev, n, ctx->L, ctx->d_pc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}

@@ -204,6 +204,15 @@ class FHEcontext {
     }
     return dev;
   }
+  // another device context with the same chain and roots on GPU `dev_index` (one per GPU in the multi-GPU model); the caller owns it
+  fhesi_ctx* replica(int dev_index) const {
+    std::vector<uint64_t> q, r;
+    for (auto& c : moduli) { q.push_back((uint64_t)c.getQ()); r.push_back((uint64_t)c.getRoot()); }
+    fhesi_ctx* h = nullptr;
+    ck(fhesi_ctx_create(&h, m_, (int32_t)q.size(), q.data(), r.data(), dev_index));
+    return h;
+  }
+  int deviceIndex() const { return device; }
  private:
   unsigned m_ = 0;
 };

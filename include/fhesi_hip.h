@@ -32,6 +32,7 @@ extern "C" {
 typedef struct fhesi_ctx fhesi_ctx;     /* FHEcontext + vector<Cmodulus> + PAlgebra (FHEContext.h, CModulus.h, PAlgebra.h) */
 typedef struct fhesi_dcrt fhesi_dcrt;   /* one DoubleCRT object (DoubleCRT.h:83-365), rows resident in HBM */
 typedef struct fhesi_ksk fhesi_ksk;     /* one KeySwitchSI matrix (FHE-SI.cpp:206-208), resident in HBM */
+typedef struct fhesi_comm fhesi_comm;   /* one rank of a multi-GPU group: an RCCL communicator (ncclComm_t) over xGMI */
 
 enum { FHESI_OP_ADD = 0, FHESI_OP_SUB = 1, FHESI_OP_MUL = 2, FHESI_OP_DIV = 3, FHESI_OP_SET = 4 };
 
@@ -212,6 +213,29 @@ int fhesi_decrypt_batch(fhesi_ctx* ctx, const fhesi_dcrt* sk1, int32_t logQ, uin
 int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
                                const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host);
 int fhesi_ksk_download(const fhesi_ksk* k, uint64_t* rows_host);                         /* whole matrix to the host (Export, FHE-SI.cpp:270-272) */
+
+/* ---- multi-GPU: independent ciphertexts are data-parallel, every GPU holds the context tables and a replica of
+ * the key-switch matrices; RCCL collectives run on the context's stream.  librccl is loaded on first use (no RCCL needed on one GPU).
+ * fhesi_comm_init_all: one process, one host thread per GPU -- ncclCommInitAll over `devices`, comms_out[r] is rank r's handle.
+ *   (If `devices` repeats a GPU -- RCCL refuses that -- the group is a "loopback" group that moves the same bytes with device copies
+ *   and host barriers between the calling threads: for exercising N > 1 host logic on a single-GPU box, never for measurements.)
+ * fhesi_comm_from_rccl: wraps a caller-owned ncclComm_t (process-per-GPU launchers: ncclCommInitRank); not destroyed by us.
+ * Collective calls must be made by every rank of the group (from its own thread or process), like the RCCL calls they are. */
+int fhesi_comm_init_all(int32_t ndev, const int32_t* devices, fhesi_comm** comms_out);
+int fhesi_comm_from_rccl(void* nccl_comm, fhesi_comm** out);
+int fhesi_comm_destroy(fhesi_comm* comm);
+int32_t fhesi_comm_rank(const fhesi_comm* comm);
+int32_t fhesi_comm_size(const fhesi_comm* comm);
+/* the set-up collective of the data-parallel model: rank `root`'s key-switch matrix (KeySwitchSI::keySwitchMatrix, FHE-SI.cpp:206-208;
+ * 297 MiB at the metric ring) into every rank's replica `k` (same shape on every rank); derived tables are rebuilt on the receivers */
+int fhesi_ksk_broadcast(fhesi_ksk* k, fhesi_comm* comm, int32_t root);
+int fhesi_comm_broadcast_dev(fhesi_ctx* ctx, fhesi_comm* comm, void* buf_dev, size_t bytes, int32_t root);   /* any HBM buffer (bytes % 8 == 0) */
+/* exchange of sharded wave outputs (Matrix<Ciphertext> waves, Matrix.cpp:150-174): rank r produced the words
+ * [offsets_words[r], offsets_words[r+1]) of base_dev; afterwards every rank holds all of them (one grouped broadcast per producer) */
+int fhesi_comm_exchange(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* base_dev, const int64_t* offsets_words);
+/* exact all-reduce of partial scaled-up sums held by the ranks (Ciphertext::operator+= on scaled-up ciphertexts is linear,
+ * Ciphertext.cpp:135-142): rows_dev [count][L][phi(m)] <- (sum over ranks) mod q_i; at most 16 ranks (64-bit partial sums of 60-bit residues) */
+int fhesi_comm_allreduce_rows(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* rows_dev, int64_t count);
 
 /* plain device-memory helpers so C callers need no HIP headers */
 int fhesi_dev_alloc(fhesi_ctx* ctx, size_t bytes, void** out_dev);

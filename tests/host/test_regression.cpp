@@ -1,7 +1,7 @@
 // test_regression.cpp -- counterpart of the reference's Test_Regression driver (Test_Regression.cpp:10-131) on the mirrored
 // classes, with coefficient-form plaintexts (slot packing is outside the hot-path scope, see fhe-si_amd/host/fhesi_matrix.h).
 //
-//   test_regression p generator dim nrows [seed] [--batched-only] [--check=ring|slots|none] [--m=M] [--logQ=B]
+//   test_regression p generator dim nrows [seed] [--batched-only] [--check=ring|slots|none] [--m=M] [--logQ=B] [--devices=0,1,...]
 //
 // Context as in Test_Regression.cpp:97-125: m = p-1, logQ from the same noise formula, SetUpSIContext(xi).  The data matrix
 // (nrows x dim) and the labels are random polynomials over Z_p; Regression::Regress is evaluated three ways
@@ -72,11 +72,13 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char* argv[]) {
   bool batchedOnly = false; std::string check = "ring"; unsigned mOverride = 0, logQOverride = 0; int repeat = 1;
+  std::vector<int> devices;                // --devices=0,1,...: also run the wave evaluator sharded over these GPUs (first = the context's)
   std::vector<char*> args;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--batched-only")) batchedOnly = true;
     else if (!strncmp(argv[i], "--check=", 8)) check = argv[i] + 8;
     else if (!strncmp(argv[i], "--repeat=", 9)) repeat = atoi(argv[i] + 9);
+    else if (!strncmp(argv[i], "--devices=", 10)) { for (char* t = strtok(argv[i] + 10, ","); t; t = strtok(nullptr, ",")) devices.push_back(atoi(t)); }
     else if (!strncmp(argv[i], "--m=", 4)) mOverride = atoi(argv[i] + 4);
     else if (!strncmp(argv[i], "--logQ=", 7)) logQOverride = atoi(argv[i] + 7);
     else args.push_back(argv[i]);
@@ -187,6 +189,17 @@ int main(int argc, char* argv[]) {
             << " key switches, " << regress.stats.automorph_key_switches << " automorphism key switches" << std::endl;
   check_fn("batched", thetaB, detB);
 
+  if (!devices.empty()) {
+    // the same waves sharded over several GPUs (keys RCCL-broadcast from rank 0, wave outputs exchanged): bit-identical results
+    std::vector<Ciphertext> thetaG; Ciphertext detG(context);
+    double tG = 0;
+    for (int it = 0; it < std::max(repeat, 1); ++it) { t0 = now(); regress.RegressBatchedMultiGpu(devices, thetaG, detG); tG = now() - t0; }
+    std::cout << "batched on " << devices.size() << " rank(s): " << tG << " s" << std::endl;
+    bool same = thetaG.size() == thetaB.size() && detG[0] == detB[0] && detG[1] == detB[1];
+    for (unsigned i = 0; same && i < thetaG.size(); ++i) same = thetaG[i][0] == thetaB[i][0] && thetaG[i][1] == thetaB[i][1];
+    std::cout << "multi-rank ciphertexts bit-identical to one GPU: " << (same ? "yes" : "NO") << std::endl;
+    if (!same) ++failures;
+  }
   if (!batchedOnly) {
     std::vector<Ciphertext> thetaA; Ciphertext detA(context);
     t0 = now();

@@ -1,0 +1,104 @@
+"""GPU: the multi-GPU side of the C ABI on ONE GPU: (i) real RCCL with a one-rank communicator (proves librccl is
+found and the collectives run on the library's streams), (ii) two ranks sharing GPU 0 -- a loopback group, because RCCL refuses
+duplicate devices -- driven by one host thread per rank, through the key broadcast, the exchange of sharded wave outputs, the exact
+all-reduce of partial scaled-up sums, and the C++ wave evaluator (GroupExecutor) whose results must be bit-identical to one GPU.
+The 8-GPU scaling itself is measured by the driver with bench.py."""
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import fhe_si_amd as F
+import fhesi_pyref as R
+import oracle_lib as O
+import params as P
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "tests", "host")
+
+
+def _threads(n, fn):
+    errs = []
+
+    def run(r):
+        try:
+            fn(r)
+        except Exception as e:      # noqa: BLE001
+            errs.append((r, e))
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_key_broadcast_exchange_and_allreduce(devices):
+    m, logQ, p = 4096, 128, 23
+    primes, roots = P.chain_for(m, logQ, p)
+    G = len(devices)
+    ctxs = [F.Context(m, primes, roots, device=d) for d in devices]
+    orc = O.Oracle(m, primes, roots)
+    n, L, nd, nl = ctxs[0].phim, len(primes), R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(3)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    a = P.rand_limbs(rng, (1, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (1, 2, n), nl, logQ)
+    want = orc.ct_mul_relin(ksm, a[0], b[0], logQ, p)
+    comms = F.Comm.init_all(devices)
+    assert [c.rank for c in comms] == list(range(G)) and all(c.size == G for c in comms)
+    ksks = [F.KeySwitchMatrix(ctxs[r], 3, nd) for r in range(G)]
+    ksks[0].upload(ksm)
+    for r in range(1, G):                                   # stale tables on the receivers must be rebuilt after the broadcast
+        ksks[r].upload(np.zeros_like(ksm))
+        ctxs[r].ct_mul_relin(ksks[r], logQ, p, a, b)
+    _threads(G, lambda r: comms[r].ksk_broadcast(ksks[r], 0))
+    for r in range(G):
+        assert np.array_equal(ksks[r].download(), ksm)
+        assert np.array_equal(ctxs[r].ct_mul_relin(ksks[r], logQ, p, a, b)[0], want), r
+    # exchange: rank r owns a slice of a buffer of 7 "ciphertexts"
+    words, total = 2 * n * nl, 7
+    bounds = [F.shard.shard_bounds(total, r, G) for r in range(G)] if hasattr(F, "shard") else None
+    from fhe_si_amd import shard
+    bounds = [shard.shard_bounds(total, r, G) for r in range(G)]
+    full = rng.integers(0, 1 << 63, size=(total, words), dtype=np.uint64)
+    bufs = []
+    for r in range(G):
+        mine = np.zeros_like(full)
+        lo, hi = bounds[r]
+        mine[lo:hi] = full[lo:hi]
+        bufs.append(ctxs[r].upload(mine))
+    off = [bounds[0][0] * words] + [hi * words for _, hi in bounds]
+    _threads(G, lambda r: comms[r].exchange(ctxs[r], bufs[r], off))
+    for r in range(G):
+        assert np.array_equal(bufs[r].download(full.shape), full), r
+    # exact all-reduce of partial scaled-up sums: 2 DoubleCRTs per rank
+    parts = [P.rand_rows(np.random.default_rng(50 + r), primes, n, 2) for r in range(G)]
+    parts[0][0, 0, :] = np.uint64(primes[0] - 1)
+    dev = [ctxs[r].upload(parts[r]) for r in range(G)]
+    _threads(G, lambda r: comms[r].allreduce_rows(ctxs[r], dev[r], 2))
+    tot = np.zeros((2, L, n), dtype=object)
+    for r in range(G):
+        tot = tot + parts[r].astype(object)
+    for i, q in enumerate(primes):
+        tot[:, i, :] %= q
+    for r in range(G):
+        assert np.array_equal(dev[r].download(parts[0].shape).astype(object), tot), r
+    for c in comms:
+        c.destroy()
+
+
+@pytest.mark.parametrize("args,devices", [(("23", "7", "3", "2", "2"), "0,0"), (("257", "3", "4", "2", "5"), "0,0,0"), (("47", "5", "3", "1", "6"), "0")])
+def test_wave_evaluator_sharded_over_ranks_is_bit_identical(args, devices):
+    """fhesi::Regression::RegressBatchedMultiGpu (fhe-si_amd/host/fhesi_matrix.h: GroupExecutor, one host thread per rank, keys
+    broadcast from rank 0, every wave's groups sharded by shard_bounds, outputs exchanged) against the one-GPU waves and the plaintext
+    regression.  `0` = one rank through real RCCL; `0,0` / `0,0,0` = ranks sharing GPU 0 (loopback group)."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(HOST, "test_regression"), *args, "--batched-only", f"--devices={devices}"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "multi-rank ciphertexts bit-identical to one GPU: yes" in r.stdout
+    assert "batched: decrypts to the plaintext regression: yes" in r.stdout
