@@ -76,6 +76,7 @@ struct CtxOptions {
   int stagger = 0;          // lanes = 2: start the second lane after the first lane's digit transform
   long long batch_chunk = 0;      // ciphertexts per pipeline chunk (0 = derived from the ring)
   long long wave_operands = 0;    // distinct operands per pass of fhesi_ct_mul_sum_relin_dev (0 = about 4 GiB of rows)
+  int dot32_v2 = 1;         // 1: dot32_kernel2 (a wave owns both key rows of a limb), 0: dot32_kernel
   int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)
 };
 
@@ -163,7 +164,7 @@ int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, 
 void aux32_free(fhesi_ctx* ctx);
 const u32* aux32_primes(fhesi_ctx* ctx);          // the four primes (host array), nullptr on error
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
-int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
+int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */);
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* [npolys*nd][4][n] */);
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */);
 int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig /* [count*ncol][4][n] */, int ncol, i64 count, u32* d_out /* [count*2*rows][4][n] */);

@@ -16,7 +16,8 @@
 #include "fhesi_internal.h"
 
 struct Tw32 { u32 w, wp; };          // constant and floor(w 2^32 / p)
-struct Aux32Primes { u32 p[4]; u32 ninv[4], ninv_p[4]; u64 pinv64[4] /* floor((2^64 - 1) / p) */, r64[4] /* 2^64 mod p */; };
+struct Aux32Primes { u32 p[4]; u32 ninv[4], ninv_p[4]; u64 pinv64[4] /* floor((2^64 - 1) / p) */, r64[4] /* 2^64 mod p */, r48[4] /* 2^48 mod p */;
+                     u32 mont[4] /* -p^-1 mod 2^32 */, ninv_m[4], ninv_m_p[4] /* n^-1 2^32 mod p and its quotient: undoes the 2^-32 of dot32_kernel2's Montgomery step */; };
 
 struct fhesi_aux32 {
   Aux32Primes pr;
@@ -171,6 +172,8 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ r
 }
 
 // the mirror: input in the forward transform's output order (values below 2p), output natural order, scaled by 1/n, reduced
+// MONT: the input carries a factor 2^-32 (dot32_kernel2's Montgomery step); the final constant is n^-1 2^32 instead of n^-1
+template <bool MONT>
 __global__ void __launch_bounds__(A32_T, 2) ntt32_inv_kernel(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs) {
   __shared__ u32 lds[32 * A32_P];
   const u32 tid = threadIdx.x;
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_inv_kernel(u32* __restrict__ r
       a32_gs(r[k], r[k + h], tab[(1 << s) + (k >> (5 - s))], p);
     }
   }
-  const Tw32 tn{pr.ninv[a], pr.ninv_p[a]};
+  const Tw32 tn{MONT ? pr.ninv_m[a] : pr.ninv[a], MONT ? pr.ninv_m_p[a] : pr.ninv_p[a]};
 #pragma unroll
   for (int k = 0; k < 32; ++k) {
     u32 v = mul_lazy32(r[k], tn, p);
@@ -293,6 +296,10 @@ static int aux32_init(fhesi_ctx* ctx) {
     x->pr.ninv_p[a] = (u32)((ninv << 32) / p);
     x->pr.pinv64[a] = ~(u64)0 / p;
     x->pr.r64[a] = (u64)(((u128)1 << 64) % p);
+    x->pr.r48[a] = ((u64)1 << 48) % p;
+    { u32 inv = 1; for (int it = 0; it < 5; ++it) inv *= 2u - (u32)p * inv; x->pr.mont[a] = 0u - inv; }      // Newton: p^-1 mod 2^32
+    { const u64 nm = hm::mulmod(ninv, ((u64)1 << 32) % p, p); x->pr.ninv_m[a] = (u32)nm; x->pr.ninv_m_p[a] = (u32)((nm << 32) / p); }
+    if (p > ((u64)1 << 30) - ((u64)1 << 15) + 1) { delete x; FHESI_FAIL("aux32: prime above 2^30 - 2^15 + 1"); }     // the bound dot32_kernel2's accumulation relies on
   }
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
   HIP_TRY(hipMemcpy(x->d_fwd, hf.data(), hf.size() * sizeof(Tw32), hipMemcpyHostToDevice));
@@ -315,12 +322,18 @@ int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
   HIP_TRY(hipGetLastError());
   return 0;
 }
-int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0) {
+int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont) {
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
   ProfScope prof(ctx, PROF_NTT_INV, (double)(count * nslots));
-  PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel);
-  ntt32_inv_kernel<<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv);
+  if (mont) {
+    PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel<true>);
+    ntt32_inv_kernel<true><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel<false>);
+  ntt32_inv_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -472,6 +485,125 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ 
 #undef DL32
 }
 
+// Second form of the dot product: a wave owns one limb l and BOTH key rows r = 0, 1 of it, so every digit value fetched from the LDS
+// tile feeds two multiply-adds (the first form is bound by the LDS pipe: one 16-byte LDS read per 4 multiply-adds saturates it exactly
+// when the VALU is saturated).  Accumulation: the v_mad_u64_u32 chain runs straight into a 64-bit total; every 16 columns the bits
+// from 48 upwards move into a 32-bit counter.  Both operands are below p <= 2^30 - 2^15 + 1, so 16 products are at most
+// 2^64 - 2^50 + 2^34 and a total below 2^48 cannot wrap: no carry detection, 3 registers per output, 2-3 extra instructions per
+// output and 16 columns.
+template <int CT, int NW>
+__global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
+                                                         u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8) {
+  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
+  static_assert(CT % 4 == 0, "ciphertexts per tile in fours (16-byte LDS reads)");
+  const u32 lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32 b = blockIdx.x;
+  const u32 s_lo = b & 7; b >>= 3;
+  const u32 tile = b % (u32)ntiles; b /= (u32)ntiles;
+  const u32 s_hi = b % (u32)nsl8;
+  const int a = (int)(b / (u32)nsl8);
+  const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64;
+  const i64 ct0 = (i64)tile * CT;
+  const u32 p = pr.p[a], twop = 2 * p;
+#define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
+  const u32* dtile = dig + ((((i64)a << (A32_LOGN - 6)) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
+#if !(defined(DOT32_ABLATE) && (DOT32_ABLATE & 4))   // ablation: no tile load
+  for (int k = w; k < ncol; k += NW) {
+    u32 v[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) v[c] = ct0 + c < count ? __builtin_nontemporal_load(&dtile[((i64)c * ncol + k) << 6]) : 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      u32 x = v[c];
+      x = x >= twop ? x - twop : x;
+      x = x >= p ? x - p : x;
+      dl32[DL32(k, c)] = x;
+    }
+  }
+#endif
+  __syncthreads();
+  const u64 r48 = pr.r48[a];
+  const u32 mont = pr.mont[a];
+  for (int l = w; l < NLB; l += NW) {
+    const u32* kp0 = k32 + ((((((i64)a * NLB + l) * (A32_N >> 6) + slice) * 2) * ncol) << 6) + lane;      // row r = 0; row 1 follows after ncol slices
+    const u32* kp1 = kp0 + ((i64)ncol << 6);
+    u64 tot[2][CT];
+    u32 th[2][CT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) { tot[r][c] = 0; th[r][c] = 0; }
+    auto fold = [&]() {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { th[r][c] += (u32)(tot[r][c] >> 48); tot[r][c] &= 0x0000ffffffffffffull; }
+    };
+    // Key words are fetched one 4-column chunk ahead into two register sets used alternately (no copies: with a copy at the end of
+    // the loop body the compiler waits for the fetch at the START of the body and the L2 latency is exposed once per chunk).
+    constexpr int CH = 4;
+    const int nfull = ncol & ~(CH - 1), n2 = ncol & ~(2 * CH - 1);
+    u32 xa[2][CH], xb[2][CH];
+    auto loadc = [&](u32 (&x)[2][CH], int k0) {
+#if defined(DOT32_ABLATE) && (DOT32_ABLATE & 1)      // ablation: no key loads
+#pragma unroll
+      for (int u = 0; u < CH; ++u) { x[0][u] = (u32)(k0 + u) * 2654435761u + lane; x[1][u] = x[0][u] ^ 0x9e3779b9u; }
+#else
+#pragma unroll
+      for (int u = 0; u < CH; ++u) { x[0][u] = kp0[(k0 + u) << 6]; x[1][u] = kp1[(k0 + u) << 6]; }
+#endif
+    };
+    auto macc = [&](const u32 (&x)[2][CH], int k0) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        u32 d[CT];
+#if defined(DOT32_ABLATE) && (DOT32_ABLATE & 2)      // ablation: no LDS reads
+#pragma unroll
+        for (int c = 0; c < CT; ++c) d[c] = x[0][u] + (u32)c * 40503u;
+#else
+#pragma unroll
+        for (int c = 0; c < CT; ++c) d[c] = dl32[DL32(k0 + u, c)];
+#endif
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { tot[0][c] += (u64)x[0][u] * d[c]; tot[1][c] += (u64)x[1][u] * d[c]; }
+      }
+    };
+    if (nfull) loadc(xa, 0);
+    int kb = 0;
+    for (; kb < n2; kb += 2 * CH) {
+      loadc(xb, kb + CH);
+      macc(xa, kb);
+      if (kb + 2 * CH < nfull) loadc(xa, kb + 2 * CH);
+      macc(xb, kb + CH);
+      if (kb & (2 * CH)) fold();                     // 16 columns since the last fold
+    }
+    if (nfull & CH) { macc(xa, kb); }
+    if ((nfull & (3 * CH)) != 0) fold();             // up to 12 columns pending, up to 3 more follow: fold here so that the tail starts below 2^48
+    for (int k = nfull; k < ncol; ++k) {             // at most 3 columns
+      const u32 x0 = kp0[k << 6], x1 = kp1[k << 6];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) { const u32 d = dl32[DL32(k, c)]; tot[0][c] += (u64)x0 * d; tot[1][c] += (u64)x1 * d; }
+    }
+    fold();                                          // at most 15 columns since the last one; leaves every total below 2^48
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (ct0 + c < count) {
+          // (th 2^48 + tot) 2^-32 mod p by one Montgomery step: v = tot + th (2^48 mod p) < 2^54, m = v (-p^-1) mod 2^32,
+          // (v + m p) / 2^32 < p + 2^22.  The factor 2^-32 is undone by the inverse transform's final constant (ntt32_inv_kernel, mont).
+          const u64 v = tot[r][c] + (u64)th[r][c] * r48;
+          const u32 mq = (u32)v * mont;
+          u32 o = (u32)((v + (u64)mq * p) >> 32);
+          o = o >= p ? o - p : o;
+          (out + ((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) * A32_N + soff)[lane] = o;
+        }
+      }
+  }
+#undef DL32
+}
+
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp) {
   FHESI_TRY(aux32_init(ctx));
   const int ncol = k->ncomp * k->ndigits;
@@ -497,7 +629,7 @@ int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol,
   if (!count) return 0;
   if (ncol > 255) FHESI_FAIL("dot32: %d columns", ncol);
   ProfScope prof(ctx, PROF_DOT, (double)count);
-  constexpr int CT = 8, NW = 16;
+  constexpr int CT = 8, NW = 16, NW2 = 16;
   const size_t shmem = (size_t)ncol * CT * 64 * 4;
   if (shmem > 160 * 1024) FHESI_FAIL("dot32: %d columns do not fit the LDS tile", ncol);
   static unsigned long long attr_done = 0;
@@ -507,6 +639,17 @@ int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol,
   }
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = A32_N / 64 / 8;
   const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
+  if (ctx->opt.dot32_v2) {
+    static unsigned long long attr2_done = 0;
+    if (!(attr2_done >> ctx->device & 1)) {
+      HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr2_done |= 1ull << ctx->device;
+    }
+    PROF_KERNEL(ctx, PROF_DOT, dot32_kernel2<CT, NW2>);
+    dot32_kernel2<CT, NW2><<<(unsigned)blocks, NW2 * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   PROF_KERNEL(ctx, PROF_DOT, dot32_kernel<CT, NW>);
   dot32_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
   HIP_TRY(hipGetLastError());
@@ -536,7 +679,7 @@ extern "C" int fhesi_selftest_aux32(fhesi_ctx* c) {
       hipMemcpy(da, ha.data(), A32_N * 4, hipMemcpyHostToDevice); hipMemcpy(db, hb.data(), A32_N * 4, hipMemcpyHostToDevice);
       if (launch_ntt32_fwd(c, da, 1, 1, a) || launch_ntt32_fwd(c, db, 1, 1, a)) { rc = 1; break; }
       aux32_pointwise_kernel<<<A32_N / 256, 256, 0, c->stream>>>(da, db, p);
-      if (launch_ntt32_inv(c, da, 1, 1, a)) { rc = 1; break; }
+      if (launch_ntt32_inv(c, da, 1, 1, a, false)) { rc = 1; break; }
       hipStreamSynchronize(c->stream);
       hipMemcpy(hr.data(), da, A32_N * 4, hipMemcpyDeviceToHost);
       const int e = pairs[t][0] + pairs[t][1];
@@ -549,7 +692,7 @@ extern "C" int fhesi_selftest_aux32(fhesi_ctx* c) {
     if (!rc) {
       for (int j = 0; j < A32_N; ++j) ha[j] = (u32)((1234567u * (u32)j + 89u) % p);
       hipMemcpy(da, ha.data(), A32_N * 4, hipMemcpyHostToDevice);
-      if (launch_ntt32_fwd(c, da, 1, 1, a) || launch_ntt32_inv(c, da, 1, 1, a)) rc = 1;
+      if (launch_ntt32_fwd(c, da, 1, 1, a) || launch_ntt32_inv(c, da, 1, 1, a, false)) rc = 1;
       hipStreamSynchronize(c->stream);
       hipMemcpy(hr.data(), da, A32_N * 4, hipMemcpyDeviceToHost);
       for (int j = 0; j < A32_N && !rc; ++j) if (hr[j] != ha[j]) { fhesi_set_error("aux32 self-test: prime %d, round trip differs at %d", a, j); rc = 1; }

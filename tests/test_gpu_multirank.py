@@ -62,7 +62,6 @@ def test_key_broadcast_exchange_and_allreduce(devices):
         assert np.array_equal(ctxs[r].ct_mul_relin(ksks[r], logQ, p, a, b)[0], want), r
     # exchange: rank r owns a slice of a buffer of 7 "ciphertexts"
     words, total = 2 * n * nl, 7
-    bounds = [F.shard.shard_bounds(total, r, G) for r in range(G)] if hasattr(F, "shard") else None
     from fhe_si_amd import shard
     bounds = [shard.shard_bounds(total, r, G) for r in range(G)]
     full = rng.integers(0, 1 << 63, size=(total, words), dtype=np.uint64)

@@ -18,7 +18,7 @@ run stress --workload stress --steps 3 --warmup 1 --cpu-sample 0
 run regression --workload regression --steps 3 --warmup 1
 run ntt --workload ntt --steps 10 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do        # one counter per pass (combining them has hung the profiler on this pool)
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 > /dev/null 2> "$O/pmc_$c.log"
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --batch 64 > /dev/null 2> "$O/pmc_$c.log"
   f=$(find "$O/pmc_$c" -name '*counter_collection.csv' | head -1)
   for kern in "dot32_kernel<8, 16>" "ntt32_fwd_kernel<true>" "dot_aux_kernel<4, 16, 1>" "ntt_fwd_tile<14, true, 0, false>"; do
     python3 "$R/tools/pmc_summary.py" "$f" "$kern" | tee -a "$O/pmc_$c.txt"

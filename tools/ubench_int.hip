@@ -59,6 +59,34 @@ template<int OP> __global__ void __launch_bounds__(256) k_raw(u32* out, u32 seed
 #define R(x) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(x) : "v"(c));
       R(a0)R(a1)R(a2)R(a3)R(a4)R(a5)R(a6)R(a7)
 #undef R
+    } else if (OP==12) { // v_mul_f64
+#define R(x) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(dc));
+      R(d0)R(d1)R(d2)R(d3)R(d4)R(d5)R(d6)R(d7)
+#undef R
+    } else if (OP==13) { // v_dot4_u32_u8: four 8x8-bit products + accumulate per lane
+#define R(x) asm volatile("v_dot4_u32_u8 %0, %0, %1, %0" : "+v"(x) : "v"(c));
+      R(a0)R(a1)R(a2)R(a3)R(a4)R(a5)R(a6)R(a7)
+#undef R
+    } else if (OP==14) { // v_mad_u64_u32 with the product's operands independent of the accumulator (dot-product shape)
+#define R(x, y) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x) : "v"(c), "v"(y) : "vcc");
+      R(b0,a1)R(b1,a2)R(b2,a3)R(b3,a4)R(b4,a5)R(b5,a6)R(b6,a7)R(b7,a0)
+#undef R
+    } else if (OP==15) { // v_pk_mul_lo_u16: two 16x16 -> low 16 products per lane
+#define R(x) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(c));
+      R(a0)R(a1)R(a2)R(a3)R(a4)R(a5)R(a6)R(a7)
+#undef R
+    } else if (OP==16) { // v_fma_f32
+#define R(x) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(c));
+      R(a0)R(a1)R(a2)R(a3)R(a4)R(a5)R(a6)R(a7)
+#undef R
+    } else if (OP==17) { // v_cvt_f64_u32 + v_cvt_u32_f64 pair
+#define R(x, y) asm volatile("v_cvt_f64_u32 %1, %0\n v_cvt_u32_f64 %0, %1" : "+v"(x), "+v"(y));
+      R(a0,d0)R(a1,d1)R(a2,d2)R(a3,d3)R(a4,d4)R(a5,d5)R(a6,d6)R(a7,d7)
+#undef R
+    } else if (OP==18) { // v_min_u32 (conditional subtract idiom: sub + min)
+#define R(x) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(c));
+      R(a0)R(a1)R(a2)R(a3)R(a4)R(a5)R(a6)R(a7)
+#undef R
     } else if (OP==11) { // v_cndmask + v_cmp (cmp_u64)
 #define R(x) asm volatile("v_cmp_ge_u64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(x), "+v"(b7), "+v"(a7), "+v"(c) : : "vcc");
       R(b0)R(b1)R(b2)R(b3)R(b4)R(b5)R(b6)R(b0)
@@ -121,9 +149,9 @@ int main() {
   u32* d; CK(hipMalloc(&d, 1<<20)); u64* d64=(u64*)d;
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   int blocks = p.multiProcessorCount*8; // 8 blocks of 256 = 32 waves/CU
-  const char* names[]={"v_mul_lo_u32","v_mul_hi_u32","v_mad_u64_u32","v_mul_u32_u24","v_add_u32","v_lshl_add_u64","v_fma_f64","add_co+addc(2 instr)","v_mul_hi_u32_u24","v_mad_u32_u24","v_add3_u32","cmp_ge_u64+cndmask(2 instr)"};
+  const char* names[]={"v_mul_lo_u32","v_mul_hi_u32","v_mad_u64_u32","v_mul_u32_u24","v_add_u32","v_lshl_add_u64","v_fma_f64","add_co+addc(2 instr)","v_mul_hi_u32_u24","v_mad_u32_u24","v_add3_u32","cmp_ge_u64+cndmask(2 instr)","v_mul_f64","v_dot4_u32_u8","v_mad_u64_u32 (indep. operands)","v_pk_mul_lo_u16","v_fma_f32","cvt_f64_u32+cvt_u32_f64(2 instr)","v_min_u32"};
 #define RUN(OP) { k_raw<OP><<<blocks,256>>>(d,1); CK(hipDeviceSynchronize()); CK(hipEventRecord(e0)); for(int r=0;r<5;r++) k_raw<OP><<<blocks,256>>>(d,r+2); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); double ops=5.0*blocks*256.0*ITER*8; printf("%-28s %8.2f Glane-instr/s  (%.3f of 78.6T full rate)\n", names[OP], ops/ms/1e6, ops/ms/1e6/78643.2*1.0); }
-  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11)
+  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18)
   u64 q = (1ull<<60) - 33*65536ull + 1; // shape only
   const char* bn[]={"harvey_shoup","shoup_nocorr","pmers_corr","pmers_nocorr"};
 #define RUNB(V) { k_bfly<V><<<blocks,256>>>(d64,q,12345,6789,(u32)(33*65536-1),1); CK(hipDeviceSynchronize()); CK(hipEventRecord(e0)); for(int r=0;r<5;r++) k_bfly<V><<<blocks,256>>>(d64,q,12345+r,6789,(u32)(33*65536-1),r); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); double ops=5.0*blocks*256.0*(ITER/4)*8; printf("%-16s %8.2f Gbutterfly/s -> n=2^14 rows/s = %.2f M (HBM 8TB/s = 30.5M)\n", bn[V], ops/ms/1e6, ops/ms/1e6*1e9/114688/1e6); }
