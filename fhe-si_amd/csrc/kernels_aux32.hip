@@ -171,6 +171,142 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ r
   }
 }
 
+// ---- third form of the forward transform: the same butterflies and the same output order, laid out for THREE workgroups per CU.
+// The row passes through an LDS buffer of HALF its size (16 sub-problem rows, 37.9 KB):
+//   exchange 1 (across the workgroup) in two passes -- registers 0..15 of every thread, read by the threads of sub-problems 0..15
+//   (waves 0..3), then registers 16..31 through the same rows for waves 4..7;
+//   exchange 2 stays inside a wave (the 16 threads of a sub-problem only trade among themselves): every wave owns two rows and
+//   moves its four sub-problems through them two at a time, with wave-level ordering only (LDS operations of a wave execute in order).
+// Twiddles are fetched stage by stage instead of far ahead, which keeps the kernel below 80 registers (6 waves per SIMD).
+static constexpr int A32_HR = 16;                   // rows of the half buffer
+template <bool DIGITS>
+__global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs,
+                                                              Dig32Src ds) {
+  __shared__ u32 lds[A32_HR * A32_P];
+  const u32 tid = threadIdx.x;
+  i64 c = blockIdx.x % count;
+  int slot = (int)(blockIdx.x / count);
+  if (DIGITS) {
+    const u32 bid = blockIdx.x;
+    slot = (int)((bid >> 3) & 3);
+    c = (i64)(bid >> 5) * 8 + (bid & 7);
+    if (c >= count) return;
+  }
+  const int a = a0 + slot;
+  const u32 p = pr.p[a];
+  const Tw32* __restrict__ tab = tabs + (i64)a * A32_N;
+  u32* __restrict__ g = rows + (c * nslots + slot) * A32_N;
+  u32 r[32];
+  if (DIGITS) {
+    const u32 d = (u32)(c % ds.nd);
+    const i64 poly = c / ds.nd;
+    const u32 bit = d * (u32)ds.digit_bits, g0 = bit >> 5, sh = bit & 31;
+    const u32 mask = (1u << ds.digit_bits) - 1;
+    const u32* __restrict__ p32 = reinterpret_cast<const u32*>(ds.parts);
+    const u32* __restrict__ w0 = p32 + (((poly * ds.nl + (g0 >> 1)) << A32_LOGN) << 1) + (g0 & 1);
+    const bool two = (sh + ds.digit_bits > 32) && (int)((g0 + 1) >> 1) < ds.nl;
+    if (two) {
+      const u32 g1 = g0 + 1;
+      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) << A32_LOGN) << 1) + (g1 & 1);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) { const u32 e = 2 * (k * A32_T + tid); r[k] = ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) r[k] = (w0[2 * (k * A32_T + tid)] >> sh) & mask;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r[k] = g[k * A32_T + tid];
+  }
+  // phase A: element e = k * 512 + tid; distances 16, 8, 4, 2, 1 in k; twiddles depend on the register index only
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int h = 16 >> s;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int k = a32_bfly_k(b, h);
+      a32_ct(r[k], r[k + h], tab[(1 << s) + (k >> (5 - s))], p);
+    }
+  }
+  const u32 kq = tid >> 4, lo = tid & 15;          // sub-problem and position inside a group of 16 (after the first exchange)
+  const bool upper = kq >= A32_HR;                 // waves 4..7
+  // exchange 1, first pass: registers 0..15 -> rows 0..15, read by sub-problems 0..15
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[k * A32_P + a32_f(tid)] = r[k];
+  __syncthreads();
+  u32 t[16];                                       // the upper half keeps its registers 16..31 aside while the lower half reads
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[k] = r[16 + k];
+  if (!upper) {
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) r[k2] = lds[kq * A32_P + a32_f(k2 * 16 + lo)];
+  }
+  __syncthreads();
+  // second pass: registers 16..31 (in t) -> the same rows, read by sub-problems 16..31
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[k * A32_P + a32_f(tid)] = t[k];
+  __syncthreads();
+  if (upper) {
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) r[k2] = lds[(kq - A32_HR) * A32_P + a32_f(k2 * 16 + lo)];
+  }
+  // phase B: sub-problem kq (512 elements t = k2 * 16 + lo); distances 16 .. 1 in k2; the 2^u twiddles of stage u fetched at the stage
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int h = 16 >> u;
+    Tw32 tb[16];
+#pragma unroll
+    for (int i = 0; i < (1 << u); ++i) tb[i] = tab[(32 << u) + (kq << u) + i];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int k2 = a32_bfly_k(b, h);
+      a32_ct(r[k2], r[k2 + h], tb[k2 >> (5 - u)], p);
+    }
+  }
+  __syncthreads();                                 // every read of exchange 1 is done: the rows change owner
+  // exchange 2 inside the wave: rows 2w, 2w + 1; sub-problems (kq & 3) = 0, 1 first, then 2, 3
+  const u32 wv = tid >> 6, sub = kq & 3;
+  u32* __restrict__ row = lds + (2 * wv + (sub & 1)) * A32_P;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    if ((int)(sub >> 1) == hh) {
+#pragma unroll
+      for (int k2 = 0; k2 < 32; ++k2) row[a32_f(k2 * 16 + lo)] = r[k2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if ((int)(sub >> 1) == hh) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) r[i] = row[lo * 36 + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // phase C: this thread holds the groups k2 = 2 lo, 2 lo + 1 (32 consecutive elements); distances 8 .. 1 inside a group
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int h = 8 >> v;
+    Tw32 tc[2][8];
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int i = 0; i < (1 << v); ++i) tc[gq][i] = tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i];
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int x = a32_bfly_k(b, h);
+        a32_ct(r[gq * 16 + x], r[gq * 16 + x + h], tc[gq][x >> (4 - v)], p);
+      }
+    }
+  }
+  u32* __restrict__ o = DIGITS ? rows + ((((i64)a << (A32_LOGN - 6)) + (kq * 8 + (lo >> 1))) * count + c) * 64 + (lo & 1) * 32 : g + kq * 512 + lo * 32;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    u32 v = r[i];
+    if (!DIGITS) { const u32 twop = 2 * p; v = v >= twop ? v - twop : v; v = v >= p ? v - p : v; }
+    o[i] = v;
+  }
+}
+
 // the mirror: input in the forward transform's output order (values below 2p), output natural order, scaled by 1/n, reduced
 // MONT: the input carries a factor 2^-32 (dot32_kernel2's Montgomery step); the final constant is n^-1 2^32 instead of n^-1
 template <bool MONT>
@@ -317,6 +453,12 @@ void aux32_free(fhesi_ctx* ctx) {
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0) {
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
+  if (ctx->opt.ntt32_v3) {
+    PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false>);
+    ntt32_fwd_kernel3<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{});
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel<false>);
   ntt32_fwd_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{});
   HIP_TRY(hipGetLastError());
@@ -344,6 +486,12 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * 4));
   ProfScope main_prof(ctx, PROF_NTT_FWD_DIGITS_MAIN, (double)(npolys * nd * 4));
   const i64 units = npolys * nd;
+  if (ctx->opt.ntt32_v3) {
+    PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true>);
+    ntt32_fwd_kernel3<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd});
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel<true>);
   ntt32_fwd_kernel<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd});
   HIP_TRY(hipGetLastError());
@@ -625,35 +773,31 @@ int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, in
 }
 
 // d_dig: tiled [4][n/64][count*ncol][64] u32; d_out: [count*2*NLB][4][n] u32
-int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
-  if (!count) return 0;
-  if (ncol > 255) FHESI_FAIL("dot32: %d columns", ncol);
-  ProfScope prof(ctx, PROF_DOT, (double)count);
-  constexpr int CT = 8, NW = 16, NW2 = 16;
+template <int CT, int NW, bool V2>
+static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)ncol * CT * 64 * 4;
-  if (shmem > 160 * 1024) FHESI_FAIL("dot32: %d columns do not fit the LDS tile", ncol);
+  const void* fn = V2 ? (const void*)dot32_kernel2<CT, NW> : (const void*)dot32_kernel<CT, NW>;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done |= 1ull << ctx->device;
   }
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = A32_N / 64 / 8;
   const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
-  if (ctx->opt.dot32_v2) {
-    static unsigned long long attr2_done = 0;
-    if (!(attr2_done >> ctx->device & 1)) {
-      HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr2_done |= 1ull << ctx->device;
-    }
-    PROF_KERNEL(ctx, PROF_DOT, dot32_kernel2<CT, NW2>);
-    dot32_kernel2<CT, NW2><<<(unsigned)blocks, NW2 * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  PROF_KERNEL(ctx, PROF_DOT, dot32_kernel<CT, NW>);
-  dot32_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
+  if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
+  prof_kernel(ctx, PROF_DOT, fn);
+  if (V2) dot32_kernel2<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
+  else dot32_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
+  if (!count) return 0;
+  ProfScope prof(ctx, PROF_DOT, (double)count);
+  // ciphertexts per LDS tile: 8 while ncol * 8 digit slices of 256 bytes fit the CU's 160 KiB (ncol <= 80), else 4 (ncol <= 160)
+  if ((size_t)ncol * 8 * 256 <= 160 * 1024) return ctx->opt.dot32_v2 ? launch_dot32_t<8, 16, true>(ctx, k, d_dig, ncol, count, d_out) : launch_dot32_t<8, 16, false>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 4 * 256 <= 160 * 1024) return ctx->opt.dot32_v2 ? launch_dot32_t<4, 16, true>(ctx, k, d_dig, ncol, count, d_out) : launch_dot32_t<4, 16, false>(ctx, k, d_dig, ncol, count, d_out);
+  FHESI_FAIL("dot32: %d columns do not fit the LDS tile", ncol);
 }
 
 // Self-test (tests/test_gpu_ntt.py): the transform pair is a ring isomorphism of Z_p[X]/(X^n + 1) -- it is linear by construction, so

@@ -696,6 +696,106 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
   crt_store_fixed<W, W, LQ>(y, 2, out, poly, n, j, nl_out);
 }
 
+// The same recombination for ANY chain shape: limb count W, logQ, limb width B and limb count NLB are run-time values, the W + 1 limbs of
+// x live in LDS (limb-major, one column per thread: run-time limb indices cost nothing there).  The compile-time instantiations above
+// serve the shapes the benchmarks run; this one makes limb mode (and the 30-bit auxiliary primes) available to every chain.
+template <int MAXW, bool A32>
+__global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __restrict__ o, i64 n, int W, int LQ, int B, int NLB, u64 q0, u64 q1, u64 q0inv, u64 q0inv_sh,
+                                                                   u64 half_hi, u64 half_lo, u64 a_hi, u64 a_lo, const u64* __restrict__ consts /* D[W+1], pinv lo, hi */,
+                                                                   const u64* __restrict__ Pfull, const u64* __restrict__ halfP, u64* __restrict__ out, int nl_out, Garner32 gc) {
+  __shared__ u64 xs[(MAXW + 1) * 128];
+#define X(i) xs[(i) * 128 + threadIdx.x]
+  const i64 poly = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  for (int i = 0; i <= W; ++i) X(i) = consts[i];
+  const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
+  const u64* base = o + poly * NLB * 2 * n + j;
+  const u32* base32 = reinterpret_cast<const u32*>(o) + poly * NLB * 4 * n + j;
+  for (int l = 0; l < NLB; ++l) {
+    u128 V;
+    if (A32) {
+      const u32 v0 = base32[(i64)(l * 4 + 0) * n], v1 = base32[(i64)(l * 4 + 1) * n], v2 = base32[(i64)(l * 4 + 2) * n], v3 = base32[(i64)(l * 4 + 3) * n];
+      const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
+      const u32 x1 = v0;
+      const u32 x2 = g32_mul(g32_sub(v1, x1, p1), gc.c[0], gc.cp[0], p1);
+      const u32 x3 = g32_mul(g32_sub(g32_mul(g32_sub(v2, x1, p2), gc.c[1], gc.cp[1], p2), x2, p2), gc.c[2], gc.cp[2], p2);
+      const u32 x4 = g32_mul(g32_sub(g32_mul(g32_sub(g32_mul(g32_sub(v3, x1, p3), gc.c[3], gc.cp[3], p3), x2, p3), gc.c[4], gc.cp[4], p3), x3, p3),
+                             gc.c[5], gc.cp[5], p3);
+      V = (u128)((u64)x3 + (u64)p2 * x4) * ((u64)p0 * p1) + ((u64)x1 + (u64)p0 * x2);
+    } else {
+      const u64 v0 = base[(i64)(l * 2 + 0) * n], v1 = base[(i64)(l * 2 + 1) * n];
+      const u64 v0r = v0 >= q1 ? v0 - q1 : v0;
+      const u64 t = d_shoup(d_submod(v1, v0r, q1), q0inv, q0inv_sh, q1);
+      V = (u128)q0 * t + v0;
+    }
+    if (V > half) V -= A;
+    V += (u128)1 << 119;
+    const int s = B * l, wd = s >> 6, bt = s & 63;
+    const u64 lo = (u64)V, hi = (u64)(V >> 64);
+    const u64 p0 = lo << bt, p1 = bt ? ((lo >> ((64 - bt) & 63)) | (hi << bt)) : hi, p2 = bt ? (hi >> ((64 - bt) & 63)) : 0;
+    u64 carry = 0;
+    for (int i = wd; i <= W; ++i) {
+      const u64 add = i == wd ? p0 : (i == wd + 1 ? p1 : (i == wd + 2 ? p2 : 0));
+      if (i > wd + 2 && !carry) break;
+      const u128 sum = (u128)X(i) + add + carry;
+      X(i) = (u64)sum;
+      carry = (u64)(sum >> 64);
+    }
+  }
+  const u64 t0 = X(W - 2), t1 = X(W - 1), pr0 = consts[W + 1], pr1 = consts[W + 2];
+  u128 mid = (u128)t1 * pr0 + (u64)(((u128)t0 * pr0) >> 64);
+  const u128 add = (u128)t0 * pr1;
+  const u128 mid2 = mid + add;
+  u128 qh = (u128)t1 * pr1 + (mid2 >> 64) + ((mid2 < add) ? ((u128)1 << 64) : 0);
+  const u64 qhat = (u64)qh;
+  {
+    u64 carry = 0, borrow = 0;
+    for (int i = 0; i < W; ++i) {
+      const u128 t = (u128)qhat * Pfull[i] + carry;
+      carry = (u64)(t >> 64);
+      const u64 xi = X(i), tl = (u64)t, d = xi - tl, b1 = xi < tl, d2 = d - borrow, b2 = d < borrow;
+      X(i) = d2;
+      borrow = b1 | b2;
+    }
+  }
+  auto ge = [&](const u64* __restrict__ c, bool strict) -> bool {      // x[0..W) >= c (or > c)
+    for (int i = W - 1; i >= 0; --i) { const u64 h = c[i], xi = X(i); if (xi != h) return xi > h; }
+    return !strict;
+  };
+  auto subP = [&]() {
+    u64 borrow = 0;
+    for (int i = 0; i < W; ++i) { const u64 pp = Pfull[i], xi = X(i), d = xi - pp, b1 = xi < pp, d2 = d - borrow, b2 = d < borrow; X(i) = d2; borrow = b1 | b2; }
+  };
+  if (ge(Pfull, false)) subP();
+  if (ge(Pfull, false)) subP();
+  if (ge(halfP, true)) subP();                                  // centre: x > (P-1)/2  ->  x - P   (DoubleCRT.cpp:375-376)
+  // mode-2 store: the centred residue modulo 2^logQ, two's complement, coefficient-major
+  const u64 sf = (X(W - 1) >> 63) ? ~0ull : 0ull;
+  const int sw = (LQ - 1) >> 6, sb = (LQ - 1) & 63;
+  const u64 hbit = ((sw < W ? X(sw) : sf) >> sb) & 1;
+  u64* op = out + (poly * n + j) * nl_out;
+  for (int i = 0; i < nl_out; ++i) {
+    u64 val = i < W ? X(i) : sf;
+    const int bits_left = LQ - 64 * i;
+    if (bits_left <= 0) val = hbit ? ~0ull : 0ull;
+    else if (bits_left < 64) { const u64 mask = (1ull << (bits_left & 63)) - 1; val = hbit ? (val | ~mask) : (val & mask); }
+    op[i] = val;
+  }
+#undef X
+}
+
+static int garner32_consts(fhesi_ctx* ctx, Garner32* gc) {
+  const u32* p = aux32_primes(ctx);
+  if (!p) return 1;
+  for (int i = 0; i < 4; ++i) gc->p[i] = p[i];
+  const int pairs[6][2] = {{0, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {2, 3}};
+  for (int e = 0; e < 6; ++e) {
+    const u64 pj = p[pairs[e][1]], c = hm::invmod(p[pairs[e][0]] % pj, pj);
+    gc->c[e] = (u32)c; gc->cp[e] = (u32)((c << 32) / pj);
+  }
+  return 0;
+}
 template <int W, int LQ, int B, int NLB, bool A32>
 static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
   const u64 q0 = ctx->q[0], q1 = ctx->q[1];
@@ -703,15 +803,8 @@ static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi
   u128 A = (u128)q0 * q1;
   Garner32 gc{};
   if (A32) {
-    const u32* p = aux32_primes(ctx);
-    if (!p) return 1;
-    for (int i = 0; i < 4; ++i) gc.p[i] = p[i];
-    const int pairs[6][2] = {{0, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {2, 3}};
-    for (int e = 0; e < 6; ++e) {
-      const u64 pj = p[pairs[e][1]], c = hm::invmod(p[pairs[e][0]] % pj, pj);
-      gc.c[e] = (u32)c; gc.cp[e] = (u32)((c << 32) / pj);
-    }
-    A = (u128)((u64)p[0] * p[1]) * ((u64)p[2] * p[3]);
+    if (garner32_consts(ctx, &gc)) return 1;
+    A = (u128)((u64)gc.p[0] * gc.p[1]) * ((u64)gc.p[2] * gc.p[3]);
   }
   const u128 half = (A - 1) / 2;
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
@@ -723,10 +816,30 @@ static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi
 int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
   if (!npolys) return 0;
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
-  if (k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 73 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 73, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
+  // compile-time instantiations for the shapes the benchmarks run (the plan of ks_limb_plan at the metric and stress chains) ...
+  if (k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
   if (!k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, false>(ctx, t, k, d_o, npolys, d_out, nl_out);
   if (!k->aux32 && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30) return launch_ks_recombine_t<34, 1024, 72, 30, false>(ctx, t, k, d_o, npolys, d_out, nl_out);
-  FHESI_FAIL("key switch, limb mode: no recombination kernel for W=%d logQ=%d B=%d rows=%d", t->W, k->aux_logQ, k->aux_limb_bits, k->aux_rows);
+  // ... and the run-time form for every other chain
+  const u64 q0 = ctx->q[0], q1 = ctx->q[1];
+  const u64 inv = hm::invmod(q0 % q1, q1);
+  u128 A = (u128)q0 * q1;
+  Garner32 gc{};
+  if (k->aux32) {
+    if (garner32_consts(ctx, &gc)) return 1;
+    A = (u128)((u64)gc.p[0] * gc.p[1]) * ((u64)gc.p[2] * gc.p[3]);
+  }
+  const u128 half = (A - 1) / 2;
+  const int W = t->W;
+  dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
+#define KS_GEN(MAXW, A32) ks_recombine_generic_kernel<MAXW, A32><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, W, k->aux_logQ, k->aux_limb_bits, k->aux_rows, q0, q1, inv, hm::shoup(inv, q1), \
+      (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, k->d_limb_consts, t->d_P + (size_t)t->nidx * t->W, t->d_halfP, d_out, nl_out, gc)
+  if (W <= 20) { if (k->aux32) KS_GEN(20, true); else KS_GEN(20, false); }
+  else if (W <= 44) { if (k->aux32) KS_GEN(44, true); else KS_GEN(44, false); }
+  else FHESI_FAIL("key switch, limb mode: chain product of %d limbs exceeds the supported 44", W);
+#undef KS_GEN
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int launch_crt(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, int nslots_layout, const int* d_slot_of, i64 npolys, int mode, int positive,

@@ -266,31 +266,33 @@ bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits) {
   return lg + 2.0 < std::log2((double)q0) + std::log2((double)q1);
 }
 
-// Limb mode is used where a recombination kernel is compiled (launch_ks_recombine): the metric chain shape (17-limb product,
-// logQ = 512: 15 limbs of 74 bits instead of 18 residues) and the stress shape (33-limb product, logQ = 1024: 30 limbs of 72 bits
-// instead of 35 residues).  Conditions: every limb product sum stays below q_0 q_1 / 2, the limbs cover P, and |S| < 2^m P.
+// Limb mode for any chain: the key polynomial's integer coefficient in [0, P) is cut into NLB limbs of B bits, with B the largest
+// width for which every limb product sum stays exact in the auxiliary modulus A (the product of the two largest chain primes, or of
+// the four 30-bit primes of kernels_aux32.hip at n = 2^14):  |V_l| <= ncol * n * 2^digit_bits * 2^B < A / 2.  The recombination
+// (ks_recombine_kernel) shifts V_l + 2^119 by B l bits as a (lo, hi) pair spread over three limbs, which needs 64 < B <= 119 - ... and
+// the whole sum inside W + 1 limbs; |S| < 2^(mbits-1) P with the quotient estimate below 2^63.  Anything else stays in residue mode.
 bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan, const u32* p32) {
-  if (ctx->opt.ks_residues) return false;               // A/B switch: residue mode
+  if (ctx->opt.ks_residues) return false;                       // A/B switch: residue mode
+  if (t->nidx != ctx->L || t->W < 3) return false;
   KsLimbPlan p;
   u128 A = (u128)ctx->q[0] * ctx->q[1];
-  // n = 2^14 at the metric chain shape: the four 30-bit primes of kernels_aux32.hip carry the limb products (FHESI_KS_AUX60=1: A/B switch)
-  if (p32 && ctx->logn == 14 && t->W == 18 && logQ == 512 && !ctx->opt.ks_aux60) {
-    p.W = 18; p.LQ = 512; p.B = 73; p.NLB = 15; p.a32 = true;
+  if (p32 && ctx->logn == 14 && !ctx->opt.ks_aux60) {          // option ks_aux60: two 60-bit primes even where the four 30-bit primes apply
+    p.a32 = true;
     A = (u128)((u64)p32[0] * p32[1]) * ((u64)p32[2] * p32[3]);
   }
-  else if (t->W == 18 && logQ == 512) { p.W = 18; p.LQ = 512; p.B = 74; p.NLB = 15; }
-  else if (t->W == 34 && logQ == 1024) { p.W = 34; p.LQ = 1024; p.B = 72; p.NLB = 30; }
-  else return false;
-  if (t->nidx != ctx->L) return false;
+  if (A >> 119 > 1) return false;                               // the +2^119 offset needs the auxiliary modulus below 2^120
+  const u128 terms = (u128)ncol * (u128)ctx->phim << digit_bits;      // ncol * n * 2^digit_bits
+  if (terms >> 50) return false;
+  int B = 0;
+  while (B < 100 && (((A / 2) >> (B + 1)) > terms)) ++B;        // the largest B with terms * 2^B < A / 2
+  if (B <= 64) return false;                                    // (the limb-scatter kernels cut limbs of 65..100 bits)
   std::vector<u64> P{1};
   for (int i = 0; i < ctx->L; ++i) P = hm::bn_mul_small(P, ctx->q[i]);
   int pbits = (int)(P.size() - 1) * 64;
   for (u64 top = P.back(); top; top >>= 1) ++pbits;
-  if (p.NLB * p.B < pbits || (p.NLB - 1) * p.B + 120 > 64 * (p.W + 1)) return false;
-  if (A >> 119 > 1) return false;                               // the +2^119 offset needs the auxiliary modulus below 2^120
-  const u128 terms = (u128)ncol * (u128)ctx->phim << digit_bits;      // ncol * n * 2^digit_bits
-  if (terms >> 50) return false;
-  if (((A / 2) >> p.B) <= terms) return false;                  // |V_l| <= terms * 2^B < q_0 q_1 / 2
+  p.W = t->W; p.LQ = logQ; p.B = B; p.NLB = (pbits + B - 1) / B;
+  if ((p.NLB - 1) * p.B + 120 > 64 * (p.W + 1)) return false;   // x = D + sum (V_l + 2^119) 2^(B l) fits W + 1 limbs
+  if (logQ < 1 || logQ > 64 * (p.W - 1)) return false;
   int m = 0;
   while (((u128)1 << m) <= terms) ++m;
   p.mbits = m + 1;                                              // |S| < terms * P < 2^(mbits-1) P

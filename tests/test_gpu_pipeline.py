@@ -173,16 +173,18 @@ def test_key_switch_paths_agree(m, logQ, p, monkeypatch):
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], orc.ct_mul_relin(ksm2, a[0], b[0], logQ, p))
 
 
-@pytest.mark.parametrize("m", [4096, 8192, 32768])       # 32768: n = 2^14, the four 30-bit auxiliary primes (kernels_aux32.hip)
-def test_key_switch_limb_mode_edge_values(m):
-    """At n >= 2^11 with the metric chain shape the key switch runs in limb mode (kernels_ksaux.hip + ks_recombine_kernel): the dot
-    product is recombined as an integer and reduced modulo the chain product P exactly.  Crafted key rows make that integer hit the
-    edges of the reduction: 0, +-1, +-(P-1)/2, (P+1)/2 (wraps), P-1, values just inside and outside the centring threshold, and a
-    large multiple pattern; the result must equal the oracle's (toPoly + ReduceCoefficients, FHE-SI.cpp:255-256)."""
-    logQ, p = 512, 23
+@pytest.mark.parametrize("m,logQ", [(4096, 512), (8192, 512), (32768, 512),          # the metric chain (18 primes); 32768: four 30-bit auxiliary primes
+                                    (4096, 128), (8192, 200), (16384, 256), (32768, 128), (32768, 341), (32768, 700), (65536, 300)])
+def test_key_switch_limb_mode_edge_values(m, logQ):
+    """For n >= 2^11 the key switch runs in limb mode (kernels_ksaux.hip + ks_recombine_kernel) for ANY chain: the limb width, the limb
+    count and the auxiliary modulus are derived per chain (ks_limb_plan); the dot product is recombined as an integer and reduced modulo
+    the chain product P exactly.  Shapes: the metric chain (compile-time instantiations), and chains of 5 to 24 primes through the
+    run-time recombination kernel, with the two 60-bit auxiliary primes and (n = 2^14) the four 30-bit ones.  Crafted key rows make
+    the integer hit the edges of the reduction: 0, +-1, +-(P-1)/2, (P+1)/2 (wraps), P-1, values just inside and outside the centring
+    threshold, and large multiples; the result must equal the oracle's (toPoly + ReduceCoefficients, FHE-SI.cpp:255-256)."""
+    p = 23
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 7 + m, 1)
     n, L = ctx.phim, ctx.L
-    assert L == 18
     primes = [int(q) for q in ctx.primes]
     Pprod = 1
     for q in primes:
@@ -190,7 +192,8 @@ def test_key_switch_limb_mode_edge_values(m):
     mod = 1 << logQ
     W = L + 2
     h = (Pprod - 1) // 2
-    edge = [h, -h, h + 1, h - 1, -h + 1, 0, 1, -1, Pprod - 1, h + 2, -h - 2, 12345, -(1 << 600), (1 << 1000) + 17, -(1 << 1050) + 3]
+    pb = Pprod.bit_length()
+    edge = [h, -h, h + 1, h - 1, -h + 1, 0, 1, -1, Pprod - 1, h + 2, -h - 2, 12345, -(1 << (pb * 4 // 7)), (1 << (pb - 58)) + 17, -(1 << (pb - 8)) + 3]
     # scaled-down parts = (digit value d at coefficient 0, 0, 0): only digit 0 of part 0 is non-zero, so the dot product is d * key row (r, 0)
     # (at position n-1 the negacyclic wrap turns the products negative: S = -d * e_j)
     for d, pos in ((1, 0), ((1 << 24) - 1, 0), ((1 << 24) - 1, n - 1), (1, n - 1)):
@@ -204,7 +207,14 @@ def test_key_switch_limb_mode_edge_values(m):
         dtp = ctx.upload(tp)
         out = ctx.alloc(2 * n * nl * 8)
         ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
-        assert np.array_equal(out.download((2, n, nl)), orc.apply_key_switch(ksm2, tp[0], logQ, nl)), (d, pos)
+        want = orc.apply_key_switch(ksm2, tp[0], logQ, nl)
+        assert np.array_equal(out.download((2, n, nl)), want), (d, pos)
+        if n == 1 << 14 and pos == 0:                 # the same chain through the two 60-bit auxiliary primes
+            ctx.set_option("ks_aux60", 1)
+            ksk3 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm2)
+            ctx.apply_key_switch_dev(ksk3, logQ, dtp, 1, out, nl)
+            ctx.set_option("ks_aux60", 0)
+            assert np.array_equal(out.download((2, n, nl)), want), (d, pos, "aux60")
 
 
 def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
