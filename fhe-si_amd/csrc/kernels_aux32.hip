@@ -27,7 +27,17 @@ struct fhesi_aux32 {
 
 static constexpr int A32_LOGN = 14, A32_N = 1 << A32_LOGN, A32_T = 512, A32_P = 592;      // LDS stride of a 512-element sub-problem (padded)
 __device__ __forceinline__ u32 a32_f(u32 t_id) { return t_id + ((t_id >> 5) << 2); }       // position inside a sub-problem (4 pad words per 32)
+#if defined(A32_FUSED_MAD)
+// y w - floor(y wp / 2^32) p as  lo32(Q * (-p) + y w): the multiply-add replaces a multiply and a subtract
+__device__ __forceinline__ u32 mul_lazy32(u32 y, Tw32 t, u32 p) {
+  const u32 Q = __umulhi(y, t.wp), yw = y * t.w, np = 0u - p;
+  u64 r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(Q), "v"(np), "v"((u64)yw) : "vcc");
+  return (u32)r;
+}
+#else
 __device__ __forceinline__ u32 mul_lazy32(u32 y, Tw32 t, u32 p) { return y * t.w - __umulhi(y, t.wp) * p; }     // y any 32-bit value -> [0, 2p)
+#endif
 __device__ __forceinline__ int a32_bfly_k(int b, int h) { return ((b / h) * 2 * h) + (b % h); }
 // Cooley-Tukey butterfly on lazy values (below 4p < 2^32):  X' = X + w Y,  Y' = X - w Y
 __device__ __forceinline__ void a32_ct(u32& x, u32& y, Tw32 t, u32 p) {
@@ -179,10 +189,16 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ r
 //   moves its four sub-problems through them two at a time, with wave-level ordering only (LDS operations of a wave execute in order).
 // Twiddles are fetched stage by stage instead of far ahead, which keeps the kernel below 80 registers (6 waves per SIMD).
 static constexpr int A32_HR = 16;                   // rows of the half buffer
+#if defined(A32_ABLATE) && (A32_ABLATE & 1)
+#define A32_TW(x) Tw32{12345u + tid, 678901u}
+#else
+#define A32_TW(x) (x)
+#endif
 template <bool DIGITS>
 __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs,
                                                               Dig32Src ds) {
   __shared__ u32 lds[A32_HR * A32_P];
+  __shared__ Tw32 tbl[992];                        // the prime's phase-B twiddles (entries 32..1023): 16 threads share each, so they are staged once per row
   const u32 tid = threadIdx.x;
   i64 c = blockIdx.x % count;
   int slot = (int)(blockIdx.x / count);
@@ -196,8 +212,16 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
   const u32 p = pr.p[a];
   const Tw32* __restrict__ tab = tabs + (i64)a * A32_N;
   u32* __restrict__ g = rows + (c * nslots + slot) * A32_N;
+  tbl[tid] = tab[32 + tid];                        // (visible to everyone after the first barrier of exchange 1)
+  if (tid < 992 - 512) tbl[512 + tid] = tab[32 + 512 + tid];
   u32 r[32];
+#if defined(A32_ABLATE) && (A32_ABLATE & 8)
+#pragma unroll
+  for (int k = 0; k < 32; ++k) r[k] = tid * (k + 1) + (u32)c;
+  if (false) {
+#else
   if (DIGITS) {
+#endif
     const u32 d = (u32)(c % ds.nd);
     const i64 poly = c / ds.nd;
     const u32 bit = d * (u32)ds.digit_bits, g0 = bit >> 5, sh = bit & 31;
@@ -225,11 +249,12 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
       const int k = a32_bfly_k(b, h);
-      a32_ct(r[k], r[k + h], tab[(1 << s) + (k >> (5 - s))], p);
+      a32_ct(r[k], r[k + h], A32_TW(tab[(1 << s) + (k >> (5 - s))]), p);
     }
   }
   const u32 kq = tid >> 4, lo = tid & 15;          // sub-problem and position inside a group of 16 (after the first exchange)
   const bool upper = kq >= A32_HR;                 // waves 4..7
+#if !(defined(A32_ABLATE) && (A32_ABLATE & 2))
   // exchange 1, first pass: registers 0..15 -> rows 0..15, read by sub-problems 0..15
 #pragma unroll
   for (int k = 0; k < 16; ++k) lds[k * A32_P + a32_f(tid)] = r[k];
@@ -250,19 +275,21 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
 #pragma unroll
     for (int k2 = 0; k2 < 32; ++k2) r[k2] = lds[(kq - A32_HR) * A32_P + a32_f(k2 * 16 + lo)];
   }
+#endif
   // phase B: sub-problem kq (512 elements t = k2 * 16 + lo); distances 16 .. 1 in k2; the 2^u twiddles of stage u fetched at the stage
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
     const int h = 16 >> u;
     Tw32 tb[16];
 #pragma unroll
-    for (int i = 0; i < (1 << u); ++i) tb[i] = tab[(32 << u) + (kq << u) + i];
+    for (int i = 0; i < (1 << u); ++i) tb[i] = A32_TW(tbl[(32 << u) - 32 + (kq << u) + i]);
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
       const int k2 = a32_bfly_k(b, h);
       a32_ct(r[k2], r[k2 + h], tb[k2 >> (5 - u)], p);
     }
   }
+#if !(defined(A32_ABLATE) && (A32_ABLATE & 2))
   __syncthreads();                                 // every read of exchange 1 is done: the rows change owner
   // exchange 2 inside the wave: rows 2w, 2w + 1; sub-problems (kq & 3) = 0, 1 first, then 2, 3
   const u32 wv = tid >> 6, sub = kq & 3;
@@ -280,6 +307,7 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
     }
     __builtin_amdgcn_wave_barrier();
   }
+#endif
   // phase C: this thread holds the groups k2 = 2 lo, 2 lo + 1 (32 consecutive elements); distances 8 .. 1 inside a group
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
@@ -288,7 +316,7 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
-      for (int i = 0; i < (1 << v); ++i) tc[gq][i] = tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i];
+      for (int i = 0; i < (1 << v); ++i) tc[gq][i] = A32_TW(tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i]);
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
 #pragma unroll
@@ -298,12 +326,34 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
       }
     }
   }
-  u32* __restrict__ o = DIGITS ? rows + ((((i64)a << (A32_LOGN - 6)) + (kq * 8 + (lo >> 1))) * count + c) * 64 + (lo & 1) * 32 : g + kq * 512 + lo * 32;
+  // Store through the wave's two LDS rows so that every store instruction writes one whole 64-element slice (256 contiguous bytes):
+  // a thread holds 32 consecutive elements, i.e. half a slice; the wave's 32 slices go out 16 at a time.  Slice t of the half sits at
+  // [t * 72, t * 72 + 72): its two halves 36 words apart (the stride of exchange 2: conflict-free 16-byte writes, consecutive 4-byte reads).
+  const u32 lane = tid & 63;
+  u32* __restrict__ stage = lds + 2 * wv * A32_P;                  // 2 * 592 = 1184 words >= 16 * 72
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    u32 v = r[i];
-    if (!DIGITS) { const u32 twop = 2 * p; v = v >= twop ? v - twop : v; v = v >= p ? v - p : v; }
-    o[i] = v;
+  for (int hh = 0; hh < 2; ++hh) {
+    __builtin_amdgcn_wave_barrier();
+    if ((int)(sub >> 1) == hh) {
+      u32* w = stage + ((sub & 1) * 8 + (lo >> 1)) * 72 + (lo & 1) * 36;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        u32 v = r[i];
+        if (!DIGITS) { const u32 twop = 2 * p; v = v >= twop ? v - twop : v; v = v >= p ? v - p : v; }
+        w[i] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const u32 pos = lane < 32 ? lane : lane + 4;                   // 36 + (lane - 32)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const u32 v = stage[t * 72 + pos];
+      const u32 sl = (4 * wv + 2 * hh + (t >> 3)) * 8 + (t & 7);    // slice of the row: sub-problem kq' = 4 wv + 2 hh + (t >> 3), pair (t & 7)
+#if defined(A32_ABLATE) && (A32_ABLATE & 4)
+      if (v == 0x12345678u)
+#endif
+      (DIGITS ? rows + ((((i64)a << (A32_LOGN - 6)) + sl) * count + c) * 64 : g + sl * 64)[lane] = v;
+    }
   }
 }
 
@@ -399,6 +449,127 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_inv_kernel(u32* __restrict__ r
   }
 }
 
+// ---- third form of the inverse transform: the mirror of ntt32_fwd_kernel3 (half-size LDS buffer, phase-B twiddles staged in LDS,
+// coalesced row loads through the wave's LDS rows); same input order, same output, same arithmetic as ntt32_inv_kernel.
+template <bool MONT>
+__global__ void __launch_bounds__(A32_T, 6) ntt32_inv_kernel3(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs) {
+  __shared__ u32 lds[A32_HR * A32_P];
+  __shared__ Tw32 tbl[992];
+  const u32 tid = threadIdx.x;
+  const i64 c = blockIdx.x % count;
+  const int slot = (int)(blockIdx.x / count), a = a0 + slot;
+  const u32 p = pr.p[a];
+  const Tw32* __restrict__ tab = tabs + (i64)a * A32_N;
+  u32* __restrict__ g = rows + (c * nslots + slot) * A32_N;
+  const u32 kq = tid >> 4, lo = tid & 15, wv = tid >> 6, sub = kq & 3, lane = tid & 63;
+  const bool upper = kq >= A32_HR;
+  tbl[tid] = tab[32 + tid];
+  if (tid < 992 - 512) tbl[512 + tid] = tab[32 + 512 + tid];
+  u32 r[32];
+  // load: every instruction reads one whole 64-element slice; through the wave's two LDS rows each thread ends up with its 32
+  // consecutive elements (the reverse of the forward kernel's store)
+  u32* __restrict__ stage = lds + 2 * wv * A32_P;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const u32 pos = lane < 32 ? lane : lane + 4;
+    u32 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = g[((4 * wv + 2 * hh + (t >> 3)) * 8 + (t & 7)) * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) stage[t * 72 + pos] = v[t];
+    __builtin_amdgcn_wave_barrier();
+    if ((int)(sub >> 1) == hh) {
+      const u32* w = stage + ((sub & 1) * 8 + (lo >> 1)) * 72 + (lo & 1) * 36;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) r[i] = w[i];
+    }
+  }
+  // phase C (mirror): distances 1 .. 8 inside the two groups of 16; per-lane twiddles fetched stage by stage
+#pragma unroll
+  for (int v = 3; v >= 0; --v) {
+    const int h = 8 >> v;
+    Tw32 tc[2][8];
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int i = 0; i < (1 << v); ++i) tc[gq][i] = tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i];
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int x = a32_bfly_k(b, h);
+        a32_gs(r[gq * 16 + x], r[gq * 16 + x + h], tc[gq][x >> (4 - v)], p);
+      }
+    }
+  }
+  // exchange 2 (mirror) inside the wave, two sub-problems at a time through the wave's two rows
+  {
+    u32* __restrict__ row = lds + (2 * wv + (sub & 1)) * A32_P;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      __builtin_amdgcn_wave_barrier();
+      if ((int)(sub >> 1) == hh) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) row[lo * 36 + i] = r[i];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if ((int)(sub >> 1) == hh) {
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) r[k2] = row[a32_f(k2 * 16 + lo)];
+      }
+    }
+  }
+  __syncthreads();                                 // the phase-B table is complete (and the rows change owner below)
+  // phase B (mirror): twiddles from the LDS table
+#pragma unroll
+  for (int u = 4; u >= 0; --u) {
+    const int h = 16 >> u;
+    Tw32 tb[16];
+#pragma unroll
+    for (int i = 0; i < (1 << u); ++i) tb[i] = tbl[(32 << u) - 32 + (kq << u) + i];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int k2 = a32_bfly_k(b, h);
+      a32_gs(r[k2], r[k2 + h], tb[k2 >> (5 - u)], p);
+    }
+  }
+  // exchange 1 (mirror) in two passes: sub-problems 0..15 write their rows, everyone reads registers 0..15; then sub-problems 16..31
+  u32 t[16];
+  if (!upper) {
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) lds[kq * A32_P + a32_f(k2 * 16 + lo)] = r[k2];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[k] = lds[k * A32_P + a32_f(tid)];
+  __syncthreads();
+  if (upper) {
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) lds[(kq - A32_HR) * A32_P + a32_f(k2 * 16 + lo)] = r[k2];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { r[16 + k] = lds[k * A32_P + a32_f(tid)]; r[k] = t[k]; }
+  // phase A (mirror): distances 1 .. 16 in the register index, uniform twiddles
+#pragma unroll
+  for (int s2 = 4; s2 >= 0; --s2) {
+    const int h = 16 >> s2;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int k = a32_bfly_k(b, h);
+      a32_gs(r[k], r[k + h], tab[(1 << s2) + (k >> (5 - s2))], p);
+    }
+  }
+  const Tw32 tn{MONT ? pr.ninv_m[a] : pr.ninv[a], MONT ? pr.ninv_m_p[a] : pr.ninv_p[a]};
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    u32 v = mul_lazy32(r[k], tn, p);
+    v = v >= p ? v - p : v;
+    g[k * A32_T + tid] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 static int aux32_init(fhesi_ctx* ctx) {
   if (ctx->aux32) return 0;
@@ -468,6 +639,12 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0,
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
   ProfScope prof(ctx, PROF_NTT_INV, (double)(count * nslots));
+  if (ctx->opt.ntt32_v3) {
+    if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv); }
+    else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv); }
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (mont) {
     PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel<true>);
     ntt32_inv_kernel<true><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv);
