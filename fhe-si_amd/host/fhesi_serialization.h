@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <istream>
 #include <ostream>
+#include <string>
 
 #include "fhesi_matrix.h"
 
@@ -15,6 +16,16 @@ namespace fhesi {
 
 template <typename T> inline void ExportRaw(std::ostream& out, const T& v) { out.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 template <typename T> inline void ImportRaw(std::istream& in, T& v) { in.read(reinterpret_cast<char*>(&v), sizeof(T)); if (!in) Error("Import: unexpected end of stream"); }
+// Sizes read from a stream drive allocations, so every importer bounds them by what the active context can hold (a corrupt or
+// hostile file must fail with a message, not with a multi-gigabyte resize): integers up to the chain product times 2^64, polynomials
+// up to degree m, rows of phi(m) words, at most 64 primes, at most 2^20 vector elements.
+inline uint32_t ImportCount(std::istream& in, uint64_t max, const char* what) {
+  uint32_t n; ImportRaw(in, n);
+  if (n > max) Error((std::string("Import: ") + what + " count in the stream exceeds what the context allows").c_str());
+  return n;
+}
+inline uint64_t ImportMaxBytes() { return activeContext ? (uint64_t)activeContext->numPrimes() * 8 + 2 * (uint64_t)activeContext->logQ / 8 + 64 : (1u << 16); }
+inline uint64_t ImportMaxDegree() { return activeContext ? (uint64_t)activeContext->zMstar.M() : (1u << 20); }
 
 // plain-old-data overloads of Serialization.h:29-37
 inline void Export(std::ostream& out, uint32_t v) { ExportRaw(out, v); }
@@ -33,7 +44,7 @@ inline void Export(std::ostream& out, const ZZ& val) {
   for (uint32_t i = 0; i < nBytes; ++i) { const unsigned char b = (unsigned char)(val.mag[i / 8] >> (8 * (i % 8))); out.put((char)b); }
 }
 inline void Import(std::istream& in, ZZ& val) {
-  uint32_t nBytes; ImportRaw(in, nBytes);
+  const uint32_t nBytes = ImportCount(in, ImportMaxBytes(), "ZZ byte");
   bool neg; ImportRaw(in, neg);
   val = ZZ();
   val.mag.assign((nBytes + 7) / 8, 0);
@@ -51,13 +62,14 @@ inline void Import(std::istream& in, ZZX& poly) {
   clear(poly);
   int32_t degree; ImportRaw(in, degree);
   if (degree < 0) return;
+  if ((uint64_t)degree > ImportMaxDegree()) Error("Import: polynomial degree in the stream exceeds m");
   poly.rep.resize(degree + 1);
   for (int32_t i = 0; i <= degree; ++i) Import(in, poly.rep[i]);
   poly.normalize();
 }
 // vec_long (Serialization.cpp:83-99)
 inline void Export(std::ostream& out, const vec_long& v) { ExportRaw(out, (uint32_t)v.size()); for (long x : v) ExportRaw(out, x); }
-inline void Import(std::istream& in, vec_long& v) { uint32_t n; ImportRaw(in, n); v.resize(n); for (auto& x : v) ImportRaw(in, x); }
+inline void Import(std::istream& in, vec_long& v) { const uint32_t n = ImportCount(in, ImportMaxDegree(), "row element"); v.resize(n); for (auto& x : v) ImportRaw(in, x); }
 
 // vector<T> (Serialization.h:41-58)
 template <typename T> void Export(std::ostream& out, const std::vector<T>& v);
@@ -71,8 +83,8 @@ inline void Export(std::ostream& out, const DoubleCRT& d) {
 }
 inline void Import(std::istream& in, DoubleCRT& d) {
   std::map<long, vec_long> map;
-  uint32_t size; ImportRaw(in, size);
-  for (uint32_t i = 0; i < size; ++i) { long key; ImportRaw(in, key); Import(in, map[key]); }
+  const uint32_t size = ImportCount(in, 64, "DoubleCRT row");
+  for (uint32_t i = 0; i < size; ++i) { long key; ImportRaw(in, key); if (key < 0 || key >= 64) Error("Import: prime index out of range"); Import(in, map[key]); }
   d.setMap(map);
 }
 inline void Export(std::ostream& out, const CiphertextPart& part) { Export(out, part.poly); }      // Serialization.cpp:101-107
@@ -82,7 +94,7 @@ inline void Import(std::istream& in, Ciphertext& ctxt) { ctxt.Clear(); Import(in
 
 template <typename T> void Export(std::ostream& out, const std::vector<T>& v) { ExportRaw(out, (uint32_t)v.size()); for (const auto& x : v) Export(out, x); }
 template <typename T> void Import(std::istream& in, std::vector<T>& v) {
-  uint32_t n; ImportRaw(in, n);
+  const uint32_t n = ImportCount(in, 1u << 20, "vector element");
   v.resize(n);
   for (auto& x : v) Import(in, x);
 }
@@ -92,7 +104,7 @@ template <typename T> void Export(std::ostream& out, const Matrix<T>& m) {
   for (unsigned i = 0; i < m.NumRows(); ++i) for (unsigned j = 0; j < m.NumCols(); ++j) Export(out, m(i, j));
 }
 template <typename T> void Import(std::istream& in, Matrix<T>& m) {
-  uint32_t r, c; ImportRaw(in, r); ImportRaw(in, c);
+  const uint32_t r = ImportCount(in, 1u << 16, "matrix row"), c = ImportCount(in, 1u << 16, "matrix column");
   m.Resize(r, c);
   for (unsigned i = 0; i < r; ++i) for (unsigned j = 0; j < c; ++j) Import(in, m(i, j));
 }
@@ -108,8 +120,10 @@ inline void ExportSIContext(const FHEcontext& c, std::ostream& out) {
 inline std::unique_ptr<FHEcontext> ImportSIContext(std::istream& in, int device = 0) {
   unsigned m, logQ, generator, decompSize; ZZ p;
   ImportRaw(in, m); ImportRaw(in, logQ); Import(in, p); ImportRaw(in, generator); ImportRaw(in, decompSize);
+  if (p.bits() > 62) Error("ImportSIContext: plaintext modulus does not fit a word");
+  if (m < 2 || m > (1u << 20) || logQ < 1 || logQ > (1u << 14) || decompSize < 1 || decompSize > 7) Error("ImportSIContext: parameters out of range");
   std::unique_ptr<FHEcontext> c(new FHEcontext(m, logQ, (unsigned)p.to_long(), generator, decompSize, device));
-  uint32_t size; ImportRaw(in, size);
+  const uint32_t size = ImportCount(in, 64, "prime");
   for (uint32_t i = 0; i < size; ++i) { long q, root; ImportRaw(in, q); ImportRaw(in, root); c->AddPrime(q, false, root); }
   return c;
 }

@@ -13,16 +13,17 @@ run() {   # name, then bench.py arguments
   cp "$O/$name"/*/"${name}_kernel_stats.csv" "$O/${name}_kernel_stats.csv" 2>/dev/null || cp "$O/$name/${name}_kernel_stats.csv" "$O/${name}_kernel_stats.csv" 2>/dev/null
   tail -1 "$O/${name}_bench.json" | cut -c1-400
 }
-run metric --steps 5 --warmup 2
+run metric --steps 5 --warmup 2 --no-bluestein-cpu
 run stress --workload stress --steps 3 --warmup 1 --cpu-sample 0
 run regression --workload regression --steps 3 --warmup 1
 run ntt --workload ntt --steps 10 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do        # one counter per pass (combining them has hung the profiler on this pool)
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --batch 64 > /dev/null 2> "$O/pmc_$c.log"
-  f=$(find "$O/pmc_$c" -name '*counter_collection.csv' | head -1)
-  for kern in "dot32_kernel<8, 16>" "ntt32_fwd_kernel<true>" "dot_aux_kernel<4, 16, 1>" "ntt_fwd_tile<14, true, 0, false>"; do
-    python3 "$R/tools/pmc_summary.py" "$f" "$kern" | tee -a "$O/pmc_$c.txt"
-  done
 done
+F=$(find "$O/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
+W=$(find "$O/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "dot32_kernel2<8, 16>" "$O/pmc_dot_aux.json" ciphertexts_per_launch=64
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true>" "$O/pmc_ntt_fwd.json" rows_per_launch=16896
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt_fwd_tile<14, false, 0, false>" "$O/pmc_ntt64_fwd.json" rows_per_launch=4608
 find "$O" -name '*.db' -delete; find "$O" -name '*agent_info.csv' -delete; find "$O" -name '*kernel_trace.csv' -delete; find "$O" -name '*counter_collection.csv' -delete
 ls -la "$O"
