@@ -101,3 +101,20 @@ def test_wave_evaluator_sharded_over_ranks_is_bit_identical(args, devices):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "multi-rank ciphertexts bit-identical to one GPU: yes" in r.stdout
     assert "batched: decrypts to the plaintext regression: yes" in r.stdout
+
+
+@pytest.mark.parametrize("workload,extra", [("metric", ["--batch", "64"]), ("regression", ["--reg-dim", "3"]), ("ntt", ["--batch", "64"])])
+def test_bench_launches_its_own_ranks(workload, extra):
+    """`python bench.py --gpus 2` without an external launcher (how a single-command driver starts it): the parent spawns the ranks
+    as a child torch.distributed.run before touching the GPU and relays rank 0's JSON line.  On this 1-GPU box both ranks use GPU 0 and
+    the collectives run over gloo (--one-device --backend gloo: plumbing only, never a measurement)."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo", "--workload", workload,
+                        "--steps", "2", "--warmup", "1", "--cpu-sample", "0", *extra], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["roofline"]["kernel"] and d["roofline"]["frac"] > 0
