@@ -144,6 +144,7 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
   c->phi = hm::cyclotomic(m);
   c->pow2 = (m & (m - 1)) == 0 && m >= 4;
   c->logn = c->pow2 ? hm::ilog2_ceil(c->phim) : 0;
+  if (!c->pow2 && m % 2 == 0 && (m / 2) % 2 == 1 && hm::is_prime((u64)(m / 2)) && 2 * c->phim - 1 <= kAux32N) c->lin_q = m / 2;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1180,9 +1181,10 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
     fhesi_ksk* km = const_cast<fhesi_ksk*>(k);
     if (!k->aux_valid || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ));
     const int R = k->aux_rows;        // L chain-prime residues, or the limbs of the key's integer coefficients (limb mode)
+    const i64 nrow = k->aux32 ? kAux32N : n;      // the 32-bit auxiliary rows always have 2^14 elements (four 4-byte residues = two 8-byte ones)
     void *d_dig, *d_o;
-    FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * 2 * n * 8, &d_dig));
-    FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * R * 2 * n * 8, &d_o));
+    FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * 2 * nrow * 8, &d_dig));
+    FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * R * 2 * nrow * 8, &d_o));
     if (k->aux32) {       // four 30-bit primes (kernels_aux32.hip): the same buffer sizes, u32 rows
       FHESI_TRY(launch_ntt32_fwd_digits(c, d_parts, nlq, 8 * decomp_bytes, nd, count * ncomp, (u32*)d_dig));
       if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }

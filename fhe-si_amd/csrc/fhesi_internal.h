@@ -93,6 +93,9 @@ struct fhesi_ctx {
   int n_big_primes = 0;                // chain primes >= 2^48
   bool has_small_prime = false;        // some chain prime is below 2^48: the tile kernels transform its rows modulo q_tile (ntt_tile.inc)
   int logn = 0;                        // log2(phim) when pow2
+  // m = 2 q' with q' an odd prime and 2 phi(m) - 1 <= 2^14 (the reference's safe-prime rings, e.g. p = 8423): the key switch's integer
+  // dot product is a LINEAR convolution carried by the 2^14-point 32-bit transforms and folded modulo X^q' + 1 and Phi_m afterwards
+  i64 lin_q = 0;                       // q' (0 = not such a ring)
   std::vector<u64> q, root;
   std::vector<int> zms_idx;            // PAlgebra::zmsIdx (PAlgebra.cpp:50-52)
   std::vector<i64> phi;                // Phi_m(X) (PAlgebra.cpp:55)
@@ -151,12 +154,14 @@ struct fhesi_ksk {
   size_t bytes = 0;
   // derived table of the two-auxiliary-prime dot product (kernels_ksaux.hip), rebuilt on the device when the rows changed
   u64* d_aux = nullptr;                // [2 aux][aux_rows][n/64][2][ncomp*ndigits][64] split 60-bit words, or (aux32) [4][aux_rows][n/64][2][ncol][64] u32
+  size_t aux_bytes = 0;                // allocated size of d_aux
   u64* d_aux_consts = nullptr;         // [L] q_0 q_1 mod q_i, then the int pair {0, 1} (prime_of_slot of auxiliary rows)
   bool aux_valid = false, aux_suborder = false;
   // limb mode (kernels_ksaux.hip): the table is built from the key polynomial's INTEGER coefficients (toPoly over the chain) cut into
   // aux_rows limbs of aux_limb_bits bits instead of from its aux_rows = L chain-prime residues; 0 = residue mode
   int aux_rows = 0, aux_limb_bits = 0, aux_logQ = 0;
-  bool aux32 = false;                  // the table holds residues modulo the four 30-bit primes of kernels_aux32.hip (u32, n = 2^14)
+  bool aux32 = false;                  // the table holds residues modulo the four 30-bit primes of kernels_aux32.hip (u32, 2^14-point rows)
+  i64 aux_fold = 0;                    // q' when the rows are linear convolutions to be folded modulo X^q' + 1 and Phi_m (ctx->lin_q), else 0
   u64* d_limb_consts = nullptr;        // [W+1] offset constant D, [2] floor(2^(64(W-2)+128) / P), then the quotient bound's bit count
 };
 struct KsLimbPlan { int W = 0, LQ = 0, B = 0, NLB = 0, mbits = 0; bool a32 = false; };
@@ -168,6 +173,8 @@ int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */);
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* [npolys*nd][4][n] */);
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */);
+bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14, or a ring with lin_q set
+static const i64 kAux32N = 1 << 14;                // row length of the 32-bit auxiliary transforms
 int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig /* [count*ncol][4][n] */, int ncol, i64 count, u32* d_out /* [count*2*rows][4][n] */);
 bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits);
 int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ);

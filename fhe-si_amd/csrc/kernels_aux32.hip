@@ -55,7 +55,7 @@ __device__ __forceinline__ void a32_gs(u32& x, u32& y, Tw32 t, u32 p) {
   y = mul_lazy32(d, t, p);
 }
 
-struct Dig32Src { const u64* parts; int nl, digit_bits, nd; };     // limb-major scaled-down parts [npolys][nl][n]
+struct Dig32Src { const u64* parts; int nl, digit_bits, nd; u32 n_src; };     // limb-major scaled-down parts [npolys][nl][n_src]; elements from n_src upwards are zero (n_src < 2^14: linear convolution)
 
 // rows: [count][nslots][n] u32; block rb -> (unit c = rb % count, slot = rb / count), prime a0 + slot.
 // DIGITS: unit c = poly * nd + digit, the values are cut out of the parts (ByteDecomp, Ciphertext.cpp:82-105); output lazy (below 4p).
@@ -86,16 +86,17 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ r
     const u32 bit = d * (u32)ds.digit_bits, g0 = bit >> 5, sh = bit & 31;
     const u32 mask = (1u << ds.digit_bits) - 1;
     const u32* __restrict__ p32 = reinterpret_cast<const u32*>(ds.parts);
-    const u32* __restrict__ w0 = p32 + (((poly * ds.nl + (g0 >> 1)) << A32_LOGN) << 1) + (g0 & 1);
+    const u32* __restrict__ w0 = p32 + (((poly * ds.nl + (g0 >> 1)) * (i64)ds.n_src) << 1) + (g0 & 1);
     const bool two = (sh + ds.digit_bits > 32) && (int)((g0 + 1) >> 1) < ds.nl;
+    const u32 ns = ds.n_src;
     if (two) {
       const u32 g1 = g0 + 1;
-      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) << A32_LOGN) << 1) + (g1 & 1);
+      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) * (i64)ds.n_src) << 1) + (g1 & 1);
 #pragma unroll
-      for (int k = 0; k < 32; ++k) { const u32 e = 2 * (k * A32_T + tid); r[k] = ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask; }
+      for (int k = 0; k < 32; ++k) { const u32 el = k * A32_T + tid, e = 2 * el; r[k] = el < ns ? ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask : 0u; }
     } else {
 #pragma unroll
-      for (int k = 0; k < 32; ++k) r[k] = (w0[2 * (k * A32_T + tid)] >> sh) & mask;
+      for (int k = 0; k < 32; ++k) { const u32 el = k * A32_T + tid; r[k] = el < ns ? (w0[2 * el] >> sh) & mask : 0u; }
     }
   } else {
 #pragma unroll
@@ -227,16 +228,17 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
     const u32 bit = d * (u32)ds.digit_bits, g0 = bit >> 5, sh = bit & 31;
     const u32 mask = (1u << ds.digit_bits) - 1;
     const u32* __restrict__ p32 = reinterpret_cast<const u32*>(ds.parts);
-    const u32* __restrict__ w0 = p32 + (((poly * ds.nl + (g0 >> 1)) << A32_LOGN) << 1) + (g0 & 1);
+    const u32* __restrict__ w0 = p32 + (((poly * ds.nl + (g0 >> 1)) * (i64)ds.n_src) << 1) + (g0 & 1);
     const bool two = (sh + ds.digit_bits > 32) && (int)((g0 + 1) >> 1) < ds.nl;
+    const u32 ns = ds.n_src;
     if (two) {
       const u32 g1 = g0 + 1;
-      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) << A32_LOGN) << 1) + (g1 & 1);
+      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) * (i64)ds.n_src) << 1) + (g1 & 1);
 #pragma unroll
-      for (int k = 0; k < 32; ++k) { const u32 e = 2 * (k * A32_T + tid); r[k] = ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask; }
+      for (int k = 0; k < 32; ++k) { const u32 el = k * A32_T + tid, e = 2 * el; r[k] = el < ns ? ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask : 0u; }
     } else {
 #pragma unroll
-      for (int k = 0; k < 32; ++k) r[k] = (w0[2 * (k * A32_T + tid)] >> sh) & mask;
+      for (int k = 0; k < 32; ++k) { const u32 el = k * A32_T + tid; r[k] = el < ns ? (w0[2 * el] >> sh) & mask : 0u; }
     }
   } else {
 #pragma unroll
@@ -571,9 +573,10 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_inv_kernel3(u32* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------- host side
+bool aux32_applies(const fhesi_ctx* ctx) { return (ctx->pow2 && ctx->logn == A32_LOGN) || ctx->lin_q != 0; }
 static int aux32_init(fhesi_ctx* ctx) {
   if (ctx->aux32) return 0;
-  if (!ctx->pow2 || ctx->logn != A32_LOGN) FHESI_FAIL("aux32: only for n = 2^14");
+  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14 and for rings m = 2 * prime with 2 phi(m) - 1 <= 2^14");
   fhesi_aux32* x = new fhesi_aux32();
   // the four largest primes below 2^30 that are 1 mod 2^15 (= 2n)
   int found = 0;
@@ -665,12 +668,12 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   const i64 units = npolys * nd;
   if (ctx->opt.ntt32_v3) {
     PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true>);
-    ntt32_fwd_kernel3<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd});
+    ntt32_fwd_kernel3<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd, (u32)ctx->phim});
     HIP_TRY(hipGetLastError());
     return 0;
   }
   PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel<true>);
-  ntt32_fwd_kernel<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd});
+  ntt32_fwd_kernel<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd, (u32)ctx->phim});
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -678,7 +681,7 @@ const u32* aux32_primes(fhesi_ctx* ctx) { return aux32_init(ctx) ? nullptr : ctx
 
 // ---------------------------------------------------------------------------------------------- key table and dot product
 // kint [2*ncol][n][W]: the key's integer coefficients;  rows32[a][(l*2 + r)*ncol + k][n] = (limb l of B bits) mod p_a
-__global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __restrict__ kint, u32* __restrict__ rows32, int ncol, int NLB, int B, int W, Aux32Primes pr) {
+__global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __restrict__ kint, u32* __restrict__ rows32, int ncol, int NLB, int B, int W, Aux32Primes pr, i64 n_src) {
   const i64 row = blockIdx.y;                 // (r * ncol + k) * NLB + l
   const int l = (int)(row % NLB);
   const i64 rk = row / NLB;
@@ -686,8 +689,8 @@ __global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __res
   const int s = B * l, wd = s >> 6, bt = s & 63;
   const i64 rows_per_a = (i64)NLB * 2 * ncol;
   for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < A32_N; j += (i64)gridDim.x * blockDim.x) {
-    const u64* x = kint + (rk * A32_N + j) * W;
-    auto word = [&](int i) -> u64 { return i < W ? x[i] : 0; };
+    const u64* x = kint + (rk * n_src + (j < n_src ? j : 0)) * W;          // key polynomials of n_src coefficients, zero above (linear convolution)
+    auto word = [&](int i) -> u64 { return (i < W && j < n_src) ? x[i] : 0; };
     const u64 w0 = word(wd), w1 = word(wd + 1), w2 = word(wd + 2);
     const u64 lo = bt ? ((w0 >> bt) | (w1 << (64 - bt))) : w0;
     u64 hi = bt ? ((w1 >> bt) | (w2 << (64 - bt))) : w1;
@@ -934,9 +937,9 @@ int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, in
   const int ncol = k->ncomp * k->ndigits;
   const i64 rows_per_a = (i64)NLB * 2 * ncol;
   u32* rows32 = (u32*)k->d_aux;
-  if ((size_t)4 * rows_per_a * A32_N * 4 > 2 * k->bytes) FHESI_FAIL("aux32: key table does not fit");
+  if ((size_t)4 * rows_per_a * A32_N * 4 > k->aux_bytes) FHESI_FAIL("aux32: key table does not fit");
   dim3 grid(64, (unsigned)(2 * ncol * NLB));
-  ks32_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(d_kint, rows32, ncol, NLB, B, W, ctx->aux32->pr);
+  ks32_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(d_kint, rows32, ncol, NLB, B, W, ctx->aux32->pr, ctx->phim);
   HIP_TRY(hipGetLastError());
   for (int a = 0; a < 4; ++a) FHESI_TRY(launch_ntt32_fwd(ctx, rows32 + (i64)a * rows_per_a * A32_N, rows_per_a, 1, a));
   for (int a = 0; a < 4; ++a) {

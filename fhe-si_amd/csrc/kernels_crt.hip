@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
 // x live in LDS (limb-major, one column per thread: run-time limb indices cost nothing there).  The compile-time instantiations above
 // serve the shapes the benchmarks run; this one makes limb mode (and the 30-bit auxiliary primes) available to every chain.
 template <int MAXW, bool A32>
-__global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __restrict__ o, i64 n, int W, int LQ, int B, int NLB, u64 q0, u64 q1, u64 q0inv, u64 q0inv_sh,
+__global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __restrict__ o, i64 n, i64 nrow, i64 fold_q, int W, int LQ, int B, int NLB, u64 q0, u64 q1, u64 q0inv, u64 q0inv_sh,
                                                                    u64 half_hi, u64 half_lo, u64 a_hi, u64 a_lo, const u64* __restrict__ consts /* D[W+1], pinv lo, hi */,
                                                                    const u64* __restrict__ Pfull, const u64* __restrict__ halfP, u64* __restrict__ out, int nl_out, Garner32 gc) {
   __shared__ u64 xs[(MAXW + 1) * 128];
@@ -710,12 +710,15 @@ __global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __
   if (j >= n) return;
   for (int i = 0; i <= W; ++i) X(i) = consts[i];
   const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
-  const u64* base = o + poly * NLB * 2 * n + j;
-  const u32* base32 = reinterpret_cast<const u32*>(o) + poly * NLB * 4 * n + j;
-  for (int l = 0; l < NLB; ++l) {
+  // rows of nrow elements (nrow = n except on the linear-convolution rings, where the rows are the 2^14-point products)
+  const u64* base = o + poly * NLB * 2 * nrow;
+  const u32* base32 = reinterpret_cast<const u32*>(o) + poly * NLB * 4 * nrow;
+  // the centred integer at position `pos` of limb row l (two's complement in 128 bits)
+  auto centred = [&](int l, i64 pos) -> u128 {
     u128 V;
     if (A32) {
-      const u32 v0 = base32[(i64)(l * 4 + 0) * n], v1 = base32[(i64)(l * 4 + 1) * n], v2 = base32[(i64)(l * 4 + 2) * n], v3 = base32[(i64)(l * 4 + 3) * n];
+      const u32 v0 = base32[(i64)(l * 4 + 0) * nrow + pos], v1 = base32[(i64)(l * 4 + 1) * nrow + pos], v2 = base32[(i64)(l * 4 + 2) * nrow + pos],
+                v3 = base32[(i64)(l * 4 + 3) * nrow + pos];
       const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
       const u32 x1 = v0;
       const u32 x2 = g32_mul(g32_sub(v1, x1, p1), gc.c[0], gc.cp[0], p1);
@@ -724,12 +727,23 @@ __global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __
                              gc.c[5], gc.cp[5], p3);
       V = (u128)((u64)x3 + (u64)p2 * x4) * ((u64)p0 * p1) + ((u64)x1 + (u64)p0 * x2);
     } else {
-      const u64 v0 = base[(i64)(l * 2 + 0) * n], v1 = base[(i64)(l * 2 + 1) * n];
+      const u64 v0 = base[(i64)(l * 2 + 0) * nrow + pos], v1 = base[(i64)(l * 2 + 1) * nrow + pos];
       const u64 v0r = v0 >= q1 ? v0 - q1 : v0;
       const u64 t = d_shoup(d_submod(v1, v0r, q1), q0inv, q0inv_sh, q1);
       V = (u128)q0 * t + v0;
     }
     if (V > half) V -= A;
+    return V;
+  };
+  for (int l = 0; l < NLB; ++l) {
+    u128 V = centred(l, j);
+    if (fold_q) {
+      // S (degree < 2n - 1) modulo X^q' + 1: R_j = S_j - S_(j+q');  modulo Phi_m = 1 - X + X^2 - ... + X^(q'-1) (degree n = q' - 1):
+      // out_j = R_j - (-1)^j R_n,  j < n   (Phi_m is monic, so this is the exact integer remainder)
+      const u128 top = centred(l, n) - centred(l, n + fold_q);
+      V -= centred(l, j + fold_q);
+      if (j & 1) V += top; else V -= top;
+    }
     V += (u128)1 << 119;
     const int s = B * l, wd = s >> 6, bt = s & 63;
     const u64 lo = (u64)V, hi = (u64)(V >> 64);
@@ -817,7 +831,7 @@ int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, 
   if (!npolys) return 0;
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
   // compile-time instantiations for the shapes the benchmarks run (the plan of ks_limb_plan at the metric and stress chains) ...
-  if (k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
+  if (!k->aux_fold && k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
   if (!k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, false>(ctx, t, k, d_o, npolys, d_out, nl_out);
   if (!k->aux32 && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30) return launch_ks_recombine_t<34, 1024, 72, 30, false>(ctx, t, k, d_o, npolys, d_out, nl_out);
   // ... and the run-time form for every other chain
@@ -832,7 +846,8 @@ int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, 
   const u128 half = (A - 1) / 2;
   const int W = t->W;
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
-#define KS_GEN(MAXW, A32) ks_recombine_generic_kernel<MAXW, A32><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, W, k->aux_logQ, k->aux_limb_bits, k->aux_rows, q0, q1, inv, hm::shoup(inv, q1), \
+  const i64 nrow = k->aux32 ? kAux32N : ctx->phim;
+#define KS_GEN(MAXW, A32) ks_recombine_generic_kernel<MAXW, A32><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, nrow, k->aux_fold, W, k->aux_logQ, k->aux_limb_bits, k->aux_rows, q0, q1, inv, hm::shoup(inv, q1), \
       (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, k->d_limb_consts, t->d_P + (size_t)t->nidx * t->W, t->d_halfP, d_out, nl_out, gc)
   if (W <= 20) { if (k->aux32) KS_GEN(20, true); else KS_GEN(20, false); }
   else if (W <= 44) { if (k->aux32) KS_GEN(44, true); else KS_GEN(44, false); }

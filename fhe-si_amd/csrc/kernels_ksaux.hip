@@ -256,11 +256,17 @@ __global__ void __launch_bounds__(256) aux_crt_kernel(const u64* __restrict__ o,
 }
 
 bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits) {
-  if (!ctx->pow2 || ctx->L < 2 || digit_bits >= 32) return false;
-  if (!((ctx->logn >= 11 && ctx->logn <= 14) || ntt_digits_suborder(ctx, digit_bits))) return false;      // single-pass digit transforms
+  if (ctx->L < 2 || digit_bits >= 32) return false;
   const u64 q0 = ctx->q[0], q1 = ctx->q[1];
   if (q0 <= q1 || q1 < (1ull << 59)) return false;             // the chain is descending from 2^60 (FHEContext.cpp:92-108)
   for (int i = 2; i < ctx->L; ++i) if (ctx->q[i] >= q1) return false;
+  if (ctx->lin_q) {
+    // the reference's safe-prime rings: only the limb mode over the four 30-bit primes exists there (linear convolution + fold); the
+    // plan decides (ks_limb_plan needs the chain's CRT tables, so the caller -- ksaux_build -- reports a failing plan as an error)
+    return !ctx->opt.ks_residues && !ctx->opt.ks_aux60;
+  }
+  if (!ctx->pow2) return false;
+  if (!((ctx->logn >= 11 && ctx->logn <= 14) || ntt_digits_suborder(ctx, digit_bits))) return false;      // single-pass digit transforms
   // |V| <= ncol * n * 2^digit_bits * q_0  must stay below q_0 q_1 / 2
   const double lg = std::log2((double)ncol) + (double)ctx->logn + digit_bits + 60.0;
   return lg + 2.0 < std::log2((double)q0) + std::log2((double)q1);
@@ -276,12 +282,15 @@ bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_
   if (t->nidx != ctx->L || t->W < 3) return false;
   KsLimbPlan p;
   u128 A = (u128)ctx->q[0] * ctx->q[1];
-  if (p32 && ctx->logn == 14 && !ctx->opt.ks_aux60) {          // option ks_aux60: two 60-bit primes even where the four 30-bit primes apply
+  if (p32 && aux32_applies(ctx) && !ctx->opt.ks_aux60) {       // option ks_aux60: two 60-bit primes even where the four 30-bit primes apply
     p.a32 = true;
     A = (u128)((u64)p32[0] * p32[1]) * ((u64)p32[2] * p32[3]);
   }
+  if (ctx->lin_q && !p.a32) return false;
   if (A >> 119 > 1) return false;                               // the +2^119 offset needs the auxiliary modulus below 2^120
-  const u128 terms = (u128)ncol * (u128)ctx->phim << digit_bits;      // ncol * n * 2^digit_bits
+  // ncol * n * 2^digit_bits bounds a coefficient of one limb product sum; on the linear-convolution rings the fold modulo X^q' + 1 and
+  // Phi_m combines four of them (C(j) - C(j+q') -+ (C(phi) - C(phi+q'))), each kept below A / 8 so that the combination stays below A / 2
+  const u128 terms = ((u128)ncol * (u128)ctx->phim << digit_bits) * (ctx->lin_q ? 4 : 1);
   if (terms >> 50) return false;
   int B = 0;
   while (B < 100 && (((A / 2) >> (B + 1)) > terms)) ++B;        // the largest B with terms * 2^B < A / 2
@@ -330,9 +339,15 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
   CrtTables* t;
   FHESI_TRY(get_crt_tables(ctx, all, &t));
   KsLimbPlan plan;
-  const bool limb = ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, ctx->logn == 14 ? aux32_primes(ctx) : nullptr);
+  const bool limb = ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, aux32_applies(ctx) ? aux32_primes(ctx) : nullptr);
+  if (ctx->lin_q && !(limb && plan.a32)) FHESI_FAIL("key switch: no exact limb plan for this ring and chain (set option ks_direct)");
   const int R = limb ? plan.NLB : L;                          // output rows per (ciphertext, key row, auxiliary prime)
-  if (!k->d_aux) HIP_TRY(hipMalloc(&k->d_aux, 2 * k->bytes));
+  {
+    // table size: residue / limb rows for two 8-byte (or four 4-byte) auxiliary residues; 2^14-element rows on the linear-convolution rings
+    const size_t need = (size_t)2 * R * 2 * ncol * (plan.a32 && limb ? kAux32N : n) * 8;
+    if (k->d_aux && k->aux_bytes < need) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(k->d_aux)); k->d_aux = nullptr; }
+    if (!k->d_aux) { HIP_TRY(hipMalloc(&k->d_aux, need)); k->aux_bytes = need; }
+  }
   if (!k->d_aux_consts) {
     HIP_TRY(hipMalloc(&k->d_aux_consts, (size_t)(L + 2) * 8));
     std::vector<u64> h(L + 2, 0);
@@ -343,9 +358,10 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   void* tmp;
-  FHESI_TRY(ws_reserve(ctx, 0, k->bytes, &tmp));
+  FHESI_TRY(ws_reserve(ctx, 0, std::max(k->bytes, (size_t)R * 2 * ncol * kAux32N * 4), &tmp));      // the key rows, later one auxiliary prime's table rows
   HIP_TRY(hipMemcpyAsync(tmp, k->d_rows, k->bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  FHESI_TRY(launch_ntt_inv(ctx, (u64*)tmp, 2 * ncol, L, nullptr, true));
+  if (ctx->pow2) FHESI_TRY(launch_ntt_inv(ctx, (u64*)tmp, 2 * ncol, L, nullptr, true));
+  else FHESI_TRY(launch_bluestein_inv(ctx, (u64*)tmp, 2 * ncol, L, all.data()));          // Cmod::iFFT of every key row on a general-m ring
   if (limb) {
     const int W = t->W;
     u64* kint = nullptr;                                        // the key's integer coefficients: one-off scratch
@@ -388,6 +404,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
     HIP_TRY(hipGetLastError());
   }
   k->aux32 = limb && plan.a32;
+  k->aux_fold = k->aux32 ? ctx->lin_q : 0;
   const int* d_slot = (const int*)(k->d_aux_consts + L);
   const i64 rows_per_a = (i64)R * 2 * ncol;
   if (!k->aux32)

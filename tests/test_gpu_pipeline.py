@@ -232,3 +232,46 @@ def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
         assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), opt
         ctx.set_option(opt, 0)
     assert np.array_equal(ref[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
+
+
+@pytest.mark.parametrize("m,logQ", [(22, 80), (46, 120), (1006, 200), (8422, 341)])
+def test_key_switch_on_safe_prime_rings(m, logQ):
+    """The reference's own rings (m = p - 1 = 2 q' for a safe prime p; Test_Regression: p = 8423, logQ = 341, 13 primes) take the exact
+    integer key switch as well: the digit (*) key products are LINEAR convolutions carried by the 2^14-point 32-bit transforms, folded
+    modulo X^q' + 1 and Phi_m inside the recombination (kernels_crt.hip: ks_recombine_generic_kernel, fold_q) -- instead of one
+    Bluestein transform of every digit polynomial per chain prime (option ks_direct, the reference's structure).  Both device paths
+    against the oracle, end to end and on crafted key rows that drive the folded integer through the edges of the reduction."""
+    p = 23
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 5 + m, 2)
+    if m > 2000:
+        orc.set_bluestein_fft(True)             # the oracle's O(N log N) form of the same transforms (bluestein.cpp:116-139)
+    n, L = ctx.phim, ctx.L
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    want = [orc.ct_mul_relin(ksm, a[c], b[c], logQ, p) for c in range(2)]
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    for c in range(2):
+        assert np.array_equal(got[c], want[c]), c
+    ctx.set_option("ks_direct", 1)
+    ksk_d = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    got_d = ctx.ct_mul_relin(ksk_d, logQ, p, a, b)
+    ctx.set_option("ks_direct", 0)
+    assert np.array_equal(got_d, got)
+    # crafted rows: scaled-down parts = (d X^pos, 0, 0), key row (r, 0) = edge polynomial e, so the dot product is d X^pos e mod Phi_m
+    primes = [int(q) for q in ctx.primes]
+    Pprod = 1
+    for q in primes:
+        Pprod *= q
+    mod, W, h, pb = 1 << logQ, L + 2, (Pprod - 1) // 2, Pprod.bit_length()
+    edge = [h, -h, h + 1, h - 1, 0, 1, -1, Pprod - 1, h + 2, 12345, -(1 << (pb * 4 // 7)), (1 << (pb - 8)) + 17]
+    for d, pos in ((1, 0), ((1 << 24) - 1, n - 1), ((1 << 24) - 1, n // 2)):
+        tp = np.zeros((1, 3, L, n), dtype=np.uint64)
+        tp[0, 0] = orc.dcrt_from_poly(O.ints_to_limbs([0] * pos + [d * mod] + [0] * (n - 1 - pos), W))
+        ksm2 = ksm.copy()
+        for r in range(2):
+            e = (edge[r:] + edge[:r]) * (n // len(edge) + 1)
+            ksm2[r, 0] = orc.dcrt_from_poly(O.ints_to_limbs(e[:n], W))
+        ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm2)
+        dtp = ctx.upload(tp)
+        out = ctx.alloc(2 * n * nl * 8)
+        ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
+        assert np.array_equal(out.download((2, n, nl)), orc.apply_key_switch(ksm2, tp[0], logQ, nl)), (d, pos)
