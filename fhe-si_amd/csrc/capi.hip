@@ -1181,7 +1181,7 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
     fhesi_ksk* km = const_cast<fhesi_ksk*>(k);
     if (!k->aux_valid || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ));
     const int R = k->aux_rows;        // L chain-prime residues, or the limbs of the key's integer coefficients (limb mode)
-    const i64 nrow = k->aux32 ? kAux32N : n;      // the 32-bit auxiliary rows always have 2^14 elements (four 4-byte residues = two 8-byte ones)
+    const i64 nrow = k->aux32 ? aux32_row_len(c) : n;      // the 32-bit auxiliary rows always have 2^14 elements (four 4-byte residues = two 8-byte ones)
     void *d_dig, *d_o;
     FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * 2 * nrow * 8, &d_dig));
     FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * R * 2 * nrow * 8, &d_o));

@@ -173,7 +173,8 @@ int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */);
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* [npolys*nd][4][n] */);
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */);
-bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14, or a ring with lin_q set
+bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14 or 2^15, or a ring with lin_q set
+i64 aux32_row_len(const fhesi_ctx* ctx);            // 2^15 for n = 2^15, else 2^14
 static const i64 kAux32N = 1 << 14;                // row length of the 32-bit auxiliary transforms
 int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig /* [count*ncol][4][n] */, int ncol, i64 count, u32* d_out /* [count*2*rows][4][n] */);
 bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits);

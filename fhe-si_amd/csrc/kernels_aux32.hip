@@ -19,10 +19,15 @@ struct Tw32 { u32 w, wp; };          // constant and floor(w 2^32 / p)
 struct Aux32Primes { u32 p[4]; u32 ninv[4], ninv_p[4]; u64 pinv64[4] /* floor((2^64 - 1) / p) */, r64[4] /* 2^64 mod p */, r48[4] /* 2^48 mod p */;
                      u32 mont[4] /* -p^-1 mod 2^32 */, ninv_m[4], ninv_m_p[4] /* n^-1 2^32 mod p and its quotient: undoes the 2^-32 of dot32_kernel2's Montgomery step */; };
 
+// n = 2^15 (S = 1): one head stage (distance 2^14, a single twiddle per prime) in front of two independent 2^14-point sub-transforms
+// with their own twiddle slices -- the structure of the 64-bit path (ntt_tile.inc); sub-row h of a row holds the evaluations of sub-block h.
+struct Aux32Head { Tw32 head[4], tail_sum[4], tail_dif[4]; };      // psi^brv(1);  1/2 and psi^-brv(1) / 2  (the tail of the inverse)
 struct fhesi_aux32 {
   Aux32Primes pr;
-  Tw32* d_fwd = nullptr;               // [4][n]  psi^brv(idx), idx = m + i (stage with m groups, group i)
-  Tw32* d_inv = nullptr;               // [4][n]  the inverses
+  Aux32Head hd;
+  int S = 0;                           // log2 of the sub-transforms per row (0: rows of 2^14 elements, 1: rows of 2^15)
+  Tw32* d_fwd = nullptr;               // [4][2^S][2^14]  psi^brv(idx), idx = m + i (stage with m groups, group i), per sub-block
+  Tw32* d_inv = nullptr;               // [4][2^S][2^14]  the inverses
 };
 
 static constexpr int A32_LOGN = 14, A32_N = 1 << A32_LOGN, A32_T = 512, A32_P = 592;      // LDS stride of a 512-element sub-problem (padded)
@@ -195,24 +200,27 @@ static constexpr int A32_HR = 16;                   // rows of the half buffer
 #else
 #define A32_TW(x) (x)
 #endif
-template <bool DIGITS>
+// PAD: the source polynomials have fewer than 2^14 coefficients (linear-convolution rings): elements from n_src upwards are zero
+template <bool DIGITS, int S, bool PAD = false>
 __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs,
-                                                              Dig32Src ds) {
+                                                              Dig32Src ds, Aux32Head hd) {
   __shared__ u32 lds[A32_HR * A32_P];
   __shared__ Tw32 tbl[992];                        // the prime's phase-B twiddles (entries 32..1023): 16 threads share each, so they are staged once per row
   const u32 tid = threadIdx.x;
   i64 c = blockIdx.x % count;
-  int slot = (int)(blockIdx.x / count);
+  int ps = (int)(blockIdx.x / count);             // (prime slot, sub-block)
   if (DIGITS) {
+    // the transforms of a digit polynomial (4 primes x 2^S sub-blocks) read the same source words: keep them on one XCD (block ids 8 apart)
     const u32 bid = blockIdx.x;
-    slot = (int)((bid >> 3) & 3);
-    c = (i64)(bid >> 5) * 8 + (bid & 7);
+    ps = (int)((bid >> 3) & ((4u << S) - 1));
+    c = (i64)(bid >> (5 + S)) * 8 + (bid & 7);
     if (c >= count) return;
   }
+  const int slot = ps >> S, h = ps & ((1 << S) - 1);
   const int a = a0 + slot;
   const u32 p = pr.p[a];
-  const Tw32* __restrict__ tab = tabs + (i64)a * A32_N;
-  u32* __restrict__ g = rows + (c * nslots + slot) * A32_N;
+  const Tw32* __restrict__ tab = tabs + (((i64)a << S) + h) * A32_N;
+  u32* __restrict__ g = rows + ((((c * nslots + slot)) << S) + h) * A32_N;
   tbl[tid] = tab[32 + tid];                        // (visible to everyone after the first barrier of exchange 1)
   if (tid < 992 - 512) tbl[512 + tid] = tab[32 + 512 + tid];
   u32 r[32];
@@ -231,14 +239,40 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
     const u32* __restrict__ w0 = p32 + (((poly * ds.nl + (g0 >> 1)) * (i64)ds.n_src) << 1) + (g0 & 1);
     const bool two = (sh + ds.digit_bits > 32) && (int)((g0 + 1) >> 1) < ds.nl;
     const u32 ns = ds.n_src;
-    if (two) {
-      const u32 g1 = g0 + 1;
-      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) * (i64)ds.n_src) << 1) + (g1 & 1);
+    if (S == 0) {
+      if (two) {
+        const u32 g1 = g0 + 1;
+        const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) * (i64)ds.n_src) << 1) + (g1 & 1);
 #pragma unroll
-      for (int k = 0; k < 32; ++k) { const u32 el = k * A32_T + tid, e = 2 * el; r[k] = el < ns ? ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask : 0u; }
+        for (int k = 0; k < 32; ++k) {
+          const u32 el = k * A32_T + tid, e = 2 * (PAD ? (el < ns ? el : 0u) : el);        // (unconditional loads from a clamped index, then a select)
+          const u32 v = ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask;
+          r[k] = (!PAD || el < ns) ? v : 0u;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const u32 el = k * A32_T + tid;
+          const u32 v = (w0[2 * (PAD ? (el < ns ? el : 0u) : el)] >> sh) & mask;
+          r[k] = (!PAD || el < ns) ? v : 0u;
+        }
+      }
     } else {
+      // rows of 2^15 coefficients: the head stage pairs coefficient el with el + 2^14 (both below 2^digit_bits):
+      //   sub-block 0: x + w y,  sub-block 1: x + 2p - w y   (below 4p), then the 2^14-point sub-transform with its twiddle slice
+      const Tw32 hw = hd.head[a];
+      const u32 g1 = g0 + 1;
+      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + ((two ? g1 : g0) >> 1)) * (i64)ds.n_src) << 1) + ((two ? g1 : g0) & 1);
+      auto digit = [&](u32 el) -> u32 {            // digit d of coefficient el (rows of 2^15: n_src = 2^15, no padding)
+        const u32 e = 2 * el;
+        return (two ? ((w0[e] >> sh) | (w1[e] << (32 - sh))) : (w0[e] >> sh)) & mask;
+      };
 #pragma unroll
-      for (int k = 0; k < 32; ++k) { const u32 el = k * A32_T + tid; r[k] = el < ns ? (w0[2 * el] >> sh) & mask : 0u; }
+      for (int k = 0; k < 32; ++k) {
+        const u32 el = k * A32_T + tid;
+        const u32 x = digit(el), t = mul_lazy32(digit(el + A32_N), hw, p);
+        r[k] = h == 0 ? x + t : x + 2 * p - t;
+      }
     }
   } else {
 #pragma unroll
@@ -354,7 +388,7 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ 
 #if defined(A32_ABLATE) && (A32_ABLATE & 4)
       if (v == 0x12345678u)
 #endif
-      (DIGITS ? rows + ((((i64)a << (A32_LOGN - 6)) + sl) * count + c) * 64 : g + sl * 64)[lane] = v;
+      (DIGITS ? rows + ((((i64)a << (A32_LOGN - 6 + S)) + ((i64)h << (A32_LOGN - 6)) + sl) * count + c) * 64 : g + sl * 64)[lane] = v;
     }
   }
 }
@@ -454,15 +488,15 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_inv_kernel(u32* __restrict__ r
 // ---- third form of the inverse transform: the mirror of ntt32_fwd_kernel3 (half-size LDS buffer, phase-B twiddles staged in LDS,
 // coalesced row loads through the wave's LDS rows); same input order, same output, same arithmetic as ntt32_inv_kernel.
 template <bool MONT>
-__global__ void __launch_bounds__(A32_T, 6) ntt32_inv_kernel3(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs) {
+__global__ void __launch_bounds__(A32_T, 6) ntt32_inv_kernel3(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs, int S) {
   __shared__ u32 lds[A32_HR * A32_P];
   __shared__ Tw32 tbl[992];
   const u32 tid = threadIdx.x;
   const i64 c = blockIdx.x % count;
-  const int slot = (int)(blockIdx.x / count), a = a0 + slot;
+  const int ps = (int)(blockIdx.x / count), slot = ps >> S, h = ps & ((1 << S) - 1), a = a0 + slot;
   const u32 p = pr.p[a];
-  const Tw32* __restrict__ tab = tabs + (i64)a * A32_N;
-  u32* __restrict__ g = rows + (c * nslots + slot) * A32_N;
+  const Tw32* __restrict__ tab = tabs + (((i64)a << S) + h) * A32_N;
+  u32* __restrict__ g = rows + (((c * nslots + slot) << S) + h) * A32_N;
   const u32 kq = tid >> 4, lo = tid & 15, wv = tid >> 6, sub = kq & 3, lane = tid & 63;
   const bool upper = kq >= A32_HR;
   tbl[tid] = tab[32 + tid];
@@ -572,36 +606,84 @@ __global__ void __launch_bounds__(A32_T, 6) ntt32_inv_kernel3(u32* __restrict__ 
   }
 }
 
+// rows of 2^15 elements, plain (non-digit) forward transform: the head stage in place before the sub-transforms (key-table build, self-test)
+__global__ void __launch_bounds__(256) ntt32_head_kernel(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, Aux32Head hd) {
+  const i64 row = blockIdx.y;
+  const int a = a0 + (int)(row % nslots);
+  const u32 p = pr.p[a];
+  u32* g = rows + row * 2 * A32_N;
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < A32_N; e += (i64)gridDim.x * blockDim.x) {
+    u32 x = g[e];
+    const u32 t = mul_lazy32(g[e + A32_N], hd.head[a], p);
+    x = x >= 2 * p ? x - 2 * p : x;
+    g[e] = x + t;
+    g[e + A32_N] = x + 2 * p - t;
+  }
+}
+// ... and the tail of the inverse: x[e] = (A + B) / 2, x[e + 2^14] = (A - B) psi^-brv(1) / 2 from the two sub-inverses (each already scaled by 2^-14)
+__global__ void __launch_bounds__(256) ntt32_tail_kernel(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, Aux32Head hd) {
+  const i64 row = blockIdx.y;
+  const int a = a0 + (int)(row % nslots);
+  const u32 p = pr.p[a];
+  u32* g = rows + row * 2 * A32_N;
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < A32_N; e += (i64)gridDim.x * blockDim.x) {
+    const u32 A = g[e], B = g[e + A32_N];          // both below p
+    u32 s0 = mul_lazy32(A + B, hd.tail_sum[a], p), s1 = mul_lazy32(A + p - B, hd.tail_dif[a], p);
+    g[e] = s0 >= p ? s0 - p : s0;
+    g[e + A32_N] = s1 >= p ? s1 - p : s1;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
-bool aux32_applies(const fhesi_ctx* ctx) { return (ctx->pow2 && ctx->logn == A32_LOGN) || ctx->lin_q != 0; }
+bool aux32_applies(const fhesi_ctx* ctx) { return (ctx->pow2 && (ctx->logn == A32_LOGN || ctx->logn == A32_LOGN + 1)) || ctx->lin_q != 0; }
+i64 aux32_row_len(const fhesi_ctx* ctx) { return (ctx->pow2 && ctx->logn == A32_LOGN + 1) ? 2 * (i64)A32_N : (i64)A32_N; }
 static int aux32_init(fhesi_ctx* ctx) {
   if (ctx->aux32) return 0;
-  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14 and for rings m = 2 * prime with 2 phi(m) - 1 <= 2^14");
+  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14, 2^15 and for rings m = 2 * prime with 2 phi(m) - 1 <= 2^14");
   fhesi_aux32* x = new fhesi_aux32();
-  // the four largest primes below 2^30 that are 1 mod 2^15 (= 2n)
+  const i64 n = aux32_row_len(ctx);                // 2^14, or 2^15 = two sub-transforms per row
+  const int S = n > A32_N ? 1 : 0, lg = A32_LOGN + S;
+  x->S = S;
+  // the four largest primes below 2^30 that are 1 mod 2n
   int found = 0;
-  for (u64 k = ((u64)1 << 15) - 1; k > 0 && found < 4; --k) {
-    const u64 cand = (k << 15) + 1;
+  for (u64 k = ((u64)1 << (29 - lg)) - 1; k > 0 && found < 4; --k) {
+    const u64 cand = (k << (lg + 1)) + 1;
     if (cand < ((u64)1 << 30) && hm::is_prime(cand)) x->pr.p[found++] = (u32)cand;
   }
   if (found < 4) { delete x; FHESI_FAIL("aux32: no primes"); }
-  std::vector<Tw32> hf((size_t)4 * A32_N), hi((size_t)4 * A32_N);
+  const size_t per_prime = (size_t)A32_N << S;
+  std::vector<Tw32> hf(4 * per_prime, Tw32{0, 0}), hi(4 * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n);
   for (int a = 0; a < 4; ++a) {
     const u64 p = x->pr.p[a];
     u64 psi = 0;
     for (u64 gq = 2; gq < 1000 && !psi; ++gq) {
-      const u64 cand = hm::powmod(gq, (p - 1) / (2 * A32_N), p);
-      if (hm::powmod(cand, A32_N, p) == p - 1) psi = cand;
+      const u64 cand = hm::powmod(gq, (p - 1) / (2 * (u64)n), p);
+      if (hm::powmod(cand, (u64)n, p) == p - 1) psi = cand;
     }
     if (!psi) { delete x; FHESI_FAIL("aux32: no 2n-th root"); }
     const u64 ipsi = hm::invmod(psi, p);
-    for (u64 idx = 0; idx < (u64)A32_N; ++idx) {
-      const u64 e = hm::brv(idx, A32_LOGN);
-      const u64 w = hm::powmod(psi, e, p), wi = hm::powmod(ipsi, e, p);
-      hf[(size_t)a * A32_N + idx] = Tw32{(u32)w, (u32)((w << 32) / p)};
-      hi[(size_t)a * A32_N + idx] = Tw32{(u32)wi, (u32)((wi << 32) / p)};
+    auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
+    for (u64 idx = 0; idx < (u64)n; ++idx) {       // the full table of the n-point transform: psi^brv(idx)
+      const u64 e = hm::brv(idx, lg);
+      ff[idx] = tw(hm::powmod(psi, e, p)); fi[idx] = tw(hm::powmod(ipsi, e, p));
     }
-    const u64 ninv = hm::invmod(A32_N % p, p);
+    if (!S) {
+      std::copy(ff.begin(), ff.end(), hf.begin() + (size_t)a * per_prime);
+      std::copy(fi.begin(), fi.end(), hi.begin() + (size_t)a * per_prime);
+    } else {
+      // sub-block h runs stage s >= 1 of the row on its groups i = h 2^(s-1) + i':  own index m' + i' (m' = 2^(s-1))  <->  2 m' + h m' + i'
+      for (int h = 0; h < 2; ++h)
+        for (u64 mp = 1; mp < (u64)A32_N; mp <<= 1)
+          for (u64 ip = 0; ip < mp; ++ip) {
+            hf[((size_t)a * 2 + h) * A32_N + mp + ip] = ff[2 * mp + h * mp + ip];
+            hi[((size_t)a * 2 + h) * A32_N + mp + ip] = fi[2 * mp + h * mp + ip];
+          }
+      const u64 inv2 = (p + 1) / 2;
+      x->hd.head[a] = ff[1];
+      x->hd.tail_sum[a] = tw(inv2);
+      x->hd.tail_dif[a] = tw(hm::mulmod(fi[1].w, inv2, p));
+    }
+    const u64 ninv = hm::invmod(A32_N % p, p);     // of the 2^14-point (sub-)transform; the tail of a 2^15-point row carries the other 1/2
     x->pr.ninv[a] = (u32)ninv;
     x->pr.ninv_p[a] = (u32)((ninv << 32) / p);
     x->pr.pinv64[a] = ~(u64)0 / p;
@@ -624,56 +706,77 @@ void aux32_free(fhesi_ctx* ctx) {
   ctx->aux32 = nullptr;
 }
 
+// rows: [count][nslots][row length]; row length = 2^14 << S.  The 2^15-point forms exist for the third-form kernels only.
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0) {
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
+  const fhesi_aux32* x = ctx->aux32;
+  const int S = x->S;
+  if (S && !ctx->opt.ntt32_v3) FHESI_FAIL("aux32: rows of 2^15 elements need option ntt32_v3");
+  if (S) {
+    ntt32_head_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
+    HIP_TRY(hipGetLastError());
+  }
   if (ctx->opt.ntt32_v3) {
-    PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false>);
-    ntt32_fwd_kernel3<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{});
+    if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 1>); ntt32_fwd_kernel3<false, 1><<<(unsigned)((count * nslots) << 1), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
+    else { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 0>); ntt32_fwd_kernel3<false, 0><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
     HIP_TRY(hipGetLastError());
     return 0;
   }
   PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel<false>);
-  ntt32_fwd_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{});
+  ntt32_fwd_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{});
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont) {
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
+  const fhesi_aux32* x = ctx->aux32;
+  const int S = x->S;
+  if (S && !ctx->opt.ntt32_v3) FHESI_FAIL("aux32: rows of 2^15 elements need option ntt32_v3");
   ProfScope prof(ctx, PROF_NTT_INV, (double)(count * nslots));
   if (ctx->opt.ntt32_v3) {
-    if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv); }
-    else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv); }
+    const unsigned grid = (unsigned)((count * nslots) << S);
+    if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S); }
+    else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S); }
     HIP_TRY(hipGetLastError());
+    if (S) {
+      ntt32_tail_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
+      HIP_TRY(hipGetLastError());
+    }
     return 0;
   }
   if (mont) {
     PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel<true>);
-    ntt32_inv_kernel<true><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv);
+    ntt32_inv_kernel<true><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv);
     HIP_TRY(hipGetLastError());
     return 0;
   }
   PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel<false>);
-  ntt32_inv_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, ctx->aux32->pr, ctx->aux32->d_inv);
+  ntt32_inv_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv);
   HIP_TRY(hipGetLastError());
   return 0;
 }
-// digit rows, tiled [4][n/64][npolys * nd][64] u32, straight from the scaled-down parts
+// digit rows, tiled [4][row length / 64][npolys * nd][64] u32, straight from the scaled-down parts
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out) {
   FHESI_TRY(aux32_init(ctx));
   if (!npolys) return 0;
+  const fhesi_aux32* x = ctx->aux32;
+  const int S = x->S;
+  if (S && !ctx->opt.ntt32_v3) FHESI_FAIL("aux32: rows of 2^15 elements need option ntt32_v3");
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * 4));
   ProfScope main_prof(ctx, PROF_NTT_FWD_DIGITS_MAIN, (double)(npolys * nd * 4));
   const i64 units = npolys * nd;
   if (ctx->opt.ntt32_v3) {
-    PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true>);
-    ntt32_fwd_kernel3<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd, (u32)ctx->phim});
+    const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim};
+    if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(((units + 7) / 8) * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+    else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+    else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
     HIP_TRY(hipGetLastError());
     return 0;
   }
   PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel<true>);
-  ntt32_fwd_kernel<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, ctx->aux32->pr, ctx->aux32->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd, (u32)ctx->phim});
+  ntt32_fwd_kernel<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd, (u32)ctx->phim});
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -681,14 +784,14 @@ const u32* aux32_primes(fhesi_ctx* ctx) { return aux32_init(ctx) ? nullptr : ctx
 
 // ---------------------------------------------------------------------------------------------- key table and dot product
 // kint [2*ncol][n][W]: the key's integer coefficients;  rows32[a][(l*2 + r)*ncol + k][n] = (limb l of B bits) mod p_a
-__global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __restrict__ kint, u32* __restrict__ rows32, int ncol, int NLB, int B, int W, Aux32Primes pr, i64 n_src) {
+__global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __restrict__ kint, u32* __restrict__ rows32, int ncol, int NLB, int B, int W, Aux32Primes pr, i64 n_src, i64 nrow) {
   const i64 row = blockIdx.y;                 // (r * ncol + k) * NLB + l
   const int l = (int)(row % NLB);
   const i64 rk = row / NLB;
   const int k = (int)(rk % ncol), r = (int)(rk / ncol);
   const int s = B * l, wd = s >> 6, bt = s & 63;
   const i64 rows_per_a = (i64)NLB * 2 * ncol;
-  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < A32_N; j += (i64)gridDim.x * blockDim.x) {
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < nrow; j += (i64)gridDim.x * blockDim.x) {
     const u64* x = kint + (rk * n_src + (j < n_src ? j : 0)) * W;          // key polynomials of n_src coefficients, zero above (linear convolution)
     auto word = [&](int i) -> u64 { return (i < W && j < n_src) ? x[i] : 0; };
     const u64 w0 = word(wd), w1 = word(wd + 1), w2 = word(wd + 2);
@@ -699,20 +802,20 @@ __global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __res
     for (int a = 0; a < 4; ++a) {
       const u64 p = pr.p[a];
       const u64 r64 = (u64)(((u128)1 << 64) % p);
-      rows32[((i64)a * rows_per_a + ((i64)l * 2 + r) * ncol + k) * A32_N + j] = (u32)((lo % p + (hi % p) * r64) % p);
+      rows32[((i64)a * rows_per_a + ((i64)l * 2 + r) * ncol + k) * nrow + j] = (u32)((lo % p + (hi % p) * r64) % p);
     }
   }
 }
 // rows of one prime [(l*2 + r)*ncol + k][n]  ->  tiled [l][slice][r][k][64]
-__global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict__ src, u32* __restrict__ dst, int ncol) {
+__global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict__ src, u32* __restrict__ dst, int ncol, i64 nrow) {
   const i64 row = blockIdx.y;
   const int k = (int)(row % ncol);
   const i64 lr = row / ncol;
   const int r = (int)(lr & 1);
   const i64 l = lr >> 1;
-  const i64 nsl = A32_N >> 6;
-  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < A32_N; j += (i64)gridDim.x * blockDim.x)
-    dst[((((l * nsl + (j >> 6)) * 2 + r) * ncol + k) << 6) + (j & 63)] = src[row * A32_N + j];
+  const i64 nsl = nrow >> 6;
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < nrow; j += (i64)gridDim.x * blockDim.x)
+    dst[((((l * nsl + (j >> 6)) * 2 + r) * ncol + k) << 6) + (j & 63)] = src[row * nrow + j];
 }
 
 // O[ct][r][l][a][slice] = sum_k D[ct][k][a][slice] * K[a][l][r][k][slice]  mod p_a.   One workgroup = a 64-element slice of CT
@@ -721,7 +824,7 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 // total with a carry counter, one reduction per output.
 template <int CT, int NW>
 __global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                        u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8) {
+                                                        u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */) {
   extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
   static_assert(CT % 4 == 0, "ciphertexts per tile in fours (16-byte LDS reads)");
   const u32 lane = threadIdx.x & 63;
@@ -736,7 +839,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ 
   const u32 p = pr.p[a], twop = 2 * p;
 #define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
   // tile load: the CT ciphertexts' ncol digit slices are one contiguous run of the tiled digit rows; CT wave-loads in flight per wave
-  const u32* dtile = dig + ((((i64)a << (A32_LOGN - 6)) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
+  const u32* dtile = dig + ((((i64)a << lognsl) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
   for (int k = w; k < ncol; k += NW) {            // (no division by the run-time column count in this loop: it would be scalar code per element)
     u32 v[CT];
 #pragma unroll
@@ -754,7 +857,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ 
   // one (limb, key row) pair per wave and pass; the 16 key words of the next column group are fetched while this one is multiplied
   for (int pr_i = w; pr_i < NLB * 2; pr_i += NW) {
     const int l = pr_i >> 1, r = pr_i & 1;
-    const u32* kp = k32 + ((((((i64)a * NLB + l) * (A32_N >> 6) + slice) * 2 + r) * ncol) << 6) + lane;
+    const u32* kp = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2 + r) * ncol) << 6) + lane;
     u64 tl[CT];
     u32 th[CT];
 #pragma unroll
@@ -806,7 +909,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ 
         u32 o = (u32)v;
         o = o >= twop ? o - twop : o;
         o = o >= p ? o - p : o;
-        (out + ((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) * A32_N + soff)[lane] = o;
+        (out + ((((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + soff))[lane] = o;
       }
     }
   }
@@ -821,7 +924,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ 
 // output and 16 columns.
 template <int CT, int NW>
 __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                         u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8) {
+                                                         u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */) {
   extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
   static_assert(CT % 4 == 0, "ciphertexts per tile in fours (16-byte LDS reads)");
   const u32 lane = threadIdx.x & 63;
@@ -835,7 +938,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
   const i64 ct0 = (i64)tile * CT;
   const u32 p = pr.p[a], twop = 2 * p;
 #define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
-  const u32* dtile = dig + ((((i64)a << (A32_LOGN - 6)) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
+  const u32* dtile = dig + ((((i64)a << lognsl) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
 #if !(defined(DOT32_ABLATE) && (DOT32_ABLATE & 4))   // ablation: no tile load
   for (int k = w; k < ncol; k += NW) {
     u32 v[CT];
@@ -854,7 +957,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
   const u64 r48 = pr.r48[a];
   const u32 mont = pr.mont[a];
   for (int l = w; l < NLB; l += NW) {
-    const u32* kp0 = k32 + ((((((i64)a * NLB + l) * (A32_N >> 6) + slice) * 2) * ncol) << 6) + lane;      // row r = 0; row 1 follows after ncol slices
+    const u32* kp0 = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + lane;      // row r = 0; row 1 follows after ncol slices
     const u32* kp1 = kp0 + ((i64)ncol << 6);
     u64 tot[2][CT];
     u32 th[2][CT];
@@ -925,7 +1028,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
           const u32 mq = (u32)v * mont;
           u32 o = (u32)((v + (u64)mq * p) >> 32);
           o = o >= p ? o - p : o;
-          (out + ((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) * A32_N + soff)[lane] = o;
+          (out + ((((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + soff))[lane] = o;
         }
       }
   }
@@ -935,18 +1038,18 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp) {
   FHESI_TRY(aux32_init(ctx));
   const int ncol = k->ncomp * k->ndigits;
-  const i64 rows_per_a = (i64)NLB * 2 * ncol;
+  const i64 rows_per_a = (i64)NLB * 2 * ncol, nrow = aux32_row_len(ctx);
   u32* rows32 = (u32*)k->d_aux;
-  if ((size_t)4 * rows_per_a * A32_N * 4 > k->aux_bytes) FHESI_FAIL("aux32: key table does not fit");
+  if ((size_t)4 * rows_per_a * nrow * 4 > k->aux_bytes) FHESI_FAIL("aux32: key table does not fit");
   dim3 grid(64, (unsigned)(2 * ncol * NLB));
-  ks32_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(d_kint, rows32, ncol, NLB, B, W, ctx->aux32->pr, ctx->phim);
+  ks32_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(d_kint, rows32, ncol, NLB, B, W, ctx->aux32->pr, ctx->phim, nrow);
   HIP_TRY(hipGetLastError());
-  for (int a = 0; a < 4; ++a) FHESI_TRY(launch_ntt32_fwd(ctx, rows32 + (i64)a * rows_per_a * A32_N, rows_per_a, 1, a));
+  for (int a = 0; a < 4; ++a) FHESI_TRY(launch_ntt32_fwd(ctx, rows32 + (i64)a * rows_per_a * nrow, rows_per_a, 1, a));
   for (int a = 0; a < 4; ++a) {
-    u32* q = rows32 + (i64)a * rows_per_a * A32_N;
-    HIP_TRY(hipMemcpyAsync(d_tmp, q, (size_t)rows_per_a * A32_N * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    u32* q = rows32 + (i64)a * rows_per_a * nrow;
+    HIP_TRY(hipMemcpyAsync(d_tmp, q, (size_t)rows_per_a * nrow * 4, hipMemcpyDeviceToDevice, ctx->stream));
     dim3 g2(64, (unsigned)rows_per_a);
-    ks32_retile_kernel<<<g2, 256, 0, ctx->stream>>>((const u32*)d_tmp, q, ncol);
+    ks32_retile_kernel<<<g2, 256, 0, ctx->stream>>>((const u32*)d_tmp, q, ncol, nrow);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -962,12 +1065,14 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done |= 1ull << ctx->device;
   }
-  const int ntiles = (int)((count + CT - 1) / CT), nsl8 = A32_N / 64 / 8;
+  const i64 nrow = aux32_row_len(ctx);
+  const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
+  const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
   const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
   prof_kernel(ctx, PROF_DOT, fn);
-  if (V2) dot32_kernel2<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
-  else dot32_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8);
+  if (V2) dot32_kernel2<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl);
+  else dot32_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -982,44 +1087,45 @@ int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol,
 
 // Self-test (tests/test_gpu_ntt.py): the transform pair is a ring isomorphism of Z_p[X]/(X^n + 1) -- it is linear by construction, so
 // checking that monomials multiply like monomials (X^i X^j = +-X^(i+j mod n)) and that inverse(forward(x)) = x pins it.
-__global__ void aux32_pointwise_kernel(u32* __restrict__ a, const u32* __restrict__ b, u32 p) {
+__global__ void aux32_pointwise_kernel(u32* __restrict__ a, const u32* __restrict__ b, u32 p, i64 n) {
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < A32_N) a[j] = (u32)(((u64)a[j] * b[j]) % p);
+  if (j < n) a[j] = (u32)(((u64)a[j] * b[j]) % p);
 }
 extern "C" int fhesi_selftest_aux32(fhesi_ctx* c) {
   if (!c) FHESI_FAIL("null context");
   HIP_TRY(hipSetDevice(c->device));
   FHESI_TRY(aux32_init(c));
+  const i64 N = aux32_row_len(c);
   u32 *da, *db;
-  HIP_TRY(hipMalloc(&da, A32_N * 4)); HIP_TRY(hipMalloc(&db, A32_N * 4));
-  std::vector<u32> ha(A32_N), hb(A32_N), hr(A32_N);
+  HIP_TRY(hipMalloc(&da, N * 4)); HIP_TRY(hipMalloc(&db, N * 4));
+  std::vector<u32> ha(N), hb(N), hr(N);
   int rc = 0;
-  const int pairs[6][2] = {{0, 0}, {1, 2}, {5, 16383}, {16383, 16383}, {8192, 8192}, {4097, 12500}};
+  const i64 pairs[6][2] = {{0, 0}, {1, 2}, {5, N - 1}, {N - 1, N - 1}, {N / 2, N / 2}, {N / 4 + 1, 3 * (N / 4) + 212}};
   for (int a = 0; a < 4 && !rc; ++a) {
     const u32 p = c->aux32->pr.p[a];
     for (int t = 0; t < 6 && !rc; ++t) {
       std::fill(ha.begin(), ha.end(), 0); std::fill(hb.begin(), hb.end(), 0);
       ha[pairs[t][0]] = 3; hb[pairs[t][1]] = 5;
-      hipMemcpy(da, ha.data(), A32_N * 4, hipMemcpyHostToDevice); hipMemcpy(db, hb.data(), A32_N * 4, hipMemcpyHostToDevice);
+      HIP_TRY(hipMemcpy(da, ha.data(), N * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
       if (launch_ntt32_fwd(c, da, 1, 1, a) || launch_ntt32_fwd(c, db, 1, 1, a)) { rc = 1; break; }
-      aux32_pointwise_kernel<<<A32_N / 256, 256, 0, c->stream>>>(da, db, p);
+      aux32_pointwise_kernel<<<(unsigned)(N / 256), 256, 0, c->stream>>>(da, db, p, N);
       if (launch_ntt32_inv(c, da, 1, 1, a, false)) { rc = 1; break; }
-      hipStreamSynchronize(c->stream);
-      hipMemcpy(hr.data(), da, A32_N * 4, hipMemcpyDeviceToHost);
-      const int e = pairs[t][0] + pairs[t][1];
-      const int pos = e % A32_N;
-      const u32 want = e >= A32_N ? p - 15 : 15;
-      for (int j = 0; j < A32_N; ++j)
-        if (hr[j] != (j == pos ? want : 0u)) { fhesi_set_error("aux32 self-test: prime %d, X^%d * X^%d: coefficient %d is %u", a, pairs[t][0], pairs[t][1], j, hr[j]); rc = 1; break; }
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipMemcpy(hr.data(), da, N * 4, hipMemcpyDeviceToHost));
+      const i64 e = pairs[t][0] + pairs[t][1];
+      const i64 pos = e % N;
+      const u32 want = e >= N ? p - 15 : 15;
+      for (i64 j = 0; j < N; ++j)
+        if (hr[j] != (j == pos ? want : 0u)) { fhesi_set_error("aux32 self-test: prime %d, X^%lld * X^%lld: coefficient %lld is %u", a, (long long)pairs[t][0], (long long)pairs[t][1], (long long)j, hr[j]); rc = 1; break; }
     }
     // round trip of a dense vector
     if (!rc) {
-      for (int j = 0; j < A32_N; ++j) ha[j] = (u32)((1234567u * (u32)j + 89u) % p);
-      hipMemcpy(da, ha.data(), A32_N * 4, hipMemcpyHostToDevice);
+      for (i64 j = 0; j < N; ++j) ha[j] = (u32)((1234567u * (u32)j + 89u) % p);
+      HIP_TRY(hipMemcpy(da, ha.data(), N * 4, hipMemcpyHostToDevice));
       if (launch_ntt32_fwd(c, da, 1, 1, a) || launch_ntt32_inv(c, da, 1, 1, a, false)) rc = 1;
-      hipStreamSynchronize(c->stream);
-      hipMemcpy(hr.data(), da, A32_N * 4, hipMemcpyDeviceToHost);
-      for (int j = 0; j < A32_N && !rc; ++j) if (hr[j] != ha[j]) { fhesi_set_error("aux32 self-test: prime %d, round trip differs at %d", a, j); rc = 1; }
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipMemcpy(hr.data(), da, N * 4, hipMemcpyDeviceToHost));
+      for (i64 j = 0; j < N && !rc; ++j) if (hr[j] != ha[j]) { fhesi_set_error("aux32 self-test: prime %d, round trip differs at %lld", a, (long long)j); rc = 1; }
     }
   }
   hipFree(da); hipFree(db);

@@ -846,7 +846,7 @@ int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, 
   const u128 half = (A - 1) / 2;
   const int W = t->W;
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
-  const i64 nrow = k->aux32 ? kAux32N : ctx->phim;
+  const i64 nrow = k->aux32 ? aux32_row_len(ctx) : ctx->phim;
 #define KS_GEN(MAXW, A32) ks_recombine_generic_kernel<MAXW, A32><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, nrow, k->aux_fold, W, k->aux_logQ, k->aux_limb_bits, k->aux_rows, q0, q1, inv, hm::shoup(inv, q1), \
       (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, k->d_limb_consts, t->d_P + (size_t)t->nidx * t->W, t->d_halfP, d_out, nl_out, gc)
   if (W <= 20) { if (k->aux32) KS_GEN(20, true); else KS_GEN(20, false); }

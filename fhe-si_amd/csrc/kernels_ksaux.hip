@@ -344,7 +344,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
   const int R = limb ? plan.NLB : L;                          // output rows per (ciphertext, key row, auxiliary prime)
   {
     // table size: residue / limb rows for two 8-byte (or four 4-byte) auxiliary residues; 2^14-element rows on the linear-convolution rings
-    const size_t need = (size_t)2 * R * 2 * ncol * (plan.a32 && limb ? kAux32N : n) * 8;
+    const size_t need = (size_t)2 * R * 2 * ncol * (plan.a32 && limb ? aux32_row_len(ctx) : n) * 8;
     if (k->d_aux && k->aux_bytes < need) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(k->d_aux)); k->d_aux = nullptr; }
     if (!k->d_aux) { HIP_TRY(hipMalloc(&k->d_aux, need)); k->aux_bytes = need; }
   }
@@ -358,7 +358,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   void* tmp;
-  FHESI_TRY(ws_reserve(ctx, 0, std::max(k->bytes, (size_t)R * 2 * ncol * kAux32N * 4), &tmp));      // the key rows, later one auxiliary prime's table rows
+  FHESI_TRY(ws_reserve(ctx, 0, std::max(k->bytes, (size_t)R * 2 * ncol * aux32_row_len(ctx) * 4), &tmp));      // the key rows, later one auxiliary prime's table rows
   HIP_TRY(hipMemcpyAsync(tmp, k->d_rows, k->bytes, hipMemcpyDeviceToDevice, ctx->stream));
   if (ctx->pow2) FHESI_TRY(launch_ntt_inv(ctx, (u64*)tmp, 2 * ncol, L, nullptr, true));
   else FHESI_TRY(launch_bluestein_inv(ctx, (u64*)tmp, 2 * ncol, L, all.data()));          // Cmod::iFFT of every key row on a general-m ring

@@ -61,9 +61,11 @@ def test_cmod_fft_single_row_bigint():
         assert np.array_equal(ctx.cmod_ifft(i, y[i]), orc.cmod_ifft(i, y[i]))
 
 
-def test_aux32_transforms_are_a_ring_isomorphism():
-    """The key switch's 32-bit auxiliary transforms (kernels_aux32.hip, n = 2^14, four primes below 2^30): monomials multiply like
-    monomials in Z_p[X]/(X^n + 1) (with the sign of the wrap) and inverse(forward(x)) = x -- checked inside the library."""
-    primes, roots = P.chain_for(1 << 15, 128, 23)
-    ctx = F.Context(1 << 15, primes, roots)
+@pytest.mark.parametrize("m", [1 << 15, 1 << 16, 1006])
+def test_aux32_transforms_are_a_ring_isomorphism(m):
+    """The key switch's 32-bit auxiliary transforms (kernels_aux32.hip, four primes below 2^30; rows of 2^14 elements for n = 2^14 and
+    for the linear-convolution rings, rows of 2^15 = head stage + two sub-transforms for n = 2^15): monomials multiply like monomials in
+    Z_p[X]/(X^N + 1) (with the sign of the wrap) and inverse(forward(x)) = x -- checked inside the library."""
+    primes, roots = P.chain_for(m, 128, 23)
+    ctx = F.Context(m, primes, roots)
     ctx.selftest_aux32()

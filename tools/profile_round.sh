@@ -23,7 +23,7 @@ done
 F=$(find "$O/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 W=$(find "$O/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "dot32_kernel2<8, 16>" "$O/pmc_dot_aux.json" ciphertexts_per_launch=64
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true>" "$O/pmc_ntt_fwd.json" rows_per_launch=16896
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true, 0>" "$O/pmc_ntt_fwd.json" rows_per_launch=16896
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt_fwd_tile<14, false, 0, false>" "$O/pmc_ntt64_fwd.json" rows_per_launch=4608
 find "$O" -name '*.db' -delete; find "$O" -name '*agent_info.csv' -delete; find "$O" -name '*kernel_trace.csv' -delete; find "$O" -name '*counter_collection.csv' -delete
 ls -la "$O"
