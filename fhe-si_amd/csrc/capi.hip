@@ -306,6 +306,7 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   for (auto& kv : c->pow64_cache) hipFree(kv.second);
   for (auto& kv : c->scalar_cache) hipFree(kv.second);
   aux32_free(c);
+  tensor32_free(c);
   for (int i = 0; i < FHESI_WS_SLOTS; ++i) if (c->lane_ws[i]) hipFree(c->lane_ws[i]);
   if (c->lane_stream) hipStreamDestroy(c->lane_stream);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -1580,9 +1581,19 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
   const i64 chunk = batch_chunk(c, 3 * k->ndigits);
   for (i64 done = 0; done < count; done += chunk) {
     const i64 cnt = std::min(chunk, count - done);
+    const size_t off = (size_t)done * 2 * n * nlimbs;
+    if (k->ncomp == 3 && tensor32_applies(c, p, nlimbs, logQ)) {
+      // tProd is not visible from here: its integers are formed over primes below 2^30 (kernels_tensor32.hip), straight to the scaled-down parts
+      FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
+      void *d_parts, *d_t2;
+      FHESI_TRY(ws_reserve(c, 2, (size_t)cnt * 3 * ((logQ + 63) / 64) * n * 8, &d_parts));
+      FHESI_TRY(launch_tensor32(c, p, a + off, b + off, nlimbs, logQ, cnt, (u64*)d_parts));
+      FHESI_TRY(ws_reserve(c, 3, (size_t)cnt * 2 * L * n * 8, &d_t2));
+      FHESI_TRY(key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, cnt, (u64*)d_t2, out + off, nlimbs));
+      continue;
+    }
     void* d_tp;
     FHESI_TRY(ws_reserve(c, 5, (size_t)cnt * 3 * L * n * 8, &d_tp));
-    const size_t off = (size_t)done * 2 * n * nlimbs;
     FHESI_TRY(fhesi_ct_mul_dev(c, p, a + off, b + off, nlimbs, cnt, (uint64_t*)d_tp));
     FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
     FHESI_TRY(apply_key_switch_consume(c, k, logQ, decomp_bytes, (u64*)d_tp, cnt, out + off, nlimbs));      // the chunk's tProd is ours: no copy

@@ -116,6 +116,7 @@ struct fhesi_ctx {
   int* d_zms_list = nullptr;           // [phim] ascending elements of Z_m^*
   BluesteinTables* blue = nullptr;
   fhesi_aux32* aux32 = nullptr;
+  struct fhesi_tensor32* tensor32 = nullptr;     // tables of the 30-bit tensor half (kernels_tensor32.hip), built on first use
   std::map<std::vector<int>, CrtTables*> crt_cache;
   std::map<int, Shoup2*> pow64_cache;  // nlimbs -> device [L][nlimbs+1] table for rns_reduce
   std::map<std::vector<u64>, u64*> scalar_cache;   // rns_reduce lift scalars (per-slot residues), keyed by the scalar list
@@ -168,6 +169,10 @@ struct KsLimbPlan { int W = 0, LQ = 0, B = 0, NLB = 0, mbits = 0; bool a32 = fal
 bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan, const u32* p32 /* the 30-bit primes, or null */);
 int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o /* [npolys][aux_rows][2][n] */, i64 npolys, u64* d_out, int nl_out);
 void aux32_free(fhesi_ctx* ctx);
+// the tensor half of the fused multiplication over primes below 2^30 (kernels_tensor32.hip)
+void tensor32_free(fhesi_ctx* ctx);
+bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ);
+int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts /* [count*3][logQ/64][n] */);
 const u32* aux32_primes(fhesi_ctx* ctx);          // the four primes (host array), nullptr on error
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */);

@@ -15,52 +15,7 @@
 // The recombination (Garner over the four residues, then exactly as ks_recombine_kernel) is in kernels_crt.hip.
 #include "fhesi_internal.h"
 
-struct Tw32 { u32 w, wp; };          // constant and floor(w 2^32 / p)
-struct Aux32Primes { u32 p[4]; u32 ninv[4], ninv_p[4]; u64 pinv64[4] /* floor((2^64 - 1) / p) */, r64[4] /* 2^64 mod p */, r48[4] /* 2^48 mod p */;
-                     u32 mont[4] /* -p^-1 mod 2^32 */, ninv_m[4], ninv_m_p[4] /* n^-1 2^32 mod p and its quotient: undoes the 2^-32 of dot32_kernel2's Montgomery step */; };
-
-// n = 2^15 (S = 1): one head stage (distance 2^14, a single twiddle per prime) in front of two independent 2^14-point sub-transforms
-// with their own twiddle slices -- the structure of the 64-bit path (ntt_tile.inc); sub-row h of a row holds the evaluations of sub-block h.
-struct Aux32Head { Tw32 head[4], tail_sum[4], tail_dif[4]; };      // psi^brv(1);  1/2 and psi^-brv(1) / 2  (the tail of the inverse)
-struct fhesi_aux32 {
-  Aux32Primes pr;
-  Aux32Head hd;
-  int S = 0;                           // log2 of the sub-transforms per row (0: rows of 2^14 elements, 1: rows of 2^15)
-  Tw32* d_fwd = nullptr;               // [4][2^S][2^14]  psi^brv(idx), idx = m + i (stage with m groups, group i), per sub-block
-  Tw32* d_inv = nullptr;               // [4][2^S][2^14]  the inverses
-};
-
-static constexpr int A32_LOGN = 14, A32_N = 1 << A32_LOGN, A32_T = 512, A32_P = 592;      // LDS stride of a 512-element sub-problem (padded)
-__device__ __forceinline__ u32 a32_f(u32 t_id) { return t_id + ((t_id >> 5) << 2); }       // position inside a sub-problem (4 pad words per 32)
-#if defined(A32_FUSED_MAD)
-// y w - floor(y wp / 2^32) p as  lo32(Q * (-p) + y w): the multiply-add replaces a multiply and a subtract
-__device__ __forceinline__ u32 mul_lazy32(u32 y, Tw32 t, u32 p) {
-  const u32 Q = __umulhi(y, t.wp), yw = y * t.w, np = 0u - p;
-  u64 r;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(Q), "v"(np), "v"((u64)yw) : "vcc");
-  return (u32)r;
-}
-#else
-__device__ __forceinline__ u32 mul_lazy32(u32 y, Tw32 t, u32 p) { return y * t.w - __umulhi(y, t.wp) * p; }     // y any 32-bit value -> [0, 2p)
-#endif
-__device__ __forceinline__ int a32_bfly_k(int b, int h) { return ((b / h) * 2 * h) + (b % h); }
-// Cooley-Tukey butterfly on lazy values (below 4p < 2^32):  X' = X + w Y,  Y' = X - w Y
-__device__ __forceinline__ void a32_ct(u32& x, u32& y, Tw32 t, u32 p) {
-  const u32 twop = 2 * p;
-  const u32 X = x >= twop ? x - twop : x;
-  const u32 T = mul_lazy32(y, t, p);
-  x = X + T;
-  y = X - T + twop;
-}
-// Gentleman-Sande butterfly on values below 2p:  X' = X + Y,  Y' = (X - Y) w
-__device__ __forceinline__ void a32_gs(u32& x, u32& y, Tw32 t, u32 p) {
-  const u32 twop = 2 * p;
-  const u32 s = x + y, d = x - y + twop;
-  x = s >= twop ? s - twop : s;
-  y = mul_lazy32(d, t, p);
-}
-
-struct Dig32Src { const u64* parts; int nl, digit_bits, nd; u32 n_src; };     // limb-major scaled-down parts [npolys][nl][n_src]; elements from n_src upwards are zero (n_src < 2^14: linear convolution)
+#include "ntt32_core.inc"
 
 // rows: [count][nslots][n] u32; block rb -> (unit c = rb % count, slot = rb / count), prime a0 + slot.
 // DIGITS: unit c = poly * nd + digit, the values are cut out of the parts (ByteDecomp, Ciphertext.cpp:82-105); output lazy (below 4p).
@@ -187,211 +142,6 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ r
   }
 }
 
-// ---- third form of the forward transform: the same butterflies and the same output order, laid out for THREE workgroups per CU.
-// The row passes through an LDS buffer of HALF its size (16 sub-problem rows, 37.9 KB):
-//   exchange 1 (across the workgroup) in two passes -- registers 0..15 of every thread, read by the threads of sub-problems 0..15
-//   (waves 0..3), then registers 16..31 through the same rows for waves 4..7;
-//   exchange 2 stays inside a wave (the 16 threads of a sub-problem only trade among themselves): every wave owns two rows and
-//   moves its four sub-problems through them two at a time, with wave-level ordering only (LDS operations of a wave execute in order).
-// Twiddles are fetched stage by stage instead of far ahead, which keeps the kernel below 80 registers (6 waves per SIMD).
-static constexpr int A32_HR = 16;                   // rows of the half buffer
-#if defined(A32_ABLATE) && (A32_ABLATE & 1)
-#define A32_TW(x) Tw32{12345u + tid, 678901u}
-#else
-#define A32_TW(x) (x)
-#endif
-// PAD: the source polynomials have fewer than 2^14 coefficients (linear-convolution rings): elements from n_src upwards are zero
-template <bool DIGITS, int S, bool PAD = false>
-__global__ void __launch_bounds__(A32_T, 6) ntt32_fwd_kernel3(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs,
-                                                              Dig32Src ds, Aux32Head hd) {
-  __shared__ u32 lds[A32_HR * A32_P];
-  __shared__ Tw32 tbl[992];                        // the prime's phase-B twiddles (entries 32..1023): 16 threads share each, so they are staged once per row
-  const u32 tid = threadIdx.x;
-  i64 c = blockIdx.x % count;
-  int ps = (int)(blockIdx.x / count);             // (prime slot, sub-block)
-  if (DIGITS) {
-    // the transforms of a digit polynomial (4 primes x 2^S sub-blocks) read the same source words: keep them on one XCD (block ids 8 apart)
-    const u32 bid = blockIdx.x;
-    ps = (int)((bid >> 3) & ((4u << S) - 1));
-    c = (i64)(bid >> (5 + S)) * 8 + (bid & 7);
-    if (c >= count) return;
-  }
-  const int slot = ps >> S, h = ps & ((1 << S) - 1);
-  const int a = a0 + slot;
-  const u32 p = pr.p[a];
-  const Tw32* __restrict__ tab = tabs + (((i64)a << S) + h) * A32_N;
-  u32* __restrict__ g = rows + ((((c * nslots + slot)) << S) + h) * A32_N;
-  tbl[tid] = tab[32 + tid];                        // (visible to everyone after the first barrier of exchange 1)
-  if (tid < 992 - 512) tbl[512 + tid] = tab[32 + 512 + tid];
-  u32 r[32];
-#if defined(A32_ABLATE) && (A32_ABLATE & 8)
-#pragma unroll
-  for (int k = 0; k < 32; ++k) r[k] = tid * (k + 1) + (u32)c;
-  if (false) {
-#else
-  if (DIGITS) {
-#endif
-    const u32 d = (u32)(c % ds.nd);
-    const i64 poly = c / ds.nd;
-    const u32 bit = d * (u32)ds.digit_bits, g0 = bit >> 5, sh = bit & 31;
-    const u32 mask = (1u << ds.digit_bits) - 1;
-    const u32* __restrict__ p32 = reinterpret_cast<const u32*>(ds.parts);
-    const u32* __restrict__ w0 = p32 + (((poly * ds.nl + (g0 >> 1)) * (i64)ds.n_src) << 1) + (g0 & 1);
-    const bool two = (sh + ds.digit_bits > 32) && (int)((g0 + 1) >> 1) < ds.nl;
-    const u32 ns = ds.n_src;
-    if (S == 0) {
-      if (two) {
-        const u32 g1 = g0 + 1;
-        const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) * (i64)ds.n_src) << 1) + (g1 & 1);
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          const u32 el = k * A32_T + tid, e = 2 * (PAD ? (el < ns ? el : 0u) : el);        // (unconditional loads from a clamped index, then a select)
-          const u32 v = ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask;
-          r[k] = (!PAD || el < ns) ? v : 0u;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          const u32 el = k * A32_T + tid;
-          const u32 v = (w0[2 * (PAD ? (el < ns ? el : 0u) : el)] >> sh) & mask;
-          r[k] = (!PAD || el < ns) ? v : 0u;
-        }
-      }
-    } else {
-      // rows of 2^15 coefficients: the head stage pairs coefficient el with el + 2^14 (both below 2^digit_bits):
-      //   sub-block 0: x + w y,  sub-block 1: x + 2p - w y   (below 4p), then the 2^14-point sub-transform with its twiddle slice
-      const Tw32 hw = hd.head[a];
-      const u32 g1 = g0 + 1;
-      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + ((two ? g1 : g0) >> 1)) * (i64)ds.n_src) << 1) + ((two ? g1 : g0) & 1);
-      auto digit = [&](u32 el) -> u32 {            // digit d of coefficient el (rows of 2^15: n_src = 2^15, no padding)
-        const u32 e = 2 * el;
-        return (two ? ((w0[e] >> sh) | (w1[e] << (32 - sh))) : (w0[e] >> sh)) & mask;
-      };
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const u32 el = k * A32_T + tid;
-        const u32 x = digit(el), t = mul_lazy32(digit(el + A32_N), hw, p);
-        r[k] = h == 0 ? x + t : x + 2 * p - t;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 32; ++k) r[k] = g[k * A32_T + tid];
-  }
-  // phase A: element e = k * 512 + tid; distances 16, 8, 4, 2, 1 in k; twiddles depend on the register index only
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int h = 16 >> s;
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int k = a32_bfly_k(b, h);
-      a32_ct(r[k], r[k + h], A32_TW(tab[(1 << s) + (k >> (5 - s))]), p);
-    }
-  }
-  const u32 kq = tid >> 4, lo = tid & 15;          // sub-problem and position inside a group of 16 (after the first exchange)
-  const bool upper = kq >= A32_HR;                 // waves 4..7
-#if !(defined(A32_ABLATE) && (A32_ABLATE & 2))
-  // exchange 1, first pass: registers 0..15 -> rows 0..15, read by sub-problems 0..15
-#pragma unroll
-  for (int k = 0; k < 16; ++k) lds[k * A32_P + a32_f(tid)] = r[k];
-  __syncthreads();
-  u32 t[16];                                       // the upper half keeps its registers 16..31 aside while the lower half reads
-#pragma unroll
-  for (int k = 0; k < 16; ++k) t[k] = r[16 + k];
-  if (!upper) {
-#pragma unroll
-    for (int k2 = 0; k2 < 32; ++k2) r[k2] = lds[kq * A32_P + a32_f(k2 * 16 + lo)];
-  }
-  __syncthreads();
-  // second pass: registers 16..31 (in t) -> the same rows, read by sub-problems 16..31
-#pragma unroll
-  for (int k = 0; k < 16; ++k) lds[k * A32_P + a32_f(tid)] = t[k];
-  __syncthreads();
-  if (upper) {
-#pragma unroll
-    for (int k2 = 0; k2 < 32; ++k2) r[k2] = lds[(kq - A32_HR) * A32_P + a32_f(k2 * 16 + lo)];
-  }
-#endif
-  // phase B: sub-problem kq (512 elements t = k2 * 16 + lo); distances 16 .. 1 in k2; the 2^u twiddles of stage u fetched at the stage
-#pragma unroll
-  for (int u = 0; u < 5; ++u) {
-    const int h = 16 >> u;
-    Tw32 tb[16];
-#pragma unroll
-    for (int i = 0; i < (1 << u); ++i) tb[i] = A32_TW(tbl[(32 << u) - 32 + (kq << u) + i]);
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int k2 = a32_bfly_k(b, h);
-      a32_ct(r[k2], r[k2 + h], tb[k2 >> (5 - u)], p);
-    }
-  }
-#if !(defined(A32_ABLATE) && (A32_ABLATE & 2))
-  __syncthreads();                                 // every read of exchange 1 is done: the rows change owner
-  // exchange 2 inside the wave: rows 2w, 2w + 1; sub-problems (kq & 3) = 0, 1 first, then 2, 3
-  const u32 wv = tid >> 6, sub = kq & 3;
-  u32* __restrict__ row = lds + (2 * wv + (sub & 1)) * A32_P;
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    if ((int)(sub >> 1) == hh) {
-#pragma unroll
-      for (int k2 = 0; k2 < 32; ++k2) row[a32_f(k2 * 16 + lo)] = r[k2];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if ((int)(sub >> 1) == hh) {
-#pragma unroll
-      for (int i = 0; i < 32; ++i) r[i] = row[lo * 36 + i];
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-#endif
-  // phase C: this thread holds the groups k2 = 2 lo, 2 lo + 1 (32 consecutive elements); distances 8 .. 1 inside a group
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int h = 8 >> v;
-    Tw32 tc[2][8];
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-      for (int i = 0; i < (1 << v); ++i) tc[gq][i] = A32_TW(tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i]);
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int x = a32_bfly_k(b, h);
-        a32_ct(r[gq * 16 + x], r[gq * 16 + x + h], tc[gq][x >> (4 - v)], p);
-      }
-    }
-  }
-  // Store through the wave's two LDS rows so that every store instruction writes one whole 64-element slice (256 contiguous bytes):
-  // a thread holds 32 consecutive elements, i.e. half a slice; the wave's 32 slices go out 16 at a time.  Slice t of the half sits at
-  // [t * 72, t * 72 + 72): its two halves 36 words apart (the stride of exchange 2: conflict-free 16-byte writes, consecutive 4-byte reads).
-  const u32 lane = tid & 63;
-  u32* __restrict__ stage = lds + 2 * wv * A32_P;                  // 2 * 592 = 1184 words >= 16 * 72
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    __builtin_amdgcn_wave_barrier();
-    if ((int)(sub >> 1) == hh) {
-      u32* w = stage + ((sub & 1) * 8 + (lo >> 1)) * 72 + (lo & 1) * 36;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        u32 v = r[i];
-        if (!DIGITS) { const u32 twop = 2 * p; v = v >= twop ? v - twop : v; v = v >= p ? v - p : v; }
-        w[i] = v;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const u32 pos = lane < 32 ? lane : lane + 4;                   // 36 + (lane - 32)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const u32 v = stage[t * 72 + pos];
-      const u32 sl = (4 * wv + 2 * hh + (t >> 3)) * 8 + (t & 7);    // slice of the row: sub-problem kq' = 4 wv + 2 hh + (t >> 3), pair (t & 7)
-#if defined(A32_ABLATE) && (A32_ABLATE & 4)
-      if (v == 0x12345678u)
-#endif
-      (DIGITS ? rows + ((((i64)a << (A32_LOGN - 6 + S)) + ((i64)h << (A32_LOGN - 6)) + sl) * count + c) * 64 : g + sl * 64)[lane] = v;
-    }
-  }
-}
 
 // the mirror: input in the forward transform's output order (values below 2p), output natural order, scaled by 1/n, reduced
 // MONT: the input carries a factor 2^-32 (dot32_kernel2's Montgomery step); the final constant is n^-1 2^32 instead of n^-1
@@ -485,126 +235,6 @@ __global__ void __launch_bounds__(A32_T, 2) ntt32_inv_kernel(u32* __restrict__ r
   }
 }
 
-// ---- third form of the inverse transform: the mirror of ntt32_fwd_kernel3 (half-size LDS buffer, phase-B twiddles staged in LDS,
-// coalesced row loads through the wave's LDS rows); same input order, same output, same arithmetic as ntt32_inv_kernel.
-template <bool MONT>
-__global__ void __launch_bounds__(A32_T, 6) ntt32_inv_kernel3(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs, int S) {
-  __shared__ u32 lds[A32_HR * A32_P];
-  __shared__ Tw32 tbl[992];
-  const u32 tid = threadIdx.x;
-  const i64 c = blockIdx.x % count;
-  const int ps = (int)(blockIdx.x / count), slot = ps >> S, h = ps & ((1 << S) - 1), a = a0 + slot;
-  const u32 p = pr.p[a];
-  const Tw32* __restrict__ tab = tabs + (((i64)a << S) + h) * A32_N;
-  u32* __restrict__ g = rows + (((c * nslots + slot) << S) + h) * A32_N;
-  const u32 kq = tid >> 4, lo = tid & 15, wv = tid >> 6, sub = kq & 3, lane = tid & 63;
-  const bool upper = kq >= A32_HR;
-  tbl[tid] = tab[32 + tid];
-  if (tid < 992 - 512) tbl[512 + tid] = tab[32 + 512 + tid];
-  u32 r[32];
-  // load: every instruction reads one whole 64-element slice; through the wave's two LDS rows each thread ends up with its 32
-  // consecutive elements (the reverse of the forward kernel's store)
-  u32* __restrict__ stage = lds + 2 * wv * A32_P;
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    const u32 pos = lane < 32 ? lane : lane + 4;
-    u32 v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = g[((4 * wv + 2 * hh + (t >> 3)) * 8 + (t & 7)) * 64 + lane];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) stage[t * 72 + pos] = v[t];
-    __builtin_amdgcn_wave_barrier();
-    if ((int)(sub >> 1) == hh) {
-      const u32* w = stage + ((sub & 1) * 8 + (lo >> 1)) * 72 + (lo & 1) * 36;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) r[i] = w[i];
-    }
-  }
-  // phase C (mirror): distances 1 .. 8 inside the two groups of 16; per-lane twiddles fetched stage by stage
-#pragma unroll
-  for (int v = 3; v >= 0; --v) {
-    const int h = 8 >> v;
-    Tw32 tc[2][8];
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-      for (int i = 0; i < (1 << v); ++i) tc[gq][i] = tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i];
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int x = a32_bfly_k(b, h);
-        a32_gs(r[gq * 16 + x], r[gq * 16 + x + h], tc[gq][x >> (4 - v)], p);
-      }
-    }
-  }
-  // exchange 2 (mirror) inside the wave, two sub-problems at a time through the wave's two rows
-  {
-    u32* __restrict__ row = lds + (2 * wv + (sub & 1)) * A32_P;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      __builtin_amdgcn_wave_barrier();
-      if ((int)(sub >> 1) == hh) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) row[lo * 36 + i] = r[i];
-      }
-      __builtin_amdgcn_wave_barrier();
-      if ((int)(sub >> 1) == hh) {
-#pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) r[k2] = row[a32_f(k2 * 16 + lo)];
-      }
-    }
-  }
-  __syncthreads();                                 // the phase-B table is complete (and the rows change owner below)
-  // phase B (mirror): twiddles from the LDS table
-#pragma unroll
-  for (int u = 4; u >= 0; --u) {
-    const int h = 16 >> u;
-    Tw32 tb[16];
-#pragma unroll
-    for (int i = 0; i < (1 << u); ++i) tb[i] = tbl[(32 << u) - 32 + (kq << u) + i];
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int k2 = a32_bfly_k(b, h);
-      a32_gs(r[k2], r[k2 + h], tb[k2 >> (5 - u)], p);
-    }
-  }
-  // exchange 1 (mirror) in two passes: sub-problems 0..15 write their rows, everyone reads registers 0..15; then sub-problems 16..31
-  u32 t[16];
-  if (!upper) {
-#pragma unroll
-    for (int k2 = 0; k2 < 32; ++k2) lds[kq * A32_P + a32_f(k2 * 16 + lo)] = r[k2];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) t[k] = lds[k * A32_P + a32_f(tid)];
-  __syncthreads();
-  if (upper) {
-#pragma unroll
-    for (int k2 = 0; k2 < 32; ++k2) lds[(kq - A32_HR) * A32_P + a32_f(k2 * 16 + lo)] = r[k2];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { r[16 + k] = lds[k * A32_P + a32_f(tid)]; r[k] = t[k]; }
-  // phase A (mirror): distances 1 .. 16 in the register index, uniform twiddles
-#pragma unroll
-  for (int s2 = 4; s2 >= 0; --s2) {
-    const int h = 16 >> s2;
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int k = a32_bfly_k(b, h);
-      a32_gs(r[k], r[k + h], tab[(1 << s2) + (k >> (5 - s2))], p);
-    }
-  }
-  const Tw32 tn{MONT ? pr.ninv_m[a] : pr.ninv[a], MONT ? pr.ninv_m_p[a] : pr.ninv_p[a]};
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    u32 v = mul_lazy32(r[k], tn, p);
-    v = v >= p ? v - p : v;
-    g[k * A32_T + tid] = v;
-  }
-}
 
 // rows of 2^15 elements, plain (non-digit) forward transform: the head stage in place before the sub-transforms (key-table build, self-test)
 __global__ void __launch_bounds__(256) ntt32_head_kernel(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, Aux32Head hd) {
@@ -737,8 +367,8 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0,
   ProfScope prof(ctx, PROF_NTT_INV, (double)(count * nslots));
   if (ctx->opt.ntt32_v3) {
     const unsigned grid = (unsigned)((count * nslots) << S);
-    if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S); }
-    else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S); }
+    if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
+    else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
     HIP_TRY(hipGetLastError());
     if (S) {
       ntt32_tail_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);

@@ -151,6 +151,56 @@ def test_sum_form_crt_undecided_coefficients(monkeypatch):
     ctx.set_option("crt_skip_cleanup", 0)
 
 
+def test_tensor_half_over_30_bit_primes_equals_the_chain():
+    """At the metric ring the fused pipeline forms tProd's integers modulo 35 primes below 2^30 instead of the chain
+    (kernels_tensor32.hip; Ciphertext.cpp:167-218 only ever exposes round(x / 2^logQ) mod 2^logQ of them).  Same bits as the chain path
+    (option tensor32 = 0) and as the oracle on random inputs, on the extremes of the centred range in every coefficient (the largest
+    |x| the bound allows), and on coefficients whose rounding sits on the edge: those must go through the exact second pass (the
+    result is wrong when that pass is switched off)."""
+    m, logQ, p, count = 32768, 512, 23, 4
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 4242, count)
+    n = ctx.phim
+    mod = 1 << logQ
+    lo, hi = -(mod >> 1), (mod >> 1) - 1
+    # ciphertext 1: the extremes everywhere (|x| up to 2 n p 2^1022)
+    rng = np.random.default_rng(5)
+    for part in range(2):
+        a[1, part] = O.ints_to_limbs([lo if v else hi for v in rng.integers(0, 2, n)], nl)
+        b[1, part] = O.ints_to_limbs([lo if v else hi for v in rng.integers(0, 2, n)], nl)
+    a[1, 0] = O.ints_to_limbs([lo] * n, nl)
+    b[1, 0] = O.ints_to_limbs([lo] * n, nl)
+    # ciphertext 2: x = p A with (x + 2^(logQ-1)) mod 2^logQ = delta around 0 (ScaleDown's rounding edge, Ciphertext.cpp:205-213)
+    inv_p = pow(p, -1, mod)
+
+    def centred(v):
+        v %= mod
+        return v - mod if v >= mod // 2 else v
+
+    deltas = [0, 1, -1, 2, -2, 3, -3, 5, -5, 7, -7, 8, -8, 100, -100, 1 << 64, -(1 << 64), 1 << 400, -(1 << 400), (1 << 448) - 1, -(1 << 448)]
+    A = [centred((d - (mod >> 1)) * inv_p) for d in deltas]
+    a[2, 0] = O.ints_to_limbs(A + [0] * (n - len(A)), nl)
+    a[2, 1] = O.ints_to_limbs([0] * (n - len(A)) + A, nl)
+    b[2, 0] = O.ints_to_limbs([1] + [0] * (n - 1), nl)
+    b[2, 1] = 0
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    assert ctx.get_option("tensor32") == 1
+    ctx.prof_enable(True)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    # the kernels that ran are the 32-bit ones
+    assert "crt32_scale_kernel" in ctx.prof_kernel_name("crt") and "rns32_reduce_kernel" in ctx.prof_kernel_name("rns_reduce")
+    ctx.prof_enable(False)
+    ctx.set_option("tensor32", 0)
+    chain = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    ctx.set_option("tensor32", 1)
+    assert np.array_equal(got, chain)
+    for c in (1, 2):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    ctx.set_option("crt_skip_cleanup", 1)
+    bad = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    ctx.set_option("crt_skip_cleanup", 0)
+    assert np.array_equal(bad[0], got[0]) and np.array_equal(bad[3], got[3]) and not np.array_equal(bad[2], got[2])
+
+
 @pytest.mark.parametrize("m,logQ,p", [(4096, 128, 23), (32768, 512, 23), (1 << 16, 200, 23)])
 def test_key_switch_paths_agree(m, logQ, p, monkeypatch):
     """The key switch has two device paths: the dot product through the two largest chain primes (kernels_ksaux.hip, default for
