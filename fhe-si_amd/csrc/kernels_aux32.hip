@@ -297,15 +297,16 @@ static int aux32_init(fhesi_ctx* ctx) {
       const u64 e = hm::brv(idx, lg);
       ff[idx] = tw(hm::powmod(psi, e, p)); fi[idx] = tw(hm::powmod(ipsi, e, p));
     }
+    auto fwd_form = [](Tw32 t) { return Tw32{0u - t.w, t.wp}; };      // what a32_ct takes: (-w mod 2^32, floor(w 2^32 / p))
     if (!S) {
-      std::copy(ff.begin(), ff.end(), hf.begin() + (size_t)a * per_prime);
+      std::transform(ff.begin(), ff.end(), hf.begin() + (size_t)a * per_prime, fwd_form);
       std::copy(fi.begin(), fi.end(), hi.begin() + (size_t)a * per_prime);
     } else {
       // sub-block h runs stage s >= 1 of the row on its groups i = h 2^(s-1) + i':  own index m' + i' (m' = 2^(s-1))  <->  2 m' + h m' + i'
       for (int h = 0; h < 2; ++h)
         for (u64 mp = 1; mp < (u64)A32_N; mp <<= 1)
           for (u64 ip = 0; ip < mp; ++ip) {
-            hf[((size_t)a * 2 + h) * A32_N + mp + ip] = ff[2 * mp + h * mp + ip];
+            hf[((size_t)a * 2 + h) * A32_N + mp + ip] = fwd_form(ff[2 * mp + h * mp + ip]);
             hi[((size_t)a * 2 + h) * A32_N + mp + ip] = fi[2 * mp + h * mp + ip];
           }
       const u64 inv2 = (p + 1) / 2;

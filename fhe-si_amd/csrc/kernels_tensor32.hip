@@ -108,7 +108,8 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
     auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
     for (u64 idx = 0; idx < (u64)n; ++idx) {
       const u64 e = hm::brv(idx, A32_LOGN);
-      hf[(size_t)a * n + idx] = tw(hm::powmod(psi, e, p));
+      const Tw32 f = tw(hm::powmod(psi, e, p));
+      hf[(size_t)a * n + idx] = Tw32{0u - f.w, f.wp};        // forward tables hold -w (a32_ct)
       hi[(size_t)a * n + idx] = tw(hm::powmod(ipsi, e, p));
     }
     const u64 ninv = hm::invmod((u64)n % p, p);

@@ -23,7 +23,12 @@ done
 F=$(find "$O/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 W=$(find "$O/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "dot32_kernel2<8, 16>" "$O/pmc_dot_aux.json" ciphertexts_per_launch=64
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true, 0>" "$O/pmc_ntt_fwd.json" rows_per_launch=16896
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt_fwd_tile<14, false, 0, false>" "$O/pmc_ntt64_fwd.json" rows_per_launch=4608
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true, 0, false, Aux32Primes>" "$O/pmc_ntt_fwd.json" rows_per_launch=16896
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<false, 0, false, T32Primes>" "$O/pmc_t32_fwd.json" rows_per_launch=8960
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<false, true, T32Primes>" "$O/pmc_t32_inv.json" rows_per_launch=6720
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "rns32_reduce_kernel<8>" "$O/pmc_t32_rns.json" ciphertexts_per_launch=64
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "crt32_scale_kernel<512, false>" "$O/pmc_t32_crt.json" ciphertexts_per_launch=64
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<true, false, Aux32Primes>" "$O/pmc_ntt_inv.json" rows_per_launch=7680
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ks_recombine_kernel" "$O/pmc_recombine.json" ciphertexts_per_launch=64
 find "$O" -name '*.db' -delete; find "$O" -name '*agent_info.csv' -delete; find "$O" -name '*kernel_trace.csv' -delete; find "$O" -name '*counter_collection.csv' -delete
 ls -la "$O"
