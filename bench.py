@@ -601,6 +601,17 @@ def main():
                     "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
                     "rows_per_launch": round(rows / launches, 1) if launches else None, "row_bytes": row_bytes // 2,
                     "row_ntts_per_s": round(rows / (ms * 1e-3), 1) if ms > 0 else None}
+    # the tensor half's forward rows (kernels_tensor32.hip: class ntt_fwd minus the digit rows), when it runs over the 30-bit primes
+    roofline_ntt_tensor = None
+    tl, trows, tms = prof["ntt_fwd"]
+    if names["ntt_fwd"].startswith("ntt32_") and aux32 and not args.ntt_rows and trows > rows and tms > ms:
+        t_rows, t_ms, t_l = trows - rows, tms - ms, max(1, tl - launches)
+        t_ach = t_rows * 2 * n * 4 / (t_ms * 1e-3) / 1e9
+        ttr, ttr_src = offline_traffic("pmc_t32_fwd.json", names["ntt_fwd"], "rows_per_launch", round(t_rows / t_l)) if args.workload == "metric" else (None, None)
+        roofline_ntt_tensor = {"bound": "hbm", "kernel": names["ntt_fwd"], "achieved": round(t_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(t_ach / HBM_PEAK_GBS, 4), "traffic": ttr, "traffic_source": ttr_src, "launches": t_l,
+                               "avg_launch_ms": round(t_ms / t_l, 4), "rows_per_launch": round(t_rows / t_l, 1), "row_bytes": n * 4,
+                               "row_ntts_per_s": round(t_rows / (t_ms * 1e-3), 1)}
     # The dominant kernel of the pipeline is the key-switch dot product through the auxiliary primes (kernels_ksaux.hip / kernels_aux32.hip):
     # algorithmic bytes per launch of c ciphertexts = (digit rows c*ncol*2 + key rows 2*R*2*ncol + output rows c*2*R*2) * n * 8
     # (DESIGN.md section 6); it is bound by the VALU (integer multiply-adds) and the LDS pipe, not by HBM -- the contract's roof is HBM.
@@ -646,7 +657,8 @@ def main():
                       else "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^15, logQ=1024 (stress shape)",
             "value": round(value, 2), "unit": "ciphertext-mults/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 (chain-prime rows u64; key-switch rows u32 modulo four 30-bit primes)" if aux32 else "u64",
+            "dtype": ("u32 (every transformed row is a row of 4-byte residues modulo a prime below 2^30: tensor half over 35 of them, key switch over four; coefficients are u64 limbs)"
+                      if roofline_ntt_tensor else "u64 (chain-prime rows u64; key-switch rows u32 modulo four 30-bit primes)") if aux32 else "u64",
             "data": f"synthetic ({uniq} distinct uniform ciphertext pairs per GPU repeated to the batch, uniform key rows)",
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
                        if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
@@ -655,7 +667,7 @@ def main():
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
             "matches_oracle": matches,
             "sclk_mhz_observed": sclk.summary(),
-            "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_dot": roofline_dot, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
+            "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_ntt_tensor": roofline_ntt_tensor, "roofline_dot": roofline_dot, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
             "kernels": {k: v for k, v in names.items() if v},
         }
         print(json.dumps(line), flush=True)
