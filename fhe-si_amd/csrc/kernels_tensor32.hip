@@ -108,8 +108,7 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
     auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
     for (u64 idx = 0; idx < (u64)n; ++idx) {
       const u64 e = hm::brv(idx, A32_LOGN);
-      const Tw32 f = tw(hm::powmod(psi, e, p));
-      hf[(size_t)a * n + idx] = Tw32{0u - f.w, f.wp};        // forward tables hold -w (a32_ct)
+      hf[(size_t)a * n + idx] = tw(hm::powmod(psi, e, p));       // (w itself: the plain-row kernels take a32_ct<false>)
       hi[(size_t)a * n + idx] = tw(hm::powmod(ipsi, e, p));
     }
     const u64 ninv = hm::invmod((u64)n % p, p);
@@ -301,8 +300,8 @@ int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int n
   }
   {
     ProfScope prof(ctx, PROF_NTT_FWD, (double)(count * 4 * NP));
-    PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes>));
-    ntt32_fwd_kernel3<false, 0, false, T32Primes><<<(unsigned)(count * 4 * NP), A32_T, 0, ctx->stream>>>((u32*)d_r, count * 4, NP, 0, x->pr, x->d_fwd, Dig32Src{}, Aux32Head{});
+    PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, false>));
+    ntt32_fwd_kernel3<false, 0, false, T32Primes, false><<<(unsigned)(count * 4 * NP), A32_T, 0, ctx->stream>>>((u32*)d_r, count * 4, NP, 0, x->pr, x->d_fwd, Dig32Src{}, Aux32Head{});
     HIP_TRY(hipGetLastError());
   }
   {
