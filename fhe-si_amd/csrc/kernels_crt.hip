@@ -613,8 +613,11 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   u64 x[W + 1];
+  u32 cnt[W + 4];
 #pragma unroll
   for (int i = 0; i <= W; ++i) x[i] = consts[i];
+#pragma unroll
+  for (int i = 0; i < W + 4; ++i) cnt[i] = 0;
   const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
   const u64* base = o + poly * NLB * 2 * n + j;
   const u32* base32 = reinterpret_cast<const u32*>(o) + poly * NLB * 4 * n + j;
@@ -641,15 +644,19 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
     const int s = B * l, wd = s >> 6, bt = s & 63;               // compile-time after unrolling
     const u64 lo = (u64)V, hi = (u64)(V >> 64);
     const u64 p0 = lo << bt, p1 = bt ? ((lo >> ((64 - bt) & 63)) | (hi << bt)) : hi, p2 = bt ? (hi >> ((64 - bt) & 63)) : 0;
+    // the three words go into their limbs; the carries out of a limb are only COUNTED here and added in one pass below (a carry chain
+    // through all the higher limbs per term was 40 % of the kernel)
+    { const u64 s0 = x[wd] + p0; cnt[wd + 1] += s0 < p0 ? 1u : 0u; x[wd] = s0; }
+    if (wd + 1 <= W) { const u64 s1 = x[wd + 1] + p1; cnt[wd + 2] += s1 < p1 ? 1u : 0u; x[wd + 1] = s1; }
+    if (wd + 2 <= W && bt) { const u64 s2 = x[wd + 2] + p2; cnt[wd + 3] += s2 < p2 ? 1u : 0u; x[wd + 2] = s2; }
+  }
+  {
     u64 carry = 0;
 #pragma unroll
-    for (int i = 0; i <= W; ++i) {
-      if (i >= wd) {
-        const u64 add = i == wd ? p0 : (i == wd + 1 ? p1 : (i == wd + 2 ? p2 : 0));
-        const u128 sum = (u128)x[i] + add + carry;
-        x[i] = (u64)sum;
-        carry = (u64)(sum >> 64);
-      }
+    for (int i = 1; i <= W; ++i) {
+      const u128 sum = (u128)x[i] + cnt[i] + carry;
+      x[i] = (u64)sum;
+      carry = (u64)(sum >> 64);
     }
   }
   // x = S + 2^m P, below 2^(64 (W-1) + 63): x[W] = 0
