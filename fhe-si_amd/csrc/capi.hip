@@ -90,6 +90,7 @@ static const OptDesc kOptions[] = {
   {"wave_operands", "FHESI_WAVE_OPERANDS", offsetof(CtxOptions, wave_operands), true},
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
   {"dot32_v2", "FHESI_DOT32_V2", offsetof(CtxOptions, dot32_v2), false},
+  {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
   {"ntt32_v3", "FHESI_NTT32_V3", offsetof(CtxOptions, ntt32_v3), false},
 };
 static void opt_store(CtxOptions* o, const OptDesc& d, long long v) {

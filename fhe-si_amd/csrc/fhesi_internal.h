@@ -78,6 +78,7 @@ struct CtxOptions {
   long long wave_operands = 0;    // distinct operands per pass of fhesi_ct_mul_sum_relin_dev (0 = about 4 GiB of rows)
   int ntt32_v3 = 1;         // 1: 32-bit transforms laid out for three workgroups per CU (half-size LDS buffer), 0: the two-workgroup form
   int dot32_v2 = 1;         // 1: dot32_kernel2 (a wave owns both key rows of a limb), 0: dot32_kernel
+  int dot32_v3 = 0;         // 1: dot32_kernel3 (two limbs per wave, 4 ciphertexts per tile, two workgroups per CU)
   int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)
 };
 

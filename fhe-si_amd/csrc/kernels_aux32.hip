@@ -687,6 +687,152 @@ int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, in
 }
 
 // d_dig: tiled [4][n/64][count*ncol][64] u32; d_out: [count*2*NLB][4][n] u32
+// ---- third form: a wave owns TWO limbs (LP = 2) and both key rows of each, so one digit value read from LDS feeds four multiply-adds
+// and the tile is half as tall (CT = 4: 66 KB at the metric shape): TWO workgroups of 8 waves share a CU, the tile load and the
+// barriers of one overlap the arithmetic of the other.  The price is twice the key words through L2 per multiply-add (CT halved).
+template <int CT, int NW, int LP>
+__global__ void __launch_bounds__(NW * 64, 4) dot32_kernel3(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
+                                                            u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl) {
+  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
+  static_assert(CT == 4, "one 16-byte LDS read per column");
+  const u32 lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32 b = blockIdx.x;
+  const u32 s_lo = b & 7; b >>= 3;
+  const u32 tile = b % (u32)ntiles; b /= (u32)ntiles;
+  const u32 s_hi = b % (u32)nsl8;
+  const int a = (int)(b / (u32)nsl8);
+  const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64;
+  const i64 ct0 = (i64)tile * CT;
+  const u32 p = pr.p[a], twop = 2 * p;
+#define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
+  const u32* dtile = dig + ((((i64)a << lognsl) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
+  for (int k0 = w * 2; k0 < ncol; k0 += NW * 2) {       // two columns (8 loads) per wave and round
+    u32 v[2][CT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) v[u][c] = (k0 + u < ncol && ct0 + c < count) ? __builtin_nontemporal_load(&dtile[((i64)c * ncol + k0 + u) << 6]) : 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (k0 + u < ncol) {
+        uint4 q;
+        u32 x;
+        x = v[u][0]; x = x >= twop ? x - twop : x; q.x = x >= p ? x - p : x;
+        x = v[u][1]; x = x >= twop ? x - twop : x; q.y = x >= p ? x - p : x;
+        x = v[u][2]; x = x >= twop ? x - twop : x; q.z = x >= p ? x - p : x;
+        x = v[u][3]; x = x >= twop ? x - twop : x; q.w = x >= p ? x - p : x;
+        *reinterpret_cast<uint4*>(&dl32[DL32(k0 + u, 0)]) = q;
+      }
+  }
+  __syncthreads();
+  const u64 r48 = pr.r48[a];
+  const u32 mont = pr.mont[a];
+  for (int l0 = w; l0 < NLB; l0 += NW * LP) {
+    // limbs l0 and l0 + NW (the second one may not exist: its arithmetic then repeats the first limb's and nothing is stored)
+    const u32* kp[LP][2];
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      const int l = l0 + j * NW < NLB ? l0 + j * NW : l0;
+      kp[j][0] = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + lane;
+      kp[j][1] = kp[j][0] + ((i64)ncol << 6);
+    }
+    u64 tot[LP][2][CT];
+    u32 th[LP][2][CT];
+#pragma unroll
+    for (int j = 0; j < LP; ++j)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { tot[j][r][c] = 0; th[j][r][c] = 0; }
+    auto fold = [&]() {
+#pragma unroll
+      for (int j = 0; j < LP; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) { th[j][r][c] += (u32)(tot[j][r][c] >> 48); tot[j][r][c] &= 0x0000ffffffffffffull; }
+    };
+    constexpr int CH = 4;
+    const int nfull = ncol & ~(CH - 1), n2 = ncol & ~(2 * CH - 1);
+    u32 xa[LP][2][CH], xb[LP][2][CH];
+    auto loadc = [&](u32 (&x)[LP][2][CH], int k0) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+#pragma unroll
+        for (int j = 0; j < LP; ++j) { x[j][0][u] = kp[j][0][(k0 + u) << 6]; x[j][1][u] = kp[j][1][(k0 + u) << 6]; }
+    };
+    auto macc = [&](const u32 (&x)[LP][2][CH], int k0) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const uint4 q = *reinterpret_cast<const uint4*>(&dl32[DL32(k0 + u, 0)]);
+        const u32 d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < LP; ++j)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) { tot[j][0][c] += (u64)x[j][0][u] * d[c]; tot[j][1][c] += (u64)x[j][1][u] * d[c]; }
+      }
+    };
+    if (nfull) loadc(xa, 0);
+    int kb = 0;
+    for (; kb < n2; kb += 2 * CH) {
+      loadc(xb, kb + CH);
+      macc(xa, kb);
+      if (kb + 2 * CH < nfull) loadc(xa, kb + 2 * CH);
+      macc(xb, kb + CH);
+      if (kb & (2 * CH)) fold();                     // 16 columns since the last fold
+    }
+    if (nfull & CH) { macc(xa, kb); }
+    if ((nfull & (3 * CH)) != 0) fold();
+    for (int k = nfull; k < ncol; ++k) {             // at most 3 columns
+      const uint4 q = *reinterpret_cast<const uint4*>(&dl32[DL32(k, 0)]);
+      const u32 d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < LP; ++j) {
+        const u32 x0 = kp[j][0][k << 6], x1 = kp[j][1][k << 6];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { tot[j][0][c] += (u64)x0 * d[c]; tot[j][1][c] += (u64)x1 * d[c]; }
+      }
+    }
+    fold();
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      const int l = l0 + j * NW;
+      if (l >= NLB) continue;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          if (ct0 + c < count) {
+            const u64 v = tot[j][r][c] + (u64)th[j][r][c] * r48;      // one Montgomery step, as in dot32_kernel2
+            const u32 mq = (u32)v * mont;
+            u32 o = (u32)((v + (u64)mq * p) >> 32);
+            o = o >= p ? o - p : o;
+            (out + ((((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + soff))[lane] = o;
+          }
+        }
+    }
+  }
+#undef DL32
+}
+static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
+  constexpr int CT = 4, NW = 8, LP = 2;
+  const size_t shmem = (size_t)ncol * CT * 64 * 4;
+  static unsigned long long attr_done = 0;
+  if (!(attr_done >> ctx->device & 1)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel3<CT, NW, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_done |= 1ull << ctx->device;
+  }
+  const i64 nrow = aux32_row_len(ctx);
+  const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
+  const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
+  const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
+  if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
+  PROF_KERNEL(ctx, PROF_DOT, dot32_kernel3<CT, NW, LP>);
+  dot32_kernel3<CT, NW, LP><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 template <int CT, int NW, bool V2>
 static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)ncol * CT * 64 * 4;
@@ -710,6 +856,7 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
 int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   if (!count) return 0;
   ProfScope prof(ctx, PROF_DOT, (double)count);
+  if (ctx->opt.dot32_v3 && (size_t)ncol * 4 * 256 <= 80 * 1024 && ctx->opt.dot32_v2) return launch_dot32_v3(ctx, k, d_dig, ncol, count, d_out);
   // ciphertexts per LDS tile: 8 while ncol * 8 digit slices of 256 bytes fit the CU's 160 KiB (ncol <= 80), else 4 (ncol <= 160)
   if ((size_t)ncol * 8 * 256 <= 160 * 1024) return ctx->opt.dot32_v2 ? launch_dot32_t<8, 16, true>(ctx, k, d_dig, ncol, count, d_out) : launch_dot32_t<8, 16, false>(ctx, k, d_dig, ncol, count, d_out);
   if ((size_t)ncol * 4 * 256 <= 160 * 1024) return ctx->opt.dot32_v2 ? launch_dot32_t<4, 16, true>(ctx, k, d_dig, ncol, count, d_out) : launch_dot32_t<4, 16, false>(ctx, k, d_dig, ncol, count, d_out);

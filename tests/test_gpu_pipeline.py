@@ -276,7 +276,7 @@ def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 4242, count)
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     ref = ctx.ct_mul_relin(ksk, logQ, p, a, b)
-    for opt in ("ks_aux60", "ks_residues", "ks_direct"):
+    for opt in ("ks_aux60", "ks_residues", "ks_direct", "dot32_v3"):     # (dot32_v3: the two-limbs-per-wave form of the 30-bit dot product)
         ctx.set_option(opt, 1)
         ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)        # a fresh matrix: the derived table is built for the selected form
         assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), opt
