@@ -16,27 +16,31 @@
 //                         28 * 14 = 392 bits upwards are formed -- the dropped part is below 2^429 and can change round(x / 2^512) only
 //                         when bits 448..511 of x + 2^511 are all ones: those workgroups are flagged and redone with every word
 //                         (EXACT), the pattern of crt_sum_kernel.
+// Rows of 2^15 (n = 2^15, the stress shape: 70 primes for logQ = 1024): the head stage of the forward transform is taken inside
+// rns32_reduce_kernel<NL, true> (a thread converts coefficients j and j + 2^14 and stores the two butterfly outputs into the two sub-rows),
+// the tail of the inverse inside crt32_scale_kernel (its first multiplication takes (A + B) or (A - B) with the tail constant folded into
+// the CRT constant), so a row still passes through exactly one forward and one inverse kernel.  With more than 62 primes the CRT words
+// are 26 bits wide (71 terms below 2^56 per 64-bit accumulator).
 // fhesi_ct_mul_dev keeps the reference chain (its rows ARE visible).  Option tensor32 = 0 keeps the chain in the fused pipeline too.
 #include "fhesi_internal.h"
 #include "ntt32_core.inc"
 #include <cmath>
 
 struct fhesi_tensor32 {
-  int NP = 0, nl = 0, logQ = 0;
+  int NP = 0, nl = 0, logQ = 0, S = 0, R = 28, WT = 0;
   u64 lift = 0;
   T32Primes pr;
-  Tw32* d_fwd = nullptr;             // [NP][2^14]
+  Tw32* d_fwd = nullptr;             // [NP][2^S][2^14]
   Tw32* d_inv = nullptr;
-  u32* d_rns = nullptr;              // [2][NP][2 nl + 4]: (s 2^(32k) mod p) k < 2 nl, -(s 2^(64 nl)) mod p, 2^32 mod p, floor(2^61 / p), p;  s = lift (class 0) or 1
-  Tw32* d_cinv = nullptr;            // [NP] (M / p_i)^-1 mod p_i
-  u32* d_inv58 = nullptr;            // [NP] floor(2^58 / p_i)
-  u32* d_M28 = nullptr;              // [NP + 1][WT]: M_i in words of 28 bits; row NP = 2^(28 WT) - M
-  int WT = 0;
+  u32* d_rns = nullptr;              // [2][NP][2 nl + 6]: (s 2^(32k) mod p) k < 2 nl, -(s 2^(64 nl)) mod p, 2^32 mod p, floor(2^61 / p), p, head twiddle (w, w');  s = lift (class 0) or 1
+  Tw32* d_cinv = nullptr;            // [NP][2] (M / p_i)^-1 mod p_i  [times 1/2 | times psi^-brv(1) / 2: the tail of a 2^15-point inverse]
+  u32* d_inv57 = nullptr;            // [NP] floor(2^57 / p_i)
+  u32* d_Mw = nullptr;               // [NP + 1][WT]: M_i in words of R bits; row NP = 2^(R WT) - M
 };
 
 static void t32_release(fhesi_tensor32* x) {
   if (!x) return;
-  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_rns); hipFree(x->d_cinv); hipFree(x->d_inv58); hipFree(x->d_M28);
+  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_rns); hipFree(x->d_cinv); hipFree(x->d_inv57); hipFree(x->d_Mw);
   delete x;
 }
 void tensor32_free(fhesi_ctx* ctx) { t32_release(ctx->tensor32); ctx->tensor32 = nullptr; }
@@ -45,43 +49,47 @@ void tensor32_free(fhesi_ctx* ctx) { t32_release(ctx->tensor32); ctx->tensor32 =
 typedef std::vector<u64> Big;
 static Big big_mul_small(const Big& a, u64 b) { return hm::bn_mul_small(a, b); }
 static u64 big_mod_small(const Big& a, u64 q) { u128 r = 0; for (size_t i = a.size(); i-- > 0;) r = ((r << 64) | a[i]) % q; return (u64)r; }
-static u32 big_bits28(const Big& a, int l) {          // word l of the radix-2^28 form
-  const int bit = 28 * l, w = bit >> 6, o = bit & 63;
+static u32 big_word(const Big& a, int l, int R) {          // word l of the radix-2^R form
+  const int bit = R * l, w = bit >> 6, o = bit & 63;
   u64 v = (size_t)w < a.size() ? a[w] >> o : 0;
-  if (o > 36 && (size_t)w + 1 < a.size()) v |= a[w + 1] << (64 - o);
-  return (u32)(v & 0xfffffffu);
+  if (o + R > 64 && (size_t)w + 1 < a.size()) v |= a[w + 1] << (64 - o);
+  return (u32)(v & (((u64)1 << R) - 1));
 }
+
+// the two compiled shapes of crt32_scale_kernel
+static constexpr int T32_WT_512 = 38, T32_R_512 = 28;        // logQ = 512: words of 28 bits (up to 62 primes), 1064 bits per table row
+static constexpr int T32_WT_1024 = 82, T32_R_1024 = 26;      // logQ = 1024: words of 26 bits (up to 72 primes), 2132 bits per table row
 
 // The number of primes the tensor half needs, 0 if this shape does not run through it.
 //   |x| < 2^TB with TB = 2 (64 nl - 1) + bits(p) + log2(n) + 1;  M > 2^(TB + 3) keeps x/M below 1/8 (kappa is then decided by a coarse
 //   fixed-point sum), and the chain product must exceed 2^(TB + 1) so that the reference's own centred integers are these same integers.
 static int t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, std::vector<u32>* primes) {
-  if (!ctx->pow2 || ctx->logn != A32_LOGN || !ctx->opt.tensor32 || !ctx->opt.ntt32_v3) return 0;
-  if (logQ != 512 || nlimbs < 1 || nlimbs > 12 || 64 * nlimbs < logQ || p < 2) return 0;       // (crt32_scale_kernel is instantiated for logQ = 512)
+  if (!ctx->pow2 || (ctx->logn != A32_LOGN && ctx->logn != A32_LOGN + 1) || !ctx->opt.tensor32 || !ctx->opt.ntt32_v3) return 0;
+  if ((logQ != 512 && logQ != 1024) || nlimbs < 1 || nlimbs > 16 || 64 * nlimbs < logQ || p < 2) return 0;       // (the instantiations of crt32_scale_kernel)
+  const int lg = ctx->logn;
   int pbits = 0;
   while (pbits < 64 && (p >> pbits)) ++pbits;
-  const double TB = 2.0 * (64 * nlimbs - 1) + pbits + A32_LOGN + 1;
+  const double TB = 2.0 * (64 * nlimbs - 1) + pbits + lg + 1;
   double chain = 0;
   for (int i = 0; i < ctx->L; ++i) chain += std::log2((double)ctx->q[i]);
   if (chain < TB + 1.5) return 0;
+  const int maxp = logQ == 512 ? 62 : T32_MAXP;
   double have = 0;
   int np = 0;
-  for (u64 k = ((u64)1 << (29 - A32_LOGN)) - 1; k > ((u64)1 << (28 - A32_LOGN)) && have < TB + 3.5; --k) {
-    const u64 cand = (k << (A32_LOGN + 1)) + 1;
+  for (u64 k = ((u64)1 << (29 - lg)) - 1; k > ((u64)1 << (28 - lg)) && have < TB + 3.5; --k) {
+    const u64 cand = (k << (lg + 1)) + 1;
     if (cand > ((u64)1 << 30) - ((u64)1 << 15) + 1 || !hm::is_prime(cand)) continue;
-    if (np == T32_MAXP) return 0;
+    if (np == maxp) return 0;
     if (primes) primes->push_back((u32)cand);
     have += std::log2((double)cand);
     ++np;
   }
   if (have < TB + 3.5) return 0;
-  // the window of crt32_scale_kernel: words up to bit 2 logQ, all of M inside 28 * 38 bits
-  if (have > 28.0 * 38 - 8) return 0;
+  // the window of crt32_scale_kernel: words up to bit 2 logQ, all of M inside the table row
+  if (have > (logQ == 512 ? (double)T32_R_512 * T32_WT_512 : (double)T32_R_1024 * T32_WT_1024) - 8) return 0;
   return np;
 }
 bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ) { return t32_plan(ctx, p, nlimbs, logQ, nullptr) > 0; }
-
-static constexpr int T32_WT = 38;          // words of 28 bits per table row (1064 bits)
 
 static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
   fhesi_tensor32* x = ctx->tensor32;
@@ -91,11 +99,15 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
   if (!NP) FHESI_FAIL("tensor32: shape not supported");
   if (x) { HIP_TRY(hipStreamSynchronize(ctx->stream)); if (ctx->lane_stream) HIP_TRY(hipStreamSynchronize(ctx->lane_stream)); tensor32_free(ctx); }
   x = new fhesi_tensor32();
-  x->NP = NP; x->nl = nlimbs; x->logQ = logQ; x->lift = lift; x->WT = T32_WT;
-  const i64 n = A32_N;
-  std::vector<Tw32> hf((size_t)NP * n), hi((size_t)NP * n);
-  const int stride = 2 * nlimbs + 4;
+  const int S = ctx->logn - A32_LOGN, lg = ctx->logn;
+  const int R = logQ == 512 ? T32_R_512 : T32_R_1024, WT = logQ == 512 ? T32_WT_512 : T32_WT_1024;
+  x->NP = NP; x->nl = nlimbs; x->logQ = logQ; x->lift = lift; x->S = S; x->R = R; x->WT = WT;
+  const i64 n = (i64)A32_N << S;
+  const size_t per_prime = (size_t)A32_N << S;
+  std::vector<Tw32> hf((size_t)NP * per_prime, Tw32{0, 0}), hi((size_t)NP * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n);
+  const int stride = 2 * nlimbs + 6;
   std::vector<u32> rns((size_t)2 * NP * stride);
+  std::vector<u64> tail_dif(NP, 0);
   for (int a = 0; a < NP; ++a) {
     const u64 p = primes[a];
     u64 psi = 0;
@@ -106,12 +118,24 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
     if (!psi) { t32_release(x); FHESI_FAIL("tensor32: no 2n-th root"); }
     const u64 ipsi = hm::invmod(psi, p);
     auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
-    for (u64 idx = 0; idx < (u64)n; ++idx) {
-      const u64 e = hm::brv(idx, A32_LOGN);
-      hf[(size_t)a * n + idx] = tw(hm::powmod(psi, e, p));       // (w itself: the plain-row kernels take a32_ct<false>)
-      hi[(size_t)a * n + idx] = tw(hm::powmod(ipsi, e, p));
+    for (u64 idx = 0; idx < (u64)n; ++idx) {       // the full table of the n-point transform: psi^brv(idx) (w itself: the plain-row kernels take a32_ct<false>)
+      const u64 e = hm::brv(idx, lg);
+      ff[idx] = tw(hm::powmod(psi, e, p)); fi[idx] = tw(hm::powmod(ipsi, e, p));
     }
-    const u64 ninv = hm::invmod((u64)n % p, p);
+    if (!S) {
+      std::copy(ff.begin(), ff.end(), hf.begin() + (size_t)a * per_prime);
+      std::copy(fi.begin(), fi.end(), hi.begin() + (size_t)a * per_prime);
+    } else {
+      // sub-block h runs stage s >= 1 of the row on its groups i = h 2^(s-1) + i':  own index m' + i' (m' = 2^(s-1))  <->  2 m' + h m' + i'  (as aux32_init)
+      for (int h = 0; h < 2; ++h)
+        for (u64 mp = 1; mp < (u64)A32_N; mp <<= 1)
+          for (u64 ip = 0; ip < mp; ++ip) {
+            hf[((size_t)a * 2 + h) * A32_N + mp + ip] = ff[2 * mp + h * mp + ip];
+            hi[((size_t)a * 2 + h) * A32_N + mp + ip] = fi[2 * mp + h * mp + ip];
+          }
+      tail_dif[a] = fi[1].w;
+    }
+    const u64 ninv = hm::invmod((u64)A32_N % p, p);     // of the 2^14-point (sub-)transform; the tail carries the other 1/2
     x->pr.p[a] = (u32)p;
     x->pr.ninv[a] = (u32)ninv;
     x->pr.ninv_p[a] = (u32)((ninv << 32) / p);
@@ -125,36 +149,44 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
       e[2 * nlimbs + 1] = (u32)b32;
       e[2 * nlimbs + 2] = x->pr.mu61[a];
       e[2 * nlimbs + 3] = (u32)p;
+      e[2 * nlimbs + 4] = S ? ff[1].w : 0;           // head stage of a 2^15-point row: psi^brv(1)
+      e[2 * nlimbs + 5] = S ? ff[1].wp : 0;
     }
   }
   // CRT tables
   Big M{1};
   for (int a = 0; a < NP; ++a) M = big_mul_small(M, primes[a]);
-  std::vector<Tw32> cinv(NP);
-  std::vector<u32> inv58(NP), M28((size_t)(NP + 1) * T32_WT);
+  std::vector<Tw32> cinv((size_t)NP * 2);
+  std::vector<u32> inv57(NP), Mw((size_t)(NP + 1) * WT);
   for (int a = 0; a < NP; ++a) {
     Big Mi{1};
     for (int b = 0; b < NP; ++b) if (b != a) Mi = big_mul_small(Mi, primes[b]);
     const u64 p = primes[a];
     const u64 c = hm::invmod(big_mod_small(Mi, p), p);
-    cinv[a] = Tw32{(u32)c, (u32)((c << 32) / p)};
-    inv58[a] = (u32)(((u64)1 << 58) / p);
-    for (int l = 0; l < T32_WT; ++l) M28[(size_t)a * T32_WT + l] = big_bits28(Mi, l);
+    auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
+    if (!S) cinv[(size_t)a * 2] = cinv[(size_t)a * 2 + 1] = tw(c);
+    else {
+      const u64 inv2 = (p + 1) / 2;
+      cinv[(size_t)a * 2] = tw(hm::mulmod(c, inv2, p));
+      cinv[(size_t)a * 2 + 1] = tw(hm::mulmod(c, hm::mulmod(tail_dif[a], inv2, p), p));
+    }
+    inv57[a] = (u32)(((u64)1 << 57) / p);
+    for (int l = 0; l < WT; ++l) Mw[(size_t)a * WT + l] = big_word(Mi, l, R);
   }
   {
-    // 2^(28 WT) - M: two's complement of M over enough limbs, read through the same word extraction (masked to 28 WT bits)
+    // 2^(R WT) - M: two's complement of M over enough limbs, read through the same word extraction (masked to R WT bits)
     Big N(M);
-    N.resize((28 * T32_WT + 63) / 64 + 1, 0);
+    N.resize((R * WT + 63) / 64 + 1, 0);
     u64 carry = 1;
     for (auto& w : N) { const u64 v = ~w + carry; carry = (carry && v == 0) ? 1 : 0; w = v; }
-    for (int l = 0; l < T32_WT; ++l) M28[(size_t)NP * T32_WT + l] = big_bits28(N, l);
+    for (int l = 0; l < WT; ++l) Mw[(size_t)NP * WT + l] = big_word(N, l, R);
   }
   auto up = [&](void** d, const void* h, size_t bytes) -> bool {
     return hipMalloc(d, bytes) == hipSuccess && hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
   if (!up((void**)&x->d_fwd, hf.data(), hf.size() * sizeof(Tw32)) || !up((void**)&x->d_inv, hi.data(), hi.size() * sizeof(Tw32)) ||
       !up((void**)&x->d_rns, rns.data(), rns.size() * 4) || !up((void**)&x->d_cinv, cinv.data(), cinv.size() * sizeof(Tw32)) ||
-      !up((void**)&x->d_inv58, inv58.data(), inv58.size() * 4) || !up((void**)&x->d_M28, M28.data(), M28.size() * 4)) {
+      !up((void**)&x->d_inv57, inv57.data(), inv57.size() * 4) || !up((void**)&x->d_Mw, Mw.data(), Mw.size() * 4)) {
     t32_release(x);
     FHESI_FAIL("tensor32: table upload failed");
   }
@@ -163,8 +195,28 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
 }
 
 // ---------------------------------------------------------------------------------------------- big integer -> residues
-// a, b: [count][2][n][NL] two's complement coefficients; rows [count][4][NP][n] (a0, a1, b0, b1), values below 3p
+// a, b: [count][2][n][NL] two's complement coefficients; rows [count][4][NP][n] (a0, a1, b0, b1), values below 4p.
+// HEAD (n = 2^15): a thread takes coefficients j and j + 2^14 and stores  x + w y  and  x + 2p - w y  into sub-rows 0 and 1 of the row
+// (the head stage of the 2^15-point transform, w = psi^brv(1)).
 template <int NL>
+__device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const u32* __restrict__ t) {
+  const u32 r32 = t[2 * NL + 1], mu = t[2 * NL + 2], p = t[2 * NL + 3];
+  // products below 2^62 - 2^47: four fit a 64-bit accumulator, three on top of a folded value (below 2^62 + 2^32)
+  u64 acc = 0;
+  int room = 4;
+#pragma unroll
+  for (int k = 0; k < 2 * NL; ++k) {
+    if (room == 0) { acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc; room = 3; }
+    acc += (u64)x[k] * t[k];
+    --room;
+  }
+  acc += neg ? t[2 * NL] : 0u;
+  acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^62 + 2^32
+  acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^61
+  const u32 q = __umulhi((u32)(acc >> 29), mu);        // at most 2 below floor(acc / p)
+  return (u32)acc - q * p;                             // below 3p
+}
+template <int NL, bool HEAD>
 __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict__ a, const u64* __restrict__ b, i64 n, u32* __restrict__ rows, int NP,
                                                             const u32* __restrict__ tab) {
   __shared__ __attribute__((aligned(16))) u64 sl[NL * 256];       // [NL][256]
@@ -174,56 +226,66 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   const i64 j0 = (i64)blockIdx.x * 256;
   const int tid = threadIdx.x;
   const u64* __restrict__ src = (cls ? b : a) + (ct * 2 + (jp & 1)) * n * NL + j0 * NL;
+  u32 x[2 * NL], x1[HEAD ? 2 * NL : 1];
 #pragma unroll
   for (int it = 0; it < NL; ++it) {
     const int e = it * 256 + tid;
     sl[(e % NL) * 256 + e / NL] = src[e];
   }
   __syncthreads();
-  u32 x[2 * NL];
 #pragma unroll
   for (int k = 0; k < NL; ++k) { const u64 v = sl[k * 256 + tid]; x[2 * k] = (u32)v; x[2 * k + 1] = (u32)(v >> 32); }
+  if constexpr (HEAD) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int e = it * 256 + tid;
+      sl[(e % NL) * 256 + e / NL] = src[(i64)A32_N * NL + e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NL; ++k) { const u64 v = sl[k * 256 + tid]; x1[2 * k] = (u32)v; x1[2 * k + 1] = (u32)(v >> 32); }
+  }
   const u32 neg = x[2 * NL - 1] >> 31;
-  constexpr int STRIDE = 2 * NL + 4;
+  u32 neg1 = 0;
+  if constexpr (HEAD) neg1 = x1[2 * NL - 1] >> 31;
+  constexpr int STRIDE = 2 * NL + 6;
   u32* __restrict__ o = rows + poly * NP * n + j0 + tid;
 #pragma unroll 2
   for (int i = 0; i < NP; ++i) {
     const u32* __restrict__ t = tab + ((i64)cls * NP + i) * STRIDE;
-    const u32 r32 = t[2 * NL + 1], mu = t[2 * NL + 2], p = t[2 * NL + 3];
-    // products below 2^62 - 2^47: four fit a 64-bit accumulator, three on top of a folded value (below 2^62 + 2^32)
-    u64 acc = 0;
-    int room = 4;
-#pragma unroll
-    for (int k = 0; k < 2 * NL; ++k) {
-      if (room == 0) { acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc; room = 3; }
-      acc += (u64)x[k] * t[k];
-      --room;
+    const u32 r0 = rns32_one<NL>(x, neg, t);
+    if constexpr (!HEAD) o[(i64)i * n] = r0;
+    else {
+      const u32 p = t[2 * NL + 3], twop = 2 * p;
+      const u32 r1 = rns32_one<NL>(x1, neg1, t);
+      const u32 X = r0 >= twop ? r0 - twop : r0;
+      const u32 T = mul_lazy32(r1, Tw32{t[2 * NL + 4], t[2 * NL + 5]}, p);
+      o[(i64)i * n] = X + T;
+      o[(i64)i * n + A32_N] = X + twop - T;
     }
-    acc += neg ? t[2 * NL] : 0u;
-    acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^62 + 2^32
-    acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^61
-    const u32 q = __umulhi((u32)(acc >> 29), mu);        // at most 2 below floor(acc / p)
-    o[(i64)i * n] = (u32)acc - q * p;
   }
 }
 
 // ---------------------------------------------------------------------------------------------- residues -> round(x / 2^logQ) mod 2^logQ
-// rows [npolys][NP][n] (below p) -> out [npolys][LQ/64][n] limb-major positive residues (crt mode 1, kernels_crt.hip)
-template <int LQ, bool EXACT>
+// rows [npolys][NP][n] (below p) -> out [npolys][LQ/64][n] limb-major positive residues (crt mode 1, kernels_crt.hip).
+// S = 1: the rows are the two sub-inverses of 2^15-point rows; coefficient j < 2^14 is (A_j + B_j) / 2, coefficient j + 2^14 is
+// (A_j - B_j) psi^-brv(1) / 2 -- the constants are folded into the CRT constant of the first multiplication.
+template <int LQ, bool EXACT, int R, int WT, int S>
 __global__ void __launch_bounds__(128) crt32_scale_kernel(const u32* __restrict__ rows, i64 n, int NP, T32Primes pr, const Tw32* __restrict__ cinv,
-                                                           const u32* __restrict__ inv58, const u32* __restrict__ M28, u64* __restrict__ out,
+                                                           const u32* __restrict__ inv57, const u32* __restrict__ Mw, u64* __restrict__ out,
                                                            unsigned char* __restrict__ flags) {
   static_assert((LQ & 63) == 0, "logQ a multiple of 64");
-  constexpr int WT = T32_WT;                          // table words
-  constexpr int WU = (2 * LQ + 27) / 28;              // words that reach below bit 2 logQ
-  constexpr int J0 = EXACT ? 0 : (LQ - 101) / 28;     // first word formed: 28 J0 + 37 <= logQ - 64
+  constexpr int WU = (2 * LQ + R - 1) / R;            // words that reach below bit 2 logQ
+  constexpr int J0 = EXACT ? 0 : (LQ - 64 - 30 - 8) / R;     // first word formed: R J0 + 30 + log2(NP + 1) + 1 <= logQ - 64
   constexpr int NW = WU - J0;
   static_assert(WU <= WT && J0 >= 0, "window");
   const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (EXACT && !flags[wg]) return;
   const i64 poly = blockIdx.y;
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u32* __restrict__ src = rows + poly * NP * n + j;
+  const int hi = S ? (int)(j >> A32_LOGN) : 0;        // (uniform per workgroup)
+  const u32* __restrict__ src = rows + poly * NP * n + (S ? (j & (A32_N - 1)) : j);
   u64 acc[NW];
 #pragma unroll
   for (int l = 0; l < NW; ++l) acc[l] = 0;
@@ -231,31 +293,33 @@ __global__ void __launch_bounds__(128) crt32_scale_kernel(const u32* __restrict_
 #pragma unroll 2
   for (int i = 0; i < NP; ++i) {
     const u32 p = pr.p[i];
-    u32 y = mul_lazy32(src[(i64)i * n], cinv[i], p);
+    u32 r = src[(i64)i * n];
+    if (S) { const u32 B = src[(i64)i * n + A32_N]; r = hi ? r + p - B : r + B; }
+    u32 y = mul_lazy32(r, cinv[2 * i + hi], p);
     y = y >= p ? y - p : y;
-    fsum += __umulhi(y, inv58[i]);                    // (y / p) 2^26, low by less than one unit
-    const u32* __restrict__ Mi = M28 + (i64)i * WT + J0;
+    fsum += __umulhi(y, inv57[i]);                    // (y / p) 2^25, low by less than one unit
+    const u32* __restrict__ Mi = Mw + (i64)i * WT + J0;
 #pragma unroll
     for (int l = 0; l < NW; ++l) acc[l] += (u64)y * Mi[l];
   }
-  // x/M is within 1/8 of an integer: kappa = round(sum y_i / p_i); x = sum - kappa M = sum + kappa (2^(28 WT) - M)  (mod 2^(28 WT))
-  const u32 kappa = (fsum + (1u << 25)) >> 26;
+  // x/M is within 1/8 of an integer: kappa = round(sum y_i / p_i); x = sum - kappa M = sum + kappa (2^(R WT) - M)  (mod 2^(R WT))
+  const u32 kappa = (fsum + (1u << 24)) >> 25;
   {
-    const u32* __restrict__ Nm = M28 + (i64)NP * WT + J0;
+    const u32* __restrict__ Nm = Mw + (i64)NP * WT + J0;
 #pragma unroll
     for (int l = 0; l < NW; ++l) acc[l] += (u64)kappa * Nm[l];
   }
-  // carries: words of 28 bits
+  // carries: words of R bits
   u64 carry = 0;
 #pragma unroll
-  for (int l = 0; l < NW; ++l) { const u64 v = acc[l] + carry; acc[l] = v & 0xfffffffull; carry = v >> 28; }
-  // 64 bits from bit B of x (two's complement, bits above 28 WU dropped)
+  for (int l = 0; l < NW; ++l) { const u64 v = acc[l] + carry; acc[l] = v & (((u64)1 << R) - 1); carry = v >> R; }
+  // 64 bits from bit B of x (two's complement, bits above R WU dropped)
   auto limb = [&](int B) -> u64 {
-    const int l0 = B / 28 - J0, o = B % 28;
+    const int l0 = B / R - J0, o = B % R;
     u64 v = acc[l0] >> o;
-    if (l0 + 1 < NW) v |= acc[l0 + 1] << (28 - o);
-    if (l0 + 2 < NW) v |= acc[l0 + 2] << (56 - o);
-    if (l0 + 3 < NW && 84 - o < 64) v |= acc[l0 + 3] << (84 - o);
+    if (l0 + 1 < NW) v |= acc[l0 + 1] << (R - o);
+    if (l0 + 2 < NW) v |= acc[l0 + 2] << (2 * R - o);
+    if (l0 + 3 < NW && 3 * R - o < 64) v |= acc[l0 + 3] << (3 * R - o);
     return v;
   };
   const u64 G = limb(LQ - 64);                         // bits logQ-64 .. logQ-1
@@ -277,53 +341,70 @@ __global__ void __launch_bounds__(128) crt32_scale_kernel(const u32* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------- the tensor half
+template <int NL>
+static int t32_launch_rns(fhesi_ctx* ctx, const fhesi_tensor32* x, const u64* d_a, const u64* d_b, i64 count, u32* d_r) {
+  const i64 n = (i64)A32_N << x->S;
+  const dim3 grid((unsigned)(A32_N / 256), (unsigned)(count * 4));
+  if (x->S) { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, true>); rns32_reduce_kernel<NL, true><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, n, d_r, x->NP, x->d_rns); }
+  else { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, false>); rns32_reduce_kernel<NL, false><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, n, d_r, x->NP, x->d_rns); }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+template <int LQ, int R, int WT, int S>
+static int t32_launch_crt(fhesi_ctx* ctx, const fhesi_tensor32* x, const u32* d_t, i64 count, u64* d_parts) {
+  const i64 n = (i64)A32_N << S;
+  const dim3 grid((unsigned)(n / 128), (unsigned)(count * 3));
+  void* d_fl;
+  FHESI_TRY(ws_reserve(ctx, 6, (size_t)grid.x * grid.y, &d_fl));          // (per lane, like every workspace slot)
+  unsigned char* fl = (unsigned char*)d_fl;
+  PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_kernel<LQ, false, R, WT, S>));
+  crt32_scale_kernel<LQ, false, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, x->NP, x->pr, x->d_cinv, x->d_inv57, x->d_Mw, d_parts, fl);
+  HIP_TRY(hipGetLastError());
+  if (!ctx->opt.crt_skip_cleanup) {
+    crt32_scale_kernel<LQ, true, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, x->NP, x->pr, x->d_cinv, x->d_inv57, x->d_Mw, d_parts, fl);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
 // a, b: [count][2][n][nlimbs] coefficients -> d_parts [count * 3][logQ/64][n]: the scaled-down tProd as ByteDecomp takes it
 int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts) {
   FHESI_TRY(t32_init(ctx, p, nlimbs, logQ));
   if (!count) return 0;
   fhesi_tensor32* x = ctx->tensor32;
-  const int NP = x->NP;
-  const i64 n = A32_N;
+  const int NP = x->NP, S = x->S;
+  const i64 n = (i64)A32_N << S;
   void *d_r, *d_t;
   FHESI_TRY(ws_reserve(ctx, 5, (size_t)count * 4 * NP * n * 4, &d_r));
   FHESI_TRY(ws_reserve(ctx, 1, (size_t)count * 3 * NP * n * 4, &d_t));
   {
     ProfScope prof(ctx, PROF_RNS, (double)(count * 4));
-    const dim3 grid((unsigned)(n / 256), (unsigned)(count * 4));
-#define T32_RNS(NL) case NL: PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL>); rns32_reduce_kernel<NL><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, n, (u32*)d_r, NP, x->d_rns); break;
+#define T32_RNS(NL) case NL: FHESI_TRY(t32_launch_rns<NL>(ctx, x, d_a, d_b, count, (u32*)d_r)); break;
     switch (nlimbs) {
       T32_RNS(1) T32_RNS(2) T32_RNS(3) T32_RNS(4) T32_RNS(5) T32_RNS(6) T32_RNS(7) T32_RNS(8) T32_RNS(9) T32_RNS(10) T32_RNS(11) T32_RNS(12)
+      T32_RNS(13) T32_RNS(14) T32_RNS(15) T32_RNS(16)
       default: FHESI_FAIL("tensor32: %d limbs", nlimbs);
     }
 #undef T32_RNS
-    HIP_TRY(hipGetLastError());
   }
   {
     ProfScope prof(ctx, PROF_NTT_FWD, (double)(count * 4 * NP));
-    PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, false>));
-    ntt32_fwd_kernel3<false, 0, false, T32Primes, false><<<(unsigned)(count * 4 * NP), A32_T, 0, ctx->stream>>>((u32*)d_r, count * 4, NP, 0, x->pr, x->d_fwd, Dig32Src{}, Aux32Head{});
+    const unsigned grid = (unsigned)((count * 4 * NP) << S);
+    if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_r, count * 4, NP, 0, x->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
+    else { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 0, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_r, count * 4, NP, 0, x->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
     HIP_TRY(hipGetLastError());
   }
   {
     ProfScope prof(ctx, PROF_NTT_INV, (double)(count * 3 * NP));
     PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, true, T32Primes>));
-    const unsigned grid = (unsigned)(((count + 7) / 8) * 24 * NP);
-    ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, x->pr, x->d_inv, 0, (const u32*)d_r);
+    const unsigned grid = (unsigned)((((count + 7) / 8) * 24 * NP) << S);
+    ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, x->pr, x->d_inv, S, (const u32*)d_r);
     HIP_TRY(hipGetLastError());
   }
   {
     ProfScope prof(ctx, PROF_CRT, (double)(count * 3));
-    const dim3 grid((unsigned)(n / 128), (unsigned)(count * 3));
-    void* d_fl;
-    FHESI_TRY(ws_reserve(ctx, 6, (size_t)grid.x * grid.y, &d_fl));          // (per lane, like every workspace slot)
-    unsigned char* fl = (unsigned char*)d_fl;
-    PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_kernel<512, false>));
-    crt32_scale_kernel<512, false><<<grid, 128, 0, ctx->stream>>>((const u32*)d_t, n, NP, x->pr, x->d_cinv, x->d_inv58, x->d_M28, d_parts, fl);
-    HIP_TRY(hipGetLastError());
-    if (!ctx->opt.crt_skip_cleanup) {
-      crt32_scale_kernel<512, true><<<grid, 128, 0, ctx->stream>>>((const u32*)d_t, n, NP, x->pr, x->d_cinv, x->d_inv58, x->d_M28, d_parts, fl);
-      HIP_TRY(hipGetLastError());
-    }
+    if (logQ == 512 && !S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 0>(ctx, x, (const u32*)d_t, count, d_parts);
+    if (logQ == 512 && S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 1>(ctx, x, (const u32*)d_t, count, d_parts);
+    if (logQ == 1024 && !S) return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 0>(ctx, x, (const u32*)d_t, count, d_parts);
+    return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 1>(ctx, x, (const u32*)d_t, count, d_parts);
   }
-  return 0;
 }

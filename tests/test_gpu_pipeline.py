@@ -151,13 +151,15 @@ def test_sum_form_crt_undecided_coefficients(monkeypatch):
     ctx.set_option("crt_skip_cleanup", 0)
 
 
-def test_tensor_half_over_30_bit_primes_equals_the_chain():
+@pytest.mark.parametrize("m,logQ,p", [(32768, 512, 23), (1 << 16, 1024, 65537)])
+def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     """At the metric ring the fused pipeline forms tProd's integers modulo 35 primes below 2^30 instead of the chain
-    (kernels_tensor32.hip; Ciphertext.cpp:167-218 only ever exposes round(x / 2^logQ) mod 2^logQ of them).  Same bits as the chain path
+    (kernels_tensor32.hip; Ciphertext.cpp:167-218 only ever exposes round(x / 2^logQ) mod 2^logQ of them; 70 primes and rows of 2^15 at
+    the stress shape, where the head / tail stages of the row transform sit inside the two conversions).  Same bits as the chain path
     (option tensor32 = 0) and as the oracle on random inputs, on the extremes of the centred range in every coefficient (the largest
     |x| the bound allows), and on coefficients whose rounding sits on the edge: those must go through the exact second pass (the
     result is wrong when that pass is switched off)."""
-    m, logQ, p, count = 32768, 512, 23, 4
+    count = 4
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 4242, count)
     n = ctx.phim
     mod = 1 << logQ
@@ -176,7 +178,8 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain():
         v %= mod
         return v - mod if v >= mod // 2 else v
 
-    deltas = [0, 1, -1, 2, -2, 3, -3, 5, -5, 7, -7, 8, -8, 100, -100, 1 << 64, -(1 << 64), 1 << 400, -(1 << 400), (1 << 448) - 1, -(1 << 448)]
+    deltas = [0, 1, -1, 2, -2, 3, -3, 5, -5, 7, -7, 8, -8, 100, -100, 1 << 64, -(1 << 64), 1 << (logQ - 112), -(1 << (logQ - 112)),
+              (1 << (logQ - 64)) - 1, -(1 << (logQ - 64))]
     A = [centred((d - (mod >> 1)) * inv_p) for d in deltas]
     a[2, 0] = O.ints_to_limbs(A + [0] * (n - len(A)), nl)
     a[2, 1] = O.ints_to_limbs([0] * (n - len(A)) + A, nl)
