@@ -841,6 +841,7 @@ int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, 
   if (!k->aux_fold && k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
   if (!k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, false>(ctx, t, k, d_o, npolys, d_out, nl_out);
   if (!k->aux32 && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30) return launch_ks_recombine_t<34, 1024, 72, 30, false>(ctx, t, k, d_o, npolys, d_out, nl_out);
+  if (!k->aux_fold && k->aux32 && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30) return launch_ks_recombine_t<34, 1024, 72, 30, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
   // ... and the run-time form for every other chain
   const u64 q0 = ctx->q[0], q1 = ctx->q[1];
   const u64 inv = hm::invmod(q0 % q1, q1);
