@@ -91,6 +91,7 @@ static const OptDesc kOptions[] = {
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
   {"dot32_v2", "FHESI_DOT32_V2", offsetof(CtxOptions, dot32_v2), false},
   {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
+  {"automorph_rows", "FHESI_AUTOMORPH_ROWS", offsetof(CtxOptions, automorph_rows), false},
   {"ntt32_v3", "FHESI_NTT32_V3", offsetof(CtxOptions, ntt32_v3), false},
 };
 static void opt_store(CtxOptions* o, const OptDesc& d, long long v) {
@@ -1299,6 +1300,17 @@ extern "C" int fhesi_ct_automorph_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* 
   void* d_parts;
   FHESI_TRY(ws_reserve(c, 2, (size_t)count * ncomp * nlq * n * 8, &d_parts));
   u64* d_rows;
+  if (kk <= 0 || kk >= c->m || c->zms_idx[kk] < 0) FHESI_FAIL("automorph: k=%lld is not in Zm*", (long long)kk);     // DoubleCRT.cpp:442-443
+  if (!c->opt.automorph_rows) {
+    // on power-of-two, prime and 2 x prime rings a(X^k) mod Phi_m is a signed gather of the coefficients: no row transform (kernels_ct.hip)
+    const int r = launch_ct_automorph_parts(c, (const u64*)in, nlimbs_in, count * ncomp, kk, logQ, (u64*)d_parts, nlq);
+    if (r == 1) return 1;
+    if (r == 0) {
+      void* d_t2;
+      FHESI_TRY(ws_reserve(c, 1, (size_t)count * 2 * c->L * n * 8, &d_t2));
+      return key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, count, (u64*)d_t2, out, nlimbs);
+    }
+  }
   if (kk == 1) {
     // no automorphism: ApplyKeySwitch on the unscaled ciphertext as it is; ByteDecomp needs the positive residues limb-major
     FHESI_TRY(automorph_rows(c, 1, in, ncomp, nlimbs_in, count, &d_rows));

@@ -79,6 +79,7 @@ struct CtxOptions {
   int ntt32_v3 = 1;         // 1: 32-bit transforms laid out for three workgroups per CU (half-size LDS buffer), 0: the two-workgroup form
   int dot32_v2 = 1;         // 1: dot32_kernel2 (a wave owns both key rows of a limb), 0: dot32_kernel
   int dot32_v3 = 0;         // 1: dot32_kernel3 (two limbs per wave, 4 ciphertexts per tile, two workgroups per CU)
+  int automorph_rows = 0;   // 1: Ciphertext >>= through DoubleCRT::automorph on evaluation rows (the reference's structure) even where the coefficient gather applies
   int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)
 };
 
@@ -258,6 +259,7 @@ int launch_rows_equal(fhesi_ctx* ctx, const u64* a, const u64* b, i64 nwords, in
 // kernels_ct.hip : coefficient-domain ciphertext algebra on device batches
 int launch_ct_add(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 ncoeffs, int nl, int logQ);
 int launch_ct_mul_long(fhesi_ctx* ctx, u64* d_ct, i64 ncoeffs, int nl, int logQ, i64 l);
+int launch_ct_automorph_parts(fhesi_ctx* ctx, const u64* d_in /* [npolys][n][nl_in] */, int nl_in, i64 npolys, i64 kk, int logQ, u64* d_parts /* [npolys][nlq][n] */, int nlq);   // 2: ring not covered
 int launch_gather(fhesi_ctx* ctx, const u64* d_pool, const int* d_idx, i64 count, i64 words, u64* d_out);
 int launch_segment_sum(fhesi_ctx* ctx, const u64* d_in, const int* d_seg, i64 ngroups, int ncomp, u64* d_out);
 int launch_encrypt_combine(fhesi_ctx* ctx, const u64* d_rows /* [count][3][L][n] */, const u64* d_pk /* [2][L][n] */, i64 count, u64* d_out /* [count][2][L][n] */);

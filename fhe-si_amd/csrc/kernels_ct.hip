@@ -81,6 +81,88 @@ int launch_ct_add(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 ncoeffs, int
   return 0;
 }
 
+// ---- Ciphertext::operator>>= on the coefficients themselves.
+// The reference takes X -> X^k in evaluation form (DoubleCRT::automorph, DoubleCRT.cpp:439-465, between DoubleCRT(poly) and toPoly:
+// Ciphertext.cpp:54-59); its result is the INTEGER polynomial a(X^k) mod Phi_m (the coefficients, at most two input coefficients
+// added, stay far below half the chain product).  On the rings below that polynomial is a signed gather:
+//   m = 2n (power of two):  X^n = -1:              out_i = +-a_j,  j k = i or i + n (mod 2n)
+//   m = 2q', q' an odd prime (the reference's safe-prime rings), phi = q' - 1:  X^q' = -1 modulo X^q' + 1 = (X + 1) Phi_m,
+//       R_i = +-a_j with j k = i (mod q'), sign - when j k mod 2q' >= q';  out_i = R_i - (-1)^i R_(q'-1)   (Phi_m = sum (-X)^i, monic)
+//   m prime, phi = m - 1:   X^m = 1,  R_i = a_j with j k = i (mod m);  out_i = R_i - R_(m-1)   (Phi_m = sum X^i)
+// so no row transform is needed at all: out = positive residue modulo 2^logQ, limb-major, as ByteDecompPart takes it (Ciphertext.cpp:94).
+// mode: 0 power of two, 1 m = 2 prime, 2 m prime.  in [npolys][n][nl_in] two's complement;  out [npolys][nlq][n].
+__global__ void __launch_bounds__(256) ct_automorph_parts_kernel(const u64* __restrict__ in, i64 n, int nl_in, i64 m, i64 kk, i64 kinv, int mode, int logQ,
+                                                                 u64* __restrict__ out, int nlq) {
+  const i64 poly = blockIdx.y;
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // term 1: s1 a[j1], term 2: s2 a[j2]  (s = 0: absent)
+  i64 j1 = 0, j2 = 0;
+  int s1 = 0, s2 = 0;
+  if (mode == 0) {
+    const i64 j = (i64)(((u128)i * (u128)kinv) % (u128)m);          // j k = i (mod 2n)
+    j1 = j < n ? j : j - n;
+    s1 = j < n ? 1 : -1;
+  } else if (mode == 1) {
+    const i64 q = m / 2;
+    auto term = [&](i64 e, i64& j, int& sg) {                        // the a_j with j k = e (mod q'), and its sign
+      j = (i64)(((u128)e * (u128)(kinv % q)) % (u128)q);
+      if (j > q - 2) { sg = 0; j = 0; return; }
+      sg = ((i64)(((u128)j * (u128)kk) % (u128)m) >= q) ? -1 : 1;
+    };
+    term(i, j1, s1);
+    term(q - 1, j2, s2);
+    s2 = (i & 1) ? s2 : -s2;                                        // - (-1)^i R_(q'-1)
+  } else {
+    auto term = [&](i64 e, i64& j, int& sg) {
+      j = (i64)(((u128)e * (u128)kinv) % (u128)m);
+      sg = j > m - 2 ? 0 : 1;
+      if (!sg) j = 0;
+    };
+    term(i, j1, s1);
+    term(m - 1, j2, s2);
+    s2 = -s2;
+  }
+  const u64* __restrict__ a1 = in + (poly * n + j1) * nl_in;
+  const u64* __restrict__ a2 = in + (poly * n + j2) * nl_in;
+  const u64 ext1 = (a1[nl_in - 1] >> 63) ? ~0ull : 0ull, ext2 = (a2[nl_in - 1] >> 63) ? ~0ull : 0ull;
+  u64 carry = (s1 < 0 ? 1 : 0) + (s2 < 0 ? 1 : 0);                  // the +1 of every two's complement negation
+  u64* __restrict__ o = out + poly * nlq * n + i;
+  for (int w = 0; w < nlq; ++w) {
+    u64 x1 = w < nl_in ? a1[w] : ext1, x2 = w < nl_in ? a2[w] : ext2;
+    x1 = s1 == 0 ? 0 : (s1 < 0 ? ~x1 : x1);
+    x2 = s2 == 0 ? 0 : (s2 < 0 ? ~x2 : x2);
+    const u128 sum = (u128)x1 + x2 + carry;
+    u64 v = (u64)sum;
+    carry = (u64)(sum >> 64);
+    const int bits_left = logQ - 64 * w;
+    if (bits_left < 64) v &= ((u64)1 << bits_left) - 1;
+    o[(i64)w * n] = v;
+  }
+}
+// 0 = launched; 2 = this ring / exponent is not covered (the caller keeps the evaluation-form path)
+int launch_ct_automorph_parts(fhesi_ctx* ctx, const u64* d_in, int nl_in, i64 npolys, i64 kk, int logQ, u64* d_parts, int nlq) {
+  const i64 m = ctx->m, n = ctx->phim;
+  int mode;
+  if (ctx->pow2) mode = 0;
+  else if (m % 2 == 0 && (m / 2) % 2 == 1 && hm::is_prime((u64)(m / 2)) && n == m / 2 - 1) mode = 1;
+  else if (hm::is_prime((u64)m) && n == m - 1) mode = 2;
+  else return 2;
+  if (!npolys) return 0;
+  // k^-1 mod m (k in Z_m^*: checked by the caller)
+  i64 kinv = 0;
+  {
+    i64 a = kk % m, b = m, x0 = 1, x1 = 0;
+    while (b) { const i64 qq = a / b; i64 t = a - qq * b; a = b; b = t; t = x0 - qq * x1; x0 = x1; x1 = t; }
+    if (a != 1) FHESI_FAIL("automorph: k=%lld is not in Zm*", (long long)kk);
+    kinv = ((x0 % m) + m) % m;
+  }
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)npolys);
+  ct_automorph_parts_kernel<<<grid, 256, 0, ctx->stream>>>(d_in, n, nl_in, m, kk % m, kinv, mode, logQ, d_parts, nlq);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int launch_ct_mul_long(fhesi_ctx* ctx, u64* d_ct, i64 ncoeffs, int nl, int logQ, i64 l) {
   if (!ncoeffs) return 0;
   if (nl > 32) FHESI_FAIL("ciphertext coefficients of %d limbs exceed the supported 32", nl);
