@@ -1282,6 +1282,15 @@ extern "C" int fhesi_ct_automorph_dev(fhesi_ctx* c, int64_t kk, const uint64_t* 
   CHECK_CTX(c);
   if (nparts < 1 || nlimbs_in < 1 || nlimbs_out < 1) FHESI_FAIL("Ciphertext >>= : bad shape");
   if (!count) return 0;
+  if (kk <= 0 || kk >= c->m || c->zms_idx[kk] < 0) FHESI_FAIL("automorph: k=%lld is not in Zm*", (long long)kk);     // DoubleCRT.cpp:442-443
+  // the coefficient gather gives the integers a(X^k) mod Phi_m themselves; the reference's toPoly centres modulo the chain product: the
+  // same thing as long as the sum of two input coefficients (64 nlimbs_in + 1 bits) stays below half of it
+  double chain = 0;
+  for (int i = 0; i < c->L; ++i) chain += std::log2((double)c->q[i]);
+  if (!c->opt.automorph_rows && 64.0 * nlimbs_in + 2 < chain) {        // (fewer output limbs truncate the two's complement value in both forms)
+    const int r = launch_ct_automorph_parts(c, (const u64*)in, nlimbs_in, count * nparts, kk, 0, (u64*)out, nlimbs_out);
+    if (r != 2) return r;
+  }
   u64* d_rows;
   FHESI_TRY(automorph_rows(c, kk, in, nparts, nlimbs_in, count, &d_rows));
   CrtTables* t;

@@ -90,7 +90,8 @@ int launch_ct_add(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 ncoeffs, int
 //       R_i = +-a_j with j k = i (mod q'), sign - when j k mod 2q' >= q';  out_i = R_i - (-1)^i R_(q'-1)   (Phi_m = sum (-X)^i, monic)
 //   m prime, phi = m - 1:   X^m = 1,  R_i = a_j with j k = i (mod m);  out_i = R_i - R_(m-1)   (Phi_m = sum X^i)
 // so no row transform is needed at all: out = positive residue modulo 2^logQ, limb-major, as ByteDecompPart takes it (Ciphertext.cpp:94).
-// mode: 0 power of two, 1 m = 2 prime, 2 m prime.  in [npolys][n][nl_in] two's complement;  out [npolys][nlq][n].
+// mode: 0 power of two, 1 m = 2 prime, 2 m prime.  in [npolys][n][nl_in] two's complement;  out [npolys][nlq][n] (logQ > 0), or the
+// integers themselves, sign-extended, coefficient-major [npolys][n][nlq] (logQ = 0: toPoly of Ciphertext >>= without a key switch).
 __global__ void __launch_bounds__(256) ct_automorph_parts_kernel(const u64* __restrict__ in, i64 n, int nl_in, i64 m, i64 kk, i64 kinv, int mode, int logQ,
                                                                  u64* __restrict__ out, int nlq) {
   const i64 poly = blockIdx.y;
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(256) ct_automorph_parts_kernel(const u64* __re
   const u64* __restrict__ a2 = in + (poly * n + j2) * nl_in;
   const u64 ext1 = (a1[nl_in - 1] >> 63) ? ~0ull : 0ull, ext2 = (a2[nl_in - 1] >> 63) ? ~0ull : 0ull;
   u64 carry = (s1 < 0 ? 1 : 0) + (s2 < 0 ? 1 : 0);                  // the +1 of every two's complement negation
-  u64* __restrict__ o = out + poly * nlq * n + i;
+  u64* __restrict__ o = logQ ? out + poly * nlq * n + i : out + (poly * n + i) * nlq;
   for (int w = 0; w < nlq; ++w) {
     u64 x1 = w < nl_in ? a1[w] : ext1, x2 = w < nl_in ? a2[w] : ext2;
     x1 = s1 == 0 ? 0 : (s1 < 0 ? ~x1 : x1);
@@ -135,9 +136,11 @@ __global__ void __launch_bounds__(256) ct_automorph_parts_kernel(const u64* __re
     const u128 sum = (u128)x1 + x2 + carry;
     u64 v = (u64)sum;
     carry = (u64)(sum >> 64);
-    const int bits_left = logQ - 64 * w;
-    if (bits_left < 64) v &= ((u64)1 << bits_left) - 1;
-    o[(i64)w * n] = v;
+    if (logQ) {
+      const int bits_left = logQ - 64 * w;
+      if (bits_left < 64) v &= ((u64)1 << bits_left) - 1;
+      o[(i64)w * n] = v;
+    } else o[w] = v;
   }
 }
 // 0 = launched; 2 = this ring / exponent is not covered (the caller keeps the evaluation-form path)
