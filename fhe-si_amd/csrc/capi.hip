@@ -1509,13 +1509,21 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
   const i64 chunk = batch_chunk(c, 3 * k->ndigits);           // groups per key-switch call
   // distinct operands per pass: bound their evaluation-form rows (2 L n words each) to about 4 GiB
   i64 ucap = (i64)(4.0 * 1024 * 1024 * 1024 / ((double)2 * L * n * 8));
+  // the sums' integers over primes below 2^30 where that path applies (kernels_tensor32.hip; tProd is not visible from here either)
+  i64 gmax = 1;
+  for (i64 g = 0; g < ngroups; ++g) gmax = std::max<i64>(gmax, seg[g + 1] - seg[g]);
+  const bool t32 = tensor32_sum_applies(c, p, nlimbs, logQ, gmax);
+  if (t32) {
+    FHESI_TRY(tensor32_sum_begin(c, p, nlimbs, logQ, gmax));
+    ucap = (i64)(4.0 * 1024 * 1024 * 1024 / ((double)tensor32_sum_bytes(c, 1) / 3 * 2));
+  }
   if (c->opt.wave_operands > 1) ucap = c->opt.wave_operands;
   if (ucap < 2) ucap = 2;
   const u64 lift[2] = {p, p};
   std::vector<int> ua, ub, sa, sb, lseg, host_idx;
   std::map<int, int> ma, mb;
   // one pass: terms [t0, t1) of the groups [g, g2) (group boundaries in gseg, relative to t0), summed into d_sum[0 .. g2-g)
-  auto pass = [&](i64 t0, i64 t1, const std::vector<int>& gseg, bool accumulate, u64* d_sum) -> int {
+  auto pass = [&](i64 t0, i64 t1, const std::vector<int>& gseg, bool accumulate, u64* d_sum) -> int {      // (d_sum: u32 rows on the 30-bit path)
     ua.clear(); ub.clear(); ma.clear(); mb.clear();
     sa.resize(t1 - t0); sb.resize(t1 - t0);
     for (i64 t = t0; t < t1; ++t) {
@@ -1524,9 +1532,9 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
       sa[t - t0] = ia->second; sb[t - t0] = ib->second;
     }
     const i64 nua = (i64)ua.size(), nub = (i64)ub.size(), nt = t1 - t0, ng = (i64)gseg.size() - 1;
-    void *d_ops, *d_rows, *d_ix;
+    void *d_ops, *d_rows = nullptr, *d_ix;
     FHESI_TRY(ws_reserve(c, 7, (size_t)(nua + nub) * ct_words * 8, &d_ops));
-    FHESI_TRY(ws_reserve(c, 0, (size_t)(nua + nub) * 2 * L * n * 8, &d_rows));
+    if (!t32) FHESI_TRY(ws_reserve(c, 0, (size_t)(nua + nub) * 2 * L * n * 8, &d_rows));
     FHESI_TRY(ws_reserve(c, 5, sizeof(int) * (size_t)(nua + nub + 2 * nt + ng + 1), &d_ix));
     host_idx.clear();
     host_idx.insert(host_idx.end(), ua.begin(), ua.end());
@@ -1542,6 +1550,7 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
     u64* ca = (u64*)d_rows;
     u64* cb = ca + (size_t)nua * 2 * L * n;
     FHESI_TRY(launch_gather(c, (const u64*)pool, dix, nua + nub, ct_words, d_a));
+    if (t32) return tensor32_sum_pass(c, d_a, nua, nub, dix + nua + nub, dix + nua + nub + nt, dix + nua + nub + 2 * nt, ng, nt, accumulate, d_sum);
     // c1 = DoubleCRT(parts * p), c2 = DoubleCRT(other.parts)   (Ciphertext.cpp:169-176)
     FHESI_TRY(launch_rns_reduce(c, d_a, nlimbs, n, nua, 2, lift, ca, L, nullptr));
     FHESI_TRY(launch_rns_reduce(c, d_b, nlimbs, n, nub, 2, nullptr, cb, L, nullptr));
@@ -1564,7 +1573,7 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
     }
     const i64 ng = g2 - g;
     void* d_sum;
-    FHESI_TRY(ws_reserve(c, 4, (size_t)ng * tp_words * 8, &d_sum));
+    FHESI_TRY(ws_reserve(c, 4, t32 ? tensor32_sum_bytes(c, ng) : (size_t)ng * tp_words * 8, &d_sum));
     if (ng == 1 && (i64)(seen_a.size() + seen_b.size()) > ucap) {
       // one group with more distinct operands than a pass holds: its terms are summed piecewise into the same accumulator
       const i64 step = ucap / 2;
@@ -1578,6 +1587,13 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
       for (i64 i = 0; i <= ng; ++i) gseg[i] = seg[g + i] - seg[g];
       FHESI_TRY(pass(seg[g], seg[g2], gseg, false, (u64*)d_sum));
     }
+    if (t32) {
+      void *d_parts, *d_t2;
+      FHESI_TRY(ws_reserve(c, 2, (size_t)ng * 3 * ((logQ + 63) / 64) * n * 8, &d_parts));
+      FHESI_TRY(tensor32_sum_finish(c, d_sum, ng, (u64*)d_parts));
+      FHESI_TRY(ws_reserve(c, 1, (size_t)ng * 2 * L * n * 8, &d_t2));
+      FHESI_TRY(key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, ng, (u64*)d_t2, out + (size_t)g * ct_words, nlimbs));
+    } else
     FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_sum, ng, out + (size_t)g * ct_words, nlimbs));
     g = g2;
   }

@@ -175,6 +175,12 @@ void aux32_free(fhesi_ctx* ctx);
 void tensor32_free(fhesi_ctx* ctx);
 bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ);
 int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts /* [count*3][logQ/64][n] */);
+// ... and for sums of products per group (fhesi_ct_mul_sum_relin_dev): begin fixes the configuration for at most gmax terms per group
+bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax);
+int tensor32_sum_begin(fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax);
+size_t tensor32_sum_bytes(const fhesi_ctx* ctx, i64 ngroups);
+int tensor32_sum_pass(fhesi_ctx* ctx, const u64* d_ops, i64 nua, i64 nub, const int* d_slot_a, const int* d_slot_b, const int* d_seg, i64 ng, i64 nterms, bool accumulate, void* d_sum);
+int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts);
 const u32* aux32_primes(fhesi_ctx* ctx);          // the four primes (host array), nullptr on error
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */);

@@ -21,29 +21,46 @@
 // the tail of the inverse inside crt32_scale_kernel (its first multiplication takes (A + B) or (A - B) with the tail constant folded into
 // the CRT constant), so a row still passes through exactly one forward and one inverse kernel.  With more than 62 primes the CRT words
 // are 26 bits wide (71 terms below 2^56 per 64-bit accumulator).
+// The reference's safe-prime rings (m = 2q', Bluestein rows in the reference and in the chain path) take the same route as LINEAR
+// convolutions: phi(m) coefficients zero-padded into rows of 2^14, products of degree < 2 phi(m) - 1, and the reduction modulo
+// X^q' + 1 and Phi_m -- out_j = S_j - S_(j+q') - (-1)^j S_(q'-1), linear, so it is applied to the residues in the loader of the CRT
+// kernel (crt32_scale_generic_kernel: any logQ, words at run-time positions through LDS).  Sums of products per group
+// (fhesi_ct_mul_sum_relin_dev: Matrix products inside Regression) are formed in evaluation form by tensor_sum32_kernel.
 // fhesi_ct_mul_dev keeps the reference chain (its rows ARE visible).  Option tensor32 = 0 keeps the chain in the fused pipeline too.
 #include "fhesi_internal.h"
 #include "ntt32_core.inc"
 #include <cmath>
 
-struct fhesi_tensor32 {
-  int NP = 0, nl = 0, logQ = 0, S = 0, R = 28, WT = 0;
+// one (lift, limb count, logQ, prime count) configuration: the conversion tables
+struct T32Config {
   u64 lift = 0;
+  int nl = 0, logQ = 0, NP = 0, R = 28, WT = 0;
+  bool generic = false;              // crt32_scale_generic_kernel (any logQ, fold) instead of the compiled shapes
   T32Primes pr;
-  Tw32* d_fwd = nullptr;             // [NP][2^S][2^14]
-  Tw32* d_inv = nullptr;
   u32* d_rns = nullptr;              // [2][NP][2 nl + 6]: (s 2^(32k) mod p) k < 2 nl, -(s 2^(64 nl)) mod p, 2^32 mod p, floor(2^61 / p), p, head twiddle (w, w');  s = lift (class 0) or 1
   Tw32* d_cinv = nullptr;            // [NP][2] (M / p_i)^-1 mod p_i  [times 1/2 | times psi^-brv(1) / 2: the tail of a 2^15-point inverse]
   u32* d_inv57 = nullptr;            // [NP] floor(2^57 / p_i)
   u32* d_Mw = nullptr;               // [NP + 1][WT]: M_i in words of R bits; row NP = 2^(R WT) - M
+  ~T32Config() { hipFree(d_rns); hipFree(d_cinv); hipFree(d_inv57); hipFree(d_Mw); }
+};
+struct fhesi_tensor32 {
+  int S = 0;                         // rows of 2^14 << S
+  std::vector<u32> primes;           // the primes with transform tables, largest first
+  std::vector<Tw32> head, tail;      // per prime: psi^brv(1), psi^-brv(1)   (S = 1)
+  Tw32* d_fwd = nullptr;             // [primes][2^S][2^14]
+  Tw32* d_inv = nullptr;
+  std::vector<T32Config*> cfgs;
+  T32Config* cur = nullptr;          // the configuration of the running sum (tensor32_sum_begin)
 };
 
-static void t32_release(fhesi_tensor32* x) {
+void tensor32_free(fhesi_ctx* ctx) {
+  fhesi_tensor32* x = ctx->tensor32;
   if (!x) return;
-  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_rns); hipFree(x->d_cinv); hipFree(x->d_inv57); hipFree(x->d_Mw);
+  for (T32Config* c : x->cfgs) delete c;
+  hipFree(x->d_fwd); hipFree(x->d_inv);
   delete x;
+  ctx->tensor32 = nullptr;
 }
-void tensor32_free(fhesi_ctx* ctx) { t32_release(ctx->tensor32); ctx->tensor32 = nullptr; }
 
 // ---------------------------------------------------------------------------------------------- host big integers (little-endian u64 limbs)
 typedef std::vector<u64> Big;
@@ -56,58 +73,67 @@ static u32 big_word(const Big& a, int l, int R) {          // word l of the radi
   return (u32)(v & (((u64)1 << R) - 1));
 }
 
-// the two compiled shapes of crt32_scale_kernel
+// the two compiled shapes of crt32_scale_kernel, and the run-time form
 static constexpr int T32_WT_512 = 38, T32_R_512 = 28;        // logQ = 512: words of 28 bits (up to 62 primes), 1064 bits per table row
 static constexpr int T32_WT_1024 = 82, T32_R_1024 = 26;      // logQ = 1024: words of 26 bits (up to 72 primes), 2132 bits per table row
+static constexpr int T32_GEN_NW = 24, T32_GEN_NWX = 40;      // generic kernel: words formed in the first pass / in the exact pass (logQ <= 512)
 
-// The number of primes the tensor half needs, 0 if this shape does not run through it.
-//   |x| < 2^TB with TB = 2 (64 nl - 1) + bits(p) + log2(n) + 1;  M > 2^(TB + 3) keeps x/M below 1/8 (kappa is then decided by a coarse
-//   fixed-point sum), and the chain product must exceed 2^(TB + 1) so that the reference's own centred integers are these same integers.
-static int t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, std::vector<u32>* primes) {
-  if (!ctx->pow2 || (ctx->logn != A32_LOGN && ctx->logn != A32_LOGN + 1) || !ctx->opt.tensor32 || !ctx->opt.ntt32_v3) return 0;
-  if ((logQ != 512 && logQ != 1024) || nlimbs < 1 || nlimbs > 16 || 64 * nlimbs < logQ || p < 2) return 0;       // (the instantiations of crt32_scale_kernel)
-  const int lg = ctx->logn;
-  int pbits = 0;
+struct T32Plan { int NP = 0; bool generic = false; };
+// The number of primes the tensor half needs (0: this shape does not run through it).
+//   |x| < 2^TB with TB = 2 (logQ - 1) + bits(p) + log2(coefficients) + 1 [+ log2(terms per sum)] [+ 2: the three-term fold of the
+//   safe-prime rings];  M > 2^(TB + 3) keeps x/M below 1/8 (kappa is then decided by a coarse fixed-point sum), and the chain product must
+//   exceed 2^(TB + 1) so that the reference's own centred integers are these same integers.
+static T32Plan t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax, std::vector<u32>* primes) {
+  T32Plan pl;
+  if (!ctx->opt.tensor32 || !ctx->opt.ntt32_v3 || p < 2 || nlimbs < 1 || nlimbs > 16 || 64 * nlimbs < logQ || gmax < 1) return pl;
+  const bool lin = ctx->lin_q != 0;
+  if (!lin && !(ctx->pow2 && (ctx->logn == A32_LOGN || ctx->logn == A32_LOGN + 1))) return pl;
+  const int lg = lin ? A32_LOGN : ctx->logn;                 // rows of 2^lg
+  const bool compiled = !lin && (logQ == 512 || logQ == 1024);
+  if (!compiled && (logQ < 64 || logQ > 512 || lg != A32_LOGN)) return pl;       // the generic CRT kernel: logQ <= 512, rows of 2^14
+  int pbits = 0, gbits = 0, cbits = 0;
   while (pbits < 64 && (p >> pbits)) ++pbits;
-  const double TB = 2.0 * (64 * nlimbs - 1) + pbits + lg + 1;
+  while (((i64)1 << gbits) < gmax) ++gbits;
+  while (((i64)1 << cbits) < ctx->phim) ++cbits;
+  // (operands are centred residues modulo 2^logQ, as every reference Ciphertext holds them: Ciphertext.cpp reduces after each operation)
+  const double TB = 2.0 * (logQ - 1) + pbits + cbits + 1 + gbits + (lin ? 2 : 0);
   double chain = 0;
   for (int i = 0; i < ctx->L; ++i) chain += std::log2((double)ctx->q[i]);
-  if (chain < TB + 1.5) return 0;
-  const int maxp = logQ == 512 ? 62 : T32_MAXP;
+  if (chain < TB + 1.5) return pl;
+  const int maxp = (compiled && logQ == 1024) ? T32_MAXP : 62;
   double have = 0;
   int np = 0;
   for (u64 k = ((u64)1 << (29 - lg)) - 1; k > ((u64)1 << (28 - lg)) && have < TB + 3.5; --k) {
     const u64 cand = (k << (lg + 1)) + 1;
     if (cand > ((u64)1 << 30) - ((u64)1 << 15) + 1 || !hm::is_prime(cand)) continue;
-    if (np == maxp) return 0;
+    if (np == maxp) return pl;
     if (primes) primes->push_back((u32)cand);
     have += std::log2((double)cand);
     ++np;
   }
-  if (have < TB + 3.5) return 0;
-  // the window of crt32_scale_kernel: words up to bit 2 logQ, all of M inside the table row
-  if (have > (logQ == 512 ? (double)T32_R_512 * T32_WT_512 : (double)T32_R_1024 * T32_WT_1024) - 8) return 0;
-  return np;
+  if (have < TB + 3.5) return pl;
+  // all of M inside the table row
+  const double room = compiled ? (logQ == 512 ? (double)T32_R_512 * T32_WT_512 : (double)T32_R_1024 * T32_WT_1024) : 28.0 * ((have + 8) / 28 + 2);
+  if (have > room - 8) return pl;
+  pl.NP = np;
+  pl.generic = !compiled;
+  return pl;
 }
-bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ) { return t32_plan(ctx, p, nlimbs, logQ, nullptr) > 0; }
+bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ) { return t32_plan(ctx, p, nlimbs, logQ, 1, nullptr).NP > 0; }
+bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax) { return t32_plan(ctx, p, nlimbs, logQ, gmax, nullptr).NP > 0; }
 
-static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
+// transform tables of the first `want` primes (grown on demand; a growth waits for the streams)
+static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
   fhesi_tensor32* x = ctx->tensor32;
-  if (x && x->lift == lift && x->nl == nlimbs && x->logQ == logQ) return 0;
-  std::vector<u32> primes;
-  const int NP = t32_plan(ctx, lift, nlimbs, logQ, &primes);
-  if (!NP) FHESI_FAIL("tensor32: shape not supported");
-  if (x) { HIP_TRY(hipStreamSynchronize(ctx->stream)); if (ctx->lane_stream) HIP_TRY(hipStreamSynchronize(ctx->lane_stream)); tensor32_free(ctx); }
-  x = new fhesi_tensor32();
-  const int S = ctx->logn - A32_LOGN, lg = ctx->logn;
-  const int R = logQ == 512 ? T32_R_512 : T32_R_1024, WT = logQ == 512 ? T32_WT_512 : T32_WT_1024;
-  x->NP = NP; x->nl = nlimbs; x->logQ = logQ; x->lift = lift; x->S = S; x->R = R; x->WT = WT;
+  if (!x) { x = new fhesi_tensor32(); x->S = (!ctx->lin_q && ctx->logn == A32_LOGN + 1) ? 1 : 0; ctx->tensor32 = x; }
+  if (x->primes.size() >= primes.size()) return 0;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->lane_stream) HIP_TRY(hipStreamSynchronize(ctx->lane_stream));
+  const int S = x->S, lg = A32_LOGN + S, NP = (int)primes.size();
   const i64 n = (i64)A32_N << S;
   const size_t per_prime = (size_t)A32_N << S;
   std::vector<Tw32> hf((size_t)NP * per_prime, Tw32{0, 0}), hi((size_t)NP * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n);
-  const int stride = 2 * nlimbs + 6;
-  std::vector<u32> rns((size_t)2 * NP * stride);
-  std::vector<u64> tail_dif(NP, 0);
+  x->head.assign(NP, Tw32{0, 0}); x->tail.assign(NP, Tw32{0, 0});
   for (int a = 0; a < NP; ++a) {
     const u64 p = primes[a];
     u64 psi = 0;
@@ -115,7 +141,7 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
       const u64 cand = hm::powmod(gq, (p - 1) / (2 * (u64)n), p);
       if (hm::powmod(cand, (u64)n, p) == p - 1) psi = cand;
     }
-    if (!psi) { t32_release(x); FHESI_FAIL("tensor32: no 2n-th root"); }
+    if (!psi) FHESI_FAIL("tensor32: no 2n-th root");
     const u64 ipsi = hm::invmod(psi, p);
     auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
     for (u64 idx = 0; idx < (u64)n; ++idx) {       // the full table of the n-point transform: psi^brv(idx) (w itself: the plain-row kernels take a32_ct<false>)
@@ -133,13 +159,42 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
             hf[((size_t)a * 2 + h) * A32_N + mp + ip] = ff[2 * mp + h * mp + ip];
             hi[((size_t)a * 2 + h) * A32_N + mp + ip] = fi[2 * mp + h * mp + ip];
           }
-      tail_dif[a] = fi[1].w;
+      x->head[a] = ff[1]; x->tail[a] = fi[1];
     }
+  }
+  hipFree(x->d_fwd); hipFree(x->d_inv);
+  x->d_fwd = x->d_inv = nullptr;
+  if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) FHESI_FAIL("tensor32: hipMalloc failed");
+  HIP_TRY(hipMemcpy(x->d_fwd, hf.data(), hf.size() * sizeof(Tw32), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(x->d_inv, hi.data(), hi.size() * sizeof(Tw32), hipMemcpyHostToDevice));
+  x->primes = primes;
+  return 0;
+}
+
+static int t32_config(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ, i64 gmax, T32Config** out) {
+  std::vector<u32> primes;
+  const T32Plan pl = t32_plan(ctx, lift, nlimbs, logQ, gmax, &primes);
+  if (!pl.NP) FHESI_FAIL("tensor32: shape not supported");
+  FHESI_TRY(t32_ring(ctx, primes));
+  fhesi_tensor32* x = ctx->tensor32;
+  for (T32Config* c : x->cfgs)
+    if (c->lift == lift && c->nl == nlimbs && c->logQ == logQ && c->NP == pl.NP && c->generic == pl.generic) { *out = c; return 0; }
+  const int NP = pl.NP, S = x->S;
+  double have = 0;
+  for (int a = 0; a < NP; ++a) have += std::log2((double)primes[a]);
+  T32Config* c = new T32Config();
+  c->lift = lift; c->nl = nlimbs; c->logQ = logQ; c->NP = NP; c->generic = pl.generic;
+  c->R = pl.generic ? 28 : (logQ == 512 ? T32_R_512 : T32_R_1024);
+  c->WT = pl.generic ? (int)((have + 8) / 28) + 2 : (logQ == 512 ? T32_WT_512 : T32_WT_1024);
+  const int R = c->R, WT = c->WT, stride = 2 * nlimbs + 6;
+  std::vector<u32> rns((size_t)2 * NP * stride);
+  for (int a = 0; a < NP; ++a) {
+    const u64 p = primes[a];
     const u64 ninv = hm::invmod((u64)A32_N % p, p);     // of the 2^14-point (sub-)transform; the tail carries the other 1/2
-    x->pr.p[a] = (u32)p;
-    x->pr.ninv[a] = (u32)ninv;
-    x->pr.ninv_p[a] = (u32)((ninv << 32) / p);
-    x->pr.mu61[a] = (u32)(((u64)1 << 61) / p);
+    c->pr.p[a] = (u32)p;
+    c->pr.ninv[a] = (u32)ninv;
+    c->pr.ninv_p[a] = (u32)((ninv << 32) / p);
+    c->pr.mu61[a] = (u32)(((u64)1 << 61) / p);
     for (int cls = 0; cls < 2; ++cls) {
       u32* e = &rns[((size_t)cls * NP + a) * stride];
       const u64 b32 = ((u64)1 << 32) % p;
@@ -147,10 +202,10 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
       for (int k = 0; k < 2 * nlimbs; ++k) { e[k] = (u32)cur; cur = hm::mulmod(cur, b32, p); }
       e[2 * nlimbs] = (u32)((p - cur) % p);          // two's complement: value = unsigned - 2^(64 nl)
       e[2 * nlimbs + 1] = (u32)b32;
-      e[2 * nlimbs + 2] = x->pr.mu61[a];
+      e[2 * nlimbs + 2] = c->pr.mu61[a];
       e[2 * nlimbs + 3] = (u32)p;
-      e[2 * nlimbs + 4] = S ? ff[1].w : 0;           // head stage of a 2^15-point row: psi^brv(1)
-      e[2 * nlimbs + 5] = S ? ff[1].wp : 0;
+      e[2 * nlimbs + 4] = S ? x->head[a].w : 0;      // head stage of a 2^15-point row: psi^brv(1)
+      e[2 * nlimbs + 5] = S ? x->head[a].wp : 0;
     }
   }
   // CRT tables
@@ -162,13 +217,13 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
     Big Mi{1};
     for (int b = 0; b < NP; ++b) if (b != a) Mi = big_mul_small(Mi, primes[b]);
     const u64 p = primes[a];
-    const u64 c = hm::invmod(big_mod_small(Mi, p), p);
+    const u64 ci = hm::invmod(big_mod_small(Mi, p), p);
     auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
-    if (!S) cinv[(size_t)a * 2] = cinv[(size_t)a * 2 + 1] = tw(c);
+    if (!S) cinv[(size_t)a * 2] = cinv[(size_t)a * 2 + 1] = tw(ci);
     else {
       const u64 inv2 = (p + 1) / 2;
-      cinv[(size_t)a * 2] = tw(hm::mulmod(c, inv2, p));
-      cinv[(size_t)a * 2 + 1] = tw(hm::mulmod(c, hm::mulmod(tail_dif[a], inv2, p), p));
+      cinv[(size_t)a * 2] = tw(hm::mulmod(ci, inv2, p));
+      cinv[(size_t)a * 2 + 1] = tw(hm::mulmod(ci, hm::mulmod(x->tail[a].w, inv2, p), p));
     }
     inv57[a] = (u32)(((u64)1 << 57) / p);
     for (int l = 0; l < WT; ++l) Mw[(size_t)a * WT + l] = big_word(Mi, l, R);
@@ -184,19 +239,21 @@ static int t32_init(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ) {
   auto up = [&](void** d, const void* h, size_t bytes) -> bool {
     return hipMalloc(d, bytes) == hipSuccess && hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
-  if (!up((void**)&x->d_fwd, hf.data(), hf.size() * sizeof(Tw32)) || !up((void**)&x->d_inv, hi.data(), hi.size() * sizeof(Tw32)) ||
-      !up((void**)&x->d_rns, rns.data(), rns.size() * 4) || !up((void**)&x->d_cinv, cinv.data(), cinv.size() * sizeof(Tw32)) ||
-      !up((void**)&x->d_inv57, inv57.data(), inv57.size() * 4) || !up((void**)&x->d_Mw, Mw.data(), Mw.size() * 4)) {
-    t32_release(x);
+  if (!up((void**)&c->d_rns, rns.data(), rns.size() * 4) || !up((void**)&c->d_cinv, cinv.data(), cinv.size() * sizeof(Tw32)) ||
+      !up((void**)&c->d_inv57, inv57.data(), inv57.size() * 4) || !up((void**)&c->d_Mw, Mw.data(), Mw.size() * 4)) {
+    delete c;
     FHESI_FAIL("tensor32: table upload failed");
   }
-  ctx->tensor32 = x;
+  x->cfgs.push_back(c);
+  *out = c;
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------- big integer -> residues
-// a, b: [count][2][n][NL] two's complement coefficients; rows [count][4][NP][n] (a0, a1, b0, b1), values below 4p.
-// HEAD (n = 2^15): a thread takes coefficients j and j + 2^14 and stores  x + w y  and  x + 2p - w y  into sub-rows 0 and 1 of the row
+// PAIRED: a, b: [count][2][n_src][NL] two's complement coefficients; rows [count][4][NP][nrow] (a0, a1, b0, b1).
+// otherwise: na2 polynomials of a (class 0: lifted by p), then those of b; rows [polys][NP][nrow].  Values below 4p; positions from
+// n_src upwards (linear-convolution rings) are zero.
+// HEAD (rows of 2^15): a thread takes coefficients j and j + 2^14 and stores  x + w y  and  x + 2p - w y  into sub-rows 0 and 1 of the row
 // (the head stage of the 2^15-point transform, w = psi^brv(1)).
 template <int NL>
 __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const u32* __restrict__ t) {
@@ -216,21 +273,28 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
   const u32 q = __umulhi((u32)(acc >> 29), mu);        // at most 2 below floor(acc / p)
   return (u32)acc - q * p;                             // below 3p
 }
-template <int NL, bool HEAD>
-__global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict__ a, const u64* __restrict__ b, i64 n, u32* __restrict__ rows, int NP,
+template <int NL, bool HEAD, bool PAIRED>
+__global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict__ a, const u64* __restrict__ b, i64 na2, i64 n_src, i64 nrow, u32* __restrict__ rows, int NP,
                                                             const u32* __restrict__ tab) {
   __shared__ __attribute__((aligned(16))) u64 sl[NL * 256];       // [NL][256]
-  const i64 poly = blockIdx.y;                                   // ct * 4 + j
-  const i64 ct = poly >> 2;
-  const int jp = (int)(poly & 3), cls = jp >> 1;
+  const i64 poly = blockIdx.y;
+  int cls;
+  const u64* __restrict__ src;
+  if (PAIRED) { const i64 ct = poly >> 2; const int jp = (int)(poly & 3); cls = jp >> 1; src = (cls ? b : a) + (ct * 2 + (jp & 1)) * n_src * NL; }
+  else { cls = poly >= na2; src = cls ? b + (poly - na2) * n_src * NL : a + poly * n_src * NL; }
   const i64 j0 = (i64)blockIdx.x * 256;
   const int tid = threadIdx.x;
-  const u64* __restrict__ src = (cls ? b : a) + (ct * 2 + (jp & 1)) * n * NL + j0 * NL;
+  u32* __restrict__ o = rows + poly * NP * nrow + j0 + tid;
+  if (j0 >= n_src) {                                             // (whole block in the zero padding)
+    for (int i = 0; i < NP; ++i) o[(i64)i * nrow] = 0;
+    return;
+  }
+  const i64 avail = (n_src - j0) * NL;                           // words of this block's 256 coefficients that exist
   u32 x[2 * NL], x1[HEAD ? 2 * NL : 1];
 #pragma unroll
   for (int it = 0; it < NL; ++it) {
     const int e = it * 256 + tid;
-    sl[(e % NL) * 256 + e / NL] = src[e];
+    sl[(e % NL) * 256 + e / NL] = e < avail ? src[j0 * NL + e] : 0;
   }
   __syncthreads();
 #pragma unroll
@@ -240,7 +304,7 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int e = it * 256 + tid;
-      sl[(e % NL) * 256 + e / NL] = src[(i64)A32_N * NL + e];
+      sl[(e % NL) * 256 + e / NL] = src[(j0 + A32_N) * NL + e];
     }
     __syncthreads();
 #pragma unroll
@@ -250,21 +314,57 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   u32 neg1 = 0;
   if constexpr (HEAD) neg1 = x1[2 * NL - 1] >> 31;
   constexpr int STRIDE = 2 * NL + 6;
-  u32* __restrict__ o = rows + poly * NP * n + j0 + tid;
 #pragma unroll 2
   for (int i = 0; i < NP; ++i) {
     const u32* __restrict__ t = tab + ((i64)cls * NP + i) * STRIDE;
     const u32 r0 = rns32_one<NL>(x, neg, t);
-    if constexpr (!HEAD) o[(i64)i * n] = r0;
+    if constexpr (!HEAD) o[(i64)i * nrow] = r0;                  // (a zero coefficient gives 0: the padding inside a partial block)
     else {
       const u32 p = t[2 * NL + 3], twop = 2 * p;
       const u32 r1 = rns32_one<NL>(x1, neg1, t);
       const u32 X = r0 >= twop ? r0 - twop : r0;
       const u32 T = mul_lazy32(r1, Tw32{t[2 * NL + 4], t[2 * NL + 5]}, p);
-      o[(i64)i * n] = X + T;
-      o[(i64)i * n + A32_N] = X + twop - T;
+      o[(i64)i * nrow] = X + T;
+      o[(i64)i * nrow + A32_N] = X + twop - T;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------- sums of tensor products, evaluation form
+//   out[g][0..2][prime][:] = sum_{t in [seg[g], seg[g+1])} (a0 b0, a0 b1 + a1 b0, a1 b1)  mod p   with a = ra[slot_a[t]], b = rb[slot_b[t]]
+// ra [nua][2][NP][nrow], rb [nub][2][NP][nrow]: forward transforms (below p); out below 2p (what the inverse transform takes)
+__global__ void __launch_bounds__(256) tensor_sum32_kernel(const u32* __restrict__ ra, const u32* __restrict__ rb, const int* __restrict__ slot_a,
+                                                           const int* __restrict__ slot_b, const int* __restrict__ seg, int accumulate, u32* __restrict__ out,
+                                                           i64 nrow, int NP, T32Primes pr) {
+  const int g = blockIdx.z, l = blockIdx.y;
+  const u32 p = pr.p[l], mu = pr.mu61[l], twop = 2 * p;
+  const u32 r32 = (u32)((((u64)1) << 32) % p);
+  const i64 rs = (i64)NP * nrow;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  u32* o0 = out + (((i64)g * 3 + 0) * NP + l) * nrow + j;
+  const int t0 = seg[g], t1 = seg[g + 1];
+  // a 64-bit total takes 8 products below 2^60; reduced to below 2p every 4 terms (t1 adds two products per term)
+  auto red = [&](u64 v) -> u32 {
+    v = (u64)(u32)(v >> 32) * r32 + (u32)v;          // below 2^62 + 2^32
+    v = (u64)(u32)(v >> 32) * r32 + (u32)v;          // below 2^61
+    const u32 q = __umulhi((u32)(v >> 29), mu);
+    const u32 r = (u32)v - q * p;                     // below 3p
+    return r >= twop ? r - twop : r;
+  };
+  u64 r0 = 0, r1 = 0, r2 = 0;
+  if (accumulate) { r0 = o0[0]; r1 = o0[rs]; r2 = o0[2 * rs]; }
+  for (int t = t0; t < t1; ++t) {
+    const u32* a = ra + (((i64)slot_a[t] * 2) * NP + l) * nrow + j;
+    const u32* b = rb + (((i64)slot_b[t] * 2) * NP + l) * nrow + j;
+    const u32 a0 = a[0], a1 = a[rs], b0 = b[0], b1 = b[rs];
+    r0 += (u64)a0 * b0;
+    r1 += (u64)a0 * b1 + (u64)a1 * b0;
+    r2 += (u64)a1 * b1;
+    if (((t - t0) & 3) == 3) { r0 = red(r0); r1 = red(r1); r2 = red(r2); }
+  }
+  o0[0] = red(r0);
+  o0[rs] = red(r1);
+  o0[2 * rs] = red(r2);
 }
 
 // ---------------------------------------------------------------------------------------------- residues -> round(x / 2^logQ) mod 2^logQ
@@ -340,71 +440,230 @@ __global__ void __launch_bounds__(128) crt32_scale_kernel(const u32* __restrict_
   }
 }
 
-// ---------------------------------------------------------------------------------------------- the tensor half
+// The same conversion for any logQ <= 512 (words of 28 bits, rows of 2^14) and for the linear-convolution rings: the window [J0, J0 + NW)
+// of words and the bit positions are run-time values, so after the (compile-time indexed) accumulation and the carry pass the words go
+// through LDS, one column per thread, and the 64-bit limbs are cut from there.  fold_q = q' (m = 2q'): the residue of output coefficient j is
+//   r_j - r_(j+q') - (-1)^j r_(q'-1)   of the linear product's residues (modulo X^q' + 1, then modulo Phi_m = sum (-X)^i).
+// NWMAX = T32_GEN_NW with J0 from the host, or T32_GEN_NWX with J0 = 0 for the exact pass over flagged workgroups.
+template <int NWMAX, bool EXACT>
+__global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __restrict__ rows, i64 nrow, i64 n_out, i64 fold_q, int NP, int LQ, int J0, int NW, int WT,
+                                                                   T32Primes pr, const Tw32* __restrict__ cinv, const u32* __restrict__ inv57, const u32* __restrict__ Mw,
+                                                                   u64* __restrict__ out, unsigned char* __restrict__ flags) {
+  constexpr int R = 28;
+  __shared__ u32 xs[NWMAX * 128];
+  const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (EXACT && !flags[wg]) return;
+  const i64 poly = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < n_out;
+  const u32* __restrict__ src = rows + poly * NP * nrow;
+  u64 acc[NWMAX];
+#pragma unroll
+  for (int l = 0; l < NWMAX; ++l) acc[l] = 0;
+  u32 fsum = 0;
+  if (active) {
+    for (int i = 0; i < NP; ++i) {
+      const u32 p = pr.p[i];
+      const u32* __restrict__ ri = src + (i64)i * nrow;
+      u32 r = ri[j];
+      if (fold_q) {
+        const u32 b = j + fold_q < nrow ? ri[j + fold_q] : 0u, c = ri[fold_q - 1];
+        r = r + (p - b) + ((j & 1) ? c : p - c);       // below 4p
+      }
+      u32 y = mul_lazy32(r, cinv[2 * i], p);
+      y = y >= p ? y - p : y;
+      fsum += __umulhi(y, inv57[i]);
+      const u32* __restrict__ Mi = Mw + (i64)i * WT + J0;
+#pragma unroll
+      for (int l = 0; l < NWMAX; ++l)
+        if (l < NW) acc[l] += (u64)y * Mi[l];
+    }
+    const u32 kappa = (fsum + (1u << 24)) >> 25;
+    const u32* __restrict__ Nm = Mw + (i64)NP * WT + J0;
+    u64 carry = 0;
+#pragma unroll
+    for (int l = 0; l < NWMAX; ++l)
+      if (l < NW) {
+        const u64 v = acc[l] + (u64)kappa * Nm[l] + carry;
+        xs[l * 128 + threadIdx.x] = (u32)(v & 0xfffffffull);
+        carry = v >> R;
+      }
+  }
+  int undecided = 0;
+  if (active) {
+    // 64 bits from bit B of x (each thread reads back its own column)
+    auto word = [&](int l) -> u64 { return (l >= 0 && l < NW) ? (u64)xs[l * 128 + threadIdx.x] : 0ull; };
+    auto limb = [&](int B) -> u64 {
+      const int l0 = B / R - J0, o = B % R;
+      u64 v = word(l0) >> o;
+      v |= word(l0 + 1) << (R - o);
+      v |= word(l0 + 2) << (2 * R - o);
+      if (3 * R - o < 64) v |= word(l0 + 3) << (3 * R - o);
+      return v;
+    };
+    const u64 G = limb(LQ - 64);                         // bits logQ-64 .. logQ-1
+    if (!EXACT) undecided = (G == 0x7fffffffffffffffull) ? 1 : 0;
+    u64 c = G >> 63;                                     // round half up: + bit logQ-1
+    const int nlq = (LQ + 63) >> 6;
+    u64* __restrict__ o = out + poly * nlq * n_out + j;
+    for (int i = 0; i < nlq; ++i) {
+      u64 v = limb(LQ + 64 * i);
+      v += c;
+      c = (c && v == 0) ? 1 : 0;
+      const int bits_left = LQ - 64 * i;
+      if (bits_left < 64) v &= ((u64)1 << bits_left) - 1;
+      o[(i64)i * n_out] = v;
+    }
+  }
+  if (!EXACT) {
+    const int any = __syncthreads_or(undecided);
+    if (threadIdx.x == 0) flags[wg] = any ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+static i64 t32_nrow(const fhesi_ctx* ctx) { return (i64)A32_N << ctx->tensor32->S; }
 template <int NL>
-static int t32_launch_rns(fhesi_ctx* ctx, const fhesi_tensor32* x, const u64* d_a, const u64* d_b, i64 count, u32* d_r) {
-  const i64 n = (i64)A32_N << x->S;
-  const dim3 grid((unsigned)(A32_N / 256), (unsigned)(count * 4));
-  if (x->S) { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, true>); rns32_reduce_kernel<NL, true><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, n, d_r, x->NP, x->d_rns); }
-  else { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, false>); rns32_reduce_kernel<NL, false><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, n, d_r, x->NP, x->d_rns); }
+static int t32_launch_rns(fhesi_ctx* ctx, const T32Config* c, const u64* d_a, const u64* d_b, i64 npolys, i64 na2, bool paired, u32* d_r) {
+  const int S = ctx->tensor32->S;
+  const i64 nrow = t32_nrow(ctx), n_src = ctx->phim;
+  const dim3 grid((unsigned)(A32_N / 256), (unsigned)npolys);
+#define T32_GO(HEAD, PAIRED) do { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, HEAD, PAIRED>); \
+    rns32_reduce_kernel<NL, HEAD, PAIRED><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, na2, n_src, nrow, d_r, c->NP, c->d_rns); } while (0)
+  if (S) { if (paired) T32_GO(true, true); else T32_GO(true, false); }
+  else { if (paired) T32_GO(false, true); else T32_GO(false, false); }
+#undef T32_GO
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static int t32_rns(fhesi_ctx* ctx, const T32Config* c, const u64* d_a, const u64* d_b, i64 npolys, i64 na2, bool paired, u32* d_r) {
+  ProfScope prof(ctx, PROF_RNS, (double)npolys);
+#define T32_RNS(NL) case NL: return t32_launch_rns<NL>(ctx, c, d_a, d_b, npolys, na2, paired, d_r);
+  switch (c->nl) {
+    T32_RNS(1) T32_RNS(2) T32_RNS(3) T32_RNS(4) T32_RNS(5) T32_RNS(6) T32_RNS(7) T32_RNS(8) T32_RNS(9) T32_RNS(10) T32_RNS(11) T32_RNS(12)
+    T32_RNS(13) T32_RNS(14) T32_RNS(15) T32_RNS(16)
+    default: break;
+  }
+#undef T32_RNS
+  FHESI_FAIL("tensor32: %d limbs", c->nl);
+}
+static int t32_fwd(fhesi_ctx* ctx, const T32Config* c, u32* d_r, i64 npolys) {
+  const fhesi_tensor32* x = ctx->tensor32;
+  ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * c->NP));
+  const unsigned grid = (unsigned)((npolys * c->NP) << x->S);
+  if (x->S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
+  else { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 0, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
   HIP_TRY(hipGetLastError());
   return 0;
 }
 template <int LQ, int R, int WT, int S>
-static int t32_launch_crt(fhesi_ctx* ctx, const fhesi_tensor32* x, const u32* d_t, i64 count, u64* d_parts) {
+static int t32_launch_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npolys, u64* d_parts) {
   const i64 n = (i64)A32_N << S;
-  const dim3 grid((unsigned)(n / 128), (unsigned)(count * 3));
+  const dim3 grid((unsigned)(n / 128), (unsigned)npolys);
   void* d_fl;
   FHESI_TRY(ws_reserve(ctx, 6, (size_t)grid.x * grid.y, &d_fl));          // (per lane, like every workspace slot)
   unsigned char* fl = (unsigned char*)d_fl;
   PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_kernel<LQ, false, R, WT, S>));
-  crt32_scale_kernel<LQ, false, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, x->NP, x->pr, x->d_cinv, x->d_inv57, x->d_Mw, d_parts, fl);
+  crt32_scale_kernel<LQ, false, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, c->NP, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
   HIP_TRY(hipGetLastError());
   if (!ctx->opt.crt_skip_cleanup) {
-    crt32_scale_kernel<LQ, true, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, x->NP, x->pr, x->d_cinv, x->d_inv57, x->d_Mw, d_parts, fl);
+    crt32_scale_kernel<LQ, true, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, c->NP, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
     HIP_TRY(hipGetLastError());
   }
   return 0;
 }
-// a, b: [count][2][n][nlimbs] coefficients -> d_parts [count * 3][logQ/64][n]: the scaled-down tProd as ByteDecomp takes it
-int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts) {
-  FHESI_TRY(t32_init(ctx, p, nlimbs, logQ));
-  if (!count) return 0;
-  fhesi_tensor32* x = ctx->tensor32;
-  const int NP = x->NP, S = x->S;
-  const i64 n = (i64)A32_N << S;
-  void *d_r, *d_t;
-  FHESI_TRY(ws_reserve(ctx, 5, (size_t)count * 4 * NP * n * 4, &d_r));
-  FHESI_TRY(ws_reserve(ctx, 1, (size_t)count * 3 * NP * n * 4, &d_t));
-  {
-    ProfScope prof(ctx, PROF_RNS, (double)(count * 4));
-#define T32_RNS(NL) case NL: FHESI_TRY(t32_launch_rns<NL>(ctx, x, d_a, d_b, count, (u32*)d_r)); break;
-    switch (nlimbs) {
-      T32_RNS(1) T32_RNS(2) T32_RNS(3) T32_RNS(4) T32_RNS(5) T32_RNS(6) T32_RNS(7) T32_RNS(8) T32_RNS(9) T32_RNS(10) T32_RNS(11) T32_RNS(12)
-      T32_RNS(13) T32_RNS(14) T32_RNS(15) T32_RNS(16)
-      default: FHESI_FAIL("tensor32: %d limbs", nlimbs);
-    }
-#undef T32_RNS
+// d_t [npolys][NP][nrow] coefficient-form residues -> d_parts [npolys][ceil(logQ/64)][phi(m)]
+static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npolys, u64* d_parts) {
+  const int S = ctx->tensor32->S, logQ = c->logQ;
+  ProfScope prof(ctx, PROF_CRT, (double)npolys);
+  if (!c->generic) {
+    if (logQ == 512 && !S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 0>(ctx, c, d_t, npolys, d_parts);
+    if (logQ == 512 && S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 1>(ctx, c, d_t, npolys, d_parts);
+    if (logQ == 1024 && !S) return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 0>(ctx, c, d_t, npolys, d_parts);
+    return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 1>(ctx, c, d_t, npolys, d_parts);
   }
-  {
-    ProfScope prof(ctx, PROF_NTT_FWD, (double)(count * 4 * NP));
-    const unsigned grid = (unsigned)((count * 4 * NP) << S);
-    if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_r, count * 4, NP, 0, x->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
-    else { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 0, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_r, count * 4, NP, 0, x->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
+  // the generic form: window from R J0 + 30 + log2(NP + 1) + 1 <= logQ - 64 up to bit 2 logQ
+  const i64 n_out = ctx->phim, nrow = t32_nrow(ctx);
+  const int WU = (2 * logQ + 27) / 28;
+  int J0 = (logQ - 64 - 38) / 28;
+  if (logQ < 64 + 38) J0 = 0;
+  const int NW = WU - J0;
+  if (NW > T32_GEN_NW || WU > T32_GEN_NWX || WU > c->WT) FHESI_FAIL("tensor32: logQ=%d outside the generic CRT window", logQ);
+  const dim3 grid((unsigned)((n_out + 127) / 128), (unsigned)npolys);
+  void* d_fl;
+  FHESI_TRY(ws_reserve(ctx, 6, (size_t)grid.x * grid.y, &d_fl));
+  unsigned char* fl = (unsigned char*)d_fl;
+  PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_generic_kernel<T32_GEN_NW, false>));
+  crt32_scale_generic_kernel<T32_GEN_NW, false><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, ctx->lin_q, c->NP, logQ, J0, NW, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
+  HIP_TRY(hipGetLastError());
+  if (!ctx->opt.crt_skip_cleanup) {
+    crt32_scale_generic_kernel<T32_GEN_NWX, true><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, ctx->lin_q, c->NP, logQ, 0, WU, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
     HIP_TRY(hipGetLastError());
   }
+  return 0;
+}
+
+// ---- pairs (fhesi_ct_mul_relin_batch_dev): a, b [count][2][phi(m)][nlimbs] -> d_parts [count * 3][ceil(logQ/64)][phi(m)]: the scaled-down tProd as ByteDecomp takes it
+int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts) {
+  T32Config* c;
+  FHESI_TRY(t32_config(ctx, p, nlimbs, logQ, 1, &c));
+  if (!count) return 0;
+  const fhesi_tensor32* x = ctx->tensor32;
+  const int NP = c->NP, S = x->S;
+  const i64 nrow = t32_nrow(ctx);
+  void *d_r, *d_t;
+  FHESI_TRY(ws_reserve(ctx, 5, (size_t)count * 4 * NP * nrow * 4, &d_r));
+  FHESI_TRY(ws_reserve(ctx, 1, (size_t)count * 3 * NP * nrow * 4, &d_t));
+  FHESI_TRY(t32_rns(ctx, c, d_a, d_b, count * 4, 0, true, (u32*)d_r));
+  FHESI_TRY(t32_fwd(ctx, c, (u32*)d_r, count * 4));
   {
     ProfScope prof(ctx, PROF_NTT_INV, (double)(count * 3 * NP));
     PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, true, T32Primes>));
     const unsigned grid = (unsigned)((((count + 7) / 8) * 24 * NP) << S);
-    ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, x->pr, x->d_inv, S, (const u32*)d_r);
+    ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, c->pr, x->d_inv, S, (const u32*)d_r);
     HIP_TRY(hipGetLastError());
   }
-  {
-    ProfScope prof(ctx, PROF_CRT, (double)(count * 3));
-    if (logQ == 512 && !S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 0>(ctx, x, (const u32*)d_t, count, d_parts);
-    if (logQ == 512 && S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 1>(ctx, x, (const u32*)d_t, count, d_parts);
-    if (logQ == 1024 && !S) return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 0>(ctx, x, (const u32*)d_t, count, d_parts);
-    return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 1>(ctx, x, (const u32*)d_t, count, d_parts);
+  return t32_crt(ctx, c, (const u32*)d_t, count * 3, d_parts);
+}
+
+// ---- sums of products per group (fhesi_ct_mul_sum_relin_dev)
+int tensor32_sum_begin(fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax) {
+  T32Config* c;
+  FHESI_TRY(t32_config(ctx, p, nlimbs, logQ, gmax, &c));
+  ctx->tensor32->cur = c;
+  return 0;
+}
+size_t tensor32_sum_bytes(const fhesi_ctx* ctx, i64 ngroups) { return (size_t)ngroups * 3 * ctx->tensor32->cur->NP * t32_nrow(ctx) * 4; }
+// d_ops: [nua + nub][2][phi(m)][nlimbs] (the a operands first); slots / segments on the device; d_sum [ng][3][NP][nrow]
+int tensor32_sum_pass(fhesi_ctx* ctx, const u64* d_ops, i64 nua, i64 nub, const int* d_slot_a, const int* d_slot_b, const int* d_seg, i64 ng, i64 nterms, bool accumulate, void* d_sum) {
+  const T32Config* c = ctx->tensor32->cur;
+  const i64 nrow = t32_nrow(ctx), n = ctx->phim;
+  if (ctx->tensor32->S) FHESI_FAIL("tensor32: sums on rows of 2^15 are not built");
+  void* d_r;
+  FHESI_TRY(ws_reserve(ctx, 0, (size_t)(nua + nub) * 2 * c->NP * nrow * 4, &d_r));
+  const u64* d_b = d_ops + (size_t)nua * 2 * n * c->nl;
+  FHESI_TRY(t32_rns(ctx, c, d_ops, d_b, (nua + nub) * 2, nua * 2, false, (u32*)d_r));
+  FHESI_TRY(t32_fwd(ctx, c, (u32*)d_r, (nua + nub) * 2));
+  const u32* ra = (const u32*)d_r;
+  const u32* rb = ra + (size_t)nua * 2 * c->NP * nrow;
+  ProfScope prof(ctx, PROF_TENSOR, (double)nterms);
+  PROF_KERNEL(ctx, PROF_TENSOR, tensor_sum32_kernel);
+  for (i64 done = 0; done < ng; done += 65535) {
+    const i64 cnt = ng - done < 65535 ? ng - done : 65535;
+    dim3 grid((unsigned)(nrow / 256), (unsigned)c->NP, (unsigned)cnt);
+    tensor_sum32_kernel<<<grid, 256, 0, ctx->stream>>>(ra, rb, d_slot_a, d_slot_b, d_seg + done, accumulate ? 1 : 0, (u32*)d_sum + (size_t)done * 3 * c->NP * nrow, nrow, c->NP, c->pr);
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts) {
+  const T32Config* c = ctx->tensor32->cur;
+  const fhesi_tensor32* x = ctx->tensor32;
+  {
+    ProfScope prof(ctx, PROF_NTT_INV, (double)(ng * 3 * c->NP));
+    PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, false, T32Primes>));
+    ntt32_inv_kernel3<false, false, T32Primes><<<(unsigned)(ng * 3 * c->NP), A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, 0, nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  return t32_crt(ctx, c, (const u32*)d_sum, ng * 3, d_parts);
 }
