@@ -151,7 +151,9 @@ def test_sum_form_crt_undecided_coefficients(monkeypatch):
     ctx.set_option("crt_skip_cleanup", 0)
 
 
-@pytest.mark.parametrize("m,logQ,p", [(32768, 512, 23), (1 << 16, 1024, 65537)])
+@pytest.mark.parametrize("m,logQ,p", [(32768, 512, 23), (1 << 16, 1024, 65537),
+                                      (32768, 200, 23),          # run-time CRT window (any logQ <= 512)
+                                      (8422, 341, 8423)])        # the reference's Test_Regression ring: linear convolutions + fold
 def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     """At the metric ring the fused pipeline forms tProd's integers modulo 35 primes below 2^30 instead of the chain
     (kernels_tensor32.hip; Ciphertext.cpp:167-218 only ever exposes round(x / 2^logQ) mod 2^logQ of them; 70 primes and rows of 2^15 at
@@ -161,6 +163,8 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     result is wrong when that pass is switched off)."""
     count = 4
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 4242, count)
+    if (m & (m - 1)) != 0:
+        orc.set_bluestein_fft(True)             # the oracle's O(N log N) form of the same transforms (bluestein.cpp:116-139)
     n = ctx.phim
     mod = 1 << logQ
     lo, hi = -(mod >> 1), (mod >> 1) - 1
@@ -180,6 +184,7 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
 
     deltas = [0, 1, -1, 2, -2, 3, -3, 5, -5, 7, -7, 8, -8, 100, -100, 1 << 64, -(1 << 64), 1 << (logQ - 112), -(1 << (logQ - 112)),
               (1 << (logQ - 64)) - 1, -(1 << (logQ - 64))]
+    deltas = [d for d in deltas if abs(d) < (1 << (logQ - 2))]
     A = [centred((d - (mod >> 1)) * inv_p) for d in deltas]
     a[2, 0] = O.ints_to_limbs(A + [0] * (n - len(A)), nl)
     a[2, 1] = O.ints_to_limbs([0] * (n - len(A)) + A, nl)
@@ -190,7 +195,7 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     ctx.prof_enable(True)
     got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     # the kernels that ran are the 32-bit ones
-    assert "crt32_scale_kernel" in ctx.prof_kernel_name("crt") and "rns32_reduce_kernel" in ctx.prof_kernel_name("rns_reduce")
+    assert "crt32_scale" in ctx.prof_kernel_name("crt") and "rns32_reduce_kernel" in ctx.prof_kernel_name("rns_reduce")
     ctx.prof_enable(False)
     ctx.set_option("tensor32", 0)
     chain = ctx.ct_mul_relin(ksk, logQ, p, a, b)
