@@ -120,7 +120,10 @@ static T32Plan t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 g
   return pl;
 }
 bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ) { return t32_plan(ctx, p, nlimbs, logQ, 1, nullptr).NP > 0; }
-bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax) { return t32_plan(ctx, p, nlimbs, logQ, gmax, nullptr).NP > 0; }
+bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax) {
+  if (ctx->pow2 && ctx->logn != A32_LOGN) return false;        // (the sums are built for rows of 2^14)
+  return t32_plan(ctx, p, nlimbs, logQ, gmax, nullptr).NP > 0;
+}
 
 // transform tables of the first `want` primes (grown on demand; a growth waits for the streams)
 static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
@@ -186,7 +189,7 @@ static int t32_config(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ, i64 gmax, 
   c->lift = lift; c->nl = nlimbs; c->logQ = logQ; c->NP = NP; c->generic = pl.generic;
   c->R = pl.generic ? 28 : (logQ == 512 ? T32_R_512 : T32_R_1024);
   c->WT = pl.generic ? (int)((have + 8) / 28) + 2 : (logQ == 512 ? T32_WT_512 : T32_WT_1024);
-  const int R = c->R, WT = c->WT, stride = 2 * nlimbs + 6;
+  const int R = c->R, WT = c->WT, stride = (2 * nlimbs + 6 + 7) & ~7;          // (rows of whole 32-byte lines: the kernel reads them with scalar loads)
   std::vector<u32> rns((size_t)2 * NP * stride);
   for (int a = 0; a < NP; ++a) {
     const u64 p = primes[a];
@@ -291,10 +294,19 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   }
   const i64 avail = (n_src - j0) * NL;                           // words of this block's 256 coefficients that exist
   u32 x[2 * NL], x1[HEAD ? 2 * NL : 1];
+  const u64* __restrict__ sblk = src + j0 * NL;
+  if (avail >= 256 * NL) {                                       // (uniform: every block but the last one of a padded row)
 #pragma unroll
-  for (int it = 0; it < NL; ++it) {
-    const int e = it * 256 + tid;
-    sl[(e % NL) * 256 + e / NL] = e < avail ? src[j0 * NL + e] : 0;
+    for (int it = 0; it < NL; ++it) {
+      const int e = it * 256 + tid;
+      sl[(e % NL) * 256 + e / NL] = sblk[e];
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int e = it * 256 + tid;
+      sl[(e % NL) * 256 + e / NL] = e < avail ? sblk[e] : 0;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -313,7 +325,7 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   const u32 neg = x[2 * NL - 1] >> 31;
   u32 neg1 = 0;
   if constexpr (HEAD) neg1 = x1[2 * NL - 1] >> 31;
-  constexpr int STRIDE = 2 * NL + 6;
+  constexpr int STRIDE = (2 * NL + 6 + 7) & ~7;
 #pragma unroll 2
   for (int i = 0; i < NP; ++i) {
     const u32* __restrict__ t = tab + ((i64)cls * NP + i) * STRIDE;
