@@ -89,10 +89,8 @@ static const OptDesc kOptions[] = {
   {"batch_chunk", "FHESI_BATCH_CHUNK", offsetof(CtxOptions, batch_chunk), true},
   {"wave_operands", "FHESI_WAVE_OPERANDS", offsetof(CtxOptions, wave_operands), true},
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
-  {"dot32_v2", "FHESI_DOT32_V2", offsetof(CtxOptions, dot32_v2), false},
   {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
   {"automorph_rows", "FHESI_AUTOMORPH_ROWS", offsetof(CtxOptions, automorph_rows), false},
-  {"ntt32_v3", "FHESI_NTT32_V3", offsetof(CtxOptions, ntt32_v3), false},
 };
 static void opt_store(CtxOptions* o, const OptDesc& d, long long v) {
   if (d.wide) *(long long*)((char*)o + d.off) = v; else *(int*)((char*)o + d.off) = (int)v;
@@ -1192,7 +1190,7 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
       FHESI_TRY(launch_ntt32_fwd_digits(c, d_parts, nlq, 8 * decomp_bytes, nd, count * ncomp, (u32*)d_dig));
       if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
       FHESI_TRY(launch_dot32(c, k, (const u32*)d_dig, ncol, count, (u32*)d_o));
-      FHESI_TRY(launch_ntt32_inv(c, (u32*)d_o, count * 2 * R, 4, 0, c->opt.dot32_v2 != 0));
+      FHESI_TRY(launch_ntt32_inv(c, (u32*)d_o, count * 2 * R, 4, 0, true));
       return launch_ks_recombine(c, t, k, (const u64*)d_o, count * 2, (u64*)out, nlimbs);
     }
     FHESI_TRY(launch_ntt_fwd_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig, 0, 2, 2));

@@ -1,4 +1,4 @@
-// kernels_aux32.hip -- the key-switch dot product through FOUR 30-bit auxiliary primes (n = 2^14).
+// kernels_aux32.hip -- the key-switch dot product through FOUR 30-bit auxiliary primes (n = 2^14, 2^15, and the linear-convolution rings).
 //
 // kernels_ksaux.hip computes the key switch's integer dot product S_l = sum_k digit_k (*) K_{k,l} modulo two 60-bit chain primes.
 // The same integers (|S_l| < 2^119) are determined just as well by their residues modulo four primes below 2^30, and there a
@@ -8,233 +8,15 @@
 // written for this one size.  Evaluation order is whatever the forward transform produces (no bit reversal anywhere): the dot
 // product is element-wise and the inverse transform is the exact mirror.
 //
-//   p_a = the four largest primes below 2^30 with p = 1 mod 2^15  (aux32_init; roots and tables per context, on first use)
-//   ntt32_fwd_kernel<DIGITS>   32 values per thread, 512 threads per row: 5 stages in registers, LDS exchange, 5 stages, exchange, 4 stages
-//   ntt32_inv_kernel           the mirror (Gentleman-Sande), 1/n folded into a final multiplication
-//   dot32_kernel               O[ct][r][l][a] = sum_k D[ct][k][a] * K[a][l][r][k]  mod p_a
+//   p_a = the four largest primes below 2^30 with p = 1 mod 2n  (aux32_init; roots and tables per context, on first use)
+//   ntt32_fwd_kernel3<DIGITS>  (ntt32_core.inc) 32 values per thread, 512 threads per row of 2^14: 5 stages in registers, LDS exchange, 5
+//                              stages, exchange, 4 stages; rows of 2^15 = head stage + two sub-transforms
+//   ntt32_inv_kernel3          the mirror (Gentleman-Sande), 1/n folded into a final multiplication
+//   dot32_kernel2              O[ct][r][l][a] = sum_k D[ct][k][a] * K[a][l][r][k]  mod p_a
 // The recombination (Garner over the four residues, then exactly as ks_recombine_kernel) is in kernels_crt.hip.
 #include "fhesi_internal.h"
 
 #include "ntt32_core.inc"
-
-// rows: [count][nslots][n] u32; block rb -> (unit c = rb % count, slot = rb / count), prime a0 + slot.
-// DIGITS: unit c = poly * nd + digit, the values are cut out of the parts (ByteDecomp, Ciphertext.cpp:82-105); output lazy (below 4p).
-// otherwise: in place on the row, output reduced (below p).
-template <bool DIGITS>
-__global__ void __launch_bounds__(A32_T, 2) ntt32_fwd_kernel(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs,
-                                                             Dig32Src ds) {
-  __shared__ u32 lds[32 * A32_P];
-  const u32 tid = threadIdx.x;
-  i64 c = blockIdx.x % count;
-  int slot = (int)(blockIdx.x / count);
-  if (DIGITS) {
-    // the four transforms of a digit polynomial read the same source words: keep them on one XCD (block ids 8 apart) and close in
-    // time, so that the source leaves HBM once instead of once per prime (the four twiddle tables, 512 KiB, fit every L2)
-    const u32 bid = blockIdx.x;
-    slot = (int)((bid >> 3) & 3);
-    c = (i64)(bid >> 5) * 8 + (bid & 7);
-    if (c >= count) return;
-  }
-  const int a = a0 + slot;
-  const u32 p = pr.p[a];
-  const Tw32* __restrict__ tab = tabs + (i64)a * A32_N;
-  u32* __restrict__ g = rows + (c * nslots + slot) * A32_N;
-  u32 r[32];
-  if (DIGITS) {
-    const u32 d = (u32)(c % ds.nd);
-    const i64 poly = c / ds.nd;
-    const u32 bit = d * (u32)ds.digit_bits, g0 = bit >> 5, sh = bit & 31;
-    const u32 mask = (1u << ds.digit_bits) - 1;
-    const u32* __restrict__ p32 = reinterpret_cast<const u32*>(ds.parts);
-    const u32* __restrict__ w0 = p32 + (((poly * ds.nl + (g0 >> 1)) * (i64)ds.n_src) << 1) + (g0 & 1);
-    const bool two = (sh + ds.digit_bits > 32) && (int)((g0 + 1) >> 1) < ds.nl;
-    const u32 ns = ds.n_src;
-    if (two) {
-      const u32 g1 = g0 + 1;
-      const u32* __restrict__ w1 = p32 + (((poly * ds.nl + (g1 >> 1)) * (i64)ds.n_src) << 1) + (g1 & 1);
-#pragma unroll
-      for (int k = 0; k < 32; ++k) { const u32 el = k * A32_T + tid, e = 2 * el; r[k] = el < ns ? ((w0[e] >> sh) | (w1[e] << (32 - sh))) & mask : 0u; }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 32; ++k) { const u32 el = k * A32_T + tid; r[k] = el < ns ? (w0[2 * el] >> sh) & mask : 0u; }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 32; ++k) r[k] = g[k * A32_T + tid];
-  }
-  // phase A: element e = k * 512 + tid; distances 16, 8, 4, 2, 1 in k; twiddles depend on the register index only
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int h = 16 >> s;
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int k = a32_bfly_k(b, h);
-      a32_ct(r[k], r[k + h], tab[(1 << s) + (k >> (5 - s))], p);
-    }
-  }
-  const u32 kq = tid >> 4, lo = tid & 15;          // sub-problem and position inside a group of 16 (after the first exchange)
-  // The twiddles of phases B and C differ per lane (2^u of them per thread in stage u).  They are fetched ahead of the exchanges and of
-  // the stages before them, so that no stage waits for an L2 round trip.
-  Tw32 tb[31];                                     // stage u at [2^u - 1, 2^(u+1) - 1)
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int i = 0; i < (1 << u); ++i) tb[(1 << u) - 1 + i] = tab[(32 << u) + (kq << u) + i];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) lds[k * A32_P + a32_f(tid)] = r[k];
-  __syncthreads();
-#pragma unroll
-  for (int k2 = 0; k2 < 32; ++k2) r[k2] = lds[kq * A32_P + a32_f(k2 * 16 + lo)];
-  // phase B: sub-problem kq (512 elements t = k2 * 16 + lo); distances 16 .. 1 in k2
-#pragma unroll
-  for (int u = 0; u < 5; ++u) {
-    const int h = 16 >> u;
-    if (u == 1) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) tb[15 + i] = tab[(32 << 4) + (kq << 4) + i];
-    }
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int k2 = a32_bfly_k(b, h);
-      a32_ct(r[k2], r[k2 + h], tb[(1 << u) - 1 + (k2 >> (5 - u))], p);
-    }
-  }
-  Tw32 tc[2][15];                                  // per group: stage v at [2^v - 1, 2^(v+1) - 1)
-#pragma unroll
-  for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-#pragma unroll
-      for (int i = 0; i < (1 << v); ++i) tc[gq][(1 << v) - 1 + i] = tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i];
-  __syncthreads();
-#pragma unroll
-  for (int k2 = 0; k2 < 32; ++k2) lds[kq * A32_P + a32_f(k2 * 16 + lo)] = r[k2];
-  __syncthreads();
-  // phase C: this thread takes the groups k2 = 2 lo, 2 lo + 1 (32 consecutive elements); distances 8 .. 1 inside a group
-#pragma unroll
-  for (int i = 0; i < 32; ++i) r[i] = lds[kq * A32_P + lo * 36 + i];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int h = 8 >> v;
-    if (v == 1) {
-#pragma unroll
-      for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tc[gq][7 + i] = tab[(1024 << 3) + ((kq * 32 + 2 * lo + gq) << 3) + i];
-    }
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int x = a32_bfly_k(b, h);
-        a32_ct(r[gq * 16 + x], r[gq * 16 + x + h], tc[gq][(1 << v) - 1 + (x >> (4 - v))], p);
-      }
-    }
-  }
-  // digit rows are stored tiled, [prime][64-element slice][unit][64], so that the dot product's tile (one slice of one prime, a run of
-  // units) is one contiguous block; plain rows in place
-  u32* __restrict__ o = DIGITS ? rows + ((((i64)a << (A32_LOGN - 6)) + (kq * 8 + (lo >> 1))) * count + c) * 64 + (lo & 1) * 32 : g + kq * 512 + lo * 32;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    u32 v = r[i];
-    if (!DIGITS) { const u32 twop = 2 * p; v = v >= twop ? v - twop : v; v = v >= p ? v - p : v; }
-    o[i] = v;
-  }
-}
-
-
-// the mirror: input in the forward transform's output order (values below 2p), output natural order, scaled by 1/n, reduced
-// MONT: the input carries a factor 2^-32 (dot32_kernel2's Montgomery step); the final constant is n^-1 2^32 instead of n^-1
-template <bool MONT>
-__global__ void __launch_bounds__(A32_T, 2) ntt32_inv_kernel(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, const Tw32* __restrict__ tabs) {
-  __shared__ u32 lds[32 * A32_P];
-  const u32 tid = threadIdx.x;
-  const i64 c = blockIdx.x % count;
-  const int slot = (int)(blockIdx.x / count), a = a0 + slot;
-  const u32 p = pr.p[a];
-  const Tw32* __restrict__ tab = tabs + (i64)a * A32_N;
-  u32* __restrict__ g = rows + (c * nslots + slot) * A32_N;
-  const u32 kq = tid >> 4, lo = tid & 15;
-  u32 r[32];
-  const u32* __restrict__ in = g + kq * 512 + lo * 32;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) r[i] = in[i];
-  Tw32 tc[2][15];                                  // the per-lane twiddles are fetched ahead (see the forward kernel)
-#pragma unroll
-  for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-    for (int v = 2; v < 4; ++v)
-#pragma unroll
-      for (int i = 0; i < (1 << v); ++i) tc[gq][(1 << v) - 1 + i] = tab[(1024 << v) + ((kq * 32 + 2 * lo + gq) << v) + i];
-#pragma unroll
-  for (int v = 3; v >= 0; --v) {
-    const int h = 8 >> v;
-    if (v == 2) {
-#pragma unroll
-      for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-        for (int vv = 0; vv < 2; ++vv)
-#pragma unroll
-          for (int i = 0; i < (1 << vv); ++i) tc[gq][(1 << vv) - 1 + i] = tab[(1024 << vv) + ((kq * 32 + 2 * lo + gq) << vv) + i];
-    }
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int x = a32_bfly_k(b, h);
-        a32_gs(r[gq * 16 + x], r[gq * 16 + x + h], tc[gq][(1 << v) - 1 + (x >> (4 - v))], p);
-      }
-    }
-  }
-  Tw32 tb[31];
-#pragma unroll
-  for (int u = 3; u < 5; ++u)
-#pragma unroll
-    for (int i = 0; i < (1 << u); ++i) tb[(1 << u) - 1 + i] = tab[(32 << u) + (kq << u) + i];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) lds[kq * A32_P + lo * 36 + i] = r[i];
-  __syncthreads();
-#pragma unroll
-  for (int k2 = 0; k2 < 32; ++k2) r[k2] = lds[kq * A32_P + a32_f(k2 * 16 + lo)];
-#pragma unroll
-  for (int u = 4; u >= 0; --u) {
-    const int h = 16 >> u;
-    if (u == 3) {
-#pragma unroll
-      for (int uu = 0; uu < 3; ++uu)
-#pragma unroll
-        for (int i = 0; i < (1 << uu); ++i) tb[(1 << uu) - 1 + i] = tab[(32 << uu) + (kq << uu) + i];
-    }
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int k2 = a32_bfly_k(b, h);
-      a32_gs(r[k2], r[k2 + h], tb[(1 << u) - 1 + (k2 >> (5 - u))], p);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k2 = 0; k2 < 32; ++k2) lds[kq * A32_P + a32_f(k2 * 16 + lo)] = r[k2];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 32; ++k) r[k] = lds[k * A32_P + a32_f(tid)];
-#pragma unroll
-  for (int s = 4; s >= 0; --s) {
-    const int h = 16 >> s;
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int k = a32_bfly_k(b, h);
-      a32_gs(r[k], r[k + h], tab[(1 << s) + (k >> (5 - s))], p);
-    }
-  }
-  const Tw32 tn{MONT ? pr.ninv_m[a] : pr.ninv[a], MONT ? pr.ninv_m_p[a] : pr.ninv_p[a]};
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    u32 v = mul_lazy32(r[k], tn, p);
-    v = v >= p ? v - p : v;
-    g[k * A32_T + tid] = v;
-  }
-}
-
 
 // rows of 2^15 elements, plain (non-digit) forward transform: the head stage in place before the sub-transforms (key-table build, self-test)
 __global__ void __launch_bounds__(256) ntt32_head_kernel(u32* __restrict__ rows, i64 count, int nslots, int a0, Aux32Primes pr, Aux32Head hd) {
@@ -343,49 +125,30 @@ int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
   if (!count) return 0;
   const fhesi_aux32* x = ctx->aux32;
   const int S = x->S;
-  if (S && !ctx->opt.ntt32_v3) FHESI_FAIL("aux32: rows of 2^15 elements need option ntt32_v3");
   if (S) {
     ntt32_head_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
     HIP_TRY(hipGetLastError());
   }
-  if (ctx->opt.ntt32_v3) {
-    if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 1>); ntt32_fwd_kernel3<false, 1><<<(unsigned)((count * nslots) << 1), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
-    else { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 0>); ntt32_fwd_kernel3<false, 0><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel<false>);
-  ntt32_fwd_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{});
+  if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 1>); ntt32_fwd_kernel3<false, 1><<<(unsigned)((count * nslots) << 1), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
+  else { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 0>); ntt32_fwd_kernel3<false, 0><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
   HIP_TRY(hipGetLastError());
   return 0;
 }
+// mont: the rows carry the factor 2^-32 of dot32_kernel2's Montgomery step
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont) {
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
   const fhesi_aux32* x = ctx->aux32;
   const int S = x->S;
-  if (S && !ctx->opt.ntt32_v3) FHESI_FAIL("aux32: rows of 2^15 elements need option ntt32_v3");
   ProfScope prof(ctx, PROF_NTT_INV, (double)(count * nslots));
-  if (ctx->opt.ntt32_v3) {
-    const unsigned grid = (unsigned)((count * nslots) << S);
-    if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
-    else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
-    HIP_TRY(hipGetLastError());
-    if (S) {
-      ntt32_tail_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
-      HIP_TRY(hipGetLastError());
-    }
-    return 0;
-  }
-  if (mont) {
-    PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel<true>);
-    ntt32_inv_kernel<true><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel<false>);
-  ntt32_inv_kernel<false><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv);
+  const unsigned grid = (unsigned)((count * nslots) << S);
+  if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
+  else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   HIP_TRY(hipGetLastError());
+  if (S) {
+    ntt32_tail_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
+    HIP_TRY(hipGetLastError());
+  }
   return 0;
 }
 // digit rows, tiled [4][row length / 64][npolys * nd][64] u32, straight from the scaled-down parts
@@ -394,20 +157,13 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   if (!npolys) return 0;
   const fhesi_aux32* x = ctx->aux32;
   const int S = x->S;
-  if (S && !ctx->opt.ntt32_v3) FHESI_FAIL("aux32: rows of 2^15 elements need option ntt32_v3");
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * 4));
   ProfScope main_prof(ctx, PROF_NTT_FWD_DIGITS_MAIN, (double)(npolys * nd * 4));
   const i64 units = npolys * nd;
-  if (ctx->opt.ntt32_v3) {
-    const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim};
-    if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(((units + 7) / 8) * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
-    else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
-    else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel<true>);
-  ntt32_fwd_kernel<true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, Dig32Src{d_parts, nl, digit_bits, nd, (u32)ctx->phim});
+  const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim};
+  if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(((units + 7) / 8) * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+  else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+  else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -450,105 +206,10 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 }
 
 // O[ct][r][l][a][slice] = sum_k D[ct][k][a][slice] * K[a][l][r][k][slice]  mod p_a.   One workgroup = a 64-element slice of CT
-// ciphertexts for one prime; the digit slices (reduced below p) sit in LDS, every wave walks its share of the (limb, key row)
-// pairs.  Products are below 2^60: 16 columns accumulate in a plain 64-bit v_mad_u64_u32 chain, groups are added into a 64-bit
-// total with a carry counter, one reduction per output.
-template <int CT, int NW>
-__global__ void __launch_bounds__(NW * 64) dot32_kernel(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                        u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */) {
-  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
-  static_assert(CT % 4 == 0, "ciphertexts per tile in fours (16-byte LDS reads)");
-  const u32 lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  u32 b = blockIdx.x;
-  const u32 s_lo = b & 7; b >>= 3;
-  const u32 tile = b % (u32)ntiles; b /= (u32)ntiles;
-  const u32 s_hi = b % (u32)nsl8;
-  const int a = (int)(b / (u32)nsl8);
-  const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64;
-  const i64 ct0 = (i64)tile * CT;
-  const u32 p = pr.p[a], twop = 2 * p;
-#define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
-  // tile load: the CT ciphertexts' ncol digit slices are one contiguous run of the tiled digit rows; CT wave-loads in flight per wave
-  const u32* dtile = dig + ((((i64)a << lognsl) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
-  for (int k = w; k < ncol; k += NW) {            // (no division by the run-time column count in this loop: it would be scalar code per element)
-    u32 v[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) v[c] = ct0 + c < count ? __builtin_nontemporal_load(&dtile[((i64)c * ncol + k) << 6]) : 0;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      u32 x = v[c];
-      x = x >= twop ? x - twop : x;
-      x = x >= p ? x - p : x;
-      dl32[DL32(k, c)] = x;
-    }
-  }
-  __syncthreads();
-  const u64 pinv = pr.pinv64[a], r64 = pr.r64[a];   // (host constants: a 128-bit division here would be hundreds of scalar instructions per wave)
-  // one (limb, key row) pair per wave and pass; the 16 key words of the next column group are fetched while this one is multiplied
-  for (int pr_i = w; pr_i < NLB * 2; pr_i += NW) {
-    const int l = pr_i >> 1, r = pr_i & 1;
-    const u32* kp = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2 + r) * ncol) << 6) + lane;
-    u64 tl[CT];
-    u32 th[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) { tl[c] = 0; th[c] = 0; }
-    const int nfull = ncol & ~15;
-    u32 xc[16], xn[16];
-    if (nfull) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) xc[u] = kp[u << 6];
-    }
-    for (int kb = 0; kb < nfull; kb += 16) {
-      if (kb + 16 < nfull) {
-        const u32* pk = kp + ((kb + 16) << 6);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) xn[u] = pk[u << 6];
-      }
-      u64 acc[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) acc[c] = 0;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] += (u64)xc[u] * dl32[DL32(kb + u, c)];
-      }
-#pragma unroll
-      for (int c = 0; c < CT; ++c) { const u64 t = tl[c] + acc[c]; th[c] += t < acc[c] ? 1u : 0u; tl[c] = t; }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) xc[u] = xn[u];
-    }
-    if (nfull < ncol) {
-      u64 acc[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) acc[c] = 0;
-      for (int k = nfull; k < ncol; ++k) {
-        const u32 x = kp[k << 6];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] += (u64)x * dl32[DL32(k, c)];
-      }
-#pragma unroll
-      for (int c = 0; c < CT; ++c) { const u64 t = tl[c] + acc[c]; th[c] += t < acc[c] ? 1u : 0u; tl[c] = t; }
-    }
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      if (ct0 + c < count) {
-        // (th 2^64 + tl) mod p
-        u64 v = tl[c] - __umul64hi(tl[c], pinv) * p;          // below 2p + small
-        v += (u64)th[c] * r64;                                // th < 2^5, r64 < 2^30
-        v = v - __umul64hi(v, pinv) * p;
-        u32 o = (u32)v;
-        o = o >= twop ? o - twop : o;
-        o = o >= p ? o - p : o;
-        (out + ((((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + soff))[lane] = o;
-      }
-    }
-  }
-#undef DL32
-}
+// ciphertexts for one prime; the digit slices (reduced below p) sit in LDS, every wave walks its share of the limbs.
 
-// Second form of the dot product: a wave owns one limb l and BOTH key rows r = 0, 1 of it, so every digit value fetched from the LDS
-// tile feeds two multiply-adds (the first form is bound by the LDS pipe: one 16-byte LDS read per 4 multiply-adds saturates it exactly
+// A wave owns one limb l and BOTH key rows r = 0, 1 of it, so every digit value fetched from the LDS tile feeds two multiply-adds
+// (round 1's form, one key row per wave, was bound by the LDS pipe: one 16-byte LDS read per 4 multiply-adds saturates it exactly
 // when the VALU is saturated).  Accumulation: the v_mad_u64_u32 chain runs straight into a 64-bit total; every 16 columns the bits
 // from 48 upwards move into a 32-bit counter.  Both operands are below p <= 2^30 - 2^15 + 1, so 16 products are at most
 // 2^64 - 2^50 + 2^34 and a total below 2^48 cannot wrap: no carry detection, 3 registers per output, 2-3 extra instructions per
@@ -833,13 +494,12 @@ static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig,
   HIP_TRY(hipGetLastError());
   return 0;
 }
-template <int CT, int NW, bool V2>
+template <int CT, int NW>
 static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)ncol * CT * 64 * 4;
-  const void* fn = V2 ? (const void*)dot32_kernel2<CT, NW> : (const void*)dot32_kernel<CT, NW>;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done |= 1ull << ctx->device;
   }
   const i64 nrow = aux32_row_len(ctx);
@@ -847,19 +507,18 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
   const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
-  prof_kernel(ctx, PROF_DOT, fn);
-  if (V2) dot32_kernel2<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl);
-  else dot32_kernel<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl);
+  PROF_KERNEL(ctx, PROF_DOT, dot32_kernel2<CT, NW>);
+  dot32_kernel2<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   if (!count) return 0;
   ProfScope prof(ctx, PROF_DOT, (double)count);
-  if (ctx->opt.dot32_v3 && (size_t)ncol * 4 * 256 <= 80 * 1024 && ctx->opt.dot32_v2) return launch_dot32_v3(ctx, k, d_dig, ncol, count, d_out);
+  if (ctx->opt.dot32_v3 && (size_t)ncol * 4 * 256 <= 80 * 1024) return launch_dot32_v3(ctx, k, d_dig, ncol, count, d_out);
   // ciphertexts per LDS tile: 8 while ncol * 8 digit slices of 256 bytes fit the CU's 160 KiB (ncol <= 80), else 4 (ncol <= 160)
-  if ((size_t)ncol * 8 * 256 <= 160 * 1024) return ctx->opt.dot32_v2 ? launch_dot32_t<8, 16, true>(ctx, k, d_dig, ncol, count, d_out) : launch_dot32_t<8, 16, false>(ctx, k, d_dig, ncol, count, d_out);
-  if ((size_t)ncol * 4 * 256 <= 160 * 1024) return ctx->opt.dot32_v2 ? launch_dot32_t<4, 16, true>(ctx, k, d_dig, ncol, count, d_out) : launch_dot32_t<4, 16, false>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 8 * 256 <= 160 * 1024) return launch_dot32_t<8, 16>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 4 * 256 <= 160 * 1024) return launch_dot32_t<4, 16>(ctx, k, d_dig, ncol, count, d_out);
   FHESI_FAIL("dot32: %d columns do not fit the LDS tile", ncol);
 }
 

@@ -85,7 +85,7 @@ struct T32Plan { int NP = 0; bool generic = false; };
 //   exceed 2^(TB + 1) so that the reference's own centred integers are these same integers.
 static T32Plan t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax, std::vector<u32>* primes) {
   T32Plan pl;
-  if (!ctx->opt.tensor32 || !ctx->opt.ntt32_v3 || p < 2 || nlimbs < 1 || nlimbs > 16 || 64 * nlimbs < logQ || gmax < 1) return pl;
+  if (!ctx->opt.tensor32 || p < 2 || nlimbs < 1 || nlimbs > 16 || 64 * nlimbs < logQ || gmax < 1) return pl;
   const bool lin = ctx->lin_q != 0;
   if (!lin && !(ctx->pow2 && (ctx->logn == A32_LOGN || ctx->logn == A32_LOGN + 1))) return pl;
   const int lg = lin ? A32_LOGN : ctx->logn;                 // rows of 2^lg
