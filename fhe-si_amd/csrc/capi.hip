@@ -1591,8 +1591,9 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
       FHESI_TRY(tensor32_sum_finish(c, d_sum, ng, (u64*)d_parts));
       FHESI_TRY(ws_reserve(c, 1, (size_t)ng * 2 * L * n * 8, &d_t2));
       FHESI_TRY(key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, ng, (u64*)d_t2, out + (size_t)g * ct_words, nlimbs));
-    } else
-    FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_sum, ng, out + (size_t)g * ct_words, nlimbs));
+    } else {
+      FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_sum, ng, out + (size_t)g * ct_words, nlimbs));
+    }
     g = g2;
   }
   return 0;
