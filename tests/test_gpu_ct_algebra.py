@@ -71,7 +71,9 @@ def test_fixtures_add_mul_long_automorph_sum_batched():
             ctx.ct_automorph_dev(2, d2, 2, nl, 1, rot, nl + 1)         # not in Zm* (DoubleCRT.cpp:442-443)
 
 
-@pytest.mark.parametrize("m,logQ,p", [(2048, 128, 23), (46, 90, 47), (4096, 300, 65537)])
+@pytest.mark.parametrize("m,logQ,p", [(2048, 128, 23), (46, 90, 47), (4096, 300, 65537),
+                                      (101, 90, 23),      # prime m: Ciphertext >>= as a gather with the Phi_m = sum X^i correction
+                                      (45, 90, 23)])      # a ring the gather does not cover: evaluation-form automorphism
 def test_batches_vs_oracle(m, logQ, p):
     primes, roots = P.chain_for(m, logQ, p)
     ctx = F.Context(m, primes, roots)
@@ -100,7 +102,9 @@ def test_batches_vs_oracle(m, logQ, p):
     # Ciphertext >>= k and the automorphism key switch with a random matrix (timing and parity do not depend on key validity)
     ksm = np.stack([P.rand_rows(rng, primes, n, 2 * nd) for _ in range(2)])
     ksk = F.KeySwitchMatrix(ctx, 2, nd).upload(ksm)
-    ks = [3, m - 1] if m % 2 == 0 else [2, m - 1]
+    import math
+    units = [k for k in range(2, m) if math.gcd(k, m) == 1]
+    ks = units[:3] + [units[len(units) // 2], m - 1]
     for k in ks:
         rot = ctx.alloc(count * 2 * n * (nl + 1) * 8)
         ctx.ct_automorph_dev(k, da, 2, nl, count, rot, nl + 1)
