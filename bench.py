@@ -303,15 +303,18 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
     kname = ctx.prof_kernel_name("ntt_fwd_digits_main")
     ctx.prof_enable(False)
     launches, rows, ms = prof["ntt_fwd_digits_main"]
-    achieved = rows * 2 * n * (4 if kname.startswith("ntt32_") else 8) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    # (the 32-bit digit rows have 2^14 elements, also on the zero-padded linear-convolution rings; the bytes counted are the rows' own)
+    row_elems = max(n, 1 << 14) if kname.startswith("ntt32_") else n
+    achieved = rows * 2 * row_elems * (4 if kname.startswith("ntt32_") else 8) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     if rank == 0:
         ksw = stats["key_switches"] + stats["automorph_key_switches"]
         line = {
-            "metric": "key-switched ciphertext products/sec inside Regression::Regress (wave-scheduled) at n=2^14, logQ=512",
+            "metric": f"key-switched ciphertext products/sec inside Regression::Regress (wave-scheduled) at phi(m)={n}, logQ={LOGQ}",
             "value": round(ksw * args.steps / dt, 2), "unit": "key-switches/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"configs[3] replay: Regression::Regress d={d}, {N} data block(s), m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3",
+            "dtype": "u32 rows (tensor products and key switch over primes below 2^30), u64 coefficient limbs" if kname.startswith("ntt32_") else "u64", "data": "synthetic",
+            "config": {"workload": (f"configs[3] replay: Regression::Regress d={d}, {N} data block(s), m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3" if M_RING == 1 << 15 else
+                                    f"configs[3]: Regression::Regress d={d}, {N} data block(s) of phi(m) slots on the reference's Test_Regression ring m={M_RING} (p={P_PLAIN}), fhe-si logQ={LOGQ}, decompSize=3"),
                        "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "automorphism_keys": len(ks), "waves": stats["waves"],
                        "products_per_regress": stats["products"], "key_switches_per_regress": stats["key_switches"],
                        "automorph_key_switches_per_regress": stats["automorph_key_switches"], "regress_per_s": round(args.steps / dt, 3),
@@ -441,6 +444,8 @@ def main():
                     "every wave's groups sharded over the ranks (strong scaling)")
     ap.add_argument("--reg-dim", type=int, default=8)
     ap.add_argument("--reg-rows", type=int, default=1)
+    ap.add_argument("--reg-ring", default="metric", choices=["metric", "reference"], help="regression workload: replay at the metric ring (default) or on "
+                    "the reference's own Test_Regression ring (p = 8423, m = 8422, logQ = 341: configs[3] itself)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 plumbing)")
     ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
@@ -450,6 +455,8 @@ def main():
     global M_RING, LOGQ, P_PLAIN
     if args.workload == "stress":
         M_RING, LOGQ, P_PLAIN = 1 << 16, 1024, 65537
+    if args.workload == "regression" and args.reg_ring == "reference":
+        M_RING, LOGQ, P_PLAIN = 8422, 341, 8423          # Test_Regression.cpp:100-108 (d = 8: logQ = 341 by its noise formula)
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -482,7 +489,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    n = M_RING // 2
+    n = sum(1 for k in range(1, M_RING) if math.gcd(k, M_RING) == 1) if M_RING & (M_RING - 1) else M_RING // 2       # phi(m)
     primes = prime_chain(M_RING, LOGQ, P_PLAIN, n)
     roots = [root_2m(q, M_RING) for q in primes]
     L = len(primes)
