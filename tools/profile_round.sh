@@ -17,6 +17,7 @@ if [ -z "${PROFILE_ONLY_PMC:-}" ]; then
 run metric --steps 5 --warmup 2 --no-bluestein-cpu
 run stress --workload stress --steps 3 --warmup 1 --cpu-sample 0
 run regression --workload regression --steps 3 --warmup 1
+run regression_ref --workload regression --reg-ring reference --steps 5 --warmup 2
 run ntt --workload ntt --steps 10 --warmup 2
 fi
 for c in FETCH_SIZE WRITE_SIZE; do        # one counter per pass (combining them has hung the profiler on this pool)
