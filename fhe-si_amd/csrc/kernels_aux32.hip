@@ -292,15 +292,23 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
         for (int c = 0; c < CT; ++c) { tot[0][c] += (u64)x[0][u] * d[c]; tot[1][c] += (u64)x[1][u] * d[c]; }
       }
     };
-    if (nfull) loadc(xa, 0);
-    int kb = 0;
-    for (; kb < n2; kb += 2 * CH) {
+    // The 8-column pairs are taken in an order ROTATED by the tile number.  The workgroups of the 8 ciphertext tiles of a (slice, prime)
+    // run side by side on one XCD and stream the same key block; in the same order they all miss on the same lines at the same moment and
+    // every chunk arrives at HBM latency.  Rotated, each of them is the first reader of its own eighth: the whole block is requested in
+    // the first microsecond and everything after that is an L2 hit.
+    const int npair = n2 / (2 * CH);
+    const int pst = npair ? (int)(tile % (u32)npair) : 0;
+    auto pk = [&](int i) { int q = i + pst; if (q >= npair) q -= npair; return q * 2 * CH; };
+    if (npair) loadc(xa, pk(0)); else if (nfull) loadc(xa, 0);
+    for (int i = 0; i < npair; ++i) {
+      const int kb = pk(i);
       loadc(xb, kb + CH);
       macc(xa, kb);
-      if (kb + 2 * CH < nfull) loadc(xa, kb + 2 * CH);
+      if (i + 1 < npair) loadc(xa, pk(i + 1)); else if (n2 < nfull) loadc(xa, n2);
       macc(xb, kb + CH);
-      if (kb & (2 * CH)) fold();                     // 16 columns since the last fold
+      if (i & 1) fold();                             // 16 columns since the last fold
     }
+    const int kb = n2;
     if (nfull & CH) { macc(xa, kb); }
     if ((nfull & (3 * CH)) != 0) fold();             // up to 12 columns pending, up to 3 more follow: fold here so that the tail starts below 2^48
     for (int k = nfull; k < ncol; ++k) {             // at most 3 columns
