@@ -604,7 +604,8 @@ static int launch_crt_sum(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows,
 // mixed radix with the constants of Garner32; otherwise the two 60-bit chain primes, [poly][NLB][2][n] u64.
 struct Garner32 { u32 p[4]; u32 c[6], cp[6]; };      // c = {p0^-1 mod p1, p0^-1 mod p2, p1^-1 mod p2, p0^-1 mod p3, p1^-1 mod p3, p2^-1 mod p3} and floor(c 2^32 / p_j)
 __device__ __forceinline__ u32 g32_mul(u32 y, u32 c, u32 cp, u32 p) { const u32 r = y * c - __umulhi(y, cp) * p; return r >= p ? r - p : r; }     // y any u32 -> [0, p)
-__device__ __forceinline__ u32 g32_sub(u32 a, u32 b, u32 p) { b = b >= p ? b - p : b; return a >= b ? a - b : a + p - b; }                     // a in [0, p), b below 2p
+__device__ __forceinline__ u32 g32_mul_lazy(u32 y, u32 c, u32 cp, u32 p) { return y * c - __umulhi(y, cp) * p; }                               // y any u32 -> [0, 2p)
+__device__ __forceinline__ u32 g32_sub(u32 a, u32 b, u32 p) { return a + 2 * p - b; }      // a, b below 2p -> a - b + 2p in (0, 4p): only ever the argument of a g32_mul
 template <int W, int LQ, int B, int NLB, bool A32>
 __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict__ o, i64 n, u64 q0, u64 q1, u64 q0inv, u64 q0inv_sh, u64 half_hi, u64 half_lo,
                                                            u64 a_hi, u64 a_lo, const u64* __restrict__ consts /* D[W+1], pinv lo, hi */,
@@ -628,9 +629,10 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
       const u32 v0 = base32[(i64)(l * 4 + 0) * n], v1 = base32[(i64)(l * 4 + 1) * n], v2 = base32[(i64)(l * 4 + 2) * n], v3 = base32[(i64)(l * 4 + 3) * n];
       const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
       const u32 x1 = v0;                                                        // all four primes lie in (2^29, 2^30): a residue of one is below twice any other
+      // (inner products stay lazy, below 2p; the mixed-radix digits x2, x3, x4 themselves are reduced)
       const u32 x2 = g32_mul(g32_sub(v1, x1, p1), gc.c[0], gc.cp[0], p1);
-      const u32 x3 = g32_mul(g32_sub(g32_mul(g32_sub(v2, x1, p2), gc.c[1], gc.cp[1], p2), x2, p2), gc.c[2], gc.cp[2], p2);
-      const u32 x4 = g32_mul(g32_sub(g32_mul(g32_sub(g32_mul(g32_sub(v3, x1, p3), gc.c[3], gc.cp[3], p3), x2, p3), gc.c[4], gc.cp[4], p3), x3, p3),
+      const u32 x3 = g32_mul(g32_sub(g32_mul_lazy(g32_sub(v2, x1, p2), gc.c[1], gc.cp[1], p2), x2, p2), gc.c[2], gc.cp[2], p2);
+      const u32 x4 = g32_mul(g32_sub(g32_mul_lazy(g32_sub(g32_mul_lazy(g32_sub(v3, x1, p3), gc.c[3], gc.cp[3], p3), x2, p3), gc.c[4], gc.cp[4], p3), x3, p3),
                              gc.c[5], gc.cp[5], p3);
       V = (u128)((u64)x3 + (u64)p2 * x4) * ((u64)p0 * p1) + ((u64)x1 + (u64)p0 * x2);       // x1 + p0 (x2 + p1 (x3 + p2 x4)), below p0 p1 p2 p3
     } else {
@@ -728,9 +730,10 @@ __global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __
                 v3 = base32[(i64)(l * 4 + 3) * nrow + pos];
       const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
       const u32 x1 = v0;
+      // (inner products stay lazy, below 2p; the mixed-radix digits x2, x3, x4 themselves are reduced)
       const u32 x2 = g32_mul(g32_sub(v1, x1, p1), gc.c[0], gc.cp[0], p1);
-      const u32 x3 = g32_mul(g32_sub(g32_mul(g32_sub(v2, x1, p2), gc.c[1], gc.cp[1], p2), x2, p2), gc.c[2], gc.cp[2], p2);
-      const u32 x4 = g32_mul(g32_sub(g32_mul(g32_sub(g32_mul(g32_sub(v3, x1, p3), gc.c[3], gc.cp[3], p3), x2, p3), gc.c[4], gc.cp[4], p3), x3, p3),
+      const u32 x3 = g32_mul(g32_sub(g32_mul_lazy(g32_sub(v2, x1, p2), gc.c[1], gc.cp[1], p2), x2, p2), gc.c[2], gc.cp[2], p2);
+      const u32 x4 = g32_mul(g32_sub(g32_mul_lazy(g32_sub(g32_mul_lazy(g32_sub(v3, x1, p3), gc.c[3], gc.cp[3], p3), x2, p3), gc.c[4], gc.cp[4], p3), x3, p3),
                              gc.c[5], gc.cp[5], p3);
       V = (u128)((u64)x3 + (u64)p2 * x4) * ((u64)p0 * p1) + ((u64)x1 + (u64)p0 * x2);
     } else {
