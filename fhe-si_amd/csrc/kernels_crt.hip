@@ -622,11 +622,23 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
   const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
   const u64* base = o + poly * NLB * 2 * n + j;
   const u32* base32 = reinterpret_cast<const u32*>(o) + poly * NLB * 4 * n + j;
+  // all the residues of the coefficient at once (the kernel waits on these loads, not on its arithmetic: one round of 4 NLB loads in
+  // flight instead of a round per limb)
+  constexpr bool PRE = A32 && NLB <= 16;           // (the 30 limbs of the stress chain would cost a wave per SIMD)
+  u32 vin[PRE ? NLB : 1][4];
+  if (PRE) {
+#pragma unroll
+    for (int l = 0; l < NLB; ++l)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) vin[l][a] = __builtin_nontemporal_load(&base32[(i64)(l * 4 + a) * n]);
+  }
 #pragma unroll
   for (int l = 0; l < NLB; ++l) {
     u128 V;
     if (A32) {
-      const u32 v0 = base32[(i64)(l * 4 + 0) * n], v1 = base32[(i64)(l * 4 + 1) * n], v2 = base32[(i64)(l * 4 + 2) * n], v3 = base32[(i64)(l * 4 + 3) * n];
+      u32 v0, v1, v2, v3;
+      if (PRE) { v0 = vin[l][0]; v1 = vin[l][1]; v2 = vin[l][2]; v3 = vin[l][3]; }
+      else { v0 = base32[(i64)(l * 4 + 0) * n]; v1 = base32[(i64)(l * 4 + 1) * n]; v2 = base32[(i64)(l * 4 + 2) * n]; v3 = base32[(i64)(l * 4 + 3) * n]; }
       const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
       const u32 x1 = v0;                                                        // all four primes lie in (2^29, 2^30): a residue of one is below twice any other
       // (inner products stay lazy, below 2p; the mixed-radix digits x2, x3, x4 themselves are reduced)
