@@ -365,14 +365,31 @@ __global__ void __launch_bounds__(256) tensor_sum32_kernel(const u32* __restrict
   };
   u64 r0 = 0, r1 = 0, r2 = 0;
   if (accumulate) { r0 = o0[0]; r1 = o0[rs]; r2 = o0[2 * rs]; }
-  for (int t = t0; t < t1; ++t) {
+  // four terms per round: their sixteen loads are issued together (the kernel waits on its loads), then one reduction
+  int t = t0;
+  for (; t + 4 <= t1; t += 4) {
+    u32 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32* a = ra + (((i64)slot_a[t + u] * 2) * NP + l) * nrow + j;
+      const u32* b = rb + (((i64)slot_b[t + u] * 2) * NP + l) * nrow + j;
+      a0[u] = a[0]; a1[u] = a[rs]; b0[u] = b[0]; b1[u] = b[rs];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      r0 += (u64)a0[u] * b0[u];
+      r1 += (u64)a0[u] * b1[u] + (u64)a1[u] * b0[u];
+      r2 += (u64)a1[u] * b1[u];
+    }
+    r0 = red(r0); r1 = red(r1); r2 = red(r2);
+  }
+  for (; t < t1; ++t) {                               // at most three more
     const u32* a = ra + (((i64)slot_a[t] * 2) * NP + l) * nrow + j;
     const u32* b = rb + (((i64)slot_b[t] * 2) * NP + l) * nrow + j;
     const u32 a0 = a[0], a1 = a[rs], b0 = b[0], b1 = b[rs];
     r0 += (u64)a0 * b0;
     r1 += (u64)a0 * b1 + (u64)a1 * b0;
     r2 += (u64)a1 * b1;
-    if (((t - t0) & 3) == 3) { r0 = red(r0); r1 = red(r1); r2 = red(r2); }
   }
   o0[0] = red(r0);
   o0[rs] = red(r1);
