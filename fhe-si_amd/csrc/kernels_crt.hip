@@ -757,14 +757,50 @@ __global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __
     if (V > half) V -= A;
     return V;
   };
+  // A32: the residues of the next limb are fetched while this one is recombined (the kernel waits on its loads), and on the
+  // linear-convolution rings the fold  S_j - S_(j+q') -+ (S_n - S_(n+q'))  is taken on the RESIDUES (it is linear and the plan keeps the
+  // combination below A / 2), so one Garner recombination per limb serves instead of four
+  u32 cur[4] = {0, 0, 0, 0}, nxt[4] = {0, 0, 0, 0};
+  auto fetch = [&](int l, u32 (&v)[4]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const u32* __restrict__ row = base32 + (i64)(l * 4 + a) * nrow;
+      if (!fold_q) { v[a] = row[j]; continue; }
+      const u32 p = gc.p[a];
+      const u32 s0 = row[j], s1 = row[j + fold_q], t0 = row[n], t1 = row[n + fold_q];      // all below p
+      u32 r = s0 + (p - s1) + ((j & 1) ? t0 + (p - t1) : t1 + (p - t0));                     // below 4p
+      r = r >= 2 * p ? r - 2 * p : r;
+      v[a] = r >= p ? r - p : r;
+    }
+  };
+  auto garner = [&](const u32 (&v)[4]) -> u128 {
+    const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
+    const u32 x1 = v[0];
+    const u32 x2 = g32_mul(g32_sub(v[1], x1, p1), gc.c[0], gc.cp[0], p1);
+    const u32 x3 = g32_mul(g32_sub(g32_mul_lazy(g32_sub(v[2], x1, p2), gc.c[1], gc.cp[1], p2), x2, p2), gc.c[2], gc.cp[2], p2);
+    const u32 x4 = g32_mul(g32_sub(g32_mul_lazy(g32_sub(g32_mul_lazy(g32_sub(v[3], x1, p3), gc.c[3], gc.cp[3], p3), x2, p3), gc.c[4], gc.cp[4], p3), x3, p3),
+                           gc.c[5], gc.cp[5], p3);
+    u128 V = (u128)((u64)x3 + (u64)p2 * x4) * ((u64)p0 * p1) + ((u64)x1 + (u64)p0 * x2);
+    if (V > half) V -= A;
+    return V;
+  };
+  if (A32) fetch(0, cur);
   for (int l = 0; l < NLB; ++l) {
-    u128 V = centred(l, j);
-    if (fold_q) {
-      // S (degree < 2n - 1) modulo X^q' + 1: R_j = S_j - S_(j+q');  modulo Phi_m = 1 - X + X^2 - ... + X^(q'-1) (degree n = q' - 1):
-      // out_j = R_j - (-1)^j R_n,  j < n   (Phi_m is monic, so this is the exact integer remainder)
-      const u128 top = centred(l, n) - centred(l, n + fold_q);
-      V -= centred(l, j + fold_q);
-      if (j & 1) V += top; else V -= top;
+    u128 V;
+    if (A32) {
+      if (l + 1 < NLB) fetch(l + 1, nxt);
+      V = garner(cur);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cur[a] = nxt[a];
+    } else {
+      V = centred(l, j);
+      if (fold_q) {
+        // S (degree < 2n - 1) modulo X^q' + 1: R_j = S_j - S_(j+q');  modulo Phi_m = 1 - X + X^2 - ... + X^(q'-1) (degree n = q' - 1):
+        // out_j = R_j - (-1)^j R_n,  j < n   (Phi_m is monic, so this is the exact integer remainder)
+        const u128 top = centred(l, n) - centred(l, n + fold_q);
+        V -= centred(l, j + fold_q);
+        if (j & 1) V += top; else V -= top;
+      }
     }
     V += (u128)1 << 119;
     const int s = B * l, wd = s >> 6, bt = s & 63;
