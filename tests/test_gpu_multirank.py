@@ -103,7 +103,8 @@ def test_wave_evaluator_sharded_over_ranks_is_bit_identical(args, devices):
     assert "batched: decrypts to the plaintext regression: yes" in r.stdout
 
 
-@pytest.mark.parametrize("workload,extra", [("metric", ["--batch", "64"]), ("regression", ["--reg-dim", "3"]), ("ntt", ["--batch", "64"])])
+@pytest.mark.parametrize("workload,extra", [("metric", ["--batch", "64"]), ("regression", ["--reg-dim", "3"]), ("ntt", ["--batch", "64"]),
+                                            ("regression", ["--reg-dim", "3", "--reg-ring", "reference"])])      # configs[3] on the reference's own ring
 def test_bench_launches_its_own_ranks(workload, extra):
     """`python bench.py --gpus 2` without an external launcher (how a single-command driver starts it): the parent spawns the ranks
     as a child torch.distributed.run before touching the GPU and relays rank 0's JSON line.  On this 1-GPU box both ranks use GPU 0 and
