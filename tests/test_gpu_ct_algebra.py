@@ -117,6 +117,13 @@ def test_batches_vs_oracle(m, logQ, p):
         got = out.download((count, 2, n, nl))
         for c in range(count):
             assert np.array_equal(got[c], orc.apply_key_switch_parts(ksm, exp[c], logQ, nl)), (k, c)
+        # the reference's own route (DoubleCRT::automorph on evaluation rows) gives the same bits as the coefficient gather
+        ctx.set_option("automorph_rows", 1)
+        ctx.ct_automorph_dev(k, da, 2, nl, count, rot, nl + 1)
+        assert np.array_equal(rot.download((count, 2, n, nl + 1)), np.stack(exp)), k
+        ctx.ct_automorph_key_switch_dev(ksk, logQ, k, da, nl, count, out, nl)
+        assert np.array_equal(out.download((count, 2, n, nl)), got), k
+        ctx.set_option("automorph_rows", 0)
     # scaled-up *= long
     tp = ctx.alloc(count * 3 * L * n * 8)
     ctx.ct_mul_dev(p, da, db, nl, count, tp)
