@@ -217,8 +217,7 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 template <int CT, int NW>
 __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
                                                          u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */) {
-  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
-  static_assert(CT % 4 == 0, "ciphertexts per tile in fours (16-byte LDS reads)");
+  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT][64 lanes]
   const u32 lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   u32 b = blockIdx.x;
@@ -229,19 +228,34 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
   const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64;
   const i64 ct0 = (i64)tile * CT;
   const u32 p = pr.p[a], twop = 2 * p;
-#define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
-  const u32* dtile = dig + ((((i64)a << lognsl) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
+#define DL32(k, c) (((((k) * CT) + (c)) << 6) + lane)
 #if !(defined(DOT32_ABLATE) && (DOT32_ABLATE & 4))   // ablation: no tile load
-  for (int k = w; k < ncol; k += NW) {
-    u32 v[CT];
+  {
+    // One load instruction moves 1 KiB: lane i takes the 16 bytes = elements 4 (i & 15) .. + 3 of column k0 + (i >> 4) of one ciphertext
+    // (four consecutive columns of a ciphertext are contiguous in the tiled digit rows), reduces them and writes them with one
+    // conflict-free 16-byte LDS write; the arithmetic reads the CT ciphertexts of a column with CT 4-byte reads.
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const u32* dbase = dig + ((((i64)a << lognsl) + slice) * (count * ncol) + ct0 * ncol) * 64;
+    constexpr int TB = 6;
+    const int nq = (ncol + 3) >> 2, items = CT * nq;
+    const u32 e0 = 4 * (lane & 15), dk = lane >> 4;
+    for (int it0 = w * TB; it0 < items; it0 += NW * TB) {
+      v4u v[TB];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) v[c] = ct0 + c < count ? __builtin_nontemporal_load(&dtile[((i64)c * ncol + k) << 6]) : 0;
+      for (int u = 0; u < TB; ++u) {
+        const int it = it0 + u, c = it / nq, k = (it - c * nq) * 4 + (int)dk;
+        v[u] = (it < items && k < ncol && ct0 + c < count) ? __builtin_nontemporal_load(reinterpret_cast<const v4u*>(dbase + (((i64)c * ncol + k) << 6) + e0)) : v4u{0, 0, 0, 0};
+      }
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      u32 x = v[c];
-      x = x >= twop ? x - twop : x;
-      x = x >= p ? x - p : x;
-      dl32[DL32(k, c)] = x;
+      for (int u = 0; u < TB; ++u) {
+        const int it = it0 + u, c = it / nq, k = (it - c * nq) * 4 + (int)dk;
+        if (it < items && k < ncol) {
+          v4u y = v[u];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { u32 t = y[j]; t = t >= twop ? t - twop : t; y[j] = t >= p ? t - p : t; }
+          *reinterpret_cast<v4u*>(&dl32[((k * CT + c) << 6) + e0]) = y;
+        }
+      }
     }
   }
 #endif
