@@ -1187,7 +1187,7 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
     FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * 2 * nrow * 8, &d_dig));
     FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * R * 2 * nrow * 8, &d_o));
     if (k->aux32) {       // four 30-bit primes (kernels_aux32.hip): the same buffer sizes, u32 rows
-      FHESI_TRY(launch_ntt32_fwd_digits(c, d_parts, nlq, 8 * decomp_bytes, nd, count * ncomp, (u32*)d_dig));
+      FHESI_TRY(launch_ntt32_fwd_digits(c, d_parts, nlq, 8 * decomp_bytes, nd, count * ncomp, (u32*)d_dig, kDigitSubCt * ncol));
       if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
       FHESI_TRY(launch_dot32(c, k, (const u32*)d_dig, ncol, count, (u32*)d_o));
       FHESI_TRY(launch_ntt32_inv(c, (u32*)d_o, count * 2 * R, 4, 0, true));
@@ -1601,6 +1601,17 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
 
 static i64 batch_chunk(const fhesi_ctx* c, int ncol) {
   if (c->opt.batch_chunk > 0) return c->opt.batch_chunk;
+  if (aux32_applies(c)) {
+    // the 32-bit pipelines (key switch over the four auxiliary primes, tensor half over primes below 2^30): the larger the launch the
+    // better -- 64 per launch 22.1 k mults/s, 128: 22.5 k, 512: 22.7 k, 1024: 23.0 k at the metric ring (more ciphertext tiles per key
+    // block in the dot product, fewer launch tails; running the tensor half and the digit transforms in sub-chunks of 64 so that their
+    // intermediate rows stay in the Infinity Cache, and only the dot product and what follows per chunk, measured 22.8 k against 23.3 k
+    // for every stage per chunk) -- so: what fits about 48 GiB of workspace (digit rows ncol * 2 * row * 8 bytes per
+    // ciphertext, the dot product's outputs and the tensor half's rows about 1.6 times that again), at most 1024
+    const double per = (double)ncol * 2 * (double)aux32_row_len(c) * 8.0 * 2.6;
+    const i64 ch = (i64)(48.0 * 1024 * 1024 * 1024 / per);
+    return ch < 1 ? 1 : (ch > 1024 ? 1024 : ch);
+  }
   // about 75k digit rows per chunk (150 rounds of the transform's 512 resident workgroups): measured best on MI355X at both the
   // metric ring (64 mults, 9.3 GiB of digit rows) and the stress ring (16-17 mults, 18 GiB) -- smaller chunks pay launch tails in
   // every stage, larger ones push the key rows out of the Infinity Cache during the dot product.  Capped at 32 GiB of digit rows.

@@ -182,7 +182,9 @@ int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts);
 const u32* aux32_primes(fhesi_ctx* ctx);          // the four primes (host array), nullptr on error
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */);
-int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* [npolys*nd][4][n] */);
+constexpr i64 kDigitSubCt = 64;                   // ciphertexts per sub-chunk of the tiled 32-bit digit rows (launch_ntt32_fwd_digits <-> launch_dot32)
+int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* tiled, see ntt32_core.inc */,
+                            i64 sub_units /* units (digit polynomials) per sub-chunk */);
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */);
 bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14 or 2^15, or a ring with lin_q set
 i64 aux32_row_len(const fhesi_ctx* ctx);            // 2^15 for n = 2^15, else 2^14

@@ -152,7 +152,7 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0,
   return 0;
 }
 // digit rows, tiled [4][row length / 64][npolys * nd][64] u32, straight from the scaled-down parts
-int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out) {
+int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out, i64 sub_units) {
   FHESI_TRY(aux32_init(ctx));
   if (!npolys) return 0;
   const fhesi_aux32* x = ctx->aux32;
@@ -160,7 +160,7 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * 4));
   ProfScope main_prof(ctx, PROF_NTT_FWD_DIGITS_MAIN, (double)(npolys * nd * 4));
   const i64 units = npolys * nd;
-  const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim};
+  const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units};
   if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(((units + 7) / 8) * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 // output and 16 columns.
 template <int CT, int NW>
 __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                         u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */) {
+                                                         u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */, int sub_ct /* ciphertexts per sub-chunk of the tiled digit rows */) {
   extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT][64 lanes]
   const u32 lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
     // (four consecutive columns of a ciphertext are contiguous in the tiled digit rows), reduces them and writes them with one
     // conflict-free 16-byte LDS write; the arithmetic reads the CT ciphertexts of a column with CT 4-byte reads.
     typedef u32 v4u __attribute__((ext_vector_type(4)));
-    const u32* dbase = dig + ((((i64)a << lognsl) + slice) * (count * ncol) + ct0 * ncol) * 64;
+    const i64 sub = ct0 / sub_ct, ct_in = ct0 - sub * sub_ct, rest = count - sub * sub_ct, cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
+    const u32* dbase = dig + sub * sub_ct * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + ct_in * ncol) * 64;
     constexpr int TB = 6;
     const int nq = (ncol + 3) >> 2, items = CT * nq;
     const u32 e0 = 4 * (lane & 15), dk = lane >> 4;
@@ -375,7 +376,7 @@ int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, in
 // barriers of one overlap the arithmetic of the other.  The price is twice the key words through L2 per multiply-add (CT halved).
 template <int CT, int NW, int LP>
 __global__ void __launch_bounds__(NW * 64, 4) dot32_kernel3(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                            u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl) {
+                                                            u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl, int sub_ct) {
   extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
   static_assert(CT == 4, "one 16-byte LDS read per column");
   const u32 lane = threadIdx.x & 63;
@@ -389,7 +390,8 @@ __global__ void __launch_bounds__(NW * 64, 4) dot32_kernel3(const u32* __restric
   const i64 ct0 = (i64)tile * CT;
   const u32 p = pr.p[a], twop = 2 * p;
 #define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
-  const u32* dtile = dig + ((((i64)a << lognsl) + slice) * (count * ncol) + ct0 * ncol) * 64 + lane;
+  const i64 sub = ct0 / sub_ct, ct_in = ct0 - sub * sub_ct, rest = count - sub * sub_ct, cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
+  const u32* dtile = dig + sub * sub_ct * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + ct_in * ncol) * 64 + lane;
   for (int k0 = w * 2; k0 < ncol; k0 += NW * 2) {       // two columns (8 loads) per wave and round
     u32 v[2][CT];
 #pragma unroll
@@ -512,7 +514,7 @@ static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig,
   const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
   PROF_KERNEL(ctx, PROF_DOT, dot32_kernel3<CT, NW, LP>);
-  dot32_kernel3<CT, NW, LP><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl);
+  dot32_kernel3<CT, NW, LP><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, (int)kDigitSubCt);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -530,7 +532,7 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
   PROF_KERNEL(ctx, PROF_DOT, dot32_kernel2<CT, NW>);
-  dot32_kernel2<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl);
+  dot32_kernel2<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, (int)kDigitSubCt);
   HIP_TRY(hipGetLastError());
   return 0;
 }
