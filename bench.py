@@ -497,7 +497,7 @@ def main():
     nl = (LOGQ + 63) // 64
     ncol = 3 * nd
     chain_bits = sum(math.log2(q) for q in primes)
-    B = args.batch if args.batch else (64 if args.workload == "stress" else 1024)
+    B = args.batch if args.batch else 1024          # (configs[4] asks for 1024 concurrent mults at the stress shape as well: 26 GB of operands and results)
 
     ctx = F.Context(M_RING, primes, roots, device=local_rank)
     for k, v in options.items():
@@ -639,8 +639,10 @@ def main():
     roofline_dot = {"bound": "hbm", "kernel": dname, "achieved": round(dach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": dtraffic, "traffic_source": dtraffic_src, "launches": dl,
                     "avg_launch_ms": round(dms / dl, 4) if dl else None, "ciphertexts_per_launch": round(dunits / dl, 1) if dl else None,
-                    "note": "integer multiply-accumulate bound by the LDS pipe and the VALU (the key slices are re-read from L2), not by HBM; see roofline_ntt for the "
-                            "DoubleCRT transform the metric's GB/s figure refers to"}
+                    "ms_per_64_ciphertexts": round(dms / dunits * 64, 4) if dunits else None,
+                    "note": "integer multiply-accumulate bound by the LDS pipe and the VALU (the key slices are re-read from L2), not by HBM; its algorithmic bytes per "
+                            "ciphertext shrink with the launch size (the key rows are read once per launch), so frac is comparable only at equal "
+                            "ciphertexts_per_launch -- ms_per_64_ciphertexts is; see roofline_ntt for the DoubleCRT transform the metric's GB/s figure refers to"}
     # `roofline` is the kernel with the largest share of the step
     roofline = roofline_dot if dms >= ms else roofline_ntt
 
