@@ -435,8 +435,8 @@ def main():
                     "a second; stress: 64; ntt workload: DoubleCRTs per step, default 1024)")
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline and compared with the timed output buffer (0 = skip)")
     ap.add_argument("--no-bluestein-cpu", action="store_true", help="skip the like-for-like (Bluestein-mode) CPU timing, about 20 s")
-    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (option lanes); 2 gave ~+4 %% with launches of 64 ciphertexts, +0.6 %% with today's launches of 1024, and "
-                    "overlapping kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (option lanes); 2 gave ~+4 %% with launches of 64 ciphertexts, +0.6 %% with today's launches of 1024; it "
+                    "overlaps kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
     ap.add_argument("--workload", default="metric", choices=["metric", "stress", "regression", "ntt"], help="metric = configs[2] (default, the contract line); "
                     "ntt = configs[1]: DoubleCRT forward+inverse round trips at n=2^13, 8 primes, --batch DoubleCRTs per GPU (default there: 1024); "
                     "stress = configs[4]: m=2^16 (n=2^15), logQ=1024, p=65537 (35 primes, 43 digits) -- reporting only; "
