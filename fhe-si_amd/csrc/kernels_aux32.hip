@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
           const u32 mq = (u32)v * mont;
           u32 o = (u32)((v + (u64)mq * p) >> 32);
           o = o >= p ? o - p : o;
-          (out + ((((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + soff))[lane] = o;
+          __builtin_nontemporal_store(o, &(out + ((((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + soff))[lane]);
         }
       }
   }

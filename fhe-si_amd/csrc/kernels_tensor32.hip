@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   for (int i = 0; i < NP; ++i) {
     const u32* __restrict__ t = tab + ((i64)cls * NP + i) * STRIDE;
     const u32 r0 = rns32_one<NL>(x, neg, t);
-    if constexpr (!HEAD) o[(i64)i * nrow] = r0;                  // (a zero coefficient gives 0: the padding inside a partial block)
+    if constexpr (!HEAD) __builtin_nontemporal_store(r0, &o[(i64)i * nrow]);                  // (a zero coefficient gives 0: the padding inside a partial block)
     else {
       const u32 p = t[2 * NL + 3], twop = 2 * p;
       const u32 r1 = rns32_one<NL>(x1, neg1, t);
