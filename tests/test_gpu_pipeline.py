@@ -292,6 +292,27 @@ def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
     assert np.array_equal(ref[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
 
 
+def test_large_launch_equals_launches_of_64():
+    """The 32-bit pipelines take up to 1024 ciphertexts per launch, with the digit rows tiled per sub-chunk of 64 ciphertexts
+    (ntt32_core.inc / dot32_kernel2).  130 ciphertexts = two full sub-chunks and a partial one: every output must equal what launches of
+    at most 64 (option batch_chunk, one sub-chunk each) and of 7 (partial tiles everywhere) produce, and the oracle's on a sample."""
+    m, logQ, p, count = 32768, 512, 23, 130
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 77, 5)
+    idx = np.arange(count) % 5
+    a, b = a[idx].copy(), b[idx].copy()
+    a[129, 0, 3] = O.ints_to_limbs([12345], nl)[0]                    # the last ciphertext is not a copy of an earlier one
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    big = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    for chunk in (64, 7):
+        ctx.set_option("batch_chunk", chunk)
+        assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b), big), chunk
+    ctx.set_option("batch_chunk", 0)
+    for c in (0, 129):
+        assert np.array_equal(big[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    for c in range(5, count - 1):
+        assert np.array_equal(big[c], big[c % 5]), c
+
+
 @pytest.mark.parametrize("m,logQ", [(22, 80), (46, 120), (1006, 200), (8422, 341)])
 def test_key_switch_on_safe_prime_rings(m, logQ):
     """The reference's own rings (m = p - 1 = 2 q' for a safe prime p; Test_Regression: p = 8423, logQ = 341, 13 primes) take the exact
