@@ -90,6 +90,7 @@ static const OptDesc kOptions[] = {
   {"wave_operands", "FHESI_WAVE_OPERANDS", offsetof(CtxOptions, wave_operands), true},
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
   {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
+  {"dot32_half", "FHESI_DOT32_HALF", offsetof(CtxOptions, dot32_half), false},
   {"automorph_rows", "FHESI_AUTOMORPH_ROWS", offsetof(CtxOptions, automorph_rows), false},
 };
 static void opt_store(CtxOptions* o, const OptDesc& d, long long v) {

@@ -76,6 +76,7 @@ struct CtxOptions {
   int stagger = 0;          // lanes = 2: start the second lane after the first lane's digit transform
   long long batch_chunk = 0;      // ciphertexts per pipeline chunk (0 = derived from the ring)
   long long wave_operands = 0;    // distinct operands per pass of fhesi_ct_mul_sum_relin_dev (0 = about 4 GiB of rows)
+  int dot32_half = 1;       // 1: dot32_kernel2<.., HALF>: tiles of 32 coefficients, two limbs per wave, two workgroups per CU (0: round 2's first form, one 135 KB workgroup per CU)
   int dot32_v3 = 0;         // 1: dot32_kernel3 (two limbs per wave, 4 ciphertexts per tile, two workgroups per CU)
   int automorph_rows = 0;   // 1: Ciphertext >>= through DoubleCRT::automorph on evaluation rows (the reference's structure) even where the coefficient gather applies
   int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)

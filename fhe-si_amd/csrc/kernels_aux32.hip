@@ -129,8 +129,10 @@ int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
     ntt32_head_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
     HIP_TRY(hipGetLastError());
   }
-  if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 1>); ntt32_fwd_kernel3<false, 1><<<(unsigned)((count * nslots) << 1), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
-  else { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 0>); ntt32_fwd_kernel3<false, 0><<<(unsigned)(count * nslots), A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
+  if (count > 0x7fffffff || (nslots << S) > 65535) FHESI_FAIL("ntt32: too many rows per launch");
+  const dim3 grid((unsigned)count, (unsigned)(nslots << S));
+  if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 1>); ntt32_fwd_kernel3<false, 1><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
+  else { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 0>); ntt32_fwd_kernel3<false, 0><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -141,7 +143,8 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0,
   const fhesi_aux32* x = ctx->aux32;
   const int S = x->S;
   ProfScope prof(ctx, PROF_NTT_INV, (double)(count * nslots));
-  const unsigned grid = (unsigned)((count * nslots) << S);
+  if (count > 0x7fffffff || (nslots << S) > 65535) FHESI_FAIL("ntt32: too many rows per launch");
+  const dim3 grid((unsigned)count, (unsigned)(nslots << S));
   if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   HIP_TRY(hipGetLastError());
@@ -160,7 +163,8 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * nd * 4));
   ProfScope main_prof(ctx, PROF_NTT_FWD_DIGITS_MAIN, (double)(npolys * nd * 4));
   const i64 units = npolys * nd;
-  const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units};
+  if (units > 0x7fffffff) FHESI_FAIL("ntt32: too many digit rows per launch");
+  const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
   if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(((units + 7) / 8) * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
@@ -214,47 +218,65 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 // from 48 upwards move into a 32-bit counter.  Both operands are below p <= 2^30 - 2^15 + 1, so 16 products are at most
 // 2^64 - 2^50 + 2^34 and a total below 2^48 cannot wrap: no carry detection, 3 registers per output, 2-3 extra instructions per
 // output and 16 columns.
-template <int CT, int NW>
-__global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                         u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */, int sub_ct /* ciphertexts per sub-chunk of the tiled digit rows */) {
-  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT][64 lanes]
+//
+// HALF: the tile is 32 coefficients wide instead of 64 and a wave carries TWO limbs (lanes 0..31 limb 2w, lanes 32..63 limb 2w + 1; both
+// halves read the same LDS words, which the LDS broadcasts).  Same multiply-adds per key word and per LDS read, but the tile is half
+// as large (66 KB at the metric shape) and the workgroup has half the waves: TWO workgroups share a CU and the tile load, the barrier
+// and the ragged end of one overlap the arithmetic of the other (with one 135 KB workgroup per CU the VALU sat idle 37 % of the time).
+template <int CT, int NW, bool HALF>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
+                                                         u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */, int sub_lg /* log2 of the ciphertexts per sub-chunk of the tiled digit rows */) {
+  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT][64 or 32 elements]
+  constexpr int LG = HALF ? 5 : 6;
   const u32 lane = threadIdx.x & 63;
+  const u32 ln = HALF ? (lane & 31) : lane;                        // element within the tile
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  u32 b = blockIdx.x;
-  const u32 s_lo = b & 7; b >>= 3;
-  const u32 tile = b % (u32)ntiles; b /= (u32)ntiles;
-  const u32 s_hi = b % (u32)nsl8;
-  const int a = (int)(b / (u32)nsl8);
-  const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64;
-  const i64 ct0 = (i64)tile * CT;
+  // grid: x = s_lo + 8 (tile + ntiles hf), y = s_hi, z = prime -- the same linear order as one flat index (workgroups 8 apart share an
+  // XCD), without the three integer divisions a flat index costs every wave (the SALU cannot divide: ~25 VALU instructions each)
+  const u32 s_lo = blockIdx.x & 7;
+  u32 tile = blockIdx.x >> 3, hf = 0;
+  if (HALF && tile >= (u32)ntiles) { hf = 1; tile -= (u32)ntiles; }
+  const u32 s_hi = blockIdx.y;
+  const int a = (int)blockIdx.z;
+  const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64 + hf * 32;
+  const int ct0 = (int)tile * CT;
   const u32 p = pr.p[a], twop = 2 * p;
-#define DL32(k, c) (((((k) * CT) + (c)) << 6) + lane)
+#define DL32(k, c) (((((k) * CT) + (c)) << LG) + ln)
 #if !(defined(DOT32_ABLATE) && (DOT32_ABLATE & 4))   // ablation: no tile load
   {
     // One load instruction moves 1 KiB: lane i takes the 16 bytes = elements 4 (i & 15) .. + 3 of column k0 + (i >> 4) of one ciphertext
     // (four consecutive columns of a ciphertext are contiguous in the tiled digit rows), reduces them and writes them with one
     // conflict-free 16-byte LDS write; the arithmetic reads the CT ciphertexts of a column with CT 4-byte reads.
     typedef u32 v4u __attribute__((ext_vector_type(4)));
-    const i64 sub = ct0 / sub_ct, ct_in = ct0 - sub * sub_ct, rest = count - sub * sub_ct, cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
-    const u32* dbase = dig + sub * sub_ct * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + ct_in * ncol) * 64;
-    constexpr int TB = 6;
-    const int nq = (ncol + 3) >> 2, items = CT * nq;
-    const u32 e0 = 4 * (lane & 15), dk = lane >> 4;
-    for (int it0 = w * TB; it0 < items; it0 += NW * TB) {
+    const int sub = ct0 >> sub_lg, sub_ct = 1 << sub_lg, ct_in = ct0 & (sub_ct - 1);
+    const i64 rest = count - ((i64)sub << sub_lg), cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
+    const u32* dbase = dig + ((i64)sub << sub_lg) * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + (i64)ct_in * ncol) * 64;
+    // (HALF: 8 lanes per 128-byte half row; 16 consecutive lanes take the same column of TWO ciphertexts, which are adjacent in LDS.)
+    // Work split without divisions: NW / NCG waves share a group of ciphertexts and take its column quads round robin.
+    constexpr int TB = 6, CG = HALF ? 2 : 1, NCG = CT / CG, WPG = NW / NCG;
+    static_assert(NW % NCG == 0, "waves per ciphertext group");
+    const int nq = (ncol + 3) >> 2;
+    const int cg = w % NCG, q0 = w / NCG;
+    const u32 e0 = HALF ? 4 * (lane & 7) : 4 * (lane & 15), dk = lane >> 4, dc = HALF ? ((lane >> 3) & 1) : 0;
+    const u32 goff = HALF ? hf * 32 + e0 : e0;
+    const int c = cg * CG + (int)dc;
+    const bool cok = ct0 + c < count;
+    for (int qb = q0; qb < nq; qb += WPG * TB) {
       v4u v[TB];
 #pragma unroll
       for (int u = 0; u < TB; ++u) {
-        const int it = it0 + u, c = it / nq, k = (it - c * nq) * 4 + (int)dk;
-        v[u] = (it < items && k < ncol && ct0 + c < count) ? __builtin_nontemporal_load(reinterpret_cast<const v4u*>(dbase + (((i64)c * ncol + k) << 6) + e0)) : v4u{0, 0, 0, 0};
+        const int q = qb + u * WPG, k = q * 4 + (int)dk;
+        v[u] = (q < nq && k < ncol && cok) ? __builtin_nontemporal_load(reinterpret_cast<const v4u*>(dbase + (((i64)c * ncol + k) << 6) + goff)) : v4u{0, 0, 0, 0};
       }
 #pragma unroll
       for (int u = 0; u < TB; ++u) {
-        const int it = it0 + u, c = it / nq, k = (it - c * nq) * 4 + (int)dk;
-        if (it < items && k < ncol) {
+        const int q = qb + u * WPG, k = q * 4 + (int)dk;
+        if (q < nq && k < ncol) {
           v4u y = v[u];
 #pragma unroll
           for (int j = 0; j < 4; ++j) { u32 t = y[j]; t = t >= twop ? t - twop : t; y[j] = t >= p ? t - p : t; }
-          *reinterpret_cast<v4u*>(&dl32[((k * CT + c) << 6) + e0]) = y;
+          *reinterpret_cast<v4u*>(&dl32[((k * CT + c) << LG) + e0]) = y;
         }
       }
     }
@@ -263,8 +285,11 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
   __syncthreads();
   const u64 r48 = pr.r48[a];
   const u32 mont = pr.mont[a];
-  for (int l = w; l < NLB; l += NW) {
-    const u32* kp0 = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + lane;      // row r = 0; row 1 follows after ncol slices
+  for (int lw = w; lw * (HALF ? 2 : 1) < NLB; lw += NW) {
+    const int lraw = HALF ? 2 * lw + (int)(lane >> 5) : lw;          // HALF: the upper lanes of the last wave may have no limb: they repeat the lower one's
+    const bool lok = lraw < NLB;
+    const int l = lok ? lraw : NLB - 1;
+    const u32* kp0 = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + (HALF ? hf * 32 + ln : lane);      // row r = 0; row 1 follows after ncol slices
     const u32* kp1 = kp0 + ((i64)ncol << 6);
     u64 tot[2][CT];
     u32 th[2][CT];
@@ -312,7 +337,8 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
     // every chunk arrives at HBM latency.  Rotated, each of them is the first reader of its own eighth: the whole block is requested in
     // the first microsecond and everything after that is an L2 hit.
     const int npair = n2 / (2 * CH);
-    const int pst = npair ? (int)(tile % (u32)npair) : 0;
+    int pst = npair > 1 ? (int)(tile & (0xffffffffu >> __builtin_clz((u32)npair - 1))) : 0;     // (tile mod npair without a division when npair is a power of two; any start is correct)
+    if (pst >= npair) pst -= npair;
     auto pk = [&](int i) { int q = i + pst; if (q >= npair) q -= npair; return q * 2 * CH; };
     if (npair) loadc(xa, pk(0)); else if (nfull) loadc(xa, 0);
     for (int i = 0; i < npair; ++i) {
@@ -332,6 +358,7 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
       for (int c = 0; c < CT; ++c) { const u32 d = dl32[DL32(k, c)]; tot[0][c] += (u64)x0 * d; tot[1][c] += (u64)x1 * d; }
     }
     fold();                                          // at most 15 columns since the last one; leaves every total below 2^48
+    u32* obase = out + ((((i64)l * 4 + a) << (lognsl + 6)) + soff) + ln;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -343,7 +370,8 @@ __global__ void __launch_bounds__(NW * 64) dot32_kernel2(const u32* __restrict__
           const u32 mq = (u32)v * mont;
           u32 o = (u32)((v + (u64)mq * p) >> 32);
           o = o >= p ? o - p : o;
-          __builtin_nontemporal_store(o, &(out + ((((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + soff))[lane]);
+          u32* q = obase + (((i64)((ct0 + c) * 2 + r) * NLB * 4) << (lognsl + 6));
+          if (!HALF || lok) __builtin_nontemporal_store(o, q);
         }
       }
   }
@@ -518,21 +546,24 @@ static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig,
   HIP_TRY(hipGetLastError());
   return 0;
 }
-template <int CT, int NW>
+template <int CT, int NW, bool HALF>
 static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
-  const size_t shmem = (size_t)ncol * CT * 64 * 4;
+  const size_t shmem = (size_t)ncol * CT * (HALF ? 32 : 64) * 4;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done |= 1ull << ctx->device;
   }
   const i64 nrow = aux32_row_len(ctx);
   const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
-  const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
-  if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
-  PROF_KERNEL(ctx, PROF_DOT, dot32_kernel2<CT, NW>);
-  dot32_kernel2<CT, NW><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, (int)kDigitSubCt);
+  const i64 blocks = (i64)8 * ntiles * (HALF ? 2 : 1);
+  if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");
+  static_assert((kDigitSubCt & (kDigitSubCt - 1)) == 0, "sub-chunks of a power of two");
+  int sub_lg = 0;
+  while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
+  PROF_KERNEL(ctx, PROF_DOT, dot32_kernel2<CT, NW, HALF>);
+  dot32_kernel2<CT, NW, HALF><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -540,9 +571,12 @@ int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol,
   if (!count) return 0;
   ProfScope prof(ctx, PROF_DOT, (double)count);
   if (ctx->opt.dot32_v3 && (size_t)ncol * 4 * 256 <= 80 * 1024) return launch_dot32_v3(ctx, k, d_dig, ncol, count, d_out);
-  // ciphertexts per LDS tile: 8 while ncol * 8 digit slices of 256 bytes fit the CU's 160 KiB (ncol <= 80), else 4 (ncol <= 160)
-  if ((size_t)ncol * 8 * 256 <= 160 * 1024) return launch_dot32_t<8, 16>(ctx, k, d_dig, ncol, count, d_out);
-  if ((size_t)ncol * 4 * 256 <= 160 * 1024) return launch_dot32_t<4, 16>(ctx, k, d_dig, ncol, count, d_out);
+  // ciphertexts per LDS tile: 8 while ncol * 8 digit slices fit (half slices of 128 bytes in 80 KiB, two workgroups per CU; whole slices
+  // of 256 bytes in 160 KiB with option dot32_half = 0): ncol <= 80; else 4 (ncol <= 160)
+  if (ctx->opt.dot32_half && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 8 * 256 <= 160 * 1024) return launch_dot32_t<8, 16, false>(ctx, k, d_dig, ncol, count, d_out);
+  if (ctx->opt.dot32_half && (size_t)ncol * 4 * 128 <= 80 * 1024) return launch_dot32_t<4, 8, true>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 4 * 256 <= 160 * 1024) return launch_dot32_t<4, 16, false>(ctx, k, d_dig, ncol, count, d_out);
   FHESI_FAIL("dot32: %d columns do not fit the LDS tile", ncol);
 }
 

@@ -579,7 +579,8 @@ static int t32_rns(fhesi_ctx* ctx, const T32Config* c, const u64* d_a, const u64
 static int t32_fwd(fhesi_ctx* ctx, const T32Config* c, u32* d_r, i64 npolys) {
   const fhesi_tensor32* x = ctx->tensor32;
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * c->NP));
-  const unsigned grid = (unsigned)((npolys * c->NP) << x->S);
+  if (npolys > 0x7fffffff) FHESI_FAIL("tensor32: too many rows per launch");
+  const dim3 grid((unsigned)npolys, (unsigned)(c->NP << x->S));
   if (x->S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
   else { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 0, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
   HIP_TRY(hipGetLastError());
@@ -648,7 +649,7 @@ int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int n
   {
     ProfScope prof(ctx, PROF_NTT_INV, (double)(count * 3 * NP));
     PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, true, T32Primes>));
-    const unsigned grid = (unsigned)((((count + 7) / 8) * 24 * NP) << S);
+    const dim3 grid((unsigned)(((count + 7) / 8) * 24), (unsigned)(NP << S));
     ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, c->pr, x->d_inv, S, (const u32*)d_r);
     HIP_TRY(hipGetLastError());
   }
@@ -691,7 +692,7 @@ int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts) {
   {
     ProfScope prof(ctx, PROF_NTT_INV, (double)(ng * 3 * c->NP));
     PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, false, T32Primes>));
-    ntt32_inv_kernel3<false, false, T32Primes><<<(unsigned)(ng * 3 * c->NP), A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, 0, nullptr);
+    ntt32_inv_kernel3<false, false, T32Primes><<<dim3((unsigned)(ng * 3), (unsigned)c->NP), A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, 0, nullptr);
     HIP_TRY(hipGetLastError());
   }
   return t32_crt(ctx, c, (const u32*)d_sum, ng * 3, d_parts);
