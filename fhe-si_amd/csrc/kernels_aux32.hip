@@ -283,7 +283,7 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   }
 #endif
   __syncthreads();
-  const u64 r48 = pr.r48[a];
+  const u32 r48 = (u32)pr.r48[a];                 // 2^48 mod p: 30 bits, one multiply-add
   const u32 mont = pr.mont[a];
   for (int lw = w; lw * (HALF ? 2 : 1) < NLB; lw += NW) {
     const int lraw = HALF ? 2 * lw + (int)(lane >> 5) : lw;          // HALF: the upper lanes of the last wave may have no limb: they repeat the lower one's
@@ -369,7 +369,7 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
           const u64 v = tot[r][c] + (u64)th[r][c] * r48;
           const u32 mq = (u32)v * mont;
           u32 o = (u32)((v + (u64)mq * p) >> 32);
-          o = o >= p ? o - p : o;
+          o = min(o, o - p);                          // o < 2p: o - p wraps to a large value exactly when o < p
           u32* q = obase + (((i64)((ct0 + c) * 2 + r) * NLB * 4) << (lognsl + 6));
           if (!HALF || lok) __builtin_nontemporal_store(o, q);
         }
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(NW * 64, 4) dot32_kernel3(const u32* __restric
       }
   }
   __syncthreads();
-  const u64 r48 = pr.r48[a];
+  const u32 r48 = (u32)pr.r48[a];                 // 2^48 mod p: 30 bits, one multiply-add
   const u32 mont = pr.mont[a];
   for (int l0 = w; l0 < NLB; l0 += NW * LP) {
     // limbs l0 and l0 + NW (the second one may not exist: its arithmetic then repeats the first limb's and nothing is stored)
