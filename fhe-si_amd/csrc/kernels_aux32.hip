@@ -344,9 +344,24 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     for (int i = 0; i < npair; ++i) {
       const int kb = pk(i);
       loadc(xb, kb + CH);
-      macc(xa, kb);
-      if (i + 1 < npair) loadc(xa, pk(i + 1)); else if (n2 < nfull) loadc(xa, n2);
-      macc(xb, kb + CH);
+      // the digit words of column u + 1 are read from LDS while column u is multiplied, across the two key chunks (two or three columns
+      // ahead measured the same; left to itself the compiler reads a column right before its multiply-adds in the second chunk).  The
+      // next chunk of keys is fetched unconditionally -- after the last pair one unused chunk -- because a conditional fetch costs eight
+      // register moves per round and 16 registers (-2.5 % together with the prefetch: -4 %).
+      u32 d[2][CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) d[0][c] = dl32[DL32(kb, c)];
+#pragma unroll
+      for (int u = 0; u < 2 * CH; ++u) {
+        if (u == CH) loadc(xa, i + 1 < npair ? pk(i + 1) : (n2 < nfull ? n2 : 0));
+        if (u + 1 < 2 * CH) {
+#pragma unroll
+          for (int c = 0; c < CT; ++c) d[(u + 1) & 1][c] = dl32[DL32(kb + u + 1, c)];
+        }
+        const u32 x0 = u < CH ? xa[0][u & (CH - 1)] : xb[0][u & (CH - 1)], x1 = u < CH ? xa[1][u & (CH - 1)] : xb[1][u & (CH - 1)];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { tot[0][c] += (u64)x0 * d[u & 1][c]; tot[1][c] += (u64)x1 * d[u & 1][c]; }
+      }
       if (i & 1) fold();                             // 16 columns since the last fold
     }
     const int kb = n2;
