@@ -147,19 +147,20 @@ static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
     if (!psi) FHESI_FAIL("tensor32: no 2n-th root");
     const u64 ipsi = hm::invmod(psi, p);
     auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
-    for (u64 idx = 0; idx < (u64)n; ++idx) {       // the full table of the n-point transform: psi^brv(idx) (w itself: the plain-row kernels take a32_ct<false>)
+    auto fwd_form = [](Tw32 t) { return Tw32{0u - t.w, t.wp}; };      // what a32_ct<NEGW> takes: (-w mod 2^32, floor(w 2^32 / p)), as aux32_init
+    for (u64 idx = 0; idx < (u64)n; ++idx) {       // the full table of the n-point transform: psi^brv(idx)
       const u64 e = hm::brv(idx, lg);
       ff[idx] = tw(hm::powmod(psi, e, p)); fi[idx] = tw(hm::powmod(ipsi, e, p));
     }
     if (!S) {
-      std::copy(ff.begin(), ff.end(), hf.begin() + (size_t)a * per_prime);
+      std::transform(ff.begin(), ff.end(), hf.begin() + (size_t)a * per_prime, fwd_form);
       std::copy(fi.begin(), fi.end(), hi.begin() + (size_t)a * per_prime);
     } else {
       // sub-block h runs stage s >= 1 of the row on its groups i = h 2^(s-1) + i':  own index m' + i' (m' = 2^(s-1))  <->  2 m' + h m' + i'  (as aux32_init)
       for (int h = 0; h < 2; ++h)
         for (u64 mp = 1; mp < (u64)A32_N; mp <<= 1)
           for (u64 ip = 0; ip < mp; ++ip) {
-            hf[((size_t)a * 2 + h) * A32_N + mp + ip] = ff[2 * mp + h * mp + ip];
+            hf[((size_t)a * 2 + h) * A32_N + mp + ip] = fwd_form(ff[2 * mp + h * mp + ip]);
             hi[((size_t)a * 2 + h) * A32_N + mp + ip] = fi[2 * mp + h * mp + ip];
           }
       x->head[a] = ff[1]; x->tail[a] = fi[1];
@@ -581,8 +582,8 @@ static int t32_fwd(fhesi_ctx* ctx, const T32Config* c, u32* d_r, i64 npolys) {
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * c->NP));
   if (npolys > 0x7fffffff) FHESI_FAIL("tensor32: too many rows per launch");
   const dim3 grid((unsigned)npolys, (unsigned)(c->NP << x->S));
-  if (x->S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
-  else { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, false>)); ntt32_fwd_kernel3<false, 0, false, T32Primes, false><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
+  if (x->S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
+  else { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 0, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
   HIP_TRY(hipGetLastError());
   return 0;
 }
