@@ -91,6 +91,7 @@ static const OptDesc kOptions[] = {
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
   {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
   {"dot32_half", "FHESI_DOT32_HALF", offsetof(CtxOptions, dot32_half), false},
+  {"dot32_mfma", "FHESI_DOT32_MFMA", offsetof(CtxOptions, dot32_mfma), false},
   {"automorph_rows", "FHESI_AUTOMORPH_ROWS", offsetof(CtxOptions, automorph_rows), false},
 };
 static void opt_store(CtxOptions* o, const OptDesc& d, long long v) {
@@ -1105,6 +1106,7 @@ extern "C" int fhesi_ksk_free(fhesi_ksk* k) {
   hipStreamSynchronize(k->ctx->stream);
   hipFree(k->d_rows);
   if (k->d_aux) hipFree(k->d_aux);
+  if (k->d_mfma) hipFree(k->d_mfma);
   if (k->d_aux_consts) hipFree(k->d_aux_consts);
   if (k->d_limb_consts) hipFree(k->d_limb_consts);
   --k->ctx->live_handles;
@@ -1190,8 +1192,9 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
     if (k->aux32) {       // four 30-bit primes (kernels_aux32.hip): the same buffer sizes, u32 rows
       FHESI_TRY(launch_ntt32_fwd_digits(c, d_parts, nlq, 8 * decomp_bytes, nd, count * ncomp, (u32*)d_dig, kDigitSubCt * ncol));
       if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
-      FHESI_TRY(launch_dot32(c, k, (const u32*)d_dig, ncol, count, (u32*)d_o));
-      FHESI_TRY(launch_ntt32_inv(c, (u32*)d_o, count * 2 * R, 4, 0, true));
+      bool mont = true;                 // dot32_kernel2 leaves the factor 2^-32 of its Montgomery step; the matrix-core form does not
+      FHESI_TRY(launch_dot32(c, km, (const u32*)d_dig, ncol, count, (u32*)d_o, &mont));
+      FHESI_TRY(launch_ntt32_inv(c, (u32*)d_o, count * 2 * R, 4, 0, mont));
       return launch_ks_recombine(c, t, k, (const u64*)d_o, count * 2, (u64*)out, nlimbs);
     }
     FHESI_TRY(launch_ntt_fwd_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig, 0, 2, 2));

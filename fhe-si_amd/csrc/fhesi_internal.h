@@ -76,6 +76,7 @@ struct CtxOptions {
   int stagger = 0;          // lanes = 2: start the second lane after the first lane's digit transform
   long long batch_chunk = 0;      // ciphertexts per pipeline chunk (0 = derived from the ring)
   long long wave_operands = 0;    // distinct operands per pass of fhesi_ct_mul_sum_relin_dev (0 = about 4 GiB of rows)
+  int dot32_mfma = 0;       // 1: the dot product on the int8 matrix cores (experimental; metric shape only: rows of 2^14, ncol <= 96, <= 16 limbs)
   int dot32_half = 1;       // 1: dot32_kernel2<.., HALF>: tiles of 32 coefficients, two limbs per wave, two workgroups per CU (0: round 2's first form, one 135 KB workgroup per CU)
   int dot32_v3 = 0;         // 1: dot32_kernel3 (two limbs per wave, 4 ciphertexts per tile, two workgroups per CU)
   int automorph_rows = 0;   // 1: Ciphertext >>= through DoubleCRT::automorph on evaluation rows (the reference's structure) even where the coefficient gather applies
@@ -162,6 +163,9 @@ struct fhesi_ksk {
   // limb mode (kernels_ksaux.hip): the table is built from the key polynomial's INTEGER coefficients (toPoly over the chain) cut into
   // aux_rows limbs of aux_limb_bits bits instead of from its aux_rows = L chain-prime residues; 0 = residue mode
   int aux_rows = 0, aux_limb_bits = 0, aux_logQ = 0;
+  void* d_mfma = nullptr;              // (option dot32_mfma) the aux32 table as signed bytes in the int8 matrix-core operand layout + column sums (kernels_aux32.hip)
+  size_t mfma_bytes = 0;
+  bool mfma_valid = false;
   bool aux32 = false;                  // the table holds residues modulo the four 30-bit primes of kernels_aux32.hip (u32, 2^14-point rows)
   i64 aux_fold = 0;                    // q' when the rows are linear convolutions to be folded modulo X^q' + 1 and Phi_m (ctx->lin_q), else 0
   u64* d_limb_consts = nullptr;        // [W+1] offset constant D, [2] floor(2^(64(W-2)+128) / P), then the quotient bound's bit count
@@ -190,7 +194,7 @@ int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, in
 bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14 or 2^15, or a ring with lin_q set
 i64 aux32_row_len(const fhesi_ctx* ctx);            // 2^15 for n = 2^15, else 2^14
 static const i64 kAux32N = 1 << 14;                // row length of the 32-bit auxiliary transforms
-int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig /* [count*ncol][4][n] */, int ncol, i64 count, u32* d_out /* [count*2*rows][4][n] */);
+int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig /* [count*ncol][4][n] */, int ncol, i64 count, u32* d_out /* [count*2*rows][4][n] */, bool* mont /* out: the rows carry 2^-32 */);
 bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits);
 int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ);
 int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig /* [count*ncol][2][n] */, int ncol, i64 count, u64* d_out /* [count][2][L][2][n] */);

@@ -395,6 +395,7 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
 
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp) {
   FHESI_TRY(aux32_init(ctx));
+  k->mfma_valid = false;
   const int ncol = k->ncomp * k->ndigits;
   const i64 rows_per_a = (i64)NLB * 2 * ncol, nrow = aux32_row_len(ctx);
   u32* rows32 = (u32*)k->d_aux;
@@ -582,9 +583,182 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   HIP_TRY(hipGetLastError());
   return 0;
 }
-int launch_dot32(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
+// ---- (experimental, option dot32_mfma) the dot product on the int8 matrix cores.  For one coefficient position and prime the dot
+// product of a tile is a dense matrix product with reuse: C[ct][(limb, row)] = sum_k D[ct][k] K[k][(limb, row)].  Both 30-bit operands are
+// cut into four signed bytes (digits: byte - 128, the offset repaid by 128 x the key's column sums; key: balanced bytes, precomputed):
+// rows (byte plane i, ciphertext) = 32, one 32-column block per key byte plane j, depth 66 -> 96 = three v_mfma_i32_32x32x32_i8 per
+// block.  The 16 partial sums of an output are 16 accumulator registers of one lane (C[i][j]: lane j + 32 ((i / 4) mod 2), register
+// 4 (i / 8) + i mod 4), recombined as sum_d t_d (256^d mod p).  DESIGN.md section 8 (1); tools/mfma_dot_plan.py, tools/mfma_dot_tile.hip.
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+constexpr int MF_KS = 3, MF_E = 32 /* coefficients per workgroup */, MF_ESTRIDE = MF_KS * 64 * 16 + 16 /* bytes of a coefficient's A operands in LDS, padded */;
+__device__ __forceinline__ int mf_balanced_byte(u32 x, int j) {
+  int carry = 0, b = 0;
+  for (int jj = 0; jj <= j; ++jj) {
+    b = (int)((x >> (8 * jj)) & 255) + carry;
+    if (jj < 3 && b >= 128) { b -= 256; carry = 1; } else carry = 0;
+  }
+  return b;
+}
+// B table [a][coef][MF_KS][4 planes][64 lanes] x 16 bytes, then the column sums [a][coef][4][32] int
+__global__ void mfma_table_kernel(const u32* __restrict__ k32, int ncol, int NLB, int lognsl, i64 n, v4i_t* __restrict__ tb, int* __restrict__ ts) {
+  const i64 nB = (i64)4 * n * MF_KS * 4 * 64, nS = (i64)4 * n * 4 * 32;
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < nB + nS; g += (i64)gridDim.x * blockDim.x) {
+    if (g < nB) {
+      const int lane = (int)(g & 63), j = (int)((g >> 6) & 3);
+      const i64 q = g >> 8;
+      const int s = (int)(q % MF_KS);
+      const i64 ac = q / MF_KS, coef = ac % n;
+      const int a = (int)(ac / n), c = lane & 31, l = c >> 1, r = c & 1;
+      u32 w[4] = {0, 0, 0, 0};
+      for (int t = 0; t < 16; ++t) {
+        const int k = 32 * s + 16 * (lane >> 5) + t;
+        int b = 0;
+        if (k < ncol && l < NLB) b = mf_balanced_byte(k32[(((((((i64)a * NLB + l) << lognsl) + (coef >> 6)) * 2 + r) * ncol + k) << 6) + (coef & 63)], j);
+        w[t >> 2] |= (u32)(b & 255) << (8 * (t & 3));
+      }
+      tb[g] = v4i_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    } else {
+      const i64 h = g - nB;
+      const int c = (int)(h & 31), j = (int)((h >> 5) & 3), l = c >> 1, r = c & 1;
+      const i64 ac = h >> 7, coef = ac % n;
+      const int a = (int)(ac / n);
+      int sum = 0;
+      if (l < NLB)
+        for (int k = 0; k < ncol; ++k) sum += mf_balanced_byte(k32[(((((((i64)a * NLB + l) << lognsl) + (coef >> 6)) * 2 + r) * ncol + k) << 6) + (coef & 63)], j);
+      ts[h] = sum;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) dot_mfma_kernel(const v4i_t* __restrict__ tb, const int* __restrict__ ts, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
+                                                       u32* __restrict__ out, Aux32Primes pr, int lognsl, int sub_lg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
+  constexpr int CT = 8;
+  const u32 tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const u32 s_lo = blockIdx.x & 7, tile = blockIdx.x >> 3, s_hi = blockIdx.y >> 1, hf = blockIdx.y & 1;
+  const int a = (int)blockIdx.z;
+  const i64 slice = (i64)(s_hi * 8 + s_lo), n = (i64)64 << lognsl;
+  const int ct0 = (int)tile * CT;
+  const u32 p = pr.p[a], twop = 2 * p;
+  u32* o_lds = reinterpret_cast<u32*>(mf_lds + MF_E * MF_ESTRIDE);          // [CT][32 columns][33]
+  // ---- the digit tile: thread (ct = tid >> 5, e = tid & 31) takes the column quads one after the other, reduces the four words below p,
+  //      flips the top bit of every byte (byte - 128 as a signed byte) and writes the four byte planes as words of four consecutive columns
+  {
+    const int sub = ct0 >> sub_lg, sub_ct = 1 << sub_lg, ct_in = ct0 & (sub_ct - 1);
+    const i64 rest = count - ((i64)sub << sub_lg), cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
+    const u32* dbase = dig + ((i64)sub << sub_lg) * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + (i64)ct_in * ncol) * 64;
+    const u32 e = tid & 31, ct = tid >> 5;
+    const bool cok = ct0 + (int)ct < count;
+    const u32* src = dbase + (((i64)ct * ncol) << 6) + hf * 32 + e;
+    unsigned char* dst = mf_lds + e * MF_ESTRIDE;
+    const int nquad = (ncol + 3) >> 2;
+    for (int it = 0; it < nquad; ++it) {
+      u32 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 4 * it + u;
+        u32 t = (cok && k < ncol) ? src[(i64)k << 6] : 0u;
+        t = t >= twop ? t - twop : t; t = t >= p ? t - p : t;
+        x[u] = t ^ 0x80808080u;
+      }
+      const int s = it >> 3, half = (it >> 2) & 1, t0 = 4 * (it & 3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32 sel = (u32)i | ((u32)(4 + i) << 8) | 0x0c0c0000u;
+        const u32 lo16 = __builtin_amdgcn_perm(x[1], x[0], sel), hi16 = __builtin_amdgcn_perm(x[3], x[2], sel);
+        const u32 wd = __builtin_amdgcn_perm(hi16, lo16, 0x05040100u);
+        *reinterpret_cast<u32*>(dst + ((s * 64 + half * 32 + i * 8 + (int)ct) * 16) + t0) = wd;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- per wave: 8 of the 32 coefficients, 12 matrix-core instructions each, then the lane-local recombination
+  u32 wpow[7];
+  {
+    u64 w = 1;
+    for (int d = 0; d < 7; ++d) { wpow[d] = (u32)w; w = (w * 256) % p; }
+  }
+  const u32 mu61 = (u32)(((u64)1 << 61) / p);
+  const i64 off = (i64)p << 30;                               // a multiple of p above the magnitude of the signed sum
+  const int c = (int)(lane & 31), h = (int)(lane >> 5);
+  for (int ee = 0; ee < MF_E / 4; ++ee) {
+    const int e = wv * (MF_E / 4) + ee;
+    const i64 coef = slice * 64 + hf * 32 + e;
+    const v4i_t* bp = tb + (((i64)a * n + coef) * MF_KS * 4) * 64 + lane;
+    v16i_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0;
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+      const v4i_t av = *reinterpret_cast<const v4i_t*>(mf_lds + e * MF_ESTRIDE + (s * 64 + (int)lane) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bp[(s * 4 + j) * 64], acc[j], 0, 0, 0);
+    }
+    int sj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = 128 * ts[(((i64)a * n + coef) * 4 + j) * 32 + c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int t[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[i + j] += acc[j][4 * i + q] + sj[j];
+      i64 v = off;
+#pragma unroll
+      for (int d = 0; d < 7; ++d) v += (i64)t[d] * (i64)wpow[d];
+      const u32 qq = __umulhi((u32)((u64)v >> 29), mu61);
+      u32 r = (u32)v - qq * p;
+      r = r >= twop ? r - twop : r;
+      r = r >= p ? r - p : r;
+      o_lds[((4 * h + q) * 32 + c) * 33 + e] = r;
+    }
+  }
+  __syncthreads();
+  // ---- the rows: 32 consecutive coefficients of (ciphertext, limb, row) per instruction and half wave
+  {
+    const u32 e = tid & 31, ct = tid >> 5;
+    if (ct0 + (int)ct < count)
+      for (int cc = 0; cc < 2 * NLB; ++cc) {
+        const int l = cc >> 1, r = cc & 1;
+        out[((((((i64)(ct0 + (int)ct) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + slice * 64 + hf * 32 + e)] = o_lds[(ct * 32 + cc) * 33 + e];
+      }
+  }
+}
+static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
+  const i64 n = aux32_row_len(ctx);
+  const int lognsl = A32_LOGN - 6, NLB = k->aux_rows;
+  const size_t nB = (size_t)4 * n * MF_KS * 4 * 64 * 16, nS = (size_t)4 * n * 4 * 32 * 4;
+  if (!k->mfma_valid) {
+    if (k->d_mfma && k->mfma_bytes < nB + nS) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(k->d_mfma)); k->d_mfma = nullptr; }
+    if (!k->d_mfma) { HIP_TRY(hipMalloc(&k->d_mfma, nB + nS)); k->mfma_bytes = nB + nS; }
+    mfma_table_kernel<<<4096, 256, 0, ctx->stream>>>((const u32*)k->d_aux, ncol, NLB, lognsl, n, (v4i_t*)k->d_mfma, (int*)((char*)k->d_mfma + nB));
+    HIP_TRY(hipGetLastError());
+    k->mfma_valid = true;
+  }
+  const size_t shmem = (size_t)MF_E * MF_ESTRIDE + (size_t)8 * 32 * 33 * 4;
+  static unsigned long long attr_done = 0;
+  if (!(attr_done >> ctx->device & 1)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)dot_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done |= 1ull << ctx->device;
+  }
+  const int ntiles = (int)((count + 7) / 8);
+  int sub_lg = 0;
+  while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
+  PROF_KERNEL(ctx, PROF_DOT, dot_mfma_kernel);
+  dot_mfma_kernel<<<dim3((unsigned)(8 * ntiles), (unsigned)((n / 64 / 8) * 2), 4), 256, shmem, ctx->stream>>>((const v4i_t*)k->d_mfma, (const int*)((const char*)k->d_mfma + nB), d_dig, ncol, NLB, count, d_out,
+                                                                                                    ctx->aux32->pr, lognsl, sub_lg);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out, bool* mont) {
+  *mont = true;
   if (!count) return 0;
   ProfScope prof(ctx, PROF_DOT, (double)count);
+  if (ctx->opt.dot32_mfma && aux32_row_len(ctx) == A32_N && ncol <= 32 * MF_KS && k->aux_rows <= 16) { *mont = false; return launch_dot_mfma(ctx, k, d_dig, ncol, count, d_out); }
   if (ctx->opt.dot32_v3 && (size_t)ncol * 4 * 256 <= 80 * 1024) return launch_dot32_v3(ctx, k, d_dig, ncol, count, d_out);
   // ciphertexts per LDS tile: 8 while ncol * 8 digit slices fit (half slices of 128 bytes in 80 KiB, two workgroups per CU; whole slices
   // of 256 bytes in 160 KiB with option dot32_half = 0): ncol <= 80; else 4 (ncol <= 160)

@@ -284,8 +284,8 @@ def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 4242, count)
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     ref = ctx.ct_mul_relin(ksk, logQ, p, a, b)
-    # (dot32_v3 = 1 / dot32_half = 0: other tilings of the 30-bit dot product)
-    for opt, val in (("ks_aux60", 1), ("ks_residues", 1), ("ks_direct", 1), ("dot32_v3", 1), ("dot32_half", 0)):
+    # (dot32_v3 = 1 / dot32_half = 0: other tilings of the 30-bit dot product; dot32_mfma = 1: the same product on the int8 matrix cores)
+    for opt, val in (("ks_aux60", 1), ("ks_residues", 1), ("ks_direct", 1), ("dot32_v3", 1), ("dot32_half", 0), ("dot32_mfma", 1)):
         ctx.set_option(opt, val)
         ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)        # a fresh matrix: the derived table is built for the selected form
         assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), opt
