@@ -591,7 +591,7 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
 // 4 (i / 8) + i mod 4), recombined as sum_d t_d (256^d mod p).  DESIGN.md section 8 (1); tools/mfma_dot_plan.py, tools/mfma_dot_tile.hip.
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef int v4i_t __attribute__((ext_vector_type(4)));
-constexpr int MF_KS = 3, MF_E = 32 /* coefficients per workgroup */, MF_ESTRIDE = MF_KS * 64 * 16 + 16 /* bytes of a coefficient's A operands in LDS, padded */;
+constexpr int MF_KS = 3, MF_E = 16 /* coefficients per workgroup: 66 KB of LDS, two workgroups per CU */, MF_ESTRIDE = MF_KS * 64 * 16 + 16 /* bytes of a coefficient's A operands in LDS, padded */;
 __device__ __forceinline__ int mf_balanced_byte(u32 x, int j) {
   int carry = 0, b = 0;
   for (int jj = 0; jj <= j; ++jj) {
@@ -630,35 +630,44 @@ __global__ void mfma_table_kernel(const u32* __restrict__ k32, int ncol, int NLB
     }
   }
 }
-__global__ void __launch_bounds__(256) dot_mfma_kernel(const v4i_t* __restrict__ tb, const int* __restrict__ ts, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
+__global__ void __launch_bounds__(256, 2) dot_mfma_kernel(const v4i_t* __restrict__ tb, const int* __restrict__ ts, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
                                                        u32* __restrict__ out, Aux32Primes pr, int lognsl, int sub_lg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
   constexpr int CT = 8;
   const u32 tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const u32 s_lo = blockIdx.x & 7, tile = blockIdx.x >> 3, s_hi = blockIdx.y >> 1, hf = blockIdx.y & 1;
+  const u32 s_lo = blockIdx.x & 7, tile = blockIdx.x >> 3, s_hi = blockIdx.y >> 2, e0 = (blockIdx.y & 3) * MF_E;      // e0: first coefficient within the 64-slice
   const int a = (int)blockIdx.z;
   const i64 slice = (i64)(s_hi * 8 + s_lo), n = (i64)64 << lognsl;
   const int ct0 = (int)tile * CT;
   const u32 p = pr.p[a], twop = 2 * p;
-  u32* o_lds = reinterpret_cast<u32*>(mf_lds + MF_E * MF_ESTRIDE);          // [CT][32 columns][33]
+  u32* o_lds = reinterpret_cast<u32*>(mf_lds + MF_E * MF_ESTRIDE);          // [CT][32 columns][MF_E + 1]
   // ---- the digit tile: thread (ct = tid >> 5, e = tid & 31) takes the column quads one after the other, reduces the four words below p,
   //      flips the top bit of every byte (byte - 128 as a signed byte) and writes the four byte planes as words of four consecutive columns
   {
     const int sub = ct0 >> sub_lg, sub_ct = 1 << sub_lg, ct_in = ct0 & (sub_ct - 1);
     const i64 rest = count - ((i64)sub << sub_lg), cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
     const u32* dbase = dig + ((i64)sub << sub_lg) * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + (i64)ct_in * ncol) * 64;
-    const u32 e = tid & 31, ct = tid >> 5;
+    const u32 e = tid & (MF_E - 1), ct = (tid >> 4) & 7, qh = tid >> 7;       // the two halves of the workgroup take alternate column quads
     const bool cok = ct0 + (int)ct < count;
-    const u32* src = dbase + (((i64)ct * ncol) << 6) + hf * 32 + e;
+    const u32* src = dbase + (((i64)ct * ncol) << 6) + e0 + e;
     unsigned char* dst = mf_lds + e * MF_ESTRIDE;
-    const int nquad = (ncol + 3) >> 2;
-    for (int it = 0; it < nquad; ++it) {
+    // every word of the thread's ciphertext is requested before the first one is used (one memory latency per tile, not one per quad:
+    // with a single workgroup of four waves on the CU nothing else hides it)
+    constexpr int NQ = 4 * MF_KS;                            // 12 of the 24 column quads (96 columns) per thread
+    u32 xs[4 * NQ];
+#pragma unroll
+    for (int m = 0; m < NQ; ++m)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int k = 4 * (2 * m + (int)qh) + u; xs[4 * m + u] = (cok && k < ncol) ? __builtin_nontemporal_load(src + ((i64)k << 6)) : 0u; }
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) {
+      const int it = 2 * m + (int)qh;
+      if (4 * it >= ncol) break;
       u32 x[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int k = 4 * it + u;
-        u32 t = (cok && k < ncol) ? src[(i64)k << 6] : 0u;
+        u32 t = xs[4 * m + u];
         t = t >= twop ? t - twop : t; t = t >= p ? t - p : t;
         x[u] = t ^ 0x80808080u;
       }
@@ -682,10 +691,31 @@ __global__ void __launch_bounds__(256) dot_mfma_kernel(const v4i_t* __restrict__
   const u32 mu61 = (u32)(((u64)1 << 61) / p);
   const i64 off = (i64)p << 30;                               // a multiple of p above the magnitude of the signed sum
   const int c = (int)(lane & 31), h = (int)(lane >> 5);
+  // the key operands of coefficient ee + 1 are fetched while coefficient ee is multiplied and recombined (12 x 16 bytes per lane)
+  const i64 coef0 = slice * 64 + e0 + wv * (MF_E / 4);
+  const v4i_t* bp0 = tb + (((i64)a * n + coef0) * MF_KS * 4) * 64 + lane;
+  const int* sp0 = ts + (((i64)a * n + coef0) * 4) * 32 + c;
+  v4i_t bn[MF_KS * 4];
+  int sn[4];
+#pragma unroll
+  for (int u = 0; u < MF_KS * 4; ++u) bn[u] = bp0[u * 64];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sn[j] = sp0[j * 32];
+#pragma unroll 1
   for (int ee = 0; ee < MF_E / 4; ++ee) {
     const int e = wv * (MF_E / 4) + ee;
-    const i64 coef = slice * 64 + hf * 32 + e;
-    const v4i_t* bp = tb + (((i64)a * n + coef) * MF_KS * 4) * 64 + lane;
+    v4i_t bc[MF_KS * 4];
+    int sj[4];
+#pragma unroll
+    for (int u = 0; u < MF_KS * 4; ++u) bc[u] = bn[u];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sj[j] = 128 * sn[j];
+    if (ee + 1 < MF_E / 4) {
+#pragma unroll
+      for (int u = 0; u < MF_KS * 4; ++u) bn[u] = bp0[((i64)(ee + 1) * MF_KS * 4 + u) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sn[j] = sp0[((ee + 1) * 4 + j) * 32];
+    }
     v16i_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -695,18 +725,22 @@ __global__ void __launch_bounds__(256) dot_mfma_kernel(const v4i_t* __restrict__
     for (int s = 0; s < MF_KS; ++s) {
       const v4i_t av = *reinterpret_cast<const v4i_t*>(mf_lds + e * MF_ESTRIDE + (s * 64 + (int)lane) * 16);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bp[(s * 4 + j) * 64], acc[j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc[s * 4 + j], acc[j], 0, 0, 0);
     }
-    int sj[4];
+    int cd[7] = {0, 0, 0, 0, 0, 0, 0};                    // the offset term of every diagonal i + j, the same for the four ciphertexts of the lane
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sj[j] = 128 * ts[(((i64)a * n + coef) * 4 + j) * 32 + c];
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cd[i + j] += sj[j];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      int t[7] = {0, 0, 0, 0, 0, 0, 0};
+      int t[7];
+#pragma unroll
+      for (int d = 0; d < 7; ++d) t[d] = cd[d];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[i + j] += acc[j][4 * i + q] + sj[j];
+        for (int j = 0; j < 4; ++j) t[i + j] += acc[j][4 * i + q];
       i64 v = off;
 #pragma unroll
       for (int d = 0; d < 7; ++d) v += (i64)t[d] * (i64)wpow[d];
@@ -714,18 +748,16 @@ __global__ void __launch_bounds__(256) dot_mfma_kernel(const v4i_t* __restrict__
       u32 r = (u32)v - qq * p;
       r = r >= twop ? r - twop : r;
       r = r >= p ? r - p : r;
-      o_lds[((4 * h + q) * 32 + c) * 33 + e] = r;
+      o_lds[((4 * h + q) * 32 + c) * (MF_E + 1) + e] = r;
     }
   }
   __syncthreads();
   // ---- the rows: 32 consecutive coefficients of (ciphertext, limb, row) per instruction and half wave
   {
-    const u32 e = tid & 31, ct = tid >> 5;
+    const u32 e = tid & (MF_E - 1), ct = (tid >> 4) & 7, r = tid >> 7;       // the two halves of the workgroup write the two key rows
     if (ct0 + (int)ct < count)
-      for (int cc = 0; cc < 2 * NLB; ++cc) {
-        const int l = cc >> 1, r = cc & 1;
-        out[((((((i64)(ct0 + (int)ct) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + slice * 64 + hf * 32 + e)] = o_lds[(ct * 32 + cc) * 33 + e];
-      }
+      for (int l = 0; l < NLB; ++l)
+        __builtin_nontemporal_store(o_lds[(ct * 32 + 2 * l + r) * (MF_E + 1) + e], &out[((((((i64)(ct0 + (int)ct) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + slice * 64 + e0 + e)]);
   }
 }
 static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
@@ -739,7 +771,7 @@ static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int n
     HIP_TRY(hipGetLastError());
     k->mfma_valid = true;
   }
-  const size_t shmem = (size_t)MF_E * MF_ESTRIDE + (size_t)8 * 32 * 33 * 4;
+  const size_t shmem = (size_t)MF_E * MF_ESTRIDE + (size_t)8 * 32 * (MF_E + 1) * 4;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> ctx->device & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)dot_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -749,7 +781,7 @@ static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int n
   int sub_lg = 0;
   while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
   PROF_KERNEL(ctx, PROF_DOT, dot_mfma_kernel);
-  dot_mfma_kernel<<<dim3((unsigned)(8 * ntiles), (unsigned)((n / 64 / 8) * 2), 4), 256, shmem, ctx->stream>>>((const v4i_t*)k->d_mfma, (const int*)((const char*)k->d_mfma + nB), d_dig, ncol, NLB, count, d_out,
+  dot_mfma_kernel<<<dim3((unsigned)(8 * ntiles), (unsigned)((n / 64 / 8) * (64 / MF_E)), 4), 256, shmem, ctx->stream>>>((const v4i_t*)k->d_mfma, (const int*)((const char*)k->d_mfma + nB), d_dig, ncol, NLB, count, d_out,
                                                                                                     ctx->aux32->pr, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
