@@ -630,10 +630,13 @@ __global__ void mfma_table_kernel(const u32* __restrict__ k32, int ncol, int NLB
     }
   }
 }
-__global__ void __launch_bounds__(256, 2) dot_mfma_kernel(const v4i_t* __restrict__ tb, const int* __restrict__ ts, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                       u32* __restrict__ out, Aux32Primes pr, int lognsl, int sub_lg) {
+struct MfConst { u32 wpow[4][7] /* 256^d mod p */, mu61[4] /* floor(2^61 / p) */; };     // (computed on the host: a 64-bit remainder costs a wave ~100 instructions)
+// G: groups of 8 ciphertexts per tile -- every key operand fetched from L2 feeds G matrix instructions
+template <int G>
+__global__ void __launch_bounds__(256, G == 1 ? 2 : 1) dot_mfma_kernel(const v4i_t* __restrict__ tb, const int* __restrict__ ts, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
+                                                       u32* __restrict__ out, Aux32Primes pr, MfConst mc, int lognsl, int sub_lg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
-  constexpr int CT = 8;
+  constexpr int CT = 8 * G, QH = 256 / (MF_E * CT);        // QH: threads per (ciphertext, coefficient)
   const u32 tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const u32 s_lo = blockIdx.x & 7, tile = blockIdx.x >> 3, s_hi = blockIdx.y >> 2, e0 = (blockIdx.y & 3) * MF_E;      // e0: first coefficient within the 64-slice
@@ -641,28 +644,28 @@ __global__ void __launch_bounds__(256, 2) dot_mfma_kernel(const v4i_t* __restric
   const i64 slice = (i64)(s_hi * 8 + s_lo), n = (i64)64 << lognsl;
   const int ct0 = (int)tile * CT;
   const u32 p = pr.p[a], twop = 2 * p;
-  u32* o_lds = reinterpret_cast<u32*>(mf_lds + MF_E * MF_ESTRIDE);          // [CT][32 columns][MF_E + 1]
+  u32* o_lds = reinterpret_cast<u32*>(mf_lds + G * MF_E * MF_ESTRIDE);          // [CT][32 columns][MF_E + 1]
   // ---- the digit tile: thread (ct = tid >> 5, e = tid & 31) takes the column quads one after the other, reduces the four words below p,
   //      flips the top bit of every byte (byte - 128 as a signed byte) and writes the four byte planes as words of four consecutive columns
   {
     const int sub = ct0 >> sub_lg, sub_ct = 1 << sub_lg, ct_in = ct0 & (sub_ct - 1);
     const i64 rest = count - ((i64)sub << sub_lg), cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
     const u32* dbase = dig + ((i64)sub << sub_lg) * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + (i64)ct_in * ncol) * 64;
-    const u32 e = tid & (MF_E - 1), ct = (tid >> 4) & 7, qh = tid >> 7;       // the two halves of the workgroup take alternate column quads
+    const u32 e = tid & (MF_E - 1), ct = (tid >> 4) % CT, qh = tid / (MF_E * CT);       // (G = 1: the two halves of the workgroup take alternate column quads)
     const bool cok = ct0 + (int)ct < count;
     const u32* src = dbase + (((i64)ct * ncol) << 6) + e0 + e;
-    unsigned char* dst = mf_lds + e * MF_ESTRIDE;
+    unsigned char* dst = mf_lds + ((ct >> 3) * MF_E + e) * MF_ESTRIDE;
     // every word of the thread's ciphertext is requested before the first one is used (one memory latency per tile, not one per quad:
     // with a single workgroup of four waves on the CU nothing else hides it)
-    constexpr int NQ = 4 * MF_KS;                            // 12 of the 24 column quads (96 columns) per thread
+    constexpr int NQ = 8 * MF_KS / QH;                       // the thread's share of the 24 column quads (96 columns)
     u32 xs[4 * NQ];
 #pragma unroll
     for (int m = 0; m < NQ; ++m)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int k = 4 * (2 * m + (int)qh) + u; xs[4 * m + u] = (cok && k < ncol) ? __builtin_nontemporal_load(src + ((i64)k << 6)) : 0u; }
+      for (int u = 0; u < 4; ++u) { const int k = 4 * (QH * m + (int)qh) + u; xs[4 * m + u] = (cok && k < ncol) ? __builtin_nontemporal_load(src + ((i64)k << 6)) : 0u; }
 #pragma unroll
     for (int m = 0; m < NQ; ++m) {
-      const int it = 2 * m + (int)qh;
+      const int it = QH * m + (int)qh;
       if (4 * it >= ncol) break;
       u32 x[4];
 #pragma unroll
@@ -677,18 +680,16 @@ __global__ void __launch_bounds__(256, 2) dot_mfma_kernel(const v4i_t* __restric
         const u32 sel = (u32)i | ((u32)(4 + i) << 8) | 0x0c0c0000u;
         const u32 lo16 = __builtin_amdgcn_perm(x[1], x[0], sel), hi16 = __builtin_amdgcn_perm(x[3], x[2], sel);
         const u32 wd = __builtin_amdgcn_perm(hi16, lo16, 0x05040100u);
-        *reinterpret_cast<u32*>(dst + ((s * 64 + half * 32 + i * 8 + (int)ct) * 16) + t0) = wd;
+        *reinterpret_cast<u32*>(dst + ((s * 64 + half * 32 + i * 8 + (int)(ct & 7)) * 16) + t0) = wd;
       }
     }
   }
   __syncthreads();
   // ---- per wave: 8 of the 32 coefficients, 12 matrix-core instructions each, then the lane-local recombination
   u32 wpow[7];
-  {
-    u64 w = 1;
-    for (int d = 0; d < 7; ++d) { wpow[d] = (u32)w; w = (w * 256) % p; }
-  }
-  const u32 mu61 = (u32)(((u64)1 << 61) / p);
+#pragma unroll
+  for (int d = 0; d < 7; ++d) wpow[d] = mc.wpow[a][d];
+  const u32 mu61 = mc.mu61[a];
   const i64 off = (i64)p << 30;                               // a multiple of p above the magnitude of the signed sum
   const int c = (int)(lane & 31), h = (int)(lane >> 5);
   // the key operands of coefficient ee + 1 are fetched while coefficient ee is multiplied and recombined (12 x 16 bytes per lane)
@@ -716,16 +717,22 @@ __global__ void __launch_bounds__(256, 2) dot_mfma_kernel(const v4i_t* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) sn[j] = sp0[((ee + 1) * 4 + j) * 32];
     }
-    v16i_t acc[4];
+    v16i_t acc[G][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0;
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][j][r] = 0;
 #pragma unroll
     for (int s = 0; s < MF_KS; ++s) {
-      const v4i_t av = *reinterpret_cast<const v4i_t*>(mf_lds + e * MF_ESTRIDE + (s * 64 + (int)lane) * 16);
+      v4i_t av[G];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc[s * 4 + j], acc[j], 0, 0, 0);
+      for (int g = 0; g < G; ++g) av[g] = *reinterpret_cast<const v4i_t*>(mf_lds + (g * MF_E + e) * MF_ESTRIDE + (s * 64 + (int)lane) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[g], bc[s * 4 + j], acc[g][j], 0, 0, 0);
     }
     int cd[7] = {0, 0, 0, 0, 0, 0, 0};                    // the offset term of every diagonal i + j, the same for the four ciphertexts of the lane
 #pragma unroll
@@ -733,14 +740,15 @@ __global__ void __launch_bounds__(256, 2) dot_mfma_kernel(const v4i_t* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) cd[i + j] += sj[j];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int gq = 0; gq < 4 * G; ++gq) {
+      const int g = gq >> 2, q = gq & 3;
       int t[7];
 #pragma unroll
       for (int d = 0; d < 7; ++d) t[d] = cd[d];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[i + j] += acc[j][4 * i + q];
+        for (int j = 0; j < 4; ++j) t[i + j] += acc[g][j][4 * i + q];
       i64 v = off;
 #pragma unroll
       for (int d = 0; d < 7; ++d) v += (i64)t[d] * (i64)wpow[d];
@@ -748,18 +756,20 @@ __global__ void __launch_bounds__(256, 2) dot_mfma_kernel(const v4i_t* __restric
       u32 r = (u32)v - qq * p;
       r = r >= twop ? r - twop : r;
       r = r >= p ? r - p : r;
-      o_lds[((4 * h + q) * 32 + c) * (MF_E + 1) + e] = r;
+      o_lds[((8 * g + 4 * h + q) * 32 + c) * (MF_E + 1) + e] = r;
     }
   }
   __syncthreads();
   // ---- the rows: 32 consecutive coefficients of (ciphertext, limb, row) per instruction and half wave
   {
-    const u32 e = tid & (MF_E - 1), ct = (tid >> 4) & 7, r = tid >> 7;       // the two halves of the workgroup write the two key rows
+    const u32 e = tid & (MF_E - 1), ct = (tid >> 4) % CT, r0 = tid / (MF_E * CT);       // (G = 1: the two halves of the workgroup write the two key rows)
     if (ct0 + (int)ct < count)
+      for (u32 r = r0; r < 2; r += QH)
       for (int l = 0; l < NLB; ++l)
         __builtin_nontemporal_store(o_lds[(ct * 32 + 2 * l + r) * (MF_E + 1) + e], &out[((((((i64)(ct0 + (int)ct) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + slice * 64 + e0 + e)]);
   }
 }
+template <int G>
 static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const i64 n = aux32_row_len(ctx);
   const int lognsl = A32_LOGN - 6, NLB = k->aux_rows;
@@ -771,18 +781,25 @@ static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int n
     HIP_TRY(hipGetLastError());
     k->mfma_valid = true;
   }
-  const size_t shmem = (size_t)MF_E * MF_ESTRIDE + (size_t)8 * 32 * (MF_E + 1) * 4;
+  const size_t shmem = (size_t)G * MF_E * MF_ESTRIDE + (size_t)8 * G * 32 * (MF_E + 1) * 4;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot_mfma_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done |= 1ull << ctx->device;
   }
-  const int ntiles = (int)((count + 7) / 8);
+  const int ntiles = (int)((count + 8 * G - 1) / (8 * G));
   int sub_lg = 0;
   while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
-  PROF_KERNEL(ctx, PROF_DOT, dot_mfma_kernel);
-  dot_mfma_kernel<<<dim3((unsigned)(8 * ntiles), (unsigned)((n / 64 / 8) * (64 / MF_E)), 4), 256, shmem, ctx->stream>>>((const v4i_t*)k->d_mfma, (const int*)((const char*)k->d_mfma + nB), d_dig, ncol, NLB, count, d_out,
-                                                                                                    ctx->aux32->pr, lognsl, sub_lg);
+  MfConst mc;
+  for (int a = 0; a < 4; ++a) {
+    const u64 p = ctx->aux32->pr.p[a];
+    u64 w = 1;
+    for (int d = 0; d < 7; ++d) { mc.wpow[a][d] = (u32)w; w = (w * 256) % p; }
+    mc.mu61[a] = (u32)(((u64)1 << 61) / p);
+  }
+  PROF_KERNEL(ctx, PROF_DOT, dot_mfma_kernel<G>);
+  dot_mfma_kernel<G><<<dim3((unsigned)(8 * ntiles), (unsigned)((n / 64 / 8) * (64 / MF_E)), 4), 256, shmem, ctx->stream>>>((const v4i_t*)k->d_mfma, (const int*)((const char*)k->d_mfma + nB), d_dig, ncol, NLB, count, d_out,
+                                                                                                    ctx->aux32->pr, mc, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -790,7 +807,7 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   *mont = true;
   if (!count) return 0;
   ProfScope prof(ctx, PROF_DOT, (double)count);
-  if (ctx->opt.dot32_mfma && aux32_row_len(ctx) == A32_N && ncol <= 32 * MF_KS && k->aux_rows <= 16) { *mont = false; return launch_dot_mfma(ctx, k, d_dig, ncol, count, d_out); }
+  if (ctx->opt.dot32_mfma && aux32_row_len(ctx) == A32_N && ncol <= 32 * MF_KS && k->aux_rows <= 16) { *mont = false; return ctx->opt.dot32_mfma == 2 ? launch_dot_mfma<2>(ctx, k, d_dig, ncol, count, d_out) : launch_dot_mfma<1>(ctx, k, d_dig, ncol, count, d_out); }
   if (ctx->opt.dot32_v3 && (size_t)ncol * 4 * 256 <= 80 * 1024) return launch_dot32_v3(ctx, k, d_dig, ncol, count, d_out);
   // ciphertexts per LDS tile: 8 while ncol * 8 digit slices fit (half slices of 128 bytes in 80 KiB, two workgroups per CU; whole slices
   // of 256 bytes in 160 KiB with option dot32_half = 0): ncol <= 80; else 4 (ncol <= 160)

@@ -285,11 +285,11 @@ def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     ref = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     # (dot32_v3 = 1 / dot32_half = 0: other tilings of the 30-bit dot product; dot32_mfma = 1: the same product on the int8 matrix cores)
-    for opt, val in (("ks_aux60", 1), ("ks_residues", 1), ("ks_direct", 1), ("dot32_v3", 1), ("dot32_half", 0), ("dot32_mfma", 1)):
+    for opt, val in (("ks_aux60", 1), ("ks_residues", 1), ("ks_direct", 1), ("dot32_v3", 1), ("dot32_half", 0), ("dot32_mfma", 1), ("dot32_mfma", 2)):
         ctx.set_option(opt, val)
         ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)        # a fresh matrix: the derived table is built for the selected form
         assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), opt
-        ctx.set_option(opt, 1 - val)
+        ctx.set_option(opt, 1 if opt == "dot32_half" else 0)
     assert np.array_equal(ref[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
 
 
