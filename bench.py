@@ -315,7 +315,8 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
             "dtype": "u32 rows (tensor products and key switch over primes below 2^30), u64 coefficient limbs" if kname.startswith("ntt32_") else "u64", "data": "synthetic",
             "config": {"workload": (f"configs[3] replay: Regression::Regress d={d}, {N} data block(s), m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3" if M_RING == 1 << 15 else
                                     f"configs[3]: Regression::Regress d={d}, {N} data block(s) of phi(m) slots on the reference's Test_Regression ring m={M_RING} (p={P_PLAIN}), fhe-si logQ={LOGQ}, decompSize=3"),
-                       "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "automorphism_keys": len(ks), "waves": stats["waves"],
+                       "L": L, "chain_bits": round(chain_bits, 1), "sp_nbits": args.sp_nbits, "ndigits": nd,
+                       "key_switch_form": {"form": F.KeySwitchMatrix.FORMS.get(ks_form, str(ks_form)), "rows": ks_rows, "limb_bits": ks_limb_bits}, "automorphism_keys": len(ks), "waves": stats["waves"],
                        "products_per_regress": stats["products"], "key_switches_per_regress": stats["key_switches"],
                        "automorph_key_switches_per_regress": stats["automorph_key_switches"], "regress_per_s": round(args.steps / dt, 3),
                        "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if world > 1 else "single GPU"},
@@ -450,6 +451,10 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="library option (fhesi_ctx_set_option), e.g. ks_direct=1, tensor32=0")
+    ap.add_argument("--sp-nbits", type=int, default=SP_NBITS, help="where the prime chain starts (FHEContext.cpp:92: 2^NTL_SP_NBITS): 60 = today's NTL (default, the contract "
+                    "line), 50 = the NTL 5.x / 6.x of the reference's era (22 primes instead of 18 at the metric ring)")
+    ap.add_argument("--gpu-seconds", type=float, default=5.0, help="metric / stress workloads: the block of exactly --steps timed steps is repeated until the GPU phase has "
+                    "lasted about this long (every block bracketed like the first; `value` is the MEDIAN block, all blocks are listed); 0 = one block")
     args = ap.parse_args()
 
     global M_RING, LOGQ, P_PLAIN
@@ -490,7 +495,7 @@ def main():
         return
 
     n = sum(1 for k in range(1, M_RING) if math.gcd(k, M_RING) == 1) if M_RING & (M_RING - 1) else M_RING // 2       # phi(m)
-    primes = prime_chain(M_RING, LOGQ, P_PLAIN, n)
+    primes = prime_chain(M_RING, LOGQ, P_PLAIN, n, 1, args.sp_nbits)
     roots = [root_2m(q, M_RING) for q in primes]
     L = len(primes)
     nd = (LOGQ + 8 * DECOMP - 1) // (8 * DECOMP)
@@ -508,10 +513,15 @@ def main():
     ksm_host = None
     if rank == 0:
         ksm_host = rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n)
+    bcast_s = None
     if world > 1:
         from fhe_si_amd import shard
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.perf_counter()
         stage = shard.broadcast_key_matrix(ksm_host, ksk.nbytes, dist, device=f"cuda:{local_rank}")   # one RCCL broadcast
         torch.cuda.synchronize()
+        bcast_s = round(time.perf_counter() - tb, 4)           # (includes rank 0's host -> device staging of the matrix)
         ksk.upload_dev(stage.data_ptr())
         del stage
     else:
@@ -551,7 +561,14 @@ def main():
     if dist:
         dist.barrier()
     ctx.prof_enable(True)
-    with SclkSampler(local_rank) as sclk:
+
+    tdev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+
+    def timed_block():
+        """exactly --steps steps between barrier + synchronize on both sides; the maximum over the ranks"""
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -559,11 +576,33 @@ def main():
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
-        dt = time.perf_counter() - t0
+        d = time.perf_counter() - t0
+        own = d
+        if dist:
+            tt = torch.tensor([d], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d, own
+
+    t_phase = time.perf_counter()
+    with SclkSampler(local_rank) as sclk:
+        block_dt, own_dt = [], []
+        d, own = timed_block()
+        block_dt.append(d); own_dt.append(own)
+        # the same number of blocks on every rank: decided from the (all-reduced) first block
+        nblocks = max(1, min(64, int(math.ceil(args.gpu_seconds / max(d, 1e-6))))) if args.gpu_seconds > 0 else 1
+        for _ in range(nblocks - 1):
+            d, own = timed_block()
+            block_dt.append(d); own_dt.append(own)
+    gpu_phase_s = time.perf_counter() - t_phase
+    dt = sorted(block_dt)[(len(block_dt) - 1) // 2]          # the median block (lower median for an even count)
+    per_rank = None
     if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([B * args.steps / sorted(own_dt)[(len(own_dt) - 1) // 2]], dtype=torch.float64, device=tdev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = [round(float(v.item()), 1) for v in allv]
+    nblk = len(block_dt)
 
     # live per-kernel timing of the timed region (HIP events on the context's stream); kernel names as the library launched them
     prof = {k: ctx.prof_read(k) for k in F.binding.PROF_CLASSES}
@@ -603,7 +642,7 @@ def main():
     if args.workload == "metric" and not args.ntt_rows and launches:
         traffic, traffic_src = offline_traffic("pmc_ntt_fwd.json", kname, "rows_per_launch", round(rows / launches))
     roofline_ntt = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_measured": False,
                     "achieved_on_traffic": round(traffic * launches / (ms * 1e-3) / 1e9, 1) if traffic and ms > 0 else None,
                     "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
                     "rows_per_launch": round(rows / launches, 1) if launches else None, "row_bytes": row_bytes // 2,
@@ -616,7 +655,7 @@ def main():
         t_ach = t_rows * 2 * n * 4 / (t_ms * 1e-3) / 1e9
         ttr, ttr_src = offline_traffic("pmc_t32_fwd.json", names["ntt_fwd"], "rows_per_launch", round(t_rows / t_l)) if args.workload == "metric" else (None, None)
         roofline_ntt_tensor = {"bound": "hbm", "kernel": names["ntt_fwd"], "achieved": round(t_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(t_ach / HBM_PEAK_GBS, 4), "traffic": ttr, "traffic_source": ttr_src, "launches": t_l,
+                               "frac": round(t_ach / HBM_PEAK_GBS, 4), "traffic": ttr, "traffic_source": ttr_src, "traffic_measured": False, "launches": t_l,
                                "avg_launch_ms": round(t_ms / t_l, 4), "rows_per_launch": round(t_rows / t_l, 1), "row_bytes": n * 4,
                                "row_ntts_per_s": round(t_rows / (t_ms * 1e-3), 1)}
     # The dominant kernel of the pipeline is the key-switch dot product through the auxiliary primes (kernels_ksaux.hip / kernels_aux32.hip):
@@ -627,7 +666,8 @@ def main():
     dl, dunits, dms = prof["dot"]
     # output rows per (ciphertext, key row, auxiliary prime): the limbs of the key's integer coefficients where the library runs the
     # key switch in limb mode (15 at the metric chain shape, 30 at the stress shape), the L residues otherwise
-    R = L if ctx.get_option("ks_residues") else {(18, 512): 15, (35, 1024): 30}.get((L, LOGQ), L)
+    ks_form, ks_rows, ks_limb_bits = ksk.form()       # which exact form of the dot product ran, and its rows (limbs or residues) per key coefficient
+    R = ks_rows if ks_rows > 0 else L
     if aux:
         dbytes = (dunits * (ncol * 2 + 2 * R * 2) + dl * (2 * R * 2 * ncol)) * n * 8
     else:
@@ -637,7 +677,7 @@ def main():
     if aux and args.workload == "metric" and dl:
         dtraffic, dtraffic_src = offline_traffic("pmc_dot_aux.json", dname, "ciphertexts_per_launch", round(dunits / dl))
     roofline_dot = {"bound": "hbm", "kernel": dname, "achieved": round(dach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": dtraffic, "traffic_source": dtraffic_src, "launches": dl,
+                    "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": dtraffic, "traffic_source": dtraffic_src, "traffic_measured": False, "launches": dl,
                     "avg_launch_ms": round(dms / dl, 4) if dl else None, "ciphertexts_per_launch": round(dunits / dl, 1) if dl else None,
                     "ms_per_64_ciphertexts": round(dms / dunits * 64, 4) if dunits else None,
                     "note": "integer multiply-accumulate bound by the LDS pipe and the VALU (the key slices are re-read from L2), not by HBM; its algorithmic bytes per "
@@ -650,7 +690,7 @@ def main():
     if rank == 0:
         total_mults = B * args.steps * world
         value = total_mults / dt
-        breakdown = {k: round(v[2] / args.steps, 3) for k, v in prof.items() if v[0] and k != "ntt_fwd_digits_main"}
+        breakdown = {k: round(v[2] / (args.steps * nblk), 3) for k, v in prof.items() if v[0] and k != "ntt_fwd_digits_main"}
         cpu, matches = None, None
         if args.cpu_sample > 0 and world == 1:       # CPU baseline on rank 0 at N=1 only; its outputs check the timed buffer
             ns = min(args.cpu_sample, uniq)
@@ -671,8 +711,10 @@ def main():
             "data": f"synthetic ({uniq} distinct uniform ciphertext pairs per GPU repeated to the batch, uniform key rows)",
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
                        if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
-                       "L": L, "chain_bits": round(chain_bits, 1), "ndigits": nd, "batch_per_gpu": B, "options": {k: ctx.get_option(k) for k in ("lanes", "ks_direct", "ks_residues", "ks_aux60", "tensor32", "batch_chunk")},
-                       "timed_region_s": round(dt, 3),
+                       "L": L, "chain_bits": round(chain_bits, 1), "sp_nbits": args.sp_nbits, "ndigits": nd,
+                       "key_switch_form": {"form": F.KeySwitchMatrix.FORMS.get(ks_form, str(ks_form)), "rows": ks_rows, "limb_bits": ks_limb_bits}, "batch_per_gpu": B, "options": {k: ctx.get_option(k) for k in ("lanes", "ks_direct", "ks_residues", "ks_aux60", "tensor32", "batch_chunk")},
+                       "timed_region_s": round(dt, 3), "blocks": nblk, "block_values": [round(B * args.steps * world / d, 1) for d in block_dt],
+                       "gpu_phase_s": round(gpu_phase_s, 3), "per_rank_value": per_rank, "key_broadcast_s": bcast_s,
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
             "matches_oracle": matches,
             "sclk_mhz_observed": sclk.summary(),

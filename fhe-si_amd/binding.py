@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
     "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_comm_init_all", "fhesi_comm_from_rccl", "fhesi_comm_destroy", "fhesi_comm_rank",
     "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
+    "fhesi_ksk_form",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -157,6 +158,7 @@ def _load():
         "fhesi_dcrt_add_primes_and_scale": [_vp, _vp, _i32, _u64, _vp],
         "fhesi_dcrt_scale_down_to_set": [_vp, _vp, _i32, _u64],
         "fhesi_ksk_upload_dev": [_vp, _vp],
+        "fhesi_ksk_form": [_vp, _vp, _vp, _vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -673,6 +675,14 @@ class KeySwitchMatrix:
         hs = (_vp * len(src))(*[d.h for d in src])
         _ck(_load().fhesi_keyswitch_init_batch(self.h, hs, len(src), dst_t.h, logQ, decomp_bytes, _p(a), a.shape[-1], _p(err)))
         return self
+
+    FORMS = {-1: "none yet", 0: "per chain prime", 1: "four 30-bit auxiliary primes, limbs", 2: "two largest chain primes, limbs", 3: "two largest chain primes, residues"}
+
+    def form(self):
+        """(form, rows, limb_bits) of the last key switch with this matrix (fhesi_ksk_form): which exact form of the dot product ran."""
+        f, r, b = C.c_int32(), C.c_int32(), C.c_int32()
+        _ck(_load().fhesi_ksk_form(self.h, C.byref(f), C.byref(r), C.byref(b)))
+        return f.value, r.value, b.value
 
     def mark_dirty(self):
         """The rows were written through device_ptr (e.g. by a collective): derived tables are rebuilt at the next key switch."""

@@ -18,7 +18,17 @@ int ws_reserve(fhesi_ctx* ctx, int slot, size_t bytes, void** out) {
   if (ctx->ws_bytes[slot] < bytes) {
     if (ctx->ws[slot]) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->ws[slot])); ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0; }
     size_t want = bytes + (bytes >> 3) + 4096;
-    HIP_TRY(hipMalloc(&ctx->ws[slot], want));
+    if (hipMalloc(&ctx->ws[slot], want) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->ws[slot] = nullptr;
+      if (hipMalloc(&ctx->ws[slot], bytes) != hipSuccess) {      // (without the growth margin)
+        (void)hipGetLastError();
+        ctx->ws[slot] = nullptr;
+        ctx->ws_oom = true;                                       // callers that can work in smaller chunks look at this
+        FHESI_FAIL("workspace slot %d: hipMalloc of %zu bytes failed", slot, bytes);
+      }
+      want = bytes;
+    }
     ctx->ws_bytes[slot] = want;
   }
   *out = ctx->ws[slot];
@@ -1145,9 +1155,16 @@ extern "C" int fhesi_ksk_upload_dev(fhesi_ksk* k, const uint64_t* rows_dev) {
   return 0;
 }
 extern "C" size_t fhesi_ksk_bytes(const fhesi_ksk* k) { return k ? k->bytes : 0; }
+extern "C" int fhesi_ksk_form(const fhesi_ksk* k, int32_t* form, int32_t* rows, int32_t* limb_bits) {
+  if (!k) FHESI_FAIL("null key-switch matrix");
+  if (form) *form = k->last_form;
+  if (rows) *rows = k->last_form > 0 ? k->aux_rows : (k->last_form == 0 ? k->ctx->L : 0);
+  if (limb_bits) *limb_bits = k->last_form > 0 ? k->aux_limb_bits : 0;
+  return 0;
+}
 
 // --------------------------------------------------------------------------------------------- ciphertext pipeline
-static i64 batch_chunk(const fhesi_ctx* c, int ncol);
+static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32);
 static std::vector<int> full_set(const fhesi_ctx* c) { std::vector<int> v(c->L); for (int i = 0; i < c->L; ++i) v[i] = i; return v; }
 
 extern "C" int fhesi_ct_mul_dev(fhesi_ctx* c, uint64_t p, const uint64_t* a, const uint64_t* b, int32_t nlimbs, int64_t count, uint64_t* tprod) {
@@ -1171,7 +1188,8 @@ extern "C" int fhesi_ct_mul_dev(fhesi_ctx* c, uint64_t p, const uint64_t* a, con
 }
 
 // ByteDecomp + DoubleCRT(digit polys) + DotProduct + toPoly + ReduceCoefficients (FHE-SI.cpp:244-256) from parts that are already
-// positive residues mod 2^logQ in limb-major layout [count*ncomp][nlq][n].  d_t: scratch for count*2 DoubleCRTs.
+// positive residues mod 2^logQ in limb-major layout [count*ncomp][nlq][n].  d_t: scratch for count*2 DoubleCRTs, needed by the per-prime
+// and the residue forms only (null: reserved here, workspace slot 1, when one of those runs -- the limb forms never touch it).
 static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, const u64* d_parts, int64_t count, u64* d_t,
                            uint64_t* out, int32_t nlimbs) {
   const i64 n = c->phim;
@@ -1181,9 +1199,11 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
   FHESI_TRY(get_crt_tables(c, all, &t));
   // Dot product through the two largest chain primes (kernels_ksaux.hip): 2 transforms per digit polynomial instead of L.
   // option ks_direct keeps the per-prime dot product below (A/B measurements; also the path of every shape the other does not cover).
-  if (ksaux_supported(c, ncol, 8 * decomp_bytes) && !c->opt.ks_direct) {
+  const int ks_mode = ksaux_mode(c, t, ncol, 8 * decomp_bytes, logQ);
+  const_cast<fhesi_ksk*>(k)->last_form = ks_mode;
+  if (ks_mode != KS_MODE_DIRECT) {
     fhesi_ksk* km = const_cast<fhesi_ksk*>(k);
-    if (!k->aux_valid || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ));
+    if (!k->aux_valid || k->aux_mode != ks_mode || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ, ks_mode));
     const int R = k->aux_rows;        // L chain-prime residues, or the limbs of the key's integer coefficients (limb mode)
     const i64 nrow = k->aux32 ? aux32_row_len(c) : n;      // the 32-bit auxiliary rows always have 2^14 elements (four 4-byte residues = two 8-byte ones)
     void *d_dig, *d_o;
@@ -1202,10 +1222,12 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
     FHESI_TRY(launch_dot_aux(c, k, (const u64*)d_dig, ncol, count, (u64*)d_o));
     FHESI_TRY(launch_ntt_inv(c, (u64*)d_o, count * 2 * R, 2, (const int*)(k->d_aux_consts + L), !k->aux_suborder));
     if (k->aux_limb_bits) return launch_ks_recombine(c, t, k, (const u64*)d_o, count * 2, (u64*)out, nlimbs);
+    if (!d_t) { void* q; FHESI_TRY(ws_reserve(c, 1, (size_t)count * 2 * L * n * 8, &q)); d_t = (u64*)q; }
     FHESI_TRY(launch_aux_crt(c, k, (const u64*)d_o, d_t, count * 2 * L));
     return launch_crt(c, t, d_t, L, nullptr, count * 2, 2, 0, logQ, (u64*)out, nlimbs);
   }
   // ByteDecomp + DoubleCRT(digit polys)   (Ciphertext.cpp:82-121, FHE-SI.cpp:244-249)
+  if (!d_t) { void* q; FHESI_TRY(ws_reserve(c, 1, (size_t)count * 2 * L * n * 8, &q)); d_t = (u64*)q; }
   void* d_dig;
   FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * L * n * 8, &d_dig));
   if (c->pow2) FHESI_TRY(launch_ntt_fwd_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig));
@@ -1317,9 +1339,7 @@ extern "C" int fhesi_ct_automorph_key_switch_dev(fhesi_ctx* c, const fhesi_ksk* 
     const int r = launch_ct_automorph_parts(c, (const u64*)in, nlimbs_in, count * ncomp, kk, logQ, (u64*)d_parts, nlq);
     if (r == 1) return 1;
     if (r == 0) {
-      void* d_t2;
-      FHESI_TRY(ws_reserve(c, 1, (size_t)count * 2 * c->L * n * 8, &d_t2));
-      return key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, count, (u64*)d_t2, out, nlimbs);
+      return key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, count, nullptr, out, nlimbs);
     }
   }
   if (kk == 1) {
@@ -1508,7 +1528,9 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
   const int L = c->L;
   const i64 ct_words = (i64)2 * n * nlimbs, tp_words = (i64)3 * L * n;
   const std::vector<int> all = full_set(c);
-  const i64 chunk = batch_chunk(c, 3 * k->ndigits);           // groups per key-switch call
+  CrtTables* t_all;
+  FHESI_TRY(get_crt_tables(c, all, &t_all));
+  const i64 chunk = batch_chunk(c, 3 * k->ndigits, ksaux_mode(c, t_all, k->ncomp * k->ndigits, 8 * decomp_bytes, logQ) == KS_MODE_LIMB32);           // groups per key-switch call
   // distinct operands per pass: bound their evaluation-form rows (2 L n words each) to about 4 GiB
   i64 ucap = (i64)(4.0 * 1024 * 1024 * 1024 / ((double)2 * L * n * 8));
   // the sums' integers over primes below 2^30 where that path applies (kernels_tensor32.hip; tProd is not visible from here either)
@@ -1590,11 +1612,10 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
       FHESI_TRY(pass(seg[g], seg[g2], gseg, false, (u64*)d_sum));
     }
     if (t32) {
-      void *d_parts, *d_t2;
+      void* d_parts;
       FHESI_TRY(ws_reserve(c, 2, (size_t)ng * 3 * ((logQ + 63) / 64) * n * 8, &d_parts));
       FHESI_TRY(tensor32_sum_finish(c, d_sum, ng, (u64*)d_parts));
-      FHESI_TRY(ws_reserve(c, 1, (size_t)ng * 2 * L * n * 8, &d_t2));
-      FHESI_TRY(key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, ng, (u64*)d_t2, out + (size_t)g * ct_words, nlimbs));
+      FHESI_TRY(key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, ng, nullptr, out + (size_t)g * ct_words, nlimbs));
     } else {
       FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_sum, ng, out + (size_t)g * ct_words, nlimbs));
     }
@@ -1603,26 +1624,42 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
   return 0;
 }
 
-static i64 batch_chunk(const fhesi_ctx* c, int ncol) {
+// Ciphertexts per launch of the fused multiplication.  ks32: the key switch really runs over the four 30-bit auxiliary primes (ksaux_mode
+// said KS_MODE_LIMB32) -- only then does the large-launch policy below apply; the 64-bit forms keep the smaller chunks measured for them.
+static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32) {
   if (c->opt.batch_chunk > 0) return c->opt.batch_chunk;
-  if (aux32_applies(c)) {
+  i64 ch;
+  double per;                                              // workspace bytes per ciphertext of a chunk (estimate)
+  if (ks32) {
     // the 32-bit pipelines (key switch over the four auxiliary primes, tensor half over primes below 2^30): the larger the launch the
     // better -- 64 per launch 22.1 k mults/s, 128: 22.5 k, 512: 22.7 k, 1024: 23.0 k at the metric ring (more ciphertext tiles per key
     // block in the dot product, fewer launch tails; running the tensor half and the digit transforms in sub-chunks of 64 so that their
     // intermediate rows stay in the Infinity Cache, and only the dot product and what follows per chunk, measured 22.8 k against 23.3 k
     // for every stage per chunk) -- so: what fits about 48 GiB of workspace (digit rows ncol * 2 * row * 8 bytes per
     // ciphertext, the dot product's outputs and the tensor half's rows about 1.6 times that again), at most 1024
-    const double per = (double)ncol * 2 * (double)aux32_row_len(c) * 8.0 * 2.6;
-    const i64 ch = (i64)(48.0 * 1024 * 1024 * 1024 / per);
-    return ch < 1 ? 1 : (ch > 1024 ? 1024 : ch);
+    per = (double)ncol * 2 * (double)aux32_row_len(c) * 8.0 * 2.6;
+    ch = (i64)(48.0 * 1024 * 1024 * 1024 / per);
+    ch = ch < 1 ? 1 : (ch > 1024 ? 1024 : ch);
+  } else {
+    // about 75k digit rows per chunk (150 rounds of the transform's 512 resident workgroups): measured best on MI355X at both the
+    // metric ring (64 mults, 9.3 GiB of digit rows) and the stress ring (16-17 mults, 18 GiB) -- smaller chunks pay launch tails in
+    // every stage, larger ones push the key rows out of the Infinity Cache during the dot product.  Capped at 32 GiB of digit rows.
+    const double rows_per = (double)ncol * c->L, bytes_per = rows_per * c->phim * 8.0;
+    ch = (i64)(76800.0 / rows_per);
+    const i64 cap = (i64)(32.0 * 1024 * 1024 * 1024 / bytes_per);
+    if (ch > cap) ch = cap;
+    per = bytes_per + 5.0 * c->L * c->phim * 8.0;          // + tProd and the two scratch DoubleCRTs
   }
-  // about 75k digit rows per chunk (150 rounds of the transform's 512 resident workgroups): measured best on MI355X at both the
-  // metric ring (64 mults, 9.3 GiB of digit rows) and the stress ring (16-17 mults, 18 GiB) -- smaller chunks pay launch tails in
-  // every stage, larger ones push the key rows out of the Infinity Cache during the dot product.  Capped at 32 GiB of digit rows.
-  const double rows_per = (double)ncol * c->L, bytes_per = rows_per * c->phim * 8.0;
-  i64 ch = (i64)(76800.0 / rows_per);
-  const i64 cap = (i64)(32.0 * 1024 * 1024 * 1024 / bytes_per);
-  if (ch > cap) ch = cap;
+  // never more than the device can hold: what is free now plus what this lane's workspace already owns, minus a margin (the other lane of
+  // option lanes = 2 keeps a second set, hence half of the free memory each)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    double have = (double)free_b / (c->opt.lanes >= 2 ? 2.0 : 1.0);
+    for (int i = 0; i < FHESI_WS_SLOTS; ++i) have += (double)c->ws_bytes[i];
+    have -= 2.0 * 1024 * 1024 * 1024;
+    const i64 fit = have > per ? (i64)(have / (per * 1.15)) : 1;
+    if (ch > fit) ch = fit;
+  } else (void)hipGetLastError();
   return ch < 1 ? 1 : ch;
 }
 
@@ -1630,25 +1667,36 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
                             uint64_t* out, int32_t nlimbs, int64_t count) {
   const i64 n = c->phim;
   const int L = c->L;
-  const i64 chunk = batch_chunk(c, 3 * k->ndigits);
-  for (i64 done = 0; done < count; done += chunk) {
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, full_set(c), &t));
+  const int ks_mode = ksaux_mode(c, t, k->ncomp * k->ndigits, 8 * decomp_bytes, logQ);
+  i64 chunk = batch_chunk(c, 3 * k->ndigits, ks_mode == KS_MODE_LIMB32);
+  for (i64 done = 0; done < count;) {
     const i64 cnt = std::min(chunk, count - done);
     const size_t off = (size_t)done * 2 * n * nlimbs;
+    c->ws_oom = false;
+    int rc;
     if (k->ncomp == 3 && tensor32_applies(c, p, nlimbs, logQ)) {
       // tProd is not visible from here: its integers are formed over primes below 2^30 (kernels_tensor32.hip), straight to the scaled-down parts
       FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
-      void *d_parts, *d_t2;
-      FHESI_TRY(ws_reserve(c, 2, (size_t)cnt * 3 * ((logQ + 63) / 64) * n * 8, &d_parts));
-      FHESI_TRY(launch_tensor32(c, p, a + off, b + off, nlimbs, logQ, cnt, (u64*)d_parts));
-      FHESI_TRY(ws_reserve(c, 3, (size_t)cnt * 2 * L * n * 8, &d_t2));
-      FHESI_TRY(key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, cnt, (u64*)d_t2, out + off, nlimbs));
-      continue;
+      void* d_parts = nullptr;
+      rc = ws_reserve(c, 2, (size_t)cnt * 3 * ((logQ + 63) / 64) * n * 8, &d_parts);
+      if (!rc) rc = launch_tensor32(c, p, a + off, b + off, nlimbs, logQ, cnt, (u64*)d_parts);
+      if (!rc) rc = key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, cnt, nullptr, out + off, nlimbs);
+    } else {
+      void* d_tp = nullptr;
+      rc = ws_reserve(c, 5, (size_t)cnt * 3 * L * n * 8, &d_tp);
+      if (!rc) rc = fhesi_ct_mul_dev(c, p, a + off, b + off, nlimbs, cnt, (uint64_t*)d_tp);
+      if (!rc) rc = key_switch_args(c, k, logQ, decomp_bytes, nlimbs);
+      if (!rc) rc = apply_key_switch_consume(c, k, logQ, decomp_bytes, (u64*)d_tp, cnt, out + off, nlimbs);      // the chunk's tProd is ours: no copy
     }
-    void* d_tp;
-    FHESI_TRY(ws_reserve(c, 5, (size_t)cnt * 3 * L * n * 8, &d_tp));
-    FHESI_TRY(fhesi_ct_mul_dev(c, p, a + off, b + off, nlimbs, cnt, (uint64_t*)d_tp));
-    FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
-    FHESI_TRY(apply_key_switch_consume(c, k, logQ, decomp_bytes, (u64*)d_tp, cnt, out + off, nlimbs));      // the chunk's tProd is ours: no copy
+    if (rc) {
+      // a workspace allocation failed (a device with less free memory than the estimate assumed): the chunk is redone at half the size --
+      // every stage of a chunk writes only workspace and its own slice of `out`, so nothing of the failed attempt survives
+      if (c->ws_oom && cnt > 1) { chunk = (cnt + 1) / 2; continue; }
+      return rc;
+    }
+    done += cnt;
   }
   return 0;
 }

@@ -128,6 +128,7 @@ struct fhesi_ctx {
   void* lane_ws[FHESI_WS_SLOTS] = {};
   size_t lane_ws_bytes[FHESI_WS_SLOTS] = {};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+  bool ws_oom = false;                 // the last failing ws_reserve failed in hipMalloc (mul_relin_chunks then retries with smaller chunks)
   bool mark_mid = false;               // record ev_mid right after the next digit-NTT launch (staggers the second lane)
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -160,6 +161,8 @@ struct fhesi_ksk {
   size_t aux_bytes = 0;                // allocated size of d_aux
   u64* d_aux_consts = nullptr;         // [L] q_0 q_1 mod q_i, then the int pair {0, 1} (prime_of_slot of auxiliary rows)
   bool aux_valid = false, aux_suborder = false;
+  int aux_mode = 0;                    // KS_MODE_* the table was built for: rebuilt when the options select another form
+  int last_form = -1;                  // KS_MODE_* of the last key switch with this matrix (fhesi_ksk_form)
   // limb mode (kernels_ksaux.hip): the table is built from the key polynomial's INTEGER coefficients (toPoly over the chain) cut into
   // aux_rows limbs of aux_limb_bits bits instead of from its aux_rows = L chain-prime residues; 0 = residue mode
   int aux_rows = 0, aux_limb_bits = 0, aux_logQ = 0;
@@ -195,8 +198,9 @@ bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14 or 2^15, or a rin
 i64 aux32_row_len(const fhesi_ctx* ctx);            // 2^15 for n = 2^15, else 2^14
 static const i64 kAux32N = 1 << 14;                // row length of the 32-bit auxiliary transforms
 int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig /* [count*ncol][4][n] */, int ncol, i64 count, u32* d_out /* [count*2*rows][4][n] */, bool* mont /* out: the rows carry 2^-32 */);
-bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits);
-int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ);
+enum { KS_MODE_DIRECT = 0, KS_MODE_LIMB32 = 1 /* four 30-bit primes, limbs */, KS_MODE_LIMB60 = 2 /* two largest chain primes, limbs */, KS_MODE_RESIDUE60 = 3 /* ..., residues */ };
+int ksaux_mode(fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ);       // the form that runs for this chain, ring and option set
+int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ, int mode);
 int launch_dot_aux(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig /* [count*ncol][2][n] */, int ncol, i64 count, u64* d_out /* [count][2][L][2][n] */);
 int launch_aux_crt(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_o /* [nrows][2][n] */, u64* d_dst /* [nrows][n] */, i64 nrows);
 

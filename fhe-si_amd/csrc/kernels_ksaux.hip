@@ -255,21 +255,30 @@ __global__ void __launch_bounds__(256) aux_crt_kernel(const u64* __restrict__ o,
   }
 }
 
-bool ksaux_supported(const fhesi_ctx* ctx, int ncol, int digit_bits) {
-  if (ctx->L < 2 || digit_bits >= 32) return false;
-  const u64 q0 = ctx->q[0], q1 = ctx->q[1];
-  if (q0 <= q1 || q1 < (1ull << 59)) return false;             // the chain is descending from 2^60 (FHEContext.cpp:92-108)
-  for (int i = 2; i < ctx->L; ++i) if (ctx->q[i] >= q1) return false;
-  if (ctx->lin_q) {
-    // the reference's safe-prime rings: only the limb mode over the four 30-bit primes exists there (linear convolution + fold); the
-    // plan decides (ks_limb_plan needs the chain's CRT tables, so the caller -- ksaux_build -- reports a failing plan as an error)
-    return !ctx->opt.ks_residues && !ctx->opt.ks_aux60;
+// Which form of the exact-integer key switch runs for this chain, ring and option set (KS_MODE_*); KS_MODE_DIRECT = none of them: the
+// per-chain-prime dot product of key_switch_tail.  The limb plan is evaluated HERE, so a chain the plan rejects (fewer than three
+// limbs in the chain product, limbs of at most 64 bits, ...) falls through to the direct path instead of failing in ksaux_build.
+int ksaux_mode(fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ) {
+  if (ctx->L < 2 || digit_bits >= 32 || ctx->opt.ks_direct) return KS_MODE_DIRECT;
+  // (1) limb mode over the four 30-bit auxiliary primes (kernels_aux32.hip): rows of 2^14 / 2^15 and the linear-convolution rings, ANY
+  //     chain -- the auxiliary modulus does not involve the chain primes, so a chain of 50-bit primes (NTL_SP_NBITS = 50) takes it too
+  if (aux32_applies(ctx) && !ctx->opt.ks_aux60 && !ctx->opt.ks_residues) {
+    const u32* p32 = aux32_primes(ctx);
+    KsLimbPlan plan;
+    if (p32 && ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, p32) && plan.a32) return KS_MODE_LIMB32;
   }
-  if (!ctx->pow2) return false;
-  if (!((ctx->logn >= 11 && ctx->logn <= 14) || ntt_digits_suborder(ctx, digit_bits))) return false;      // single-pass digit transforms
+  if (ctx->lin_q) return KS_MODE_DIRECT;                       // no other exact form exists on those rings: per-prime Bluestein rows
+  // (2) the two largest chain primes as auxiliary modulus: needs the reference's chain descending from 2^60 (FHEContext.cpp:92-108)
+  const u64 q0 = ctx->q[0], q1 = ctx->q[1];
+  if (q0 <= q1 || q1 < (1ull << 59)) return KS_MODE_DIRECT;
+  for (int i = 2; i < ctx->L; ++i) if (ctx->q[i] >= q1) return KS_MODE_DIRECT;
+  if (!ctx->pow2) return KS_MODE_DIRECT;
+  if (!((ctx->logn >= 11 && ctx->logn <= 14) || ntt_digits_suborder(ctx, digit_bits))) return KS_MODE_DIRECT;      // single-pass digit transforms
   // |V| <= ncol * n * 2^digit_bits * q_0  must stay below q_0 q_1 / 2
   const double lg = std::log2((double)ncol) + (double)ctx->logn + digit_bits + 60.0;
-  return lg + 2.0 < std::log2((double)q0) + std::log2((double)q1);
+  if (!(lg + 2.0 < std::log2((double)q0) + std::log2((double)q1))) return KS_MODE_DIRECT;
+  KsLimbPlan plan;
+  return ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, nullptr) ? KS_MODE_LIMB60 : KS_MODE_RESIDUE60;
 }
 
 // Limb mode for any chain: the key polynomial's integer coefficient in [0, P) is cut into NLB limbs of B bits, with B the largest
@@ -330,7 +339,7 @@ static bool bn_ge(const std::vector<u64>& a, const std::vector<u64>& b) {
 }
 
 // builds k->d_aux from k->d_rows (device work only; the caller holds the context's stream)
-int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
+int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ, int mode) {
   const i64 n = ctx->phim;
   const int L = ctx->L, ncol = k->ncomp * k->ndigits;
   const bool suborder = ntt_digits_suborder(ctx, digit_bits);
@@ -339,8 +348,9 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
   CrtTables* t;
   FHESI_TRY(get_crt_tables(ctx, all, &t));
   KsLimbPlan plan;
-  const bool limb = ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, aux32_applies(ctx) ? aux32_primes(ctx) : nullptr);
-  if (ctx->lin_q && !(limb && plan.a32)) FHESI_FAIL("key switch: no exact limb plan for this ring and chain (set option ks_direct)");
+  if (mode == KS_MODE_DIRECT) FHESI_FAIL("key switch: no auxiliary-prime table for the direct path");
+  const bool limb = mode != KS_MODE_RESIDUE60 && ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, mode == KS_MODE_LIMB32 ? aux32_primes(ctx) : nullptr);
+  if ((mode != KS_MODE_RESIDUE60) != limb || (limb && plan.a32 != (mode == KS_MODE_LIMB32))) FHESI_FAIL("key switch: the limb plan does not match the selected form");
   const int R = limb ? plan.NLB : L;                          // output rows per (ciphertext, key row, auxiliary prime)
   {
     // table size: residue / limb rows for two 8-byte (or four 4-byte) auxiliary residues; 2^14-element rows on the linear-convolution rings
@@ -419,6 +429,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));       // one-off: another lane's stream may use the table right away
   k->aux_suborder = suborder;
   k->aux_rows = R; k->aux_limb_bits = limb ? plan.B : 0; k->aux_logQ = logQ;
+  k->aux_mode = mode;
   k->aux_valid = true;
   return 0;
 }

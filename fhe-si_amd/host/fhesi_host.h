@@ -143,6 +143,7 @@ class FHEcontext {
   PAlgebra zMstar;
   IndexSet ctxtPrimes, specialPrimes;
   double stdev = 3.2;
+  int spNbits = 60;                    // NTL_SP_NBITS of the NTL build being mirrored: where AddPrimesBySize starts (FHEContext.cpp:92); 50 in NTL 5.x / 6.x, 60 today
   ZZ modulusQ;
   unsigned logQ = 0, decompSize = 3, ndigits = 0;
 
@@ -177,7 +178,7 @@ class FHEcontext {
     if (special) specialPrimes.insert(i); else ctxtPrimes.insert(i);
   }
   void SetUpSIContext(long xi = 1) {   // FHEContext.cpp:83-85
-    AddPrimesBySize(log(modulusQ) * 2 + log(ModulusP()) + std::log((double)zMstar.phiM()) * 2 + std::log(2.0) + std::log((double)xi), false);
+    AddPrimesBySize(log(modulusQ) * 2 + log(ModulusP()) + std::log((double)zMstar.phiM()) * 2 + std::log(2.0) + std::log((double)xi), false, spNbits);
   }
   double AddPrimesBySize(double totalSize, bool special, int sp_nbits = 60) {   // FHEContext.cpp:88-115
     if (!zMstar.M() || zMstar.M() > (1u << 20)) Error("AddModuli1: m undefined or larger than 2^20");

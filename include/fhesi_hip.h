@@ -147,6 +147,12 @@ int fhesi_ksk_mark_dirty(fhesi_ksk* k);                                         
                                                                                         and rebuilds them at the next key switch */
 int fhesi_ksk_upload_dev(fhesi_ksk* k, const uint64_t* rows_dev);                    /* whole matrix from another HBM buffer (copies and invalidates) */
 size_t fhesi_ksk_bytes(const fhesi_ksk* k);
+/* Which form of KeySwitchSI::ApplyKeySwitch's dot product (Util.h:79-98 at FHE-SI.cpp:251-254) the last key switch with this matrix ran:
+ * form 0 = one dot product per chain prime (the reference's own structure), 1 = exact integer dot product over four 30-bit auxiliary
+ * primes in limb mode, 2 = over the two largest chain primes in limb mode, 3 = over them in residue mode; rows = limbs (or residues) per
+ * key coefficient, limb_bits = their width (0 in residue mode).  All forms give the reference's bits; a caller (bench, tests) reads this to
+ * state which one it measured.  Before the first key switch: form -1. */
+int fhesi_ksk_form(const fhesi_ksk* k, int32_t* form, int32_t* rows, int32_t* limb_bits);
 
 int fhesi_selftest_aux32(fhesi_ctx* c);                                              /* diagnostic: checks the 32-bit auxiliary transforms of the key switch
                                                                                         (n = 2^14 only) as a ring isomorphism; 0 = ok */

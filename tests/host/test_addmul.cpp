@@ -5,6 +5,7 @@
 // `--dump` (with a seed) prints the secret key, both ciphertexts and the mul+keyswitch result as JSON for the parity test
 // against tests/golden/ciphertext.json (same documented PRNG stream as the Python model).
 #include <cstring>
+#include <ctime>
 #include <iostream>
 
 #include "../../fhe-si_amd/host/fhesi_host.h"
@@ -13,6 +14,12 @@ using namespace fhesi;
 namespace fhesi { FHEcontext* activeContext = nullptr; }
 
 static std::vector<long> mul_mod_phi(const std::vector<long>& a, const std::vector<long>& b, const FHEcontext& c, long p) {
+  const long m = (long)c.zMstar.M(), n = (long)c.zMstar.phiM();
+  if (!(m & (m - 1))) {                 // Phi_m = X^n + 1: plain negacyclic convolution on machine words (the generic path below is cubic in bigints at n = 2^14)
+    std::vector<long> out(n, 0);
+    for (long i = 0; i < n; ++i) { const long ai = a[i] % p; if (!ai) continue; for (long j = 0; j < n; ++j) { const long k = i + j, t = ai * (b[j] % p) % p; if (k < n) out[k] = (out[k] + t) % p; else out[k - n] = (out[k - n] + p - t) % p; } }
+    return out;
+  }
   ZZX x, y; for (size_t i = 0; i < a.size(); ++i) SetCoeff(x, (long)i, a[i]); for (size_t i = 0; i < b.size(); ++i) SetCoeff(y, (long)i, b[i]);
   ZZX r = mul(x, y); rem(r, r, c.zMstar.PhimX());
   std::vector<long> out(c.zMstar.phiM(), 0); for (long i = 0; i <= deg(r); ++i) out[i] = rem(r.rep[i], p);
@@ -22,6 +29,8 @@ static void dump_poly(const char* name, const ZZX& p, long n, bool last = false)
   std::cout << "\"" << name << "\":["; for (long i = 0; i < n; ++i) std::cout << (i ? "," : "") << "\"" << coeff(p, i).str() << "\""; std::cout << "]" << (last ? "" : ",");
 }
 
+static bool g_time = false;
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, bool dump) {
   SetSeed((uint64_t)seed);                                            // Test_AddMul.cpp:15-16
   FHESISecKey secretKey(context);
@@ -39,11 +48,18 @@ static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, 
   publicKey.Encrypt(ctxt1, ptxt1); publicKey.Encrypt(ctxt2, ptxt2);
   Ciphertext cSum = ctxt1; cSum += ctxt2;
   Ciphertext cSumMult = ctxt2; for (int i = 1; i < 7; ++i) cSumMult += ctxt2;
+  double t_mul = now_s();
   Ciphertext cProd = ctxt1; cProd *= ctxt2;
+  t_mul = now_s() - t_mul;
   Plaintext resSum, resSumMult, resProd, resProd2, resSumQuad;
   secretKey.Decrypt(resSum, cSum); secretKey.Decrypt(resSumMult, cSumMult);
+  double t_kg = now_s();
   KeySwitchSI keySwitch(secretKey);
+  t_kg = now_s() - t_kg;
+  double t_ks = now_s();
   keySwitch.ApplyKeySwitch(cProd);
+  t_ks = now_s() - t_ks;
+  if (g_time) std::cout << "surface timing (one object at a time, first use): operator*= " << t_mul * 1e3 << " ms, ApplyKeySwitch " << t_ks * 1e3 << " ms, KeySwitchSI(sk) " << t_kg * 1e3 << " ms" << std::endl;
   secretKey.Decrypt(resProd, cProd);
   if (dump) {
     ZZX t; secretKey.GetRepresentation()[1].toPoly(t);
@@ -52,9 +68,13 @@ static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, 
     dump_poly("c2_0", ctxt2[0].poly, phim); dump_poly("c2_1", ctxt2[1].poly, phim); dump_poly("res_0", cProd[0].poly, phim); dump_poly("res_1", cProd[1].poly, phim, true);
     std::cout << "}" << std::endl;
   }
+  double t2 = now_s();
   cProd *= cProd;
   Ciphertext tmp = cProd, cSumQuad = cProd;
-  keySwitch.ApplyKeySwitch(cProd); secretKey.Decrypt(resProd2, cProd);
+  keySwitch.ApplyKeySwitch(cProd);
+  t2 = now_s() - t2;
+  if (g_time) std::cout << "surface timing (second use): operator*= + copy + ApplyKeySwitch " << t2 * 1e3 << " ms = " << 1.0 / t2 << " ciphertext-mults/s through the class surface" << std::endl;
+  secretKey.Decrypt(resProd2, cProd);
   for (int i = 0; i < 8; ++i) cSumQuad += tmp;
   keySwitch.ApplyKeySwitch(cSumQuad); cSumQuad *= cProd; keySwitch.ApplyKeySwitch(cSumQuad);
   secretKey.Decrypt(resSumQuad, cSumQuad);
@@ -72,16 +92,24 @@ static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, 
 }
 
 int main(int argc, char* argv[]) {
-  bool dump = false; int ntests = 20;
+  bool dump = false; int ntests = 20, sp_nbits = 60; long m_override = 0;
   std::vector<char*> args;
-  for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "--dump")) dump = true; else if (!strncmp(argv[i], "--tests=", 8)) ntests = atoi(argv[i] + 8); else args.push_back(argv[i]); }
-  if (args.size() < 3) { std::cout << "usage: test_addmul logQ p generator [seed] [--dump] [--tests=N]" << std::endl; return 1; }
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--dump")) dump = true; else if (!strncmp(argv[i], "--tests=", 8)) ntests = atoi(argv[i] + 8);
+    else if (!strncmp(argv[i], "--m=", 4)) m_override = atol(argv[i] + 4);               // a ring other than the reference driver's m = p - 1 (e.g. 32768: the metric ring)
+    else if (!strncmp(argv[i], "--sp-nbits=", 11)) sp_nbits = atoi(argv[i] + 11);        // NTL_SP_NBITS of the mirrored NTL build (FHEContext.cpp:92)
+    else if (!strcmp(argv[i], "--time")) g_time = true;
+    else args.push_back(argv[i]);
+  }
+  if (args.size() < 3) { std::cout << "usage: test_addmul logQ p generator [seed] [--dump] [--tests=N] [--m=M] [--sp-nbits=B] [--time]" << std::endl; return 1; }
   unsigned logQ = atoi(args[0]), p = atoi(args[1]), g = atoi(args[2]);
   if (!dump) std::cout << "==================================================" << std::endl << "Running add/multiply tests using Brakerski system." << std::endl << "==================================================" << std::endl;
-  FHEcontext context(p - 1, logQ, p, g, 3);
+  FHEcontext context(m_override ? (unsigned)m_override : p - 1, logQ, p, g, 3);
   activeContext = &context;
+  context.spNbits = sp_nbits;
   context.SetUpSIContext();
-  if (!dump) std::cout << "Finished setting up context." << std::endl;
+  if (!dump) std::cout << "Finished setting up context: m=" << context.zMstar.M() << " phi(m)=" << context.zMstar.phiM() << " logQ=" << logQ << " primes=" << context.numPrimes()
+                       << " first prime bits=" << ZZ(context.ithPrime(0)).bits() << " ndigits=" << context.ndigits << std::endl;
   if (args.size() >= 4) {
     long long seed = atoll(args[3]);
     bool res = runTest(true, seed, p, context, dump);

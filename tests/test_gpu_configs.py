@@ -85,6 +85,46 @@ def test_config2_metric_ring_several_chunks():
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
 
 
+def test_config2_with_a_chain_of_50_bit_primes():
+    """configs[2] as the reference's era would have built it: FHEContext.cpp:92 starts the chain at 2^NTL_SP_NBITS, 50 in NTL 5.x / 6.x,
+    which gives 22 primes instead of 18.  Multiplication + relinearisation against the oracle on the first, the last and
+    the sub-chunk-boundary ciphertexts; the key switch must run over the four 30-bit auxiliary primes (limb mode), not per prime."""
+    m, logQ, p, count = 1 << 15, 512, 23, 66
+    primes, roots = P.chain_for(m, logQ, p, 1, 50)
+    assert len(primes) == 22 and max(primes).bit_length() == 50
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(50)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    a[count - 1, 0, 0] = O.ints_to_limbs([-(1 << (logQ - 1))], nl)[0]
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    form, rows, bits = ksk.form()
+    assert form == 1 and rows == 15 and bits > 64, (form, rows, bits)      # the chain product has the same ~1058 bits as with 60-bit primes: 15 limbs of 74 bits
+    for c in (0, 63, 64, count - 1):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    ctx.set_option("ks_direct", 1)                    # the per-prime form of the reference's own structure on the same chain
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[:2], b[:2]), got[:2]) and ksk.form()[0] == 0
+    ctx.set_option("ks_direct", 0)
+    ctx.set_option("tensor32", 0)                     # ... and the tensor half over the chain itself (22 rows of 50-bit residues)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[:2], b[:2]), got[:2])
+
+
+def test_addmul_sequence_at_the_metric_ring_with_50_bit_primes():
+    """Test_AddMul's operation sequence (Test_AddMul.cpp:18-86: add, 7-fold add, mul + key switch, square + key switch, 9-fold add +
+    key switch, mul, key switch) on the C++ mirror of the class surface at configs[2]'s ring, chain started at 2^50: key generation on
+    the device, and every result decrypts to the plaintext value (the reference's own predicate) -- the valid-key check of this chain."""
+    host = os.path.join(ROOT, "tests", "host")
+    subprocess.check_call(["make", "-C", host], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(host, "test_addmul"), "512", "23", "7", "11", "--m=32768", "--sp-nbits=50", "--time"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "m=32768 phi(m)=16384 logQ=512 primes=22 first prime bits=50 ndigits=22" in r.stdout, r.stdout
+    assert "Test SUCCEEDED" in r.stdout
+
+
 def test_config3_regression_at_the_reference_size():
     """configs[3] at its own parameters: Test_Regression's safe prime p = 8423 (m = 8422, phi(m) = 4210, Bluestein rows with N = 2^15),
     d = 8, one data block of 4096 points (blockSize = usable slots = 4096, Test_Regression.cpp:111-121), logQ = 341 by the

@@ -112,10 +112,12 @@ def test_bench_launches_its_own_ranks(workload, extra):
     import json
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo", "--workload", workload,
-                        "--steps", "2", "--warmup", "1", "--cpu-sample", "0", *extra], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--gpu-seconds", "0.5", *extra], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     assert d["roofline"]["kernel"] and d["roofline"]["frac"] > 0
+    if workload == "metric":
+        assert len(d["config"]["per_rank_value"]) == 2 and d["config"]["blocks"] >= 1 and d["config"]["key_broadcast_s"] > 0

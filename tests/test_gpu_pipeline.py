@@ -11,8 +11,8 @@ import params as P
 pytestmark = pytest.mark.gpu
 
 
-def setup(m, logQ, p, seed, count):
-    primes, roots = P.chain_for(m, logQ, p)
+def setup(m, logQ, p, seed, count, sp_nbits=60):
+    primes, roots = P.chain_for(m, logQ, p, 1, sp_nbits)
     ctx = F.Context(m, primes, roots)
     orc = O.Oracle(m, primes, roots)
     n, L = ctx.phim, len(primes)
@@ -231,19 +231,21 @@ def test_key_switch_paths_agree(m, logQ, p, monkeypatch):
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], orc.ct_mul_relin(ksm2, a[0], b[0], logQ, p))
 
 
-@pytest.mark.parametrize("m,logQ", [(4096, 512), (8192, 512), (32768, 512),          # the metric chain (18 primes); 32768: four 30-bit auxiliary primes
-                                    (4096, 128), (8192, 200), (16384, 256), (32768, 128), (32768, 341), (32768, 700), (65536, 300)])
-def test_key_switch_limb_mode_edge_values(m, logQ):
+@pytest.mark.parametrize("m,logQ,sp_nbits", [(4096, 512, 60), (8192, 512, 60), (32768, 512, 60),          # the metric chain (18 primes); 32768: four 30-bit auxiliary primes
+                                             (4096, 128, 60), (8192, 200, 60), (16384, 256, 60), (32768, 128, 60), (32768, 341, 60), (32768, 700, 60), (65536, 300, 60),
+                                             (32768, 512, 50), (65536, 300, 50), (8422, 341, 50)])      # chains of 50-bit primes (NTL_SP_NBITS = 50): 22, 14 and 15 primes
+def test_key_switch_limb_mode_edge_values(m, logQ, sp_nbits):
     """For n >= 2^11 the key switch runs in limb mode (kernels_ksaux.hip + ks_recombine_kernel) for ANY chain: the limb width, the limb
     count and the auxiliary modulus are derived per chain (ks_limb_plan); the dot product is recombined as an integer and reduced modulo
     the chain product P exactly.  Shapes: the metric chain (compile-time instantiations), and chains of 5 to 24 primes through the
     run-time recombination kernel, with the two 60-bit auxiliary primes and (n = 2^14) the four 30-bit ones.  Crafted key rows make
     the integer hit the edges of the reduction: 0, +-1, +-(P-1)/2, (P+1)/2 (wraps), P-1, values just inside and outside the centring
     threshold, and large multiples; the result must equal the oracle's (toPoly + ReduceCoefficients, FHE-SI.cpp:255-256)."""
-    p = 23
-    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 7 + m, 1)
+    p = 23 if m != 8422 else 8423
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 7 + m, 1, sp_nbits)
     n, L = ctx.phim, ctx.L
     primes = [int(q) for q in ctx.primes]
+    assert max(primes).bit_length() == sp_nbits
     Pprod = 1
     for q in primes:
         Pprod *= q
@@ -267,7 +269,11 @@ def test_key_switch_limb_mode_edge_values(m, logQ):
         ctx.apply_key_switch_dev(ksk2, logQ, dtp, 1, out, nl)
         want = orc.apply_key_switch(ksm2, tp[0], logQ, nl)
         assert np.array_equal(out.download((2, n, nl)), want), (d, pos)
-        if n == 1 << 14 and pos == 0:                 # the same chain through the two 60-bit auxiliary primes
+        if sp_nbits == 50:
+            # a chain of 50-bit primes has no pair of 60-bit primes to serve as auxiliary modulus: the four 30-bit primes carry it
+            # wherever their transforms exist (rows of 2^14 / 2^15, the safe-prime rings) -- it must not drop to the per-prime form silently
+            assert ksk2.form()[0] == 1, ksk2.form()
+        if n == 1 << 14 and pos == 0 and sp_nbits == 60:                 # the same chain through the two 60-bit auxiliary primes
             ctx.set_option("ks_aux60", 1)
             ksk3 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm2)
             ctx.apply_key_switch_dev(ksk3, logQ, dtp, 1, out, nl)
@@ -291,6 +297,14 @@ def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
         assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), opt
         ctx.set_option(opt, 1 if opt == "dot32_half" else 0)
     assert np.array_equal(ref[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
+    # ... and on ONE live matrix: an option that selects another form rebuilds the derived table (it used to be kept silently)
+    assert ksk.form()[0] == 1
+    for opt, form in (("ks_aux60", 2), ("ks_residues", 3), ("ks_direct", 0)):
+        ctx.set_option(opt, 1)
+        assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[:3], b[:3]), ref[:3]), opt
+        assert ksk.form()[0] == form, (opt, ksk.form())
+        ctx.set_option(opt, 0)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[:3], b[:3]), ref[:3]) and ksk.form()[0] == 1
 
 
 def test_large_launch_equals_launches_of_64():
@@ -312,6 +326,21 @@ def test_large_launch_equals_launches_of_64():
         assert np.array_equal(big[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
     for c in range(5, count - 1):
         assert np.array_equal(big[c], big[c % 5]), c
+
+
+@pytest.mark.parametrize("m,logQ", [(22, 20), (46, 24)])
+def test_safe_prime_ring_with_a_chain_too_narrow_for_the_limb_plan(m, logQ):
+    """On m = 2 x prime the exact-integer key switch exists in limb mode only.  Whether a chain admits a limb plan is decided where the
+    form is chosen (ksaux_mode), so a chain without one -- here a single prime -- takes the per-prime Bluestein form instead of failing
+    in ksaux_build with 'no exact limb plan'; a two-prime chain that does admit a plan runs it.  Both must give the oracle's bits."""
+    p = 23 if m == 22 else 47
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 5 + m, 2)
+    assert ctx.L <= 2
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    for c in range(2):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    assert ksk.form()[0] == (0 if ctx.L == 1 else 1)
 
 
 @pytest.mark.parametrize("m,logQ", [(22, 80), (46, 120), (1006, 200), (8422, 341)])
