@@ -451,6 +451,7 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="library option (fhesi_ctx_set_option), e.g. ks_direct=1, tensor32=0")
+    ap.add_argument("--no-surface", dest="surface", action="store_false", help="skip the class-surface / host-buffer rates (about 15 s)")
     ap.add_argument("--sp-nbits", type=int, default=SP_NBITS, help="where the prime chain starts (FHEContext.cpp:92: 2^NTL_SP_NBITS): 60 = today's NTL (default, the contract "
                     "line), 50 = the NTL 5.x / 6.x of the reference's era (22 primes instead of 18 at the metric ring)")
     ap.add_argument("--gpu-seconds", type=float, default=5.0, help="metric / stress workloads: the block of exactly --steps timed steps is repeated until the GPU phase has "
@@ -686,10 +687,51 @@ def main():
     # `roofline` is the kernel with the largest share of the step
     roofline = roofline_dot if dms >= ms else roofline_ntt
 
+    # What a caller of the kept class surface gets (missing 1): the same multiplication (a) from HOST buffers through
+    # fhesi_ct_mul_relin_batch at several batch sizes (upload + compute + download, pageable memory), (b) one Ciphertext object at a time
+    # through the C++ mirror of Ciphertext::operator*= + KeySwitchSI::ApplyKeySwitch and through its MulRelinBatch (tests/host/test_addmul
+    # --time at this ring; host big-integer conversions included).  Reported beside `value`, never as `value`.
+    surface = None
+    if rank == 0 and world == 1 and args.workload == "metric" and args.surface:
+        surface = {"device_resident_batch": None, "host_buffers": {}, "class_surface": None}
+        for hb in (1, 8, 64, 1024):
+            try:
+                reps = (hb + uniq - 1) // uniq
+                ah = np.concatenate([a_host] * reps)[:hb] if hb > uniq else a_host[:hb]
+                bh = np.concatenate([b_host] * reps)[:hb] if hb > uniq else b_host[:hb]
+                ctx.ct_mul_relin(ksk, LOGQ, P_PLAIN, ah, bh, DECOMP)          # (first call of a shape allocates)
+                best = None
+                for _ in range(1 if hb >= 1024 else 3):
+                    t0 = time.perf_counter()
+                    ctx.ct_mul_relin(ksk, LOGQ, P_PLAIN, ah, bh, DECOMP)
+                    d = time.perf_counter() - t0
+                    best = d if best is None or d < best else best
+                surface["host_buffers"][str(hb)] = round(hb / best, 1)
+                del ah, bh
+            except MemoryError:
+                surface["host_buffers"][str(hb)] = None
+        exe = os.path.join(ROOT, "tests", "host", "test_addmul")
+        if os.path.exists(exe):
+            import re
+            import subprocess
+            try:
+                r = subprocess.run([exe, str(LOGQ), str(P_PLAIN), "7", "11", f"--m={M_RING}", f"--sp-nbits={args.sp_nbits}", "--time"], capture_output=True, text=True, timeout=600)
+                cs = {"ok": r.returncode == 0 and "Test SUCCEEDED" in r.stdout}
+                mm = re.search(r"second use\): .*? = ([0-9.]+) ciphertext-mults/s", r.stdout)
+                if mm:
+                    cs["object_at_a_time"] = round(float(mm.group(1)), 1)
+                for cnt, rate in re.findall(r"MulRelinBatch of (\d+)\): .*? = ([0-9.]+) ciphertext-mults/s", r.stdout):
+                    cs[f"MulRelinBatch_{cnt}"] = round(float(rate), 1)
+                surface["class_surface"] = cs
+            except Exception as e:          # the surface figures are extras: never fail the contract line over them
+                surface["class_surface"] = {"ok": False, "error": str(e)[:200]}
+
     ok = True
     if rank == 0:
         total_mults = B * args.steps * world
         value = total_mults / dt
+        if surface is not None:
+            surface["device_resident_batch"] = round(value, 1)
         breakdown = {k: round(v[2] / (args.steps * nblk), 3) for k, v in prof.items() if v[0] and k != "ntt_fwd_digits_main"}
         cpu, matches = None, None
         if args.cpu_sample > 0 and world == 1:       # CPU baseline on rank 0 at N=1 only; its outputs check the timed buffer
@@ -718,6 +760,7 @@ def main():
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
             "matches_oracle": matches,
             "sclk_mhz_observed": sclk.summary(),
+            "surface": surface,
             "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_ntt_tensor": roofline_ntt_tensor, "roofline_dot": roofline_dot, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
             "kernels": {k: v for k, v in names.items() if v},
         }

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
     "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_comm_init_all", "fhesi_comm_from_rccl", "fhesi_comm_destroy", "fhesi_comm_rank",
     "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
-    "fhesi_ksk_form",
+    "fhesi_ksk_form", "fhesi_ct_add_const_dev", "fhesi_ct_mul_poly_dev",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -159,6 +159,8 @@ def _load():
         "fhesi_dcrt_scale_down_to_set": [_vp, _vp, _i32, _u64],
         "fhesi_ksk_upload_dev": [_vp, _vp],
         "fhesi_ksk_form": [_vp, _vp, _vp, _vp],
+        "fhesi_ct_add_const_dev": [_vp, _i32, _u64, _vp, _i32, _i32, _i64, _vp, _i32],
+        "fhesi_ct_mul_poly_dev": [_vp, _i32, _vp, _i32, _i32, _i64, _vp, _i32],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -363,6 +365,16 @@ class Context:
 
     def ct_mul_long_dev(self, logQ: int, ct: DevBuf, l: int, nparts: int, nlimbs: int, count: int):
         _ck(_load().fhesi_ct_mul_long_dev(self.h, logQ, ct.ptr, l, nparts, nlimbs, count))
+
+    def ct_add_const_dev(self, logQ: int, p: int, ct: DevBuf, nparts: int, nlimbs: int, count: int, poly: np.ndarray):
+        """Ciphertext::operator+=(const ZZX&) on unscaled ciphertexts (Ciphertext.cpp:147-156); poly [npoly][phim] int64, npoly 1 or count."""
+        poly = np.ascontiguousarray(poly, dtype=np.int64).reshape(-1, self.phim)
+        _ck(_load().fhesi_ct_add_const_dev(self.h, logQ, p, ct.ptr, nparts, nlimbs, count, _p(poly), poly.shape[0]))
+
+    def ct_mul_poly_dev(self, logQ: int, ct: DevBuf, nparts: int, nlimbs: int, count: int, poly: np.ndarray):
+        """Ciphertext::operator*=(const ZZX&) on unscaled ciphertexts (Ciphertext.cpp:245-249, :29-36)."""
+        poly = np.ascontiguousarray(poly, dtype=np.int64).reshape(-1, self.phim)
+        _ck(_load().fhesi_ct_mul_poly_dev(self.h, logQ, ct.ptr, nparts, nlimbs, count, _p(poly), poly.shape[0]))
 
     def rows_mul_long_dev(self, rows: DevBuf, l: int, count: int):
         _ck(_load().fhesi_rows_mul_long_dev(self.h, rows.ptr, l, count))

@@ -1366,6 +1366,61 @@ extern "C" int fhesi_ct_mul_long_dev(fhesi_ctx* c, int32_t logQ, uint64_t* ct, i
   if (nparts < 1 || nlimbs < 1 || logQ < 1 || nlimbs * 64 < logQ) FHESI_FAIL("Ciphertext *= long: coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
   return launch_ct_mul_long(c, (u64*)ct, count * nparts * c->phim, nlimbs, logQ, l);
 }
+// Ciphertext::operator+=(const ZZX&) / (const ZZ_pX&) on unscaled ciphertexts (Ciphertext.cpp:147-161)
+extern "C" int fhesi_ct_add_const_dev(fhesi_ctx* c, int32_t logQ, uint64_t p, uint64_t* ct, int32_t nparts, int32_t nlimbs, int64_t count, const int64_t* poly_host, int32_t npoly) {
+  CHECK_CTX(c);
+  if (nparts < 1 || nlimbs < 1 || logQ < 1 || nlimbs * 64 < logQ) FHESI_FAIL("Ciphertext += ZZX: coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  if (p < 2) FHESI_FAIL("Ciphertext += ZZX: plaintext modulus %llu", (unsigned long long)p);
+  if (npoly != 1 && npoly != count) FHESI_FAIL("Ciphertext += ZZX: %d constants for %lld ciphertexts (one for all, or one each)", npoly, (long long)count);
+  if (!count) return 0;
+  void* d_poly;
+  FHESI_TRY(ws_reserve(c, 9, (size_t)npoly * c->phim * 8, &d_poly));
+  HIP_TRY(hipMemcpyAsync(d_poly, poly_host, (size_t)npoly * c->phim * 8, hipMemcpyHostToDevice, c->stream));
+  const int rc = launch_ct_add_const(c, (u64*)ct, (const i64*)d_poly, npoly, nparts, nlimbs, logQ, p, count);
+  HIP_TRY(hipStreamSynchronize(c->stream));        // poly_host may be released on return
+  return rc;
+}
+// Ciphertext::operator*=(const ZZX&) / (const ZZ_pX&) on unscaled ciphertexts (Ciphertext.cpp:245-252 -> CiphertextPart::operator*=(ZZX) :29-36):
+// parts[i].poly *= other as INTEGER polynomials, rem Phi_m, Reduce.  The integer product modulo Phi_m is formed in the chain (DoubleCRT of
+// both factors, product, toPoly): exact because its coefficients stay below half the chain product, which is checked here.
+extern "C" int fhesi_ct_mul_poly_dev(fhesi_ctx* c, int32_t logQ, uint64_t* ct, int32_t nparts, int32_t nlimbs, int64_t count, const int64_t* poly_host, int32_t npoly) {
+  CHECK_CTX(c);
+  if (nparts < 1 || nlimbs < 1 || logQ < 1 || nlimbs * 64 < logQ) FHESI_FAIL("Ciphertext *= ZZX: coefficients of %d limbs cannot hold logQ=%d bits", nlimbs, logQ);
+  if (npoly != 1 && npoly != count) FHESI_FAIL("Ciphertext *= ZZX: %d polynomials for %lld ciphertexts (one for all, or one each)", npoly, (long long)count);
+  if (!count) return 0;
+  const i64 n = c->phim;
+  const int L = c->L;
+  // |coefficient of the product modulo Phi_m| <= growth * n * 2^(logQ-1) * max|other_j|, growth = 1 (X^n + 1), 2 (the two-term folds of prime and
+  // 2 x prime rings) or, conservatively, n for a general Phi_m
+  u64 maxc = 0;
+  for (i64 i = 0; i < (i64)npoly * n; ++i) { const i64 v = poly_host[i]; const u64 a = v < 0 ? (u64)(-(v + 1)) + 1 : (u64)v; if (a > maxc) maxc = a; }
+  double bits = (logQ - 1) + std::log2((double)n) + (maxc ? std::log2((double)maxc) + 1e-9 : 0.0) + 1.0;
+  bits += c->pow2 ? 0.0 : ((c->lin_q || hm::is_prime((u64)c->m)) ? 1.0 : std::log2((double)n));
+  double chain = 0.0;
+  for (int i = 0; i < L; ++i) chain += std::log2((double)c->q[i]);
+  if (bits + 1.0 >= chain) FHESI_FAIL("Ciphertext *= ZZX: the product needs %.0f bits, the chain holds %.0f", bits + 1.0, chain);
+  const std::vector<int> all = full_set(c);
+  CrtTables* t;
+  FHESI_TRY(get_crt_tables(c, all, &t));
+  void *d_rows, *d_prow, *d_pl;
+  FHESI_TRY(ws_reserve(c, 0, (size_t)count * nparts * L * n * 8, &d_rows));
+  FHESI_TRY(ws_reserve(c, 3, (size_t)npoly * L * n * 8, &d_prow));
+  FHESI_TRY(ws_reserve(c, 9, (size_t)npoly * n * 8, &d_pl));
+  HIP_TRY(hipMemcpyAsync(d_pl, poly_host, (size_t)npoly * n * 8, hipMemcpyHostToDevice, c->stream));      // one signed limb per coefficient
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)d_pl, 1, n, npoly, 1, nullptr, (u64*)d_prow, L, nullptr));
+  FHESI_TRY(row_fwd(c, (u64*)d_prow, npoly, L, nullptr, all.data()));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)ct, nlimbs, n, count, nparts, nullptr, (u64*)d_rows, L, nullptr));
+  FHESI_TRY(row_fwd(c, (u64*)d_rows, count * nparts, L, nullptr, all.data()));
+  if (npoly == 1) {
+    for (i64 done = 0; done < count * nparts; done += 65535) FHESI_TRY(launch_rows_mul_bcast(c, (u64*)d_rows + (size_t)done * L * n, (const u64*)d_rows + (size_t)done * L * n, (const u64*)d_prow, std::min<i64>(65535, count * nparts - done)));
+  } else {
+    for (i64 ci = 0; ci < count; ++ci) FHESI_TRY(launch_rows_mul_bcast(c, (u64*)d_rows + (size_t)ci * nparts * L * n, (const u64*)d_rows + (size_t)ci * nparts * L * n, (const u64*)d_prow + (size_t)ci * L * n, nparts));
+  }
+  FHESI_TRY(row_inv(c, (u64*)d_rows, count * nparts, L, nullptr, all.data()));
+  FHESI_TRY(launch_crt(c, t, (const u64*)d_rows, L, nullptr, count * nparts, 2, 0, logQ, (u64*)ct, nlimbs));
+  HIP_TRY(hipStreamSynchronize(c->stream));        // poly_host may be released on return
+  return 0;
+}
 extern "C" int fhesi_rows_mul_long_dev(fhesi_ctx* c, uint64_t* rows, int64_t l, int64_t count) {
   CHECK_CTX(c);
   if (!count) return 0;
@@ -1741,10 +1796,11 @@ extern "C" int fhesi_ct_mul_relin_batch(fhesi_ctx* c, const fhesi_ksk* k, int32_
   CHECK_CTX(c);
   if (!count) return 0;
   const size_t bytes = (size_t)count * 2 * c->phim * nlimbs * 8;
-  u64 *da, *db, *dout;
-  HIP_TRY(hipMalloc(&da, bytes));
-  HIP_TRY(hipMalloc(&db, bytes));
-  HIP_TRY(hipMalloc(&dout, bytes));
+  // staging for the two operand batches and the results: one grow-only workspace slot (a hipMalloc / hipFree pair per call costs
+  // milliseconds for a single ciphertext and seconds for gigabytes -- object-at-a-time callers of the class surface come through here)
+  void* stage;
+  FHESI_TRY(ws_reserve(c, 11, 3 * bytes, &stage));
+  u64 *da = (u64*)stage, *db = (u64*)((char*)stage + bytes), *dout = (u64*)((char*)stage + 2 * bytes);
   int r = 0;
   if (hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
     fhesi_set_error("upload of ciphertext batch failed"); r = 1;
@@ -1752,6 +1808,5 @@ extern "C" int fhesi_ct_mul_relin_batch(fhesi_ctx* c, const fhesi_ksk* k, int32_
   if (!r) r = fhesi_ct_mul_relin_batch_dev(c, k, logQ, p, decomp_bytes, da, db, dout, nlimbs, count);
   if (!r && hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { fhesi_set_error("download of ciphertext batch failed"); r = 1; }
   hipStreamSynchronize(c->stream);
-  hipFree(da); hipFree(db); hipFree(dout);
   return r;
 }

@@ -139,7 +139,7 @@ struct fhesi_ctx {
   //   4 wave sums, per-call constants                    5 tProd of a chunk / message staging
   //   6 row transforms above 2^14 (two-pass, bit reversal)   7 Bluestein slot map / wave operands
   //   8 Bluestein convolution buffer, index lists        9 Bluestein inverse output, scalar lists (no Bluestein call in between)
-  //   10 auxiliary-prime dot product output (kernels_ksaux.hip)
+  //   10 auxiliary-prime dot product output (kernels_ksaux.hip)      11 staging of host batches (fhesi_ct_mul_relin_batch)
   void* ws[FHESI_WS_SLOTS] = {};
   size_t ws_bytes[FHESI_WS_SLOTS] = {};
 };
@@ -274,6 +274,7 @@ int launch_rows_equal(fhesi_ctx* ctx, const u64* a, const u64* b, i64 nwords, in
 // kernels_ct.hip : coefficient-domain ciphertext algebra on device batches
 int launch_ct_add(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 ncoeffs, int nl, int logQ);
 int launch_ct_mul_long(fhesi_ctx* ctx, u64* d_ct, i64 ncoeffs, int nl, int logQ, i64 l);
+int launch_ct_add_const(fhesi_ctx* ctx, u64* d_ct /* [count][nparts][n][nl] */, const i64* d_poly /* [npoly][n] */, int npoly, int nparts, int nl, int logQ, u64 p, i64 count);
 int launch_ct_automorph_parts(fhesi_ctx* ctx, const u64* d_in /* [npolys][n][nl_in] */, int nl_in, i64 npolys, i64 kk, int logQ, u64* d_parts /* [npolys][nlq][n] */, int nlq);   // 2: ring not covered
 int launch_gather(fhesi_ctx* ctx, const u64* d_pool, const int* d_idx, i64 count, i64 words, u64* d_out);
 int launch_segment_sum(fhesi_ctx* ctx, const u64* d_in, const int* d_seg, i64 ngroups, int ncomp, u64* d_out);

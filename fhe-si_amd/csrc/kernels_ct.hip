@@ -180,6 +180,69 @@ int launch_ct_mul_long(fhesi_ctx* ctx, u64* d_ct, i64 ncoeffs, int nl, int logQ,
   return 0;
 }
 
+// ---- Ciphertext::operator+=(const ZZX&) on unscaled ciphertexts (Ciphertext.cpp:147-156): scaledConstant_j = (other_j << logQ) / p
+// with NTL's floor division, parts[0] += scaledConstant, ReduceCoefficients.  poly: [npoly][n] machine-word coefficients (npoly = 1:
+// one constant for the whole batch).  Only the quotient modulo 2^logQ matters; it is formed limb by limb from the top by 128 / 64-bit
+// long division of |other_j| 2^logQ, and a negative constant takes -(q + [remainder != 0]) (floor, not truncation).
+template <int MAXNL>
+__global__ void __launch_bounds__(256) ct_add_const_kernel(u64* __restrict__ ct, const i64* __restrict__ poly, int npoly, i64 n, int nparts, int nl, int logQ, u64 p) {
+  const i64 c = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const i64 cv = poly[(npoly == 1 ? 0 : c) * n + j];
+  const u64 mag = cv < 0 ? (u64)(-(cv + 1)) + 1 : (u64)cv;
+  // |cv| 2^logQ occupies limbs sh .. sh + 1 (sh = logQ / 64), shifted by logQ % 64 bits
+  const int sh = logQ >> 6, bs = logQ & 63;
+  const u64 lo = bs ? mag << bs : mag, hi = bs ? mag >> (64 - bs) : 0;
+  u64 q[MAXNL];
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i) q[i] = 0;
+  u64 rem = 0;
+  for (int i = sh + 1; i >= 0; --i) {
+    const u64 limb = i == sh + 1 ? hi : (i == sh ? lo : 0);
+    const u128 cur = ((u128)rem << 64) | limb;
+    const u64 ql = (u64)(cur / p);
+    rem = (u64)(cur % p);
+#pragma unroll
+    for (int t = 0; t < MAXNL; ++t) if (t == i) q[t] = ql;       // (limbs at or above nl only matter modulo 2^logQ: dropped)
+  }
+  if (cv < 0) {
+    // -(q + (rem != 0)) in two's complement
+    u64 carry = rem != 0;
+#pragma unroll
+    for (int t = 0; t < MAXNL; ++t) { const u64 v = q[t] + carry; carry = v < carry; q[t] = v; }
+    u64 cneg = 1;
+#pragma unroll
+    for (int t = 0; t < MAXNL; ++t) { const u64 v = ~q[t] + cneg; cneg = (cneg && v == 0); q[t] = v; }
+  }
+  u64* x0 = ct + ((c * nparts) * n + j) * nl;                     // part 0 of ciphertext c
+  u64 x[MAXNL];
+  u64 carry = 0;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i < nl) { const u64 a = x0[i], s1 = a + q[i], s2 = s1 + carry; carry = (s1 < a) | (s2 < s1); x[i] = s2; }
+  u64 sb = 0;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i == (logQ - 1) >> 6) sb = (x[i] >> ((logQ - 1) & 63)) & 1;
+#pragma unroll
+  for (int i = 0; i < MAXNL; ++i)
+    if (i < nl) x0[i] = reduce_limb(x[i], i, logQ, sb);
+}
+int launch_ct_add_const(fhesi_ctx* ctx, u64* d_ct, const i64* d_poly, int npoly, int nparts, int nl, int logQ, u64 p, i64 count) {
+  if (!count) return 0;
+  if (nl > 32) FHESI_FAIL("ciphertext coefficients of %d limbs exceed the supported 32", nl);
+  if (count > 65535) FHESI_FAIL("Ciphertext += ZZX: more than 65535 ciphertexts per call");
+  const dim3 grid((unsigned)((ctx->phim + 255) / 256), (unsigned)count);
+  // (the quotient needs limbs 0 .. logQ / 64 + 1 <= nl + 1: the instantiation one step above nl holds them)
+  if (nl < 2) ct_add_const_kernel<4><<<grid, 256, 0, ctx->stream>>>(d_ct, d_poly, npoly, ctx->phim, nparts, nl, logQ, p);
+  else if (nl < 7) ct_add_const_kernel<8><<<grid, 256, 0, ctx->stream>>>(d_ct, d_poly, npoly, ctx->phim, nparts, nl, logQ, p);
+  else if (nl < 15) ct_add_const_kernel<16><<<grid, 256, 0, ctx->stream>>>(d_ct, d_poly, npoly, ctx->phim, nparts, nl, logQ, p);
+  else ct_add_const_kernel<34><<<grid, 256, 0, ctx->stream>>>(d_ct, d_poly, npoly, ctx->phim, nparts, nl, logQ, p);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ---- gather: out[i] = pool[idx[i]], `words` u64 per element (operands of one wave of Matrix products)
 __global__ void __launch_bounds__(256) gather_kernel(const u64* __restrict__ pool, const int* __restrict__ idx, u64* __restrict__ out, i64 words) {
   const u64* __restrict__ s = pool + (i64)idx[blockIdx.y] * words;

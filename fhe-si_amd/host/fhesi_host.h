@@ -222,6 +222,13 @@ extern FHEcontext* activeContext;   // FHEContext.cpp:21
 // ---------------------------------------------------------------- ZZX <-> limb buffers
 inline int limbs_for(const ZZX& p) { long b = 1; for (auto& c : p.rep) b = std::max(b, c.bits() + 1); return (int)((b + 63) / 64); }
 inline std::vector<uint64_t> to_limbs(const ZZX& p, int nl) { std::vector<uint64_t> v(std::max<size_t>(1, p.rep.size()) * nl, 0); for (size_t i = 0; i < p.rep.size(); ++i) p.rep[i].to_limbs(&v[i * nl], nl); return v; }
+// n coefficients of p as nl two's complement limbs each (zero above the degree), without a ZZ copy per coefficient; and back
+inline void poly_to_limbs(const ZZX& p, uint64_t* dst, long n, int nl) {
+  const long have = std::min<long>(n, (long)p.rep.size());
+  for (long j = 0; j < have; ++j) p.rep[j].to_limbs(dst + (size_t)j * nl, nl);
+  if (have < n) std::fill(dst + (size_t)have * nl, dst + (size_t)n * nl, (uint64_t)0);
+}
+inline void limbs_to_poly(ZZX& p, const uint64_t* src, long n, int nl) { p.rep.resize(n); for (long j = 0; j < n; ++j) p.rep[j] = ZZ::from_limbs(src + (size_t)j * nl, nl); p.normalize(); }
 inline ZZX from_limbs(const std::vector<uint64_t>& v, long n, int nl) { ZZX p; p.rep.resize(n); for (long i = 0; i < n; ++i) p.rep[i] = ZZ::from_limbs(&v[i * nl], nl); p.normalize(); return p; }
 
 inline void Cmodulus::FFT(vec_long& y, const ZZX& x) const {
@@ -501,6 +508,7 @@ class CiphertextPart {
   CiphertextPart& operator+=(const ZZX& o) { poly += o; return *this; }
   CiphertextPart& operator+=(const CiphertextPart& o) { poly += o.poly; return *this; }
   CiphertextPart& operator*=(long l) { for (auto& c : poly.rep) { c *= ZZ(l); Reduce(c, context.logQ); } poly.normalize(); return *this; }   // Ciphertext.cpp:21-27
+  CiphertextPart& operator*=(const ZZX& o) { poly = mul(poly, o); rem(poly, poly, context.zMstar.PhimX()); for (auto& c : poly.rep) Reduce(c, context.logQ); poly.normalize(); return *this; }   // :29-36 (host form; Ciphertext::operator*=(ZZX) takes the device call)
   CiphertextPart& operator>>=(long k) { DoubleCRT tmp(poly); tmp >>= k; tmp.toPoly(poly); return *this; }                                    // :54-59
   bool operator==(const CiphertextPart& o) const { return poly == o.poly; }
 };
@@ -509,6 +517,7 @@ class Ciphertext {
   const FHEcontext* context;
   std::vector<DoubleCRT> tProd;
   bool scaledUp = false;
+  friend class KeySwitchSI;            // ApplyKeySwitch hands the scaled-up rows to the fused device call without a round trip through the host
  public:
   std::vector<CiphertextPart> parts;
   Ciphertext() : context(activeContext) {}
@@ -534,6 +543,26 @@ class Ciphertext {
     return *this;
   }
   Ciphertext& operator*=(const Ciphertext& o) {   // Ciphertext.cpp:167-192
+    if (!scaledUp && !o.scaledUp && parts.size() == 2 && o.parts.size() == 2) {
+      // two fresh ciphertexts (every multiplication the reference's drivers perform): the lift by p, the four DoubleCRT conversions and the
+      // tensor products as ONE device call (fhesi_ct_mul_dev) instead of 4 + 4 + 4 object operations; the same rows, bit for bit
+      // (tests/host/test_wire.cpp compares with the loop below)
+      fhesi_ctx* h = context->handle();
+      const long n = context->zMstar.phiM(), L = context->numPrimes(); const int nl = (int)((context->logQ + 63) / 64);
+      std::vector<uint64_t> host((size_t)2 * 2 * n * nl, 0);
+      for (int part = 0; part < 2; ++part) { poly_to_limbs(parts[part].poly, &host[(size_t)part * n * nl], n, nl); poly_to_limbs(o.parts[part].poly, &host[(size_t)(2 + part) * n * nl], n, nl); }
+      void *in, *tp; ck(fhesi_dev_alloc(h, host.size() * 8, &in)); ck(fhesi_dev_alloc(h, (size_t)3 * L * n * 8, &tp));
+      ck(fhesi_dev_upload(h, in, host.data(), host.size() * 8));
+      int rc = fhesi_ct_mul_dev(h, (uint64_t)context->ModulusP().to_long(), (const uint64_t*)in, (const uint64_t*)in + (size_t)2 * n * nl, nl, 1, (uint64_t*)tp);
+      if (!rc) { tProd.assign(3, DoubleCRT(*context)); for (int i = 0; i < 3 && !rc; ++i) rc = fhesi_dev_copy(h, fhesi_dcrt_device_ptr(tProd[i].handle()), (const uint64_t*)tp + (size_t)i * L * n, (size_t)L * n * 8); }
+      fhesi_dev_free(h, in); fhesi_dev_free(h, tp);
+      ck(rc);
+      parts.clear(); scaledUp = true;
+      return *this;
+    }
+    return MulObjects(o);
+  }
+  Ciphertext& MulObjects(const Ciphertext& o) {   // the reference's loop, one DoubleCRT object at a time
     std::vector<DoubleCRT> c1, c2;
     for (auto& p : parts) c1.push_back(DoubleCRT(p.poly * context->ModulusP(), *context));
     for (auto& p : o.parts) c2.push_back(DoubleCRT(p.poly, *context));
@@ -544,6 +573,53 @@ class Ciphertext {
     return *this;
   }
   Ciphertext& operator*=(long l) { if (!scaledUp) for (auto& p : parts) p *= l; else for (auto& t : tProd) t *= l; return *this; }   // :232-243
+  // operator+=(const ZZX&) (Ciphertext.cpp:147-161): the constant is scaled by q / p with NTL's floor division and added to part 0
+  // (unscaled: device call fhesi_ct_add_const_dev when the coefficients are machine words, else the same arithmetic on the host), or to
+  // tProd[0] (scaled-up: DoubleCRT += ZZX).  The std::vector<long> overloads take the role of the reference's ZZ_pX ones (:158-160, :256-258):
+  // the mirror's Plaintext holds its message as machine words.
+  Ciphertext& operator+=(const ZZX& other) {
+    std::vector<int64_t> small;
+    if (!scaledUp && words_of(other, small)) { with_parts_on_device([&](uint64_t* dev, int nl) {
+        ck(fhesi_ct_add_const_dev(context->handle(), (int32_t)context->logQ, (uint64_t)context->ModulusP().to_long(), dev, (int32_t)parts.size(), nl, 1, small.data(), 1)); });
+      return *this; }
+    ZZX sc(other);
+    for (auto& c : sc.rep) { c <<= (long)context->logQ; c /= context->ModulusP(); }     // floor division, like NTL
+    sc.normalize();
+    if (!scaledUp) { parts[0] += sc; ReduceCoefficients(parts[0].poly, context->logQ); } else tProd[0] += sc;
+    return *this;
+  }
+  Ciphertext& operator+=(const std::vector<long>& msg) { return *this += words_to_ZZX(msg); }
+  // operator*=(const ZZX&) (Ciphertext.cpp:245-258): unscaled -- every part times the polynomial over the integers, modulo Phi_m, Reduce
+  // (CiphertextPart::operator*=(ZZX), :29-36; device call fhesi_ct_mul_poly_dev); scaled-up -- tProd[i] *= DoubleCRT(other)
+  Ciphertext& operator*=(const ZZX& other) {
+    if (scaledUp) { DoubleCRT o(other, *context); for (auto& t : tProd) t *= o; return *this; }
+    std::vector<int64_t> small;
+    if (words_of(other, small)) with_parts_on_device([&](uint64_t* dev, int nl) { ck(fhesi_ct_mul_poly_dev(context->handle(), (int32_t)context->logQ, dev, (int32_t)parts.size(), nl, 1, small.data(), 1)); });
+    else for (auto& p : parts) p *= other;
+    return *this;
+  }
+  Ciphertext& operator*=(const std::vector<long>& msg) { return *this *= words_to_ZZX(msg); }
+ private:
+  static ZZX words_to_ZZX(const std::vector<long>& v) { ZZX p; p.rep.resize(v.size()); for (size_t i = 0; i < v.size(); ++i) p.rep[i] = ZZ(v[i]); p.normalize(); return p; }
+  // the polynomial as phi(m) machine words, if every coefficient fits one (a ZZ_pX message always does)
+  bool words_of(const ZZX& p, std::vector<int64_t>& out) const {
+    const long n = context->zMstar.phiM();
+    if ((long)p.rep.size() > n) return false;
+    out.assign(n, 0);
+    for (size_t i = 0; i < p.rep.size(); ++i) { if (p.rep[i].bits() > 62) return false; out[i] = (int64_t)p.rep[i].to_long(); }
+    return true;
+  }
+  // the unscaled parts as one device ciphertext [nparts][phi(m)][nl] around a device call, and back
+  template <class Fn> void with_parts_on_device(Fn fn) {
+    const long n = context->zMstar.phiM(); const int nl = (int)((context->logQ + 63) / 64); const size_t np = parts.size();
+    std::vector<uint64_t> host(np * n * nl, 0);
+    for (size_t i = 0; i < np; ++i) poly_to_limbs(parts[i].poly, &host[(i * n) * nl], n, nl);
+    void* dev; ck(fhesi_dev_alloc(context->handle(), host.size() * 8, &dev)); ck(fhesi_dev_upload(context->handle(), dev, host.data(), host.size() * 8));
+    fn((uint64_t*)dev, nl);
+    ck(fhesi_dev_download(context->handle(), host.data(), dev, host.size() * 8)); ck(fhesi_dev_free(context->handle(), dev));
+    for (size_t i = 0; i < np; ++i) limbs_to_poly(parts[i].poly, &host[(i * n) * nl], n, nl);
+  }
+ public:
   Ciphertext& operator>>=(long k) { if (!scaledUp) for (auto& p : parts) p >>= k; else for (auto& t : tProd) t >>= k; return *this; }   // :264-275
   void ScaleDown() {   // Ciphertext.cpp:194-218
     if (!scaledUp) return;
@@ -667,7 +743,7 @@ class KeySwitchSI {
   KeySwitchSI(const FHESISecKey& s) : context(s.GetContext()) { InitS2(s); }
   KeySwitchSI(const FHESISecKey& src, const FHESISecKey& dst) : context(src.GetContext()) { Init(src, dst); }
   const std::vector<std::vector<DoubleCRT>>& GetRepresentation() const { return keySwitchMatrix; }
-  void UpdateRepresentation(const std::vector<std::vector<DoubleCRT>>& rep) { keySwitchMatrix = rep; }
+  void UpdateRepresentation(const std::vector<std::vector<DoubleCRT>>& rep) { keySwitchMatrix = rep; drop_device_key(); }
   const FHEcontext& GetContext() const { return context; }
   // FHE-SI.cpp:153-209.  The randomness is drawn here in the reference's order (per column: the SampleRandom polynomial, then the
   // Gaussian error); the arithmetic of all columns -- 2 ncol L forward and ncol L inverse row transforms, products, CRT, the shifted
@@ -697,7 +773,7 @@ class KeySwitchSI {
         ck(fhesi_dev_copy(context.handle(), fhesi_dcrt_device_ptr(d.handle()), rows + ((size_t)r * ncol + col) * rowWords, rowWords * 8));
         keySwitchMatrix[r].push_back(d);
       }
-    fhesi_ksk_free(k);
+    drop_device_key(); devKey = k;                            // the device object the matrix was generated in serves the fused calls as it is
   }
   void InitObjects(const FHESISecKey& src, const FHESISecKey& dst) {   // the reference's loop, one object at a time
     std::vector<DoubleCRT> s = src.GetRepresentation(); std::vector<ZZX> sCoeff(s.size());
@@ -715,6 +791,7 @@ class KeySwitchSI {
         ReduceCoefficients(bCoeff, context.logQ);
         A.push_back(a); b.push_back(DoubleCRT(bCoeff, context));
       }
+    drop_device_key();
     keySwitchMatrix.clear(); keySwitchMatrix.push_back(b); keySwitchMatrix.push_back(A);
   }
   void InitS2(const FHESISecKey& s) {   // FHE-SI.cpp:211-227
@@ -732,12 +809,72 @@ class KeySwitchSI {
     automorphedKey.UpdateRepresentation(sKeys);
     InitAny(automorphedKey, s);
   }
-  void ApplyKeySwitch(Ciphertext& ctxt) const {   // FHE-SI.cpp:241-260
+  // ApplyKeySwitch (FHE-SI.cpp:241-260).  The reference's body -- ScaleDown, ByteDecomp, one DoubleCRT per digit polynomial, two DotProducts,
+  // toPoly, ReduceCoefficients -- is ApplyKeySwitchObjects below, one object at a time (2 s per call at the metric ring: the digits alone
+  // are 66 polynomials through the host).  ApplyKeySwitch itself hands the ciphertext to the fused device call with the matrix resident in
+  // HBM as one object (built on first use): the same bits (tests/host/test_wire.cpp compares the two), about 100 times faster.
+  void ApplyKeySwitch(Ciphertext& ctxt) const {
+    const size_t ncomp = keySwitchMatrix.empty() ? 0 : keySwitchMatrix[0].size() / context.ndigits;
+    if (objectAtATime || ncomp < 2 || ctxt.size() != ncomp) { ApplyKeySwitchObjects(ctxt); return; }
+    fhesi_ctx* h = context.handle(); fhesi_ksk* k = device_key();
+    const long n = context.zMstar.phiM(), L = context.numPrimes(); const int nl = (int)((context.logQ + 63) / 64);
+    void* out; ck(fhesi_dev_alloc(h, (size_t)2 * n * nl * 8, &out));
+    if (ctxt.scaledUp) {
+      void* rows; ck(fhesi_dev_alloc(h, ncomp * L * n * 8, &rows));
+      for (size_t i = 0; i < ncomp; ++i) ck(fhesi_dev_copy(h, (uint64_t*)rows + i * L * n, fhesi_dcrt_device_ptr(ctxt.tProd[i].handle()), (size_t)L * n * 8));
+      int rc = fhesi_apply_key_switch_dev(h, k, (int32_t)context.logQ, (int32_t)context.decompSize, (const uint64_t*)rows, 1, (uint64_t*)out, nl);
+      fhesi_dev_free(h, rows);
+      if (rc) { fhesi_dev_free(h, out); ck(rc); }
+    } else {
+      // an unscaled ciphertext (after an automorphism): ScaleDown returns at once (Ciphertext.cpp:195), ByteDecomp takes the positive residues
+      std::vector<uint64_t> host(ncomp * n * nl, 0);
+      for (size_t i = 0; i < ncomp; ++i) poly_to_limbs(ctxt.parts[i].poly, &host[(i * n) * nl], n, nl);
+      void* in; ck(fhesi_dev_alloc(h, host.size() * 8, &in)); ck(fhesi_dev_upload(h, in, host.data(), host.size() * 8));
+      int rc = fhesi_ct_automorph_key_switch_dev(h, k, (int32_t)context.logQ, (int32_t)context.decompSize, 1, (const uint64_t*)in, nl, 1, (uint64_t*)out, nl);
+      fhesi_dev_free(h, in);
+      if (rc) { fhesi_dev_free(h, out); ck(rc); }
+    }
+    std::vector<uint64_t> res((size_t)2 * n * nl);
+    ck(fhesi_dev_download(h, res.data(), out, res.size() * 8)); ck(fhesi_dev_free(h, out));
+    ctxt.tProd.clear(); ctxt.scaledUp = false; ctxt.parts.assign(2, CiphertextPart(context));
+    for (int r = 0; r < 2; ++r) limbs_to_poly(ctxt.parts[r].poly, &res[(size_t)r * n * nl], n, nl);
+  }
+  void ApplyKeySwitchObjects(Ciphertext& ctxt) const {   // the reference's loop, one object at a time
     ctxt.ScaleDown(); ctxt.ByteDecomp();
     std::vector<DoubleCRT> bd; for (auto& p : ctxt.parts) bd.push_back(DoubleCRT(p.poly, context));
     std::vector<CiphertextPart> newCtxt(keySwitchMatrix.size(), CiphertextPart(context));
     for (size_t i = 0; i < keySwitchMatrix.size(); ++i) { DoubleCRT dp(context); DotProduct(dp, keySwitchMatrix[i], bd); dp.toPoly(newCtxt[i].poly); ReduceCoefficients(newCtxt[i].poly, context.logQ); }
     ctxt.parts = newCtxt;
+  }
+  // a[i] *= b[i]; ApplyKeySwitch(a[i]) for every i in ONE device call (fhesi_ct_mul_relin_batch): what a loop over a Matrix<Ciphertext> row or a
+  // vector of ciphertexts should call instead of the two statements per object -- the objects cross the host boundary once per batch
+  void MulRelinBatch(std::vector<Ciphertext>& a, const std::vector<Ciphertext>& b) const {
+    if (a.size() != b.size()) Error("MulRelinBatch: the operand vectors differ in length");
+    const size_t count = a.size(); if (!count) return;
+    const long n = context.zMstar.phiM(); const int nl = (int)((context.logQ + 63) / 64);
+    std::vector<uint64_t> ha(count * 2 * n * nl, 0), hb(ha.size(), 0), ho(ha.size());
+    for (size_t c = 0; c < count; ++c) {
+      if (a[c].isScaledUp() || b[c].isScaledUp() || a[c].size() != 2 || b[c].size() != 2) Error("MulRelinBatch: operands must be unscaled two-part ciphertexts");
+      for (int part = 0; part < 2; ++part) { poly_to_limbs(a[c].parts[part].poly, &ha[((c * 2 + part) * n) * nl], n, nl); poly_to_limbs(b[c].parts[part].poly, &hb[((c * 2 + part) * n) * nl], n, nl); }
+    }
+    ck(fhesi_ct_mul_relin_batch(context.handle(), device_key(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), (int32_t)context.decompSize, ha.data(), hb.data(), ho.data(), nl, (int64_t)count));
+    for (size_t c = 0; c < count; ++c) for (int part = 0; part < 2; ++part) limbs_to_poly(a[c].parts[part].poly, &ho[((c * 2 + part) * n) * nl], n, nl);
+  }
+  ~KeySwitchSI() { if (devKey) fhesi_ksk_free(devKey); }
+  KeySwitchSI(const KeySwitchSI& o) : context(o.context), keySwitchMatrix(o.keySwitchMatrix), objectAtATime(o.objectAtATime) {}      // (the device object is rebuilt on first use)
+  KeySwitchSI& operator=(const KeySwitchSI& o) { if (&context != &o.context) Error("Incompatible contexts."); keySwitchMatrix = o.keySwitchMatrix; objectAtATime = o.objectAtATime; drop_device_key(); return *this; }
+ private:
+  mutable fhesi_ksk* devKey = nullptr;                         // keySwitchMatrix as one HBM-resident fhesi_ksk for the fused calls
+  void drop_device_key() const { if (devKey) { fhesi_ksk_free(devKey); devKey = nullptr; } }
+  fhesi_ksk* device_key() const {
+    if (devKey) return devKey;
+    const size_t ncol = keySwitchMatrix[0].size(), ncomp = ncol / context.ndigits; const size_t rowWords = (size_t)context.numPrimes() * context.zMstar.phiM();
+    ck(fhesi_ksk_create(context.handle(), (int32_t)ncomp, (int32_t)context.ndigits, &devKey));
+    uint64_t* rows = (uint64_t*)fhesi_ksk_device_ptr(devKey);
+    for (int r = 0; r < 2; ++r) for (size_t col = 0; col < ncol; ++col)
+      ck(fhesi_dev_copy(context.handle(), rows + ((size_t)r * ncol + col) * rowWords, fhesi_dcrt_device_ptr(keySwitchMatrix[r][col].handle()), rowWords * 8));
+    ck(fhesi_ksk_mark_dirty(devKey));
+    return devKey;
   }
 };
 

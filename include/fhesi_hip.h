@@ -177,6 +177,14 @@ int fhesi_apply_key_switch_dev(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ,
  * Unscaled ciphertexts: [count][nparts][phi(m)][nlimbs] two's complement; scaled-up ones (tProd): [count][3][L][phi(m)] rows. */
 int fhesi_ct_add_dev(fhesi_ctx* ctx, int32_t logQ, uint64_t* dst_dev, const uint64_t* src_dev, int32_t nparts, int32_t nlimbs, int64_t count);
                                                                                      /* Ciphertext::operator+= unscaled: Ciphertext.cpp:123-134 (scaled-up: fhesi_rows_op_dev) */
+int fhesi_ct_add_const_dev(fhesi_ctx* ctx, int32_t logQ, uint64_t p, uint64_t* ct_dev, int32_t nparts, int32_t nlimbs, int64_t count,
+                           const int64_t* poly_host /* [npoly][phi(m)] */, int32_t npoly /* 1 = the same constant for every ciphertext, or count */);
+                                                                                     /* Ciphertext::operator+=(const ZZX&) unscaled: Ciphertext.cpp:147-156 -- part 0 += (other << logQ) / p
+                                                                                        (floor), ReduceCoefficients; the scaled-up branch (:157-159) is DoubleCRT += ZZX = fhesi_dcrt_from_poly + fhesi_dcrt_op */
+int fhesi_ct_mul_poly_dev(fhesi_ctx* ctx, int32_t logQ, uint64_t* ct_dev, int32_t nparts, int32_t nlimbs, int64_t count,
+                          const int64_t* poly_host /* [npoly][phi(m)] */, int32_t npoly);
+                                                                                     /* Ciphertext::operator*=(const ZZX&) unscaled: Ciphertext.cpp:245-249 -> CiphertextPart::operator*=(ZZX) :29-36
+                                                                                        (integer product, rem Phi_m, Reduce); scaled-up (:250-254): tProd[i] *= DoubleCRT(other) = fhesi_dcrt_op */
 int fhesi_ct_mul_long_dev(fhesi_ctx* ctx, int32_t logQ, uint64_t* ct_dev, int64_t l, int32_t nparts, int32_t nlimbs, int64_t count);
                                                                                      /* Ciphertext::operator*=(long) unscaled: Ciphertext.cpp:232-237 -> :21-27 */
 int fhesi_rows_mul_long_dev(fhesi_ctx* ctx, uint64_t* rows_dev, int64_t l, int64_t count);   /* ... scaled-up: Ciphertext.cpp:238-241 (DoubleCRT *= long); count DoubleCRTs */

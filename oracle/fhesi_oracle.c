@@ -581,6 +581,39 @@ void orc_ct_mul_long(const orc_ctx* c, u64* a, i64 l, int nparts, int nlimbs, in
   for (i64 j = 0; j < (i64)nparts * n; j++) { bn_copy_ext(x, W, a + j * nlimbs, nlimbs); int s = bn_sign(x, W); if (s) bn_neg(x, W); bn_mul_u64(x, mag, W); if (s != (l < 0)) bn_neg(x, W);
     reduce_logq(x, W, logQ, 0); memcpy(a + j * nlimbs, x, 8 * nlimbs); }
 }
+/* Ciphertext::operator+=(const ZZX&) on an unscaled ciphertext (Ciphertext.cpp:147-156): scaledConstant[i] = (other[i] << logQ) / p with
+ * NTL's floor division (the quotient of a negative numerator rounds towards minus infinity), parts[0] += scaledConstant,
+ * ReduceCoefficients.  a: [nparts][phim][nlimbs], only part 0 changes; poly: [phim] machine-word coefficients */
+void orc_ct_add_const(const orc_ctx* c, u64* a, const i64* poly, int nlimbs, int logQ, u64 p) {
+  i64 n = c->phim; int W = nlimbs + 3; u64 x[W], q[W];
+  for (i64 j = 0; j < n; j++) {
+    i64 v = poly[j]; u64 mag = v < 0 ? (u64)(-(v + 1)) + 1 : (u64)v;
+    memset(x, 0, 8 * W); x[0] = mag; bn_shl(x, W, logQ);                         /* |other| << logQ  (NTL shifts the magnitude) */
+    u64 rem = 0; for (int i = W - 1; i >= 0; i--) { u128 cur = ((u128)rem << 64) | x[i]; q[i] = (u64)(cur / p); rem = (u64)(cur % p); }
+    if (v < 0) { if (rem) { u64 one[W]; memset(one, 0, 8 * W); one[0] = 1; bn_add(q, one, W); } bn_neg(q, W); }   /* floor(-|x| / p) = -ceil(|x| / p) */
+    bn_copy_ext(x, W, a + j * nlimbs, nlimbs); bn_add(x, q, W); reduce_logq(x, W, logQ, 0); memcpy(a + j * nlimbs, x, 8 * nlimbs);
+  }
+}
+/* Ciphertext::operator*=(const ZZX&) on an unscaled ciphertext (Ciphertext.cpp:245-249) = CiphertextPart::operator*=(const ZZX&) (:29-36) on
+ * every part: poly *= other as integer polynomials, rem(poly, poly, PhimX), Reduce of every coefficient.  Schoolbook product and long
+ * division by the monic Phi_m on fixed-width big integers.  a: [nparts][phim][nlimbs]; poly: [phim] machine words */
+void orc_ct_mul_poly(const orc_ctx* c, u64* a, const i64* poly, int nparts, int nlimbs, int logQ) {
+  i64 n = c->phim; int W = nlimbs + 3; i64 len = 2 * n - 1;
+  u64* prod = malloc(8 * (size_t)len * W); u64 x[W];
+  for (int part = 0; part < nparts; part++) {
+    u64* ap = a + (i64)part * n * nlimbs;
+    memset(prod, 0, 8 * (size_t)len * W);
+    for (i64 i = 0; i < n; i++) { bn_copy_ext(x, W, ap + i * nlimbs, nlimbs); int neg = bn_sign(x, W); if (neg) bn_neg(x, W);
+      for (i64 j = 0; j < n; j++) { i64 b = poly[j]; if (!b) continue; bn_addmul_i64(prod + (i + j) * W, x, neg ? -b : b, W); } }
+    for (i64 d = len - 1; d >= n; d--) {                                           /* rem by the monic Phi_m (degree n = phi(m)) */
+      u64* lead = prod + d * W; int neg = bn_sign(lead, W); memcpy(x, lead, 8 * W); if (neg) bn_neg(x, W);
+      for (i64 t = 0; t < n; t++) { i64 f = c->phi[t]; if (f) bn_addmul_i64(prod + (d - n + t) * W, x, neg ? f : -f, W); }
+      memset(lead, 0, 8 * W);
+    }
+    for (i64 i = 0; i < n; i++) { reduce_logq(prod + i * W, W, logQ, 0); memcpy(ap + i * nlimbs, prod + i * W, 8 * nlimbs); }
+  }
+  free(prod);
+}
 /* Ciphertext::operator>>= on an unscaled ciphertext (Ciphertext.cpp:264-269; CiphertextPart::operator>>= :54-59):
  * DoubleCRT(poly) >>= k; toPoly.  in: [nparts][phim][nlimbs], out: [nparts][phim][nlimbs_out] (centred modulo the chain) */
 int orc_ct_automorph(const orc_ctx* c, const u64* in, i64 k, int nparts, int nlimbs, u64* out, int nlimbs_out) {

@@ -692,6 +692,22 @@ def ct_mul_long(ctx: Ctx, parts: Sequence[Sequence[int]], l: int) -> List[List[i
     return [[reduce_logq(c * l, ctx.logQ) for c in part] for part in parts]
 
 
+def ct_add_const(ctx: Ctx, parts: Sequence[Sequence[int]], other: Sequence[int]) -> List[List[int]]:
+    """Ciphertext::operator+=(const ZZX&) on an unscaled ciphertext (Ciphertext.cpp:147-156): scaledConstant[i] = (other[i] << logQ) / p
+    -- NTL shifts the magnitude and divides with floor, which is what Python's << and // do on signed integers -- then
+    parts[0] += scaledConstant; ReduceCoefficients."""
+    sc = [(int(c) << ctx.logQ) // ctx.p for c in other]
+    out = [list(part) for part in parts]
+    out[0] = [reduce_logq(x + (sc[i] if i < len(sc) else 0), ctx.logQ) for i, x in enumerate(out[0])]
+    return out
+
+
+def ct_mul_poly(ctx: Ctx, parts: Sequence[Sequence[int]], other: Sequence[int]) -> List[List[int]]:
+    """Ciphertext::operator*=(const ZZX&) on an unscaled ciphertext (Ciphertext.cpp:245-249) = CiphertextPart::operator*=(const ZZX&)
+    (:29-36) on every part: poly *= other over the integers; rem(poly, poly, PhimX); Reduce of every coefficient."""
+    return [[reduce_logq(c, ctx.logQ) for c in poly_mul_mod_phi(ctx, list(part), [int(x) for x in other])] for part in parts]
+
+
 def tprod_mul_long(ctx: Ctx, tprod: Sequence[dict], l: int) -> List[dict]:
     """Ciphertext::operator*=(long) on a scaled-up ciphertext (Ciphertext.cpp:238-241): DoubleCRT *= long."""
     return [dcrt_op_scalar(ctx, t, l, "mul") for t in tprod]

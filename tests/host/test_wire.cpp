@@ -102,6 +102,20 @@ int main(int argc, char* argv[]) {
     for (int r = 0; same && r < 2; ++r) for (size_t c = 0; same && c < A[r].size(); ++c) same = A[r][c] == B[r][c];
     if (!same) { std::cout << "batched KeySwitchSI::Init differs from the object-at-a-time loop" << std::endl; ++failures; }
   }
+  // ApplyKeySwitch through the fused device call (the form that runs) equals the reference's object-at-a-time body, on a scaled-up product
+  // and on an unscaled three-part ciphertext; MulRelinBatch gives the same ciphertexts again
+  {
+    Ciphertext x = c1; x *= c2; Ciphertext y = c1; y.MulObjects(c2);          // (operator*= is one device call; MulObjects the reference's loop)
+    ks2.ApplyKeySwitch(x); ks2.ApplyKeySwitchObjects(y);
+    if (!(x.size() == 2 && y.size() == 2 && x[0] == y[0] && x[1] == y[1])) { std::cout << "ApplyKeySwitch (device) differs from the object-at-a-time body on a scaled-up ciphertext" << std::endl; ++failures; }
+    Ciphertext u = prod, v = prod;
+    ks2.ApplyKeySwitch(u); ks2.ApplyKeySwitchObjects(v);
+    if (!(u.size() == 2 && v.size() == 2 && u[0] == v[0] && u[1] == v[1])) { std::cout << "ApplyKeySwitch (device) differs from the object-at-a-time body on an unscaled ciphertext" << std::endl; ++failures; }
+    std::vector<Ciphertext> va{c1, c2, c1}, vb{c2, c2, c1};
+    ks2.MulRelinBatch(va, vb);
+    Ciphertext z = c2; z *= c2; ks2.ApplyKeySwitch(z);
+    if (!(va[0][0] == x[0] && va[0][1] == x[1] && va[1][0] == z[0] && va[1][1] == z[1])) { std::cout << "MulRelinBatch differs from operator*= + ApplyKeySwitch" << std::endl; ++failures; }
+  }
   // the imported product has 3 parts (it was scaled down on export): relinearise it with the imported matrix
   if (prod.parts.size() != 3) { std::cout << "imported product has " << prod.parts.size() << " parts" << std::endl; ++failures; }
   ks2.ApplyKeySwitch(prod);

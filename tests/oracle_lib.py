@@ -67,6 +67,8 @@ def lib():
         _lib.orc_decrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         _lib.orc_ct_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib.orc_ct_mul_long.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
+        _lib.orc_ct_add_const.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+        _lib.orc_ct_mul_poly.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib.orc_ct_automorph.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _lib.orc_ct_automorph.restype = C.c_int
         _lib.orc_apply_key_switch_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -299,6 +301,20 @@ class Oracle:
     def ct_mul_long(self, a: np.ndarray, l: int, logQ: int) -> np.ndarray:
         a = np.array(a, dtype=np.uint64, copy=True)
         lib().orc_ct_mul_long(self.h, _p(a), l, a.shape[0], a.shape[-1], logQ)
+        return a
+
+    def ct_add_const(self, a: np.ndarray, poly, logQ: int, p: int) -> np.ndarray:
+        """Ciphertext::operator+=(const ZZX&), unscaled (Ciphertext.cpp:147-156); a [nparts][phim][nlimbs], poly [phim] int64"""
+        a = np.array(a, dtype=np.uint64, copy=True)
+        poly = np.ascontiguousarray(poly, dtype=np.int64)
+        lib().orc_ct_add_const(self.h, _p(a), _p(poly), a.shape[-1], logQ, p)
+        return a
+
+    def ct_mul_poly(self, a: np.ndarray, poly, logQ: int) -> np.ndarray:
+        """Ciphertext::operator*=(const ZZX&), unscaled (Ciphertext.cpp:245-249, :29-36)"""
+        a = np.array(a, dtype=np.uint64, copy=True)
+        poly = np.ascontiguousarray(poly, dtype=np.int64)
+        lib().orc_ct_mul_poly(self.h, _p(a), _p(poly), a.shape[0], a.shape[-1], logQ)
         return a
 
     def ct_automorph(self, a: np.ndarray, k: int, nlimbs_out: int) -> np.ndarray:

@@ -176,3 +176,41 @@ def test_wave_of_products_sum_and_key_switch(chunk, operands, monkeypatch):
     g_out = ctx.alloc(3 * 2 * n * nl * 8)
     ctx.ct_gather_dev(dpool, [5, 0, 5], 2 * n * nl, g_out)
     assert np.array_equal(g_out.download((3, 2, n, nl)), pool[[5, 0, 5]])
+
+
+@pytest.mark.parametrize("m,logQ,p", [(4096, 128, 23), (2026, 120, 2027), (32768, 512, 23), (45, 100, 7), (101, 90, 7)])
+def test_ct_add_const_and_mul_poly_vs_oracle(m, logQ, p):
+    """Ciphertext::operator+=(const ZZX&) / operator*=(const ZZX&) on unscaled device batches (Ciphertext.cpp:147-156, 245-249 ->
+    CiphertextPart::operator*=(ZZX) :29-36) against the C oracle's literal restatement (floor-divided scaled constant; integer product,
+    rem Phi_m, Reduce): power-of-two rings incl. the metric ring, Test_General's ring (p = 2027, m = 2026), a composite and a prime m;
+    one constant for the whole batch and one per ciphertext; messages in [0, p) (what a ZZ_pX holds) and signed ones."""
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nl, count = ctx.phim, (logQ + 63) // 64, 3
+    rng = np.random.default_rng(m + logQ)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    a[0, 0, 0] = O.ints_to_limbs([-(1 << (logQ - 1))], nl)[0]
+    a[0, 1, 0] = O.ints_to_limbs([(1 << (logQ - 1)) - 1], nl)[0]
+    small = n > 8192            # the oracle's schoolbook product is quadratic: one part of one ciphertext at the metric ring
+    for npoly in (1, count):
+        poly = rng.integers(0, p, size=(npoly, n)).astype(np.int64)
+        poly[0, :3] = [-(p - 1), p - 1, -1]
+        poly[-1, n // 2:] = 0
+        buf = ctx.upload(a)
+        ctx.ct_add_const_dev(logQ, p, buf, 2, nl, count, poly)
+        got = buf.download(a.shape)
+        for c in range(count):
+            assert np.array_equal(got[c], orc.ct_add_const(a[c], poly[c % npoly], logQ, p)), (npoly, c)
+        buf = ctx.upload(a)
+        ctx.ct_mul_poly_dev(logQ, buf, 2, nl, count, poly)
+        got = buf.download(a.shape)
+        for c in ((count - 1,) if small else range(count)):
+            want = orc.ct_mul_poly(a[c][:1] if small else a[c], poly[c % npoly], logQ)
+            assert np.array_equal(got[c][:want.shape[0]], want), (npoly, c)
+    # the largest machine-word constants still fit the chain (it is sized for logQ-bit x logQ-bit products, FHEContext.cpp:83-85)
+    if m == 4096:
+        big = np.full((1, n), -(1 << 62), dtype=np.int64)
+        buf = ctx.upload(a[:1])
+        ctx.ct_mul_poly_dev(logQ, buf, 2, nl, 1, big)
+        assert np.array_equal(buf.download(a[:1].shape)[0], orc.ct_mul_poly(a[0], big[0], logQ))

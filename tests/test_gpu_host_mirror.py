@@ -32,6 +32,19 @@ def test_addmul_power_of_two_ring():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("args", [["1"], ["2"], ["5", "47", "5", "90"]])      # Test_General's own p = 2027, g = 3, logQ = 120 (seeds 1, 2); a small ring m = 46
+def test_general_sequence(args):
+    """Test_General.cpp:16-101 on the mirror: ciphertext x ciphertext + key switch, `+= constant`, `*= constant`, rotation + automorphism key
+    switch, negation, and the final combination; every ciphertext decrypts to the plaintext-side value, and the device forms of
+    Ciphertext::operator+=(ZZX) / operator*=(ZZX) equal the host forms that follow Ciphertext.cpp:29-36,147-156 literally."""
+    build()
+    r = subprocess.run([os.path.join(HOST, "test_general"), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "All tests finished. Test SUCCEEDED" in r.stdout
+    if len(args) == 1:
+        assert "m=2026 phi(m)=1012 logQ=120" in r.stdout
+
+
 def test_dump_matches_python_model_fixture():
     build()
     fx = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "ciphertext.json")))["mul_relin"] if c["m"] == 22][0]
