@@ -306,6 +306,7 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
     # (the 32-bit digit rows have 2^14 elements, also on the zero-padded linear-convolution rings; the bytes counted are the rows' own)
     row_elems = max(n, 1 << 14) if kname.startswith("ntt32_") else n
     achieved = rows * 2 * row_elems * (4 if kname.startswith("ntt32_") else 8) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    ks_form, ks_rows, ks_limb_bits = ksk.form()
     if rank == 0:
         ksw = stats["key_switches"] + stats["automorph_key_switches"]
         line = {

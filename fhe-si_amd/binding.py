@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_comm_init_all", "fhesi_comm_from_rccl", "fhesi_comm_destroy", "fhesi_comm_rank",
     "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
     "fhesi_ksk_form", "fhesi_ct_add_const_dev", "fhesi_ct_mul_poly_dev",
+    "fhesi_encrypt_batch_seeded", "fhesi_keyswitch_init_batch_seeded", "fhesi_dcrt_sample",
 ]
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
@@ -159,6 +160,9 @@ def _load():
         "fhesi_dcrt_scale_down_to_set": [_vp, _vp, _i32, _u64],
         "fhesi_ksk_upload_dev": [_vp, _vp],
         "fhesi_ksk_form": [_vp, _vp, _vp, _vp],
+        "fhesi_encrypt_batch_seeded": [_vp, _vp, _vp, _i32, _u64, _u64, _u64, _vp, _i64, _vp, _i32],
+        "fhesi_keyswitch_init_batch_seeded": [_vp, _vp, _i32, _vp, _i32, _i32, _u64, _u64],
+        "fhesi_dcrt_sample": [_vp, _i32, _i64, _u64, _u64],
         "fhesi_ct_add_const_dev": [_vp, _i32, _u64, _vp, _i32, _i32, _i64, _vp, _i32],
         "fhesi_ct_mul_poly_dev": [_vp, _i32, _vp, _i32, _i32, _i64, _vp, _i32],
     }
@@ -354,6 +358,11 @@ class Context:
         assert rand.shape[0] == msg.shape[0] and rand.shape[1] == 3
         _ck(_load().fhesi_encrypt_batch(self.h, pk0.h, pk1.h, logQ, p, _p(rand), _p(msg), msg.shape[0], out.ptr, nlimbs))
 
+    def encrypt_batch_seeded(self, pk0: "DoubleCRT", pk1: "DoubleCRT", logQ: int, p: int, seed: int, first_index: int, msg: np.ndarray, out: DevBuf, nlimbs: int):
+        """FHESIPubKey::Encrypt with r, e0, e1 drawn on the device from (seed, first_index + i) -- philox.h."""
+        msg = np.ascontiguousarray(msg, dtype=np.int64)
+        _ck(_load().fhesi_encrypt_batch_seeded(self.h, pk0.h, pk1.h, logQ, p, seed, first_index, _p(msg), msg.shape[0], out.ptr, nlimbs))
+
     def decrypt_batch(self, sk1: "DoubleCRT", logQ: int, p: int, ct: DevBuf, nlimbs: int, count: int) -> np.ndarray:
         msg = np.zeros((count, self.phim), dtype=np.int64)
         _ck(_load().fhesi_decrypt_batch(self.h, sk1.h, logQ, p, ct.ptr, nlimbs, count, _p(msg)))
@@ -471,6 +480,11 @@ class DoubleCRT:
         out = np.zeros(self.ctx.phim, dtype=np.uint64)
         _ck(_load().fhesi_dcrt_download_row(self.h, prime, _p(out)))
         return out
+
+    def sample(self, kind: int, param: int, seed: int, index: int):
+        """DoubleCRT::sampleHWt(param) (kind 0) / sampleGaussian() (kind 1) drawn on the device from (seed, index) -- philox.h."""
+        _ck(_load().fhesi_dcrt_sample(self.h, kind, param, seed, index))
+        return self
 
     def set_row(self, prime: int, row: np.ndarray):
         row = np.ascontiguousarray(row, dtype=np.uint64)
@@ -686,6 +700,12 @@ class KeySwitchMatrix:
         assert a.shape[0] == err.shape[0] == self.ncomp * self.ndigits
         hs = (_vp * len(src))(*[d.h for d in src])
         _ck(_load().fhesi_keyswitch_init_batch(self.h, hs, len(src), dst_t.h, logQ, decomp_bytes, _p(a), a.shape[-1], _p(err)))
+        return self
+
+    def init_batch_seeded(self, src, dst_t: "DoubleCRT", logQ: int, seed: int, first_index: int = 0, decomp_bytes: int = 3):
+        """KeySwitchSI::Init with the column randomness drawn on the device from (seed, first_index + column) -- philox.h."""
+        hs = (_vp * len(src))(*[d.h for d in src])
+        _ck(_load().fhesi_keyswitch_init_batch_seeded(self.h, hs, len(src), dst_t.h, logQ, decomp_bytes, seed, first_index))
         return self
 
     FORMS = {-1: "none yet", 0: "per chain prime", 1: "four 30-bit auxiliary primes, limbs", 2: "two largest chain primes, limbs", 3: "two largest chain primes, residues"}

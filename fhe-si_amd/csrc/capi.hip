@@ -1445,8 +1445,8 @@ extern "C" int fhesi_ct_gather_dev(fhesi_ctx* c, const uint64_t* pool, const int
 // --------------------------------------------------------------------------------------------- Encrypt / Decrypt batches
 // FHESIPubKey::Encrypt (FHE-SI.cpp:10-36) for `count` plaintexts; the randomness is the caller's (the reference draws it from NTL's
 // PRNG): rand_host = [count][3][phi(m)] int64 = (r binary, e0, e1 Gaussian samples before the multiplication by p)
-extern "C" int fhesi_encrypt_batch(fhesi_ctx* c, const fhesi_dcrt* pk0, const fhesi_dcrt* pk1, int32_t logQ, uint64_t p, const int64_t* rand_host,
-                                   const int64_t* msg_host, int64_t count, uint64_t* out_dev, int32_t nlimbs) {
+static int encrypt_batch_impl(fhesi_ctx* c, const fhesi_dcrt* pk0, const fhesi_dcrt* pk1, int32_t logQ, uint64_t p, const int64_t* rand_host, bool seeded, u64 seed, u64 first,
+                              const int64_t* msg_host, int64_t count, uint64_t* out_dev, int32_t nlimbs) {
   CHECK_CTX(c);
   if (!pk0 || !pk1 || pk0->ctx != c || pk1->ctx != c) FHESI_FAIL("Encrypt: public key belongs to another context");
   if ((int)pk0->idx.size() != c->L || (int)pk1->idx.size() != c->L) FHESI_FAIL("Encrypt: public key must be defined over all primes");
@@ -1467,7 +1467,8 @@ extern "C" int fhesi_encrypt_batch(fhesi_ctx* c, const fhesi_dcrt* pk0, const fh
   std::vector<u64> delta(nlimbs, 0);
   { u128 rem = 0; for (int i = nlimbs - 1; i >= 0; --i) { const u64 limb = (i == logQ / 64) ? (1ull << (logQ % 64)) : 0; const u128 cur = (rem << 64) | limb; delta[i] = (u64)(cur / p); rem = cur % p; }
     if (logQ == 64 * nlimbs) { /* 2^logQ needs limb nlimbs: redo with the extra limb */ rem = 1; for (int i = nlimbs - 1; i >= 0; --i) { const u128 cur = rem << 64; delta[i] = (u64)(cur / p); rem = cur % p; } } }
-  HIP_TRY(hipMemcpyAsync(d_small, rand_host, (size_t)count * 3 * n * 8, hipMemcpyHostToDevice, c->stream));
+  if (seeded) FHESI_TRY(launch_sample_encrypt(c, (i64*)d_small, count, seed, first));      // r, e0, e1 drawn in HBM (kernels_sample.hip)
+  else HIP_TRY(hipMemcpyAsync(d_small, rand_host, (size_t)count * 3 * n * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d_msg, msg_host, (size_t)count * n * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d_delta, delta.data(), (size_t)nlimbs * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d_pk, pk0->d_rows, (size_t)L * n * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -1484,6 +1485,17 @@ extern "C" int fhesi_encrypt_batch(fhesi_ctx* c, const fhesi_dcrt* pk0, const fh
   FHESI_TRY(launch_add_scaled_msg(c, (u64*)out_dev, (const i64*)d_msg, (const u64*)d_delta, count, nlimbs, logQ));   // += delta*msg, Reduce (:31-35)
   HIP_TRY(hipStreamSynchronize(c->stream));      // the host arrays may be released on return
   return 0;
+}
+
+extern "C" int fhesi_encrypt_batch(fhesi_ctx* c, const fhesi_dcrt* pk0, const fhesi_dcrt* pk1, int32_t logQ, uint64_t p, const int64_t* rand_host,
+                                   const int64_t* msg_host, int64_t count, uint64_t* out_dev, int32_t nlimbs) {
+  if (!rand_host) FHESI_FAIL("Encrypt: null randomness (fhesi_encrypt_batch_seeded draws it on the device)");
+  return encrypt_batch_impl(c, pk0, pk1, logQ, p, rand_host, false, 0, 0, msg_host, count, out_dev, nlimbs);
+}
+// ... with the randomness drawn on the device: plaintext i takes the streams of object index first_index + i (philox.h)
+extern "C" int fhesi_encrypt_batch_seeded(fhesi_ctx* c, const fhesi_dcrt* pk0, const fhesi_dcrt* pk1, int32_t logQ, uint64_t p, uint64_t seed, uint64_t first_index,
+                                          const int64_t* msg_host, int64_t count, uint64_t* out_dev, int32_t nlimbs) {
+  return encrypt_batch_impl(c, pk0, pk1, logQ, p, nullptr, true, seed, first_index, msg_host, count, out_dev, nlimbs);
 }
 
 // FHESISecKey::Decrypt (FHE-SI.cpp:93-119) of `count` unscaled 2-part ciphertexts [count][2][phi(m)][nlimbs] in HBM
@@ -1517,8 +1529,8 @@ extern "C" int fhesi_decrypt_batch(fhesi_ctx* c, const fhesi_dcrt* sk1, int32_t 
 }
 
 // KeySwitchSI::Init (FHE-SI.cpp:153-209) for all columns of a matrix at once; the randomness is the caller's, in the reference's draw order
-extern "C" int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
-                                          const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host) {
+static int keyswitch_init_impl(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
+                               const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host, bool seeded, u64 seed, u64 first) {
   if (!k) FHESI_FAIL("null key-switch matrix");
   fhesi_ctx* c = k->ctx;
   CHECK_CTX(c);
@@ -1549,8 +1561,11 @@ extern "C" int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const*
   FHESI_TRY(row_inv(c, (u64*)d_s, nsrc, L, nullptr, all.data()));
   FHESI_TRY(launch_crt(c, t, (const u64*)d_s, L, nullptr, nsrc, 0, 0, 0, (u64*)d_scoef, W));
   // A[ind] = DoubleCRT(poly)   (:176-179)
-  HIP_TRY(hipMemcpyAsync(d_in, a_host, (size_t)ncol * n * nlimbs * 8, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(d_err, err_host, (size_t)ncol * n * 8, hipMemcpyHostToDevice, c->stream));
+  if (seeded) FHESI_TRY(launch_sample_keygen(c, (u64*)d_in, (i64*)d_err, ncol, nlimbs, logQ, seed, first));      // polynomials and errors drawn in HBM
+  else {
+    HIP_TRY(hipMemcpyAsync(d_in, a_host, (size_t)ncol * n * nlimbs * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_err, err_host, (size_t)ncol * n * 8, hipMemcpyHostToDevice, c->stream));
+  }
   FHESI_TRY(launch_rns_reduce(c, (const u64*)d_in, nlimbs, n, ncol, 1, nullptr, d_A, L, nullptr));
   FHESI_TRY(row_fwd(c, d_A, ncol, L, nullptr, all.data()));
   // b[ind] = A[ind] * t; toPoly   (:180-187)
@@ -1566,6 +1581,36 @@ extern "C" int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const*
   FHESI_TRY(fhesi_rows_mul_long_dev(c, d_A, -1, ncol));
   k->aux_valid = false;
   HIP_TRY(hipStreamSynchronize(c->stream));             // the host arrays and the scratch may be released on return
+  return 0;
+}
+extern "C" int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
+                                          const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host) {
+  if (!a_host || !err_host) FHESI_FAIL("KeySwitchSI::Init: null randomness (fhesi_keyswitch_init_batch_seeded draws it on the device)");
+  return keyswitch_init_impl(k, src, nsrc, dst_t, logQ, decomp_bytes, a_host, nlimbs, err_host, false, 0, 0);
+}
+// ... with the column randomness drawn on the device: column i takes the streams of object index first_index + i (philox.h)
+extern "C" int fhesi_keyswitch_init_batch_seeded(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
+                                                 uint64_t seed, uint64_t first_index) {
+  return keyswitch_init_impl(k, src, nsrc, dst_t, logQ, decomp_bytes, nullptr, (logQ + 63) / 64, nullptr, true, seed, first_index);
+}
+// DoubleCRT::sampleHWt / sampleGaussian (DoubleCRT.h; NumbTh.cpp:340-404) with the polynomial drawn on the device: kind 0 = Hamming weight
+// `param` with +-1 entries (the secret key, FHE-SI.cpp:90), kind 1 = rounded Gaussian with the context's stdev 3.2 (FHEContext.h:106)
+extern "C" int fhesi_dcrt_sample(fhesi_dcrt* d, int32_t kind, int64_t param, uint64_t seed, uint64_t index) {
+  if (!d) FHESI_FAIL("null DoubleCRT");
+  fhesi_ctx* c = d->ctx;
+  CHECK_CTX(c);
+  if (d->coeff_form) FHESI_FAIL("sample: the object is a SingleCRT");
+  if (kind == 0 && param < 0) FHESI_FAIL("sampleHWt: negative weight");
+  const i64 n = c->phim;
+  const int K = (int)d->idx.size();
+  void* d_poly;
+  FHESI_TRY(ws_reserve(c, 9, (size_t)n * 8, &d_poly));
+  FHESI_TRY(launch_sample_poly(c, (i64*)d_poly, kind, param, seed, index));
+  int* d_pos = nullptr;
+  FHESI_TRY(upload_idx(c, d->idx, &d_pos));
+  FHESI_TRY(launch_rns_reduce(c, (const u64*)d_poly, 1, n, 1, 1, nullptr, d->d_rows, K, d_pos));
+  FHESI_TRY(row_fwd(c, d->d_rows, 1, K, d_pos, d->idx.data()));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -28,6 +28,7 @@ struct RcclApi {
   int (*CommUserRank)(nccl_comm_t, int*) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -51,6 +52,7 @@ RcclApi* rccl() {
     api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
     api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
     api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
     api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
@@ -59,21 +61,35 @@ RcclApi* rccl() {
   return api.lib ? &api : nullptr;
 }
 
-// ranks of one process that share a device: publish buffer pointers, meet at a host barrier, copy
+// ranks of one process that share a device: publish buffer pointers, meet at a host barrier, copy.  A rank whose part of a collective
+// fails still takes every barrier of that collective (its peers would wait for ever otherwise) and records the failure; after the last
+// barrier every rank of the group returns an error for that collective.
 struct LoopGroup {
   int nranks = 0, refs = 0;
   std::mutex mu;
   std::condition_variable cv;
   int arrived = 0;
   long generation = 0;
+  std::atomic<long> failed_at{-1};     // generation of the closing barrier of a collective in which some rank failed
   std::vector<void*> ptr;
-  void barrier() {
+  long barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const long gen = generation;
     if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
     else cv.wait(lk, [&] { return generation != gen; });
+    return gen;
+  }
+  // closing barrier of a collective: rc = this rank's status; returns non-zero on EVERY rank when any rank failed
+  int close(int rc) {
+    long gen_now;
+    { std::lock_guard<std::mutex> lk(mu); gen_now = generation; }
+    if (rc) failed_at.store(gen_now);
+    const long gen = barrier();
+    if (!rc && failed_at.load() == gen) { fhesi_set_error("loopback collective: another rank of the group failed"); return 1; }
+    return rc;
   }
 };
+#define HIP_SOFT(rc, expr) do { if (!(rc)) { hipError_t e__ = (expr); if (e__ != hipSuccess) { fhesi_set_error("%s failed: %s", #expr, hipGetErrorString(e__)); (rc) = 1; } } } while (0)
 
 }  // namespace
 
@@ -133,12 +149,12 @@ static int comm_broadcast(fhesi_ctx* ctx, fhesi_comm* c, void* buf, size_t bytes
   if (c->nranks == 1 && !c->nccl) return 0;       // (a one-rank RCCL communicator still goes through RCCL)
   if (c->loop) {
     LoopGroup* g = c->loop;
+    int rc = 0;
     g->ptr[c->rank] = buf;
     g->barrier();
-    if (c->rank != root) HIP_TRY(hipMemcpyAsync(buf, g->ptr[root], bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    g->barrier();                              // the root's buffer stays untouched until every rank has read it
-    return 0;
+    if (c->rank != root) HIP_SOFT(rc, hipMemcpyAsync(buf, g->ptr[root], bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_SOFT(rc, hipStreamSynchronize(ctx->stream));
+    return g->close(rc);                       // the root's buffer stays untouched until every rank has read it
   }
   RcclApi* api = rccl();
   if (!api) FHESI_FAIL("broadcast: librccl.so.1 could not be loaded");
@@ -174,20 +190,32 @@ extern "C" int fhesi_comm_exchange(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* b
   if (comm->nranks == 1 && !comm->nccl) return 0;
   if (comm->loop) {
     LoopGroup* g = comm->loop;
+    int rc = 0;
     g->ptr[comm->rank] = base_dev;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));       // my shard is complete before anyone reads it
+    HIP_SOFT(rc, hipStreamSynchronize(ctx->stream));  // my shard is complete before anyone reads it
     g->barrier();
-    for (int r = 0; r < comm->nranks; ++r) {
+    for (int r = 0; r < comm->nranks && !rc; ++r) {
       const i64 lo = offsets_words[r], hi = offsets_words[r + 1];
       if (r == comm->rank || hi <= lo) continue;
-      HIP_TRY(hipMemcpyAsync(base_dev + lo, (const u64*)g->ptr[r] + lo, (size_t)(hi - lo) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      HIP_SOFT(rc, hipMemcpyAsync(base_dev + lo, (const u64*)g->ptr[r] + lo, (size_t)(hi - lo) * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    g->barrier();
-    return 0;
+    HIP_SOFT(rc, hipStreamSynchronize(ctx->stream));
+    return g->close(rc);
   }
   RcclApi* api = rccl();
   if (!api) FHESI_FAIL("exchange: librccl.so.1 could not be loaded");
+  {
+    // equal shards (the usual case: a wave's groups divide evenly over the ranks) are ONE in-place all-gather: a single ring over xGMI
+    // instead of one broadcast per producing rank
+    const i64 each = offsets_words[1] - offsets_words[0];
+    bool uniform = each > 0;
+    for (int r = 0; r < comm->nranks && uniform; ++r) uniform = offsets_words[r + 1] - offsets_words[r] == each;
+    if (uniform) {
+      RCCL_TRY(api, api->AllGather(base_dev + offsets_words[comm->rank], base_dev + offsets_words[0], (size_t)each, kNcclUint64, comm->nccl, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      return 0;
+    }
+  }
   RCCL_TRY(api, api->GroupStart());
   for (int r = 0; r < comm->nranks; ++r) {
     const i64 lo = offsets_words[r], hi = offsets_words[r + 1];
@@ -219,20 +247,22 @@ extern "C" int fhesi_comm_allreduce_rows(fhesi_ctx* ctx, fhesi_comm* comm, uint6
   if (comm->loop) {
     // sum through a staging copy of every other rank's rows (plumbing path: ranks share the device)
     LoopGroup* g = comm->loop;
-    void* stage;
-    HIP_TRY(hipMalloc(&stage, (size_t)words * 8));
-    HIP_TRY(hipMemcpyAsync(stage, rows_dev, (size_t)words * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    g->ptr[comm->rank] = stage;
+    void* stage = nullptr;
+    int rc = 0;
+    HIP_SOFT(rc, hipMalloc(&stage, (size_t)words * 8));
+    HIP_SOFT(rc, hipMemcpyAsync(stage, rows_dev, (size_t)words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_SOFT(rc, hipStreamSynchronize(ctx->stream));
+    g->ptr[comm->rank] = rc ? nullptr : stage;
     g->barrier();
-    for (int r = 0; r < comm->nranks; ++r) {
+    for (int r = 0; r < comm->nranks && !rc; ++r) {
       if (r == comm->rank) continue;
-      if (launch_ew_op(ctx, rows_dev, (const u64*)g->ptr[r], count, ctx->L, nullptr, FHESI_OP_ADD)) { hipFree(stage); return 1; }
+      if (!g->ptr[r]) { fhesi_set_error("allreduce: rank %d has no staging copy", r); rc = 1; break; }
+      rc = launch_ew_op(ctx, rows_dev, (const u64*)g->ptr[r], count, ctx->L, nullptr, FHESI_OP_ADD);
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    g->barrier();
-    HIP_TRY(hipFree(stage));
-    return 0;
+    HIP_SOFT(rc, hipStreamSynchronize(ctx->stream));
+    rc = g->close(rc);                         // every rank has read every staging copy
+    if (stage) hipFree(stage);
+    return rc;
   }
   RcclApi* api = rccl();
   if (!api) FHESI_FAIL("allreduce: librccl.so.1 could not be loaded");

@@ -547,10 +547,10 @@ __global__ void __launch_bounds__(NW * 64, 4) dot32_kernel3(const u32* __restric
 static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   constexpr int CT = 4, NW = 8, LP = 2;
   const size_t shmem = (size_t)ncol * CT * 64 * 4;
-  static unsigned long long attr_done = 0;
-  if (!(attr_done >> ctx->device & 1)) {
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!(attr_done.load() >> ctx->device & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel3<CT, NW, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_done |= 1ull << ctx->device;
+    attr_done.fetch_or(1ull << ctx->device);
   }
   const i64 nrow = aux32_row_len(ctx);
   const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
@@ -565,10 +565,10 @@ static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig,
 template <int CT, int NW, bool HALF>
 static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)ncol * CT * (HALF ? 32 : 64) * 4;
-  static unsigned long long attr_done = 0;
-  if (!(attr_done >> ctx->device & 1)) {
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!(attr_done.load() >> ctx->device & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done |= 1ull << ctx->device;
+    attr_done.fetch_or(1ull << ctx->device);
   }
   const i64 nrow = aux32_row_len(ctx);
   const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
@@ -782,10 +782,10 @@ static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int n
     k->mfma_valid = true;
   }
   const size_t shmem = (size_t)G * MF_E * MF_ESTRIDE + (size_t)8 * G * 32 * (MF_E + 1) * 4;
-  static unsigned long long attr_done = 0;
-  if (!(attr_done >> ctx->device & 1)) {
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!(attr_done.load() >> ctx->device & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)dot_mfma_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done |= 1ull << ctx->device;
+    attr_done.fetch_or(1ull << ctx->device);
   }
   const int ntiles = (int)((count + 8 * G - 1) / (8 * G));
   int sub_lg = 0;

@@ -479,8 +479,8 @@ static int launch_crt_t(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows, i
                         int positive, int logQ, u64* d_out, int nl_out, const unsigned char* d_block_flags = nullptr) {
   const int TB = 128;
   const size_t shmem = LQFIX ? 0 : (size_t)t->W * TB * sizeof(u64);
-  static unsigned long long attr_done = 0;     // one bit per device: the attribute is per device
-  if (!LQFIX && !(attr_done >> ctx->device & 1)) { HIP_TRY(hipFuncSetAttribute((const void*)crt_kernel<MAXW, KFIX, WFIX, LQFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, MAXW * TB * 8)); attr_done |= 1ull << ctx->device; }
+  static std::atomic<unsigned long long> attr_done{0};     // one bit per device: the attribute is per device
+  if (!LQFIX && !(attr_done.load() >> ctx->device & 1)) { HIP_TRY(hipFuncSetAttribute((const void*)crt_kernel<MAXW, KFIX, WFIX, LQFIX>, hipFuncAttributeMaxDynamicSharedMemorySize, MAXW * TB * 8)); attr_done.fetch_or(1ull << ctx->device); }
   dim3 grid((unsigned)((ctx->phim + TB - 1) / TB), (unsigned)npolys);
   crt_kernel<MAXW, KFIX, WFIX, LQFIX><<<grid, TB, shmem, ctx->stream>>>(d_rows, ctx->phim, nslots_layout, d_slot_of, t->nidx, t->W, t->d_idx, t->d_pow64, t->d_pinv, t->d_P,
                                                     t->d_halfP, ctx->d_pc, mode, positive, logQ, d_out, nl_out, d_block_flags);

@@ -440,10 +440,10 @@ static int launch_dot_aux_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_dig
   const i64 n = ctx->phim;
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(n / 64 / 8);
   const size_t shmem = (size_t)ncol * CT * 64 * 8;
-  static unsigned long long attr_done = 0;
-  if (!(attr_done >> ctx->device & 1)) {
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!(attr_done.load() >> ctx->device & 1)) {
     HIP_TRY(hipFuncSetAttribute((const void*)dot_aux_kernel<CT, NW, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done |= 1ull << ctx->device;
+    attr_done.fetch_or(1ull << ctx->device);
   }
   const i64 blocks = (i64)8 * ntiles * nsl8 * 2;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot_aux: too many ciphertexts per call");

@@ -718,6 +718,19 @@ class FHESIPubKey {
       for (int part = 0; part < 2; ++part) { ZZX poly; poly.rep.resize(n); for (long j = 0; j < n; ++j) poly.rep[j] = ZZ::from_limbs(&host[((c * 2 + part) * n + j) * nl], nl); poly.normalize(); ctxts[c][part].poly = poly; }
     }
   }
+  // ... with r and the noise drawn ON THE DEVICE from the counter-based generator (fhesi_encrypt_batch_seeded, csrc/philox.h): plaintext i
+  // uses the streams of object index first + i, so a batch can be split or repeated anywhere and give the same ciphertexts
+  void EncryptBatchSeeded(std::vector<Ciphertext>& ctxts, const std::vector<Plaintext>& ptxts, uint64_t seed, uint64_t first = 0) const {
+    const long n = context.zMstar.phiM(), count = (long)ptxts.size(); const int nl = (int)((context.logQ + 63) / 64);
+    std::vector<int64_t> msg((size_t)count * n, 0);
+    for (long c = 0; c < count; ++c) for (size_t k = 0; k < ptxts[c].message.size() && (long)k < n; ++k) msg[c * n + k] = ptxts[c].message[k];
+    void* dev; ck(fhesi_dev_alloc(context.handle(), (size_t)count * 2 * n * nl * 8, &dev));
+    ck(fhesi_encrypt_batch_seeded(context.handle(), publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), seed, first, msg.data(), count, (uint64_t*)dev, nl));
+    std::vector<uint64_t> host((size_t)count * 2 * n * nl);
+    ck(fhesi_dev_download(context.handle(), host.data(), dev, host.size() * 8)); ck(fhesi_dev_free(context.handle(), dev));
+    ctxts.assign(count, Ciphertext(context));
+    for (long c = 0; c < count; ++c) { ctxts[c].Initialize(2, context); for (int part = 0; part < 2; ++part) limbs_to_poly(ctxts[c][part].poly, &host[((size_t)(c * 2 + part) * n) * nl], n, nl); }
+  }
   void Encrypt(Ciphertext& ctxt, const Plaintext& ptxt) const {   // FHE-SI.cpp:10-36
     ctxt.Initialize(2, context);
     ZZX small; small.rep.assign(context.zMstar.phiM(), ZZ());
@@ -774,6 +787,30 @@ class KeySwitchSI {
         keySwitchMatrix[r].push_back(d);
       }
     drop_device_key(); devKey = k;                            // the device object the matrix was generated in serves the fused calls as it is
+  }
+  // the same matrix with the column randomness drawn on the device (fhesi_keyswitch_init_batch_seeded): column c <-> object index first + c
+  struct Seeded { uint64_t seed, first; };
+  KeySwitchSI(const FHESISecKey& s, Seeded sd) : context(s.GetContext()) {
+    std::vector<DoubleCRT> sKeys = s.GetRepresentation(), tKeys(sKeys.size() * 2 - 1, sKeys[1]);
+    tKeys[0] = sKeys[0];
+    for (size_t i = 2; i < tKeys.size(); ++i) tKeys[i] *= tKeys[i - 1];
+    InitSeeded(tKeys, s, sd);
+  }
+  void InitSeeded(const std::vector<DoubleCRT>& s, const FHESISecKey& dst, Seeded sd) {
+    const size_t n = s.size(); const long phim = context.zMstar.phiM(), L = context.numPrimes(); const long ncol = (long)(context.ndigits * n);
+    fhesi_ksk* k = nullptr;
+    ck(fhesi_ksk_create(context.handle(), (int32_t)n, (int32_t)context.ndigits, &k));
+    std::vector<const fhesi_dcrt*> hs; for (auto& d : s) hs.push_back(d.handle());
+    int rc = fhesi_keyswitch_init_batch_seeded(k, hs.data(), (int32_t)n, dst.GetRepresentation()[1].handle(), (int32_t)context.logQ, (int32_t)context.decompSize, sd.seed, sd.first);
+    if (rc) { fhesi_ksk_free(k); ck(rc); }
+    const uint64_t* rows = (const uint64_t*)fhesi_ksk_device_ptr(k); const size_t rowWords = (size_t)L * phim;
+    keySwitchMatrix.assign(2, std::vector<DoubleCRT>());
+    for (int r = 0; r < 2; ++r) for (long col = 0; col < ncol; ++col) {
+      DoubleCRT d(context);
+      ck(fhesi_dev_copy(context.handle(), fhesi_dcrt_device_ptr(d.handle()), rows + ((size_t)r * ncol + col) * rowWords, rowWords * 8));
+      keySwitchMatrix[r].push_back(d);
+    }
+    drop_device_key(); devKey = k;
   }
   void InitObjects(const FHESISecKey& src, const FHESISecKey& dst) {   // the reference's loop, one object at a time
     std::vector<DoubleCRT> s = src.GetRepresentation(); std::vector<ZZX> sCoeff(s.size());

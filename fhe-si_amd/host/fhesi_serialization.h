@@ -24,8 +24,13 @@ inline uint32_t ImportCount(std::istream& in, uint64_t max, const char* what) {
   if (n > max) Error((std::string("Import: ") + what + " count in the stream exceeds what the context allows").c_str());
   return n;
 }
-inline uint64_t ImportMaxBytes() { return activeContext ? (uint64_t)activeContext->numPrimes() * 8 + 2 * (uint64_t)activeContext->logQ / 8 + 64 : (1u << 16); }
-inline uint64_t ImportMaxDegree() { return activeContext ? (uint64_t)activeContext->zMstar.M() : (1u << 20); }
+// The bounds come from the context the stream is imported INTO: the key / ciphertext importers below name it (ImportBounds), plain
+// Import calls fall back to activeContext -- on which new DoubleCRT elements are built anyway (Serialization.h:50-58 -> DoubleCRT.cpp:261-266).
+inline const FHEcontext*& ImportBoundsContext() { static thread_local const FHEcontext* c = nullptr; return c; }
+struct ImportBounds { const FHEcontext* prev; explicit ImportBounds(const FHEcontext& c) : prev(ImportBoundsContext()) { ImportBoundsContext() = &c; } ~ImportBounds() { ImportBoundsContext() = prev; } };
+inline const FHEcontext* ImportTargetContext() { return ImportBoundsContext() ? ImportBoundsContext() : activeContext; }
+inline uint64_t ImportMaxBytes() { const FHEcontext* c = ImportTargetContext(); return c ? (uint64_t)c->numPrimes() * 8 + 2 * (uint64_t)c->logQ / 8 + 64 : (1u << 16); }
+inline uint64_t ImportMaxDegree() { const FHEcontext* c = ImportTargetContext(); return c ? (uint64_t)c->zMstar.M() : (1u << 20); }
 
 // plain-old-data overloads of Serialization.h:29-37
 inline void Export(std::ostream& out, uint32_t v) { ExportRaw(out, v); }
@@ -120,7 +125,7 @@ inline void ExportSIContext(const FHEcontext& c, std::ostream& out) {
 inline std::unique_ptr<FHEcontext> ImportSIContext(std::istream& in, int device = 0) {
   unsigned m, logQ, generator, decompSize; ZZ p;
   ImportRaw(in, m); ImportRaw(in, logQ); Import(in, p); ImportRaw(in, generator); ImportRaw(in, decompSize);
-  if (p.bits() > 62) Error("ImportSIContext: plaintext modulus does not fit a word");
+  if (p.bits() > 32 || p < ZZ(2L)) Error("ImportSIContext: the plaintext modulus must fit the 32-bit `unsigned p` of FHEcontext's constructor (FHEContext.h:105)");
   if (m < 2 || m > (1u << 20) || logQ < 1 || logQ > (1u << 14) || decompSize < 1 || decompSize > 7) Error("ImportSIContext: parameters out of range");
   std::unique_ptr<FHEcontext> c(new FHEcontext(m, logQ, (unsigned)p.to_long(), generator, decompSize, device));
   const uint32_t size = ImportCount(in, 64, "prime");
@@ -133,8 +138,8 @@ inline void Export(std::ostream& out, const FHESISecKey& k) { Export(out, k.GetR
 inline void Export(std::ostream& out, const FHESIPubKey& k) { Export(out, k.GetRepresentation()); }
 inline void Export(std::ostream& out, const KeySwitchSI& k) { Export(out, k.GetRepresentation()); }
 // (new DoubleCRT elements are built on activeContext, as in the reference: Serialization.h:50-58 -> DoubleCRT.cpp:261-266)
-inline void Import(std::istream& in, FHESISecKey& k) { std::vector<DoubleCRT> rep; Import(in, rep); k.UpdateRepresentation(rep); }
-inline void Import(std::istream& in, FHESIPubKey& k) { std::vector<DoubleCRT> rep; Import(in, rep); k.UpdateRepresentation(rep); }
-inline void Import(std::istream& in, KeySwitchSI& k) { std::vector<std::vector<DoubleCRT>> rep; Import(in, rep); k.UpdateRepresentation(rep); }
+inline void Import(std::istream& in, FHESISecKey& k) { ImportBounds b(k.GetContext()); std::vector<DoubleCRT> rep; Import(in, rep); k.UpdateRepresentation(rep); }
+inline void Import(std::istream& in, FHESIPubKey& k) { ImportBounds b(k.GetContext()); std::vector<DoubleCRT> rep; Import(in, rep); k.UpdateRepresentation(rep); }
+inline void Import(std::istream& in, KeySwitchSI& k) { ImportBounds b(k.GetContext()); std::vector<std::vector<DoubleCRT>> rep; Import(in, rep); k.UpdateRepresentation(rep); }
 
 }  // namespace fhesi

@@ -228,6 +228,19 @@ int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const* src, int32
                                const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host);
 int fhesi_ksk_download(const fhesi_ksk* k, uint64_t* rows_host);                         /* whole matrix to the host (Export, FHE-SI.cpp:270-272) */
 
+/* ---- the same three with the randomness drawn ON THE DEVICE (sampleHWt / sampleGaussian NumbTh.cpp:340-404, the binary
+ * and Gaussian polynomials of Encrypt FHE-SI.cpp:14-25, SampleRandom + sampleGaussian per key-switch column FHE-SI.cpp:174-190).  NTL's
+ * sequential PRNG cannot be reproduced outside NTL, so these entry points use a counter-based generator instead -- Philox-4x32-10 keyed by
+ * `seed`, counter = (coefficient, object index, purpose); definition in fhe-si_amd/csrc/philox.h, restated by the oracle and the Python
+ * model -- which makes a ciphertext or a key a function of (seed, index) alone: the same on every GPU, in any batch split, and on the CPU.
+ * The explicit-randomness forms above remain for callers that bring their own randomness (and for reproducing fixtures). */
+int fhesi_encrypt_batch_seeded(fhesi_ctx* ctx, const fhesi_dcrt* pk0, const fhesi_dcrt* pk1, int32_t logQ, uint64_t p, uint64_t seed, uint64_t first_index,
+                               const int64_t* msg_host, int64_t count, uint64_t* out_dev, int32_t nlimbs);      /* plaintext i <-> object index first_index + i */
+int fhesi_keyswitch_init_batch_seeded(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
+                                      uint64_t seed, uint64_t first_index);                                      /* column c <-> object index first_index + c */
+int fhesi_dcrt_sample(fhesi_dcrt* d, int32_t kind, int64_t param, uint64_t seed, uint64_t index);               /* DoubleCRT::sampleHWt(param) (kind 0), ::sampleGaussian() with
+                                                                                                                    stdev 3.2 (kind 1): DoubleCRT.h:340-345 */
+
 /* ---- multi-GPU: independent ciphertexts are data-parallel, every GPU holds the context tables and a replica of
  * the key-switch matrices; RCCL collectives run on the context's stream.  librccl is loaded on first use (no RCCL needed on one GPU).
  * fhesi_comm_init_all: one process, one host thread per GPU -- ncclCommInitAll over `devices`, comms_out[r] is rank r's handle.

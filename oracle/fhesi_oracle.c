@@ -639,6 +639,70 @@ void orc_apply_key_switch_parts(const orc_ctx* c, const u64* ksm, const u64* par
   free(dig); free(bd); free(acc); free(tmp); free(big);
 }
 
+/* ------------------------------------------------------------------ counter-based randomness for sampling on the device
+ * The reference draws from NTL's sequential PRNG (NumbTh.cpp:340-404 via RandomBnd, FHE-SI.cpp:14-25,174-190), which only an NTL process
+ * can reproduce.  The device draws instead from Philox-4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+ * SC'11) keyed by a seed, counter = (coefficient j, object index low / high word, purpose << 16 | block); this is the checker's own
+ * statement of that definition (the product states it in fhe-si_amd/csrc/philox.h, the Python model in fhesi_pyref.py).
+ * Known answers of the generator: tests/test_oracle_golden.py. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static void draw(u64 seed, u64 object, uint32_t j, uint32_t purpose, uint32_t block, uint32_t w[4]) {
+  uint32_t ctr[4] = {j, (uint32_t)object, (uint32_t)(object >> 32), purpose << 16 | block}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  orc_philox4x32_10(ctr, key, w);
+}
+/* floor(2^64 P(|X| <= k)), X = round(N(0, 3.2^2)): the distribution of sampleGaussian's Box-Muller + floor(x + 0.5) (NumbTh.cpp:377-404) with
+ * FHEContext.h:106's stdev, sampled by inversion on integers */
+static const u64 gauss_cdf[30] = {
+  0x1fc936cfb902b000ull, 0x5c5a3878a5513000ull, 0x90ba6b457f6e7800ull, 0xb9d6e65c2e45a000ull, 0xd7212f1da26f6200ull, 0xea12314c4c373a00ull,
+  0xf53070328c8acd80ull, 0xfb1cdac9f40b6980ull, 0xfdfa2ace3c107960ull, 0xff3c09d0d6606540ull, 0xffbc45110abb0cdcull, 0xffeaa36c3c86f3c9ull,
+  0xfff9db4fc8bf1e60ull, 0xfffe63d9a0b88f51ull, 0xffff9da028c31301ull, 0xffffea9fbab7b7e9ull, 0xfffffbc5e81f8a58ull, 0xffffff3d57e1db7bull,
+  0xffffffe027626c9eull, 0xfffffffb4348bc92ull, 0xffffffff5c0429c2ull, 0xffffffffebd8d7e9ull, 0xfffffffffdbfd855ull, 0xffffffffffc58a4cull,
+  0xfffffffffffa9c86ull, 0xffffffffffff8c81ull, 0xfffffffffffff738ull, 0xffffffffffffff65ull, 0xfffffffffffffff7ull, 0xffffffffffffffffull };
+static i64 gaussian_of(const uint32_t w[4]) {
+  u64 u = (u64)w[0] | (u64)w[1] << 32; int k = 0;
+  for (int i = 0; i < 30; i++) k += u > gauss_cdf[i];
+  return (w[2] & 1) ? -(i64)k : (i64)k;
+}
+/* purposes: 0 binary r, 1 / 2 noise of part 0 / 1, 3 key-switch column polynomial, 4 its error, 5 sampleHWt draws, 6 sampleGaussian */
+/* the randomness of one Encrypt (FHE-SI.cpp:14-25): small [phim] binary, noise [2][phim] Gaussian samples before the multiplication by p */
+void orc_draw_encrypt(const orc_ctx* c, u64 seed, u64 index, i64* small, i64* noise) {
+  uint32_t w[4];
+  for (i64 j = 0; j < c->phim; j++) {
+    draw(seed, index, (uint32_t)j, 0, 0, w); small[j] = w[0] & 1;
+    draw(seed, index, (uint32_t)j, 1, 0, w); noise[j] = gaussian_of(w);
+    draw(seed, index, (uint32_t)j, 2, 0, w); noise[c->phim + j] = gaussian_of(w);
+  }
+}
+/* the randomness of one key-switch column (FHE-SI.cpp:174-190): a [phim][nlimbs] = SampleRandom(2^logQ) (Util.cpp:49-55: RandomBnd(q) - q/2) from
+ * logQ random bits (limb i = words 2 (i mod 2), 2 (i mod 2) + 1 of block i / 2), err [phim] Gaussian */
+void orc_draw_keygen(const orc_ctx* c, u64 seed, u64 index, int nlimbs, int logQ, u64* a, i64* err) {
+  uint32_t w[4]; int W = nlimbs + 1; u64 x[W], half[W];
+  for (i64 j = 0; j < c->phim; j++) {
+    memset(x, 0, 8 * W);
+    for (int i = 0; i * 64 < logQ; i++) { draw(seed, index, (uint32_t)j, 3, (uint32_t)(i / 2), w); x[i] = (u64)w[2 * (i % 2)] | (u64)w[2 * (i % 2) + 1] << 32; }
+    if (logQ % 64) x[logQ / 64] &= (1ull << (logQ % 64)) - 1;                     /* logQ random bits: RandomBnd(2^logQ) */
+    memset(half, 0, 8 * W); half[(logQ - 1) / 64] = 1ull << ((logQ - 1) % 64); bn_sub(x, half, W);   /* - q / 2 */
+    memcpy(a + j * nlimbs, x, 8 * nlimbs);
+    draw(seed, index, (uint32_t)j, 4, 0, w); err[j] = gaussian_of(w);
+  }
+}
+/* sampleHWt (NumbTh.cpp:340-360): draws t = 0, 1, ... pick a position and a sign; positions already set are skipped */
+void orc_draw_hwt(const orc_ctx* c, u64 seed, u64 index, i64 hwt, i64* poly) {
+  uint32_t w[4]; i64 n = c->phim; memset(poly, 0, 8 * n); if (hwt > n) hwt = n;
+  uint32_t t = 0;
+  for (i64 i = 0; i < hwt; t++) { draw(seed, index, t, 5, 0, w); u64 u = ((u64)w[0] | (u64)w[1] << 32) % (u64)n; if (!poly[u]) { poly[u] = (w[2] & 1) ? 1 : -1; i++; } }
+}
+void orc_draw_gaussian(const orc_ctx* c, u64 seed, u64 index, i64* poly) { uint32_t w[4]; for (i64 j = 0; j < c->phim; j++) { draw(seed, index, (uint32_t)j, 6, 0, w); poly[j] = gaussian_of(w); } }
+
 /* ------------------------------------------------------------------ Encrypt / Decrypt with explicit randomness */
 /* FHESIPubKey::Encrypt (FHE-SI.cpp:10-36).  pk: [2][L][phim] rows; small: the binary polynomial r (:14-18); noise: [2][phim]
  * Gaussian samples before the multiplication by p (:24-25); msg: [phim] in [0,p).  out: [2][phim][nlimbs] */

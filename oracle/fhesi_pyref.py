@@ -673,6 +673,70 @@ def key_switch_init_s2(ctx: Ctx, t: Sequence[int], rng: SplitMix64):
 
 
 # --------------------------------------------------------------------------------------------
+# Counter-based randomness for sampling on the device: Philox-4x32-10, key = seed, counter = (coefficient j, object
+# index low / high word, purpose << 16 | block).  Independent statement of fhe-si_amd/csrc/philox.h; purposes: 0 binary r, 1 / 2 noise of
+# part 0 / 1, 3 key-switch column polynomial, 4 its error, 5 sampleHWt draws, 6 sampleGaussian.
+# --------------------------------------------------------------------------------------------
+def philox4x32_10(ctr: Sequence[int], key: Sequence[int]) -> List[int]:
+    c, k = list(ctr), list(key)
+    for r in range(10):
+        if r:
+            k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
+    return c
+
+
+def phx_draw(seed: int, obj: int, j: int, purpose: int, block: int = 0) -> List[int]:
+    return philox4x32_10([j, obj & 0xFFFFFFFF, obj >> 32, purpose << 16 | block], [seed & 0xFFFFFFFF, seed >> 32])
+
+
+GAUSS_CDF = [0x1fc936cfb902b000, 0x5c5a3878a5513000, 0x90ba6b457f6e7800, 0xb9d6e65c2e45a000, 0xd7212f1da26f6200, 0xea12314c4c373a00,
+             0xf53070328c8acd80, 0xfb1cdac9f40b6980, 0xfdfa2ace3c107960, 0xff3c09d0d6606540, 0xffbc45110abb0cdc, 0xffeaa36c3c86f3c9,
+             0xfff9db4fc8bf1e60, 0xfffe63d9a0b88f51, 0xffff9da028c31301, 0xffffea9fbab7b7e9, 0xfffffbc5e81f8a58, 0xffffff3d57e1db7b,
+             0xffffffe027626c9e, 0xfffffffb4348bc92, 0xffffffff5c0429c2, 0xffffffffebd8d7e9, 0xfffffffffdbfd855, 0xffffffffffc58a4c,
+             0xfffffffffffa9c86, 0xffffffffffff8c81, 0xfffffffffffff738, 0xffffffffffffff65, 0xfffffffffffffff7, 0xffffffffffffffff]
+
+
+def phx_gaussian(w: Sequence[int]) -> int:
+    """round(N(0, 3.2^2)) by inversion on integers: magnitude = number of table entries below u, sign = bit 0 of word 2"""
+    u = w[0] | w[1] << 32
+    k = sum(1 for t in GAUSS_CDF if u > t)
+    return -k if w[2] & 1 else k
+
+
+def draw_encrypt(n: int, seed: int, index: int):
+    """(r, e0, e1) of FHESIPubKey::Encrypt (FHE-SI.cpp:14-25) for plaintext `index`"""
+    return ([phx_draw(seed, index, j, 0)[0] & 1 for j in range(n)], [phx_gaussian(phx_draw(seed, index, j, 1)) for j in range(n)],
+            [phx_gaussian(phx_draw(seed, index, j, 2)) for j in range(n)])
+
+
+def draw_keygen(n: int, logQ: int, seed: int, index: int):
+    """(SampleRandom polynomial modulo 2^logQ, Gaussian error) of key-switch column `index` (FHE-SI.cpp:174-190, Util.cpp:49-55)"""
+    poly = []
+    for j in range(n):
+        u = 0
+        for i in range((logQ + 63) // 64):
+            w = phx_draw(seed, index, j, 3, i // 2)
+            u |= (w[2 * (i % 2)] | w[2 * (i % 2) + 1] << 32) << (64 * i)
+        poly.append((u & ((1 << logQ) - 1)) - (1 << (logQ - 1)))
+    return poly, [phx_gaussian(phx_draw(seed, index, j, 4)) for j in range(n)]
+
+
+def draw_hwt(n: int, hwt: int, seed: int, index: int) -> List[int]:
+    """sampleHWt (NumbTh.cpp:340-360)"""
+    poly, i, t = [0] * n, 0, 0
+    hwt = min(hwt, n)
+    while i < hwt:
+        w = phx_draw(seed, index, t, 5)
+        u = (w[0] | w[1] << 32) % n
+        if poly[u] == 0:
+            poly[u] = 1 if w[2] & 1 else -1
+            i += 1
+        t += 1
+    return poly
+
+
 # Ciphertext algebra used by Matrix<Ciphertext> / Regression (SURVEY.md 8(f) 1-2)
 # --------------------------------------------------------------------------------------------
 def ct_add(ctx: Ctx, a_parts: Sequence[Sequence[int]], b_parts: Sequence[Sequence[int]]) -> List[List[int]]:

@@ -116,6 +116,23 @@ int main(int argc, char* argv[]) {
     Ciphertext z = c2; z *= c2; ks2.ApplyKeySwitch(z);
     if (!(va[0][0] == x[0] && va[0][1] == x[1] && va[1][0] == z[0] && va[1][1] == z[1])) { std::cout << "MulRelinBatch differs from operator*= + ApplyKeySwitch" << std::endl; ++failures; }
   }
+  // randomness drawn on the device (csrc/philox.h): seeded encryptions decrypt to their messages, do not depend on how a batch is split, and
+  // a seeded key-switch matrix relinearises their product
+  {
+    std::vector<Plaintext> pts(3); pts[0].message = m1; pts[1].message = m2; pts[2].message = m1;
+    std::vector<Ciphertext> all, tail;
+    pk2.EncryptBatchSeeded(all, pts, 99, 10);
+    std::vector<Plaintext> last(pts.begin() + 2, pts.end());
+    pk2.EncryptBatchSeeded(tail, last, 99, 12);
+    if (!(tail[0][0] == all[2][0] && tail[0][1] == all[2][1])) { std::cout << "seeded encryption depends on the batch split" << std::endl; ++failures; }
+    if (all[0][0] == all[2][0]) { std::cout << "seeded encryptions of one message under different indices coincide" << std::endl; ++failures; }
+    std::vector<Plaintext> dec; sk2.DecryptBatch(dec, all);
+    if (dec.size() != 3 || dec[0].message != m1 || dec[1].message != m2 || dec[2].message != m1) { std::cout << "seeded encryptions do not decrypt" << std::endl; ++failures; }
+    KeySwitchSI kseed(sk2, KeySwitchSI::Seeded{4711, 0});
+    Ciphertext pr = all[0]; pr *= all[1]; kseed.ApplyKeySwitch(pr);
+    Plaintext r; sk2.Decrypt(r, pr);
+    if (r.message != mul_mod_phi(m1, m2, *ctx2, (long)p)) { std::cout << "seeded key-switch matrix does not relinearise" << std::endl; ++failures; }
+  }
   // the imported product has 3 parts (it was scaled down on export): relinearise it with the imported matrix
   if (prod.parts.size() != 3) { std::cout << "imported product has " << prod.parts.size() << " parts" << std::endl; ++failures; }
   ks2.ApplyKeySwitch(prod);

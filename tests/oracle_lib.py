@@ -67,6 +67,11 @@ def lib():
         _lib.orc_decrypt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         _lib.orc_ct_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib.orc_ct_mul_long.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
+        _lib.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_draw_encrypt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        _lib.orc_draw_keygen.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.orc_draw_hwt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]
+        _lib.orc_draw_gaussian.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         _lib.orc_ct_add_const.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64]
         _lib.orc_ct_mul_poly.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib.orc_ct_automorph.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -80,6 +85,15 @@ def _p(a: np.ndarray):
 
 
 # ---- big-int <-> limb arrays -------------------------------------------------------------------
+def philox4x32_10(ctr, key):
+    """the C oracle's Philox-4x32-10"""
+    c = np.array(ctr, dtype=np.uint32)
+    k = np.array(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_p(c), _p(k), _p(out))
+    return [int(x) for x in out]
+
+
 def ints_to_limbs(vals, nlimbs: int) -> np.ndarray:
     """signed Python ints -> [len][nlimbs] uint64 two's complement little-endian."""
     out = np.zeros((len(vals), nlimbs), dtype=np.uint64)
@@ -302,6 +316,30 @@ class Oracle:
         a = np.array(a, dtype=np.uint64, copy=True)
         lib().orc_ct_mul_long(self.h, _p(a), l, a.shape[0], a.shape[-1], logQ)
         return a
+
+    # ---- counter-based randomness (the checker's statement of fhe-si_amd/csrc/philox.h)
+    def draw_encrypt(self, seed: int, index: int):
+        """(small [phim], noise [2][phim]) of plaintext `index` under `seed`"""
+        small = np.zeros(self.phim, dtype=np.int64)
+        noise = np.zeros((2, self.phim), dtype=np.int64)
+        lib().orc_draw_encrypt(self.h, seed, index, _p(small), _p(noise))
+        return small, noise
+
+    def draw_keygen(self, seed: int, index: int, nlimbs: int, logQ: int):
+        a = np.zeros((self.phim, nlimbs), dtype=np.uint64)
+        err = np.zeros(self.phim, dtype=np.int64)
+        lib().orc_draw_keygen(self.h, seed, index, nlimbs, logQ, _p(a), _p(err))
+        return a, err
+
+    def draw_hwt(self, seed: int, index: int, hwt: int) -> np.ndarray:
+        poly = np.zeros(self.phim, dtype=np.int64)
+        lib().orc_draw_hwt(self.h, seed, index, hwt, _p(poly))
+        return poly
+
+    def draw_gaussian(self, seed: int, index: int) -> np.ndarray:
+        poly = np.zeros(self.phim, dtype=np.int64)
+        lib().orc_draw_gaussian(self.h, seed, index, _p(poly))
+        return poly
 
     def ct_add_const(self, a: np.ndarray, poly, logQ: int, p: int) -> np.ndarray:
         """Ciphertext::operator+=(const ZZX&), unscaled (Ciphertext.cpp:147-156); a [nparts][phim][nlimbs], poly [phim] int64"""

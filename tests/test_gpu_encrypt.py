@@ -135,3 +135,74 @@ def test_keyswitch_init_batch_vs_oracle(m, logQ, nsrc):
         prod = ctx.ct_mul_relin(ksk, logQ, p, ca, cb)[0]
         dec = R.decrypt(cx, tl, [O.limbs_to_ints(prod[0]), O.limbs_to_ints(prod[1])])
         assert dec == [x % p for x in R.poly_mul_mod_phi(cx, m1, m2)]
+
+
+@pytest.mark.parametrize("m,logQ,p", [(4096, 128, 23), (46, 90, 47), (32768, 512, 23)])
+def test_seeded_encrypt_keygen_and_samplers_vs_oracle(m, logQ, p):
+    """On-device sampling: fhesi_encrypt_batch_seeded, fhesi_keyswitch_init_batch_seeded and fhesi_dcrt_sample draw their
+    randomness in HBM from the counter-based generator of philox.h.  The oracle draws the same polynomials from its own statement of the
+    generator and computes Encrypt / KeySwitchSI::Init with them (FHE-SI.cpp:10-36, 153-209): the device results must be those bits, for a
+    batch that does not start at index 0; the secret key from fhesi_dcrt_sample(HWt 64) equals DoubleCRT(draw); encrypt o decrypt = id."""
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, L, nd, nl = ctx.phim, len(primes), R.ndigits(logQ), (logQ + 63) // 64
+    seed, first = 0x1234567890ABCDEF, 41
+    W = L + 2
+    # secret key t = sampleHWt(64) and a Gaussian polynomial, drawn on the device
+    sk1 = F.DoubleCRT(ctx).sample(0, 64, seed, 7)
+    t = orc.draw_hwt(seed, 7, 64)
+    t_rows = orc.dcrt_from_poly(O.ints_to_limbs([int(x) for x in t], W))
+    assert all(np.array_equal(sk1.row(i), t_rows[i]) for i in range(L))
+    g = F.DoubleCRT(ctx).sample(1, 0, seed, 8)
+    g_rows = orc.dcrt_from_poly(O.ints_to_limbs([int(x) for x in orc.draw_gaussian(seed, 8)], W))
+    assert all(np.array_equal(g.row(i), g_rows[i]) for i in range(L))
+    # public key (valid): pk0 = e + t c1, pk1 = -c1 with c1 uniform, built through the oracle's rows
+    rng = np.random.default_rng(m)
+    c1 = P.rand_limbs(rng, (n,), nl, logQ)
+    c1_rows = orc.dcrt_from_poly(c1)
+    e_rows = orc.dcrt_from_poly(O.ints_to_limbs([int(x) for x in orc.draw_gaussian(seed, 9)], W))
+    pk0_rows = orc.dcrt_op(orc.dcrt_op(t_rows, c1_rows, 2), e_rows, 0)
+    zero = np.zeros_like(c1_rows)
+    pk1_rows = orc.dcrt_op(zero, c1_rows, 1)
+    # (the reference reduces pk0 modulo 2^logQ in coefficient form; for the encrypt/decrypt identity below the unreduced rows serve as well)
+    pk0, pk1 = dcrt_from_rows(ctx, pk0_rows), dcrt_from_rows(ctx, pk1_rows)
+    count = 3
+    msg = rng.integers(0, p, size=(count, n)).astype(np.int64)
+    out = ctx.alloc(count * 2 * n * nl * 8)
+    ctx.encrypt_batch_seeded(pk0, pk1, logQ, p, seed, first, msg, out, nl)
+    got = out.download((count, 2, n, nl))
+    pk = np.stack([pk0_rows, pk1_rows])
+    for c in range(count):
+        small, noise = orc.draw_encrypt(seed, first + c)
+        assert np.array_equal(got[c], orc.encrypt(pk, small, noise, msg[c], logQ, p, nl)), c
+    # the explicit-randomness entry point with the oracle's draws gives the same ciphertexts
+    rand = np.stack([np.concatenate([orc.draw_encrypt(seed, first + c)[0][None], orc.draw_encrypt(seed, first + c)[1]]) for c in range(count)])
+    out2 = ctx.alloc(count * 2 * n * nl * 8)
+    ctx.encrypt_batch(pk0, pk1, logQ, p, rand, msg, out2, nl)
+    assert np.array_equal(out2.download((count, 2, n, nl)), got)
+    if m <= 4096:
+        assert np.array_equal(ctx.decrypt_batch(sk1, logQ, p, out, nl, count), msg)
+    # key-switch matrix of (1, t, t^2) -> t with the column randomness drawn on the device
+    one_rows = orc.dcrt_from_poly(O.ints_to_limbs([1] + [0] * (n - 1), W))
+    src_rows = [one_rows, t_rows, orc.dcrt_op(t_rows, t_rows, 2)]
+    src = [dcrt_from_rows(ctx, r) for r in src_rows]
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded(src, src[1], logQ, seed, 1000)
+    kgot = ksk.download()
+    ncol = 3 * nd
+    cols = (0, 1, ncol - 1) if n > 8192 else range(ncol)
+    a = np.zeros((ncol, n, nl), dtype=np.uint64)
+    err = np.zeros((ncol, n), dtype=np.int64)
+    for col in range(ncol):
+        a[col], err[col] = orc.draw_keygen(seed, 1000 + col, nl, logQ)
+    if n <= 8192:
+        want = orc.keyswitch_init(np.stack(src_rows), t_rows, logQ, a, err)
+        assert np.array_equal(kgot[1], want[1]) and np.array_equal(kgot[0], want[0])
+    else:
+        # the metric ring: the A rows of the sampled columns = -DoubleCRT(a) checked row by row, and the whole matrix against the device call
+        # that takes the oracle's draws as explicit randomness (itself checked against the oracle in test_keyswitch_init_batch_vs_oracle)
+        for col in cols:
+            arows = orc.dcrt_from_poly(a[col])
+            assert np.array_equal(kgot[1][col], orc.dcrt_op(np.zeros_like(arows), arows, 1)), col
+        k2 = F.KeySwitchMatrix(ctx, 3, nd).init_batch(src, src[1], logQ, a, err)
+        assert np.array_equal(k2.download(), kgot)
