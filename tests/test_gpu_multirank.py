@@ -91,6 +91,53 @@ def test_key_broadcast_exchange_and_allreduce(devices):
         c.destroy()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0]])
+def test_metric_key_matrix_through_the_broadcast(devices):
+    """The set-up collective at its real size: configs[2]'s key-switch matrix (2 x 66 DoubleCRTs of 18 x 2^14 words = 297 MiB) goes through
+    fhesi_ksk_broadcast -- real RCCL with one rank, and rank 0 -> rank 1 in a group sharing the GPU -- into a replica that had already
+    served a key switch (its derived tables are stale and must be rebuilt); the receiving rank's multiplication + key switch then equals
+    the oracle's on the first and the last ciphertext of a batch, and equal exchange shards take the single all-gather."""
+    m, logQ, p, count = 1 << 15, 512, 23, 9
+    primes, roots = P.chain_for(m, logQ, p)
+    G = len(devices)
+    ctxs = [F.Context(m, primes, roots, device=d) for d in devices]
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctxs[0].phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(297)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    assert ksm.nbytes == 2 * 66 * 18 * 16384 * 8
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    comms = F.Comm.init_all(devices)
+    ksks = [F.KeySwitchMatrix(ctxs[r], 3, nd) for r in range(G)]
+    ksks[0].upload(ksm)
+    for r in range(1, G):
+        ksks[r].upload(np.ascontiguousarray(ksm[::-1]))      # another matrix, used once: stale derived tables on the receiver
+        ctxs[r].ct_mul_relin(ksks[r], logQ, p, a[:1], b[:1])
+    _threads(G, lambda r: comms[r].ksk_broadcast(ksks[r], 0))
+    last = G - 1
+    got = ctxs[last].ct_mul_relin(ksks[last], logQ, p, a, b)
+    assert ksks[last].form()[0] == 1
+    for c in (0, count - 1):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    if G > 1:
+        assert np.array_equal(ctxs[0].ct_mul_relin(ksks[0], logQ, p, a, b), got)
+    # equal shards: 2 G ciphertexts, G ranks
+    words, total = 2 * n * nl, 2 * G
+    full = rng.integers(0, 1 << 63, size=(total, words), dtype=np.uint64)
+    bufs = []
+    for r in range(G):
+        mine = np.zeros_like(full)
+        mine[2 * r:2 * r + 2] = full[2 * r:2 * r + 2]
+        bufs.append(ctxs[r].upload(mine))
+    off = [2 * r * words for r in range(G + 1)]
+    _threads(G, lambda r: comms[r].exchange(ctxs[r], bufs[r], off))
+    for r in range(G):
+        assert np.array_equal(bufs[r].download(full.shape), full), r
+    for c in comms:
+        c.destroy()
+
+
 @pytest.mark.parametrize("args,devices", [(("23", "7", "3", "2", "2"), "0,0"), (("257", "3", "4", "2", "5"), "0,0,0"), (("47", "5", "3", "1", "6"), "0")])
 def test_wave_evaluator_sharded_over_ranks_is_bit_identical(args, devices):
     """fhesi::Regression::RegressBatchedMultiGpu (fhe-si_amd/host/fhesi_matrix.h: GroupExecutor, one host thread per rank, keys
