@@ -14,14 +14,14 @@ run() {   # name, then bench.py arguments
   tail -1 "$O/${name}_bench.json" | cut -c1-400
 }
 if [ -z "${PROFILE_ONLY_PMC:-}" ]; then
-run metric --steps 5 --warmup 2 --no-bluestein-cpu
-run stress --workload stress --steps 3 --warmup 1 --cpu-sample 0
+run metric --steps 5 --warmup 2 --no-bluestein-cpu --no-surface --gpu-seconds 0
+run stress --workload stress --steps 3 --warmup 1 --cpu-sample 0 --gpu-seconds 0
 run regression --workload regression --steps 3 --warmup 1
 run regression_ref --workload regression --reg-ring reference --steps 5 --warmup 2
 run ntt --workload ntt --steps 10 --warmup 2
 fi
 for c in FETCH_SIZE WRITE_SIZE; do        # one counter per pass (combining them has hung the profiler on this pool)
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --batch 1024 > /dev/null 2> "$O/pmc_$c.log"
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --batch 1024 --no-surface --gpu-seconds 0 > /dev/null 2> "$O/pmc_$c.log"
 done
 F=$(find "$O/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 W=$(find "$O/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
