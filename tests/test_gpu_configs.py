@@ -68,6 +68,43 @@ def test_config4_stress_ring_several_chunks():
         assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[c:c + 1], b[c:c + 1])[0], got[c]), c
 
 
+def test_config4_1024_concurrent_mults():
+    """configs[4] as BASELINE.json words it: 1024 concurrent ciphertext mults at the stress shape (n = 2^15, logQ = 1024) in ONE call on
+    device-resident buffers (24 GiB of operands and results; the library takes them in launches of up to 292).  64 distinct random pairs are
+    replicated on the device to fill the batch (as bench.py --workload stress does): every one of the 1024 results must equal the result of
+    the same pair in a call of its own 64 -- a launch or chunk boundary, or a neighbour, must not change a ciphertext -- and pair 0 the oracle's."""
+    m, logQ, p, count, uniq = 1 << 16, 1024, 65537, 1024, 64
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(1024)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    a = P.rand_limbs(rng, (uniq, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (uniq, 2, n), nl, logQ)
+    ct_bytes = a.nbytes // uniq
+    da, db, dout = ctx.alloc(ct_bytes * count), ctx.alloc(ct_bytes * count), ctx.alloc(ct_bytes * count)
+    da.upload(a)
+    db.upload(b)
+    done = uniq
+    while done < count:
+        cnt = min(done, count - done)
+        ctx.dev_copy(da.ptr.value + done * ct_bytes, da.ptr.value, cnt * ct_bytes)
+        ctx.dev_copy(db.ptr.value + done * ct_bytes, db.ptr.value, cnt * ct_bytes)
+        done += cnt
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    ctx.sync()
+    want = ctx.ct_mul_relin(ksk, logQ, p, a, b)          # the 64 distinct pairs in a call of their own
+    assert np.array_equal(want[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
+    for blk in range(count // uniq):
+        got = np.empty_like(want)
+        import ctypes as C
+        from fhe_si_amd import binding as Bd
+        Bd._ck(Bd._load().fhesi_dev_download(ctx.h, got.ctypes.data_as(C.c_void_p), C.c_void_p(dout.ptr.value + blk * uniq * ct_bytes), got.nbytes))
+        assert np.array_equal(got, want), blk
+
+
 def test_config2_metric_ring_several_chunks():
     """configs[2] at a batch that spans three chunks of 64: first, last and chunk-boundary ciphertexts vs the oracle."""
     m, logQ, p, count = 1 << 15, 512, 23, 130

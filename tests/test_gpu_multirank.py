@@ -150,6 +150,21 @@ def test_wave_evaluator_sharded_over_ranks_is_bit_identical(args, devices):
     assert "batched: decrypts to the plaintext regression: yes" in r.stdout
 
 
+def test_config3_sharded_over_eight_ranks():
+    """configs[3] as BASELINE.json words it -- Test_Regression d = 8, one block of 4096 points on the reference's ring (p = 8423, m = 8422,
+    logQ = 341), the ciphertext batches of every wave sharded over EIGHT ranks with the keys broadcast from rank 0 -- on the one GPU of this
+    box: eight ranks in a group sharing GPU 0 (fhesi_comm_init_all's loopback group; RCCL itself needs eight devices and is exercised by the
+    driver's 8-GPU run).  The sharded waves must produce the ciphertexts of the one-GPU evaluation bit for bit and decrypt to the plaintext
+    regression (Regression.h:193-214)."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(HOST, "test_regression"), "8423", "7", "8", "1", "1", "--batched-only", "--check=slots", "--devices=0,0,0,0,0,0,0,0"],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "phi(m)=4210 logQ=341 primes=13 ndigits=15 dim=8 rows=1" in r.stdout, r.stdout
+    assert "multi-rank ciphertexts bit-identical to one GPU: yes" in r.stdout
+    assert "batched: decrypts to the plaintext regression: yes" in r.stdout
+
+
 @pytest.mark.parametrize("workload,extra", [("metric", ["--batch", "64"]), ("regression", ["--reg-dim", "3"]), ("ntt", ["--batch", "64"]),
                                             ("regression", ["--reg-dim", "3", "--reg-ring", "reference"])])      # configs[3] on the reference's own ring
 def test_bench_launches_its_own_ranks(workload, extra):
