@@ -103,7 +103,17 @@ static int aux32_init(fhesi_ctx* ctx) {
     x->pr.r64[a] = (u64)(((u128)1 << 64) % p);
     x->pr.r48[a] = ((u64)1 << 48) % p;
     { u32 inv = 1; for (int it = 0; it < 5; ++it) inv *= 2u - (u32)p * inv; x->pr.mont[a] = 0u - inv; }      // Newton: p^-1 mod 2^32
-    { const u64 nm = hm::mulmod(ninv, ((u64)1 << 32) % p, p); x->pr.ninv_m[a] = (u32)nm; x->pr.ninv_m_p[a] = (u32)((nm << 32) / p); }
+    const u64 nm = hm::mulmod(ninv, ((u64)1 << 32) % p, p);
+    x->pr.ninv_m[a] = (u32)nm; x->pr.ninv_m_p[a] = (u32)((nm << 32) / p);
+    // the inverse transform's last stage carries the final scaling (ntt32_inv_kernel3): table entries 0 and 1 of every (prime, sub-block) become
+    // 1/n and w / n, w = that sub-block's distance-16 twiddle; the Montgomery pair (2^32 / n, w 2^32 / n) travels with the primes
+    for (int h = 0; h < (S ? 2 : 1); ++h) {
+      Tw32* t0 = &hi[((size_t)a * (S ? 2 : 1) + h) * A32_N];
+      const u64 w1 = t0[1].w, wn = hm::mulmod(w1, ninv, p), wm = hm::mulmod(w1, nm, p);
+      t0[0] = tw(ninv); t0[1] = tw(wn);
+      x->pr.ninv_mw[a][h] = (u32)wm; x->pr.ninv_mw_p[a][h] = (u32)((wm << 32) / p);
+    }
+    if (!S) { x->pr.ninv_mw[a][1] = x->pr.ninv_mw[a][0]; x->pr.ninv_mw_p[a][1] = x->pr.ninv_mw_p[a][0]; }
     if (p > ((u64)1 << 30) - ((u64)1 << 15) + 1) { delete x; FHESI_FAIL("aux32: prime above 2^30 - 2^15 + 1"); }     // the bound dot32_kernel2's accumulation relies on
   }
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
@@ -164,6 +174,7 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   ProfScope main_prof(ctx, PROF_NTT_FWD_DIGITS_MAIN, (double)(npolys * nd * 4));
   const i64 units = npolys * nd;
   if (units > 0x7fffffff) FHESI_FAIL("ntt32: too many digit rows per launch");
+  if (digit_bits > 30) FHESI_FAIL("ntt32: digits of %d bits (the first stage of a digit row assumes values below 2p)", digit_bits);
   const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
   if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(((units + 7) / 8) * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }

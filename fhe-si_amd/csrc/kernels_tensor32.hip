@@ -166,6 +166,16 @@ static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
       x->head[a] = ff[1]; x->tail[a] = fi[1];
     }
   }
+  // the inverse transform's last stage carries the final scaling (ntt32_inv_kernel3): entries 0 and 1 of every (prime, sub-block) table
+  // become 1/n and w / n, w = that sub-block's distance-16 twiddle (n = 2^14: the sub-transform's length)
+  for (size_t a = 0; a < primes.size(); ++a) {
+    const u64 p = primes[a], ninv = hm::invmod((u64)A32_N % p, p);
+    for (int h = 0; h < (S ? 2 : 1); ++h) {
+      Tw32* t0 = &hi[(a * (S ? 2 : 1) + h) * A32_N];
+      const u64 wn = hm::mulmod(t0[1].w, ninv, p);
+      t0[0] = Tw32{(u32)ninv, (u32)((ninv << 32) / p)}; t0[1] = Tw32{(u32)wn, (u32)((wn << 32) / p)};
+    }
+  }
   hipFree(x->d_fwd); hipFree(x->d_inv);
   x->d_fwd = x->d_inv = nullptr;
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) FHESI_FAIL("tensor32: hipMalloc failed");
