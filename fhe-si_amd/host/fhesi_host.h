@@ -10,6 +10,7 @@
 #pragma once
 #include <cassert>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <set>
@@ -118,6 +119,7 @@ class PAlgebra {
 };
 
 class FHEcontext;
+inline void drop_ct_engine(const FHEcontext*);   // fhesi_engine.h: the arena of device-resident ciphertexts goes before the device context does
 
 // ---------------------------------------------------------------- Cmodulus (CModulus.h:42-170)
 class Cmodulus {
@@ -148,7 +150,7 @@ class FHEcontext {
   unsigned logQ = 0, decompSize = 3, ndigits = 0;
 
   FHEcontext(unsigned m, unsigned logQ_, unsigned p, unsigned gen, unsigned decomp = 3, int device_ = 0) : device(device_) { Init(m, logQ_, ZZ((long)p), gen, decomp); }
-  ~FHEcontext() { if (dev) fhesi_ctx_destroy(dev); }
+  ~FHEcontext() { drop_ct_engine(this); if (dev) fhesi_ctx_destroy(dev); }
   FHEcontext(const FHEcontext&) = delete;
   void Init(unsigned m, unsigned logQ_, const ZZ& p, unsigned gen, unsigned decomp = 3) {   // FHEContext.h:105-118
     m_ = m; logQ = logQ_; modulusQ = ZZ(1L) << (long)logQ_; decompSize = decomp;
@@ -495,6 +497,10 @@ template <typename T> void DotProduct(T& res, const std::vector<T>& v1, const st
   for (size_t i = 1; i < v1.size(); ++i) { T val = v1[i]; val *= v2[i]; res += val; }
 }
 
+}  // namespace fhesi
+#include "fhesi_engine.h"   // device-resident, lazily evaluated ciphertext values (needs FHEcontext above)
+namespace fhesi {
+
 // ---------------------------------------------------------------- Ciphertext (Ciphertext.h, Ciphertext.cpp)
 class CiphertextPart {
   const FHEcontext& context;
@@ -513,29 +519,109 @@ class CiphertextPart {
   bool operator==(const CiphertextPart& o) const { return poly == o.poly; }
 };
 
+// The unscaled parts of a Ciphertext: the reference's `vector<CiphertextPart> parts` (Ciphertext.h:71) with the same access
+// (size, [], iteration, assign, push_back, =), whose contents may live in HBM as a CtValue (fhesi_engine.h) instead of in host big
+// integers.  Every access through this interface brings them to the host first; a writable access also drops the device image.
+class CtParts {
+ public:
+  typedef std::vector<CiphertextPart> Vec;
+ private:
+  mutable Vec host_;
+  mutable bool onHost = true;          // false: the value is `val` only (always two parts)
+  mutable CtRef val;                   // the same two parts in HBM, or the recorded operation that will produce them; null: host only
+  void fetch() const {
+    CtEngine& e = *val->eng;
+    std::vector<uint64_t> lim((size_t)e.words);
+    e.download(val, lim.data());
+    host_.assign(2, CiphertextPart(e.ctx()));
+    for (int part = 0; part < 2; ++part) limbs_to_poly(host_[part].poly, &lim[(size_t)part * e.n * e.nl], e.n, e.nl);
+    onHost = true;
+  }
+ public:
+  const Vec& host() const { if (!onHost) fetch(); return host_; }
+  Vec& host() { if (!onHost) fetch(); val.reset(); return host_; }
+  size_t size() const { return onHost ? host_.size() : 2; }
+  bool empty() const { return size() == 0; }
+  CiphertextPart& operator[](size_t i) { return host()[i]; }
+  const CiphertextPart& operator[](size_t i) const { return host()[i]; }
+  Vec::iterator begin() { return host().begin(); }
+  Vec::iterator end() { return host().end(); }
+  Vec::const_iterator begin() const { return host().begin(); }
+  Vec::const_iterator end() const { return host().end(); }
+  void clear() { host_.clear(); onHost = true; val.reset(); }
+  void assign(size_t cnt, const CiphertextPart& v) { clear(); host_.assign(cnt, v); }
+  void push_back(const CiphertextPart& v) { host().push_back(v); }
+  CtParts& operator=(const Vec& v) { clear(); host_ = v; return *this; }
+  operator const Vec&() const { return host(); }
+  // the device side
+  bool resident() const { return (bool)val; }
+  const CtRef& value() const { return val; }
+  void set_value(CtRef v) { host_.clear(); onHost = false; val = std::move(v); }     // the value lives in HBM from now on
+  void cache_value(CtRef v) const { val = std::move(v); }                              // ... in both places
+};
+
 class Ciphertext {
   const FHEcontext* context;
-  std::vector<DoubleCRT> tProd;
+  // scaled up (Ciphertext.cpp:167-192): the tensor product as DoubleCRT objects, or -- while nobody has looked at it -- as the list of
+  // products of device-resident ciphertexts it is the sum of (multiplied out by the key switch that consumes it, fhesi_engine.h)
+  mutable std::vector<DoubleCRT> tProd;
+  mutable CtTerms terms;
   bool scaledUp = false;
   friend class KeySwitchSI;            // ApplyKeySwitch hands the scaled-up rows to the fused device call without a round trip through the host
+  friend class FHESISecKey;
+  friend class FHESIPubKey;
+  CtEngine& engine() const { return ct_engine(*context); }
+  bool lazy2() const { return LazyCiphertexts() && !scaledUp && parts.size() == 2; }
+  // multiply the recorded products out into tProd (someone wants the rows themselves)
+  void materialise() const {
+    if (terms.empty()) return;
+    CtEngine& e = engine(); e.flush();
+    const long n = e.n, L = context->numPrimes();
+    void* tp; ck(fhesi_dev_alloc(e.h, (size_t)3 * L * n * 8, &tp));
+    tProd.clear();
+    for (auto& t : terms) {
+      int rc = fhesi_ct_mul_dev(e.h, (uint64_t)context->ModulusP().to_long(), e.ptr(t.first->slot), e.ptr(t.second->slot), e.nl, 1, (uint64_t*)tp);
+      std::vector<DoubleCRT> one(3, DoubleCRT(*context));
+      for (int i = 0; i < 3 && !rc; ++i) rc = fhesi_dev_copy(e.h, fhesi_dcrt_device_ptr(one[i].handle()), (const uint64_t*)tp + (size_t)i * L * n, (size_t)L * n * 8);
+      if (rc) { fhesi_dev_free(e.h, tp); ck(rc); }
+      if (tProd.empty()) tProd = one; else for (int i = 0; i < 3; ++i) tProd[i] += one[i];
+    }
+    ck(fhesi_dev_free(e.h, tp));
+    terms.clear();
+  }
  public:
-  std::vector<CiphertextPart> parts;
+  CtParts parts;
   Ciphertext() : context(activeContext) {}
   Ciphertext(const FHEcontext& c) : context(&c) {}
   void Initialize(unsigned n, const FHEcontext& c) { context = &c; parts.assign(n, CiphertextPart(c)); }
-  unsigned size() const { return scaledUp ? (unsigned)tProd.size() : (unsigned)parts.size(); }
+  unsigned size() const { return scaledUp ? (terms.empty() ? (unsigned)tProd.size() : 3u) : (unsigned)parts.size(); }
   CiphertextPart& operator[](unsigned i) { return parts[i]; }
   CiphertextPart GetPart(unsigned i) const { return parts[i]; }
   bool isScaledUp() const { return scaledUp; }
-  void Clear() { tProd.clear(); scaledUp = false; parts.clear(); }     // Ciphertext.cpp:160-165
+  void Clear() { tProd.clear(); terms.clear(); scaledUp = false; parts.clear(); }     // Ciphertext.cpp:160-165
+  // this unscaled two-part ciphertext as a value in HBM (uploaded once, then shared by every copy and every product that uses it)
+  CtRef device_value() const {
+    if (parts.resident()) return parts.value();
+    if (scaledUp || parts.size() != 2) Error("Ciphertext::device_value: expects an unscaled 2-part ciphertext");
+    CtEngine& e = engine();
+    std::vector<uint64_t> lim((size_t)e.words);
+    for (int part = 0; part < 2; ++part) poly_to_limbs(parts.host()[part].poly, &lim[(size_t)part * e.n * e.nl], e.n, e.nl);
+    parts.cache_value(e.upload(lim.data()));
+    return parts.value();
+  }
+  void set_device_value(CtRef v) { tProd.clear(); terms.clear(); scaledUp = false; parts.set_value(std::move(v)); }
 
   Ciphertext& operator+=(const Ciphertext& o) {   // Ciphertext.cpp:123-145
     assert(scaledUp == o.scaledUp);
     if (!scaledUp) {
+      if (lazy2() && o.parts.size() == 2 && (parts.resident() || o.parts.resident())) { CtRef a = device_value(), b = o.device_value(); parts.set_value(engine().add(a, b)); return *this; }
+      CtParts::Vec& mine = parts.host(); const CtParts::Vec& theirs = o.parts.host();
       unsigned i = 0;
-      for (; i < parts.size() && i < o.parts.size(); ++i) { parts[i] += o.parts[i]; ReduceCoefficients(parts[i].poly, context->logQ); }
-      for (; i < o.parts.size(); ++i) parts.push_back(o.parts[i]);
+      for (; i < mine.size() && i < theirs.size(); ++i) { mine[i] += theirs[i]; ReduceCoefficients(mine[i].poly, context->logQ); }
+      for (; i < theirs.size(); ++i) mine.push_back(theirs[i]);
     } else {
+      if (tProd.empty() && o.tProd.empty()) { CtTerms add = o.terms; terms.insert(terms.end(), add.begin(), add.end()); return *this; }   // both still recorded: the sum of all their products
+      materialise(); o.materialise();
       unsigned i = 0;
       for (; i < tProd.size() && i < o.tProd.size(); ++i) tProd[i] += o.tProd[i];
       for (; i < o.tProd.size(); ++i) tProd.push_back(o.tProd[i]);
@@ -544,9 +630,14 @@ class Ciphertext {
   }
   Ciphertext& operator*=(const Ciphertext& o) {   // Ciphertext.cpp:167-192
     if (!scaledUp && !o.scaledUp && parts.size() == 2 && o.parts.size() == 2) {
-      // two fresh ciphertexts (every multiplication the reference's drivers perform): the lift by p, the four DoubleCRT conversions and the
-      // tensor products as ONE device call (fhesi_ct_mul_dev) instead of 4 + 4 + 4 object operations; the same rows, bit for bit
-      // (tests/host/test_wire.cpp compares with the loop below)
+      // two fresh ciphertexts (every multiplication the reference's drivers perform)
+      if (LazyCiphertexts()) {          // recorded: the key switch that follows takes the sum of such products in one device call
+        CtRef a = device_value(), b = o.device_value();
+        terms.assign(1, std::make_pair(a, b)); tProd.clear(); parts.clear(); scaledUp = true;
+        return *this;
+      }
+      // at once: the lift by p, the four DoubleCRT conversions and the tensor products as ONE device call (fhesi_ct_mul_dev) instead of
+      // 4 + 4 + 4 object operations; the same rows, bit for bit (tests/host/test_wire.cpp compares with MulObjects below)
       fhesi_ctx* h = context->handle();
       const long n = context->zMstar.phiM(), L = context->numPrimes(); const int nl = (int)((context->logQ + 63) / 64);
       std::vector<uint64_t> host((size_t)2 * 2 * n * nl, 0);
@@ -566,13 +657,17 @@ class Ciphertext {
     std::vector<DoubleCRT> c1, c2;
     for (auto& p : parts) c1.push_back(DoubleCRT(p.poly * context->ModulusP(), *context));
     for (auto& p : o.parts) c2.push_back(DoubleCRT(p.poly, *context));
-    tProd.assign(c1.size() + c2.size() - 1, DoubleCRT(*context));
+    tProd.assign(c1.size() + c2.size() - 1, DoubleCRT(*context)); terms.clear();
     for (size_t i = 0; i < c1.size(); ++i)
       for (size_t j = 0; j < c2.size(); ++j) { DoubleCRT tmp = c1[i]; tmp *= c2[j]; tProd[i + j] += tmp; }
     parts.clear(); scaledUp = true;
     return *this;
   }
-  Ciphertext& operator*=(long l) { if (!scaledUp) for (auto& p : parts) p *= l; else for (auto& t : tProd) t *= l; return *this; }   // :232-243
+  Ciphertext& operator*=(long l) {   // Ciphertext.cpp:232-243
+    if (lazy2() && parts.resident()) { parts.set_value(engine().scale(parts.value(), l)); return *this; }
+    if (!scaledUp) for (auto& p : parts) p *= l; else { materialise(); for (auto& t : tProd) t *= l; }
+    return *this;
+  }
   // operator+=(const ZZX&) (Ciphertext.cpp:147-161): the constant is scaled by q / p with NTL's floor division and added to part 0
   // (unscaled: device call fhesi_ct_add_const_dev when the coefficients are machine words, else the same arithmetic on the host), or to
   // tProd[0] (scaled-up: DoubleCRT += ZZX).  The std::vector<long> overloads take the role of the reference's ZZ_pX ones (:158-160, :256-258):
@@ -585,14 +680,14 @@ class Ciphertext {
     ZZX sc(other);
     for (auto& c : sc.rep) { c <<= (long)context->logQ; c /= context->ModulusP(); }     // floor division, like NTL
     sc.normalize();
-    if (!scaledUp) { parts[0] += sc; ReduceCoefficients(parts[0].poly, context->logQ); } else tProd[0] += sc;
+    if (!scaledUp) { parts[0] += sc; ReduceCoefficients(parts[0].poly, context->logQ); } else { materialise(); tProd[0] += sc; }
     return *this;
   }
   Ciphertext& operator+=(const std::vector<long>& msg) { return *this += words_to_ZZX(msg); }
   // operator*=(const ZZX&) (Ciphertext.cpp:245-258): unscaled -- every part times the polynomial over the integers, modulo Phi_m, Reduce
   // (CiphertextPart::operator*=(ZZX), :29-36; device call fhesi_ct_mul_poly_dev); scaled-up -- tProd[i] *= DoubleCRT(other)
   Ciphertext& operator*=(const ZZX& other) {
-    if (scaledUp) { DoubleCRT o(other, *context); for (auto& t : tProd) t *= o; return *this; }
+    if (scaledUp) { materialise(); DoubleCRT o(other, *context); for (auto& t : tProd) t *= o; return *this; }
     std::vector<int64_t> small;
     if (words_of(other, small)) with_parts_on_device([&](uint64_t* dev, int nl) { ck(fhesi_ct_mul_poly_dev(context->handle(), (int32_t)context->logQ, dev, (int32_t)parts.size(), nl, 1, small.data(), 1)); });
     else for (auto& p : parts) p *= other;
@@ -609,8 +704,10 @@ class Ciphertext {
     for (size_t i = 0; i < p.rep.size(); ++i) { if (p.rep[i].bits() > 62) return false; out[i] = (int64_t)p.rep[i].to_long(); }
     return true;
   }
-  // the unscaled parts as one device ciphertext [nparts][phi(m)][nl] around a device call, and back
+  // the unscaled parts as one device ciphertext [nparts][phi(m)][nl] around a device call: on a copy of the value's arena slot (the result
+  // stays in HBM), or -- recording off, or not two parts -- through a temporary buffer and back to the host
   template <class Fn> void with_parts_on_device(Fn fn) {
+    if (lazy2()) { CtEngine& e = engine(); const long s = e.clone_slot(device_value()); fn(e.ptr(s), e.nl); parts.set_value(e.wrap(s)); return; }
     const long n = context->zMstar.phiM(); const int nl = (int)((context->logQ + 63) / 64); const size_t np = parts.size();
     std::vector<uint64_t> host(np * n * nl, 0);
     for (size_t i = 0; i < np; ++i) poly_to_limbs(parts[i].poly, &host[(i * n) * nl], n, nl);
@@ -620,9 +717,17 @@ class Ciphertext {
     for (size_t i = 0; i < np; ++i) limbs_to_poly(parts[i].poly, &host[(i * n) * nl], n, nl);
   }
  public:
-  Ciphertext& operator>>=(long k) { if (!scaledUp) for (auto& p : parts) p >>= k; else for (auto& t : tProd) t >>= k; return *this; }   // :264-275
+  Ciphertext& operator>>=(long k) {   // Ciphertext.cpp:264-275
+    if (lazy2() && parts.resident()) {
+      if (!context->zMstar.inZmStar((unsigned)k)) Error("DoubleCRT::automorph: k not in Zm*");
+      parts.set_value(engine().automorph(parts.value(), k)); return *this;
+    }
+    if (!scaledUp) for (auto& p : parts) p >>= k; else { materialise(); for (auto& t : tProd) t >>= k; }
+    return *this;
+  }
   void ScaleDown() {   // Ciphertext.cpp:194-218
     if (!scaledUp) return;
+    materialise();
     ZZ q = context->modulusQ, q2 = q * ZZ(2L);
     parts.clear();
     for (auto& t : tProd) {
@@ -634,7 +739,7 @@ class Ciphertext {
     scaledUp = false; tProd.clear();
   }
   Ciphertext& ByteDecomp() {   // Ciphertext.cpp:82-121: part-major, digit-minor
-    std::vector<CiphertextPart> orig = parts; const unsigned nd = context->ndigits, bits = 8 * context->decompSize;
+    std::vector<CiphertextPart> orig = parts.host(); const unsigned nd = context->ndigits, bits = 8 * context->decompSize;
     parts.assign(orig.size() * nd, CiphertextPart(*context));
     ZZ mask = (ZZ(1L) << (long)bits) - ZZ(1L);
     for (size_t pi = 0; pi < orig.size(); ++pi)
@@ -663,16 +768,37 @@ class FHESISecKey {
   // Decrypt for many unscaled 2-part ciphertexts in one device call (fhesi_decrypt_batch); same values as repeated Decrypt calls
   void DecryptBatch(std::vector<Plaintext>& ptxts, const std::vector<Ciphertext>& ctxts) const {
     const long n = context.zMstar.phiM(), count = (long)ctxts.size(); const int nl = (int)((context.logQ + 63) / 64);
-    std::vector<uint64_t> host((size_t)count * 2 * n * nl);
-    for (long c = 0; c < count; ++c) for (int part = 0; part < 2; ++part) for (long j = 0; j < n; ++j) coeff(ctxts[c].GetPart((unsigned)part).poly, j).to_limbs(&host[((c * 2 + part) * n + j) * nl], nl);
-    void* dev; ck(fhesi_dev_alloc(context.handle(), host.size() * 8, &dev)); ck(fhesi_dev_upload(context.handle(), dev, host.data(), host.size() * 8));
     std::vector<int64_t> msg((size_t)count * n);
-    ck(fhesi_decrypt_batch(context.handle(), sKeys[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), (const uint64_t*)dev, nl, count, msg.data()));
-    ck(fhesi_dev_free(context.handle(), dev));
+    if (LazyCiphertexts() && count) {
+      // the ciphertexts as values in HBM (whatever was recorded for them runs now), gathered into one run of the arena
+      CtEngine& e = ct_engine(context);
+      std::vector<CtRef> vals; for (auto& c : ctxts) vals.push_back(c.device_value());
+      e.flush();
+      std::vector<int32_t> idx; for (auto& v : vals) { e.force(v); idx.push_back((int32_t)v->slot); }
+      const long run = e.alloc_run(count);
+      ck(fhesi_ct_gather_dev(e.h, e.pool(), idx.data(), count, e.words, e.ptr(run)));
+      int rc = fhesi_decrypt_batch(e.h, sKeys[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), e.ptr(run), nl, count, msg.data());
+      e.free_run(run, count);
+      ck(rc);
+    } else {
+      std::vector<uint64_t> host((size_t)count * 2 * n * nl);
+      for (long c = 0; c < count; ++c) for (int part = 0; part < 2; ++part) for (long j = 0; j < n; ++j) coeff(ctxts[c].GetPart((unsigned)part).poly, j).to_limbs(&host[((c * 2 + part) * n + j) * nl], nl);
+      void* dev; ck(fhesi_dev_alloc(context.handle(), host.size() * 8, &dev)); ck(fhesi_dev_upload(context.handle(), dev, host.data(), host.size() * 8));
+      ck(fhesi_decrypt_batch(context.handle(), sKeys[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), (const uint64_t*)dev, nl, count, msg.data()));
+      ck(fhesi_dev_free(context.handle(), dev));
+    }
     ptxts.assign(count, Plaintext());
     for (long c = 0; c < count; ++c) ptxts[c].message.assign(msg.begin() + c * n, msg.begin() + (c + 1) * n);
   }
   void Decrypt(Plaintext& ptxt, const Ciphertext& ctxt) const {   // FHE-SI.cpp:93-119
+    if (LazyCiphertexts() && !ctxt.isScaledUp() && ctxt.parts.resident() && sKeys.size() == 2) {
+      // the ciphertext lives in HBM: the same dot product with (1, t), rounding and reduction as ONE device call on it (fhesi_decrypt_batch)
+      CtEngine& e = ct_engine(context); CtRef v = ctxt.parts.value(); e.force(v);
+      std::vector<int64_t> msg((size_t)e.n);
+      ck(fhesi_decrypt_batch(e.h, sKeys[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), e.ptr(v->slot), e.nl, 1, msg.data()));
+      ptxt.message.assign(msg.begin(), msg.end());
+      return;
+    }
     std::vector<DoubleCRT> cp, sp;
     for (size_t i = 0; i < sKeys.size(); ++i) { cp.push_back(DoubleCRT(ctxt.GetPart((unsigned)i).poly, context)); sp.push_back(sKeys[i]); }
     DoubleCRT tmp(context); DotProduct(tmp, cp, sp);
@@ -707,6 +833,14 @@ class FHESIPubKey {
       for (int i = 0; i < 2; ++i) { ZZX e; sampleGaussian(e, n, context.stdev); for (long j = 0; j < n; ++j) rnd[(c * 3 + 1 + i) * n + j] = coeff(e, j).to_long(); }
       for (size_t k = 0; k < ptxts[c].message.size() && (long)k < n; ++k) msg[c * n + k] = ptxts[c].message[k];
     }
+    if (LazyCiphertexts() && count) {            // the ciphertexts stay in HBM, as consecutive slots of the arena
+      CtEngine& e = ct_engine(context); const long first = e.alloc_run(count);
+      int rc = fhesi_encrypt_batch(e.h, publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), rnd.data(), msg.data(), count, e.ptr(first), nl);
+      if (rc) { e.free_run(first, count); ck(rc); }
+      ctxts.assign(count, Ciphertext(context));
+      for (long c = 0; c < count; ++c) ctxts[c].set_device_value(e.wrap(first + c));
+      return;
+    }
     void* dev; ck(fhesi_dev_alloc(context.handle(), (size_t)count * 2 * n * nl * 8, &dev));
     ck(fhesi_encrypt_batch(context.handle(), publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), rnd.data(), msg.data(),
                            count, (uint64_t*)dev, nl));
@@ -720,12 +854,20 @@ class FHESIPubKey {
   }
   // ... with r and the noise drawn ON THE DEVICE from the counter-based generator (fhesi_encrypt_batch_seeded, csrc/philox.h): plaintext i
   // uses the streams of object index first + i, so a batch can be split or repeated anywhere and give the same ciphertexts
-  void EncryptBatchSeeded(std::vector<Ciphertext>& ctxts, const std::vector<Plaintext>& ptxts, uint64_t seed, uint64_t first = 0) const {
+  void EncryptBatchSeeded(std::vector<Ciphertext>& ctxts, const std::vector<Plaintext>& ptxts, uint64_t seed, uint64_t first_obj = 0) const {
     const long n = context.zMstar.phiM(), count = (long)ptxts.size(); const int nl = (int)((context.logQ + 63) / 64);
     std::vector<int64_t> msg((size_t)count * n, 0);
     for (long c = 0; c < count; ++c) for (size_t k = 0; k < ptxts[c].message.size() && (long)k < n; ++k) msg[c * n + k] = ptxts[c].message[k];
+    if (LazyCiphertexts() && count) {
+      CtEngine& e = ct_engine(context); const long first = e.alloc_run(count);
+      int rc = fhesi_encrypt_batch_seeded(e.h, publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), seed, first_obj, msg.data(), count, e.ptr(first), nl);
+      if (rc) { e.free_run(first, count); ck(rc); }
+      ctxts.assign(count, Ciphertext(context));
+      for (long c = 0; c < count; ++c) ctxts[c].set_device_value(e.wrap(first + c));
+      return;
+    }
     void* dev; ck(fhesi_dev_alloc(context.handle(), (size_t)count * 2 * n * nl * 8, &dev));
-    ck(fhesi_encrypt_batch_seeded(context.handle(), publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), seed, first, msg.data(), count, (uint64_t*)dev, nl));
+    ck(fhesi_encrypt_batch_seeded(context.handle(), publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), seed, first_obj, msg.data(), count, (uint64_t*)dev, nl));
     std::vector<uint64_t> host((size_t)count * 2 * n * nl);
     ck(fhesi_dev_download(context.handle(), host.data(), dev, host.size() * 8)); ck(fhesi_dev_free(context.handle(), dev));
     ctxts.assign(count, Ciphertext(context));
@@ -786,7 +928,7 @@ class KeySwitchSI {
         ck(fhesi_dev_copy(context.handle(), fhesi_dcrt_device_ptr(d.handle()), rows + ((size_t)r * ncol + col) * rowWords, rowWords * 8));
         keySwitchMatrix[r].push_back(d);
       }
-    drop_device_key(); devKey = k;                            // the device object the matrix was generated in serves the fused calls as it is
+    devKey = std::make_shared<DeviceKey>(k);                  // the device object the matrix was generated in serves the fused calls as it is
   }
   // the same matrix with the column randomness drawn on the device (fhesi_keyswitch_init_batch_seeded): column c <-> object index first + c
   struct Seeded { uint64_t seed, first; };
@@ -810,7 +952,7 @@ class KeySwitchSI {
       ck(fhesi_dev_copy(context.handle(), fhesi_dcrt_device_ptr(d.handle()), rows + ((size_t)r * ncol + col) * rowWords, rowWords * 8));
       keySwitchMatrix[r].push_back(d);
     }
-    drop_device_key(); devKey = k;
+    devKey = std::make_shared<DeviceKey>(k);
   }
   void InitObjects(const FHESISecKey& src, const FHESISecKey& dst) {   // the reference's loop, one object at a time
     std::vector<DoubleCRT> s = src.GetRepresentation(); std::vector<ZZX> sCoeff(s.size());
@@ -853,6 +995,21 @@ class KeySwitchSI {
   void ApplyKeySwitch(Ciphertext& ctxt) const {
     const size_t ncomp = keySwitchMatrix.empty() ? 0 : keySwitchMatrix[0].size() / context.ndigits;
     if (objectAtATime || ncomp < 2 || ctxt.size() != ncomp) { ApplyKeySwitchObjects(ctxt); return; }
+    if (LazyCiphertexts()) {
+      CtEngine& e = ct_engine(context);
+      if (ctxt.scaledUp && !ctxt.terms.empty() && ncomp == 3) {       // a sum of recorded products: multiplied out and key-switched in one call of the next evaluation
+        CtRef v = e.ks_sum(std::move(ctxt.terms), device_key_ref());
+        ctxt.set_device_value(v);
+        return;
+      }
+      if (!ctxt.scaledUp && ncomp == 2 && ctxt.parts.size() == 2 && ctxt.parts.resident()) {   // after an automorphism (Regression.h:170-172)
+        CtRef in = ctxt.parts.value();
+        CtRef v = (in->kind == CtValue::AUTO && in->pending()) ? e.auto_ks(in->a, in->s, device_key_ref()) : e.auto_ks(in, 1, device_key_ref());
+        ctxt.set_device_value(v);
+        return;
+      }
+    }
+    ctxt.materialise();
     fhesi_ctx* h = context.handle(); fhesi_ksk* k = device_key();
     const long n = context.zMstar.phiM(), L = context.numPrimes(); const int nl = (int)((context.logQ + 63) / 64);
     void* out; ck(fhesi_dev_alloc(h, (size_t)2 * n * nl * 8, &out));
@@ -888,6 +1045,13 @@ class KeySwitchSI {
   void MulRelinBatch(std::vector<Ciphertext>& a, const std::vector<Ciphertext>& b) const {
     if (a.size() != b.size()) Error("MulRelinBatch: the operand vectors differ in length");
     const size_t count = a.size(); if (!count) return;
+    if (LazyCiphertexts() && !objectAtATime) {    // recorded: the two statements per object become one wave at the next evaluation, operands and results in HBM
+      for (size_t c = 0; c < count; ++c) {
+        if (a[c].isScaledUp() || b[c].isScaledUp() || a[c].size() != 2 || b[c].size() != 2) Error("MulRelinBatch: operands must be unscaled two-part ciphertexts");
+        a[c] *= b[c]; ApplyKeySwitch(a[c]);
+      }
+      return;
+    }
     const long n = context.zMstar.phiM(); const int nl = (int)((context.logQ + 63) / 64);
     std::vector<uint64_t> ha(count * 2 * n * nl, 0), hb(ha.size(), 0), ho(ha.size());
     for (size_t c = 0; c < count; ++c) {
@@ -897,22 +1061,26 @@ class KeySwitchSI {
     ck(fhesi_ct_mul_relin_batch(context.handle(), device_key(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), (int32_t)context.decompSize, ha.data(), hb.data(), ho.data(), nl, (int64_t)count));
     for (size_t c = 0; c < count; ++c) for (int part = 0; part < 2; ++part) limbs_to_poly(a[c].parts[part].poly, &ho[((c * 2 + part) * n) * nl], n, nl);
   }
-  ~KeySwitchSI() { if (devKey) fhesi_ksk_free(devKey); }
-  KeySwitchSI(const KeySwitchSI& o) : context(o.context), keySwitchMatrix(o.keySwitchMatrix), objectAtATime(o.objectAtATime) {}      // (the device object is rebuilt on first use)
-  KeySwitchSI& operator=(const KeySwitchSI& o) { if (&context != &o.context) Error("Incompatible contexts."); keySwitchMatrix = o.keySwitchMatrix; objectAtATime = o.objectAtATime; drop_device_key(); return *this; }
+  KeySwitchSI(const KeySwitchSI& o) : context(o.context), keySwitchMatrix(o.keySwitchMatrix), objectAtATime(o.objectAtATime), devKey(o.devKey) {}      // (the device object is immutable once built: shared)
+  KeySwitchSI& operator=(const KeySwitchSI& o) { if (&context != &o.context) Error("Incompatible contexts."); keySwitchMatrix = o.keySwitchMatrix; objectAtATime = o.objectAtATime; devKey = o.devKey; return *this; }
  private:
-  mutable fhesi_ksk* devKey = nullptr;                         // keySwitchMatrix as one HBM-resident fhesi_ksk for the fused calls
-  void drop_device_key() const { if (devKey) { fhesi_ksk_free(devKey); devKey = nullptr; } }
-  fhesi_ksk* device_key() const {
+  // keySwitchMatrix as one HBM-resident fhesi_ksk for the fused calls; shared with the recorded operations that will use it (fhesi_engine.h),
+  // so a matrix that is replaced or destroyed before they run stays alive until they have
+  mutable DeviceKeyRef devKey;
+  void drop_device_key() const { devKey.reset(); }
+  const DeviceKeyRef& device_key_ref() const {
     if (devKey) return devKey;
     const size_t ncol = keySwitchMatrix[0].size(), ncomp = ncol / context.ndigits; const size_t rowWords = (size_t)context.numPrimes() * context.zMstar.phiM();
-    ck(fhesi_ksk_create(context.handle(), (int32_t)ncomp, (int32_t)context.ndigits, &devKey));
-    uint64_t* rows = (uint64_t*)fhesi_ksk_device_ptr(devKey);
+    fhesi_ksk* k = nullptr;
+    ck(fhesi_ksk_create(context.handle(), (int32_t)ncomp, (int32_t)context.ndigits, &k));
+    devKey = std::make_shared<DeviceKey>(k);
+    uint64_t* rows = (uint64_t*)fhesi_ksk_device_ptr(k);
     for (int r = 0; r < 2; ++r) for (size_t col = 0; col < ncol; ++col)
       ck(fhesi_dev_copy(context.handle(), rows + ((size_t)r * ncol + col) * rowWords, fhesi_dcrt_device_ptr(keySwitchMatrix[r][col].handle()), rowWords * 8));
-    ck(fhesi_ksk_mark_dirty(devKey));
+    ck(fhesi_ksk_mark_dirty(k));
     return devKey;
   }
+  fhesi_ksk* device_key() const { return device_key_ref()->k; }
 };
 
 }  // namespace fhesi

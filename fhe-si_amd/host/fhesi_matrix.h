@@ -149,11 +149,22 @@ class RankState {
     ck(fhesi_ct_mul_long_dev(h, (int32_t)context.logQ, ptr(first), -1, 2, nl, (int64_t)idx.size()));
   }
   void upload(const Ciphertext& ct, long idx) {
+    if (LazyCiphertexts() && h == context.handle() && ct.parts.resident()) {      // already a value in HBM of this GPU (fhesi_engine.h): device to device
+      CtEngine& e = ct_engine(context); CtRef v = ct.parts.value(); e.force(v);
+      ck(fhesi_dev_copy(h, ptr(idx), e.ptr(v->slot), (size_t)words * 8));
+      return;
+    }
     std::vector<uint64_t> v(words);
     for (int part = 0; part < 2; ++part) for (long i = 0; i < n; ++i) coeff(ct.parts[part].poly, i).to_limbs(&v[(part * n + i) * nl], nl);
     ck(fhesi_dev_upload(h, ptr(idx), v.data(), (size_t)words * 8));
   }
   void download(long idx, Ciphertext& ct) const {
+    if (LazyCiphertexts() && h == context.handle()) {                             // stays in HBM; the host form is made when somebody reads parts[i].poly
+      CtEngine& e = ct_engine(context); const long s = e.alloc_run(1);
+      ck(fhesi_dev_copy(h, e.ptr(s), ptr(idx), (size_t)words * 8));
+      ct = Ciphertext(context); ct.set_device_value(e.wrap(s));
+      return;
+    }
     std::vector<uint64_t> v(words);
     ck(fhesi_dev_download(h, v.data(), ptr(idx), (size_t)words * 8));
     ct.Initialize(2, context);

@@ -94,8 +94,8 @@ inline void Import(std::istream& in, DoubleCRT& d) {
 }
 inline void Export(std::ostream& out, const CiphertextPart& part) { Export(out, part.poly); }      // Serialization.cpp:101-107
 inline void Import(std::istream& in, CiphertextPart& part) { Import(in, part.poly); }
-inline void Export(std::ostream& out, const Ciphertext& ctxt) { Ciphertext copy = ctxt; copy.ScaleDown(); Export(out, copy.parts); }   // :109-114
-inline void Import(std::istream& in, Ciphertext& ctxt) { ctxt.Clear(); Import(in, ctxt.parts); }                                        // :116-119
+inline void Export(std::ostream& out, const Ciphertext& ctxt) { Ciphertext copy = ctxt; copy.ScaleDown(); Export(out, copy.parts.host()); }   // :109-114
+inline void Import(std::istream& in, Ciphertext& ctxt) { ctxt.Clear(); Import(in, ctxt.parts.host()); }                                        // :116-119
 
 template <typename T> void Export(std::ostream& out, const std::vector<T>& v) { ExportRaw(out, (uint32_t)v.size()); for (const auto& x : v) Export(out, x); }
 template <typename T> void Import(std::istream& in, std::vector<T>& v) {

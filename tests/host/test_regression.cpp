@@ -5,7 +5,8 @@
 //
 // Context as in Test_Regression.cpp:97-125: m = p-1, logQ from the same noise formula, SetUpSIContext(xi).  The data matrix
 // (nrows x dim) and the labels are random polynomials over Z_p; Regression::Regress is evaluated three ways
-//   (1) object at a time through LMatrix<Ciphertext> (matrix_literal.h) -- the reference's control flow,
+//   (1) object at a time through LMatrix<Ciphertext> (matrix_literal.h) -- the reference's control flow, its statements recorded and evaluated
+//       in batches by the mirror's Ciphertext (fhesi_engine.h); with --at-once also with every statement run at once (FHESI_EAGER),
 //   (2) in waves on the device (Regression::RegressBatched),
 //   (3) in the plaintext ring Z_p[X]/Phi_m with the same LMatrix<T> template,
 // and the run succeeds when (1) and (2) give bit-identical ciphertexts and both decrypt to (3).
@@ -71,11 +72,12 @@ static long eval_at(const std::vector<long>& c, long x, long p) { long r = 0; fo
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char* argv[]) {
-  bool batchedOnly = false; std::string check = "ring"; unsigned mOverride = 0, logQOverride = 0; int repeat = 1;
+  bool batchedOnly = false, atOnce = false; std::string check = "ring"; unsigned mOverride = 0, logQOverride = 0; int repeat = 1;
   std::vector<int> devices;                // --devices=0,1,...: also run the wave evaluator sharded over these GPUs (first = the context's)
   std::vector<char*> args;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--batched-only")) batchedOnly = true;
+    else if (!strcmp(argv[i], "--at-once")) atOnce = true;
     else if (!strncmp(argv[i], "--check=", 8)) check = argv[i] + 8;
     else if (!strncmp(argv[i], "--repeat=", 9)) repeat = atoi(argv[i] + 9);
     else if (!strncmp(argv[i], "--devices=", 10)) { for (char* t = strtok(argv[i] + 10, ","); t; t = strtok(nullptr, ",")) devices.push_back(atoi(t)); }
@@ -202,15 +204,31 @@ int main(int argc, char* argv[]) {
   }
   if (!batchedOnly) {
     std::vector<Ciphertext> thetaA; Ciphertext detA(context);
+    CtEngine& eng = ct_engine(context);
+    const long calls0 = eng.stats.calls, rec0 = eng.stats.recorded;
     t0 = now();
     RegressLiteral(regress, thetaA, detA);
+    SyncCiphertexts(context);
     double tA = now() - t0;
-    std::cout << "object at a time: " << tA << " s" << std::endl;
+    std::cout << "object at a time" << (LazyCiphertexts() ? " (recorded: " + std::to_string(eng.stats.recorded - rec0) + " operations, " + std::to_string(eng.stats.calls - calls0) + " device calls)" : std::string(" (at once)"))
+              << ": " << tA << " s" << std::endl;
     check_fn("object at a time", thetaA, detA);
     bool same = thetaA.size() == thetaB.size() && detA[0] == detB[0] && detA[1] == detB[1];
     for (unsigned i = 0; same && i < thetaA.size(); ++i) same = thetaA[i][0] == thetaB[i][0] && thetaA[i][1] == thetaB[i][1];
     std::cout << "ciphertexts of both evaluators bit-identical: " << (same ? "yes" : "NO") << std::endl;
     if (!same) ++failures;
+    if (atOnce && LazyCiphertexts()) {
+      LazyCiphertexts() = false;
+      std::vector<Ciphertext> thetaE; Ciphertext detE(context);
+      t0 = now();
+      RegressLiteral(regress, thetaE, detE);
+      std::cout << "object at a time (at once): " << now() - t0 << " s" << std::endl;
+      LazyCiphertexts() = true;
+      bool sameE = thetaE.size() == thetaA.size() && detE[0] == detA[0] && detE[1] == detA[1];
+      for (unsigned i = 0; sameE && i < thetaE.size(); ++i) sameE = thetaE[i][0] == thetaA[i][0] && thetaE[i][1] == thetaA[i][1];
+      std::cout << "recorded and at-once ciphertexts bit-identical: " << (sameE ? "yes" : "NO") << std::endl;
+      if (!sameE) ++failures;
+    }
   }
   std::cout << (failures ? "Test FAILED" : "Test SUCCEEDED") << std::endl;
   return failures;

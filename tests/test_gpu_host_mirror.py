@@ -87,11 +87,31 @@ def test_regression_object_path_equals_batched_waves(p, g, dim, rows, seed):
     device waves (RegressBatched), plaintext ring -- see tests/host/test_regression.cpp.  m = 22 and 46 run Bluestein rows,
     m = 16 and 256 the power-of-two NTT."""
     build()
-    r = subprocess.run([REG, str(p), str(g), str(dim), str(rows), str(seed)], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([REG, str(p), str(g), str(dim), str(rows), str(seed), "--at-once"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ciphertexts of both evaluators bit-identical: yes" in r.stdout
+    assert "recorded and at-once ciphertexts bit-identical: yes" in r.stdout       # the literal control flow recorded (fhesi_engine.h) = run statement by statement
     assert r.stdout.count("decrypts to the plaintext regression: yes") == 2
     assert "Test SUCCEEDED" in r.stdout
+
+
+def test_regression_literal_with_recording_off():
+    """FHESI_EAGER=1: every statement of the literal control flow runs at once (no recording anywhere in the process); same ciphertexts as the waves."""
+    build()
+    r = subprocess.run([REG, "23", "7", "3", "2", "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, FHESI_EAGER="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "object at a time (at once)" in r.stdout and "ciphertexts of both evaluators bit-identical: yes" in r.stdout
+
+
+@pytest.mark.parametrize("args", [[], ["46", "90", "47", "5"], ["256", "130", "257", "3", "3"]])
+def test_recorded_ciphertext_operations_equal_statements_run_at_once(args):
+    """The mirror's Ciphertext records operator*= / += / *= long / >>= / ApplyKeySwitch on device-resident values and evaluates them in
+    batches (fhe-si_amd/host/fhesi_engine.h); every flow of tests/host/test_lazy.cpp must give the ciphertexts the same statements give
+    when each runs at once through the bodies that follow Ciphertext.cpp:123-275 and FHE-SI.cpp:241-260."""
+    build()
+    r = subprocess.run([os.path.join(HOST, "test_lazy"), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Test SUCCEEDED" in r.stdout and "FAIL" not in r.stdout
 
 
 def test_wire_format_bytes_match_python_model(tmp_path):
