@@ -724,6 +724,18 @@ def main():
                 for cnt, rate in re.findall(r"MulRelinBatch of (\d+)\): .*? = ([0-9.]+) ciphertext-mults/s", r.stdout):
                     cs[f"MulRelinBatch_{cnt}"] = round(float(rate), 1)
                 surface["class_surface"] = cs
+                # the per-object statements `c *= d; keySwitch.ApplyKeySwitch(c)` in a loop over 1024 (and 64) ciphertexts, results read
+                # afterwards: the mirror records them and runs one device call (fhe-si_amd/host/fhesi_engine.h); tests/host/test_lazy --time
+                lz = os.path.join(ROOT, "tests", "host", "test_lazy")
+                if os.path.exists(lz):
+                    for cnt in (1024, 64):
+                        r = subprocess.run([lz, "--time", str(cnt), str(M_RING), str(LOGQ), str(P_PLAIN), "7"], capture_output=True, text=True, timeout=600)
+                        rates = [float(x) for x in re.findall(r"recorded: .*? = ([0-9.]+) per second", r.stdout)]
+                        if r.returncode == 0 and rates:
+                            cs[f"per_object_loop_{cnt}"] = round(max(rates[1:] or rates), 1)
+                        mm = re.search(r"at once: .*? = ([0-9.]+) per second", r.stdout)
+                        if mm and cnt == 64:
+                            cs["per_object_statements_at_once"] = round(float(mm.group(1)), 1)
             except Exception as e:          # the surface figures are extras: never fail the contract line over them
                 surface["class_surface"] = {"ok": False, "error": str(e)[:200]}
 

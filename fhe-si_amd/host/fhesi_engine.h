@@ -10,7 +10,8 @@
 //     KS_SUM   out = ApplyKeySwitch(sum_t a_t *= b_t)        -> fhesi_ct_mul_sum_relin_dev  (Ciphertext.cpp:167-192 + :135-142 + FHE-SI.cpp:241-260)
 //     AUTO_KS  out = ApplyKeySwitch_k(a >>= k)               -> fhesi_ct_automorph_key_switch_dev (Regression.h:170-172)
 //     ADD / SCALE / AUTO  unscaled +=, *= long, >>= k        -> fhesi_ct_add_dev / fhesi_ct_mul_long_dev / fhesi_ct_automorph_dev
-// Values are immutable, so copies of a Ciphertext share them.  The results are the bits the object-at-a-time bodies give (every batched
+// Values are immutable, so copies of a Ciphertext share them, and an operation recorded twice on the same inputs is recorded once
+// (the Laplace expansion of Matrix.cpp:227-263 recomputes equal minors: d = 8 writes 5.5 * 10^5 partial determinants, 12870 are distinct).  The results are the bits the object-at-a-time bodies give (every batched
 // call is checked against them: tests/host/test_lazy.cpp, test_regression.cpp); FHESI_EAGER=1 (or LazyCiphertexts() = false) turns the
 // recording off and runs every statement at once, as before.  Errors of a recorded operation surface when it runs, not when it is
 // recorded.  Single-threaded, like the reference's classes.
@@ -23,7 +24,9 @@ inline bool& LazyCiphertexts() { static bool on = std::getenv("FHESI_EAGER") == 
 // a key-switching matrix as ONE object in HBM, shared by the KeySwitchSI it mirrors and by the recorded operations that will use it
 struct DeviceKey {
   fhesi_ksk* k = nullptr;
-  explicit DeviceKey(fhesi_ksk* kk) : k(kk) {}
+  const long id;                                            // never reused (an address can be)
+  static long next_id() { static long n = 0; return ++n; }
+  explicit DeviceKey(fhesi_ksk* kk) : k(kk), id(next_id()) {}
   ~DeviceKey() { if (k) fhesi_ksk_free(k); }
   DeviceKey(const DeviceKey&) = delete;
 };
@@ -38,6 +41,7 @@ struct CtValue {
   enum Kind : uint8_t { DEVICE, KS_SUM, AUTO_KS, ADD, SCALE, AUTO };
   std::shared_ptr<CtEngine> eng;
   Kind kind = DEVICE;
+  long id = 0;                    // unique per engine; never reused
   long slot = -1;                 // arena index once the value exists in HBM
   int depth = -1;                 // scratch of CtEngine::flush
   CtTerms terms;                  // KS_SUM
@@ -55,6 +59,9 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
   std::map<long, long> freeRuns;                       // start -> length, coalesced
   std::vector<std::weak_ptr<CtValue>> recorded;        // every value that was pending when created
   bool dead = false;
+  typedef std::vector<long> Sig;                       // (kind, scalar, key, ids of the inputs): equal signatures = equal values
+  std::map<Sig, std::weak_ptr<CtValue>> memo;
+  long nextId = 0;
 
   void add_free(long start, long len) {
     auto it = freeRuns.lower_bound(start);
@@ -73,10 +80,20 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
     cap = ncap;
   }
   CtRef make(CtValue::Kind kind) {
-    CtRef v = std::make_shared<CtValue>(); v->eng = shared_from_this(); v->kind = kind;
+    CtRef v = std::make_shared<CtValue>(); v->eng = shared_from_this(); v->kind = kind; v->id = ++nextId;
     if (kind != CtValue::DEVICE) { recorded.push_back(v); ++stats.recorded; }
     return v;
   }
+  CtRef known(const Sig& sig) {
+    if (!shareEqual) return nullptr;
+    auto it = memo.find(sig);
+    if (it == memo.end()) return nullptr;
+    if (CtRef v = it->second.lock()) { ++stats.shared; return v; }
+    memo.erase(it);
+    return nullptr;
+  }
+  CtRef remember(const Sig& sig, CtRef v) { if (shareEqual) memo[sig] = v; maybe_flush(); return v; }
+  static Sig sig_of(CtValue::Kind kind, long s, const DeviceKey* key, const CtValue* a, const CtValue* b) { return Sig{(long)kind, s, key ? key->id : 0, a ? a->id : 0, b ? b->id : 0}; }
   static void done(CtValue* v, long slot) { v->slot = slot; v->terms.clear(); v->a.reset(); v->b.reset(); v->key.reset(); }
   std::vector<int32_t> slots_of(const std::vector<CtValue*>& vs, bool second) const { std::vector<int32_t> r; for (auto v : vs) r.push_back((int32_t)(second ? v->b->slot : v->a->slot)); return r; }
 
@@ -85,12 +102,13 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
   const long n;
   const int nl;
   const long words;                                    // uint64 per ciphertext: [2][phi(m)][nl]
-  struct Stats { long recorded = 0, flushes = 0, calls = 0, products = 0, key_switches = 0; } stats;
+  struct Stats { long recorded = 0, shared = 0, flushes = 0, calls = 0, products = 0, key_switches = 0; } stats;
+  bool shareEqual = true;                              // an operation recorded again on the same values returns the value recorded first
   long flushAt = 8192;                                 // recorded operations that trigger an evaluation by themselves (bounds the graph held on the host)
 
   explicit CtEngine(const FHEcontext& c) : context(c), h(c.handle()), n(c.zMstar.phiM()), nl((int)((c.logQ + 63) / 64)), words(2 * (long)c.zMstar.phiM() * (long)((c.logQ + 63) / 64)) {}
   ~CtEngine() { shutdown(); }
-  void shutdown() { dead = true; recorded.clear(); if (base) { fhesi_dev_free(h, base); base = nullptr; } cap = 0; freeRuns.clear(); }
+  void shutdown() { dead = true; recorded.clear(); memo.clear(); if (base) { fhesi_dev_free(h, base); base = nullptr; } cap = 0; freeRuns.clear(); }
   const FHEcontext& ctx() const { return context; }
   uint64_t* ptr(long slot) const { return base + slot * words; }
   const uint64_t* pool() const { return base; }
@@ -111,11 +129,32 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
   void download(const CtRef& v, uint64_t* host) { force(v); ck(fhesi_dev_download(h, host, ptr(v->slot), (size_t)words * 8)); }
   long clone_slot(const CtRef& v) { force(v); const long s = alloc_run(1); ck(fhesi_dev_copy(h, ptr(s), ptr(v->slot), (size_t)words * 8)); return s; }
   // ---- recorded operations
-  CtRef ks_sum(CtTerms terms, DeviceKeyRef key) { CtRef v = make(CtValue::KS_SUM); v->terms = std::move(terms); v->key = std::move(key); maybe_flush(); return v; }
-  CtRef auto_ks(CtRef a, long k, DeviceKeyRef key) { CtRef v = make(CtValue::AUTO_KS); v->a = std::move(a); v->s = k; v->key = std::move(key); maybe_flush(); return v; }
-  CtRef add(CtRef a, CtRef b) { CtRef v = make(CtValue::ADD); v->a = std::move(a); v->b = std::move(b); maybe_flush(); return v; }
-  CtRef scale(CtRef a, long l) { CtRef v = make(CtValue::SCALE); v->a = std::move(a); v->s = l; maybe_flush(); return v; }
-  CtRef automorph(CtRef a, long k) { CtRef v = make(CtValue::AUTO); v->a = std::move(a); v->s = k; maybe_flush(); return v; }
+  CtRef ks_sum(CtTerms terms, DeviceKeyRef key) {
+    Sig sig{(long)CtValue::KS_SUM, 0, key->id};
+    for (auto& t : terms) { sig.push_back(t.first->id); sig.push_back(t.second->id); }
+    if (CtRef v = known(sig)) return v;
+    CtRef v = make(CtValue::KS_SUM); v->terms = std::move(terms); v->key = std::move(key); return remember(sig, v);
+  }
+  CtRef auto_ks(CtRef a, long k, DeviceKeyRef key) {
+    const Sig sig = sig_of(CtValue::AUTO_KS, k, key.get(), a.get(), nullptr);
+    if (CtRef v = known(sig)) return v;
+    CtRef v = make(CtValue::AUTO_KS); v->a = std::move(a); v->s = k; v->key = std::move(key); return remember(sig, v);
+  }
+  CtRef add(CtRef a, CtRef b) {
+    const Sig sig = sig_of(CtValue::ADD, 0, nullptr, a.get(), b.get());
+    if (CtRef v = known(sig)) return v;
+    CtRef v = make(CtValue::ADD); v->a = std::move(a); v->b = std::move(b); return remember(sig, v);
+  }
+  CtRef scale(CtRef a, long l) {
+    const Sig sig = sig_of(CtValue::SCALE, l, nullptr, a.get(), nullptr);
+    if (CtRef v = known(sig)) return v;
+    CtRef v = make(CtValue::SCALE); v->a = std::move(a); v->s = l; return remember(sig, v);
+  }
+  CtRef automorph(CtRef a, long k) {
+    const Sig sig = sig_of(CtValue::AUTO, k, nullptr, a.get(), nullptr);
+    if (CtRef v = known(sig)) return v;
+    CtRef v = make(CtValue::AUTO); v->a = std::move(a); v->s = k; return remember(sig, v);
+  }
   void maybe_flush() { if ((long)recorded.size() >= flushAt) flush(); }
   void force(const CtRef& v) { if (v->pending()) flush(); if (v->pending()) Error("CtEngine: a recorded operation was not evaluated"); }
 
@@ -124,6 +163,7 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
     std::vector<CtRef> todo;
     for (auto& w : recorded) if (CtRef v = w.lock()) if (v->pending()) todo.push_back(v);
     recorded.clear();
+    for (auto it = memo.begin(); it != memo.end();) { if (it->second.expired()) it = memo.erase(it); else ++it; }
     if (todo.empty()) return;
     ++stats.flushes;
     for (auto& v : todo) v->depth = -1;

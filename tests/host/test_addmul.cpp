@@ -50,7 +50,7 @@ static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, 
   Ciphertext cSumMult = ctxt2; for (int i = 1; i < 7; ++i) cSumMult += ctxt2;
   double t_mul = now_s();
   Ciphertext cProd = ctxt1; cProd *= ctxt2;
-  t_mul = now_s() - t_mul;
+  t_mul = now_s() - t_mul;                                            // (recorded, not run, unless FHESI_EAGER=1: fhesi_engine.h)
   Plaintext resSum, resSumMult, resProd, resProd2, resSumQuad;
   secretKey.Decrypt(resSum, cSum); secretKey.Decrypt(resSumMult, cSumMult);
   double t_kg = now_s();
@@ -58,6 +58,7 @@ static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, 
   t_kg = now_s() - t_kg;
   double t_ks = now_s();
   keySwitch.ApplyKeySwitch(cProd);
+  if (g_time) SyncCiphertexts(context);                               // the recorded product + key switch run here
   t_ks = now_s() - t_ks;
   if (g_time) std::cout << "surface timing (one object at a time, first use): operator*= " << t_mul * 1e3 << " ms, ApplyKeySwitch " << t_ks * 1e3 << " ms, KeySwitchSI(sk) " << t_kg * 1e3 << " ms" << std::endl;
   secretKey.Decrypt(resProd, cProd);
@@ -72,6 +73,7 @@ static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, 
   cProd *= cProd;
   Ciphertext tmp = cProd, cSumQuad = cProd;
   keySwitch.ApplyKeySwitch(cProd);
+  if (g_time) SyncCiphertexts(context);                               // a batch of ONE: the result is asked for after every object
   t2 = now_s() - t2;
   if (g_time) std::cout << "surface timing (second use): operator*= + copy + ApplyKeySwitch " << t2 * 1e3 << " ms = " << 1.0 / t2 << " ciphertext-mults/s through the class surface" << std::endl;
   secretKey.Decrypt(resProd2, cProd);
@@ -80,7 +82,7 @@ static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, 
     // written against this surface should use; the objects cross the host boundary once per batch
     for (int count : {8, 64}) {
       std::vector<Ciphertext> va(count, ctxt1), vb(count, ctxt2);
-      double tb = now_s(); keySwitch.MulRelinBatch(va, vb); tb = now_s() - tb;
+      double tb = now_s(); keySwitch.MulRelinBatch(va, vb); SyncCiphertexts(context); tb = now_s() - tb;
       Plaintext r; secretKey.Decrypt(r, va[count - 1]);
       std::cout << "surface timing (MulRelinBatch of " << count << "): " << tb * 1e3 << " ms = " << count / tb << " ciphertext-mults/s" << (r.message == prod ? "" : "  WRONG RESULT") << std::endl;
     }

@@ -176,3 +176,19 @@ def test_config3_regression_at_the_reference_size():
     assert "automorphism keys: 12" in r.stdout
     assert "batched: decrypts to the plaintext regression: yes" in r.stdout
     assert "Test SUCCEEDED" in r.stdout
+
+
+def test_config3_reference_control_flow_object_at_a_time():
+    """configs[3] through the reference's OWN control flow: Regression::Regress written one Ciphertext object at a time on Matrix<Ciphertext>
+    (Matrix.cpp:57-98,150-263, Regression.h:102-149,166-178; tests/host/matrix_literal.h) -- 5.5 * 10^5 partial determinants at d = 8.  The
+    mirror's Ciphertext records the statements, shares equal ones and evaluates them level by level in batched device calls
+    (fhe-si_amd/host/fhesi_engine.h); the ciphertexts are bit-identical to the explicit waves of RegressBatched and decrypt to the plaintext
+    regression."""
+    host = os.path.join(ROOT, "tests", "host")
+    subprocess.check_call(["make", "-C", host], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(host, "test_regression"), "8423", "7", "8", "1", "1", "--check=slots"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "phi(m)=4210 logQ=341 primes=13 ndigits=15 dim=8 rows=1" in r.stdout, r.stdout
+    assert "object at a time: decrypts to the plaintext regression: yes" in r.stdout
+    assert "ciphertexts of both evaluators bit-identical: yes" in r.stdout
+    assert "Test SUCCEEDED" in r.stdout
