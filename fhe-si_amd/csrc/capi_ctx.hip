@@ -75,6 +75,7 @@ static const OptDesc kOptions[] = {
   {"stagger", "FHESI_STAGGER", offsetof(CtxOptions, stagger), false},
   {"batch_chunk", "FHESI_BATCH_CHUNK", offsetof(CtxOptions, batch_chunk), true},
   {"wave_operands", "FHESI_WAVE_OPERANDS", offsetof(CtxOptions, wave_operands), true},
+  {"wave_single", "FHESI_WAVE_SINGLE", offsetof(CtxOptions, wave_single), false},
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
   {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
   {"dot32_half", "FHESI_DOT32_HALF", offsetof(CtxOptions, dot32_half), false},

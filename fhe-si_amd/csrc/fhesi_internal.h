@@ -77,6 +77,7 @@ struct CtxOptions {
   int stagger = 0;          // lanes = 2: start the second lane after the first lane's digit transform
   long long batch_chunk = 0;      // ciphertexts per pipeline chunk (0 = derived from the ring)
   long long wave_operands = 0;    // distinct operands per pass of fhesi_ct_mul_sum_relin_dev (0 = about 4 GiB of rows)
+  int wave_single = 1;      // 1: a wave whose groups are single products takes the batch pipeline of fhesi_ct_mul_relin_batch_dev on gathered operands (0: the sum kernels, the checker)
   int dot32_mfma = 0;       // 1: the dot product on the int8 matrix cores (experimental; metric shape only: rows of 2^14, ncol <= 96, <= 16 limbs)
   int dot32_half = 1;       // 1: dot32_kernel2<.., HALF>: tiles of 32 coefficients, two limbs per wave, two workgroups per CU (0: round 2's first form, one 135 KB workgroup per CU)
   int dot32_v3 = 0;         // 1: dot32_kernel3 (two limbs per wave, 4 ciphertexts per tile, two workgroups per CU)

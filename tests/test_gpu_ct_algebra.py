@@ -178,6 +178,38 @@ def test_wave_of_products_sum_and_key_switch(chunk, operands, monkeypatch):
     assert np.array_equal(g_out.download((3, 2, n, nl)), pool[[5, 0, 5]])
 
 
+@pytest.mark.parametrize("m,logQ,p", [(1024, 128, 23), (32768, 512, 23), (46, 90, 47)])
+def test_wave_of_single_products_takes_the_batch_pipeline(m, logQ, p):
+    """A wave whose groups are single products (the recorded loop `c *= d; ApplyKeySwitch(c)` of the host mirror) runs through the batch
+    pipeline on gathered operands (option wave_single, default) -- same bits as the sum kernels (wave_single = 0), as
+    fhesi_ct_mul_relin_batch_dev on the same pairs, and as the oracle; operands repeated, shared between groups, and squared."""
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(5)
+    npool = 7
+    pool = P.rand_limbs(rng, (npool, 2, n), nl, logQ)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    pairs = [(0, 1), (2, 2), (6, 0), (1, 0), (3, 4), (5, 6), (0, 1), (4, 4), (2, 5)]
+    a_idx, b_idx, seg = [x for x, _ in pairs], [y for _, y in pairs], np.arange(len(pairs) + 1)
+    dpool = ctx.upload(pool)
+    outs = []
+    for single in (1, 0):
+        ctx.set_option("wave_single", single)
+        out = ctx.alloc(len(pairs) * 2 * n * nl * 8)
+        ctx.ct_mul_sum_relin_dev(ksk, logQ, p, dpool, nl, a_idx, b_idx, seg, out)
+        outs.append(out.download((len(pairs), 2, n, nl)))
+    assert np.array_equal(outs[0], outs[1])
+    da, db, dout = ctx.upload(pool[a_idx]), ctx.upload(pool[b_idx]), ctx.alloc(len(pairs) * 2 * n * nl * 8)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, len(pairs), 3)
+    assert np.array_equal(dout.download((len(pairs), 2, n, nl)), outs[0])
+    for gi in ([0, 1, len(pairs) - 1] if n > 4096 else range(len(pairs))):
+        x, y = pairs[gi]
+        assert np.array_equal(outs[0][gi], orc.apply_key_switch(ksm, orc.ct_mul(pool[x], pool[y], p), logQ, nl)), gi
+
+
 @pytest.mark.parametrize("m,logQ,p", [(4096, 128, 23), (2026, 120, 2027), (32768, 512, 23), (45, 100, 7), (101, 90, 7)])
 def test_ct_add_const_and_mul_poly_vs_oracle(m, logQ, p):
     """Ciphertext::operator+=(const ZZX&) / operator*=(const ZZX&) on unscaled device batches (Ciphertext.cpp:147-156, 245-249 ->
