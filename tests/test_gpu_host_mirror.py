@@ -103,6 +103,19 @@ def test_regression_literal_with_recording_off():
     assert "object at a time (at once)" in r.stdout and "ciphertexts of both evaluators bit-identical: yes" in r.stdout
 
 
+@pytest.mark.parametrize("args", [["23", "7", "2", "2", "1"], ["47", "5", "3", "3", "2"], ["257", "3", "3", "2", "3"], ["8423", "7", "4", "2", "1"]])
+def test_statistics_moments_and_covariance(args):
+    """Statistics::ComputeNthMoment / ComputeCovariance (Statistics.h:48-133) on the mirror (fhe-si_amd/host/fhesi_statistics.h), driven as
+    Test_Statistics.cpp:66-244 drives it (its logQ formula, SetUpSIContext(xi)): recorded and at-once evaluation give bit-identical
+    ciphertexts, and mean, second moments, N, N^2 and the covariance matrix decrypt to the same statistics computed in the plaintext ring
+    Z_p[X]/Phi_m.  m = 22 / 46 / 8422 are the reference's safe-prime rings, m = 256 a power of two."""
+    build()
+    r = subprocess.run([os.path.join(HOST, "test_statistics"), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("decrypt to the plaintext statistics: yes") == 2
+    assert "recorded and at-once ciphertexts bit-identical: yes" in r.stdout and "Test SUCCEEDED" in r.stdout
+
+
 @pytest.mark.parametrize("args", [[], ["46", "90", "47", "5"], ["256", "130", "257", "3", "3"]])
 def test_recorded_ciphertext_operations_equal_statements_run_at_once(args):
     """The mirror's Ciphertext records operator*= / += / *= long / >>= / ApplyKeySwitch on device-resident values and evaluates them in
