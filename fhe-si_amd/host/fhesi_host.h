@@ -873,7 +873,15 @@ class FHESIPubKey {
     ctxts.assign(count, Ciphertext(context));
     for (long c = 0; c < count; ++c) { ctxts[c].Initialize(2, context); for (int part = 0; part < 2; ++part) limbs_to_poly(ctxts[c][part].poly, &host[((size_t)(c * 2 + part) * n) * nl], n, nl); }
   }
-  void Encrypt(Ciphertext& ctxt, const Plaintext& ptxt) const {   // FHE-SI.cpp:10-36
+  // Encrypt (FHE-SI.cpp:10-36).  With recording on, the randomness is drawn here exactly as below and the arithmetic is the device call of
+  // EncryptBatch on one plaintext; the ciphertext stays in HBM (the same bits: tests/host/test_wire.cpp compares EncryptBatch with EncryptObjects)
+  void Encrypt(Ciphertext& ctxt, const Plaintext& ptxt) const {
+    if (!LazyCiphertexts()) { EncryptObjects(ctxt, ptxt); return; }
+    std::vector<Ciphertext> one;
+    EncryptBatch(one, std::vector<Plaintext>(1, ptxt));
+    ctxt = one[0];
+  }
+  void EncryptObjects(Ciphertext& ctxt, const Plaintext& ptxt) const {   // the reference's body, one DoubleCRT object at a time
     ctxt.Initialize(2, context);
     ZZX small; small.rep.assign(context.zMstar.phiM(), ZZ());
     for (auto& c : small.rep) c = ZZ(RandomBnd(2L));

@@ -86,7 +86,7 @@ int main(int argc, char* argv[]) {
   // batched Encrypt / Decrypt on the device give what the per-object methods give from the same PRNG state
   {
     std::vector<Plaintext> pts(3); pts[0].message = m1; pts[1].message = m2; pts[2].message = m1;
-    SetSeed(777); std::vector<Ciphertext> one(3, Ciphertext(*ctx2)); for (int i = 0; i < 3; ++i) pk2.Encrypt(one[i], pts[i]);
+    SetSeed(777); std::vector<Ciphertext> one(3, Ciphertext(*ctx2)); for (int i = 0; i < 3; ++i) pk2.EncryptObjects(one[i], pts[i]);
     SetSeed(777); std::vector<Ciphertext> many; pk2.EncryptBatch(many, pts);
     bool same = many.size() == 3; for (int i = 0; same && i < 3; ++i) same = one[i][0] == many[i][0] && one[i][1] == many[i][1];
     if (!same) { std::cout << "EncryptBatch differs from Encrypt" << std::endl; ++failures; }
