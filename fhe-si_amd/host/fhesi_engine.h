@@ -15,7 +15,13 @@
 // call is checked against them: tests/host/test_lazy.cpp, test_regression.cpp); FHESI_EAGER=1 (or LazyCiphertexts() = false) turns the
 // recording off and runs every statement at once, as before.  Errors of a recorded operation surface when it runs, not when it is
 // recorded.  Single-threaded, like the reference's classes.
+//
+// Several GPUs: EnableCiphertextGroup(context, devices) gives every GPU of the list a replica of the arena (same slots,
+// same contents) and of every key-switching matrix a recorded operation uses (one RCCL broadcast each, FHE-SI.cpp:206-208).  The groups of a
+// key-switch level are then sharded over the GPUs (shard_bounds) and the level's outputs exchanged (fhesi_comm_exchange), one host thread per
+// GPU; the cheap unscaled operations run on every GPU.  Every ciphertext operation is deterministic, so the results are the bits one GPU gives.
 #pragma once
+#include <thread>
 
 namespace fhesi {
 
@@ -25,11 +31,23 @@ inline bool& LazyCiphertexts() { static bool on = std::getenv("FHESI_EAGER") == 
 struct DeviceKey {
   fhesi_ksk* k = nullptr;
   const long id;                                            // never reused (an address can be)
+  int ncomp = 0, ndigits = 0;                               // the matrix's shape (source-key components, digits per component)
+  std::vector<fhesi_ksk*> replicas;                         // [rank] on the GPUs of an engine group, rank 0 = k (CtEngine::key_on_ranks); freed by the engine at shutdown
+  long groupGen = 0;
   static long next_id() { static long n = 0; return ++n; }
-  explicit DeviceKey(fhesi_ksk* kk) : k(kk), id(next_id()) {}
-  ~DeviceKey() { if (k) fhesi_ksk_free(k); }
+  DeviceKey(fhesi_ksk* kk, int nc, int nd) : k(kk), id(next_id()), ncomp(nc), ndigits(nd) {}
+  void drop_replicas() { for (size_t r = 1; r < replicas.size(); ++r) if (replicas[r]) fhesi_ksk_free(replicas[r]); replicas.clear(); }
+  ~DeviceKey() { drop_replicas(); if (k) fhesi_ksk_free(k); }
   DeviceKey(const DeviceKey&) = delete;
 };
+
+// contiguous, balanced shard [lo, hi) of `total` units for `rank` (the first total % world ranks get one more) -- the rule of
+// fhe-si_amd/shard.py::shard_bounds, so the C++ and Python hosts split a wave identically
+inline void shard_bounds(long total, int rank, int world, long& lo, long& hi) {
+  const long base = total / world, extra = total % world;
+  lo = rank * base + std::min<long>(rank, extra);
+  hi = lo + base + (rank < extra ? 1 : 0);
+}
 typedef std::shared_ptr<DeviceKey> DeviceKeyRef;
 
 class CtEngine;
@@ -62,6 +80,41 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
   typedef std::vector<long> Sig;                       // (kind, scalar, key, ids of the inputs): equal signatures = equal values
   std::map<Sig, std::weak_ptr<CtValue>> memo;
   long nextId = 0;
+  // the other GPUs of a group (rank r = peers[r - 1]; rank 0 is the context's own GPU): a device context, a replica of the arena, a communicator
+  struct Peer { fhesi_ctx* h = nullptr; uint64_t* base = nullptr; fhesi_comm* comm = nullptr; };
+  std::vector<Peer> peers;
+  fhesi_comm* comm0 = nullptr;
+  long groupGen = 0;
+  std::vector<std::weak_ptr<DeviceKey>> replicated;    // keys with replicas on the peers (freed before the peers' contexts go)
+  int world() const { return 1 + (int)peers.size(); }
+  fhesi_ctx* h_of(int r) const { return r ? peers[r - 1].h : h; }
+  uint64_t* base_of(int r) const { return r ? peers[r - 1].base : base; }
+  fhesi_comm* comm_of(int r) const { return r ? peers[r - 1].comm : comm0; }
+  template <class F> void on_all(F f) {                // f(rank) on one host thread per GPU
+    std::vector<std::thread> th;
+    for (int r = 1; r < world(); ++r) th.emplace_back([&f, r] { f(r); });
+    f(0);
+    for (auto& t : th) t.join();
+  }
+  // the key's matrix on every GPU of the group: replicas created and filled by ONE broadcast from rank 0 on first use
+  void key_on_ranks(const DeviceKeyRef& key) {
+    if (peers.empty() || (key->groupGen == groupGen && (int)key->replicas.size() == world())) return;
+    key->drop_replicas();
+    key->replicas.assign(world(), nullptr); key->replicas[0] = key->k;
+    for (int r = 1; r < world(); ++r) ck(fhesi_ksk_create(h_of(r), key->ncomp, key->ndigits, &key->replicas[r]));
+    on_all([&](int r) { ck(fhesi_ksk_broadcast(key->replicas[r], comm_of(r), 0)); });
+    key->groupGen = groupGen;
+    replicated.push_back(key);
+  }
+  fhesi_ksk* key_of(const DeviceKey* key, int r) const { return r ? key->replicas[r] : key->k; }
+  // slots [first, first + count) produced in shards by the ranks -> everywhere
+  void exchange(long first, long count) {
+    if (peers.empty()) return;
+    const int R = world();
+    std::vector<int64_t> off(R + 1);
+    for (int r = 0; r < R; ++r) { long lo, hi; shard_bounds(count, r, R, lo, hi); off[r] = (first + lo) * words; off[r + 1] = (first + hi) * words; }
+    on_all([&](int r) { ck(fhesi_comm_exchange(h_of(r), comm_of(r), base_of(r), off.data())); });
+  }
 
   void add_free(long start, long len) {
     auto it = freeRuns.lower_bound(start);
@@ -73,9 +126,12 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
     long tail = 0;                                      // a free run that ends at the top is extended instead of left behind
     if (!freeRuns.empty()) { auto last = std::prev(freeRuns.end()); if (last->first + last->second == cap) tail = last->second; }
     const long ncap = std::max<long>(std::max(cap * 2, cap + count - tail), 32);
-    void* nb; ck(fhesi_dev_alloc(h, (size_t)ncap * words * 8, &nb));
-    if (base) { ck(fhesi_dev_copy(h, nb, base, (size_t)cap * words * 8)); ck(fhesi_ctx_sync(h)); ck(fhesi_dev_free(h, base)); }
-    base = (uint64_t*)nb;
+    on_all([&](int r) {
+      uint64_t*& b = r ? peers[r - 1].base : base;
+      void* nb; ck(fhesi_dev_alloc(h_of(r), (size_t)ncap * words * 8, &nb));
+      if (b) { ck(fhesi_dev_copy(h_of(r), nb, b, (size_t)cap * words * 8)); ck(fhesi_ctx_sync(h_of(r))); ck(fhesi_dev_free(h_of(r), b)); }
+      b = (uint64_t*)nb;
+    });
     add_free(cap, ncap - cap);
     cap = ncap;
   }
@@ -108,7 +164,44 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
 
   explicit CtEngine(const FHEcontext& c) : context(c), h(c.handle()), n(c.zMstar.phiM()), nl((int)((c.logQ + 63) / 64)), words(2 * (long)c.zMstar.phiM() * (long)((c.logQ + 63) / 64)) {}
   ~CtEngine() { shutdown(); }
-  void shutdown() { dead = true; recorded.clear(); memo.clear(); if (base) { fhesi_dev_free(h, base); base = nullptr; } cap = 0; freeRuns.clear(); }
+  void shutdown() { dead = true; recorded.clear(); memo.clear(); drop_group(); if (base) { fhesi_dev_free(h, base); base = nullptr; } cap = 0; freeRuns.clear(); }
+  // ---- several GPUs
+  // devices[0] must be the context's own GPU; a repeated device makes a loopback group (fhesi_comm_init_all), which is how one GPU tests this
+  void enable_group(const std::vector<int>& devices) {
+    if (dead) Error("CtEngine: the context is gone");
+    flush();
+    drop_group();
+    const int G = (int)devices.size();
+    if (G < 2) return;
+    if (devices[0] != context.deviceIndex()) Error("EnableCiphertextGroup: devices[0] must be the context's GPU");
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    std::vector<fhesi_comm*> comms(G, nullptr);
+    ck(fhesi_comm_init_all(G, devs.data(), comms.data()));
+    comm0 = comms[0];
+    peers.resize(G - 1);
+    for (int r = 1; r < G; ++r) { peers[r - 1].h = context.replica(devices[r]); peers[r - 1].comm = comms[r]; }
+    ++groupGen;
+    if (cap) {                                         // the arena as it is now, on every GPU
+      for (int r = 1; r < G; ++r) { void* nb; ck(fhesi_dev_alloc(h_of(r), (size_t)cap * words * 8, &nb)); peers[r - 1].base = (uint64_t*)nb; }
+      publish(0, cap);
+    }
+  }
+  void drop_group() {
+    if (peers.empty() && !comm0) return;
+    for (auto& w : replicated) if (auto key = w.lock()) key->drop_replicas();
+    replicated.clear();
+    for (auto& pe : peers) { if (pe.base) fhesi_dev_free(pe.h, pe.base); if (pe.comm) fhesi_comm_destroy(pe.comm); }
+    if (comm0) { fhesi_comm_destroy(comm0); comm0 = nullptr; }
+    for (auto& pe : peers) if (pe.h) fhesi_ctx_destroy(pe.h);
+    peers.clear();
+  }
+  int group_size() const { return world(); }
+  // slots written on rank 0 only (an encryption batch, a copy modified in place, ...) -> every GPU of the group
+  void publish(long first, long count) {
+    if (peers.empty() || count <= 0) return;
+    on_all([&](int r) { ck(fhesi_comm_broadcast_dev(h_of(r), comm_of(r), base_of(r) + first * words, (size_t)count * words * 8, 0)); });
+  }
+  void sync_all() { for (int r = 0; r < world(); ++r) ck(fhesi_ctx_sync(h_of(r))); }
   const FHEcontext& ctx() const { return context; }
   uint64_t* ptr(long slot) const { return base + slot * words; }
   const uint64_t* pool() const { return base; }
@@ -125,7 +218,7 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
 
   // ---- values that exist
   CtRef wrap(long slot) { CtRef v = make(CtValue::DEVICE); v->slot = slot; return v; }                 // takes ownership of a filled slot
-  CtRef upload(const uint64_t* host) { const long s = alloc_run(1); ck(fhesi_dev_upload(h, ptr(s), host, (size_t)words * 8)); return wrap(s); }
+  CtRef upload(const uint64_t* host) { const long s = alloc_run(1); on_all([&](int r) { ck(fhesi_dev_upload(h_of(r), base_of(r) + s * words, host, (size_t)words * 8)); }); return wrap(s); }
   void download(const CtRef& v, uint64_t* host) { force(v); ck(fhesi_dev_download(h, host, ptr(v->slot), (size_t)words * 8)); }
   long clone_slot(const CtRef& v) { force(v); const long s = alloc_run(1); ck(fhesi_dev_copy(h, ptr(s), ptr(v->slot), (size_t)words * 8)); return s; }
   // ---- recorded operations
@@ -204,32 +297,53 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
       case CtValue::AUTO: autos[v->s].push_back(v); break;
       default: Error("CtEngine: a device value among the recorded operations");
     }
-    for (auto& kv : sums) {                            // one wave: out[g] = KeySwitch(sum of the group's products)
+    const int R = world();
+    for (auto& kv : sums) {                            // one wave: out[g] = KeySwitch(sum of the group's products); the groups sharded over the GPUs
       const auto& g = kv.second; const long G = (long)g.size();
       std::vector<int32_t> a, b, seg{0};
       for (CtValue* v : g) { for (auto& t : v->terms) { a.push_back((int32_t)t.first->slot); b.push_back((int32_t)t.second->slot); } seg.push_back((int32_t)a.size()); }
       const long first = alloc_run(G);
-      ck(fhesi_ct_mul_sum_relin_dev(h, kv.first->k, logQ, p, decomp, base, nl, a.data(), b.data(), seg.data(), G, ptr(first)));
+      key_on_ranks(g[0]->key);
+      on_all([&](int r) {
+        long lo, hi; shard_bounds(G, r, R, lo, hi);
+        if (hi <= lo) return;
+        const int32_t t0 = seg[lo];
+        std::vector<int32_t> sseg(seg.begin() + lo, seg.begin() + hi + 1);
+        for (auto& x : sseg) x -= t0;
+        ck(fhesi_ct_mul_sum_relin_dev(h_of(r), key_of(kv.first, r), logQ, p, decomp, base_of(r), nl, a.data() + t0, b.data() + t0, sseg.data(), hi - lo, base_of(r) + (first + lo) * words));
+      });
+      exchange(first, G);
       ++stats.calls; stats.products += (long)a.size(); stats.key_switches += G;
       for (long i = 0; i < G; ++i) done(g[i], first + i);
     }
-    for (auto& kv : autoKs) {                          // (ctxt >>= k; ApplyKeySwitch) on the gathered inputs
+    for (auto& kv : autoKs) {                          // (ctxt >>= k; ApplyKeySwitch) on the gathered inputs, sharded likewise
       const auto& g = kv.second; const long G = (long)g.size();
       const std::vector<int32_t> idx = slots_of(g, false);
       const long tmp = alloc_run(G), out = alloc_run(G);
-      ck(fhesi_ct_gather_dev(h, base, idx.data(), G, words, ptr(tmp)));
-      ck(fhesi_ct_automorph_key_switch_dev(h, kv.first.first->k, logQ, decomp, (int64_t)kv.first.second, ptr(tmp), nl, G, ptr(out), nl));
+      key_on_ranks(g[0]->key);
+      on_all([&](int r) {
+        long lo, hi; shard_bounds(G, r, R, lo, hi);
+        if (hi <= lo) return;
+        uint64_t* bs = base_of(r);
+        ck(fhesi_ct_gather_dev(h_of(r), bs, idx.data() + lo, hi - lo, words, bs + (tmp + lo) * words));
+        ck(fhesi_ct_automorph_key_switch_dev(h_of(r), key_of(kv.first.first, r), logQ, decomp, (int64_t)kv.first.second, bs + (tmp + lo) * words, nl, hi - lo, bs + (out + lo) * words, nl));
+      });
+      exchange(out, G);
       free_run(tmp, G);                                // (stream order: whoever reuses it is queued behind the call that reads it)
       ++stats.calls; stats.key_switches += G;
       for (long i = 0; i < G; ++i) done(g[i], out + i);
     }
+    // the unscaled operations are cheap and local: every GPU of a group computes all of them (no exchange)
     if (!adds.empty()) {
       const long G = (long)adds.size();
       const std::vector<int32_t> ia = slots_of(adds, false), ib = slots_of(adds, true);
       const long tmp = alloc_run(G), out = alloc_run(G);
-      ck(fhesi_ct_gather_dev(h, base, ia.data(), G, words, ptr(out)));
-      ck(fhesi_ct_gather_dev(h, base, ib.data(), G, words, ptr(tmp)));
-      ck(fhesi_ct_add_dev(h, logQ, ptr(out), ptr(tmp), 2, nl, G));
+      on_all([&](int r) {
+        uint64_t* bs = base_of(r);
+        ck(fhesi_ct_gather_dev(h_of(r), bs, ia.data(), G, words, bs + out * words));
+        ck(fhesi_ct_gather_dev(h_of(r), bs, ib.data(), G, words, bs + tmp * words));
+        ck(fhesi_ct_add_dev(h_of(r), logQ, bs + out * words, bs + tmp * words, 2, nl, G));
+      });
       free_run(tmp, G);
       ++stats.calls;
       for (long i = 0; i < G; ++i) done(adds[i], out + i);
@@ -238,8 +352,11 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
       const auto& g = kv.second; const long G = (long)g.size();
       const std::vector<int32_t> idx = slots_of(g, false);
       const long out = alloc_run(G);
-      ck(fhesi_ct_gather_dev(h, base, idx.data(), G, words, ptr(out)));
-      ck(fhesi_ct_mul_long_dev(h, logQ, ptr(out), (int64_t)kv.first, 2, nl, G));
+      on_all([&](int r) {
+        uint64_t* bs = base_of(r);
+        ck(fhesi_ct_gather_dev(h_of(r), bs, idx.data(), G, words, bs + out * words));
+        ck(fhesi_ct_mul_long_dev(h_of(r), logQ, bs + out * words, (int64_t)kv.first, 2, nl, G));
+      });
       ++stats.calls;
       for (long i = 0; i < G; ++i) done(g[i], out + i);
     }
@@ -247,8 +364,11 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
       const auto& g = kv.second; const long G = (long)g.size();
       const std::vector<int32_t> idx = slots_of(g, false);
       const long tmp = alloc_run(G), out = alloc_run(G);
-      ck(fhesi_ct_gather_dev(h, base, idx.data(), G, words, ptr(tmp)));
-      ck(fhesi_ct_automorph_dev(h, (int64_t)kv.first, ptr(tmp), 2, nl, G, ptr(out), nl));
+      on_all([&](int r) {
+        uint64_t* bs = base_of(r);
+        ck(fhesi_ct_gather_dev(h_of(r), bs, idx.data(), G, words, bs + tmp * words));
+        ck(fhesi_ct_automorph_dev(h_of(r), (int64_t)kv.first, bs + tmp * words, 2, nl, G, bs + out * words, nl));
+      });
       free_run(tmp, G);
       ++stats.calls;
       for (long i = 0; i < G; ++i) done(g[i], out + i);
@@ -268,6 +388,9 @@ inline CtEngine& ct_engine(const FHEcontext& c) {
 }
 inline void drop_ct_engine(const FHEcontext* c) { auto& m = ct_engines(); auto it = m.find(c); if (it != m.end()) { it->second->shutdown(); m.erase(it); } }
 // evaluate everything recorded for this context and wait for the device (timing harnesses; results need no explicit call)
-inline void SyncCiphertexts(const FHEcontext& c) { ct_engine(c).flush(); ck(fhesi_ctx_sync(c.handle())); }
+inline void SyncCiphertexts(const FHEcontext& c) { ct_engine(c).flush(); ct_engine(c).sync_all(); }
+// the recorded operations of this context's ciphertexts run on the GPUs `devices` from now on (devices[0] = the context's own); {} or one
+// device: back to one GPU.  Keys are broadcast on first use, key-switch levels sharded, their outputs exchanged (see the head of this file).
+inline void EnableCiphertextGroup(const FHEcontext& c, const std::vector<int>& devices) { ct_engine(c).enable_group(devices); }
 
 }  // namespace fhesi

@@ -707,7 +707,7 @@ class Ciphertext {
   // the unscaled parts as one device ciphertext [nparts][phi(m)][nl] around a device call: on a copy of the value's arena slot (the result
   // stays in HBM), or -- recording off, or not two parts -- through a temporary buffer and back to the host
   template <class Fn> void with_parts_on_device(Fn fn) {
-    if (lazy2()) { CtEngine& e = engine(); const long s = e.clone_slot(device_value()); fn(e.ptr(s), e.nl); parts.set_value(e.wrap(s)); return; }
+    if (lazy2()) { CtEngine& e = engine(); const long s = e.clone_slot(device_value()); fn(e.ptr(s), e.nl); e.publish(s, 1); parts.set_value(e.wrap(s)); return; }
     const long n = context->zMstar.phiM(); const int nl = (int)((context->logQ + 63) / 64); const size_t np = parts.size();
     std::vector<uint64_t> host(np * n * nl, 0);
     for (size_t i = 0; i < np; ++i) poly_to_limbs(parts[i].poly, &host[(i * n) * nl], n, nl);
@@ -837,6 +837,7 @@ class FHESIPubKey {
       CtEngine& e = ct_engine(context); const long first = e.alloc_run(count);
       int rc = fhesi_encrypt_batch(e.h, publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), rnd.data(), msg.data(), count, e.ptr(first), nl);
       if (rc) { e.free_run(first, count); ck(rc); }
+      e.publish(first, count);
       ctxts.assign(count, Ciphertext(context));
       for (long c = 0; c < count; ++c) ctxts[c].set_device_value(e.wrap(first + c));
       return;
@@ -862,6 +863,7 @@ class FHESIPubKey {
       CtEngine& e = ct_engine(context); const long first = e.alloc_run(count);
       int rc = fhesi_encrypt_batch_seeded(e.h, publicKey[0].handle(), publicKey[1].handle(), (int32_t)context.logQ, (uint64_t)context.ModulusP().to_long(), seed, first_obj, msg.data(), count, e.ptr(first), nl);
       if (rc) { e.free_run(first, count); ck(rc); }
+      e.publish(first, count);
       ctxts.assign(count, Ciphertext(context));
       for (long c = 0; c < count; ++c) ctxts[c].set_device_value(e.wrap(first + c));
       return;
@@ -936,7 +938,7 @@ class KeySwitchSI {
         ck(fhesi_dev_copy(context.handle(), fhesi_dcrt_device_ptr(d.handle()), rows + ((size_t)r * ncol + col) * rowWords, rowWords * 8));
         keySwitchMatrix[r].push_back(d);
       }
-    devKey = std::make_shared<DeviceKey>(k);                  // the device object the matrix was generated in serves the fused calls as it is
+    devKey = std::make_shared<DeviceKey>(k, (int)n, (int)context.ndigits);   // the device object the matrix was generated in serves the fused calls as it is
   }
   // the same matrix with the column randomness drawn on the device (fhesi_keyswitch_init_batch_seeded): column c <-> object index first + c
   struct Seeded { uint64_t seed, first; };
@@ -960,7 +962,7 @@ class KeySwitchSI {
       ck(fhesi_dev_copy(context.handle(), fhesi_dcrt_device_ptr(d.handle()), rows + ((size_t)r * ncol + col) * rowWords, rowWords * 8));
       keySwitchMatrix[r].push_back(d);
     }
-    devKey = std::make_shared<DeviceKey>(k);
+    devKey = std::make_shared<DeviceKey>(k, (int)n, (int)context.ndigits);
   }
   void InitObjects(const FHESISecKey& src, const FHESISecKey& dst) {   // the reference's loop, one object at a time
     std::vector<DoubleCRT> s = src.GetRepresentation(); std::vector<ZZX> sCoeff(s.size());
@@ -1081,7 +1083,7 @@ class KeySwitchSI {
     const size_t ncol = keySwitchMatrix[0].size(), ncomp = ncol / context.ndigits; const size_t rowWords = (size_t)context.numPrimes() * context.zMstar.phiM();
     fhesi_ksk* k = nullptr;
     ck(fhesi_ksk_create(context.handle(), (int32_t)ncomp, (int32_t)context.ndigits, &k));
-    devKey = std::make_shared<DeviceKey>(k);
+    devKey = std::make_shared<DeviceKey>(k, (int)ncomp, (int)context.ndigits);
     uint64_t* rows = (uint64_t*)fhesi_ksk_device_ptr(k);
     for (int r = 0; r < 2; ++r) for (size_t col = 0; col < ncol; ++col)
       ck(fhesi_dev_copy(context.handle(), rows + ((size_t)r * ncol + col) * rowWords, fhesi_dcrt_device_ptr(keySwitchMatrix[r][col].handle()), rowWords * 8));

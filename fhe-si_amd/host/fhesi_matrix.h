@@ -260,6 +260,7 @@ class RankState {
     if (LazyCiphertexts() && h == context.handle()) {                             // stays in HBM; the host form is made when somebody reads parts[i].poly
       CtEngine& e = ct_engine(context); const long s = e.alloc_run(1);
       ck(fhesi_dev_copy(h, e.ptr(s), ptr(idx), (size_t)words * 8));
+      e.publish(s, 1);
       ct = Ciphertext(context); ct.set_device_value(e.wrap(s));
       return;
     }
@@ -270,13 +271,7 @@ class RankState {
   }
 };
 
-// contiguous, balanced shard [lo, hi) of `total` units for `rank` (the first total % world ranks get one more) -- the rule of
-// fhe-si_amd/shard.py::shard_bounds, so the C++ and Python hosts split a wave identically
-inline void shard_bounds(long total, int rank, int world, long& lo, long& hi) {
-  const long base = total / world, extra = total % world;
-  lo = rank * base + std::min<long>(rank, extra);
-  hi = lo + base + (rank < extra ? 1 : 0);
-}
+// (shard_bounds: fhesi_engine.h)
 
 class SingleGpuExecutor : public WaveExecutor {
   RankState rs;

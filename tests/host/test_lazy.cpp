@@ -3,8 +3,10 @@
 // operations recorded and evaluated in batches on ciphertexts that stay in HBM, exactly the ciphertexts it gives when every statement runs
 // at once (LazyCiphertexts() = false: the bodies that follow Ciphertext.cpp / FHE-SI.cpp:241-260 statement by statement).
 //
-//   test_lazy [m logQ p g [seed]]                      the checks below; exit code = number of failed checks
-//   test_lazy --time N [m logQ p g]                    N multiplications + key switches written per object, recorded vs at once (rates)
+//   test_lazy [m logQ p g [seed]] [--devices=0,1,..]   the checks below; exit code = number of failed checks
+//   test_lazy --time N [m logQ p g] [--devices=..]     N multiplications + key switches written per object, recorded vs at once (rates)
+// --devices: the recorded operations run on this group of GPUs (EnableCiphertextGroup; the first = the context's; a repeated device makes a
+// loopback group on one GPU) -- every check must come out the same.
 #include <chrono>
 #include <cstring>
 #include <iostream>
@@ -27,8 +29,12 @@ static std::vector<Plaintext> random_plaintexts(long count, long n, long p) { st
 struct Eager { bool was; Eager() : was(LazyCiphertexts()) { LazyCiphertexts() = false; } ~Eager() { LazyCiphertexts() = was; } };   // statements run at once inside the scope
 
 int main(int argc, char* argv[]) {
-  long timeN = 0; std::vector<char*> args;
-  for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "--time") && i + 1 < argc) timeN = atol(argv[++i]); else args.push_back(argv[i]); }
+  long timeN = 0; std::vector<char*> args; std::vector<int> devices;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--time") && i + 1 < argc) timeN = atol(argv[++i]);
+    else if (!strncmp(argv[i], "--devices=", 10)) { for (char* t = strtok(argv[i] + 10, ","); t; t = strtok(nullptr, ",")) devices.push_back(atoi(t)); }
+    else args.push_back(argv[i]);
+  }
   const unsigned m = args.size() >= 4 ? atoi(args[0]) : 64, logQ = args.size() >= 4 ? atoi(args[1]) : 100, p = args.size() >= 4 ? atoi(args[2]) : 23, g = args.size() >= 4 ? atoi(args[3]) : 7;
   const long long seed = args.size() >= 5 ? atoll(args[4]) : 1;
   SetSeed((uint64_t)seed);
@@ -40,7 +46,8 @@ int main(int argc, char* argv[]) {
   KeySwitchSI keySwitch(secretKey);
   const long n = context.zMstar.phiM();
   CtEngine& eng = ct_engine(context);
-  std::cout << "m=" << m << " phi(m)=" << n << " logQ=" << logQ << " primes=" << context.numPrimes() << " recording " << (LazyCiphertexts() ? "on" : "off") << std::endl;
+  if (!devices.empty()) EnableCiphertextGroup(context, devices);
+  std::cout << "m=" << m << " phi(m)=" << n << " logQ=" << logQ << " primes=" << context.numPrimes() << " recording " << (LazyCiphertexts() ? "on" : "off") << ", " << eng.group_size() << " GPU rank(s)" << std::endl;
 
   if (timeN) {
     // the per-object statements at the rate a caller of the class surface sees: operands encrypted on the device, results decrypted in one batch
@@ -193,6 +200,16 @@ int main(int argc, char* argv[]) {
     bool ok = true;
     { Eager at_once; for (long i = 0; i < N; ++i) { Ciphertext e = ha[i]; e *= hb[(i + 1) % N]; keySwitch.ApplyKeySwitch(e); ok = ok && same(e, cs[i]); } }
     expect(ok, "evaluation triggered by the recording threshold gives the same ciphertexts");
+  }
+  // (7) the group is changed while ciphertexts exist: the arena is replicated as it is, results stay the same
+  {
+    std::vector<Ciphertext> cs(a.begin(), a.begin() + 6);
+    EnableCiphertextGroup(context, devices.empty() ? std::vector<int>{context.deviceIndex(), context.deviceIndex()} : std::vector<int>());
+    for (long i = 0; i < 6; ++i) { cs[i] *= b[i]; keySwitch.ApplyKeySwitch(cs[i]); cs[i] += a[(i + 1) % 6]; }
+    bool ok = true;
+    { Eager at_once; for (long i = 0; i < 6; ++i) { Ciphertext e = ha[i]; e *= hb[i]; keySwitch.ApplyKeySwitch(e); e += ha[(i + 1) % 6]; ok = ok && same(e, cs[i]); } }
+    expect(ok, devices.empty() ? "switched to a loopback group of two ranks mid-life: same ciphertexts" : "switched back to one GPU mid-life: same ciphertexts");
+    EnableCiphertextGroup(context, devices);
   }
   std::cout << "engine: " << eng.stats.recorded << " operations recorded, " << eng.stats.flushes << " evaluations, " << eng.stats.calls << " device calls" << std::endl;
   std::cout << (failures ? "Test FAILED" : "Test SUCCEEDED") << std::endl;

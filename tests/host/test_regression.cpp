@@ -44,6 +44,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char* argv[]) {
   bool batchedOnly = false, atOnce = false; std::string check = "ring"; unsigned mOverride = 0, logQOverride = 0; int repeat = 1;
+  std::vector<int> literalDevices;         // --literal-devices=0,1,...: the recorded literal control flow runs on this group of GPUs (EnableCiphertextGroup)
   std::vector<int> devices;                // --devices=0,1,...: also run the wave evaluator sharded over these GPUs (first = the context's)
   std::vector<char*> args;
   for (int i = 1; i < argc; ++i) {
@@ -51,6 +52,7 @@ int main(int argc, char* argv[]) {
     else if (!strcmp(argv[i], "--at-once")) atOnce = true;
     else if (!strncmp(argv[i], "--check=", 8)) check = argv[i] + 8;
     else if (!strncmp(argv[i], "--repeat=", 9)) repeat = atoi(argv[i] + 9);
+    else if (!strncmp(argv[i], "--literal-devices=", 18)) { for (char* t = strtok(argv[i] + 18, ","); t; t = strtok(nullptr, ",")) literalDevices.push_back(atoi(t)); }
     else if (!strncmp(argv[i], "--devices=", 10)) { for (char* t = strtok(argv[i] + 10, ","); t; t = strtok(nullptr, ",")) devices.push_back(atoi(t)); }
     else if (!strncmp(argv[i], "--m=", 4)) mOverride = atoi(argv[i] + 4);
     else if (!strncmp(argv[i], "--logQ=", 7)) logQOverride = atoi(argv[i] + 7);
@@ -176,6 +178,7 @@ int main(int argc, char* argv[]) {
   if (!batchedOnly) {
     std::vector<Ciphertext> thetaA; Ciphertext detA(context);
     CtEngine& eng = ct_engine(context);
+    if (!literalDevices.empty()) { EnableCiphertextGroup(context, literalDevices); std::cout << "recorded operations run on " << eng.group_size() << " GPU rank(s)" << std::endl; }
     const long calls0 = eng.stats.calls, rec0 = eng.stats.recorded;
     t0 = now();
     RegressLiteral(regress, thetaA, detA);

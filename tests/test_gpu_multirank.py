@@ -183,3 +183,24 @@ def test_bench_launches_its_own_ranks(workload, extra):
     assert d["roofline"]["kernel"] and d["roofline"]["frac"] > 0
     if workload == "metric":
         assert len(d["config"]["per_rank_value"]) == 2 and d["config"]["blocks"] >= 1 and d["config"]["key_broadcast_s"] > 0
+
+
+@pytest.mark.parametrize("args", [["--devices=0,0,0"], ["46", "90", "47", "5", "--devices=0,0"]])
+def test_recorded_ciphertext_operations_on_a_group_of_ranks(args):
+    """The recording evaluator of the C++ mirror's Ciphertext (fhe-si_amd/host/fhesi_engine.h) with EnableCiphertextGroup: arena and keys
+    replicated on every rank (RCCL broadcast), key-switch levels sharded, outputs exchanged.  Loopback group on one GPU; every flow of
+    tests/host/test_lazy.cpp must give the ciphertexts of the statements run at once, and switching the group mid-life must not change them."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(HOST, "test_lazy"), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Test SUCCEEDED" in r.stdout and "FAIL" not in r.stdout and "GPU rank(s)" in r.stdout
+
+
+def test_reference_regress_control_flow_on_a_group_of_ranks():
+    """Regression::Regress written one object at a time (Regression.h:102-149), recorded, evaluated on a loopback group of three ranks:
+    bit-identical to the explicit waves on one GPU and to the statements run at once."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(HOST, "test_regression"), "47", "5", "4", "1", "6", "--at-once", "--literal-devices=0,0,0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "recorded operations run on 3 GPU rank(s)" in r.stdout
+    assert "ciphertexts of both evaluators bit-identical: yes" in r.stdout and "recorded and at-once ciphertexts bit-identical: yes" in r.stdout
