@@ -11,10 +11,11 @@
 //     AUTO_KS  out = ApplyKeySwitch_k(a >>= k)               -> fhesi_ct_automorph_key_switch_dev (Regression.h:170-172)
 //     ADD / SCALE / AUTO  unscaled +=, *= long, >>= k        -> fhesi_ct_add_dev / fhesi_ct_mul_long_dev / fhesi_ct_automorph_dev
 // Values are immutable, so copies of a Ciphertext share them, and an operation recorded twice on the same inputs is recorded once
-// (the Laplace expansion of Matrix.cpp:227-263 recomputes equal minors: d = 8 writes 5.5 * 10^5 partial determinants, 12870 are distinct).  The results are the bits the object-at-a-time bodies give (every batched
-// call is checked against them: tests/host/test_lazy.cpp, test_regression.cpp); FHESI_EAGER=1 (or LazyCiphertexts() = false) turns the
-// recording off and runs every statement at once, as before.  Errors of a recorded operation surface when it runs, not when it is
-// recorded.  Single-threaded, like the reference's classes.
+// (the Laplace expansion of Matrix.cpp:227-263 recomputes equal minors: d = 8 writes 5.5 * 10^5 partial determinants, 12870 are distinct).
+// The results are the bits the object-at-a-time bodies give (every batched call is checked against them: tests/host/test_lazy.cpp,
+// test_regression.cpp, test_statistics.cpp); FHESI_EAGER=1 (or LazyCiphertexts() = false) turns the recording off and runs every statement
+// at once.  Errors of a recorded operation surface when it runs, not when it is recorded.  One host thread uses the classes of a context,
+// as in the reference.
 //
 // Several GPUs: EnableCiphertextGroup(context, devices) gives every GPU of the list a replica of the arena (same slots,
 // same contents) and of every key-switching matrix a recorded operation uses (one RCCL broadcast each, FHE-SI.cpp:206-208).  The groups of a
@@ -40,6 +41,7 @@ struct DeviceKey {
   ~DeviceKey() { drop_replicas(); if (k) fhesi_ksk_free(k); }
   DeviceKey(const DeviceKey&) = delete;
 };
+typedef std::shared_ptr<DeviceKey> DeviceKeyRef;
 
 // contiguous, balanced shard [lo, hi) of `total` units for `rank` (the first total % world ranks get one more) -- the rule of
 // fhe-si_amd/shard.py::shard_bounds, so the C++ and Python hosts split a wave identically
@@ -48,7 +50,6 @@ inline void shard_bounds(long total, int rank, int world, long& lo, long& hi) {
   lo = rank * base + std::min<long>(rank, extra);
   hi = lo + base + (rank < extra ? 1 : 0);
 }
-typedef std::shared_ptr<DeviceKey> DeviceKeyRef;
 
 class CtEngine;
 struct CtValue;
