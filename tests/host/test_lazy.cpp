@@ -5,6 +5,7 @@
 //
 //   test_lazy [m logQ p g [seed]] [--devices=0,1,..]   the checks below; exit code = number of failed checks
 //   test_lazy --time N [m logQ p g] [--devices=..]     N multiplications + key switches written per object, recorded vs at once (rates)
+//   test_lazy --fuzz N [m logQ p g [seed]] [--devices=..]   N random statements over a pool of ciphertexts, recorded and at once side by side
 // --devices: the recorded operations run on this group of GPUs (EnableCiphertextGroup; the first = the context's; a repeated device makes a
 // loopback group on one GPU) -- every check must come out the same.
 #include <chrono>
@@ -29,9 +30,10 @@ static std::vector<Plaintext> random_plaintexts(long count, long n, long p) { st
 struct Eager { bool was; Eager() : was(LazyCiphertexts()) { LazyCiphertexts() = false; } ~Eager() { LazyCiphertexts() = was; } };   // statements run at once inside the scope
 
 int main(int argc, char* argv[]) {
-  long timeN = 0; std::vector<char*> args; std::vector<int> devices;
+  long timeN = 0, fuzzN = 0; std::vector<char*> args; std::vector<int> devices;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--time") && i + 1 < argc) timeN = atol(argv[++i]);
+    else if (!strcmp(argv[i], "--fuzz") && i + 1 < argc) fuzzN = atol(argv[++i]);
     else if (!strncmp(argv[i], "--devices=", 10)) { for (char* t = strtok(argv[i] + 10, ","); t; t = strtok(nullptr, ",")) devices.push_back(atoi(t)); }
     else args.push_back(argv[i]);
   }
@@ -48,6 +50,47 @@ int main(int argc, char* argv[]) {
   CtEngine& eng = ct_engine(context);
   if (!devices.empty()) EnableCiphertextGroup(context, devices);
   std::cout << "m=" << m << " phi(m)=" << n << " logQ=" << logQ << " primes=" << context.numPrimes() << " recording " << (LazyCiphertexts() ? "on" : "off") << ", " << eng.group_size() << " GPU rank(s)" << std::endl;
+
+  if (fuzzN) {
+    // Random statements of the kinds the reference's drivers write, on a pool of ciphertexts that is kept twice: L (recorded, device values)
+    // and E (every statement at once, host values).  Noise is irrelevant here -- the two pools must hold the same BITS whenever they are
+    // compared -- so products are chained far beyond what would still decrypt.  Exercises the arena (slots freed and reused, growth), the
+    // sharing of equal operations, the levelling of deep and wide graphs, evaluation triggered by reads, by the threshold and by copies.
+    const int K = 10;
+    std::vector<unsigned> ks; { unsigned k = context.Generator(); for (int i = 0; i < 2; ++i) { ks.push_back(k); k = (unsigned)(((unsigned long)k * k) % m); } }
+    std::vector<KeySwitchSI> autoKeys; for (unsigned kk : ks) autoKeys.push_back(KeySwitchSI(secretKey, kk));
+    std::vector<Plaintext> pts = random_plaintexts(K, n, p);
+    std::vector<Ciphertext> L, E;
+    publicKey.EncryptBatchSeeded(L, pts, 21, 0);
+    for (auto& c : L) E.push_back(host_copy(c));
+    SplitMix64 rng((uint64_t)seed * 977 + 5);
+    auto pick = [&](int mod) { return (int)(rng.next() % (uint64_t)mod); };
+    long compared = 0, mism = 0;
+    auto compare_all = [&]() { for (int i = 0; i < K; ++i) { ++compared; Ciphertext a = L[i], b = E[i]; if (!same(a, b)) { ++mism; std::cout << "  mismatch in pool entry " << i << std::endl; } } };
+    for (long step = 0; step < fuzzN; ++step) {
+      const int op = pick(12), i = pick(K), j = pick(K), a2 = pick(K), b2 = pick(K);
+      auto both = [&](auto stmt) { stmt(L); { Eager at_once; stmt(E); } };
+      switch (op) {
+        case 0: case 1: both([&](std::vector<Ciphertext>& P) { Ciphertext c = P[i]; c *= P[j]; keySwitch.ApplyKeySwitch(c); P[i] = c; }); break;
+        case 2: both([&](std::vector<Ciphertext>& P) { P[i] += P[j]; }); break;
+        case 3: { const long l = (long)pick(5) - 2; both([&](std::vector<Ciphertext>& P) { P[i] *= l; }); break; }
+        case 4: { const int w = pick((int)ks.size()); both([&](std::vector<Ciphertext>& P) { Ciphertext t = P[i]; t >>= (long)ks[w]; autoKeys[w].ApplyKeySwitch(t); P[j] += t; }); break; }
+        case 5: { std::vector<long> cst(n); for (auto& v : cst) v = (long)(rng.next() % p); both([&](std::vector<Ciphertext>& P) { P[i] += cst; }); break; }
+        case 6: both([&](std::vector<Ciphertext>& P) { Ciphertext t = P[i]; t *= P[j]; Ciphertext u = P[a2]; u *= P[b2]; t += u; Ciphertext sq = P[j]; sq *= sq; t += sq; keySwitch.ApplyKeySwitch(t); P[a2] = t; }); break;
+        case 7: both([&](std::vector<Ciphertext>& P) { P[i] = P[j]; }); break;
+        case 8: { Plaintext d1, d2; secretKey.Decrypt(d1, L[i]); { Eager at_once; secretKey.Decrypt(d2, E[i]); } ++compared; if (d1.message != d2.message) { ++mism; std::cout << "  decryptions differ at step " << step << std::endl; } break; }
+        case 9: { std::vector<Plaintext> one = random_plaintexts(1, n, p); std::vector<Ciphertext> fresh; publicKey.EncryptBatchSeeded(fresh, one, 77, (uint64_t)step); L[i] = fresh[0]; E[i] = host_copy(fresh[0]); break; }
+        case 10: eng.flushAt = (pick(2) ? 3 : 8192); break;
+        case 11: { std::vector<long> poly(n, 0); poly[0] = 1 + pick(3); poly[pick((int)n)] += 1; both([&](std::vector<Ciphertext>& P) { P[i] *= poly; }); break; }
+      }
+      if (step % 64 == 63) compare_all();
+    }
+    compare_all();
+    std::cout << "fuzz: " << fuzzN << " statements, " << compared << " comparisons, " << mism << " mismatches; engine: " << eng.stats.recorded << " recorded, " << eng.stats.shared << " shared, "
+              << eng.stats.flushes << " evaluations, " << eng.stats.calls << " device calls" << std::endl;
+    std::cout << (mism ? "Test FAILED" : "Test SUCCEEDED") << std::endl;
+    return mism ? 1 : 0;
+  }
 
   if (timeN) {
     // the per-object statements at the rate a caller of the class surface sees: operands encrypted on the device, results decrypted in one batch

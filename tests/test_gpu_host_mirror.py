@@ -165,3 +165,15 @@ def test_single_crt_mirror_class(m):
     r = subprocess.run([os.path.join(HOST, "test_scrt"), str(m)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Test SUCCEEDED" in r.stdout
+
+
+@pytest.mark.parametrize("args", [["--fuzz", "400", "64", "100", "23", "7", "1"], ["--fuzz", "400", "64", "100", "23", "7", "2"], ["--fuzz", "300", "46", "90", "47", "5", "4", "--devices=0,0,0"],
+                                  ["--fuzz", "200", "2048", "200", "23", "7", "9"]])
+def test_recorded_ciphertext_operations_fuzz(args):
+    """Random statements (products + key switch, sums of products, +=, *= long, automorphism + its key switch, += constant, *= polynomial,
+    copies, re-encryption, reads, changes of the evaluation threshold) over a pool of ciphertexts kept twice -- recorded on device values
+    and run at once on host values: the two pools hold the same bits at every comparison (tests/host/test_lazy.cpp --fuzz)."""
+    build()
+    r = subprocess.run([os.path.join(HOST, "test_lazy"), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 mismatches" in r.stdout and "Test SUCCEEDED" in r.stdout
