@@ -690,7 +690,7 @@ def main():
 
     # What a caller of the kept class surface gets (missing 1): the same multiplication (a) from HOST buffers through
     # fhesi_ct_mul_relin_batch at several batch sizes (upload + compute + download, pageable memory), (b) one Ciphertext object at a time
-    # through the C++ mirror of Ciphertext::operator*= + KeySwitchSI::ApplyKeySwitch and through its MulRelinBatch (tests/host/test_addmul
+    # through the C++ mirror of Ciphertext::operator*= + KeySwitchSI::ApplyKeySwitch (tests/host/test_addmul
     # --time at this ring; host big-integer conversions included).  Reported beside `value`, never as `value`.
     surface = None
     if rank == 0 and world == 1 and args.workload == "metric" and args.surface:
@@ -721,8 +721,6 @@ def main():
                 mm = re.search(r"second use\): .*? = ([0-9.]+) ciphertext-mults/s", r.stdout)
                 if mm:
                     cs["object_at_a_time"] = round(float(mm.group(1)), 1)
-                for cnt, rate in re.findall(r"MulRelinBatch of (\d+)\): .*? = ([0-9.]+) ciphertext-mults/s", r.stdout):
-                    cs[f"MulRelinBatch_{cnt}"] = round(float(rate), 1)
                 surface["class_surface"] = cs
                 # the per-object statements `c *= d; keySwitch.ApplyKeySwitch(c)` in a loop over 1024 (and 64) ciphertexts, results read
                 # afterwards: the mirror records them and runs one device call (fhe-si_amd/host/fhesi_engine.h); tests/host/test_lazy --time

@@ -77,16 +77,6 @@ static bool runTest(bool disp, long long seed, unsigned p, FHEcontext& context, 
   t2 = now_s() - t2;
   if (g_time) std::cout << "surface timing (second use): operator*= + copy + ApplyKeySwitch " << t2 * 1e3 << " ms = " << 1.0 / t2 << " ciphertext-mults/s through the class surface" << std::endl;
   secretKey.Decrypt(resProd2, cProd);
-  if (g_time) {
-    // the same multiplication for a vector of ciphertexts in one call (KeySwitchSI::MulRelinBatch): what a loop over a Matrix<Ciphertext>
-    // written against this surface should use; the objects cross the host boundary once per batch
-    for (int count : {8, 64}) {
-      std::vector<Ciphertext> va(count, ctxt1), vb(count, ctxt2);
-      double tb = now_s(); keySwitch.MulRelinBatch(va, vb); SyncCiphertexts(context); tb = now_s() - tb;
-      Plaintext r; secretKey.Decrypt(r, va[count - 1]);
-      std::cout << "surface timing (MulRelinBatch of " << count << "): " << tb * 1e3 << " ms = " << count / tb << " ciphertext-mults/s" << (r.message == prod ? "" : "  WRONG RESULT") << std::endl;
-    }
-  }
   for (int i = 0; i < 8; ++i) cSumQuad += tmp;
   keySwitch.ApplyKeySwitch(cSumQuad); cSumQuad *= cProd; keySwitch.ApplyKeySwitch(cSumQuad);
   secretKey.Decrypt(resSumQuad, cSumQuad);
