@@ -284,7 +284,7 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
         const i64 cnt = std::min<i64>(step, ngroups - g0);
         const size_t ops_bytes = (size_t)2 * cnt * ct_words * 8;
         void* d_ops;
-        FHESI_TRY(ws_reserve(c, 6, ops_bytes + sizeof(int) * 2 * (size_t)cnt, &d_ops));
+        FHESI_TRY(ws_reserve(c, 12, ops_bytes + sizeof(int) * 2 * (size_t)cnt, &d_ops));      // (a slot of its own: the pipeline called below uses most of the others)
         int* d_ix = (int*)((char*)d_ops + ops_bytes);
         ix.resize(2 * cnt);
         for (i64 g = 0; g < cnt; ++g) { ix[g] = a_idx[seg[g0 + g]]; ix[cnt + g] = b_idx[seg[g0 + g]]; }

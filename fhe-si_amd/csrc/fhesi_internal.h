@@ -18,7 +18,7 @@ void fhesi_set_error(const char* fmt, ...);
 #define FHESI_FAIL(...) do { fhesi_set_error(__VA_ARGS__); return 1; } while (0)
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fhesi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return 1; } } while (0)
 #define FHESI_OP_SET_ 4
-#define FHESI_WS_SLOTS 12
+#define FHESI_WS_SLOTS 13
 #define FHESI_TRY(expr) do { int r__ = (expr); if (r__) return r__; } while (0)
 
 // --------------------------------------------------------------------------------- per-prime device constants
