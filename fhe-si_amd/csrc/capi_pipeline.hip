@@ -69,6 +69,7 @@ extern "C" int fhesi_ksk_form(const fhesi_ksk* k, int32_t* form, int32_t* rows, 
 
 // --------------------------------------------------------------------------------------------- ciphertext pipeline
 static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32);
+static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a, const uint64_t* b, uint64_t* out, int32_t nlimbs, int64_t count);
 
 extern "C" int fhesi_ct_mul_dev(fhesi_ctx* c, uint64_t p, const uint64_t* a, const uint64_t* b, int32_t nlimbs, int64_t count, uint64_t* tprod) {
   CHECK_CTX(c);
@@ -274,7 +275,8 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
   {
     // every group a single product (a loop of `c *= d; ApplyKeySwitch(c)` recorded by the host mirror, fhesi_engine.h): the operands are
     // gathered into two batches and take the batch pipeline of fhesi_ct_mul_relin_batch_dev -- the tensor products formed in the loader
-    // of the inverse transform instead of the sum kernels below (19.6 k -> 24 k multiplications per second at the metric ring)
+    // of the inverse transform instead of the sum kernels below (19.6 k -> 22 k multiplications per second at the metric ring with the
+    // operands gathered, more with them addressed through the indices)
     bool single = c->opt.wave_single != 0;
     for (i64 g = 0; single && g < ngroups; ++g) single = seg[g + 1] - seg[g] == 1;
     if (single) {
@@ -283,15 +285,25 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
       for (i64 g0 = 0; g0 < ngroups; g0 += step) {
         const i64 cnt = std::min<i64>(step, ngroups - g0);
         const size_t ops_bytes = (size_t)2 * cnt * ct_words * 8;
+        // where the tensor half runs over the 30-bit primes its first kernel takes the operands through the indices (no copy at all);
+        // elsewhere they are gathered into two batches first
+        const bool indexed = tensor32_applies(c, p, nlimbs, logQ);
         void* d_ops;
-        FHESI_TRY(ws_reserve(c, 12, ops_bytes + sizeof(int) * 2 * (size_t)cnt, &d_ops));      // (a slot of its own: the pipeline called below uses most of the others)
-        int* d_ix = (int*)((char*)d_ops + ops_bytes);
+        FHESI_TRY(ws_reserve(c, 12, (indexed ? 0 : ops_bytes) + sizeof(int) * 2 * (size_t)cnt, &d_ops));      // (a slot of its own: the pipeline called below uses most of the others)
+        int* d_ix = (int*)((char*)d_ops + (indexed ? 0 : ops_bytes));
         ix.resize(2 * cnt);
         for (i64 g = 0; g < cnt; ++g) { ix[g] = a_idx[seg[g0 + g]]; ix[cnt + g] = b_idx[seg[g0 + g]]; }
         HIP_TRY(hipMemcpyAsync(d_ix, ix.data(), sizeof(int) * ix.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));             // ix is reused by the next chunk
-        FHESI_TRY(launch_gather(c, (const u64*)pool, d_ix, 2 * cnt, ct_words, (u64*)d_ops));
-        FHESI_TRY(fhesi_ct_mul_relin_batch_dev(c, k, logQ, p, decomp_bytes, (const u64*)d_ops, (const u64*)d_ops + (size_t)cnt * ct_words, out + (size_t)g0 * ct_words, nlimbs, cnt));
+        if (indexed) {
+          c->op_idx = d_ix; c->op_idx_n = cnt; c->op_idx_done = 0;
+          const int rc = mul_relin_chunks(c, k, logQ, p, decomp_bytes, (const u64*)pool, (const u64*)pool, out + (size_t)g0 * ct_words, nlimbs, cnt);
+          c->op_idx = nullptr;
+          if (rc) return rc;
+        } else {
+          FHESI_TRY(launch_gather(c, (const u64*)pool, d_ix, 2 * cnt, ct_words, (u64*)d_ops));
+          FHESI_TRY(fhesi_ct_mul_relin_batch_dev(c, k, logQ, p, decomp_bytes, (const u64*)d_ops, (const u64*)d_ops + (size_t)cnt * ct_words, out + (size_t)g0 * ct_words, nlimbs, cnt));
+        }
       }
       return 0;
     }
@@ -450,7 +462,8 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
       FHESI_TRY(key_switch_args(c, k, logQ, decomp_bytes, nlimbs));
       void* d_parts = nullptr;
       rc = ws_reserve(c, 2, (size_t)cnt * 3 * ((logQ + 63) / 64) * n * 8, &d_parts);
-      if (!rc) rc = launch_tensor32(c, p, a + off, b + off, nlimbs, logQ, cnt, (u64*)d_parts);
+      if (c->op_idx) c->op_idx_done = done;                  // indexed operands: the chunk is a window of the index arrays, the buffer stays put
+      if (!rc) rc = launch_tensor32(c, p, c->op_idx ? a : a + off, c->op_idx ? b : b + off, nlimbs, logQ, cnt, (u64*)d_parts);
       if (!rc) rc = key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, cnt, nullptr, out + off, nlimbs);
     } else {
       void* d_tp = nullptr;

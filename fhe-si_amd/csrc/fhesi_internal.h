@@ -131,6 +131,10 @@ struct fhesi_ctx {
   size_t lane_ws_bytes[FHESI_WS_SLOTS] = {};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
   bool ws_oom = false;                 // the last failing ws_reserve failed in hipMalloc (mul_relin_chunks then retries with smaller chunks)
+  // operands of the fused multiplication addressed through pool indices instead of two contiguous batches (single-product waves of
+  // fhesi_ct_mul_sum_relin_dev): device array [2][op_idx_n] (a's, then b's) of ciphertext slots in the buffer passed as `a`; null = contiguous
+  const int* op_idx = nullptr;
+  long long op_idx_n = 0, op_idx_done = 0;
   bool mark_mid = false;               // record ev_mid right after the next digit-NTT launch (staggers the second lane)
   bool prof_on = false;
   std::vector<ProfRec> prof;

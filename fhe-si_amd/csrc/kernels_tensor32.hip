@@ -289,12 +289,16 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
 }
 template <int NL, bool HEAD, bool PAIRED>
 __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict__ a, const u64* __restrict__ b, i64 na2, i64 n_src, i64 nrow, u32* __restrict__ rows, int NP,
-                                                            const u32* __restrict__ tab) {
+                                                            const u32* __restrict__ tab, const int* __restrict__ idx_a = nullptr, const int* __restrict__ idx_b = nullptr) {
   __shared__ __attribute__((aligned(16))) u64 sl[NL * 256];       // [NL][256]
   const i64 poly = blockIdx.y;
   int cls;
   const u64* __restrict__ src;
-  if (PAIRED) { const i64 ct = poly >> 2; const int jp = (int)(poly & 3); cls = jp >> 1; src = (cls ? b : a) + (ct * 2 + (jp & 1)) * n_src * NL; }
+  if (PAIRED) {      // (idx_a / idx_b: operand ct of the a's / b's is ciphertext idx[ct] of the buffer -- pool indices of a wave of single products)
+    const i64 ct = poly >> 2; const int jp = (int)(poly & 3); cls = jp >> 1;
+    const i64 cs = idx_a ? (i64)(cls ? idx_b : idx_a)[ct] : ct;
+    src = (cls ? b : a) + (cs * 2 + (jp & 1)) * n_src * NL;
+  }
   else { cls = poly >= na2; src = cls ? b + (poly - na2) * n_src * NL : a + poly * n_src * NL; }
   const i64 j0 = (i64)blockIdx.x * 256;
   const int tid = threadIdx.x;
@@ -568,8 +572,10 @@ static int t32_launch_rns(fhesi_ctx* ctx, const T32Config* c, const u64* d_a, co
   const int S = ctx->tensor32->S;
   const i64 nrow = t32_nrow(ctx), n_src = ctx->phim;
   const dim3 grid((unsigned)(A32_N / 256), (unsigned)npolys);
+  const int* ia = paired && ctx->op_idx ? ctx->op_idx + ctx->op_idx_done : nullptr;
+  const int* ib = ia ? ia + ctx->op_idx_n : nullptr;
 #define T32_GO(HEAD, PAIRED) do { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, HEAD, PAIRED>); \
-    rns32_reduce_kernel<NL, HEAD, PAIRED><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, na2, n_src, nrow, d_r, c->NP, c->d_rns); } while (0)
+    rns32_reduce_kernel<NL, HEAD, PAIRED><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, na2, n_src, nrow, d_r, c->NP, c->d_rns, ia, ib); } while (0)
   if (S) { if (paired) T32_GO(true, true); else T32_GO(true, false); }
   else { if (paired) T32_GO(false, true); else T32_GO(false, false); }
 #undef T32_GO
