@@ -85,6 +85,8 @@ class IndexSet {
   void insert(const IndexSet& o) { s.insert(o.s.begin(), o.s.end()); }
   void remove(long j) { s.erase(j); }
   void remove(const IndexSet& o) { for (long j : o.s) s.erase(j); }
+  void retain(const IndexSet& o) { for (auto it = s.begin(); it != s.end();) { if (!o.s.count(*it)) it = s.erase(it); else ++it; } }   // intersection, in place (IndexSet.h:122-123)
+  bool disjointFrom(const IndexSet& o) const { for (long j : s) if (o.s.count(j)) return false; return true; }                    // IndexSet.h:94-95
   void clear() { s.clear(); }
   bool operator==(const IndexSet& o) const { return s == o.s; }
   bool operator!=(const IndexSet& o) const { return s != o.s; }
@@ -97,7 +99,7 @@ class IndexSet {
   friend bool operator>(const IndexSet& a, const IndexSet& b) { return a.contains(b) && a != b; }
 };
 inline long card(const IndexSet& s) { return s.card(); }
-inline bool disjoint(const IndexSet& a, const IndexSet& b) { return (a & b).card() == 0; }
+inline bool disjoint(const IndexSet& a, const IndexSet& b) { return a.disjointFrom(b); }
 
 // ---------------------------------------------------------------- PAlgebra (PAlgebra.h:53-88)
 class PAlgebra {
@@ -169,6 +171,12 @@ class FHEcontext {
   bool inChain(long p) const { for (auto& c : moduli) if (c.getQ() == p) return true; return false; }
   ZZ productOfPrimes(const IndexSet& s) const { ZZ p(1L); for (long i = s.first(); i <= s.last(); i = s.next(i)) p *= ZZ(ithPrime(i)); return p; }
   ZZ productOfPrimes() const { return productOfPrimes(ctxtPrimes); }
+  double logOfPrime(unsigned i) const { return std::log((double)ithPrime(i)); }                                                   // FHEContext.h:178
+  double logOfProduct(const IndexSet& s) const {                                                                                  // FHEContext.h:181-189
+    if (s.last() >= numPrimes()) Error("FHEContext::logOfProduct: IndexSet has too many rows");
+    double ans = 0.0; for (long i = s.first(); i <= s.last(); i = s.next(i)) ans += logOfPrime((unsigned)i); return ans;
+  }
+  bool isZeroDivisor(const ZZ& num) const { for (auto& c : moduli) if (rem(num, c.getQ()) == 0) return true; return false; }      // FHEContext.h:152-156
 
   void AddPrime(long p, bool special, long root = 0) {   // FHEContext.cpp:30-43
     if (dev) Error("FHEcontext::AddPrime: the chain is already bound to the device");
@@ -193,6 +201,19 @@ class FHEcontext {
       if (!inChain(p)) { AddPrime(p, special); sizeLeft -= std::log((double)p); }
     }
     return totalSize - sizeLeft;
+  }
+  // nPrimes primes = 1 mod 2m ASCENDING from p (FHEContext.cpp:118-141); returns the natural log of their product
+  double AddPrimesByNumber(long nPrimes, long p = 1, bool special = false) {
+    if (!zMstar.M() || zMstar.M() > (1u << 20)) Error("FHEcontext::AddModuli2: m undefined or larger than 2^20");
+    const long twoM = 2 * (long)zMstar.M();
+    if (p < 1) p = 1;
+    p -= (p % twoM) - 1;
+    double sizeSoFar = 0.0;
+    while (nPrimes > 0) {
+      do { p += twoM; } while (!ProbPrime((uint64_t)p));
+      if (!inChain(p)) { AddPrime(p, special); --nPrimes; sizeSoFar += std::log((double)p); }
+    }
+    return sizeSoFar;
   }
   // the device context is created on first use, from the finished chain
   fhesi_ctx* handle() const {
@@ -220,6 +241,8 @@ class FHEcontext {
   unsigned m_ = 0;
 };
 extern FHEcontext* activeContext;   // FHEContext.cpp:21
+inline double AddPrimesBySize(FHEcontext& c, double totalSize, bool special = false) { return c.AddPrimesBySize(totalSize, special, c.spNbits); }   // FHEContext.h: free functions of the same name
+inline double AddPrimesByNumber(FHEcontext& c, long nPrimes, long p = 1, bool special = false) { return c.AddPrimesByNumber(nPrimes, p, special); }
 
 // ---------------------------------------------------------------- ZZX <-> limb buffers
 inline int limbs_for(const ZZX& p) { long b = 1; for (auto& c : p.rep) b = std::max(b, c.bits() + 1); return (int)((b + 63) / 64); }
@@ -345,6 +368,7 @@ class DoubleCRT {
   void setRow(long i, const vec_long& r) { std::vector<uint64_t> v(r.begin(), r.end()); ck(fhesi_dcrt_upload_row(h, (int32_t)i, v.data())); }
   fhesi_dcrt* handle() const { return h; }
   void randomize() { IndexSet s = getIndexSet(); long n = context.zMstar.phiM(); for (long i = s.first(); i <= s.last(); i = s.next(i)) { vec_long r(n); for (long j = 0; j < n; ++j) r[j] = RandomBnd(context.ithPrime(i)); setRow(i, r); } }   // :468-481
+  void sampleSmall();
   void sampleHWt(long Hwt);
   void sampleGaussian(double stdev = 0.0);
   ZZ getCoefficientModulus() const { return context.productOfPrimes(); }
@@ -465,6 +489,11 @@ inline void sampleHWt(ZZX& poly, long Hwt, long n) {
   while (i < Hwt) { long u = RandomBnd(n); if (poly.rep[u].is_zero()) { long b = (long)(global_rng().next() & 2) - 1; poly.rep[u] = ZZ(b); ++i; } }
   poly.normalize();
 }
+inline void sampleSmall(ZZX& poly, long n) {                          // NumbTh.cpp:361-375: 0 with probability 1/2, else +-1
+  poly.rep.assign(n, ZZ());
+  for (long i = 0; i < n; ++i) { const uint64_t u = global_rng().next(); if (u & 1) poly.rep[i] = ZZ((long)(u & 2) - 1); }
+  poly.normalize();
+}
 inline void sampleGaussian(ZZX& poly, long n, double stdev) {
   static const double Pi = 4.0 * std::atan(1.0); static const long bignum = 0xfffffff;
   poly.rep.assign(n, ZZ());
@@ -481,6 +510,7 @@ inline void SampleRandom(ZZX& poly, const ZZ& modulus, unsigned degn) {   // Uti
   for (unsigned i = 0; i < degn; ++i) poly.rep[i] = RandomBnd(modulus) - offset;
   poly.normalize();
 }
+inline void DoubleCRT::sampleSmall() { ZZX p; fhesi::sampleSmall(p, context.zMstar.phiM()); *this = p; }           // DoubleCRT.h:308-311
 inline void DoubleCRT::sampleHWt(long Hwt) { ZZX p; fhesi::sampleHWt(p, Hwt, context.zMstar.phiM()); *this = p; }
 inline void DoubleCRT::sampleGaussian(double sd) { if (sd == 0.0) sd = context.stdev; ZZX p; fhesi::sampleGaussian(p, context.zMstar.phiM(), sd); *this = p; }
 
@@ -598,7 +628,8 @@ class Ciphertext {
   CiphertextPart& operator[](unsigned i) { return parts[i]; }
   CiphertextPart GetPart(unsigned i) const { return parts[i]; }
   bool isScaledUp() const { return scaledUp; }
-  void Clear() { tProd.clear(); terms.clear(); scaledUp = false; parts.clear(); }     // Ciphertext.cpp:160-165
+  void Clear() { tProd.clear(); terms.clear(); scaledUp = false; parts.clear(); }     // Ciphertext.cpp:226-230
+  void SetTensorRepresentation(std::vector<DoubleCRT>& repr) { parts.clear(); terms.clear(); std::swap(tProd, repr); scaledUp = true; }   // Ciphertext.cpp:220-224
   // this unscaled two-part ciphertext as a value in HBM (uploaded once, then shared by every copy and every product that uses it)
   CtRef device_value() const {
     if (parts.resident()) return parts.value();

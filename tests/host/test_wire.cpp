@@ -141,6 +141,36 @@ int main(int argc, char* argv[]) {
   // re-export equals the file
   { std::ostringstream os; Export(os, ks2); std::ifstream f(path("ksk.bin"), std::ios::binary); std::string orig((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     if (os.str() != orig) { std::cout << "re-export of the key-switch matrix differs" << std::endl; ++failures; } }
+  // odds and ends of the class surface (IndexSet.h:94-123, FHEContext.cpp:118-141, FHEContext.h:152-189, NumbTh.cpp:361-375, Ciphertext.cpp:220-224)
+  {
+    IndexSet s1(0, 5), s2(4, 9), s3(6, 9);
+    IndexSet r = s1; r.retain(s2);
+    if (!(r == IndexSet(4, 5)) || s1.disjointFrom(s2) || !s1.disjointFrom(s3) || !disjoint(s1, s3)) { std::cout << "IndexSet::retain / disjointFrom wrong" << std::endl; ++failures; }
+    FHEcontext byNumber(ctx2->zMstar.M(), logQ, p, g);
+    const double lg = AddPrimesByNumber(byNumber, 3, 1000);
+    const long twoM = 2 * (long)byNumber.zMstar.M();
+    bool ok = byNumber.numPrimes() == 3 && byNumber.ithPrime(0) > 1000 && byNumber.ithPrime(0) < byNumber.ithPrime(1) && byNumber.ithPrime(1) < byNumber.ithPrime(2);
+    for (unsigned i = 0; i < 3 && ok; ++i) ok = byNumber.ithPrime(i) % twoM == 1 && ProbPrime((uint64_t)byNumber.ithPrime(i));
+    ok = ok && std::fabs(lg - byNumber.logOfProduct(byNumber.ctxtPrimes)) < 1e-9 && byNumber.isZeroDivisor(ZZ(byNumber.ithPrime(1)) * ZZ(7L)) && !byNumber.isZeroDivisor(ZZ(7L));
+    if (!ok) { std::cout << "AddPrimesByNumber / logOfProduct / isZeroDivisor wrong" << std::endl; ++failures; }
+    DoubleCRT small(*ctx2); small.sampleSmall(); ZZX sp; small.toPoly(sp);
+    bool tern = true; long nz = 0; for (auto& cf : sp.rep) { tern = tern && cf.bits() <= 1; if (!cf.is_zero()) ++nz; }
+    if (!tern) { std::cout << "sampleSmall left a coefficient outside {-1, 0, 1}" << std::endl; ++failures; }
+    // SetTensorRepresentation: the rows of a product handed to another Ciphertext object relinearise to the same ciphertext
+    const bool was = LazyCiphertexts(); LazyCiphertexts() = false;
+    Ciphertext x(*ctx2), y(*ctx2); Plaintext px, py; px.message = m1; py.message = m2; pk2.EncryptObjects(x, px); pk2.EncryptObjects(y, py);
+    Ciphertext direct = x; direct.MulObjects(y); ks2.ApplyKeySwitch(direct);
+    // (the tensor product formed by hand on DoubleCRT objects, Ciphertext.cpp:169-186)
+    std::vector<DoubleCRT> c1, c2, rows(3, DoubleCRT(*ctx2));
+    for (unsigned i = 0; i < 2; ++i) { c1.push_back(DoubleCRT(x[i].poly * ctx2->ModulusP(), *ctx2)); c2.push_back(DoubleCRT(y[i].poly, *ctx2)); }
+    for (unsigned i = 0; i < 2; ++i) for (unsigned j = 0; j < 2; ++j) { DoubleCRT t = c1[i]; t *= c2[j]; rows[i + j] += t; }
+    Ciphertext handed(*ctx2); handed.SetTensorRepresentation(rows);
+    bool okT = handed.isScaledUp() && handed.size() == 3 && rows.empty();
+    ks2.ApplyKeySwitch(handed);
+    okT = okT && handed[0] == direct[0] && handed[1] == direct[1];
+    if (!okT) { std::cout << "SetTensorRepresentation: rows handed over do not relinearise to the product" << std::endl; ++failures; }
+    LazyCiphertexts() = was;
+  }
   std::cout << (failures ? "wire roundtrip FAILED" : "wire roundtrip ok") << std::endl;
   activeContext = nullptr;
   return failures;
