@@ -153,6 +153,13 @@ int main(int argc, char* argv[]) {
     for (unsigned i = 0; i < 3 && ok; ++i) ok = byNumber.ithPrime(i) % twoM == 1 && ProbPrime((uint64_t)byNumber.ithPrime(i));
     ok = ok && std::fabs(lg - byNumber.logOfProduct(byNumber.ctxtPrimes)) < 1e-9 && byNumber.isZeroDivisor(ZZ(byNumber.ithPrime(1)) * ZZ(7L)) && !byNumber.isZeroDivisor(ZZ(7L));
     if (!ok) { std::cout << "AddPrimesByNumber / logOfProduct / isZeroDivisor wrong" << std::endl; ++failures; }
+    { ZZX zz; for (long i = 0; i < 6; ++i) SetCoeff(zz, i, ZZ((long)(i * 37 - 90)));         // Util.cpp:33-43 against Reduce for a power of two, and an odd modulus by hand
+      ZZX a1 = zz, a2 = zz; ReduceCoefficientsSlow(a1, ZZ(64L)); ReduceCoefficients(a2, 6);
+      ZZX a3 = zz; ReduceCoefficientsSlow(a3, 7u, true);
+      bool okR = true; for (long i = 0; i < 6; ++i) { okR = okR && (coeff(a1, i) == coeff(a2, i) || (coeff(a1, i) == ZZ(32L) && coeff(a2, i) == ZZ(-32L))) && coeff(a3, i) == ZZ((long)((((i * 37 - 90) % 7) + 7) % 7)); }
+      std::vector<long> v1{2, 3}, v2{5, 7, 11}, tp; TensorProduct(tp, v1, v2);
+      okR = okR && tp == std::vector<long>{10, 14, 22, 15, 21, 33} && ComputeLog(1u) == 0 && ComputeLog(1024ul) == 10 && ComputeLog(1025ul) == 10;
+      if (!okR) { std::cout << "ReduceCoefficientsSlow / TensorProduct / ComputeLog wrong" << std::endl; ++failures; } }
     DoubleCRT small(*ctx2); small.sampleSmall(); ZZX sp; small.toPoly(sp);
     bool tern = true; long nz = 0; for (auto& cf : sp.rep) { tern = tern && cf.bits() <= 1; if (!cf.is_zero()) ++nz; }
     if (!tern) { std::cout << "sampleSmall left a coefficient outside {-1, 0, 1}" << std::endl; ++failures; }
