@@ -160,6 +160,20 @@ int main(int argc, char* argv[]) {
       std::vector<long> v1{2, 3}, v2{5, 7, 11}, tp; TensorProduct(tp, v1, v2);
       okR = okR && tp == std::vector<long>{10, 14, 22, 15, 21, 33} && ComputeLog(1u) == 0 && ComputeLog(1024ul) == 10 && ComputeLog(1025ul) == 10;
       if (!okR) { std::cout << "ReduceCoefficientsSlow / TensorProduct / ComputeLog wrong" << std::endl; ++failures; } }
+    {   // NumbTh.h:43-66,76-79,202
+      auto coeffs = [](const ZZX& f) { std::vector<long> v; for (auto& c : f.rep) v.push_back(c.to_long()); return v; };
+      bool okN = Cyclotomic((int)ctx2->zMstar.M()) == ctx2->zMstar.PhimX() && coeffs(Cyclotomic(16)) == std::vector<long>{1, 0, 0, 0, 0, 0, 0, 0, 1}
+                 && coeffs(Cyclotomic(15)) == std::vector<long>{1, -1, 0, 1, -1, 1, 0, -1, 1} && deg(Cyclotomic(105)) == 48 && largestCoeff(Cyclotomic(105)) == ZZ(2L);
+      okN = okN && phi_N(8422) == 4210 && phi_N(105) == 48 && mobius(30) == -1 && mobius(12) == 0 && mobius(35) == 1 && ord(48, 2) == 4 && ord(48, 5) == 0;
+      const int gr = primroot(23, 22); std::set<long> seen; long x = 1; for (int i = 0; i < 22; ++i) { x = x * gr % 23; seen.insert(x); }
+      okN = okN && seen.size() == 22;
+      std::vector<long> fs; factorize(fs, 8422); okN = okN && fs == std::vector<long>{2, 4211};
+      ZZX in, o1, o2, o3; for (long i = 0; i < 5; ++i) SetCoeff(in, i, ZZ((long)(i * 5 - 9)));        // -9 -4 1 6 11
+      PolyRed(o1, in, 7); PolyRed(o2, in, 7, true); PolyRed(o3, in, 2);
+      okN = okN && coeffs(o1) == std::vector<long>{-2, 3, 1, -1, -3} && coeffs(o2) == std::vector<long>{5, 3, 1, 6, 4} && coeffs(o3) == std::vector<long>{-1, 0, 1, 0, 1};
+      std::vector<long> av{3, 9, -2, 9}; okN = okN && argmax(av) == 1 && argmin(av) == 2;
+      if (!okN) { std::cout << "Cyclotomic / phi_N / mobius / ord / primroot / factorize / PolyRed / argmax wrong" << std::endl; ++failures; }
+    }
     DoubleCRT small(*ctx2); small.sampleSmall(); ZZX sp; small.toPoly(sp);
     bool tern = true; long nz = 0; for (auto& cf : sp.rep) { tern = tern && cf.bits() <= 1; if (!cf.is_zero()) ++nz; }
     if (!tern) { std::cout << "sampleSmall left a coefficient outside {-1, 0, 1}" << std::endl; ++failures; }
