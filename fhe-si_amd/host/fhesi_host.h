@@ -409,6 +409,9 @@ class DoubleCRT {
   ZZ getCoefficientModulus() const { return context.productOfPrimes(); }
 };
 inline ZZX to_ZZX(const DoubleCRT& d) { ZZX p; d.toPoly(p); return p; }
+inline void conv(DoubleCRT& d, const ZZX& p) { d = p; }                 // DoubleCRT.h:368-378
+inline DoubleCRT to_DoubleCRT(const ZZX& p) { return DoubleCRT(p); }
+inline void conv(ZZX& p, const DoubleCRT& d) { d.toPoly(p); }
 
 // ---------------------------------------------------------------- SingleCRT (SingleCRT.h:41-175, SingleCRT.cpp)
 // Coefficient-domain RNS form: per prime of the index set, the polynomial's coefficients modulo that prime, resident in HBM.
@@ -505,6 +508,7 @@ class SingleCRT {
 inline void conv(SingleCRT& s, const ZZX& p) { s = p; }
 inline void conv(ZZX& p, const SingleCRT& s) { s.toPoly(p); }
 inline ZZX to_ZZX(const SingleCRT& s) { ZZX p; s.toPoly(p); return p; }
+inline void conv(DoubleCRT& d, const SingleCRT& s);                      // DoubleCRT.h:380
 inline DoubleCRT& DoubleCRT::operator=(const SingleCRT& scrt) {
   if (&context != &scrt.getContext()) Error("DoubleCRT=SingleCRT -- incompatible contexts");
   ck(fhesi_dcrt_assign_scrt(h, scrt.handle()));
@@ -517,6 +521,7 @@ inline void DoubleCRT::toSingleCRT(SingleCRT& scrt, const IndexSet& s) const {
   ck(fhesi_scrt_assign_dcrt(scrt.handle(), h, v.data(), (int32_t)v.size()));
 }
 inline void DoubleCRT::toSingleCRT(SingleCRT& scrt) const { toSingleCRT(scrt, getIndexSet()); }
+inline void conv(DoubleCRT& d, const SingleCRT& s) { d = s; }
 
 // ---------------------------------------------------------------- samplers (NumbTh.cpp:340-404) on the documented PRNG
 inline void sampleHWt(ZZX& poly, long Hwt, long n) {
