@@ -1,0 +1,53 @@
+"""GPU parity over RANDOM shapes: the fused ciphertext multiplication + key switch (fhesi_ct_mul_relin_batch, Ciphertext.cpp:167-218 +
+FHE-SI.cpp:241-260) against the C oracle on rings, moduli, plaintext moduli and batch sizes drawn from a seeded generator -- the fixed-shape
+tests pin the configurations the reference's drivers use; this one walks the plan selection in between (limb plans of the key switch,
+bounds of the 30-bit tensor half, chunking, ragged batches, launches of one)."""
+import numpy as np
+import pytest
+
+import fhe_si_amd as F
+import fhesi_pyref as R
+import oracle_lib as O
+import params as P
+
+pytestmark = pytest.mark.gpu
+
+POW2 = [8, 16, 32, 64, 128, 256, 512, 1024, 2048]
+SAFE = [22, 46, 94, 118, 166, 214]              # m = 2 q', q' prime: the reference's m = p - 1 rings
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice(POW2 if seed % 3 else SAFE))
+    logQ = int(rng.integers(40, 420))
+    p = int(rng.choice([2, 3, 23, 257, 2027, 8423, 65537, int(rng.integers(2, 1 << 20)), (1 << 31) - 1]))
+    count = int(rng.integers(1, 6))
+    return m, logQ, p, count
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_mul_relin_on_random_shapes(seed):
+    m, logQ, p, count = _case(seed)
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(seed)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    a[0, 0, 0] = O.ints_to_limbs([-(1 << (logQ - 1))], nl)[0]          # the extremes of the centred range
+    b[0, 1, 0] = O.ints_to_limbs([(1 << (logQ - 1)) - 1], nl)[0]
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    if seed % 4 == 3:
+        ctx.set_option("batch_chunk", 2)                                # ragged chunks
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    form = ksk.form()
+    for c in range(count):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), (m, logQ, p, count, c, form)
+    # the same pairs as a wave of single products through pool indices (the recorded per-object loop of the host mirror)
+    pool = np.concatenate([a, b])
+    dpool = ctx.upload(pool)
+    out = ctx.alloc(count * 2 * n * nl * 8)
+    ctx.ct_mul_sum_relin_dev(ksk, logQ, p, dpool, nl, list(range(count)), list(range(count, 2 * count)), np.arange(count + 1), out)
+    assert np.array_equal(out.download((count, 2, n, nl)), got), (m, logQ, p, count, "wave")
