@@ -14,18 +14,19 @@ pytestmark = pytest.mark.gpu
 
 POW2 = [8, 16, 32, 64, 128, 256, 512, 1024, 2048]
 SAFE = [22, 46, 94, 118, 166, 214]              # m = 2 q', q' prime: the reference's m = p - 1 rings
+GENERAL = [9, 12, 15, 20, 21, 45, 60, 100, 101, 105, 126]      # everything else: Bluestein rows (Phi_105 has a coefficient -2)
 
 
 def _case(seed):
     rng = np.random.default_rng(1000 + seed)
-    m = int(rng.choice(POW2 if seed % 3 else SAFE))
+    m = int(rng.choice(GENERAL if seed >= 24 else (POW2 if seed % 3 else SAFE)))
     logQ = int(rng.integers(40, 420))
     p = int(rng.choice([2, 3, 23, 257, 2027, 8423, 65537, int(rng.integers(2, 1 << 20)), (1 << 31) - 1]))
     count = int(rng.integers(1, 6))
     return m, logQ, p, count
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(36))
 def test_mul_relin_on_random_shapes(seed):
     m, logQ, p, count = _case(seed)
     primes, roots = P.chain_for(m, logQ, p)
