@@ -1174,6 +1174,9 @@ class KeySwitchSI {
     return devKey;
   }
   fhesi_ksk* device_key() const { return device_key_ref()->k; }
+ public:
+  // the matrix as ONE device object, built on first use and shared (the wave executors of fhesi_matrix.h use it instead of a copy of their own)
+  const DeviceKeyRef& DeviceMatrix() const { return device_key_ref(); }
 };
 
 }  // namespace fhesi

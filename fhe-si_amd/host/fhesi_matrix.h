@@ -182,24 +182,14 @@ struct WaveExecutor {
 
 // One KeySwitchSI matrix as a fhesi_ksk on the device of `h`
 class DeviceKeySwitch {
-  fhesi_ksk* k = nullptr;
+  DeviceKeyRef shared;               // rank 0: the device object of the mirrored KeySwitchSI itself (no second copy of 300 MB, no second set of derived tables)
+  fhesi_ksk* k = nullptr;            // other ranks: an empty replica of the same shape, the target of fhesi_ksk_broadcast
  public:
-  // copied from the mirrored object (device to device: the DoubleCRT rows already live in HBM of the context's GPU)
-  DeviceKeySwitch(const FHEcontext& c, const KeySwitchSI& ks) {
-    const auto& M = ks.GetRepresentation();
-    const long ncol = (long)M[0].size(), rowWords = (long)c.numPrimes() * c.zMstar.phiM();
-    ck(fhesi_ksk_create(c.handle(), (int32_t)(ncol / c.ndigits), (int32_t)c.ndigits, &k));
-    uint64_t* dst = (uint64_t*)fhesi_ksk_device_ptr(k);
-    for (int r = 0; r < 2; ++r)
-      for (long col = 0; col < ncol; ++col) ck(fhesi_dev_copy(c.handle(), dst + (r * ncol + col) * rowWords, fhesi_dcrt_device_ptr(M[r][col].handle()), (size_t)rowWords * 8));
-    ck(fhesi_ksk_mark_dirty(k));      // rows written through the pointer: derived tables are rebuilt at the first key switch
-    ck(fhesi_ctx_sync(c.handle()));
-  }
-  // an empty replica of the same shape on another GPU's context: the target of fhesi_ksk_broadcast
+  DeviceKeySwitch(const FHEcontext& c, const KeySwitchSI& ks) : shared(ks.DeviceMatrix()) { ck(fhesi_ctx_sync(c.handle())); }
   DeviceKeySwitch(fhesi_ctx* h, int32_t ncomp, int32_t ndigits) { ck(fhesi_ksk_create(h, ncomp, ndigits, &k)); }
   ~DeviceKeySwitch() { if (k) fhesi_ksk_free(k); }
   DeviceKeySwitch(const DeviceKeySwitch&) = delete;
-  fhesi_ksk* handle() const { return k; }
+  fhesi_ksk* handle() const { return shared ? shared->k : k; }
 };
 
 // the pool and the keys of ONE GPU, and the work of one rank on a wave
