@@ -177,3 +177,15 @@ def test_recorded_ciphertext_operations_fuzz(args):
     r = subprocess.run([os.path.join(HOST, "test_lazy"), *args], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 mismatches" in r.stdout and "Test SUCCEEDED" in r.stdout
+
+
+@pytest.mark.parametrize("prog,args,expect", [("test_general", ["1"], "Test SUCCEEDED"), ("test_addmul", ["80", "23", "7", "--tests=3"], "All tests SUCCEEDED!"),
+                                              ("test_statistics", ["47", "5", "3", "3", "2"], "Test SUCCEEDED"), ("test_wire", ["100", "23", "7", "1", "TMP"], "wire roundtrip ok")])
+def test_host_programs_with_recording_off(prog, args, expect, tmp_path):
+    """FHESI_EAGER=1: every Ciphertext statement of the drivers runs at once (the bodies that follow Ciphertext.cpp / FHE-SI.cpp statement by
+    statement) -- the checker form of the mirror must keep passing the drivers on its own, not only as the other side of a comparison."""
+    build()
+    argv = [str(tmp_path) if a == "TMP" else a for a in args]
+    r = subprocess.run([os.path.join(HOST, prog), *argv], capture_output=True, text=True, timeout=900, env=dict(os.environ, FHESI_EAGER="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert expect in r.stdout
