@@ -466,6 +466,7 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
       if (!rc) rc = launch_tensor32(c, p, c->op_idx ? a : a + off, c->op_idx ? b : b + off, nlimbs, logQ, cnt, (u64*)d_parts);
       if (!rc) rc = key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, cnt, nullptr, out + off, nlimbs);
     } else {
+      if (c->op_idx) FHESI_FAIL("ct_mul_relin: indexed operands reached the chain path");      // (only the 30-bit tensor half reads through indices; the caller checks tensor32_applies)
       void* d_tp = nullptr;
       rc = ws_reserve(c, 5, (size_t)cnt * 3 * L * n * 8, &d_tp);
       if (!rc) rc = fhesi_ct_mul_dev(c, p, a + off, b + off, nlimbs, cnt, (uint64_t*)d_tp);
