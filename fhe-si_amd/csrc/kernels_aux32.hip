@@ -234,6 +234,9 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 // halves read the same LDS words, which the LDS broadcasts).  Same multiply-adds per key word and per LDS read, but the tile is half
 // as large (66 KB at the metric shape) and the workgroup has half the waves: TWO workgroups share a CU and the tile load, the barrier
 // and the ragged end of one overlap the arithmetic of the other (with one 135 KB workgroup per CU the VALU sat idle 37 % of the time).
+#ifndef DOT32_MASK_IDLE
+#define DOT32_MASK_IDLE 1
+#endif
 template <int CT, int NW, bool HALF>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
@@ -299,6 +302,11 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   for (int lw = w; lw * (HALF ? 2 : 1) < NLB; lw += NW) {
     const int lraw = HALF ? 2 * lw + (int)(lane >> 5) : lw;          // HALF: the upper lanes of the last wave may have no limb: they repeat the lower one's
     const bool lok = lraw < NLB;
+#if DOT32_MASK_IDLE
+    // the half wave without a limb (15 limbs on 16 half waves) leaves the loop: its lanes are masked off for the multiply-adds instead of
+    // repeating the neighbour's -- same issue slots, but the step runs at the power limit and idle lanes draw less
+    if (HALF && !lok) continue;
+#endif
     const int l = lok ? lraw : NLB - 1;
     const u32* kp0 = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + (HALF ? hf * 32 + ln : lane);      // row r = 0; row 1 follows after ncol slices
     const u32* kp1 = kp0 + ((i64)ncol << 6);
