@@ -1,17 +1,16 @@
 // fhesi_matrix.h -- mirror of Matrix<T> (Matrix.h:16-83, Matrix.cpp) and of Regression (Regression.h:68-191) on the classes of
 // fhesi_host.h, plus the batched evaluator that SURVEY.md 8(f) ranks next after the multiplication path:
 //
-//   * Matrix<T>            the whole class (Matrix.h:16-83): storage, shape, element access, and the arithmetic of Matrix.cpp:20-263 --
-//                          sums, products, MultByTranspose, the Laplace Determinant and the adjugate Invert -- written one T object at a time
-//                          as the reference writes it.  With T = Ciphertext the statements are RECORDED by the mirror's Ciphertext and
-//                          evaluated in batched device calls (fhesi_engine.h), so this literal arithmetic is a product path.
+//   * Matrix<T>            the CONTAINER only (Matrix.h:16-83: storage, shape, transpose flag, element access, AddRow / Concatenate / MapAll and
+//                          the wire format of fhesi_serialization.h).  The arithmetic of Matrix.cpp:20-263 is NOT restated in the package: in an
+//                          integration the reference's own Matrix.cpp compiles unmodified on the mirror's recording Ciphertext (INTEGRATION.md
+//                          section 3.1); the test harness keeps a literal restatement as its checker (tests/host/matrix_literal.h).
 //   * ProductWave / WaveExecutor  device-resident unscaled ciphertexts addressed by pool index; one ProductWave = many independent
 //                          "sum of products, then key switch" groups submitted as ONE fhesi_ct_mul_sum_relin_dev call per GPU
 //                          (SingleGpuExecutor), or sharded over the GPUs of a node with the keys RCCL-broadcast and the wave
 //                          outputs exchanged (GroupExecutor: one host thread per GPU).
-//   * Regression           Regress() is the reference's method (Regression.h:102-149) written as the reference writes it, on recorded
-//                          ciphertexts; RegressBatched() evaluates the same expression DAG (Regression.h:102-149) level by level (inner products -> SumBatchedData -> minors of growing size ->
-//                          determinant -> adj * last) in waves.  Every ciphertext operation is deterministic, so equal minors
+//   * Regression           keys, data and RegressBatched(): the expression DAG of Regression::Regress (Regression.h:102-149) evaluated level by
+//                          level (inner products -> SumBatchedData -> minors of growing size -> determinant -> adj * last) in waves.  Every ciphertext operation is deterministic, so equal minors
 //                          the Laplace recursion of Matrix.cpp:227-263 recomputes are evaluated once; results are bit-identical to the
 //                          literal object-at-a-time control flow (tests/host/matrix_literal.h: RegressLiteral).
 // Slot packing (PlaintextSpace.cpp) is outside the hot-path scope: plaintexts are coefficient vectors and only the slot COUNT
@@ -28,10 +27,8 @@
 namespace fhesi {
 
 // ---------------------------------------------------------------- Matrix<T> (Matrix.h:16-83, Matrix.cpp)
-// The arithmetic is generic over T (Ciphertext, or any ring element with +=, *=, *= long: the plaintext side of the test drivers).  On
-// Ciphertext objects each statement below is recorded, not run (fhesi_engine.h): an inner product `t = a(i,k); t *= b(k,j); acc += t` stays a
-// list of products until the caller's `reduce` / MapAll key switch turns it into one value, and equal minors of the Laplace recursion are
-// recorded once.  RegressBatched (below) submits the same expressions as explicit waves; both give identical ciphertexts.
+// Container only: what the wave evaluator, Regression's data store and the wire format need.  (Matrix.cpp's arithmetic written against
+// this container and the recording Ciphertext is test infrastructure: tests/host/matrix_literal.h.)
 template <class T>
 class Matrix {
  protected:
@@ -40,28 +37,6 @@ class Matrix {
   bool transpose = false;
   T& ElemAt(unsigned r, unsigned c) { return transpose ? mat[c][r] : mat[r][c]; }
   const T& ElemAt(unsigned r, unsigned c) const { return transpose ? mat[c][r] : mat[r][c]; }
-  // Laplace expansion along the first unused row (Matrix.cpp:227-263); `reduce` runs on every partial determinant of size >= 2
-  void Determinant(T& det, std::vector<bool>& usedRows, std::vector<bool>& usedCols, unsigned dim, std::function<void(T&)> reduce) const {
-    const unsigned matDim = NumRows();
-    unsigned row = 0;
-    while (usedRows[row]) ++row;
-    bool negative = false, first = true;
-    for (unsigned col = 0; col < matDim; ++col) {
-      if (usedCols[col]) continue;
-      if (dim == 1) { det = ElemAt(row, col); return; }
-      T term = ElemAt(row, col);
-      if (negative) term *= -1;
-      negative = !negative;
-      usedRows[row] = usedCols[col] = true;
-      T minor(dummy);
-      Determinant(minor, usedRows, usedCols, dim - 1, reduce);
-      usedRows[row] = usedCols[col] = false;
-      term *= minor;
-      if (first) { det = term; first = false; } else det += term;
-    }
-    if (reduce) reduce(det);
-  }
-
  public:
   Matrix() : dummy(T()) {}
   Matrix(const T& d) : dummy(d) {}
@@ -80,78 +55,6 @@ class Matrix {
   std::vector<T>& operator[](unsigned r) { return mat[r]; }
   const std::vector<T>& operator[](unsigned r) const { return mat[r]; }
   const T& Dummy() const { return dummy; }
-
-  Matrix& operator+=(const Matrix& o) { for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) ElemAt(i, j) += o(i, j); return *this; }   // Matrix.cpp:20-28
-  Matrix operator+(const Matrix& o) const { Matrix r = *this; r += o; return r; }
-  Matrix& operator-=(const Matrix& o) {                                                      // Matrix.cpp:30-40: += of the negated entry
-    for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) { T t = o(i, j); t *= -1; ElemAt(i, j) += t; }
-    return *this;
-  }
-  Matrix operator-(const Matrix& o) const { Matrix r = *this; r -= o; return r; }
-  Matrix& operator*=(Matrix& o) {                                                            // Matrix.cpp:57-79
-    if (mat.empty()) return *this;
-    Matrix prod(NumRows(), o.NumCols(), dummy);
-    for (unsigned i = 0; i < NumRows(); ++i)
-      for (unsigned j = 0; j < o.NumCols(); ++j) {
-        prod(i, j) = ElemAt(i, 0);
-        prod(i, j) *= o(0, j);
-        for (unsigned k = 1; k < NumCols(); ++k) { T t = ElemAt(i, k); t *= o(k, j); prod(i, j) += t; }
-      }
-    std::swap(prod.mat, mat);
-    transpose = false;
-    return *this;
-  }
-  Matrix& operator*=(std::vector<T>& v) {                                                   // Matrix.cpp:81-98 (the entries are multiplied in place first)
-    if (mat.empty()) return *this;
-    Matrix prod(NumRows(), 1, dummy);
-    for (unsigned i = 0; i < NumRows(); ++i) {
-      ElemAt(i, 0) *= v[0];
-      prod(i, 0) = ElemAt(i, 0);
-      for (unsigned j = 1; j < NumCols(); ++j) { ElemAt(i, j) *= v[j]; prod(i, 0) += ElemAt(i, j); }
-    }
-    std::swap(mat, prod.mat);
-    transpose = false;
-    return *this;
-  }
-  Matrix& operator*=(T& s) { for (unsigned i = 0; i < NumRows(); ++i) for (unsigned j = 0; j < NumCols(); ++j) ElemAt(i, j) *= s; return *this; }   // Matrix.cpp:100-108
-  Matrix operator*(Matrix& o) const { Matrix r = *this; r *= o; return r; }
-  Matrix operator*(std::vector<T>& v) const { Matrix r = *this; r *= v; return r; }
-
-  void MultByTranspose() {                                                                 // Matrix.cpp:150-174: upper triangle, mirrored
-    if (mat.empty()) return;
-    Matrix prod(NumRows(), NumRows(), dummy);
-    for (unsigned i = 0; i < NumRows(); ++i)
-      for (unsigned j = i; j < NumRows(); ++j) {
-        prod(i, j) = ElemAt(i, 0);
-        prod(i, j) *= ElemAt(j, 0);
-        for (unsigned k = 1; k < NumCols(); ++k) { T t = ElemAt(i, k); t *= ElemAt(j, k); prod(i, j) += t; }
-        if (i != j) prod(j, i) = prod(i, j);
-      }
-    std::swap(prod.mat, mat);
-    transpose = false;
-  }
-  void Determinant(T& det, std::function<void(T&)> reduce = nullptr) const {                // Matrix.cpp:218-225
-    std::vector<bool> usedRows(NumRows()), usedCols(NumRows());
-    Determinant(det, usedRows, usedCols, NumRows(), reduce);
-  }
-  void Invert(T& det, std::function<void(T&)> reduce = nullptr) {                          // Matrix.cpp:182-216: adjugate, then det from its first column
-    const unsigned dim = NumRows();
-    Matrix adj(dim, dim, dummy);
-    std::vector<bool> usedRows(dim), usedCols(dim);
-    for (unsigned i = 0; i < dim; ++i)
-      for (unsigned j = 0; j < dim; ++j) {
-        usedRows[i] = usedCols[j] = true;
-        Determinant(adj(j, i), usedRows, usedCols, dim - 1, reduce);
-        usedRows[i] = usedCols[j] = false;
-        if ((i + j) % 2 == 1) adj(j, i) *= -1;
-      }
-    det = ElemAt(0, 0);
-    det *= adj(0, 0);
-    for (unsigned i = 1; i < dim; ++i) { T t = ElemAt(0, i); t *= adj(i, 0); det += t; }
-    if (reduce) reduce(det);
-    std::swap(adj.mat, mat);
-    transpose = false;
-  }
 };
 
 // ---------------------------------------------------------------- slot counts (PlaintextSpace.cpp:29-43): factors of Phi_m mod p
@@ -426,27 +329,7 @@ class Regression {
   const FHEcontext& Context() const { return context; }
   void SumBatchedDataObject(Ciphertext& ct) const { SumBatchedData(ct); }
 
-  // Regression::Regress (Regression.h:102-149), the reference's control flow one Ciphertext object at a time -- its statements are recorded
-  // by the mirror's Ciphertext and evaluated in batches when theta / det are looked at (fhesi_engine.h).  Without the GenerateNoise masking,
-  // which needs slot packing (see the head of this file).
-  void Regress(std::vector<Ciphertext>& theta, Ciphertext& det) const {
-    Matrix<Ciphertext> dataCopy = data;
-    std::vector<Ciphertext> lab = labels;
-    dataCopy.Transpose();
-    Matrix<Ciphertext> last = dataCopy * lab;
-    dataCopy.MultByTranspose();
-    auto processFunc = [this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); SumBatchedData(ct); };
-    last.MapAll(processFunc);
-    dataCopy.MapAll(processFunc);
-    if (data.NumCols() == 1) { det = dataCopy(0, 0); theta.assign(1, last(0, 0)); return; }
-    dataCopy.Invert(det, [this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); });
-    dataCopy *= last;
-    dataCopy.MapAll([this](Ciphertext& ct) { keySwitch.ApplyKeySwitch(ct); });
-    theta.assign(dataCopy.NumRows(), Ciphertext(context));
-    for (unsigned i = 0; i < dataCopy.NumRows(); ++i) theta[i] = dataCopy(i, 0);
-  }
-
-  // The same expressions as explicit waves on the context's GPU
+  // The expressions of Regression::Regress (Regression.h:102-149) as explicit waves on the context's GPU
   void RegressBatched(std::vector<Ciphertext>& theta, Ciphertext& det) {
     if (!single) single.reset(new SingleGpuExecutor(context, keySwitch, autoKeySwitch, autoK));
     single->reset();

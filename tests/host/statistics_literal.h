@@ -1,11 +1,11 @@
-// fhesi_statistics.h -- mirror of Statistics (Statistics.h:12-177): encrypted first / second moments and the covariance matrix of batched
-// data, written against Ciphertext / Matrix<Ciphertext> / KeySwitchSI exactly as the reference's class is -- one object at a time.  The
-// statements are recorded by the mirror's Ciphertext and run as batched device calls when a result is looked at (fhesi_engine.h): the class
-// adds no device code of its own.  As in Regression (fhesi_matrix.h), plaintexts are coefficient vectors, the slot COUNT sizes the list of
+// statistics_literal.h -- TEST HARNESS (not part of the package; SURVEY.md section 2 marks Statistics.h out of scope): a caller of the
+// class surface in the shape of the reference's Statistics (Statistics.h:12-177), used only to drive the recording Ciphertext of
+// fhesi_engine.h with one more object-at-a-time control flow (moments, covariance) and compare recorded with at-once evaluation.  In an
+// integration the reference's own Statistics.h compiles unmodified on the mirrored classes.  As in Regression (fhe-si_amd/host/fhesi_matrix.h), plaintexts are coefficient vectors, the slot COUNT sizes the list of
 // automorphism keys (Statistics.h:17-26), and GenerateNoise (Statistics.h:163-174: EmbedInSlots, slot packing) is not applied -- the results
 // are the unmasked moments.
 #pragma once
-#include "fhesi_matrix.h"
+#include "matrix_literal.h"
 
 namespace fhesi {
 
@@ -16,7 +16,7 @@ class Statistics {
   KeySwitchSI keySwitch;
   std::vector<KeySwitchSI> autoKeySwitch;
   std::vector<unsigned> autoK;
-  Matrix<Ciphertext> data;
+  LMatrix<Ciphertext> data;
   std::vector<Ciphertext> nElems;
 
   void SumBatchedData(Ciphertext& batchedData) const {           // Statistics.h:148-161
@@ -74,10 +74,10 @@ class Statistics {
     }
   }
 
-  void ComputeCovariance(Matrix<Ciphertext>& cov, std::vector<Ciphertext>& mu, Ciphertext& n, Ciphertext& n2) {   // Statistics.h:87-133
+  void ComputeCovariance(LMatrix<Ciphertext>& cov, std::vector<Ciphertext>& mu, Ciphertext& n, Ciphertext& n2) {   // Statistics.h:87-133
     ComputeNthMoment(mu, n, 1);
     Ciphertext dummy(context);
-    Matrix<Ciphertext> muMat(dummy);
+    LMatrix<Ciphertext> muMat(dummy);
     muMat.AddRow(mu);
     muMat.Transpose();
     muMat.MultByTranspose();

@@ -1,19 +1,19 @@
 // test_statistics.cpp -- counterpart of the reference's Test_Statistics driver (Test_Statistics.cpp:66-244) on the mirrored classes, with
-// coefficient-form plaintexts (slot packing is outside the hot-path scope, see fhe-si_amd/host/fhesi_statistics.h).
+// coefficient-form plaintexts (slot packing is outside the hot-path scope, see statistics_literal.h).
 //
 //   test_statistics p generator dim nblocks [seed] [--m=M] [--logQ=B]
 //
 // Context as in Test_Statistics.cpp:199-241: m = p - 1, logQ = ceil((6.5 ln n + ln xi) / ln 2 + 36.1) with n = (p-1)/2 - 1, xi = max(blocks,
 // dim), SetUpSIContext(xi).  The data blocks (nblocks x dim) and the block sizes are random polynomials over Z_p in place of the packed
 // columns; Statistics::ComputeCovariance runs (a) with the Ciphertext operations recorded and evaluated in batches, (b) with every statement
-// run at once (LazyCiphertexts() = false), and (c) in the plaintext ring Z_p[X]/Phi_m with the same Matrix<T> template and the same sequence
+// run at once (LazyCiphertexts() = false), and (c) in the plaintext ring Z_p[X]/Phi_m with the same LMatrix<T> template and the same sequence
 // (mean = SumBatched(sum of the column), cov = SumBatched(X^T X) * n - mu mu^T, n^2); the run succeeds when (a) and (b) give bit-identical
 // ciphertexts and decrypt to (c).  ComputeNthMoment(2) is checked the same way.  Exit code = number of failed checks.
 #include <chrono>
 #include <cstring>
 #include <iostream>
 
-#include "../../fhe-si_amd/host/fhesi_statistics.h"
+#include "statistics_literal.h"
 #include "ring_elem.h"
 
 namespace fhesi { FHEcontext* activeContext = nullptr; }
@@ -42,7 +42,7 @@ int main(int argc, char* argv[]) {
   Statistics stats(context);
 
   Matrix<Plaintext> blocks; std::vector<Plaintext> blockSizes(nBlocks);
-  Matrix<RingElem> X(nBlocks, dim); std::vector<RingElem> sizes(nBlocks);
+  LMatrix<RingElem> X(nBlocks, dim); std::vector<RingElem> sizes(nBlocks);
   for (unsigned i = 0; i < nBlocks; ++i) {
     std::vector<Plaintext> row(dim);
     for (unsigned j = 0; j < dim; ++j) { row[j].message.resize(phim); for (auto& v : row[j].message) v = RandomBnd((long)p); X(i, j).c = row[j].message; }
@@ -61,12 +61,12 @@ int main(int argc, char* argv[]) {
     for (unsigned i = 1; i < nBlocks; ++i) { muP[j] += X(i, j); RingElem t = X(i, j); t *= X(i, j); m2P[j] += t; }
     sumBatched(muP[j]); sumBatched(m2P[j]);
   }
-  Matrix<RingElem> covP = X; covP.Transpose(); covP.MultByTranspose();
+  LMatrix<RingElem> covP = X; covP.Transpose(); covP.MultByTranspose();
   for (unsigned i = 0; i < dim; ++i) for (unsigned j = 0; j < dim; ++j) { sumBatched(covP(i, j)); covP(i, j) *= nP; RingElem t = muP[i]; t *= muP[j]; t *= -1; covP(i, j) += t; }
   RingElem n2P = nP; n2P *= nP;
 
   int failures = 0;
-  auto run = [&](bool recorded, Matrix<Ciphertext>& cov, std::vector<Ciphertext>& mu, std::vector<Ciphertext>& m2, Ciphertext& encN, Ciphertext& encN2) {
+  auto run = [&](bool recorded, LMatrix<Ciphertext>& cov, std::vector<Ciphertext>& mu, std::vector<Ciphertext>& m2, Ciphertext& encN, Ciphertext& encN2) {
     LazyCiphertexts() = recorded;
     CtEngine& eng = ct_engine(context);
     const long calls0 = eng.stats.calls, rec0 = eng.stats.recorded;
@@ -88,7 +88,7 @@ int main(int argc, char* argv[]) {
     if (!ok) ++failures;
     LazyCiphertexts() = true;
   };
-  Ciphertext proto(context); Matrix<Ciphertext> covA(proto), covB(proto); std::vector<Ciphertext> muA, muB, m2A, m2B; Ciphertext nA(context), nB(context), n2A(context), n2B(context);
+  Ciphertext proto(context); LMatrix<Ciphertext> covA(proto), covB(proto); std::vector<Ciphertext> muA, muB, m2A, m2B; Ciphertext nA(context), nB(context), n2A(context), n2B(context);
   run(true, covA, muA, m2A, nA, n2A);
   run(false, covB, muB, m2B, nB, n2B);
   auto eq = [](Ciphertext& a, Ciphertext& b) { return a.size() == 2 && b.size() == 2 && a[0] == b[0] && a[1] == b[1]; };

@@ -105,7 +105,7 @@ def test_regression_literal_with_recording_off():
 
 @pytest.mark.parametrize("args", [["23", "7", "2", "2", "1"], ["47", "5", "3", "3", "2"], ["257", "3", "3", "2", "3"], ["8423", "7", "4", "2", "1"]])
 def test_statistics_moments_and_covariance(args):
-    """Statistics::ComputeNthMoment / ComputeCovariance (Statistics.h:48-133) on the mirror (fhe-si_amd/host/fhesi_statistics.h), driven as
+    """Statistics::ComputeNthMoment / ComputeCovariance (Statistics.h:48-133) on the mirrored classes (harness: tests/host/statistics_literal.h), driven as
     Test_Statistics.cpp:66-244 drives it (its logQ formula, SetUpSIContext(xi)): recorded and at-once evaluation give bit-identical
     ciphertexts, and mean, second moments, N, N^2 and the covariance matrix decrypt to the same statistics computed in the plaintext ring
     Z_p[X]/Phi_m.  m = 22 / 46 / 8422 are the reference's safe-prime rings, m = 256 a power of two."""
