@@ -176,9 +176,10 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   if (units > 0x7fffffff) FHESI_FAIL("ntt32: too many digit rows per launch");
   if (digit_bits > 30) FHESI_FAIL("ntt32: digits of %d bits (the first stage of a digit row assumes values below 2p)", digit_bits);
   const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
-  if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(((units + 7) / 8) * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
-  else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
-  else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(((units + 7) / 8) * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+  const i64 ug = A32_LAY_PAIR ? (units + 15) / 16 * 2 : (units + 7) / 8;      // groups of 8 units (one per XCD), x 4 primes x 2^S sub-blocks workgroups each
+  if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(ug * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+  else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(ug * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+  else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(ug * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   HIP_TRY(hipGetLastError());
   return 0;
 }
