@@ -134,7 +134,12 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
   c->phi = hm::cyclotomic(m);
   c->pow2 = (m & (m - 1)) == 0 && m >= 4;
   c->logn = c->pow2 ? hm::ilog2_ceil(c->phim) : 0;
-  if (!c->pow2 && m % 2 == 0 && (m / 2) % 2 == 1 && hm::is_prime((u64)(m / 2)) && 2 * c->phim - 1 <= kAux32N) c->lin_q = m / 2;
+  if (!c->pow2 && 2 * c->phim - 1 <= 2 * kAux32N) {
+    // rings whose products run as linear convolutions on padded power-of-two rows (larger ones keep the per-prime Bluestein rows)
+    if (m % 2 == 0 && (m / 2) % 2 == 1 && hm::is_prime((u64)(m / 2))) c->lin_q = m / 2;
+    else if (m % 2 == 1 && m > 2 && hm::is_prime((u64)m)) { c->lin_q = m; c->lin_prime = true; }
+    if (c->lin_q) c->lin_lg = 2 * c->phim - 1 <= kAux32N ? 14 : 15;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

@@ -97,9 +97,13 @@ struct fhesi_ctx {
   int n_big_primes = 0;                // chain primes >= 2^48
   bool has_small_prime = false;        // some chain prime is below 2^48: the tile kernels transform its rows modulo q_tile (ntt_tile.inc)
   int logn = 0;                        // log2(phim) when pow2
-  // m = 2 q' with q' an odd prime and 2 phi(m) - 1 <= 2^14 (the reference's safe-prime rings, e.g. p = 8423): the key switch's integer
-  // dot product is a LINEAR convolution carried by the 2^14-point 32-bit transforms and folded modulo X^q' + 1 and Phi_m afterwards
-  i64 lin_q = 0;                       // q' (0 = not such a ring)
+  // m = 2 q' with q' an odd prime (the reference's safe-prime rings, e.g. p = 8423) or m an odd prime, and 2 phi(m) - 1 <= 2^15: the
+  // integer products of the key switch and of the tensor half are LINEAR convolutions carried by the 2^14- or 2^15-point 32-bit
+  // transforms on zero-padded rows and folded afterwards, exactly, modulo X^q' + 1 and Phi_m = sum (-X)^i  (m = 2q':  out_j =
+  // S_j - S_(j+q') - (-1)^j S_(q'-1))  or modulo X^m - 1 and Phi_m = sum X^i  (m prime:  out_j = S_j + S_(j+m) - S_(m-1))
+  i64 lin_q = 0;                       // the fold's offset: q' (m = 2q') or m (m prime); 0 = not such a ring
+  bool lin_prime = false;              // m itself is the prime
+  int lin_lg = 0;                      // log2 of the padded rows: 14 or 15
   std::vector<u64> q, root;
   std::vector<int> zms_idx;            // PAlgebra::zmsIdx (PAlgebra.cpp:50-52)
   std::vector<i64> phi;                // Phi_m(X) (PAlgebra.cpp:55)
@@ -176,7 +180,7 @@ struct fhesi_ksk {
   size_t mfma_bytes = 0;
   bool mfma_valid = false;
   bool aux32 = false;                  // the table holds residues modulo the four 30-bit primes of kernels_aux32.hip (u32, 2^14-point rows)
-  i64 aux_fold = 0;                    // q' when the rows are linear convolutions to be folded modulo X^q' + 1 and Phi_m (ctx->lin_q), else 0
+  i64 aux_fold = 0;                    // q' when the rows are linear convolutions to be folded modulo X^q' + 1 and Phi_m (ctx->lin_q), -m for a prime m (modulo X^m - 1 and Phi_m), else 0
   u64* d_limb_consts = nullptr;        // [W+1] offset constant D, [2] floor(2^(64(W-2)+128) / P), then the quotient bound's bit count
 };
 struct KsLimbPlan { int W = 0, LQ = 0, B = 0, NLB = 0, mbits = 0; bool a32 = false; };
@@ -201,7 +205,7 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
                             i64 sub_units /* units (digit polynomials) per sub-chunk */);
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */);
 bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14 or 2^15, or a ring with lin_q set
-i64 aux32_row_len(const fhesi_ctx* ctx);            // 2^15 for n = 2^15, else 2^14
+i64 aux32_row_len(const fhesi_ctx* ctx);            // 2^15 for n = 2^15 and for linear-convolution rings with 2 phi(m) - 1 > 2^14, else 2^14
 static const i64 kAux32N = 1 << 14;                // row length of the 32-bit auxiliary transforms
 int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig /* [count*ncol][4][n] */, int ncol, i64 count, u32* d_out /* [count*2*rows][4][n] */, bool* mont /* out: the rows carry 2^-32 */);
 enum { KS_MODE_DIRECT = 0, KS_MODE_LIMB32 = 1 /* four 30-bit primes, limbs */, KS_MODE_LIMB60 = 2 /* two largest chain primes, limbs */, KS_MODE_RESIDUE60 = 3 /* ..., residues */ };

@@ -48,10 +48,10 @@ __global__ void __launch_bounds__(256) ntt32_tail_kernel(u32* __restrict__ rows,
 
 // ---------------------------------------------------------------------------------------------- host side
 bool aux32_applies(const fhesi_ctx* ctx) { return (ctx->pow2 && (ctx->logn == A32_LOGN || ctx->logn == A32_LOGN + 1)) || ctx->lin_q != 0; }
-i64 aux32_row_len(const fhesi_ctx* ctx) { return (ctx->pow2 && ctx->logn == A32_LOGN + 1) ? 2 * (i64)A32_N : (i64)A32_N; }
+i64 aux32_row_len(const fhesi_ctx* ctx) { return ((ctx->pow2 && ctx->logn == A32_LOGN + 1) || ctx->lin_lg == A32_LOGN + 1) ? 2 * (i64)A32_N : (i64)A32_N; }
 static int aux32_init(fhesi_ctx* ctx) {
   if (ctx->aux32) return 0;
-  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14, 2^15 and for rings m = 2 * prime with 2 phi(m) - 1 <= 2^14");
+  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14, 2^15 and for rings m = prime or 2 * prime with 2 phi(m) - 1 <= 2^15");
   fhesi_aux32* x = new fhesi_aux32();
   const i64 n = aux32_row_len(ctx);                // 2^14, or 2^15 = two sub-transforms per row
   const int S = n > A32_N ? 1 : 0, lg = A32_LOGN + S;
@@ -177,7 +177,8 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   if (digit_bits > 30) FHESI_FAIL("ntt32: digits of %d bits (the first stage of a digit row assumes values below 2p)", digit_bits);
   const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
   const i64 ug = A32_LAY_PAIR ? (units + 15) / 16 * 2 : (units + 7) / 8;      // groups of 8 units (one per XCD), x 4 primes x 2^S sub-blocks workgroups each
-  if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(ug * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+  if (S && ctx->lin_q) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1, true>); ntt32_fwd_kernel3<true, 1, true><<<(unsigned)(ug * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+  else if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(ug * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(ug * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(ug * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
   HIP_TRY(hipGetLastError());

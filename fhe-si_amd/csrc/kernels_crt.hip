@@ -767,8 +767,14 @@ __global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __
       const u32* __restrict__ row = base32 + (i64)(l * 4 + a) * nrow;
       if (!fold_q) { v[a] = row[j]; continue; }
       const u32 p = gc.p[a];
-      const u32 s0 = row[j], s1 = row[j + fold_q], t0 = row[n], t1 = row[n + fold_q];      // all below p
-      u32 r = s0 + (p - s1) + ((j & 1) ? t0 + (p - t1) : t1 + (p - t0));                     // below 4p
+      u32 r;
+      if (fold_q > 0) {        // m = 2q':  S_j - S_(j+q') -+ (S_n - S_(n+q'))
+        const u32 s0 = row[j], s1 = row[j + fold_q], t0 = row[n], t1 = n + fold_q < nrow ? row[n + fold_q] : 0u;      // all below p
+        r = s0 + (p - s1) + ((j & 1) ? t0 + (p - t1) : t1 + (p - t0));                     // below 4p
+      } else {                 // m prime (offset -fold_q = m, n = m - 1):  S_j + S_(j+m) - S_(m-1)
+        const u32 s0 = row[j], s1 = j - fold_q < nrow ? row[j - fold_q] : 0u, t0 = row[n];
+        r = s0 + s1 + (p - t0);                                                               // below 3p
+      }
       r = r >= 2 * p ? r - 2 * p : r;
       v[a] = r >= p ? r - p : r;
     }
@@ -794,7 +800,7 @@ __global__ void __launch_bounds__(128) ks_recombine_generic_kernel(const u64* __
       for (int a = 0; a < 4; ++a) cur[a] = nxt[a];
     } else {
       V = centred(l, j);
-      if (fold_q) {
+      if (fold_q > 0) {      // (the two-prime auxiliary form never runs on a linear-convolution ring: ks_limb_plan)
         // S (degree < 2n - 1) modulo X^q' + 1: R_j = S_j - S_(j+q');  modulo Phi_m = 1 - X + X^2 - ... + X^(q'-1) (degree n = q' - 1):
         // out_j = R_j - (-1)^j R_n,  j < n   (Phi_m is monic, so this is the exact integer remainder)
         const u128 top = centred(l, n) - centred(l, n + fold_q);

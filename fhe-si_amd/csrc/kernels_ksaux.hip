@@ -414,7 +414,7 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ, int mode
     HIP_TRY(hipGetLastError());
   }
   k->aux32 = limb && plan.a32;
-  k->aux_fold = k->aux32 ? ctx->lin_q : 0;
+  k->aux_fold = k->aux32 ? (ctx->lin_prime ? -ctx->lin_q : ctx->lin_q) : 0;      // (negative: the fold of a prime m)
   const int* d_slot = (const int*)(k->d_aux_consts + L);
   const i64 rows_per_a = (i64)R * 2 * ncol;
   if (!k->aux32)

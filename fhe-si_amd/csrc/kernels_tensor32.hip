@@ -88,9 +88,9 @@ static T32Plan t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 g
   if (!ctx->opt.tensor32 || p < 2 || nlimbs < 1 || nlimbs > 16 || 64 * nlimbs < logQ || gmax < 1) return pl;
   const bool lin = ctx->lin_q != 0;
   if (!lin && !(ctx->pow2 && (ctx->logn == A32_LOGN || ctx->logn == A32_LOGN + 1))) return pl;
-  const int lg = lin ? A32_LOGN : ctx->logn;                 // rows of 2^lg
+  const int lg = lin ? ctx->lin_lg : ctx->logn;              // rows of 2^lg
   const bool compiled = !lin && (logQ == 512 || logQ == 1024);
-  if (!compiled && (logQ < 64 || logQ > 512 || lg != A32_LOGN)) return pl;       // the generic CRT kernel: logQ <= 512, rows of 2^14
+  if (!compiled && (logQ < 64 || logQ > 512)) return pl;     // the generic CRT kernel: logQ <= 512 (rows of 2^14, or two sub-rows of a 2^15-point row)
   int pbits = 0, gbits = 0, cbits = 0;
   while (pbits < 64 && (p >> pbits)) ++pbits;
   while (((i64)1 << gbits) < gmax) ++gbits;
@@ -121,14 +121,14 @@ static T32Plan t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 g
 }
 bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ) { return t32_plan(ctx, p, nlimbs, logQ, 1, nullptr).NP > 0; }
 bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax) {
-  if (ctx->pow2 && ctx->logn != A32_LOGN) return false;        // (the sums are built for rows of 2^14)
+  if (ctx->pow2 && ctx->logn != A32_LOGN) return false;        // (power-of-two rings: the sums are built for rows of 2^14)
   return t32_plan(ctx, p, nlimbs, logQ, gmax, nullptr).NP > 0;
 }
 
 // transform tables of the first `want` primes (grown on demand; a growth waits for the streams)
 static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
   fhesi_tensor32* x = ctx->tensor32;
-  if (!x) { x = new fhesi_tensor32(); x->S = (!ctx->lin_q && ctx->logn == A32_LOGN + 1) ? 1 : 0; ctx->tensor32 = x; }
+  if (!x) { x = new fhesi_tensor32(); x->S = ((ctx->lin_q ? ctx->lin_lg : ctx->logn) == A32_LOGN + 1) ? 1 : 0; ctx->tensor32 = x; }
   if (x->primes.size() >= primes.size()) return 0;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->lane_stream) HIP_TRY(hipStreamSynchronize(ctx->lane_stream));
@@ -289,7 +289,7 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
 }
 template <int NL, bool HEAD, bool PAIRED>
 __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict__ a, const u64* __restrict__ b, i64 na2, i64 n_src, i64 nrow, u32* __restrict__ rows, int NP,
-                                                            const u32* __restrict__ tab, const int* __restrict__ idx_a = nullptr, const int* __restrict__ idx_b = nullptr) {
+                                                            const u32* __restrict__ tab, const int* __restrict__ idx_a = nullptr, const int* __restrict__ idx_b = nullptr, int dup = 0) {
   __shared__ __attribute__((aligned(16))) u64 sl[NL * 256];       // [NL][256]
   const i64 poly = blockIdx.y;
   int cls;
@@ -303,8 +303,10 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   const i64 j0 = (i64)blockIdx.x * 256;
   const int tid = threadIdx.x;
   u32* __restrict__ o = rows + poly * NP * nrow + j0 + tid;
+  // dup (padded rows of 2^15 on a linear-convolution ring: the polynomial's upper half is zero, so the head stage x +- w 0 leaves x in both
+  // sub-rows): every value is written to sub-row 1 as well
   if (j0 >= n_src) {                                             // (whole block in the zero padding)
-    for (int i = 0; i < NP; ++i) o[(i64)i * nrow] = 0;
+    for (int i = 0; i < NP; ++i) { o[(i64)i * nrow] = 0; if (dup) o[(i64)i * nrow + A32_N] = 0; }
     return;
   }
   const i64 avail = (n_src - j0) * NL;                           // words of this block's 256 coefficients that exist
@@ -345,7 +347,10 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   for (int i = 0; i < NP; ++i) {
     const u32* __restrict__ t = tab + ((i64)cls * NP + i) * STRIDE;
     const u32 r0 = rns32_one<NL>(x, neg, t);
-    if constexpr (!HEAD) __builtin_nontemporal_store(r0, &o[(i64)i * nrow]);                  // (a zero coefficient gives 0: the padding inside a partial block)
+    if constexpr (!HEAD) {
+      __builtin_nontemporal_store(r0, &o[(i64)i * nrow]);                  // (a zero coefficient gives 0: the padding inside a partial block)
+      if (dup) __builtin_nontemporal_store(r0, &o[(i64)i * nrow + A32_N]);
+    }
     else {
       const u32 p = t[2 * NL + 3], twop = 2 * p;
       const u32 r1 = rns32_one<NL>(x1, neg1, t);
@@ -489,8 +494,11 @@ __global__ void __launch_bounds__(128) crt32_scale_kernel(const u32* __restrict_
 // through LDS, one column per thread, and the 64-bit limbs are cut from there.  fold_q = q' (m = 2q'): the residue of output coefficient j is
 //   r_j - r_(j+q') - (-1)^j r_(q'-1)   of the linear product's residues (modulo X^q' + 1, then modulo Phi_m = sum (-X)^i).
 // NWMAX = T32_GEN_NW with J0 from the host, or T32_GEN_NWX with J0 = 0 for the exact pass over flagged workgroups.
+// S = 1 (rows of 2^15 = the two sub-inverses A, B of ntt32_inv_kernel3): the coefficient at position e < 2^14 is (A_e + B_e) / 2, at e + 2^14
+// (A_e - B_e) psi^-brv(1) / 2; the two constants sit in cinv[2i], cinv[2i + 1] (times the CRT constant), so the positions of the lower and of
+// the upper half are summed separately and the residue is  lo c_lo + hi c_hi.
 template <int NWMAX, bool EXACT>
-__global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __restrict__ rows, i64 nrow, i64 n_out, i64 fold_q, int NP, int LQ, int J0, int NW, int WT,
+__global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __restrict__ rows, i64 nrow, i64 n_out, i64 fold_q, int S, int NP, int LQ, int J0, int NW, int WT,
                                                                    T32Primes pr, const Tw32* __restrict__ cinv, const u32* __restrict__ inv57, const u32* __restrict__ Mw,
                                                                    u64* __restrict__ out, unsigned char* __restrict__ flags) {
   constexpr int R = 28;
@@ -509,13 +517,37 @@ __global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __r
     for (int i = 0; i < NP; ++i) {
       const u32 p = pr.p[i];
       const u32* __restrict__ ri = src + (i64)i * nrow;
+      u32 y;
+      if (S) {
+        const u32 twop = 2 * p;
+        // t(e) for a position of the lower half, below 2p; the position j + |fold_q| may lie in the upper half
+        auto low = [&](i64 e) -> u32 { return ri[e] + ri[e + A32_N]; };
+        auto red2 = [&](u32 v) -> u32 { return min(v, v - twop); };                 // [0, 4p) -> [0, 2p)
+        u32 lo = low(j), hi = 0;
+        if (fold_q) {
+          const i64 off = fold_q > 0 ? fold_q : -fold_q, e = j + off;
+          const bool sub_b = fold_q > 0;                                              // m = 2q': - S_(j+q');  m prime: + S_(j+m)
+          if (e < A32_N) { const u32 b = low(e); lo = red2(lo + (sub_b ? twop - b : b)); }
+          else if (e < nrow) { const u32 A = ri[e - A32_N], B = ri[e]; hi = sub_b ? B + p - A : A + p - B; }      // +-(A - B), below 2p
+          const u32 c = low(off - 1);
+          const bool sub_c = fold_q < 0 || !(j & 1);                                  // m = 2q': - (-1)^j S_(q'-1);  m prime: - S_(m-1)
+          lo = red2(lo + (sub_c ? twop - c : c));
+        }
+        y = mul_lazy32(lo, cinv[2 * i], p) + mul_lazy32(hi, cinv[2 * i + 1], p);    // below 4p
+        y = min(y, y - twop);
+        y = min(y, y - p);
+      } else {
       u32 r = ri[j];
-      if (fold_q) {
+      if (fold_q > 0) {              // m = 2q'
         const u32 b = j + fold_q < nrow ? ri[j + fold_q] : 0u, c = ri[fold_q - 1];
         r = r + (p - b) + ((j & 1) ? c : p - c);       // below 4p
+      } else if (fold_q < 0) {       // m prime, offset -fold_q = m:  r_j + r_(j+m) - r_(m-1)
+        const u32 b = j - fold_q < nrow ? ri[j - fold_q] : 0u, c = ri[-fold_q - 1];
+        r = r + b + (p - c);                           // below 3p
       }
-      u32 y = mul_lazy32(r, cinv[2 * i], p);
+      y = mul_lazy32(r, cinv[2 * i], p);
       y = y >= p ? y - p : y;
+      }
       fsum += __umulhi(y, inv57[i]);
       const u32* __restrict__ Mi = Mw + (i64)i * WT + J0;
 #pragma unroll
@@ -574,9 +606,10 @@ static int t32_launch_rns(fhesi_ctx* ctx, const T32Config* c, const u64* d_a, co
   const dim3 grid((unsigned)(A32_N / 256), (unsigned)npolys);
   const int* ia = paired && ctx->op_idx ? ctx->op_idx + ctx->op_idx_done : nullptr;
   const int* ib = ia ? ia + ctx->op_idx_n : nullptr;
+  const int dup = S && ctx->lin_q ? 1 : 0;
 #define T32_GO(HEAD, PAIRED) do { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, HEAD, PAIRED>); \
-    rns32_reduce_kernel<NL, HEAD, PAIRED><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, na2, n_src, nrow, d_r, c->NP, c->d_rns, ia, ib); } while (0)
-  if (S) { if (paired) T32_GO(true, true); else T32_GO(true, false); }
+    rns32_reduce_kernel<NL, HEAD, PAIRED><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, na2, n_src, nrow, d_r, c->NP, c->d_rns, ia, ib, dup); } while (0)
+  if (S && !dup) { if (paired) T32_GO(true, true); else T32_GO(true, false); }
   else { if (paired) T32_GO(false, true); else T32_GO(false, false); }
 #undef T32_GO
   HIP_TRY(hipGetLastError());
@@ -641,10 +674,10 @@ static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npoly
   FHESI_TRY(ws_reserve(ctx, 6, (size_t)grid.x * grid.y, &d_fl));
   unsigned char* fl = (unsigned char*)d_fl;
   PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_generic_kernel<T32_GEN_NW, false>));
-  crt32_scale_generic_kernel<T32_GEN_NW, false><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, ctx->lin_q, c->NP, logQ, J0, NW, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
+  crt32_scale_generic_kernel<T32_GEN_NW, false><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, (ctx->lin_prime ? -ctx->lin_q : ctx->lin_q), S, c->NP, logQ, J0, NW, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
   HIP_TRY(hipGetLastError());
   if (!ctx->opt.crt_skip_cleanup) {
-    crt32_scale_generic_kernel<T32_GEN_NWX, true><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, ctx->lin_q, c->NP, logQ, 0, WU, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
+    crt32_scale_generic_kernel<T32_GEN_NWX, true><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, (ctx->lin_prime ? -ctx->lin_q : ctx->lin_q), S, c->NP, logQ, 0, WU, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -685,7 +718,6 @@ size_t tensor32_sum_bytes(const fhesi_ctx* ctx, i64 ngroups) { return (size_t)ng
 int tensor32_sum_pass(fhesi_ctx* ctx, const u64* d_ops, i64 nua, i64 nub, const int* d_slot_a, const int* d_slot_b, const int* d_seg, i64 ng, i64 nterms, bool accumulate, void* d_sum) {
   const T32Config* c = ctx->tensor32->cur;
   const i64 nrow = t32_nrow(ctx), n = ctx->phim;
-  if (ctx->tensor32->S) FHESI_FAIL("tensor32: sums on rows of 2^15 are not built");
   void* d_r;
   FHESI_TRY(ws_reserve(ctx, 0, (size_t)(nua + nub) * 2 * c->NP * nrow * 4, &d_r));
   const u64* d_b = d_ops + (size_t)nua * 2 * n * c->nl;
@@ -709,7 +741,7 @@ int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts) {
   {
     ProfScope prof(ctx, PROF_NTT_INV, (double)(ng * 3 * c->NP));
     PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, false, T32Primes>));
-    ntt32_inv_kernel3<false, false, T32Primes><<<dim3((unsigned)(ng * 3), (unsigned)c->NP), A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, 0, nullptr);
+    ntt32_inv_kernel3<false, false, T32Primes><<<dim3((unsigned)(ng * 3), (unsigned)(c->NP << x->S)), A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, x->S, nullptr);
     HIP_TRY(hipGetLastError());
   }
   return t32_crt(ctx, c, (const u32*)d_sum, ng * 3, d_parts);

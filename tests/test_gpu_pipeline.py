@@ -153,7 +153,9 @@ def test_sum_form_crt_undecided_coefficients(monkeypatch):
 
 @pytest.mark.parametrize("m,logQ,p", [(32768, 512, 23), (1 << 16, 1024, 65537),
                                       (32768, 200, 23),          # run-time CRT window (any logQ <= 512)
-                                      (8422, 341, 8423)])        # the reference's Test_Regression ring: linear convolutions + fold
+                                      (8422, 341, 8423),         # the reference's Test_Regression ring: linear convolutions + fold
+                                      (32602, 128, 32603),       # ... with phi(m) = 16300: padded rows of 2^15 (head = duplication, tail inside the CRT kernel)
+                                      (101, 128, 23), (16381, 128, 23)])      # odd prime m: the three-term fold modulo X^m - 1 and Phi_m
 def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     """At the metric ring the fused pipeline forms tProd's integers modulo 35 primes below 2^30 instead of the chain
     (kernels_tensor32.hip; Ciphertext.cpp:167-218 only ever exposes round(x / 2^logQ) mod 2^logQ of them; 70 primes and rows of 2^15 at
@@ -201,7 +203,7 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     chain = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     ctx.set_option("tensor32", 1)
     assert np.array_equal(got, chain)
-    for c in (1, 2):
+    for c in ((2,) if ctx.phim > 10000 and (m & (m - 1)) != 0 else (1, 2)):      # (general m at this size: seconds per Bluestein row in the oracle)
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
     ctx.set_option("crt_skip_cleanup", 1)
     bad = ctx.ct_mul_relin(ksk, logQ, p, a, b)
@@ -343,12 +345,15 @@ def test_safe_prime_ring_with_a_chain_too_narrow_for_the_limb_plan(m, logQ):
     assert ksk.form()[0] == (0 if ctx.L == 1 else 1)
 
 
-@pytest.mark.parametrize("m,logQ", [(22, 80), (46, 120), (1006, 200), (8422, 341)])
+@pytest.mark.parametrize("m,logQ", [(22, 80), (46, 120), (1006, 200), (8422, 341),
+                                    (32602, 120),              # p = 32603: phi(m) = 16300, the metric's size in the reference's own parameterisation -- padded rows of 2^15
+                                    (101, 80), (16381, 120)])  # odd prime m: fold modulo X^m - 1 and Phi_m = 1 + X + ... + X^(m-1) (rows of 2^14 and 2^15)
 def test_key_switch_on_safe_prime_rings(m, logQ):
     """The reference's own rings (m = p - 1 = 2 q' for a safe prime p; Test_Regression: p = 8423, logQ = 341, 13 primes) take the exact
-    integer key switch as well: the digit (*) key products are LINEAR convolutions carried by the 2^14-point 32-bit transforms, folded
-    modulo X^q' + 1 and Phi_m inside the recombination (kernels_crt.hip: ks_recombine_generic_kernel, fold_q) -- instead of one
-    Bluestein transform of every digit polynomial per chain prime (option ks_direct, the reference's structure).  Both device paths
+    integer key switch as well: the digit (*) key products are LINEAR convolutions carried by the 2^14- or 2^15-point 32-bit transforms on
+    zero-padded rows, folded modulo X^q' + 1 and Phi_m inside the recombination (kernels_crt.hip: ks_recombine_generic_kernel, fold_q) --
+    instead of one Bluestein transform of every digit polynomial per chain prime (option ks_direct, the reference's structure,
+    CModulus.cpp:90-132 + bluestein.cpp:93-144).  Odd prime m takes the same route with its own fold.  Both device paths
     against the oracle, end to end and on crafted key rows that drive the folded integer through the edges of the reduction."""
     p = 23
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 5 + m, 2)
@@ -356,9 +361,10 @@ def test_key_switch_on_safe_prime_rings(m, logQ):
         orc.set_bluestein_fft(True)             # the oracle's O(N log N) form of the same transforms (bluestein.cpp:116-139)
     n, L = ctx.phim, ctx.L
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
-    want = [orc.ct_mul_relin(ksm, a[c], b[c], logQ, p) for c in range(2)]
+    want = [orc.ct_mul_relin(ksm, a[c], b[c], logQ, p) for c in range(1 if m > 10000 else 2)]      # (the oracle's Bluestein rows of 2^16 / 2^17 points take seconds each)
     got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
-    for c in range(2):
+    assert ksk.form()[0] == 1, ksk.form()            # limbs over the four 30-bit auxiliary primes = the linear-convolution form ran
+    for c in range(len(want)):
         assert np.array_equal(got[c], want[c]), c
     ctx.set_option("ks_direct", 1)
     ksk_d = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
@@ -372,7 +378,7 @@ def test_key_switch_on_safe_prime_rings(m, logQ):
         Pprod *= q
     mod, W, h, pb = 1 << logQ, L + 2, (Pprod - 1) // 2, Pprod.bit_length()
     edge = [h, -h, h + 1, h - 1, 0, 1, -1, Pprod - 1, h + 2, 12345, -(1 << (pb * 4 // 7)), (1 << (pb - 8)) + 17]
-    for d, pos in ((1, 0), ((1 << 24) - 1, n - 1), ((1 << 24) - 1, n // 2)):
+    for d, pos in ((1, 0), ((1 << 24) - 1, n - 1), ((1 << 24) - 1, n // 2))[(1 if m > 10000 else 0):(2 if m > 10000 else 3)]:
         tp = np.zeros((1, 3, L, n), dtype=np.uint64)
         tp[0, 0] = orc.dcrt_from_poly(O.ints_to_limbs([0] * pos + [d * mod] + [0] * (n - 1 - pos), W))
         ksm2 = ksm.copy()
