@@ -304,7 +304,7 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
     ctx.prof_enable(False)
     launches, rows, ms = prof["ntt_fwd_digits_main"]
     # (the 32-bit digit rows have 2^14 elements, also on the zero-padded linear-convolution rings; the bytes counted are the rows' own)
-    row_elems = max(n, 1 << 14) if kname.startswith("ntt32_") else n
+    row_elems = max(n if M_RING & (M_RING - 1) == 0 else 1 << (2 * n - 2).bit_length(), 1 << 14) if kname.startswith("ntt32_") else n      # (padded rows of 2^14 / 2^15 on the linear-convolution rings)
     achieved = rows * 2 * row_elems * (4 if kname.startswith("ntt32_") else 8) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     ks_form, ks_rows, ks_limb_bits = ksk.form()
     if rank == 0:
@@ -448,6 +448,7 @@ def main():
     ap.add_argument("--reg-rows", type=int, default=1)
     ap.add_argument("--reg-ring", default="metric", choices=["metric", "reference"], help="regression workload: replay at the metric ring (default) or on "
                     "the reference's own Test_Regression ring (p = 8423, m = 8422, logQ = 341: configs[3] itself)")
+    ap.add_argument("--reg-p", type=int, default=8423, help="--reg-ring reference: the safe prime p (m = p - 1); 8423 = Test_Regression's, 32603 = phi(m) 16300")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 plumbing)")
     ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
@@ -463,7 +464,14 @@ def main():
     if args.workload == "stress":
         M_RING, LOGQ, P_PLAIN = 1 << 16, 1024, 65537
     if args.workload == "regression" and args.reg_ring == "reference":
-        M_RING, LOGQ, P_PLAIN = 8422, 341, 8423          # Test_Regression.cpp:100-108 (d = 8: logQ = 341 by its noise formula)
+        # Test_Regression.cpp:100-108: m = p - 1, logQ by its noise formula (p = 8423, d = 8: 341; p = 32603 -- phi(m) = 16300, the metric's size in
+        # the reference's own parameterisation --: 377)
+        pp, dim = args.reg_p, args.reg_dim
+        if not _is_prime(pp) or not _is_prime((pp - 1) // 2):
+            raise SystemExit(f"--reg-p {pp}: the reference's rings are m = p - 1 for a safe prime p")
+        nn = (pp - 1) // 2 - 1
+        lgq = 4.5 * math.log(nn) + max(1, dim - 1) * (math.log(1280) + 2 * math.log(nn) + math.log(max(args.reg_rows, dim)))
+        M_RING, LOGQ, P_PLAIN = pp - 1, int(math.ceil(lgq / math.log(2) + 24.7)), pp
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))

@@ -121,7 +121,6 @@ static T32Plan t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 g
 }
 bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ) { return t32_plan(ctx, p, nlimbs, logQ, 1, nullptr).NP > 0; }
 bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax) {
-  if (ctx->pow2 && ctx->logn != A32_LOGN) return false;        // (power-of-two rings: the sums are built for rows of 2^14)
   return t32_plan(ctx, p, nlimbs, logQ, gmax, nullptr).NP > 0;
 }
 
@@ -520,18 +519,18 @@ __global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __r
       u32 y;
       if (S) {
         const u32 twop = 2 * p;
-        // t(e) for a position of the lower half, below 2p; the position j + |fold_q| may lie in the upper half
-        auto low = [&](i64 e) -> u32 { return ri[e] + ri[e + A32_N]; };
+        // position e of the row: lower half (A_e + B_e), upper half (A - B)(e - 2^14), each below 2p, summed per half with its sign
         auto red2 = [&](u32 v) -> u32 { return min(v, v - twop); };                 // [0, 4p) -> [0, 2p)
-        u32 lo = low(j), hi = 0;
+        u32 lo = 0, hi = 0;
+        auto add = [&](i64 e, bool neg) {
+          if (e < A32_N) { const u32 t = ri[e] + ri[e + A32_N]; lo = red2(lo + (neg ? twop - t : t)); }
+          else if (e < nrow) { const u32 A = ri[e - A32_N], B = ri[e]; hi = red2(hi + (neg ? B + p - A : A + p - B)); }
+        };
+        add(j, false);
         if (fold_q) {
-          const i64 off = fold_q > 0 ? fold_q : -fold_q, e = j + off;
-          const bool sub_b = fold_q > 0;                                              // m = 2q': - S_(j+q');  m prime: + S_(j+m)
-          if (e < A32_N) { const u32 b = low(e); lo = red2(lo + (sub_b ? twop - b : b)); }
-          else if (e < nrow) { const u32 A = ri[e - A32_N], B = ri[e]; hi = sub_b ? B + p - A : A + p - B; }      // +-(A - B), below 2p
-          const u32 c = low(off - 1);
-          const bool sub_c = fold_q < 0 || !(j & 1);                                  // m = 2q': - (-1)^j S_(q'-1);  m prime: - S_(m-1)
-          lo = red2(lo + (sub_c ? twop - c : c));
+          const i64 off = fold_q > 0 ? fold_q : -fold_q;
+          add(j + off, fold_q > 0);                                                   // m = 2q': - S_(j+q');  m prime: + S_(j+m)
+          add(off - 1, fold_q < 0 || !(j & 1));                                       // m = 2q': - (-1)^j S_(q'-1);  m prime: - S_(m-1)
         }
         y = mul_lazy32(lo, cinv[2 * i], p) + mul_lazy32(hi, cinv[2 * i + 1], p);    // below 4p
         y = min(y, y - twop);

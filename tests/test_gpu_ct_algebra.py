@@ -178,6 +178,58 @@ def test_wave_of_products_sum_and_key_switch(chunk, operands, monkeypatch):
     assert np.array_equal(g_out.download((3, 2, n, nl)), pool[[5, 0, 5]])
 
 
+@pytest.mark.parametrize("m,logQ,p", [(46, 128, 47), (101, 128, 23), (16381, 128, 23), (32602, 128, 32603),
+                                      (1 << 16, 200, 23)])      # power-of-two rows of 2^15: head stage in the conversion, tail in the run-time CRT kernel
+def test_wave_of_products_on_linear_convolution_rings(m, logQ, p):
+    """Sums of products per group on the rings whose products run as linear convolutions over primes below 2^30 (kernels_tensor32.hip:
+    m = 2q' and m an odd prime, padded rows of 2^14 or of 2^15 -- phi(m) = 16300 at p = 32603, the metric's size in the reference's own
+    m = p - 1 parameterisation): the same bits as the chain path (option tensor32 = 0: per-prime Bluestein rows, CModulus.cpp:90-132 +
+    bluestein.cpp:93-144) on every group, and as the oracle composed the way Matrix.cpp does where that takes seconds."""
+    primes, roots = P.chain_for(m, logQ, p, 8)             # SetUpSIContext(xi = 8): the chain leaves room for sums of 8 products (FHEContext.cpp:83-85)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    if m > 2000:
+        orc.set_bluestein_fft(True)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(m)
+    npool = 5
+    pool = P.rand_limbs(rng, (npool, 2, n), nl, logQ)
+    lo, hi = -(1 << (logQ - 1)), (1 << (logQ - 1)) - 1
+    pool[4, 0] = O.ints_to_limbs([lo if v else hi for v in rng.integers(0, 2, n)], nl)      # the extremes of the centred range everywhere
+    pool[4, 1] = O.ints_to_limbs([lo] * n, nl)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    groups = [[(0, 1), (2, 3)], [(4, 4), (4, 4), (4, 4), (4, 4)], [(1, 1), (3, 0), (2, 4)]]
+    a_idx = [x for g in groups for x, _ in g]
+    b_idx = [y for g in groups for _, y in g]
+    seg = np.cumsum([0] + [len(g) for g in groups])
+    dpool = ctx.upload(pool)
+    outs = []
+    for t32 in (1, 0):
+        ctx.set_option("tensor32", t32)
+        ctx.set_option("wave_single", 0)
+        out = ctx.alloc(len(groups) * 2 * n * nl * 8)
+        ctx.prof_enable(True)
+        ctx.ct_mul_sum_relin_dev(ksk, logQ, p, dpool, nl, a_idx, b_idx, seg, out)
+        if t32:
+            assert "tensor_sum32" in ctx.prof_kernel_name("tensor"), ctx.prof_kernel_name("tensor")
+        ctx.prof_enable(False)
+        outs.append(out.download((len(groups), 2, n, nl)))
+    ctx.set_option("tensor32", 1)
+    assert np.array_equal(outs[0], outs[1])
+    for gi in ((0,) if m > 20000 else range(len(groups))):
+        tp = None
+        for x, y in groups[gi]:
+            t = orc.ct_mul(pool[x], pool[y], p)
+            if tp is None:
+                tp = t
+            else:
+                for comp in range(3):
+                    for i, q in enumerate(primes):
+                        tp[comp][i] = (tp[comp][i] + t[comp][i]) % np.uint64(q)
+        assert np.array_equal(outs[0][gi], orc.apply_key_switch(ksm, tp, logQ, nl)), gi
+
+
 @pytest.mark.parametrize("m,logQ,p", [(1024, 128, 23), (32768, 512, 23), (46, 90, 47)])
 def test_wave_of_single_products_takes_the_batch_pipeline(m, logQ, p):
     """A wave whose groups are single products (the recorded loop `c *= d; ApplyKeySwitch(c)` of the host mirror) runs through the batch
