@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
     "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
     "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
-    "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
+    "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_ctx_copy_options", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
     "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_comm_init_all", "fhesi_comm_from_rccl", "fhesi_comm_destroy", "fhesi_comm_rank",
     "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
@@ -140,6 +140,7 @@ def _load():
         "fhesi_prof_kernel_name": [_vp, _i32, _vp, C.c_size_t],
         "fhesi_ctx_set_option": [_vp, C.c_char_p, _i64],
         "fhesi_ctx_get_option": [_vp, C.c_char_p, _vp],
+        "fhesi_ctx_copy_options": [_vp, _vp],
         "fhesi_ksk_mark_dirty": [_vp],
         "fhesi_comm_init_all": [_i32, _vp, _vp],
         "fhesi_comm_from_rccl": [_vp, _vp],
@@ -161,7 +162,7 @@ def _load():
         "fhesi_ksk_upload_dev": [_vp, _vp],
         "fhesi_ksk_form": [_vp, _vp, _vp, _vp],
         "fhesi_encrypt_batch_seeded": [_vp, _vp, _vp, _i32, _u64, _u64, _u64, _vp, _i64, _vp, _i32],
-        "fhesi_keyswitch_init_batch_seeded": [_vp, _vp, _i32, _vp, _i32, _i32, _u64, _u64],
+        "fhesi_keyswitch_init_batch_seeded": [_vp, _vp, _i32, _vp, _i32, _i32, _u64, _u64, _u64],
         "fhesi_dcrt_sample": [_vp, _i32, _i64, _u64, _u64],
         "fhesi_ct_add_const_dev": [_vp, _i32, _u64, _vp, _i32, _i32, _i64, _vp, _i32],
         "fhesi_ct_mul_poly_dev": [_vp, _i32, _vp, _i32, _i32, _i64, _vp, _i32],
@@ -702,10 +703,13 @@ class KeySwitchMatrix:
         _ck(_load().fhesi_keyswitch_init_batch(self.h, hs, len(src), dst_t.h, logQ, decomp_bytes, _p(a), a.shape[-1], _p(err)))
         return self
 
-    def init_batch_seeded(self, src, dst_t: "DoubleCRT", logQ: int, seed: int, first_index: int = 0, decomp_bytes: int = 3):
-        """KeySwitchSI::Init with the column randomness drawn on the device from (seed, first_index + column) -- philox.h."""
+    def init_batch_seeded(self, src, dst_t: "DoubleCRT", logQ: int, seed: int, public_seed: int, first_index: int, decomp_bytes: int = 3):
+        """KeySwitchSI::Init with the column randomness drawn on the device -- philox.h: the public polynomials a from (public_seed, first_index +
+        column), the secret errors from (seed, first_index + column).  No default index: an (seed, index) pair must never be used twice."""
+        if public_seed == seed:
+            raise ValueError("public_seed must differ from the secret seed")
         hs = (_vp * len(src))(*[d.h for d in src])
-        _ck(_load().fhesi_keyswitch_init_batch_seeded(self.h, hs, len(src), dst_t.h, logQ, decomp_bytes, seed, first_index))
+        _ck(_load().fhesi_keyswitch_init_batch_seeded(self.h, hs, len(src), dst_t.h, logQ, decomp_bytes, seed, public_seed, first_index))
         return self
 
     FORMS = {-1: "none yet", 0: "per chain prime", 1: "four 30-bit auxiliary primes, limbs", 2: "two largest chain primes, limbs", 3: "two largest chain primes, residues"}

@@ -176,7 +176,7 @@ extern "C" int fhesi_decrypt_batch(fhesi_ctx* c, const fhesi_dcrt* sk1, int32_t 
 
 // KeySwitchSI::Init (FHE-SI.cpp:153-209) for all columns of a matrix at once; the randomness is the caller's, in the reference's draw order
 static int keyswitch_init_impl(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
-                               const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host, bool seeded, u64 seed, u64 first) {
+                               const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host, bool seeded, u64 seed, u64 pub_seed, u64 first) {
   if (!k) FHESI_FAIL("null key-switch matrix");
   fhesi_ctx* c = k->ctx;
   CHECK_CTX(c);
@@ -207,7 +207,7 @@ static int keyswitch_init_impl(fhesi_ksk* k, const fhesi_dcrt* const* src, int32
   FHESI_TRY(row_inv(c, (u64*)d_s, nsrc, L, nullptr, all.data()));
   FHESI_TRY(launch_crt(c, t, (const u64*)d_s, L, nullptr, nsrc, 0, 0, 0, (u64*)d_scoef, W));
   // A[ind] = DoubleCRT(poly)   (:176-179)
-  if (seeded) FHESI_TRY(launch_sample_keygen(c, (u64*)d_in, (i64*)d_err, ncol, nlimbs, logQ, seed, first));      // polynomials and errors drawn in HBM
+  if (seeded) FHESI_TRY(launch_sample_keygen(c, (u64*)d_in, (i64*)d_err, ncol, nlimbs, logQ, seed, pub_seed, first));      // polynomials and errors drawn in HBM
   else {
     HIP_TRY(hipMemcpyAsync(d_in, a_host, (size_t)ncol * n * nlimbs * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_err, err_host, (size_t)ncol * n * 8, hipMemcpyHostToDevice, c->stream));
@@ -232,12 +232,14 @@ static int keyswitch_init_impl(fhesi_ksk* k, const fhesi_dcrt* const* src, int32
 extern "C" int fhesi_keyswitch_init_batch(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
                                           const uint64_t* a_host, int32_t nlimbs, const int64_t* err_host) {
   if (!a_host || !err_host) FHESI_FAIL("KeySwitchSI::Init: null randomness (fhesi_keyswitch_init_batch_seeded draws it on the device)");
-  return keyswitch_init_impl(k, src, nsrc, dst_t, logQ, decomp_bytes, a_host, nlimbs, err_host, false, 0, 0);
+  return keyswitch_init_impl(k, src, nsrc, dst_t, logQ, decomp_bytes, a_host, nlimbs, err_host, false, 0, 0, 0);
 }
-// ... with the column randomness drawn on the device: column i takes the streams of object index first_index + i (philox.h)
+// ... with the column randomness drawn on the device: column i takes the streams of object index first_index + i (philox.h); the public
+// polynomials a draw from public_seed, the secret errors from seed
 extern "C" int fhesi_keyswitch_init_batch_seeded(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
-                                                 uint64_t seed, uint64_t first_index) {
-  return keyswitch_init_impl(k, src, nsrc, dst_t, logQ, decomp_bytes, nullptr, (logQ + 63) / 64, nullptr, true, seed, first_index);
+                                                 uint64_t seed, uint64_t public_seed, uint64_t first_index) {
+  if (public_seed == seed) FHESI_FAIL("KeySwitchSI::Init (seeded): public_seed must differ from the secret seed (the polynomials a are public, the errors are not)");
+  return keyswitch_init_impl(k, src, nsrc, dst_t, logQ, decomp_bytes, nullptr, (logQ + 63) / 64, nullptr, true, seed, public_seed, first_index);
 }
 // DoubleCRT::sampleHWt / sampleGaussian (DoubleCRT.h; NumbTh.cpp:340-404) with the polynomial drawn on the device: kind 0 = Hamming weight
 // `param` with +-1 entries (the secret key, FHE-SI.cpp:90), kind 1 = rounded Gaussian with the context's stdev 3.2 (FHEContext.h:106)

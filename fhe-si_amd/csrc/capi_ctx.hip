@@ -99,6 +99,11 @@ extern "C" int fhesi_ctx_get_option(const fhesi_ctx* c, const char* name, int64_
   for (const OptDesc& d : kOptions)
     if (!strcmp(d.name, name)) { *value = opt_load(&c->opt, d); return 0; }
   FHESI_FAIL("get_option: unknown option '%s'", name);
+}
+extern "C" int fhesi_ctx_copy_options(fhesi_ctx* dst, const fhesi_ctx* src) {
+  if (!dst || !src) FHESI_FAIL("copy_options: null argument");
+  dst->opt = src->opt;
+  return 0;
 }   // set by bluestein_init: its convolution context needs sizes up to 4m
 
 extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, const uint64_t* q, const uint64_t* root, int32_t device) {

@@ -476,11 +476,22 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
     if (rc) {
       // a workspace allocation failed (a device with less free memory than the estimate assumed): the chunk is redone at half the size --
       // every stage of a chunk writes only workspace and its own slice of `out`, so nothing of the failed attempt survives
-      if (c->ws_oom && cnt > 1) { chunk = (cnt + 1) / 2; continue; }
+      // The grow-only slots that already grew for the oversized attempt are released first: left in place they would compete with the smaller
+      // attempt for the same memory and the halving could run down to one ciphertext on a device that fits a mid-sized chunk.
+      if (c->ws_oom && cnt > 1) {
+        hipStreamSynchronize(c->stream);
+        for (int slot : {0, 1, 2, 5, 10}) if (c->ws[slot]) { hipFree(c->ws[slot]); c->ws[slot] = nullptr; c->ws_bytes[slot] = 0; }
+        (void)hipGetLastError();
+        fhesi_set_error("%s", "");
+        chunk = (cnt + 1) / 2;
+        continue;
+      }
+      c->ws_oom = false;
       return rc;
     }
     done += cnt;
   }
+  c->ws_oom = false;
   return 0;
 }
 static void swap_lane(fhesi_ctx* c) {

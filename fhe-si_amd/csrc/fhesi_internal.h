@@ -286,7 +286,7 @@ int launch_ct_add(fhesi_ctx* ctx, u64* d_dst, const u64* d_src, i64 ncoeffs, int
 int launch_ct_mul_long(fhesi_ctx* ctx, u64* d_ct, i64 ncoeffs, int nl, int logQ, i64 l);
 // kernels_sample.hip: counter-based randomness (philox.h) for Encrypt / key generation, drawn on the device
 int launch_sample_encrypt(fhesi_ctx* ctx, i64* d_rnd /* [count][3][n] */, i64 count, u64 seed, u64 first);
-int launch_sample_keygen(fhesi_ctx* ctx, u64* d_a /* [ncol][n][nl] */, i64* d_err /* [ncol][n] */, i64 ncol, int nl, int logQ, u64 seed, u64 first);
+int launch_sample_keygen(fhesi_ctx* ctx, u64* d_a, i64* d_err, i64 ncol, int nl, int logQ, u64 seed, u64 pub_seed, u64 first);
 int launch_sample_poly(fhesi_ctx* ctx, i64* d_poly /* [n] */, int kind /* 0 sampleHWt(param), 1 sampleGaussian */, i64 param, u64 seed, u64 obj);
 int launch_ct_add_const(fhesi_ctx* ctx, u64* d_ct /* [count][nparts][n][nl] */, const i64* d_poly /* [npoly][n] */, int npoly, int nparts, int nl, int logQ, u64 p, i64 count);
 int launch_ct_automorph_parts(fhesi_ctx* ctx, const u64* d_in /* [npolys][n][nl_in] */, int nl_in, i64 npolys, i64 kk, int logQ, u64* d_parts /* [npolys][nlq][n] */, int nlq);   // 2: ring not covered

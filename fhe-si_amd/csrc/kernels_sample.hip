@@ -17,8 +17,10 @@ __global__ void __launch_bounds__(256) sample_encrypt_kernel(i64* __restrict__ r
   o[n] = phx_gaussian(phx_draw(seed, obj, (u32)j, PHX_NOISE0, 0));
   o[2 * n] = phx_gaussian(phx_draw(seed, obj, (u32)j, PHX_NOISE1, 0));
 }
-// a [ncol][n][nl]: SampleRandom(poly, 2^logQ, n) as two's complement limbs;  err [ncol][n]: sampleGaussian -- of column `first + col`
-__global__ void __launch_bounds__(256) sample_keygen_kernel(u64* __restrict__ a, i64* __restrict__ err, i64 n, int nl, int logQ, u64 seed, u64 first) {
+// a [ncol][n][nl]: SampleRandom(poly, 2^logQ, n) as two's complement limbs;  err [ncol][n]: sampleGaussian -- of column `first + col`.
+// The polynomial a is PUBLIC (it is the matrix's second row up to sign) and draws from `pub_seed`; the error is secret and draws from `seed`:
+// a published pub_seed (keys compressed to a seed) says nothing about the errors.
+__global__ void __launch_bounds__(256) sample_keygen_kernel(u64* __restrict__ a, i64* __restrict__ err, i64 n, int nl, int logQ, u64 seed, u64 pub_seed, u64 first) {
   const i64 col = blockIdx.y;
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -29,7 +31,7 @@ __global__ void __launch_bounds__(256) sample_keygen_kernel(u64* __restrict__ a,
   for (int i = 0; i < nl; ++i) {
     u64 v = 0;
     if (i <= top) {
-      const Philox4 d = phx_draw(seed, obj, (u32)j, PHX_KEY_POLY, (u32)(i >> 1));
+      const Philox4 d = phx_draw(pub_seed, obj, (u32)j, PHX_KEY_POLY, (u32)(i >> 1));
       v = (u64)d.w[2 * (i & 1)] | (u64)d.w[2 * (i & 1) + 1] << 32;
       if (i == top) {
         if (tb < 63) v &= (2ull << tb) - 1;                    // logQ random bits in all
@@ -42,10 +44,9 @@ __global__ void __launch_bounds__(256) sample_keygen_kernel(u64* __restrict__ a,
   }
   err[col * n + j] = phx_gaussian(phx_draw(seed, obj, (u32)j, PHX_KEY_ERR, 0));
 }
-// poly [n]: sampleHWt (NumbTh.cpp:340-360) -- a sequential rejection loop of Hwt <= 64 accepted draws: one thread
+// poly [n] (zeroed by the launcher): sampleHWt (NumbTh.cpp:340-360) -- a sequential rejection loop of Hwt accepted draws: one thread
 __global__ void sample_hwt_kernel(i64* __restrict__ poly, i64 n, i64 hwt, u64 seed, u64 obj) {
   if (blockIdx.x || threadIdx.x) return;
-  for (i64 j = 0; j < n; ++j) poly[j] = 0;
   if (hwt > n) hwt = n;
   u32 t = 0;
   for (i64 i = 0; i < hwt; ++t) {
@@ -59,22 +60,31 @@ __global__ void __launch_bounds__(256) sample_gaussian_kernel(i64* __restrict__ 
   if (j < n) poly[j] = phx_gaussian(phx_draw(seed, obj, (u32)j, PHX_GAUSS, 0));
 }
 
+// (the object index sits in gridDim.y: launches of at most 65535 objects, the index and the pointers advanced per launch)
 int launch_sample_encrypt(fhesi_ctx* ctx, i64* d_rnd, i64 count, u64 seed, u64 first) {
-  if (!count) return 0;
-  if (count > 65535) FHESI_FAIL("Encrypt: more than 65535 plaintexts per seeded call");
-  sample_encrypt_kernel<<<dim3((unsigned)((ctx->phim + 255) / 256), (unsigned)count), 256, 0, ctx->stream>>>(d_rnd, ctx->phim, seed, first);
-  HIP_TRY(hipGetLastError());
+  const i64 n = ctx->phim;
+  for (i64 done = 0; done < count; done += 65535) {
+    const i64 cnt = std::min<i64>(65535, count - done);
+    sample_encrypt_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)cnt), 256, 0, ctx->stream>>>(d_rnd + done * 3 * n, n, seed, first + (u64)done);
+    HIP_TRY(hipGetLastError());
+  }
   return 0;
 }
-int launch_sample_keygen(fhesi_ctx* ctx, u64* d_a, i64* d_err, i64 ncol, int nl, int logQ, u64 seed, u64 first) {
-  if (!ncol) return 0;
-  if (ncol > 65535) FHESI_FAIL("KeySwitchSI::Init: more than 65535 columns");
-  sample_keygen_kernel<<<dim3((unsigned)((ctx->phim + 255) / 256), (unsigned)ncol), 256, 0, ctx->stream>>>(d_a, d_err, ctx->phim, nl, logQ, seed, first);
-  HIP_TRY(hipGetLastError());
+int launch_sample_keygen(fhesi_ctx* ctx, u64* d_a, i64* d_err, i64 ncol, int nl, int logQ, u64 seed, u64 pub_seed, u64 first) {
+  const i64 n = ctx->phim;
+  for (i64 done = 0; done < ncol; done += 65535) {
+    const i64 cnt = std::min<i64>(65535, ncol - done);
+    sample_keygen_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)cnt), 256, 0, ctx->stream>>>(d_a + done * n * nl, d_err + done * n, n, nl, logQ, seed, pub_seed, first + (u64)done);
+    HIP_TRY(hipGetLastError());
+  }
   return 0;
 }
 int launch_sample_poly(fhesi_ctx* ctx, i64* d_poly, int kind, i64 param, u64 seed, u64 obj) {
-  if (kind == 0) sample_hwt_kernel<<<1, 1, 0, ctx->stream>>>(d_poly, ctx->phim, param, seed, obj);
+  if (kind == 0) {
+    if (param < 0) FHESI_FAIL("sampleHWt: negative Hamming weight");
+    HIP_TRY(hipMemsetAsync(d_poly, 0, (size_t)ctx->phim * 8, ctx->stream));
+    sample_hwt_kernel<<<1, 1, 0, ctx->stream>>>(d_poly, ctx->phim, param, seed, obj);
+  }
   else if (kind == 1) sample_gaussian_kernel<<<(unsigned)((ctx->phim + 255) / 256), 256, 0, ctx->stream>>>(d_poly, ctx->phim, seed, obj);
   else FHESI_FAIL("sample: unknown kind %d", kind);
   HIP_TRY(hipGetLastError());

@@ -16,6 +16,12 @@
 //               0, 1, ... (limb i = words 2 (i mod 2), 2 (i mod 2) + 1 of block i / 2), minus 2^(logQ-1)
 //   sampleHWt   draw t = 0, 1, ...: position (word0 | word1 << 32) mod n, value +1 if word 2 bit 0 else -1, kept when the position is
 //               still zero, until Hwt positions are set (NumbTh.cpp:340-360)
+//
+// NOT a cryptographic generator: Philox-4x32-10 has a 64-bit key and no security claim.  It is here because its k-th number is a pure function
+// of (key, counter) that three independent implementations can agree on bit for bit -- fixtures, parity tests, multi-GPU runs that must
+// produce one key on every rank.  Rules for callers (include/fhesi_hip.h): the seed is secret uniform 64 bits, an (seed, object index) pair is
+// never used twice, and the one PUBLIC stream (purpose 3, the polynomial a of a key-switch column) is keyed by a separate public seed so that
+// publishing it says nothing about the secret streams.  Key material with a stronger requirement uses the explicit-randomness entry points.
 #pragma once
 #include <stdint.h>
 

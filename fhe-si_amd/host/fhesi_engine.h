@@ -285,6 +285,7 @@ class CtEngine : public std::enable_shared_from_this<CtEngine> {
 
  private:
   void run_level(const std::vector<CtValue*>& vs) {
+    for (size_t r = 0; r < peers.size(); ++r) ck(fhesi_ctx_copy_options(peers[r].h, h));      // options changed on the primary context since the group was made apply to every rank
     const int32_t logQ = (int32_t)context.logQ, decomp = (int32_t)context.decompSize; const uint64_t p = (uint64_t)context.ModulusP().to_long();
     std::map<DeviceKey*, std::vector<CtValue*>> sums;
     std::map<std::pair<DeviceKey*, long>, std::vector<CtValue*>> autoKs;

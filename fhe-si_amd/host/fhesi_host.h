@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <set>
+#include <atomic>
 #include <vector>
 
 #include "../../include/fhesi_hip.h"
@@ -269,6 +270,7 @@ class FHEcontext {
     for (auto& c : moduli) { q.push_back((uint64_t)c.getQ()); r.push_back((uint64_t)c.getRoot()); }
     fhesi_ctx* h = nullptr;
     ck(fhesi_ctx_create(&h, m_, (int32_t)q.size(), q.data(), r.data(), dev_index));
+    ck(fhesi_ctx_copy_options(h, handle()));            // the replica runs the forms selected on this context (checker and A/B switches included)
     return h;
   }
   int deviceIndex() const { return device; }
@@ -891,6 +893,19 @@ class FHESISecKey {
     for (long i = 0; i <= deg(z); ++i) { ZZ c = z.rep[i]; c *= ZZ(2L) * p; c += q; c /= q2; ptxt.message[i] = rem(c, p.to_long()); }
   }
 };
+// One stream of on-device randomness (csrc/philox.h): the secret seed, the public seed of the key polynomials, and ONE monotonically
+// increasing object counter shared by every Encrypt and every KeySwitchSI that draws from it -- callers never pick indices, so a pair
+// (seed, index) cannot be handed out twice.  Both seeds must be uniformly random and the secret one stays secret; Philox is not a CSPRNG
+// (64-bit key): see include/fhesi_hip.h for what that is good for.
+struct SeedSequence {
+  const uint64_t seed, public_seed;
+  SeedSequence(uint64_t secret, uint64_t pub, uint64_t first = 0) : seed(secret), public_seed(pub), next(first) { if (secret == pub) Error("SeedSequence: the public seed must differ from the secret seed"); }
+  uint64_t take(uint64_t count) { return next.fetch_add(count); }      // first index of a fresh range of `count` objects
+  uint64_t used() const { return next.load(); }
+ private:
+  std::atomic<uint64_t> next;
+};
+
 class FHESIPubKey {
   const FHEcontext& context;
   std::vector<DoubleCRT> publicKey;
@@ -938,7 +953,9 @@ class FHESIPubKey {
   }
   // ... with r and the noise drawn ON THE DEVICE from the counter-based generator (fhesi_encrypt_batch_seeded, csrc/philox.h): plaintext i
   // uses the streams of object index first + i, so a batch can be split or repeated anywhere and give the same ciphertexts
-  void EncryptBatchSeeded(std::vector<Ciphertext>& ctxts, const std::vector<Plaintext>& ptxts, uint64_t seed, uint64_t first_obj = 0) const {
+  // (no default index: an (seed, index) pair used twice repeats r, e0, e1 -- the difference of the two ciphertexts is delta (m1 - m2) in the clear)
+  void EncryptBatchSeeded(std::vector<Ciphertext>& ctxts, const std::vector<Plaintext>& ptxts, SeedSequence& seq) const { EncryptBatchSeeded(ctxts, ptxts, seq.seed, seq.take(ptxts.size())); }
+  void EncryptBatchSeeded(std::vector<Ciphertext>& ctxts, const std::vector<Plaintext>& ptxts, uint64_t seed, uint64_t first_obj) const {
     const long n = context.zMstar.phiM(), count = (long)ptxts.size(); const int nl = (int)((context.logQ + 63) / 64);
     std::vector<int64_t> msg((size_t)count * n, 0);
     for (long c = 0; c < count; ++c) for (size_t k = 0; k < ptxts[c].message.size() && (long)k < n; ++k) msg[c * n + k] = ptxts[c].message[k];
@@ -1023,8 +1040,10 @@ class KeySwitchSI {
       }
     devKey = std::make_shared<DeviceKey>(k, (int)n, (int)context.ndigits);   // the device object the matrix was generated in serves the fused calls as it is
   }
-  // the same matrix with the column randomness drawn on the device (fhesi_keyswitch_init_batch_seeded): column c <-> object index first + c
-  struct Seeded { uint64_t seed, first; };
+  // the same matrix with the column randomness drawn on the device (fhesi_keyswitch_init_batch_seeded): column c <-> object index first + c;
+  // the public polynomials a from public_seed, the secret errors from seed.  KeySwitchSI(sk, seq) takes its index range from a SeedSequence.
+  struct Seeded { uint64_t seed, public_seed, first; };
+  KeySwitchSI(const FHESISecKey& s, SeedSequence& seq) : KeySwitchSI(s, Seeded{seq.seed, seq.public_seed, seq.take((uint64_t)(s.GetContext().ndigits * (s.GetRepresentation().size() * 2 - 1)))}) {}
   KeySwitchSI(const FHESISecKey& s, Seeded sd) : context(s.GetContext()) {
     std::vector<DoubleCRT> sKeys = s.GetRepresentation(), tKeys(sKeys.size() * 2 - 1, sKeys[1]);
     tKeys[0] = sKeys[0];
@@ -1036,7 +1055,7 @@ class KeySwitchSI {
     fhesi_ksk* k = nullptr;
     ck(fhesi_ksk_create(context.handle(), (int32_t)n, (int32_t)context.ndigits, &k));
     std::vector<const fhesi_dcrt*> hs; for (auto& d : s) hs.push_back(d.handle());
-    int rc = fhesi_keyswitch_init_batch_seeded(k, hs.data(), (int32_t)n, dst.GetRepresentation()[1].handle(), (int32_t)context.logQ, (int32_t)context.decompSize, sd.seed, sd.first);
+    int rc = fhesi_keyswitch_init_batch_seeded(k, hs.data(), (int32_t)n, dst.GetRepresentation()[1].handle(), (int32_t)context.logQ, (int32_t)context.decompSize, sd.seed, sd.public_seed, sd.first);
     if (rc) { fhesi_ksk_free(k); ck(rc); }
     const uint64_t* rows = (const uint64_t*)fhesi_ksk_device_ptr(k); const size_t rowWords = (size_t)L * phim;
     keySwitchMatrix.assign(2, std::vector<DoubleCRT>());

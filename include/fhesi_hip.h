@@ -62,6 +62,7 @@ void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t a
  * fhesi_ctx_destroy fails while DoubleCRT / key-switch handles of the context are alive (they hold the reference's `const FHEcontext&`). */
 int fhesi_ctx_set_option(fhesi_ctx* ctx, const char* name, int64_t value);
 int fhesi_ctx_get_option(const fhesi_ctx* ctx, const char* name, int64_t* value);
+int fhesi_ctx_copy_options(fhesi_ctx* dst, const fhesi_ctx* src);      /* every switch of src onto dst: the per-GPU replicas of one FHEcontext run the same forms */
 /* HIP-event stopwatch on the context's stream (bench.py's per-kernel timing) */
 int fhesi_timer_start(fhesi_ctx* ctx);
 int fhesi_timer_stop(fhesi_ctx* ctx, float* elapsed_ms);
@@ -233,11 +234,20 @@ int fhesi_ksk_download(const fhesi_ksk* k, uint64_t* rows_host);                
  * sequential PRNG cannot be reproduced outside NTL, so these entry points use a counter-based generator instead -- Philox-4x32-10 keyed by
  * `seed`, counter = (coefficient, object index, purpose); definition in fhe-si_amd/csrc/philox.h, restated by the oracle and the Python
  * model -- which makes a ciphertext or a key a function of (seed, index) alone: the same on every GPU, in any batch split, and on the CPU.
- * The explicit-randomness forms above remain for callers that bring their own randomness (and for reproducing fixtures). */
+ * The explicit-randomness forms above remain for callers that bring their own randomness (and for reproducing fixtures).
+ *
+ * WHAT THE CALLER OWES THESE ENTRY POINTS.  (1) Philox is a reproducible counter-based generator with a 64-bit key, NOT a CSPRNG: use it for
+ * fixtures, tests and deployments whose threat model accepts that; key material that must withstand more takes the explicit-randomness
+ * entry points with randomness from the caller's CSPRNG.  `seed` must in any case be secret, uniformly random 64 bits.  (2) An
+ * (seed, object index) pair must never be used twice: two encryptions under the same pair share r, e0, e1, so their difference is
+ * delta * (m1 - m2) in the clear; two key-switch columns under the same pair share a and the error.  There is no default index -- every call
+ * names the first index of a range nobody else uses (the C++ mirror's SeedSequence hands out disjoint ranges from one counter shared by
+ * Encrypt and every KeySwitchSI).  (3) The polynomials `a` of a key-switch matrix are public; they draw from `public_seed`, the errors from
+ * `seed`: publishing public_seed (a matrix shipped as its seed) discloses nothing secret.  public_seed != seed. */
 int fhesi_encrypt_batch_seeded(fhesi_ctx* ctx, const fhesi_dcrt* pk0, const fhesi_dcrt* pk1, int32_t logQ, uint64_t p, uint64_t seed, uint64_t first_index,
                                const int64_t* msg_host, int64_t count, uint64_t* out_dev, int32_t nlimbs);      /* plaintext i <-> object index first_index + i */
 int fhesi_keyswitch_init_batch_seeded(fhesi_ksk* k, const fhesi_dcrt* const* src, int32_t nsrc, const fhesi_dcrt* dst_t, int32_t logQ, int32_t decomp_bytes,
-                                      uint64_t seed, uint64_t first_index);                                      /* column c <-> object index first_index + c */
+                                      uint64_t seed, uint64_t public_seed, uint64_t first_index);                /* column c <-> object index first_index + c; a from public_seed, errors from seed */
 int fhesi_dcrt_sample(fhesi_dcrt* d, int32_t kind, int64_t param, uint64_t seed, uint64_t index);               /* DoubleCRT::sampleHWt(param) (kind 0), ::sampleGaussian() with
                                                                                                                     stdev 3.2 (kind 1): DoubleCRT.h:340-345 */
 

@@ -24,6 +24,7 @@ int64_t fhesi_ctx_phim(const fhesi_ctx* c) { return c->phim; }
 int fhesi_ctx_zms_idx(const fhesi_ctx* c, int32_t* out) { int k = 0; for (int64_t i = 0; i < c->m; ++i) { int64_t a = i, b = c->m; while (b) { int64_t t = a % b; a = b; b = t; } out[i] = a == 1 ? k++ : -1; } return 0; }
 int fhesi_ctx_phi_m(const fhesi_ctx* c, int64_t* out) { for (int64_t i = 0; i <= c->phim; ++i) out[i] = 0; out[0] = 1; out[c->phim] = 1; return 0; }   // (X^phi + 1: exact for powers of two, enough here)
 int fhesi_ctx_sync(fhesi_ctx*) { return 0; }
+int fhesi_ctx_copy_options(fhesi_ctx*, const fhesi_ctx*) { return 0; }
 int fhesi_dev_alloc(fhesi_ctx* c, size_t bytes, void** out) { *out = std::malloc(bytes ? bytes : 1); ++c->live_allocs; return *out ? 0 : 1; }
 int fhesi_dev_free(fhesi_ctx* c, void* p) { std::free(p); --c->live_allocs; return 0; }
 int fhesi_dev_upload(fhesi_ctx*, void* d, const void* s, size_t n) { std::memcpy(d, s, n); return 0; }

@@ -128,7 +128,9 @@ int main(int argc, char* argv[]) {
     if (all[0][0] == all[2][0]) { std::cout << "seeded encryptions of one message under different indices coincide" << std::endl; ++failures; }
     std::vector<Plaintext> dec; sk2.DecryptBatch(dec, all);
     if (dec.size() != 3 || dec[0].message != m1 || dec[1].message != m2 || dec[2].message != m1) { std::cout << "seeded encryptions do not decrypt" << std::endl; ++failures; }
-    KeySwitchSI kseed(sk2, KeySwitchSI::Seeded{4711, 0});
+    SeedSequence seq(4711, 815, 1000);                      // one counter for every object drawn from this stream
+    KeySwitchSI kseed(sk2, seq);
+    if (seq.used() != 1000 + 3 * ctx2->ndigits) { std::cout << "SeedSequence did not advance by the matrix's columns" << std::endl; ++failures; }
     Ciphertext pr = all[0]; pr *= all[1]; kseed.ApplyKeySwitch(pr);
     Plaintext r; sk2.Decrypt(r, pr);
     if (r.message != mul_mod_phi(m1, m2, *ctx2, (long)p)) { std::cout << "seeded key-switch matrix does not relinearise" << std::endl; ++failures; }

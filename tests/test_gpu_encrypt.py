@@ -187,14 +187,17 @@ def test_seeded_encrypt_keygen_and_samplers_vs_oracle(m, logQ, p):
     one_rows = orc.dcrt_from_poly(O.ints_to_limbs([1] + [0] * (n - 1), W))
     src_rows = [one_rows, t_rows, orc.dcrt_op(t_rows, t_rows, 2)]
     src = [dcrt_from_rows(ctx, r) for r in src_rows]
-    ksk = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded(src, src[1], logQ, seed, 1000)
+    pub_seed = seed ^ 0x5DEECE66D
+    with pytest.raises(ValueError):
+        F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded(src, src[1], logQ, seed, seed, 1000)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded(src, src[1], logQ, seed, pub_seed, 1000)
     kgot = ksk.download()
     ncol = 3 * nd
     cols = (0, 1, ncol - 1) if n > 8192 else range(ncol)
     a = np.zeros((ncol, n, nl), dtype=np.uint64)
     err = np.zeros((ncol, n), dtype=np.int64)
     for col in range(ncol):
-        a[col], err[col] = orc.draw_keygen(seed, 1000 + col, nl, logQ)
+        a[col], err[col] = orc.draw_keygen(pub_seed, 1000 + col, nl, logQ)[0], orc.draw_keygen(seed, 1000 + col, nl, logQ)[1]      # public a, secret error
     if n <= 8192:
         want = orc.keyswitch_init(np.stack(src_rows), t_rows, logQ, a, err)
         assert np.array_equal(kgot[1], want[1]) and np.array_equal(kgot[0], want[0])

@@ -5,6 +5,9 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 K=$1; TAG=$2; shift 2
 PROG=$(realpath "$1"); shift
+# the profiler's preloaded library initialises the GPU before the program starts: anything that execs another program behind `--` (a script
+# with an interpreter line, a launcher) is the forbidden exec-after-GPU-init -- only ELF binaries are profiled here
+if [ "$(head -c 4 "$PROG" | od -An -c | tr -d ' ')" != '177ELF' ]; then echo "pmc_sq_bin.sh: $PROG is not an ELF binary (scripts and launchers are refused)"; exit 2; fi
 O=$R/gpurun_out/pmc_sq_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
@@ -12,6 +15,8 @@ i=0
 for grp in "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
   timeout 180 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$O/g$i" -o pmc -- "$PROG" "$@" > "$O/g$i.out" 2> "$O/g$i.log"
+  rc=$?
+  if [ $rc -eq 124 ]; then echo "pass $i ($grp): TIMED OUT after 180 s" | tee -a "$O/summary.txt"; elif [ $rc -ne 0 ]; then echo "pass $i ($grp): exit code $rc" | tee -a "$O/summary.txt"; fi
   python3 - "$O/g$i" "$K" <<'PY' | tee -a "$O/summary.txt"
 import csv, glob, sys, collections
 d, k = sys.argv[1], sys.argv[2]

@@ -1,7 +1,9 @@
 #!/bin/bash
 # SQ counters of SEVERAL kernels of the metric step from ONE set of --pmc passes (run ON THE GPU BOX through gpurun):
 #   tools/pmc_sq_multi.sh "<kernel substring>" "<kernel substring>" ...
-# Four counter groups, one rocprofv3 pass each (never combined with other trace domains); per kernel: per-launch averages, the kernel's
+# Four groups of four SQ counters, one rocprofv3 pass each, every pass with --kernel-trace for the durations (--pmc is never combined with
+# -s/-r or the hip/hsa/memory-copy trace domains, which gpurun refuses; tools/profile_round.sh takes ONE counter per pass -- the slower,
+# safer form -- when a group of four does not come back).  A pass that times out or fails is reported as such in summary.txt.  Per kernel: per-launch averages, the kernel's
 # duration under the pass, the effective shader clock (GRBM_GUI_ACTIVE / 8 XCDs / duration) and
 # VALU busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8).  Output: gpurun_out/pmc_sq_multi/summary.txt
 set -u
@@ -13,8 +15,10 @@ i=0
 for grp in "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
   timeout 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$O/g$i" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --batch 1024 --no-surface --gpu-seconds 0 > /dev/null 2> "$O/g$i.log"
+  rc=$?
+  if [ $rc -eq 124 ]; then echo "pass $i ($grp): TIMED OUT after 240 s" | tee -a "$O/failed_passes.txt"; elif [ $rc -ne 0 ]; then echo "pass $i ($grp): rocprofv3 exit code $rc" | tee -a "$O/failed_passes.txt"; fi
 done
-python3 - "$O" "$@" <<'PY' | tee "$O/summary.txt"
+{ [ -f "$O/failed_passes.txt" ] && cat "$O/failed_passes.txt"; python3 - "$O" "$@" <<'PY'
 import csv, glob, sys, collections
 O, kernels = sys.argv[1], sys.argv[2:]
 for k in kernels:
@@ -42,4 +46,5 @@ for k in kernels:
     if "SQ_ACTIVE_INST_VALU" in tot and "GRBM_GUI_ACTIVE" in tot:
         print(f"  VALU busy = {tot['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / (tot['GRBM_GUI_ACTIVE'] / 8):.3f};  VALU instructions per wave = {tot.get('SQ_INSTS_VALU', 0) / max(tot.get('SQ_WAVES', 1), 1):.0f}")
 PY
+} | tee "$O/summary.txt"
 find "$O" -name '*.db' -delete; find "$O" -name '*.csv' -delete
