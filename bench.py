@@ -662,22 +662,43 @@ def main():
     surface = None
     if rank == 0 and world == 1 and args.workload == "metric" and args.surface:
         surface = {"device_resident_batch": None, "host_buffers": {}, "class_surface": None}
+        surface["host_buffers_pinned"] = {}
+        first_out = None
         for hb in (1, 8, 64, 1024):
             try:
                 reps = (hb + uniq - 1) // uniq
                 ah = np.concatenate([a_host] * reps)[:hb] if hb > uniq else a_host[:hb]
                 bh = np.concatenate([b_host] * reps)[:hb] if hb > uniq else b_host[:hb]
-                ctx.ct_mul_relin(ksk, LOGQ, P_PLAIN, ah, bh, DECOMP)          # (first call of a shape allocates)
+                oh = np.zeros_like(ah)
+                oh.fill(1)                                                    # (touch the pages: a caller's result buffer exists before the call)
+                ctx.ct_mul_relin(ksk, LOGQ, P_PLAIN, ah, bh, DECOMP, out=oh)  # (first call of a shape allocates)
+                if hb == 8:
+                    first_out = oh.copy()
                 best = None
-                for _ in range(1 if hb >= 1024 else 3):
+                for _ in range(2 if hb >= 1024 else 5):
                     t0 = time.perf_counter()
-                    ctx.ct_mul_relin(ksk, LOGQ, P_PLAIN, ah, bh, DECOMP)
+                    ctx.ct_mul_relin(ksk, LOGQ, P_PLAIN, ah, bh, DECOMP, out=oh)
                     d = time.perf_counter() - t0
                     best = d if best is None or d < best else best
                 surface["host_buffers"][str(hb)] = round(hb / best, 1)
-                del ah, bh
+                # the same from buffers the caller allocated pinned (fhesi_host_alloc): no staging copy
+                pa, pb2, po = ctx.host_array(ah.shape), ctx.host_array(ah.shape), ctx.host_array(ah.shape)
+                pa[...] = ah; pb2[...] = bh
+                ctx.ct_mul_relin(ksk, LOGQ, P_PLAIN, pa, pb2, DECOMP, out=po)
+                best = None
+                for _ in range(2 if hb >= 1024 else 5):
+                    t0 = time.perf_counter()
+                    ctx.ct_mul_relin(ksk, LOGQ, P_PLAIN, pa, pb2, DECOMP, out=po)
+                    d = time.perf_counter() - t0
+                    best = d if best is None or d < best else best
+                surface["host_buffers_pinned"][str(hb)] = round(hb / best, 1)
+                surface["host_buffers_pinned_equals_pageable"] = bool(np.array_equal(po, oh)) and surface.get("host_buffers_pinned_equals_pageable", True)
+                del ah, bh, oh, pa, pb2, po
             except MemoryError:
                 surface["host_buffers"][str(hb)] = None
+        if first_out is not None:
+            # ... and the host-buffer results are those of the device-resident call on the same pairs
+            surface["host_buffers_equal_device_batch"] = bool(np.array_equal(first_out, dout.download((8, 2, n, nl)))) if uniq >= 8 else None
         exe = os.path.join(ROOT, "tests", "host", "test_addmul")
         if os.path.exists(exe):
             import re

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
     "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
     "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
-    "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_ctx_copy_options", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
+    "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_ctx_copy_options", "fhesi_host_alloc", "fhesi_host_free", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
     "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_comm_init_all", "fhesi_comm_from_rccl", "fhesi_comm_destroy", "fhesi_comm_rank",
     "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
@@ -141,6 +141,8 @@ def _load():
         "fhesi_ctx_set_option": [_vp, C.c_char_p, _i64],
         "fhesi_ctx_get_option": [_vp, C.c_char_p, _vp],
         "fhesi_ctx_copy_options": [_vp, _vp],
+        "fhesi_host_alloc": [_vp, C.c_size_t, _vp],
+        "fhesi_host_free": [_vp, _vp],
         "fhesi_ksk_mark_dirty": [_vp],
         "fhesi_comm_init_all": [_i32, _vp, _vp],
         "fhesi_comm_from_rccl": [_vp, _vp],
@@ -411,13 +413,30 @@ class Context:
     def ct_mul_relin_dev(self, ksk: "KeySwitchMatrix", logQ: int, p: int, a: DevBuf, b: DevBuf, out: DevBuf, nlimbs: int, count: int, decomp_bytes: int = 3):
         _ck(_load().fhesi_ct_mul_relin_batch_dev(self.h, ksk.h, logQ, p, decomp_bytes, a.ptr, b.ptr, out.ptr, nlimbs, count))
 
-    def ct_mul_relin(self, ksk: "KeySwitchMatrix", logQ: int, p: int, a: np.ndarray, b: np.ndarray, decomp_bytes: int = 3) -> np.ndarray:
-        """a, b: [count][2][phim][nlimbs] uint64 two's complement -> same shape."""
+    def ct_mul_relin(self, ksk: "KeySwitchMatrix", logQ: int, p: int, a: np.ndarray, b: np.ndarray, decomp_bytes: int = 3, out: np.ndarray = None) -> np.ndarray:
+        """a, b: [count][2][phim][nlimbs] uint64 two's complement -> same shape (host buffers: fhesi_ct_mul_relin_batch).  `out`: a result
+        array to reuse (a fresh numpy array costs a page fault per 4 KiB on first touch); arrays from host_array() are pinned and take the
+        DMA path without the staging copy."""
         a = np.ascontiguousarray(a, dtype=np.uint64)
         b = np.ascontiguousarray(b, dtype=np.uint64)
-        out = np.zeros_like(a)
+        if out is None:
+            out = np.empty_like(a)
+        elif out.shape != a.shape or out.dtype != np.uint64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint64 array of the operands' shape")
         _ck(_load().fhesi_ct_mul_relin_batch(self.h, ksk.h, logQ, p, decomp_bytes, _p(a), _p(b), _p(out), a.shape[-1], a.shape[0]))
         return out
+
+    def host_array(self, shape, dtype=np.uint64) -> np.ndarray:
+        """numpy array over PINNED host memory (fhesi_host_alloc); freed when the array (and its views) are collected."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = _vp()
+        _ck(_load().fhesi_host_alloc(self.h, n, C.byref(ptr)))
+        buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        import weakref
+        h, lib, addr = self.h, _load(), ptr.value
+        weakref.finalize(buf, lambda: lib.fhesi_host_free(h, C.c_void_p(addr)))
+        return arr
 
 
 class DoubleCRT:

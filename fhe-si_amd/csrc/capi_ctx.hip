@@ -81,6 +81,8 @@ static const OptDesc kOptions[] = {
   {"dot32_half", "FHESI_DOT32_HALF", offsetof(CtxOptions, dot32_half), false},
   {"dot32_mfma", "FHESI_DOT32_MFMA", offsetof(CtxOptions, dot32_mfma), false},
   {"automorph_rows", "FHESI_AUTOMORPH_ROWS", offsetof(CtxOptions, automorph_rows), false},
+  {"host_chunk", "FHESI_HOST_CHUNK", offsetof(CtxOptions, host_chunk), true},
+  {"host_threads", "FHESI_HOST_THREADS", offsetof(CtxOptions, host_threads), false},
 };
 static void opt_store(CtxOptions* o, const OptDesc& d, long long v) {
   if (d.wide) *(long long*)((char*)o + d.off) = v; else *(int*)((char*)o + d.off) = (int)v;
@@ -308,6 +310,7 @@ extern "C" int fhesi_ctx_destroy(fhesi_ctx* c) {
   aux32_free(c);
   tensor32_free(c);
   for (int i = 0; i < FHESI_WS_SLOTS; ++i) if (c->lane_ws[i]) hipFree(c->lane_ws[i]);
+  host_stage_free(c);
   if (c->lane_stream) hipStreamDestroy(c->lane_stream);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);

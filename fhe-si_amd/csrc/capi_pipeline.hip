@@ -1,5 +1,8 @@
 // capi_pipeline.hip -- the key-switch matrix and the fused ciphertext multiplication + key switch, per stage and per batch (include/fhesi_hip.h)
 #include "capi_common.h"
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 // --------------------------------------------------------------------------------------------- key-switch matrix
 extern "C" int fhesi_ksk_create(fhesi_ctx* c, int32_t ncomp, int32_t ndigits, fhesi_ksk** out) {
@@ -68,7 +71,7 @@ extern "C" int fhesi_ksk_form(const fhesi_ksk* k, int32_t* form, int32_t* rows, 
 }
 
 // --------------------------------------------------------------------------------------------- ciphertext pipeline
-static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32);
+static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32, i64 count = -1);
 static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a, const uint64_t* b, uint64_t* out, int32_t nlimbs, int64_t count);
 
 extern "C" int fhesi_ct_mul_dev(fhesi_ctx* c, uint64_t p, const uint64_t* a, const uint64_t* b, int32_t nlimbs, int64_t count, uint64_t* tprod) {
@@ -407,7 +410,7 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
 
 // Ciphertexts per launch of the fused multiplication.  ks32: the key switch really runs over the four 30-bit auxiliary primes (ksaux_mode
 // said KS_MODE_LIMB32) -- only then does the large-launch policy below apply; the 64-bit forms keep the smaller chunks measured for them.
-static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32) {
+static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32, i64 count) {
   if (c->opt.batch_chunk > 0) return c->opt.batch_chunk;
   i64 ch;
   double per;                                              // workspace bytes per ciphertext of a chunk (estimate)
@@ -433,7 +436,10 @@ static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32) {
   }
   // never more than the device can hold: what is free now plus what this lane's workspace already owns, minus a margin (the other lane of
   // option lanes = 2 keeps a second set, hence half of the free memory each)
+  // (a call whose whole batch needs less than a gigabyte skips the query: hipMemGetInfo costs tens of microseconds, a quarter of the issue
+  // time of a single multiplication; should the allocation fail after all, the chunk is halved and retried like any other)
   size_t free_b = 0, total_b = 0;
+  if (count >= 0 && (double)count * per * 1.15 < 1024.0 * 1024 * 1024) return std::min<i64>(ch, std::max<i64>(count, 1));
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
     double have = (double)free_b / (c->opt.lanes >= 2 ? 2.0 : 1.0);
     for (int i = 0; i < FHESI_WS_SLOTS; ++i) have += (double)c->ws_bytes[i];
@@ -451,7 +457,7 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
   CrtTables* t;
   FHESI_TRY(get_crt_tables(c, full_set(c), &t));
   const int ks_mode = ksaux_mode(c, t, k->ncomp * k->ndigits, 8 * decomp_bytes, logQ);
-  i64 chunk = batch_chunk(c, 3 * k->ndigits, ks_mode == KS_MODE_LIMB32);
+  i64 chunk = batch_chunk(c, 3 * k->ndigits, ks_mode == KS_MODE_LIMB32, count);
   for (i64 done = 0; done < count;) {
     const i64 cnt = std::min(chunk, count - done);
     const size_t off = (size_t)done * 2 * n * nlimbs;
@@ -530,22 +536,184 @@ extern "C" int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* c, const fhesi_ksk* k, in
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------- host buffers
+// fhesi_ct_mul_relin_batch takes and returns HOST buffers (what a caller of the class surface holds: Test_AddMul.cpp:59-67).  6 MiB cross the
+// bus per multiplication at the metric ring (two operands in, one result out), and a pageable hipMemcpy moves them through the runtime's
+// own bounce buffer on one thread, strictly before and after the compute: 2.9 k mults/s where the device does 24 k and the bus allows ~12 k.
+// Here the batch runs as a pipeline of stages of `host_chunk` ciphertexts over a ring of two PINNED slots:
+//     caller's a, b --(copy threads)--> pinned slot --(stream `up`, DMA)--> device slot --(context stream: the fused pipeline)-->
+//     device slot --(stream `down`, DMA)--> pinned slot --(copy threads)--> caller's out
+// so the upload of stage i + 1, the compute of stage i and the download of stage i - 1 overlap, and the pageable side is copied by several
+// threads.  Buffers the caller allocated pinned (fhesi_host_alloc, or any hipHostMalloc / registered memory) skip the copy threads: the DMA
+// reads and writes them directly.  Results are those of fhesi_ct_mul_relin_batch_dev bit for bit (the same calls on the same values).
+struct HostStage {
+  static constexpr int NS = 2;
+  size_t slot_bytes = 0;                 // bytes per operand per slot
+  void* pin[NS][3] = {};                 // a, b, out
+  void* dev[NS][3] = {};
+  hipStream_t up = nullptr, down = nullptr;
+  hipEvent_t ev_up[NS] = {}, ev_comp[NS] = {}, ev_down[NS] = {};
+  std::vector<hipEvent_t> ev_piece[NS];  // one per downloaded piece of a stage (pageable results)
+  // copy threads: parallel memcpy of one region, the caller's thread takes a share
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  const char* src = nullptr; char* dst = nullptr; size_t len = 0, piece = 0;
+  unsigned long long gen = 0; int pending = 0; bool quit = false;
+  void worker(int id, unsigned long long seen) {      // seen: the generation at the time the thread was started (a restarted pool must not replay the last job)
+    for (;;) {
+      const char* s; char* d; size_t n, pc;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; s = src; d = dst; n = len; pc = piece; }
+      const size_t off = (size_t)(id + 1) * pc;
+      if (off < n) memcpy(d + off, s + off, std::min(pc, n - off));
+      { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+    }
+  }
+  void start(int nthreads) { unsigned long long g0; { std::lock_guard<std::mutex> lk(mu); g0 = gen; pending = 0; } for (int i = 0; i < nthreads; ++i) th.emplace_back([this, i, g0] { worker(i, g0); }); }
+  void copy(void* d, const void* s, size_t n) {
+    const int T = (int)th.size() + 1;
+    if (T == 1 || n < (size_t)256 << 10) { memcpy(d, s, n); return; }
+    size_t pc = (n + T - 1) / T; pc = (pc + 4095) & ~(size_t)4095;
+    { std::lock_guard<std::mutex> lk(mu); src = (const char*)s; dst = (char*)d; len = n; piece = pc; pending = (int)th.size(); ++gen; }
+    cv.notify_all();
+    memcpy(d, s, std::min(pc, n));
+    std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  void stop() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+    th.clear();
+    quit = false;
+  }
+  void release() {
+    stop();
+    for (int s = 0; s < NS; ++s) for (int k = 0; k < 3; ++k) { if (pin[s][k]) hipHostFree(pin[s][k]); if (dev[s][k]) hipFree(dev[s][k]); pin[s][k] = dev[s][k] = nullptr; }
+    for (int s = 0; s < NS; ++s) { if (ev_up[s]) hipEventDestroy(ev_up[s]); if (ev_comp[s]) hipEventDestroy(ev_comp[s]); if (ev_down[s]) hipEventDestroy(ev_down[s]); for (hipEvent_t e : ev_piece[s]) hipEventDestroy(e); ev_piece[s].clear(); }
+    if (up) hipStreamDestroy(up);
+    if (down) hipStreamDestroy(down);
+  }
+};
+void host_stage_free(fhesi_ctx* c) {
+  if (!c->host_stage) return;
+  c->host_stage->release();
+  delete c->host_stage;
+  c->host_stage = nullptr;
+}
+static int host_stage_get(fhesi_ctx* c, size_t slot_bytes, HostStage** out) {
+  HostStage* h = c->host_stage;
+  if (!h) {
+    h = new HostStage();
+    c->host_stage = h;
+    HIP_TRY(hipStreamCreateWithFlags(&h->up, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h->down, hipStreamNonBlocking));
+    for (int s = 0; s < HostStage::NS; ++s) {
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_up[s], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_comp[s], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_down[s], hipEventDisableTiming));
+    }
+  }
+  {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int T = c->opt.host_threads > 0 ? c->opt.host_threads : (int)std::min(8u, hw);      // (8 measured best on a 256-thread host: 4 slightly slower, 16 - 64 progressively slower -- the pieces are 8 MiB)
+    if ((int)h->th.size() != T - 1) { h->stop(); h->start(T - 1); }      // (first use, or the option changed)
+  }
+  if (h->slot_bytes < slot_bytes) {
+    HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipStreamSynchronize(h->up)); HIP_TRY(hipStreamSynchronize(h->down));
+    for (int s = 0; s < HostStage::NS; ++s) for (int k = 0; k < 3; ++k) {
+      if (h->pin[s][k]) { hipHostFree(h->pin[s][k]); h->pin[s][k] = nullptr; }
+      if (h->dev[s][k]) { hipFree(h->dev[s][k]); h->dev[s][k] = nullptr; }
+    }
+    h->slot_bytes = 0;
+    for (int s = 0; s < HostStage::NS; ++s) for (int k = 0; k < 3; ++k) {
+      if (hipHostMalloc(&h->pin[s][k], slot_bytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&h->dev[s][k], slot_bytes) != hipSuccess) { (void)hipGetLastError(); FHESI_FAIL("host staging: allocation of %zu bytes (pinned + device) failed", slot_bytes); }
+    }
+    h->slot_bytes = slot_bytes;
+  }
+  *out = h;
+  return 0;
+}
+static bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+extern "C" int fhesi_host_alloc(fhesi_ctx* c, size_t bytes, void** out) {
+  CHECK_CTX(c);
+  if (!out) FHESI_FAIL("host_alloc: null output pointer");
+  if (hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; FHESI_FAIL("host_alloc: %zu pinned bytes not available", bytes); }
+  return 0;
+}
+extern "C" int fhesi_host_free(fhesi_ctx* c, void* p) {
+  CHECK_CTX(c);
+  if (p) HIP_TRY(hipHostFree(p));
+  return 0;
+}
+
 extern "C" int fhesi_ct_mul_relin_batch(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a,
                                         const uint64_t* b, uint64_t* out, int32_t nlimbs, int64_t count) {
   CHECK_CTX(c);
   if (!count) return 0;
-  const size_t bytes = (size_t)count * 2 * c->phim * nlimbs * 8;
-  // staging for the two operand batches and the results: one grow-only workspace slot (a hipMalloc / hipFree pair per call costs
-  // milliseconds for a single ciphertext and seconds for gigabytes -- object-at-a-time callers of the class surface come through here)
-  void* stage;
-  FHESI_TRY(ws_reserve(c, 11, 3 * bytes, &stage));
-  u64 *da = (u64*)stage, *db = (u64*)((char*)stage + bytes), *dout = (u64*)((char*)stage + 2 * bytes);
-  int r = 0;
-  if (hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-    fhesi_set_error("upload of ciphertext batch failed"); r = 1;
+  if (!a || !b || !out) FHESI_FAIL("ct_mul_relin: null host buffer");
+  const size_t ct_bytes = (size_t)2 * c->phim * nlimbs * 8;
+  // stage size: the whole batch in at least two stages (so that transfers and compute overlap), at most 32 ciphertexts (64 MiB per operand
+  // at the metric ring; larger stages only lengthen the pipeline's fill and drain)
+  // (measured at the metric ring, profiles/r04_host_buffers.txt: 1024 per call 7.9 / 9.6 / 9.7 / 10.6 k mults/s with stages of 8 / 16 / 32
+  // ciphertexts and 4 - 8 copy threads, 7.7 k with 128; 64 per call 8.5 k with stages of 16, 7.6 k with 32; 8 per call 5.1 k with two stages of 4)
+  i64 hc = c->opt.host_chunk > 0 ? c->opt.host_chunk : (count >= 256 ? 32 : (count >= 32 ? 16 : std::max<i64>(1, (count + 1) / 2)));
+  if (hc > count) hc = count;
+  HostStage* h;
+  FHESI_TRY(host_stage_get(c, (size_t)hc * ct_bytes, &h));
+  const bool pa = is_pinned_host(a), pb = is_pinned_host(b), po = is_pinned_host(out);
+  const i64 nst = (count + hc - 1) / hc;
+  // inside a stage the pageable side moves in pieces: the copy threads fill piece j + 1 of the ring while the DMA engine takes piece j up,
+  // and on the way back they empty piece j while piece j + 1 comes down (one event per piece)
+  const size_t piece = (size_t)8 << 20;
+  const size_t npc_max = ((size_t)hc * ct_bytes + piece - 1) / piece;
+  for (int s = 0; s < HostStage::NS; ++s)
+    while (h->ev_piece[s].size() < npc_max) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_piece[s].push_back(e); }
+  int rc = 0;
+  auto upload = [&](int s, int which, const void* src, bool pinned, size_t bytes) -> bool {
+    if (pinned) return hipMemcpyAsync(h->dev[s][which], src, bytes, hipMemcpyHostToDevice, h->up) == hipSuccess;
+    for (size_t o = 0; o < bytes; o += piece) {
+      const size_t len = std::min(piece, bytes - o);
+      h->copy((char*)h->pin[s][which] + o, (const char*)src + o, len);
+      if (hipMemcpyAsync((char*)h->dev[s][which] + o, (char*)h->pin[s][which] + o, len, hipMemcpyHostToDevice, h->up) != hipSuccess) return false;
+    }
+    return true;
+  };
+  auto finish = [&](i64 st) -> int {            // stage st: as its pieces arrive, hand them to the caller's buffer
+    const int s = (int)(st % HostStage::NS);
+    const size_t bytes = (size_t)std::min(hc, count - st * hc) * ct_bytes, off = (size_t)st * hc * ct_bytes;
+    if (po) { if (hipEventSynchronize(h->ev_down[s]) != hipSuccess) { fhesi_set_error("download of ciphertext batch failed"); return 1; } return 0; }
+    size_t j = 0;
+    for (size_t o = 0; o < bytes; o += piece, ++j) {
+      if (hipEventSynchronize(h->ev_piece[s][j]) != hipSuccess) { fhesi_set_error("download of ciphertext batch failed"); return 1; }
+      h->copy((char*)out + off + o, (char*)h->pin[s][2] + o, std::min(piece, bytes - o));
+    }
+    return 0;
+  };
+  for (i64 st = 0; st < nst && !rc; ++st) {
+    const int s = (int)(st % HostStage::NS);
+    const i64 cnt = std::min(hc, count - st * hc);
+    const size_t bytes = (size_t)cnt * ct_bytes, off = (size_t)st * hc * ct_bytes;
+    // the slot's previous user (stage st - 2) was finished before stage st - 1 was issued: its pinned and device buffers are free
+    if (!upload(s, 0, (const char*)a + off, pa, bytes) || !upload(s, 1, (const char*)b + off, pb, bytes) ||
+        hipEventRecord(h->ev_up[s], h->up) != hipSuccess || hipStreamWaitEvent(c->stream, h->ev_up[s], 0) != hipSuccess) { fhesi_set_error("upload of ciphertext batch failed"); rc = 1; break; }
+    rc = fhesi_ct_mul_relin_batch_dev(c, k, logQ, p, decomp_bytes, (const u64*)h->dev[s][0], (const u64*)h->dev[s][1], (u64*)h->dev[s][2], nlimbs, cnt);
+    if (rc) break;
+    bool ok = hipEventRecord(h->ev_comp[s], c->stream) == hipSuccess && hipStreamWaitEvent(h->down, h->ev_comp[s], 0) == hipSuccess;
+    if (ok && po) ok = hipMemcpyAsync((char*)out + off, h->dev[s][2], bytes, hipMemcpyDeviceToHost, h->down) == hipSuccess;
+    else if (ok) {
+      size_t j = 0;
+      for (size_t o = 0; ok && o < bytes; o += piece, ++j)
+        ok = hipMemcpyAsync((char*)h->pin[s][2] + o, (char*)h->dev[s][2] + o, std::min(piece, bytes - o), hipMemcpyDeviceToHost, h->down) == hipSuccess &&
+             hipEventRecord(h->ev_piece[s][j], h->down) == hipSuccess;
+    }
+    if (!ok || hipEventRecord(h->ev_down[s], h->down) != hipSuccess) { fhesi_set_error("download of ciphertext batch failed"); rc = 1; break; }
+    if (st >= 1) rc = finish(st - 1);              // (overlaps stage st on the device; frees the other slot for stage st + 1)
   }
-  if (!r) r = fhesi_ct_mul_relin_batch_dev(c, k, logQ, p, decomp_bytes, da, db, dout, nlimbs, count);
-  if (!r && hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { fhesi_set_error("download of ciphertext batch failed"); r = 1; }
-  hipStreamSynchronize(c->stream);
-  return r;
+  if (!rc) rc = finish(nst - 1);
+  if (rc) { hipStreamSynchronize(h->up); hipStreamSynchronize(c->stream); hipStreamSynchronize(h->down); }
+  return rc;
 }

@@ -68,6 +68,8 @@ struct ProfRec { int cls; double units; hipEvent_t e0, e1; };
 // Behaviour switches of one context (fhesi_ctx_set_option).  The FHESI_* environment variables of the same meaning are read ONCE, when
 // the context is created, as initial values -- never per call.
 struct CtxOptions {
+  long long host_chunk = 0;  // ciphertexts per stage of the host-buffer pipeline of fhesi_ct_mul_relin_batch (0 = derived from the batch)
+  int host_threads = 0;     // threads that copy between the caller's pageable buffers and the pinned ring (0 = min(16, hardware threads))
   int ks_direct = 0;        // 1: per-chain-prime key-switch dot product (the reference's structure) instead of the auxiliary-prime path
   int ks_residues = 0;      // 1: auxiliary-prime key switch in residue mode (no limb mode)
   int ks_aux60 = 0;         // 1: two 60-bit auxiliary primes even where the four 30-bit primes apply
@@ -125,6 +127,7 @@ struct fhesi_ctx {
   BluesteinTables* blue = nullptr;
   fhesi_aux32* aux32 = nullptr;
   struct fhesi_tensor32* tensor32 = nullptr;     // tables of the 30-bit tensor half (kernels_tensor32.hip), built on first use
+  std::map<std::vector<long long>, std::pair<int, std::vector<uint32_t>>> t32_memo;      // t32_plan's answers: (lift, limbs, logQ, bits of the group size, option) -> (2 NP + generic, primes)
   std::map<std::vector<int>, CrtTables*> crt_cache;
   std::map<int, Shoup2*> pow64_cache;  // nlimbs -> device [L][nlimbs+1] table for rns_reduce
   std::map<std::vector<u64>, u64*> scalar_cache;   // rns_reduce lift scalars (per-slot residues), keyed by the scalar list
@@ -140,6 +143,7 @@ struct fhesi_ctx {
   const int* op_idx = nullptr;
   long long op_idx_n = 0, op_idx_done = 0;
   bool mark_mid = false;               // record ev_mid right after the next digit-NTT launch (staggers the second lane)
+  struct HostStage* host_stage = nullptr;      // pinned staging ring + copy streams + copy threads of the host-buffer entry points (capi_pipeline.hip), built on first use
   bool prof_on = false;
   std::vector<ProfRec> prof;
   const void* prof_fn[16] = {};        // host stub of the kernel the last profiled launch of each class ran (fhesi_prof_kernel_name)
@@ -189,6 +193,7 @@ int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, 
 void aux32_free(fhesi_ctx* ctx);
 // the tensor half of the fused multiplication over primes below 2^30 (kernels_tensor32.hip)
 void tensor32_free(fhesi_ctx* ctx);
+void host_stage_free(fhesi_ctx* ctx);            // capi_pipeline.hip
 bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ);
 int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts /* [count*3][logQ/64][n] */);
 // ... and for sums of products per group (fhesi_ct_mul_sum_relin_dev): begin fixes the configuration for at most gmax terms per group

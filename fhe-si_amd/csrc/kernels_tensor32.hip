@@ -83,7 +83,26 @@ struct T32Plan { int NP = 0; bool generic = false; };
 //   |x| < 2^TB with TB = 2 (logQ - 1) + bits(p) + log2(coefficients) + 1 [+ log2(terms per sum)] [+ 2: the three-term fold of the
 //   safe-prime rings];  M > 2^(TB + 3) keeps x/M below 1/8 (kappa is then decided by a coarse fixed-point sum), and the chain product must
 //   exceed 2^(TB + 1) so that the reference's own centred integers are these same integers.
+static T32Plan t32_plan_search(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax, std::vector<u32>* primes);
+// (the search tests a few hundred candidates for primality: a tenth of a millisecond, which a caller of single multiplications would pay
+// twice per call -- so the answer is kept per (lift, limbs, logQ, bits of the group size, option tensor32))
 static T32Plan t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax, std::vector<u32>* primes) {
+  int gbits = 0;
+  while (((i64)1 << gbits) < gmax) ++gbits;
+  auto& memo = const_cast<fhesi_ctx*>(ctx)->t32_memo;          // (a context serves one host thread at a time)
+  const std::vector<long long> key{(long long)p, nlimbs, logQ, gbits, ctx->opt.tensor32};
+  auto it = memo.find(key);
+  if (it == memo.end()) {
+    std::vector<u32> pr;
+    const T32Plan pl = t32_plan_search(ctx, p, nlimbs, logQ, gmax, &pr);
+    it = memo.emplace(key, std::make_pair(pl.NP * 2 + (pl.generic ? 1 : 0), std::move(pr))).first;
+  }
+  if (primes) *primes = it->second.second;
+  T32Plan pl;
+  pl.NP = it->second.first >> 1; pl.generic = it->second.first & 1;
+  return pl;
+}
+static T32Plan t32_plan_search(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax, std::vector<u32>* primes) {
   T32Plan pl;
   if (!ctx->opt.tensor32 || p < 2 || nlimbs < 1 || nlimbs > 16 || 64 * nlimbs < logQ || gmax < 1) return pl;
   const bool lin = ctx->lin_q != 0;

@@ -165,6 +165,12 @@ int fhesi_selftest_aux32(fhesi_ctx* c);                                         
  * nlimbs must be >= ceil(logQ/64).  decomp_bytes = FHEcontext::decompSize (3 at every reference call site). */
 int fhesi_ct_mul_relin_batch(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes,
                              const uint64_t* a_host, const uint64_t* b_host, uint64_t* out_host, int32_t nlimbs, int64_t count);
+/* The host-buffer form runs as a pipeline of stages over a pinned staging ring: upload of stage i + 1, compute of stage i and download of
+ * stage i - 1 overlap on three streams, and pageable buffers are copied into / out of the ring by several threads (options "host_chunk":
+ * ciphertexts per stage, "host_threads").  Buffers allocated with fhesi_host_alloc (pinned) are read and written by the DMA engines
+ * directly, without the copy.  Same bits as the _dev form. */
+int fhesi_host_alloc(fhesi_ctx* ctx, size_t bytes, void** out);                      /* pinned host memory for ciphertext batches */
+int fhesi_host_free(fhesi_ctx* ctx, void* p);
 int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes,
                                  const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev, int32_t nlimbs, int64_t count);
 /* Separately callable stages of the same pipeline (parity tests check each against the oracle) */

@@ -107,6 +107,22 @@ int main(int argc, char* argv[]) {
       const double t1 = now() - t0;
       std::cout << "recorded: " << timeN << " x (operator*=, ApplyKeySwitch) in " << t1 << " s (" << tr << " s recording) = " << timeN / t1 << " per second; device calls so far " << eng.stats.calls << std::endl;
     }
+    {
+      // the same statements with every result asked for before the next object is touched (a batch of one per object: what the reference's
+      // object-at-a-time semantics cost when results are read between statements, Test_AddMul.cpp:59-86)
+      std::vector<Ciphertext> ea, eb;
+      const long oneN = std::min<long>(timeN, 256);
+      std::vector<Plaintext> qa(pa.begin(), pa.begin() + oneN), qb(pb.begin(), pb.begin() + oneN);
+      publicKey.EncryptBatchSeeded(ea, qa, 12, 0); publicKey.EncryptBatchSeeded(eb, qb, 12, (uint64_t)timeN);
+      SyncCiphertexts(context);
+      for (int rep = 0; rep < 2; ++rep) {
+        if (rep) { publicKey.EncryptBatchSeeded(ea, qa, 13, 0); SyncCiphertexts(context); }
+        const double t0 = now();
+        for (long i = 0; i < oneN; ++i) { ea[i] *= eb[i]; keySwitch.ApplyKeySwitch(ea[i]); SyncCiphertexts(context); }
+        const double t1 = now() - t0;
+        std::cout << "result asked after every object: " << oneN << " x (operator*=, ApplyKeySwitch, evaluate) in " << t1 << " s = " << oneN / t1 << " per second" << std::endl;
+      }
+    }
     secretKey.DecryptBatch(dec, a);
     bool ok = true;
     {   // the plaintext-side product of the first and the last pair

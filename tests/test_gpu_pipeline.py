@@ -401,3 +401,39 @@ def test_key_switch_on_safe_prime_rings(m, logQ):
         else:
             want_rows = orc.apply_key_switch(ksm2, tp[0], logQ, nl)
         assert np.array_equal(out.download((2, n, nl)), want_rows), (d, pos)
+
+
+@pytest.mark.parametrize("count,host_chunk", [(1, 0), (3, 0), (8, 0), (37, 5), (130, 0)])
+def test_host_buffer_pipeline_equals_the_device_batch(count, host_chunk):
+    """fhesi_ct_mul_relin_batch (host buffers: what a caller of Ciphertext::operator*= + ApplyKeySwitch holds, Test_AddMul.cpp:59-67)
+    runs as a pipeline of stages over a pinned ring -- upload, compute and download of neighbouring stages overlapped on three streams, the
+    pageable side copied by several threads.  Same bits as fhesi_ct_mul_relin_batch_dev on the same pairs and as the oracle, for a single
+    ciphertext, ragged last stages, more stages than ring slots, pinned buffers (fhesi_host_alloc: no staging copy) and mixed ones,
+    and when the same context is called again with another batch size."""
+    m, logQ, p = 2048, 128, 23
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 77 + count, count)
+    n = ctx.phim
+    if host_chunk:
+        ctx.set_option("host_chunk", host_chunk)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(count * 2 * n * nl * 8)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    want = dout.download((count, 2, n, nl))
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert np.array_equal(got, want)
+    for c in (0, count - 1):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    # pinned operands and result; then pinned a, pageable b, pageable result reused
+    pa, pb, po = ctx.host_array(a.shape), ctx.host_array(a.shape), ctx.host_array(a.shape)
+    pa[...] = a
+    pb[...] = b
+    po[...] = 0
+    assert ctx.ct_mul_relin(ksk, logQ, p, pa, pb, out=po) is po and np.array_equal(po, want)
+    out2 = np.zeros_like(a)
+    ctx.ct_mul_relin(ksk, logQ, p, pa, b, out=out2)
+    assert np.array_equal(out2, want)
+    # another batch size on the same context (the ring is re-sized or re-used)
+    k2 = max(1, count // 2)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[:k2], b[:k2]), want[:k2])
+    big = np.concatenate([a, a])
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, big, np.concatenate([b, b])), np.concatenate([want, want]))
