@@ -121,8 +121,9 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
       if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
       bool mont = true;                 // dot32_kernel2 leaves the factor 2^-32 of its Montgomery step; the matrix-core form does not
       FHESI_TRY(launch_dot32(c, km, (const u32*)d_dig, ncol, count, (u32*)d_o, &mont));
-      FHESI_TRY(launch_ntt32_inv(c, (u32*)d_o, count * 2 * R, 4, 0, mont));
-      return launch_ks_recombine(c, t, k, (const u64*)d_o, count * 2, (u64*)out, nlimbs);
+      const bool fold_tail = ks_recombine_takes_tail(c, t, k);      // (rows of 2^15 at the stress chain: the inverse's tail stage runs in the recombination's loader)
+      FHESI_TRY(launch_ntt32_inv(c, (u32*)d_o, count * 2 * R, 4, 0, mont, !fold_tail));
+      return launch_ks_recombine(c, t, k, (const u64*)d_o, count * 2, (u64*)out, nlimbs, fold_tail);
     }
     FHESI_TRY(launch_ntt_fwd_digits(c, d_parts, nlq, logQ, 8 * decomp_bytes, nd, count * ncomp, (u64*)d_dig, 0, 2, 2));
     if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }

@@ -189,7 +189,9 @@ struct fhesi_ksk {
 };
 struct KsLimbPlan { int W = 0, LQ = 0, B = 0, NLB = 0, mbits = 0; bool a32 = false; };
 bool ks_limb_plan(const fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int logQ, KsLimbPlan* plan, const u32* p32 /* the 30-bit primes, or null */);
-int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o /* [npolys][aux_rows][2][n] */, i64 npolys, u64* d_out, int nl_out);
+int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o /* [npolys][aux_rows][2][n] */, i64 npolys, u64* d_out, int nl_out, bool tail_pending = false);
+bool ks_recombine_takes_tail(const fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k);
+int aux32_tail_consts(fhesi_ctx* ctx, uint32_t (*tw)[2], uint32_t (*twp)[2]);      // per auxiliary prime: (1/2, psi^-brv(1)/2) and their quotients
 void aux32_free(fhesi_ctx* ctx);
 // the tensor half of the fused multiplication over primes below 2^30 (kernels_tensor32.hip)
 void tensor32_free(fhesi_ctx* ctx);
@@ -204,7 +206,7 @@ int tensor32_sum_pass(fhesi_ctx* ctx, const u64* d_ops, i64 nua, i64 nub, const 
 int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts);
 const u32* aux32_primes(fhesi_ctx* ctx);          // the four primes (host array), nullptr on error
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
-int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */);
+int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */, bool tail = true /* false: rows of 2^15 are left as their two sub-inverses */);
 constexpr i64 kDigitSubCt = 64;                   // ciphertexts per sub-chunk of the tiled 32-bit digit rows (launch_ntt32_fwd_digits <-> launch_dot32)
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* tiled, see ntt32_core.inc */,
                             i64 sub_units /* units (digit polynomials) per sub-chunk */);

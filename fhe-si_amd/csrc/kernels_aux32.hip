@@ -147,7 +147,7 @@ int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
   return 0;
 }
 // mont: the rows carry the factor 2^-32 of dot32_kernel2's Montgomery step
-int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont) {
+int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont, bool tail) {
   FHESI_TRY(aux32_init(ctx));
   if (!count) return 0;
   const fhesi_aux32* x = ctx->aux32;
@@ -158,10 +158,16 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0,
   if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   HIP_TRY(hipGetLastError());
-  if (S) {
+  if (S && tail) {
     ntt32_tail_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
     HIP_TRY(hipGetLastError());
   }
+  return 0;
+}
+int aux32_tail_consts(fhesi_ctx* ctx, uint32_t (*tw)[2], uint32_t (*twp)[2]) {
+  FHESI_TRY(aux32_init(ctx));
+  const fhesi_aux32* x = ctx->aux32;
+  for (int a = 0; a < 4; ++a) { tw[a][0] = x->hd.tail_sum[a].w; twp[a][0] = x->hd.tail_sum[a].wp; tw[a][1] = x->hd.tail_dif[a].w; twp[a][1] = x->hd.tail_dif[a].wp; }
   return 0;
 }
 // digit rows, tiled [4][row length / 64][npolys * nd][64] u32, straight from the scaled-down parts

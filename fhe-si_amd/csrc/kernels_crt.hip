@@ -602,11 +602,14 @@ static int launch_crt_sum(fhesi_ctx* ctx, const CrtTables* t, const u64* d_rows,
 //   corrections, centring -- all exact integer arithmetic on W + 1 limbs -- then the mode-2 store of the sum-form kernel.
 // A32: the residues are those of the four 30-bit auxiliary primes (kernels_aux32.hip), [poly][NLB][4][n] u32, recombined by Garner's
 // mixed radix with the constants of Garner32; otherwise the two 60-bit chain primes, [poly][NLB][2][n] u64.
-struct Garner32 { u32 p[4]; u32 c[6], cp[6]; };      // c = {p0^-1 mod p1, p0^-1 mod p2, p1^-1 mod p2, p0^-1 mod p3, p1^-1 mod p3, p2^-1 mod p3} and floor(c 2^32 / p_j)
+struct Garner32 { u32 p[4]; u32 c[6], cp[6]; u32 tw[4][2], twp[4][2]; };      // tw: the tail of a 2^15-point inverse per prime (1/2 | psi^-brv(1) / 2) and its quotient (kernels with S = 1)      // c = {p0^-1 mod p1, p0^-1 mod p2, p1^-1 mod p2, p0^-1 mod p3, p1^-1 mod p3, p2^-1 mod p3} and floor(c 2^32 / p_j)
 __device__ __forceinline__ u32 g32_mul(u32 y, u32 c, u32 cp, u32 p) { const u32 r = y * c - __umulhi(y, cp) * p; return r >= p ? r - p : r; }     // y any u32 -> [0, p)
 __device__ __forceinline__ u32 g32_mul_lazy(u32 y, u32 c, u32 cp, u32 p) { return y * c - __umulhi(y, cp) * p; }                               // y any u32 -> [0, 2p)
 __device__ __forceinline__ u32 g32_sub(u32 a, u32 b, u32 p) { return a + 2 * p - b; }      // a, b below 2p -> a - b + 2p in (0, 4p): only ever the argument of a g32_mul
-template <int W, int LQ, int B, int NLB, bool A32>
+// S = 1 (A32 only): the rows are the two sub-inverses A, B of 2^15-point rows as ntt32_inv_kernel3 leaves them -- coefficient e < 2^14 is
+// (A_e + B_e) / 2, coefficient e + 2^14 is (A_e - B_e) psi^-brv(1) / 2 (ntt32_tail_kernel's arithmetic, taken here in the loader: the rows are
+// read once instead of being rewritten by a pass of their own).
+template <int W, int LQ, int B, int NLB, bool A32, int S = 0>
 __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict__ o, i64 n, u64 q0, u64 q1, u64 q0inv, u64 q0inv_sh, u64 half_hi, u64 half_lo,
                                                            u64 a_hi, u64 a_lo, const u64* __restrict__ consts /* D[W+1], pinv lo, hi */,
                                                            const u64* __restrict__ Pfull, const u64* __restrict__ halfP, u64* __restrict__ out, int nl_out, Garner32 gc) {
@@ -621,7 +624,12 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
   for (int i = 0; i < W + 4; ++i) cnt[i] = 0;
   const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
   const u64* base = o + poly * NLB * 2 * n + j;
-  const u32* base32 = reinterpret_cast<const u32*>(o) + poly * NLB * 4 * n + j;
+  const u32* base32 = reinterpret_cast<const u32*>(o) + poly * NLB * 4 * n + (S ? (j & ((i64)(1 << 14) - 1)) : j);
+  const int up = S ? (int)(j >> 14) : 0;           // (uniform per workgroup)
+  auto tail = [&](u32 Av, u32 Bv, int a) -> u32 {  // both below p
+    const u32 p = gc.p[a];
+    return g32_mul(up ? Av + p - Bv : Av + Bv, gc.tw[a][up], gc.twp[a][up], p);
+  };
   // all the residues of the coefficient at once (the kernel waits on these loads, not on its arithmetic: one round of 4 NLB loads in
   // flight instead of a round per limb)
   constexpr bool PRE = A32 && NLB <= 16;           // (the 30 limbs of the stress chain would cost a wave per SIMD)
@@ -638,6 +646,11 @@ __global__ void __launch_bounds__(128) ks_recombine_kernel(const u64* __restrict
     if (A32) {
       u32 v0, v1, v2, v3;
       if (PRE) { v0 = vin[l][0]; v1 = vin[l][1]; v2 = vin[l][2]; v3 = vin[l][3]; }
+      else if (S) {
+        const u32* r0 = base32 + (i64)(l * 4) * n;
+        const u32 a0 = r0[0], b0 = r0[1 << 14], a1 = r0[n], b1 = r0[n + (1 << 14)], a2 = r0[2 * n], b2 = r0[2 * n + (1 << 14)], a3 = r0[3 * n], b3 = r0[3 * n + (1 << 14)];
+        v0 = tail(a0, b0, 0); v1 = tail(a1, b1, 1); v2 = tail(a2, b2, 2); v3 = tail(a3, b3, 3);
+      }
       else { v0 = base32[(i64)(l * 4 + 0) * n]; v1 = base32[(i64)(l * 4 + 1) * n]; v2 = base32[(i64)(l * 4 + 2) * n]; v3 = base32[(i64)(l * 4 + 3) * n]; }
       const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
       const u32 x1 = v0;                                                        // all four primes lie in (2^29, 2^30): a residue of one is below twice any other
@@ -874,7 +887,7 @@ static int garner32_consts(fhesi_ctx* ctx, Garner32* gc) {
   }
   return 0;
 }
-template <int W, int LQ, int B, int NLB, bool A32>
+template <int W, int LQ, int B, int NLB, bool A32, int S = 0>
 static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
   const u64 q0 = ctx->q[0], q1 = ctx->q[1];
   const u64 inv = hm::invmod(q0 % q1, q1);
@@ -886,13 +899,20 @@ static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi
   }
   const u128 half = (A - 1) / 2;
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
-  ks_recombine_kernel<W, LQ, B, NLB, A32><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, q0, q1, inv, hm::shoup(inv, q1), (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A,
+  if (S && aux32_tail_consts(ctx, gc.tw, gc.twp)) return 1;
+  ks_recombine_kernel<W, LQ, B, NLB, A32, S><<<grid, 128, 0, ctx->stream>>>(d_o, ctx->phim, q0, q1, inv, hm::shoup(inv, q1), (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A,
                                                                           k->d_limb_consts, t->d_P + (size_t)t->nidx * t->W, t->d_halfP, d_out, nl_out, gc);
   HIP_TRY(hipGetLastError());
   return 0;
 }
-int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
+// does the recombination of this matrix take the tail of the 2^15-point inverse in its loader (so that launch_ntt32_inv leaves it out)?
+bool ks_recombine_takes_tail(const fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k) {
+  return !k->aux_fold && k->aux32 && ctx->pow2 && aux32_row_len(ctx) == 2 * kAux32N && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30;
+}
+int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out, bool tail_pending) {
   if (!npolys) return 0;
+  if (tail_pending != ks_recombine_takes_tail(ctx, t, k) && tail_pending) FHESI_FAIL("key switch: rows without their tail stage reached a recombination that does not take it");
+  if (tail_pending) { ProfScope prof(ctx, PROF_CRT, (double)npolys); return launch_ks_recombine_t<34, 1024, 72, 30, true, 1>(ctx, t, k, d_o, npolys, d_out, nl_out); }
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
   // compile-time instantiations for the shapes the benchmarks run (the plan of ks_limb_plan at the metric and stress chains) ...
   if (!k->aux_fold && k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
