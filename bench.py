@@ -290,7 +290,7 @@ def run_ntt_round_trips(args, rank, world, local_rank, dist, torch, F):
     uniform residues per GPU; one step = forward + inverse transform of the whole batch (2 B L row transforms); the round trip must
     reproduce the input bit for bit, and one DoubleCRT is checked against the C oracle in both directions."""
     m, n, L = 1 << 14, 1 << 13, 8
-    B = args.batch if args.batch else 1024
+    B = args.batch if args.batch else 8192          # (65536 rows per launch: at 1024 the launch is 10.7 rounds of the resident workgroups and the sub-millisecond kernels never leave the clock ramp -- profiles/r04_pmc_sq_ntt64.txt)
     primes, q = [], (1 << 60) - 1
     q -= q % (2 * m)
     q += 2 * m + 1
@@ -389,13 +389,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="ciphertext mults per GPU per step (default 1024 = 16 chunks of the library, so that 20 steps time more than "
-                    "a second; stress: 64; ntt workload: DoubleCRTs per step, default 1024)")
+                    "a second; stress: 64; ntt workload: DoubleCRTs per step, default 8192)")
     ap.add_argument("--cpu-sample", type=int, default=3, help="oracle ciphertext mults timed for cpu_baseline and compared with the timed output buffer (0 = skip)")
     ap.add_argument("--no-bluestein-cpu", action="store_true", help="skip the like-for-like (Bluestein-mode) CPU timing, about 20 s")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (option lanes); 2 gave ~+4 %% with launches of 64 ciphertexts, +0.6 %% with today's launches of 1024; it "
                     "overlaps kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
     ap.add_argument("--workload", default="metric", choices=["metric", "stress", "regression", "ntt"], help="metric = configs[2] (default, the contract line); "
-                    "ntt = configs[1]: DoubleCRT forward+inverse round trips at n=2^13, 8 primes, --batch DoubleCRTs per GPU (default there: 1024); "
+                    "ntt = configs[1]: DoubleCRT forward+inverse round trips at n=2^13, 8 primes, --batch DoubleCRTs per GPU (default there: 8192); "
                     "stress = configs[4]: m=2^16 (n=2^15), logQ=1024, p=65537 (35 primes, 43 digits) -- reporting only; "
                     "regression = configs[3] replayed at the metric ring: Regression::Regress (d = --reg-dim, --reg-rows data blocks) in waves, "
                     "every wave's groups sharded over the ranks (strong scaling)")
