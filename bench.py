@@ -404,6 +404,8 @@ def main():
     ap.add_argument("--reg-ring", default="metric", choices=["metric", "reference"], help="regression workload: replay at the metric ring (default) or on "
                     "the reference's own Test_Regression ring (p = 8423, m = 8422, logQ = 341: configs[3] itself)")
     ap.add_argument("--reg-p", type=int, default=8423, help="--reg-ring reference: the safe prime p (m = p - 1); 8423 = Test_Regression's, 32603 = phi(m) 16300")
+    ap.add_argument("--keys", default="generated", choices=["generated", "uniform"], help="key-switch matrix of the mult workloads: generated = KeySwitchSI::Init of a "
+                    "sampleHWt(64) secret key (what every reference driver holds; default); uniform = uniform residues in every row")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 plumbing)")
     ap.add_argument("--one-device", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0 (never for measurements)")
     ap.add_argument("--ntt-rows", type=int, default=0, help="extra: rows for a standalone forward-NTT timing (0 = use pipeline launches)")
@@ -474,10 +476,24 @@ def main():
         ctx.set_option(k, v)
     ksk = F.KeySwitchMatrix(ctx, 3, nd)
 
-    # key-switch matrix: generated on rank 0, RCCL-broadcast over xGMI into every rank's HBM copy
+    # key-switch matrix: generated on rank 0, RCCL-broadcast over xGMI into every rank's HBM copy.  --keys generated (default): what the
+    # reference's drivers hold -- KeySwitchSI(secretKey) (Test_AddMul.cpp:48-52 -> FHE-SI.cpp:153-226) of a sampleHWt(64) secret key, built on
+    # the device by the seeded batch key generation; --keys uniform: uniform residues in every row (no matrix a key generation can produce:
+    # the library then runs its general limbs, reported beside the line as surface.uniform_key_matrix)
     ksm_host = None
     if rank == 0:
-        ksm_host = rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n)
+        if args.keys == "generated":
+            one = np.zeros((n, 1), dtype=np.uint64)
+            one[0, 0] = 1
+            sk_seed = 0x5EC2E7C0FFEE1234
+            t = F.DoubleCRT(ctx).sample(0, 64, sk_seed, 1)                  # FHESISecKey::Init (FHE-SI.cpp:88-91)
+            t2 = t.copy()
+            t2.op(t, 2)
+            gen = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([F.DoubleCRT.from_poly(ctx, one), t, t2], t, LOGQ, sk_seed, sk_seed ^ 0x9E3779B97F4A7C15, 1000, DECOMP)
+            ksm_host = gen.download()
+            del gen, t, t2
+        else:
+            ksm_host = rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n)
     bcast_s = None
     if world > 1:
         from fhe_si_amd import shard
@@ -699,6 +715,20 @@ def main():
         if first_out is not None:
             # ... and the host-buffer results are those of the device-resident call on the same pairs
             surface["host_buffers_equal_device_batch"] = bool(np.array_equal(first_out, dout.download((8, 2, n, nl)))) if uniq >= 8 else None
+        if args.keys == "generated":
+            # the same timed step with a matrix of uniform residues (what rounds 1-3 measured): no key generation produces such rows, the
+            # library measures the coefficients and runs its general limbs (15 instead of 7 at the metric ring)
+            ku = F.KeySwitchMatrix(ctx, 3, nd).upload(rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n))
+            ctx.ct_mul_relin_dev(ku, LOGQ, P_PLAIN, da, db, dout, nl, B, DECOMP)
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ctx.ct_mul_relin_dev(ku, LOGQ, P_PLAIN, da, db, dout, nl, B, DECOMP)
+            ctx.sync()
+            surface["uniform_key_matrix"] = {"value": round(5 * B / (time.perf_counter() - t0), 1), "rows": ku.form()[1], "centred_limbs": ku.key_bits()[0]}
+            ctx.ct_mul_relin_dev(ksk, LOGQ, P_PLAIN, da, db, dout, nl, B, DECOMP)      # (the timed buffer's contents again, for the check below)
+            ctx.sync()
+            del ku
         exe = os.path.join(ROOT, "tests", "host", "test_addmul")
         if os.path.exists(exe):
             import re
@@ -749,11 +779,13 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("u32 (every transformed row is a row of 4-byte residues modulo a prime below 2^30: tensor half over 35 of them, key switch over four; coefficients are u64 limbs)"
                       if roofline_ntt_tensor else "u64 (chain-prime rows u64; key-switch rows u32 modulo four 30-bit primes)") if aux32 else "u64",
-            "data": f"synthetic ({uniq} distinct uniform ciphertext pairs per GPU repeated to the batch, uniform key rows)",
+            "data": f"synthetic ({uniq} distinct uniform ciphertext pairs per GPU repeated to the batch; key-switch matrix " +
+                    ("generated by KeySwitchSI::Init from a sampleHWt(64) secret key, FHE-SI.cpp:153-226)" if args.keys == "generated" else "of uniform residues)"),
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
                        if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
                        "L": L, "chain_bits": round(chain_bits, 1), "sp_nbits": args.sp_nbits, "ndigits": nd,
-                       "key_switch_form": {"form": F.KeySwitchMatrix.FORMS.get(ks_form, str(ks_form)), "rows": ks_rows, "limb_bits": ks_limb_bits}, "batch_per_gpu": B, "options": {k: ctx.get_option(k) for k in ("lanes", "ks_direct", "ks_residues", "ks_aux60", "tensor32", "batch_chunk")},
+                       "key_switch_form": {"form": F.KeySwitchMatrix.FORMS.get(ks_form, str(ks_form)), "rows": ks_rows, "limb_bits": ks_limb_bits,
+                                           "centred_limbs": ksk.key_bits()[0], "key_coefficient_bits": ksk.key_bits()[1]}, "keys": args.keys, "batch_per_gpu": B, "options": {k: ctx.get_option(k) for k in ("lanes", "ks_direct", "ks_residues", "ks_aux60", "tensor32", "batch_chunk")},
                        "timed_region_s": round(dt, 3), "blocks": nblk, "block_values": [round(B * args.steps * world / d, 1) for d in block_dt],
                        "gpu_phase_s": round(gpu_phase_s, 3), "per_rank_value": per_rank, "key_broadcast_s": bcast_s,
                        "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},

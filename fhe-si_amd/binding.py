@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "fhesi_dev_copy", "fhesi_prof_enable", "fhesi_prof_read",
     "fhesi_ct_add_dev", "fhesi_ct_mul_long_dev", "fhesi_rows_mul_long_dev", "fhesi_ct_automorph_dev", "fhesi_ct_automorph_key_switch_dev",
     "fhesi_ct_gather_dev", "fhesi_ct_mul_sum_relin_dev", "fhesi_encrypt_batch", "fhesi_decrypt_batch", "fhesi_dcrt_exp", "fhesi_selftest_aux32",
-    "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_ctx_copy_options", "fhesi_host_alloc", "fhesi_host_free", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
+    "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_ctx_copy_options", "fhesi_host_alloc", "fhesi_host_free", "fhesi_ksk_key_bits", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
     "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_comm_init_all", "fhesi_comm_from_rccl", "fhesi_comm_destroy", "fhesi_comm_rank",
     "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
@@ -143,6 +143,7 @@ def _load():
         "fhesi_ctx_copy_options": [_vp, _vp],
         "fhesi_host_alloc": [_vp, C.c_size_t, _vp],
         "fhesi_host_free": [_vp, _vp],
+        "fhesi_ksk_key_bits": [_vp, _vp, _vp],
         "fhesi_ksk_mark_dirty": [_vp],
         "fhesi_comm_init_all": [_i32, _vp, _vp],
         "fhesi_comm_from_rccl": [_vp, _vp],
@@ -738,6 +739,13 @@ class KeySwitchMatrix:
         f, r, b = C.c_int32(), C.c_int32(), C.c_int32()
         _ck(_load().fhesi_ksk_form(self.h, C.byref(f), C.byref(r), C.byref(b)))
         return f.value, r.value, b.value
+
+    def key_bits(self):
+        """(centred, nb) of the last table built from this matrix (fhesi_ksk_key_bits): centred limbs of a generated matrix, and the measured
+        size of its integer coefficients."""
+        c, b = C.c_int32(), C.c_int32()
+        _ck(_load().fhesi_ksk_key_bits(self.h, C.byref(c), C.byref(b)))
+        return bool(c.value), b.value
 
     def mark_dirty(self):
         """The rows were written through device_ptr (e.g. by a collective): derived tables are rebuilt at the next key switch."""

@@ -81,6 +81,8 @@ static const OptDesc kOptions[] = {
   {"dot32_half", "FHESI_DOT32_HALF", offsetof(CtxOptions, dot32_half), false},
   {"dot32_mfma", "FHESI_DOT32_MFMA", offsetof(CtxOptions, dot32_mfma), false},
   {"automorph_rows", "FHESI_AUTOMORPH_ROWS", offsetof(CtxOptions, automorph_rows), false},
+  {"ks_long_keys", "FHESI_KS_LONG_KEYS", offsetof(CtxOptions, ks_long_keys), false},
+  {"dot32_small", "FHESI_DOT32_SMALL", offsetof(CtxOptions, dot32_small), false},
   {"host_chunk", "FHESI_HOST_CHUNK", offsetof(CtxOptions, host_chunk), true},
   {"host_threads", "FHESI_HOST_THREADS", offsetof(CtxOptions, host_threads), false},
 };

@@ -70,6 +70,13 @@ extern "C" int fhesi_ksk_form(const fhesi_ksk* k, int32_t* form, int32_t* rows, 
   return 0;
 }
 
+extern "C" int fhesi_ksk_key_bits(const fhesi_ksk* k, int32_t* centred, int32_t* key_bits) {
+  if (!k) FHESI_FAIL("null key-switch matrix");
+  if (centred) *centred = k->aux_valid && k->aux_centred ? 1 : 0;
+  if (key_bits) *key_bits = k->aux_valid ? k->aux_key_bits : 0;
+  return 0;
+}
+
 // --------------------------------------------------------------------------------------------- ciphertext pipeline
 static i64 batch_chunk(fhesi_ctx* c, int ncol, bool ks32, i64 count = -1);
 static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes, const uint64_t* a, const uint64_t* b, uint64_t* out, int32_t nlimbs, int64_t count);
@@ -110,7 +117,7 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
   const_cast<fhesi_ksk*>(k)->last_form = ks_mode;
   if (ks_mode != KS_MODE_DIRECT) {
     fhesi_ksk* km = const_cast<fhesi_ksk*>(k);
-    if (!k->aux_valid || k->aux_mode != ks_mode || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ, ks_mode));
+    if (!k->aux_valid || k->aux_mode != ks_mode || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ || k->aux_long_opt != c->opt.ks_long_keys) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ, ks_mode));
     const int R = k->aux_rows;        // L chain-prime residues, or the limbs of the key's integer coefficients (limb mode)
     const i64 nrow = k->aux32 ? aux32_row_len(c) : n;      // the 32-bit auxiliary rows always have 2^14 elements (four 4-byte residues = two 8-byte ones)
     void *d_dig, *d_o;

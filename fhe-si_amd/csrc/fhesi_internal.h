@@ -70,6 +70,8 @@ struct ProfRec { int cls; double units; hipEvent_t e0, e1; };
 struct CtxOptions {
   long long host_chunk = 0;  // ciphertexts per stage of the host-buffer pipeline of fhesi_ct_mul_relin_batch (0 = derived from the batch)
   int host_threads = 0;     // threads that copy between the caller's pageable buffers and the pinned ring (0 = min(16, hardware threads))
+  int ks_long_keys = 0;     // 1: limbs cut from the key coefficient in [0, P) whatever its size (the general form; A/B and checker of the centred limbs)
+  int dot32_small = 0;      // key switch with at most 8 limbs (A/B): 0 = the plain 8-wave form (default), 1 = two groups of four waves on half of the tile's ciphertexts each, 2 = workgroups of four waves on tiles of 4 ciphertexts
   int ks_direct = 0;        // 1: per-chain-prime key-switch dot product (the reference's structure) instead of the auxiliary-prime path
   int ks_residues = 0;      // 1: auxiliary-prime key switch in residue mode (no limb mode)
   int ks_aux60 = 0;         // 1: two 60-bit auxiliary primes even where the four 30-bit primes apply
@@ -180,6 +182,13 @@ struct fhesi_ksk {
   // limb mode (kernels_ksaux.hip): the table is built from the key polynomial's INTEGER coefficients (toPoly over the chain) cut into
   // aux_rows limbs of aux_limb_bits bits instead of from its aux_rows = L chain-prime residues; 0 = residue mode
   int aux_rows = 0, aux_limb_bits = 0, aux_logQ = 0;
+  // centred limbs (kernels_aux32.hip): every integer coefficient of the matrix lies in [-2^nb, 2^nb] with nb far below the chain product --
+  // what KeySwitchSI::Init produces (FHE-SI.cpp:176-204: the polynomial is sampled modulo 2^logQ, b is reduced modulo 2^logQ) -- so the limbs
+  // are cut from the CENTRED integer (top limb signed): ceil(nb / B) of them instead of ceil(log2 P / B), 7 instead of 15 at the metric ring,
+  // and the dot product as an integer is below P / 2 by itself: no reduction modulo the chain product is left, only modulo 2^logQ
+  bool aux_centred = false;
+  int aux_key_bits = 0;                // nb of the matrix the table was built from (measured on the device at build time)
+  int aux_long_opt = 0;                // option ks_long_keys at build time (a change rebuilds the table)
   void* d_mfma = nullptr;              // (option dot32_mfma) the aux32 table as signed bytes in the int8 matrix-core operand layout + column sums (kernels_aux32.hip)
   size_t mfma_bytes = 0;
   bool mfma_valid = false;
@@ -210,7 +219,8 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0,
 constexpr i64 kDigitSubCt = 64;                   // ciphertexts per sub-chunk of the tiled 32-bit digit rows (launch_ntt32_fwd_digits <-> launch_dot32)
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* tiled, see ntt32_core.inc */,
                             i64 sub_units /* units (digit polynomials) per sub-chunk */);
-int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */);
+int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */, bool centred = false /* d_kint holds centred two's complement values: top limb signed */);
+int ks32_key_bits(fhesi_ctx* ctx, const u64* d_kint /* [count][W] centred two's complement */, i64 count, int W, int* nbits /* smallest nb with every value in [-2^nb, 2^nb] */);
 bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14 or 2^15, or a ring with lin_q set
 i64 aux32_row_len(const fhesi_ctx* ctx);            // 2^15 for n = 2^15 and for linear-convolution rings with 2 phi(m) - 1 > 2^14, else 2^14
 static const i64 kAux32N = 1 << 14;                // row length of the 32-bit auxiliary transforms

@@ -194,27 +194,71 @@ const u32* aux32_primes(fhesi_ctx* ctx) { return aux32_init(ctx) ? nullptr : ctx
 
 // ---------------------------------------------------------------------------------------------- key table and dot product
 // kint [2*ncol][n][W]: the key's integer coefficients;  rows32[a][(l*2 + r)*ncol + k][n] = (limb l of B bits) mod p_a
-__global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __restrict__ kint, u32* __restrict__ rows32, int ncol, int NLB, int B, int W, Aux32Primes pr, i64 n_src, i64 nrow) {
+// centred: kint holds CENTRED two's complement values in [-2^(B NLB), 2^(B NLB)] (ks32_key_bits): limbs 0 .. NLB - 2 are the unsigned B-bit fields,
+// the top limb is floor(x / 2^(B (NLB - 1))) in [-2^B, 2^B], a signed field of B + 2 bits whose residue is taken with its sign
+__global__ void __launch_bounds__(256) ks32_limb_scatter_kernel(const u64* __restrict__ kint, u32* __restrict__ rows32, int ncol, int NLB, int B, int W, Aux32Primes pr, i64 n_src, i64 nrow, int centred) {
   const i64 row = blockIdx.y;                 // (r * ncol + k) * NLB + l
   const int l = (int)(row % NLB);
   const i64 rk = row / NLB;
   const int k = (int)(rk % ncol), r = (int)(rk / ncol);
   const int s = B * l, wd = s >> 6, bt = s & 63;
   const i64 rows_per_a = (i64)NLB * 2 * ncol;
+  const bool top = centred && l == NLB - 1;
+  const int fb = top ? B + 2 : B;             // field width: 66 .. 102 bits
   for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < nrow; j += (i64)gridDim.x * blockDim.x) {
     const u64* x = kint + (rk * n_src + (j < n_src ? j : 0)) * W;          // key polynomials of n_src coefficients, zero above (linear convolution)
-    auto word = [&](int i) -> u64 { return (i < W && j < n_src) ? x[i] : 0; };
+    const u64 sfill = (centred && j < n_src && (x[W - 1] >> 63)) ? ~0ull : 0ull;      // words above W: the sign extension of a centred value
+    auto word = [&](int i) -> u64 { return j < n_src ? (i < W ? x[i] : sfill) : 0; };
     const u64 w0 = word(wd), w1 = word(wd + 1), w2 = word(wd + 2);
     const u64 lo = bt ? ((w0 >> bt) | (w1 << (64 - bt))) : w0;
     u64 hi = bt ? ((w1 >> bt) | (w2 << (64 - bt))) : w1;
-    hi &= ((u64)1 << (B - 64)) - 1;
+    hi &= ((u64)1 << (fb - 64)) - 1;
+    const bool neg = top && ((hi >> (fb - 65)) & 1);                        // sign bit of the top field
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const u64 p = pr.p[a];
       const u64 r64 = (u64)(((u128)1 << 64) % p);
-      rows32[((i64)a * rows_per_a + ((i64)l * 2 + r) * ncol + k) * nrow + j] = (u32)((lo % p + (hi % p) * r64) % p);
+      u64 v = (lo % p + (hi % p) * r64) % p;
+      if (neg) { const u64 m = (u64)(((u128)1 << fb) % p); v = (v + p - m) % p; }      // field - 2^fb
+      rows32[((i64)a * rows_per_a + ((i64)l * 2 + r) * ncol + k) * nrow + j] = (u32)v;
     }
   }
+}
+// nbits[0] = max over the values of the smallest nb with -2^nb <= x <= 2^nb, i.e. the bit length of |x| - 1 (x: W-word two's complement)
+__global__ void __launch_bounds__(256) ks32_key_bits_kernel(const u64* __restrict__ kint, i64 count, int W, int* __restrict__ nbits) {
+  int best = 0;
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += (i64)gridDim.x * blockDim.x) {
+    const u64* x = kint + g * W;
+    const bool neg = x[W - 1] >> 63;
+    // m = |x| - 1 as W words: x - 1 for x > 0, ~x = -x - 1 for x < 0; x = 0 counts as 0 bits
+    int nb = 0;
+    u64 borrow = neg ? 0 : 1;
+    bool zero = true;
+    for (int i = 0; i < W; ++i) zero = zero && x[i] == 0;
+    if (!zero) {
+      for (int i = 0; i < W; ++i) {
+        u64 w;
+        if (neg) w = ~x[i];
+        else { w = x[i] - borrow; borrow = (borrow && x[i] == 0) ? 1 : 0; }
+        if (w) nb = 64 * i + 64 - __clzll((long long)w);
+      }
+    }
+    best = nb > best ? nb : best;
+  }
+  for (int o = 32; o; o >>= 1) { const int v = __shfl_xor(best, o); best = v > best ? v : best; }
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(nbits, best);
+}
+int ks32_key_bits(fhesi_ctx* ctx, const u64* d_kint, i64 count, int W, int* nbits) {
+  int* d_n;
+  HIP_TRY(hipMalloc(&d_n, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(d_n, 0, sizeof(int), ctx->stream));
+  ks32_key_bits_kernel<<<1024, 256, 0, ctx->stream>>>(d_kint, count, W, d_n);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(nbits, d_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_n);
+  if (e != hipSuccess) FHESI_FAIL("key switch: measuring the key coefficients failed: %s", hipGetErrorString(e));
+  return 0;
 }
 // rows of one prime [(l*2 + r)*ncol + k][n]  ->  tiled [l][slice][r][k][64]
 __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict__ src, u32* __restrict__ dst, int ncol, i64 nrow) {
@@ -245,7 +289,10 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 #ifndef DOT32_MASK_IDLE
 #define DOT32_MASK_IDLE 1
 #endif
-template <int CT, int NW, bool HALF>
+// CSPLIT (few limbs: NLB <= 2 NW / CSPLIT in the HALF form): the waves form CSPLIT groups, every group walks the limbs for its own CT / CSPLIT
+// ciphertexts of the tile -- with 7 limbs (centred limbs of a generated matrix) and CSPLIT = 2 all eight waves carry multiply-adds where the plain
+// form leaves waves 4 .. 7 without a limb.  A key word then feeds CT / CSPLIT ciphertexts per wave (the second group's loads hit in L1 / L2).
+template <int CT, int NW, bool HALF, int CSPLIT = 1>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
                                                          u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */, int sub_lg /* log2 of the ciphertexts per sub-chunk of the tiled digit rows */) {
@@ -307,7 +354,10 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   __syncthreads();
   const u32 r48 = (u32)pr.r48[a];                 // 2^48 mod p: 30 bits, one multiply-add
   const u32 mont = pr.mont[a];
-  for (int lw = w; lw * (HALF ? 2 : 1) < NLB; lw += NW) {
+  constexpr int CW = CT / CSPLIT, NWG = NW / CSPLIT;      // ciphertexts per wave, waves per group
+  static_assert(CT % CSPLIT == 0 && NW % CSPLIT == 0, "wave groups");
+  const int wl = w % NWG, c0 = (w / NWG) * CW;            // the wave's place in its group; first ciphertext of the group
+  for (int lw = wl; lw * (HALF ? 2 : 1) < NLB; lw += NWG) {
     const int lraw = HALF ? 2 * lw + (int)(lane >> 5) : lw;          // HALF: the upper lanes of the last wave may have no limb: they repeat the lower one's
     const bool lok = lraw < NLB;
 #if DOT32_MASK_IDLE
@@ -318,17 +368,17 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     const int l = lok ? lraw : NLB - 1;
     const u32* kp0 = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + (HALF ? hf * 32 + ln : lane);      // row r = 0; row 1 follows after ncol slices
     const u32* kp1 = kp0 + ((i64)ncol << 6);
-    u64 tot[2][CT];
-    u32 th[2][CT];
+    u64 tot[2][CW];
+    u32 th[2][CW];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) { tot[r][c] = 0; th[r][c] = 0; }
+      for (int c = 0; c < CW; ++c) { tot[r][c] = 0; th[r][c] = 0; }
     auto fold = [&]() {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { th[r][c] += (u32)(tot[r][c] >> 48); tot[r][c] &= 0x0000ffffffffffffull; }
+        for (int c = 0; c < CW; ++c) { th[r][c] += (u32)(tot[r][c] >> 48); tot[r][c] &= 0x0000ffffffffffffull; }
     };
     // Key words are fetched one 4-column chunk ahead into two register sets used alternately (no copies: with a copy at the end of
     // the loop body the compiler waits for the fetch at the START of the body and the L2 latency is exposed once per chunk).
@@ -347,16 +397,16 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     auto macc = [&](const u32 (&x)[2][CH], int k0) {
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
-        u32 d[CT];
+        u32 d[CW];
 #if defined(DOT32_ABLATE) && (DOT32_ABLATE & 2)      // ablation: no LDS reads
 #pragma unroll
-        for (int c = 0; c < CT; ++c) d[c] = x[0][u] + (u32)c * 40503u;
+        for (int c = 0; c < CW; ++c) d[c] = x[0][u] + (u32)c * 40503u;
 #else
 #pragma unroll
-        for (int c = 0; c < CT; ++c) d[c] = dl32[DL32(k0 + u, c)];
+        for (int c = 0; c < CW; ++c) d[c] = dl32[DL32(k0 + u, c0 + c)];
 #endif
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { tot[0][c] += (u64)x[0][u] * d[c]; tot[1][c] += (u64)x[1][u] * d[c]; }
+        for (int c = 0; c < CW; ++c) { tot[0][c] += (u64)x[0][u] * d[c]; tot[1][c] += (u64)x[1][u] * d[c]; }
       }
     };
     // The 8-column pairs are taken in an order ROTATED by the tile number.  The workgroups of the 8 ciphertext tiles of a (slice, prime)
@@ -375,19 +425,19 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
       // ahead measured the same; left to itself the compiler reads a column right before its multiply-adds in the second chunk).  The
       // next chunk of keys is fetched unconditionally -- after the last pair one unused chunk -- because a conditional fetch costs eight
       // register moves per round and 16 registers (-2.5 % together with the prefetch: -4 %).
-      u32 d[2][CT];
+      u32 d[2][CW];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) d[0][c] = dl32[DL32(kb, c)];
+      for (int c = 0; c < CW; ++c) d[0][c] = dl32[DL32(kb, c0 + c)];
 #pragma unroll
       for (int u = 0; u < 2 * CH; ++u) {
         if (u == CH) loadc(xa, i + 1 < npair ? pk(i + 1) : (n2 < nfull ? n2 : 0));
         if (u + 1 < 2 * CH) {
 #pragma unroll
-          for (int c = 0; c < CT; ++c) d[(u + 1) & 1][c] = dl32[DL32(kb + u + 1, c)];
+          for (int c = 0; c < CW; ++c) d[(u + 1) & 1][c] = dl32[DL32(kb + u + 1, c0 + c)];
         }
         const u32 x0 = u < CH ? xa[0][u & (CH - 1)] : xb[0][u & (CH - 1)], x1 = u < CH ? xa[1][u & (CH - 1)] : xb[1][u & (CH - 1)];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { tot[0][c] += (u64)x0 * d[u & 1][c]; tot[1][c] += (u64)x1 * d[u & 1][c]; }
+        for (int c = 0; c < CW; ++c) { tot[0][c] += (u64)x0 * d[u & 1][c]; tot[1][c] += (u64)x1 * d[u & 1][c]; }
       }
       if (i & 1) fold();                             // 16 columns since the last fold
     }
@@ -397,22 +447,22 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     for (int k = nfull; k < ncol; ++k) {             // at most 3 columns
       const u32 x0 = kp0[k << 6], x1 = kp1[k << 6];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) { const u32 d = dl32[DL32(k, c)]; tot[0][c] += (u64)x0 * d; tot[1][c] += (u64)x1 * d; }
+      for (int c = 0; c < CW; ++c) { const u32 d = dl32[DL32(k, c0 + c)]; tot[0][c] += (u64)x0 * d; tot[1][c] += (u64)x1 * d; }
     }
     fold();                                          // at most 15 columns since the last one; leaves every total below 2^48
     u32* obase = out + ((((i64)l * 4 + a) << (lognsl + 6)) + soff) + ln;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        if (ct0 + c < count) {
+      for (int c = 0; c < CW; ++c) {
+        if (ct0 + c0 + c < count) {
           // (th 2^48 + tot) 2^-32 mod p by one Montgomery step: v = tot + th (2^48 mod p) < 2^54, m = v (-p^-1) mod 2^32,
           // (v + m p) / 2^32 < p + 2^22.  The factor 2^-32 is undone by the inverse transform's final constant (ntt32_inv_kernel, mont).
           const u64 v = tot[r][c] + (u64)th[r][c] * r48;
           const u32 mq = (u32)v * mont;
           u32 o = (u32)((v + (u64)mq * p) >> 32);
           o = min(o, o - p);                          // o < 2p: o - p wraps to a large value exactly when o < p
-          u32* q = obase + (((i64)((ct0 + c) * 2 + r) * NLB * 4) << (lognsl + 6));
+          u32* q = obase + (((i64)((ct0 + c0 + c) * 2 + r) * NLB * 4) << (lognsl + 6));
           if (!HALF || lok) __builtin_nontemporal_store(o, q);
         }
       }
@@ -420,7 +470,7 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
 #undef DL32
 }
 
-int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp) {
+int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp, bool centred) {
   FHESI_TRY(aux32_init(ctx));
   k->mfma_valid = false;
   const int ncol = k->ncomp * k->ndigits;
@@ -428,7 +478,7 @@ int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, in
   u32* rows32 = (u32*)k->d_aux;
   if ((size_t)4 * rows_per_a * nrow * 4 > k->aux_bytes) FHESI_FAIL("aux32: key table does not fit");
   dim3 grid(64, (unsigned)(2 * ncol * NLB));
-  ks32_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(d_kint, rows32, ncol, NLB, B, W, ctx->aux32->pr, ctx->phim, nrow);
+  ks32_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(d_kint, rows32, ncol, NLB, B, W, ctx->aux32->pr, ctx->phim, nrow, centred ? 1 : 0);
   HIP_TRY(hipGetLastError());
   for (int a = 0; a < 4; ++a) FHESI_TRY(launch_ntt32_fwd(ctx, rows32 + (i64)a * rows_per_a * nrow, rows_per_a, 1, a));
   for (int a = 0; a < 4; ++a) {
@@ -589,12 +639,12 @@ static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig,
   HIP_TRY(hipGetLastError());
   return 0;
 }
-template <int CT, int NW, bool HALF>
+template <int CT, int NW, bool HALF, int CSPLIT = 1>
 static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)ncol * CT * (HALF ? 32 : 64) * 4;
   static std::atomic<unsigned long long> attr_done{0};
   if (!(attr_done.load() >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW, HALF, CSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.fetch_or(1ull << ctx->device);
   }
   const i64 nrow = aux32_row_len(ctx);
@@ -605,8 +655,8 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   static_assert((kDigitSubCt & (kDigitSubCt - 1)) == 0, "sub-chunks of a power of two");
   int sub_lg = 0;
   while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
-  PROF_KERNEL(ctx, PROF_DOT, dot32_kernel2<CT, NW, HALF>);
-  dot32_kernel2<CT, NW, HALF><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, sub_lg);
+  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel2<CT, NW, HALF, CSPLIT>));
+  dot32_kernel2<CT, NW, HALF, CSPLIT><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -838,6 +888,15 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   if (ctx->opt.dot32_v3 && (size_t)ncol * 4 * 256 <= 80 * 1024) return launch_dot32_v3(ctx, k, d_dig, ncol, count, d_out);
   // ciphertexts per LDS tile: 8 while ncol * 8 digit slices fit (half slices of 128 bytes in 80 KiB, two workgroups per CU; whole slices
   // of 256 bytes in 160 KiB with option dot32_half = 0): ncol <= 80; else 4 (ncol <= 160)
+  // at most 8 limbs (centred limbs of a generated matrix: 7 at the metric ring): four of the eight waves carry them all, two each.  Measured at
+  // the metric ring (profiles/r04_ab_dot_few_limbs.txt, ms per launch of 1024): the plain 8-wave form 6.4-6.7 (waves 4 .. 7 only help to load the
+  // tile), two groups of four waves on half the ciphertexts each 7.0, workgroups of four waves on tiles of 4 / 8 ciphertexts 6.8 / 6.9, tiles of 16
+  // 7.4-7.8: with half the multiply-adds gone the kernel runs at the rate the L2 delivers the key words (80 GB per launch through L2 -> L1),
+  // so the plain form stays; option dot32_small selects the others (A/B)
+  if (ctx->opt.dot32_half && k->aux_rows <= 8 && ctx->opt.dot32_small != 0) {
+    if (ctx->opt.dot32_small == 1 && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true, 2>(ctx, k, d_dig, ncol, count, d_out);      // two wave groups of four ciphertexts each
+    if (ctx->opt.dot32_small == 2 && (size_t)ncol * 4 * 128 <= 40 * 1024) return launch_dot32_t<4, 4, true>(ctx, k, d_dig, ncol, count, d_out);          // four workgroups of four waves per CU
+  }
   if (ctx->opt.dot32_half && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true>(ctx, k, d_dig, ncol, count, d_out);
   if ((size_t)ncol * 8 * 256 <= 160 * 1024) return launch_dot32_t<8, 16, false>(ctx, k, d_dig, ncol, count, d_out);
   if (ctx->opt.dot32_half && (size_t)ncol * 4 * 128 <= 80 * 1024) return launch_dot32_t<4, 8, true>(ctx, k, d_dig, ncol, count, d_out);

@@ -905,14 +905,126 @@ static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi
   HIP_TRY(hipGetLastError());
   return 0;
 }
+// ---- centred limbs (fhesi_ksk::aux_centred): the limb product sums V_l = sum_k digit_k (*) K_{k,l} come from the CENTRED integer coefficients
+// of the matrix (top limb signed), and S = sum_l V_l 2^(B l) is below P / 2 in magnitude by the build-time check -- S is its own centred
+// residue modulo the chain product, so toPoly + ReduceCoefficients (FHE-SI.cpp:255-256) leave exactly the centred residue of S modulo 2^logQ:
+// only the words below bit logQ are formed, no quotient by P, no comparison with P.  V_l: Garner over the four 30-bit residues, centred,
+// + 2^119 to make it non-negative (the constant sum_l 2^(119 + B l) is taken off the start value).  fold: the linear-convolution rings,
+// on the residues, as in ks_recombine_generic_kernel.  NWORDS = 64-bit words below bit logQ (8: logQ <= 512, 16: logQ <= 1024).
+struct CentredConsts { u64 d[16]; };
+template <int NWORDS>
+__global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __restrict__ o32, i64 n, i64 nrow, i64 fold_q, int LQ, int B, int NLB, u64 half_hi, u64 half_lo,
+                                                                   u64 a_hi, u64 a_lo, CentredConsts cc, u64* __restrict__ out, int nl_out, Garner32 gc) {
+  const i64 poly = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  u64 x[NWORDS];
+#pragma unroll
+  for (int i = 0; i < NWORDS; ++i) x[i] = cc.d[i];
+  const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
+  const u32* base32 = o32 + poly * NLB * 4 * nrow;
+  u32 cur[4] = {0, 0, 0, 0}, nxt[4] = {0, 0, 0, 0};
+  auto fetch = [&](int l, u32 (&v)[4]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const u32* __restrict__ row = base32 + (i64)(l * 4 + a) * nrow;
+      if (!fold_q) { v[a] = row[j]; continue; }
+      const u32 p = gc.p[a];
+      u32 r;
+      if (fold_q > 0) {        // m = 2q':  S_j - S_(j+q') -+ (S_n - S_(n+q'))
+        const u32 s0 = row[j], s1 = row[j + fold_q], t0 = row[n], t1 = n + fold_q < nrow ? row[n + fold_q] : 0u;
+        r = s0 + (p - s1) + ((j & 1) ? t0 + (p - t1) : t1 + (p - t0));
+      } else {                 // m prime:  S_j + S_(j+m) - S_(m-1)
+        const u32 s0 = row[j], s1 = j - fold_q < nrow ? row[j - fold_q] : 0u, t0 = row[n];
+        r = s0 + s1 + (p - t0);
+      }
+      r = r >= 2 * p ? r - 2 * p : r;
+      v[a] = r >= p ? r - p : r;
+    }
+  };
+  fetch(0, cur);
+  for (int l = 0; l < NLB; ++l) {
+    if (l + 1 < NLB) fetch(l + 1, nxt);
+    const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
+    const u32 x1 = cur[0];
+    const u32 x2 = g32_mul(g32_sub(cur[1], x1, p1), gc.c[0], gc.cp[0], p1);
+    const u32 x3 = g32_mul(g32_sub(g32_mul_lazy(g32_sub(cur[2], x1, p2), gc.c[1], gc.cp[1], p2), x2, p2), gc.c[2], gc.cp[2], p2);
+    const u32 x4 = g32_mul(g32_sub(g32_mul_lazy(g32_sub(g32_mul_lazy(g32_sub(cur[3], x1, p3), gc.c[3], gc.cp[3], p3), x2, p3), gc.c[4], gc.cp[4], p3), x3, p3),
+                           gc.c[5], gc.cp[5], p3);
+    u128 V = (u128)((u64)x3 + (u64)p2 * x4) * ((u64)p0 * p1) + ((u64)x1 + (u64)p0 * x2);
+    if (V > half) V -= A;
+    V += (u128)1 << 119;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) cur[a] = nxt[a];
+    const int s = B * l, wd = s >> 6, bt = s & 63;
+    const u64 lo = (u64)V, hi = (u64)(V >> 64);
+    const u64 q0 = lo << bt, q1 = bt ? ((lo >> ((64 - bt) & 63)) | (hi << bt)) : hi, q2 = bt ? (hi >> ((64 - bt) & 63)) : 0;
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < NWORDS; ++i) {              // (words above bit logQ are not formed: the sum is taken modulo 2^(64 NWORDS))
+      if (i >= wd) {
+        const u64 add = i == wd ? q0 : (i == wd + 1 ? q1 : (i == wd + 2 ? q2 : 0));
+        const u64 s1 = x[i] + add, c1 = s1 < add, s2 = s1 + carry, c2 = s2 < carry;
+        x[i] = s2;
+        carry = c1 | c2;
+      }
+    }
+  }
+  // centred residue modulo 2^logQ, two's complement, coefficient-major (mode 2 of crt_store_fixed)
+  const int sw = (LQ - 1) >> 6, sb = (LQ - 1) & 63;
+  u64 hbit = 0;
+#pragma unroll
+  for (int i = 0; i < NWORDS; ++i) if (i == sw) hbit = (x[i] >> sb) & 1;
+  u64* o = out + (poly * n + j) * nl_out;
+#pragma unroll
+  for (int i = 0; i < NWORDS; ++i) {
+    if (i < nl_out) {
+      u64 val = x[i];
+      const int bits_left = LQ - 64 * i;
+      if (bits_left <= 0) val = hbit ? ~0ull : 0ull;
+      else if (bits_left < 64) { const u64 mask = (1ull << (bits_left & 63)) - 1; val = hbit ? (val | ~mask) : (val & mask); }
+      o[i] = val;
+    }
+  }
+  for (int i = NWORDS; i < nl_out; ++i) o[i] = hbit ? ~0ull : 0ull;
+}
+static int garner32_consts(fhesi_ctx* ctx, Garner32* gc);
+static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
+  Garner32 gc{};
+  if (garner32_consts(ctx, &gc)) return 1;
+  const u128 A = (u128)((u64)gc.p[0] * gc.p[1]) * ((u64)gc.p[2] * gc.p[3]), half = (A - 1) / 2;
+  const int LQ = k->aux_logQ, B = k->aux_limb_bits, NLB = k->aux_rows, NW = LQ <= 512 ? 8 : 16;
+  if (LQ > 1024) FHESI_FAIL("key switch, centred limbs: logQ=%d above 1024", LQ);
+  // start value: - sum_l 2^(119 + B l)  modulo 2^(64 NW)
+  CentredConsts cc{};
+  {
+    std::vector<u64> D((size_t)NW, 0);
+    for (int l = 0; l < NLB; ++l) {
+      const int bit = 119 + B * l;
+      if (bit >= 64 * NW) continue;
+      u64 borrow = (u64)1 << (bit & 63);
+      for (int i = bit >> 6; i < NW && borrow; ++i) { const u64 v = D[i]; D[i] = v - borrow; borrow = v < borrow ? 1 : 0; }
+    }
+    for (int i = 0; i < NW; ++i) cc.d[i] = D[i];
+  }
+  const i64 nrow = aux32_row_len(ctx);
+  const i64 fold = k->aux_fold;
+  dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
+  if (NW == 8) ks_recombine_centred_kernel<8><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  else ks_recombine_centred_kernel<16><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // does the recombination of this matrix take the tail of the 2^15-point inverse in its loader (so that launch_ntt32_inv leaves it out)?
 bool ks_recombine_takes_tail(const fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k) {
-  return !k->aux_fold && k->aux32 && ctx->pow2 && aux32_row_len(ctx) == 2 * kAux32N && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30;
+  return !k->aux_centred && !k->aux_fold && k->aux32 && ctx->pow2 && aux32_row_len(ctx) == 2 * kAux32N && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30;
 }
 int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out, bool tail_pending) {
   if (!npolys) return 0;
   if (tail_pending != ks_recombine_takes_tail(ctx, t, k) && tail_pending) FHESI_FAIL("key switch: rows without their tail stage reached a recombination that does not take it");
   if (tail_pending) { ProfScope prof(ctx, PROF_CRT, (double)npolys); return launch_ks_recombine_t<34, 1024, 72, 30, true, 1>(ctx, t, k, d_o, npolys, d_out, nl_out); }
+  if (k->aux_centred) { ProfScope prof(ctx, PROF_CRT, (double)npolys); return launch_ks_recombine_centred(ctx, k, d_o, npolys, d_out, nl_out); }
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
   // compile-time instantiations for the shapes the benchmarks run (the plan of ks_limb_plan at the metric and stress chains) ...
   if (!k->aux_fold && k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);

@@ -351,13 +351,17 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ, int mode
   if (mode == KS_MODE_DIRECT) FHESI_FAIL("key switch: no auxiliary-prime table for the direct path");
   const bool limb = mode != KS_MODE_RESIDUE60 && ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, mode == KS_MODE_LIMB32 ? aux32_primes(ctx) : nullptr);
   if ((mode != KS_MODE_RESIDUE60) != limb || (limb && plan.a32 != (mode == KS_MODE_LIMB32))) FHESI_FAIL("key switch: the limb plan does not match the selected form");
-  const int R = limb ? plan.NLB : L;                          // output rows per (ciphertext, key row, auxiliary prime)
-  {
+  int R = limb ? plan.NLB : L;                                // output rows per (ciphertext, key row, auxiliary prime)
+  bool centred = false;
+  int key_bits = 0;
+  auto alloc_table = [&]() -> int {
     // table size: residue / limb rows for two 8-byte (or four 4-byte) auxiliary residues; 2^14-element rows on the linear-convolution rings
     const size_t need = (size_t)2 * R * 2 * ncol * (plan.a32 && limb ? aux32_row_len(ctx) : n) * 8;
     if (k->d_aux && k->aux_bytes < need) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(k->d_aux)); k->d_aux = nullptr; }
     if (!k->d_aux) { HIP_TRY(hipMalloc(&k->d_aux, need)); k->aux_bytes = need; }
-  }
+    return 0;
+  };
+  if (!(limb && plan.a32)) FHESI_TRY(alloc_table());           // (the 30-bit limb form sizes its table after it has looked at the key's coefficients)
   if (!k->d_aux_consts) {
     HIP_TRY(hipMalloc(&k->d_aux_consts, (size_t)(L + 2) * 8));
     std::vector<u64> h(L + 2, 0);
@@ -376,8 +380,28 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ, int mode
     const int W = t->W;
     u64* kint = nullptr;                                        // the key's integer coefficients: one-off scratch
     HIP_TRY(hipMalloc(&kint, (size_t)2 * ncol * n * W * 8));
-    int rc = launch_crt(ctx, t, (const u64*)tmp, L, nullptr, 2 * ncol, 0, 1, 0, kint, W);
-    if (!rc && plan.a32) rc = ks32_build(ctx, k, kint, W, plan.B, R, tmp);
+    int rc = 0;
+    if (plan.a32 && !ctx->opt.ks_long_keys) {
+      // Centred limbs: KeySwitchSI::Init draws its polynomial modulo 2^logQ and reduces b modulo 2^logQ (FHE-SI.cpp:176-204), so the integer
+      // coefficients of a generated matrix lie in [-2^(logQ-1), 2^(logQ-1)] where the chain product has more than twice as many bits.  The
+      // size is MEASURED here, on the matrix at hand (any matrix is legal input): if ceil(nb / B) limbs of the centred integer are fewer
+      // than the plan's, and the dot product  sum_k digit_k (*) K_k  of such coefficients is below P / 2 by itself, the table is built from
+      // the centred integers -- then S needs no reduction modulo P at all, only modulo 2^logQ (ks_recombine_centred_kernel).
+      rc = launch_crt(ctx, t, (const u64*)tmp, L, nullptr, 2 * ncol, 0, 0, 0, kint, W);
+      if (!rc) rc = ks32_key_bits(ctx, kint, (i64)2 * ncol * n, W, &key_bits);
+      if (!rc) {
+        std::vector<u64> P{1};
+        for (int i = 0; i < L; ++i) P = hm::bn_mul_small(P, ctx->q[i]);
+        int pbits = (int)(P.size() - 1) * 64;
+        for (u64 top = P.back(); top; top >>= 1) ++pbits;
+        const int nlc = std::max(1, (key_bits + plan.B - 1) / plan.B);
+        // |S| <= terms 2^nb  (terms = ncol n 2^digit_bits, x 4 on the folded rings: mbits - 1 bits)  must stay below P / 2
+        if (nlc < plan.NLB && plan.mbits + key_bits + 1 < pbits && logQ <= 1024) { centred = true; R = nlc; }
+      }
+    }
+    if (!rc && !centred) rc = launch_crt(ctx, t, (const u64*)tmp, L, nullptr, 2 * ncol, 0, 1, 0, kint, W);
+    if (!rc && plan.a32) rc = alloc_table();
+    if (!rc && plan.a32) rc = ks32_build(ctx, k, kint, W, plan.B, R, tmp, centred);
     else if (!rc) {
       dim3 grid((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), (unsigned)(2 * ncol * R));
       ks_limb_scatter_kernel<<<grid, 256, 0, ctx->stream>>>(kint, k->d_aux, ncol, R, plan.B, W, n, ctx->q[0], ctx->q[1]);
@@ -414,6 +438,9 @@ int ksaux_build(fhesi_ctx* ctx, fhesi_ksk* k, int digit_bits, int logQ, int mode
     HIP_TRY(hipGetLastError());
   }
   k->aux32 = limb && plan.a32;
+  k->aux_centred = centred;
+  k->aux_long_opt = ctx->opt.ks_long_keys;
+  k->aux_key_bits = key_bits;
   k->aux_fold = k->aux32 ? (ctx->lin_prime ? -ctx->lin_q : ctx->lin_q) : 0;      // (negative: the fold of a prime m)
   const int* d_slot = (const int*)(k->d_aux_consts + L);
   const i64 rows_per_a = (i64)R * 2 * ncol;

@@ -154,6 +154,13 @@ size_t fhesi_ksk_bytes(const fhesi_ksk* k);
  * key coefficient, limb_bits = their width (0 in residue mode).  All forms give the reference's bits; a caller (bench, tests) reads this to
  * state which one it measured.  Before the first key switch: form -1. */
 int fhesi_ksk_form(const fhesi_ksk* k, int32_t* form, int32_t* rows, int32_t* limb_bits);
+/* Form 1 looks at the matrix it is given: KeySwitchSI::Init (FHE-SI.cpp:176-204) samples its polynomial modulo 2^logQ and reduces b modulo
+ * 2^logQ, so the integer coefficients of a generated matrix lie in [-2^(logQ-1), 2^(logQ-1)] -- less than half the bits of the chain
+ * product.  The library measures the coefficients when it builds its table; when they are that small it cuts the limbs from the CENTRED
+ * integers (7 instead of 15 at the metric ring; `rows` above says how many) and the dot product needs no reduction modulo the chain product.
+ * Any other matrix (uniform residues, say) takes the general limbs.  centred: 1 if the last table was built that way; key_bits: the measured
+ * nb with every coefficient in [-2^nb, 2^nb] (0 if the table was not measured).  Option "ks_long_keys" = 1 forces the general limbs. */
+int fhesi_ksk_key_bits(const fhesi_ksk* k, int32_t* centred, int32_t* key_bits);
 
 int fhesi_selftest_aux32(fhesi_ctx* c);                                              /* diagnostic: checks the 32-bit auxiliary transforms of the key switch
                                                                                         (n = 2^14 only) as a ring isomorphism; 0 = ok */

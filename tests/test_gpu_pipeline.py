@@ -437,3 +437,77 @@ def test_host_buffer_pipeline_equals_the_device_batch(count, host_chunk):
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[:k2], b[:k2]), want[:k2])
     big = np.concatenate([a, a])
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, big, np.concatenate([b, b])), np.concatenate([want, want]))
+
+
+@pytest.mark.parametrize("m,logQ,p", [(32768, 512, 23), (32768, 130, 23), (1 << 16, 300, 65537), (8422, 341, 8423), (101, 80, 23)])
+def test_key_switch_centred_limbs_of_generated_matrices(m, logQ, p):
+    """KeySwitchSI::Init (FHE-SI.cpp:176-204) samples its polynomial modulo 2^logQ and reduces b modulo 2^logQ: the integer coefficients of a
+    generated key-switch matrix lie in [-2^(logQ-1), 2^(logQ-1)], fewer than half the bits of the chain product.  The library measures the
+    coefficients of the matrix it is given; when they are that small the limbs of the exact-integer key switch are cut from the CENTRED
+    integers (7 instead of 15 at the metric ring) and the dot product needs no reduction modulo the chain product (kernels_aux32.hip:
+    ks32_key_bits, kernels_crt.hip: ks_recombine_centred_kernel).  Same bits as the oracle, as the general limbs (option ks_long_keys) and as
+    the per-prime dot product of the reference's structure (ks_direct) -- on random coefficients of that size, on the extremes -2^(logQ-1),
+    2^(logQ-1) - 1 and +2^(logQ-1) (the value -poly takes when poly = -2^(logQ-1)) in every position of some columns, on digits at their
+    maximum, and on a matrix with ONE coefficient a few bits larger (one more limb, or the general form: still exact)."""
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 1234 + m, 2)
+    if m > 2000 and (m & (m - 1)) != 0:
+        orc.set_bluestein_fft(True)
+    n, L = ctx.phim, ctx.L
+    W = L + 2
+    rng = np.random.default_rng(m + logQ)
+    half = 1 << (logQ - 1)
+    ncol = 3 * nd
+
+    def rows_of(ints):
+        return orc.dcrt_from_poly(O.ints_to_limbs(ints, W))
+
+    # a generated-looking matrix: uniform in [-2^(logQ-1), 2^(logQ-1)), with the extremes in a few columns
+    km = np.empty((2, ncol, L, n), dtype=np.uint64)
+    for r in range(2):
+        for c in range(ncol):
+            km[r, c] = orc.dcrt_from_poly(P.rand_limbs(rng, (n,), W, logQ))
+    km[0, 0] = rows_of([-half] * n)
+    km[1, 0] = rows_of([half - 1] * n)
+    km[0, 1] = rows_of([half if i % 2 else -half for i in range(n)])          # +2^(logQ-1): the value -poly takes when poly = -2^(logQ-1)
+    km[1, ncol - 1] = rows_of([(-1) ** i * (half - i) for i in range(n)])
+    km[0, ncol - 1] = rows_of([0] * n)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(km)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    form, rows, bits = ksk.form()
+    centred, nb = ksk.key_bits()
+    assert form == 1 and centred and nb == logQ - 1, (form, rows, bits, centred, nb)
+    assert rows == -(-nb // bits)                              # ceil(nb / B) limbs
+    for c in range(2):
+        assert np.array_equal(got[c], orc.ct_mul_relin(km, a[c], b[c], logQ, p)), c
+    # digits at their maximum against the extreme columns: scaled-down parts with every byte 0xff
+    tp = np.zeros((1, 3, L, n), dtype=np.uint64)
+    allones = (1 << logQ) - 1
+    for part in range(3):
+        tp[0, part] = rows_of([allones << logQ] * n)           # ScaleDown leaves 2^logQ - 1 (every digit at its maximum)
+    dtp = ctx.upload(tp)
+    out = ctx.alloc(2 * n * nl * 8)
+    ctx.apply_key_switch_dev(ksk, logQ, dtp, 1, out, nl)
+    want = orc.apply_key_switch(km, tp[0], logQ, nl)
+    assert np.array_equal(out.download((2, n, nl)), want)
+    # the general limbs and the reference's per-prime structure on the same matrix
+    ctx.set_option("ks_long_keys", 1)
+    long_ = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert not ksk.key_bits()[0] and ksk.form()[1] > rows
+    ctx.set_option("ks_long_keys", 0)
+    assert np.array_equal(long_, got)
+    ctx.set_option("ks_direct", 1)
+    direct = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    ctx.set_option("ks_direct", 0)
+    assert np.array_equal(direct, got)
+    # one coefficient a few bits larger: the measurement sees it
+    km2 = km.copy()
+    km2[1, 2] = rows_of([0] * (n - 1) + [-(half << 5) - 3])
+    ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(km2)
+    got2 = ctx.ct_mul_relin(ksk2, logQ, p, a, b)
+    assert ksk2.key_bits()[1] == logQ + 5
+    assert np.array_equal(got2[0], orc.ct_mul_relin(km2, a[0], b[0], logQ, p))
+    # a matrix of uniform residues (the other tests' matrices) is measured too, and takes the general limbs
+    ksk3 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    got3 = ctx.ct_mul_relin(ksk3, logQ, p, a, b)
+    assert not ksk3.key_bits()[0]
+    assert np.array_equal(got3[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
