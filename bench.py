@@ -199,7 +199,36 @@ class _CountingBackend:
         return first
 
 
-def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, dist, torch, F, chain_bits):
+class KeyGen:
+    """The key-switch matrices the reference's drivers hold (Test_AddMul.cpp:48-52, Regression.h:68-80), generated on the device:
+    a sampleHWt(64) secret key t (FHE-SI.cpp:88-91), KeySwitchSI(secretKey) = Init((1, t, t^2) -> t) (FHE-SI.cpp:211-226) and
+    KeySwitchSI(secretKey, k) = Init((1, t(X^k)) -> t) (:228-239), randomness from the seeded generator (csrc/philox.h)."""
+
+    def __init__(self, ctx, F, n, nd):
+        self.ctx, self.F, self.nd = ctx, F, nd
+        self.seed, self.pub_seed, self.next = 0x5EC2E7C0FFEE1234, 0x5EC2E7C0FFEE1234 ^ 0x9E3779B97F4A7C15, 1000
+        one = np.zeros((n, 1), dtype=np.uint64)
+        one[0, 0] = 1
+        self.one = F.DoubleCRT.from_poly(ctx, one)
+        self.t = F.DoubleCRT(ctx).sample(0, 64, self.seed, 1)
+
+    def _matrix(self, src):
+        m = self.F.KeySwitchMatrix(self.ctx, len(src), self.nd).init_batch_seeded(src, self.t, LOGQ, self.seed, self.pub_seed, self.next, DECOMP)
+        self.next += len(src) * self.nd                                     # (one counter for every column ever drawn from this seed)
+        return m.download()
+
+    def s2_matrix(self):
+        t2 = self.t.copy()
+        t2.op(self.t, 2)
+        return self._matrix([self.one, self.t, t2])
+
+    def automorph_matrix(self, k):
+        tk = self.t.copy()
+        tk.automorph(k)
+        return self._matrix([self.one, tk])
+
+
+def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, dist, torch, F, chain_bits, keygen=None):
     """configs[3] (Test_Regression d=8) replayed at the metric ring: one step = one Regression::Regress
     (Regression.h:102-134) evaluated in waves (fhe-si_amd/regression.py); the groups of every wave are sharded over the ranks
     and the wave's outputs exchanged (RCCL broadcast per producing rank), so total work is fixed: strong scaling."""
@@ -210,7 +239,9 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
     autos = []
     for i in range(len(ks)):             # KeySwitchSI(secretKey, k) matrices (2 source components), broadcast like the main one
         a = F.KeySwitchMatrix(ctx, 2, nd)
-        host = rand_residue_rows(np.random.default_rng(100 + i), primes, (2, 2 * nd), n) if rank == 0 else None
+        host = None
+        if rank == 0:
+            host = keygen.automorph_matrix(ks[i]) if keygen is not None else rand_residue_rows(np.random.default_rng(100 + i), primes, (2, 2 * nd), n)
         if world > 1:
             stage = shard.broadcast_key_matrix(host, a.nbytes, dist, device=dev)
             torch.cuda.synchronize()
@@ -272,7 +303,8 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
             "config": {"workload": (f"configs[3] replay: Regression::Regress d={d}, {N} data block(s), m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3" if M_RING == 1 << 15 else
                                     f"configs[3]: Regression::Regress d={d}, {N} data block(s) of phi(m) slots on the reference's Test_Regression ring m={M_RING} (p={P_PLAIN}), fhe-si logQ={LOGQ}, decompSize=3"),
                        "L": L, "chain_bits": round(chain_bits, 1), "sp_nbits": args.sp_nbits, "ndigits": nd,
-                       "key_switch_form": {"form": F.KeySwitchMatrix.FORMS.get(ks_form, str(ks_form)), "rows": ks_rows, "limb_bits": ks_limb_bits}, "automorphism_keys": len(ks), "waves": stats["waves"],
+                       "key_switch_form": {"form": F.KeySwitchMatrix.FORMS.get(ks_form, str(ks_form)), "rows": ks_rows, "limb_bits": ks_limb_bits,
+                                           "centred_limbs": ksk.key_bits()[0], "key_coefficient_bits": ksk.key_bits()[1]}, "keys": args.keys, "automorphism_keys": len(ks), "waves": stats["waves"],
                        "products_per_regress": stats["products"], "key_switches_per_regress": stats["key_switches"],
                        "automorph_key_switches_per_regress": stats["automorph_key_switches"], "regress_per_s": round(args.steps / dt, 3),
                        "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if world > 1 else "single GPU"},
@@ -481,17 +513,11 @@ def main():
     # the device by the seeded batch key generation; --keys uniform: uniform residues in every row (no matrix a key generation can produce:
     # the library then runs its general limbs, reported beside the line as surface.uniform_key_matrix)
     ksm_host = None
+    keygen = None
     if rank == 0:
         if args.keys == "generated":
-            one = np.zeros((n, 1), dtype=np.uint64)
-            one[0, 0] = 1
-            sk_seed = 0x5EC2E7C0FFEE1234
-            t = F.DoubleCRT(ctx).sample(0, 64, sk_seed, 1)                  # FHESISecKey::Init (FHE-SI.cpp:88-91)
-            t2 = t.copy()
-            t2.op(t, 2)
-            gen = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([F.DoubleCRT.from_poly(ctx, one), t, t2], t, LOGQ, sk_seed, sk_seed ^ 0x9E3779B97F4A7C15, 1000, DECOMP)
-            ksm_host = gen.download()
-            del gen, t, t2
+            keygen = KeyGen(ctx, F, n, nd)
+            ksm_host = keygen.s2_matrix()
         else:
             ksm_host = rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n)
     bcast_s = None
@@ -509,7 +535,7 @@ def main():
         ksk.upload(ksm_host)
 
     if args.workload == "regression":
-        run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, dist, torch, F, chain_bits)
+        run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, dist, torch, F, chain_bits, keygen)
         if dist:
             dist.barrier()
             dist.destroy_process_group()

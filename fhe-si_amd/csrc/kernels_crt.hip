@@ -913,7 +913,7 @@ static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi
 // on the residues, as in ks_recombine_generic_kernel.  NWORDS = 64-bit words below bit logQ (8: logQ <= 512, 16: logQ <= 1024).
 struct CentredConsts { u64 d[16]; };
 template <int NWORDS>
-__global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __restrict__ o32, i64 n, i64 nrow, i64 fold_q, int LQ, int B, int NLB, u64 half_hi, u64 half_lo,
+__global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __restrict__ o32, i64 n, i64 nrow, i64 fold_q, int S /* 1: rows of 2^15 left as their two sub-inverses (the tail stage is taken here) */, int LQ, int B, int NLB, u64 half_hi, u64 half_lo,
                                                                    u64 a_hi, u64 a_lo, CentredConsts cc, u64* __restrict__ out, int nl_out, Garner32 gc) {
   const i64 poly = blockIdx.y;
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -928,6 +928,13 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const u32* __restrict__ row = base32 + (i64)(l * 4 + a) * nrow;
+      if (S) {                 // (power-of-two rows of 2^15: no fold)
+        const i64 e = j & ((i64)(1 << 14) - 1);
+        const int up = (int)(j >> 14);
+        const u32 p = gc.p[a], Av = row[e], Bv = row[e + (1 << 14)];
+        v[a] = g32_mul(up ? Av + p - Bv : Av + Bv, gc.tw[a][up], gc.twp[a][up], p);
+        continue;
+      }
       if (!fold_q) { v[a] = row[j]; continue; }
       const u32 p = gc.p[a];
       u32 r;
@@ -989,9 +996,11 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
   for (int i = NWORDS; i < nl_out; ++i) o[i] = hbit ? ~0ull : 0ull;
 }
 static int garner32_consts(fhesi_ctx* ctx, Garner32* gc);
-static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out) {
+static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out, bool tail_pending) {
   Garner32 gc{};
   if (garner32_consts(ctx, &gc)) return 1;
+  const int S = tail_pending ? 1 : 0;
+  if (S && aux32_tail_consts(ctx, gc.tw, gc.twp)) return 1;
   const u128 A = (u128)((u64)gc.p[0] * gc.p[1]) * ((u64)gc.p[2] * gc.p[3]), half = (A - 1) / 2;
   const int LQ = k->aux_logQ, B = k->aux_limb_bits, NLB = k->aux_rows, NW = LQ <= 512 ? 8 : 16;
   if (LQ > 1024) FHESI_FAIL("key switch, centred limbs: logQ=%d above 1024", LQ);
@@ -1010,21 +1019,23 @@ static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const
   const i64 nrow = aux32_row_len(ctx);
   const i64 fold = k->aux_fold;
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
-  if (NW == 8) ks_recombine_centred_kernel<8><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
-  else ks_recombine_centred_kernel<16><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  if (NW == 8) ks_recombine_centred_kernel<8><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  else ks_recombine_centred_kernel<16><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 // does the recombination of this matrix take the tail of the 2^15-point inverse in its loader (so that launch_ntt32_inv leaves it out)?
 bool ks_recombine_takes_tail(const fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k) {
-  return !k->aux_centred && !k->aux_fold && k->aux32 && ctx->pow2 && aux32_row_len(ctx) == 2 * kAux32N && t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30;
+  if (k->aux_fold || !k->aux32 || !ctx->pow2 || aux32_row_len(ctx) != 2 * kAux32N) return false;
+  if (k->aux_centred) return true;                       // ks_recombine_centred_kernel, any chain
+  return t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30;
 }
 int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out, bool tail_pending) {
   if (!npolys) return 0;
   if (tail_pending != ks_recombine_takes_tail(ctx, t, k) && tail_pending) FHESI_FAIL("key switch: rows without their tail stage reached a recombination that does not take it");
+  if (k->aux_centred) { ProfScope prof(ctx, PROF_CRT, (double)npolys); return launch_ks_recombine_centred(ctx, k, d_o, npolys, d_out, nl_out, tail_pending); }
   if (tail_pending) { ProfScope prof(ctx, PROF_CRT, (double)npolys); return launch_ks_recombine_t<34, 1024, 72, 30, true, 1>(ctx, t, k, d_o, npolys, d_out, nl_out); }
-  if (k->aux_centred) { ProfScope prof(ctx, PROF_CRT, (double)npolys); return launch_ks_recombine_centred(ctx, k, d_o, npolys, d_out, nl_out); }
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
   // compile-time instantiations for the shapes the benchmarks run (the plan of ks_limb_plan at the metric and stress chains) ...
   if (!k->aux_fold && k->aux32 && t->W == 18 && k->aux_logQ == 512 && k->aux_limb_bits == 74 && k->aux_rows == 15) return launch_ks_recombine_t<18, 512, 74, 15, true>(ctx, t, k, d_o, npolys, d_out, nl_out);
