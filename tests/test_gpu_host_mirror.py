@@ -15,7 +15,7 @@ EXE = os.path.join(HOST, "test_addmul")
 
 
 def build():
-    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)      # normally a no-op: __graft_entry__.build() built them
+    subprocess.check_call(["make", "-C", HOST, "-j8"], stdout=subprocess.DEVNULL)      # normally a no-op: __graft_entry__.build() built them
 
 
 def test_addmul_sequence_readme_parameters():

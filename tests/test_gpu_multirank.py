@@ -143,7 +143,7 @@ def test_wave_evaluator_sharded_over_ranks_is_bit_identical(args, devices):
     """fhesi::Regression::RegressBatchedMultiGpu (fhe-si_amd/host/fhesi_matrix.h: GroupExecutor, one host thread per rank, keys
     broadcast from rank 0, every wave's groups sharded by shard_bounds, outputs exchanged) against the one-GPU waves and the plaintext
     regression.  `0` = one rank through real RCCL; `0,0` / `0,0,0` = ranks sharing GPU 0 (loopback group)."""
-    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HOST, "-j8"], stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(HOST, "test_regression"), *args, "--batched-only", f"--devices={devices}"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "multi-rank ciphertexts bit-identical to one GPU: yes" in r.stdout
@@ -156,7 +156,7 @@ def test_config3_sharded_over_eight_ranks():
     box: eight ranks in a group sharing GPU 0 (fhesi_comm_init_all's loopback group; RCCL itself needs eight devices and is exercised by the
     driver's 8-GPU run).  The sharded waves must produce the ciphertexts of the one-GPU evaluation bit for bit and decrypt to the plaintext
     regression (Regression.h:193-214)."""
-    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HOST, "-j8"], stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(HOST, "test_regression"), "8423", "7", "8", "1", "1", "--batched-only", "--check=slots", "--devices=0,0,0,0,0,0,0,0"],
                        capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -190,7 +190,7 @@ def test_recorded_ciphertext_operations_on_a_group_of_ranks(args):
     """The recording evaluator of the C++ mirror's Ciphertext (fhe-si_amd/host/fhesi_engine.h) with EnableCiphertextGroup: arena and keys
     replicated on every rank (RCCL broadcast), key-switch levels sharded, outputs exchanged.  Loopback group on one GPU; every flow of
     tests/host/test_lazy.cpp must give the ciphertexts of the statements run at once, and switching the group mid-life must not change them."""
-    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HOST, "-j8"], stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(HOST, "test_lazy"), *args], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Test SUCCEEDED" in r.stdout and "FAIL" not in r.stdout and "GPU rank(s)" in r.stdout
@@ -199,7 +199,7 @@ def test_recorded_ciphertext_operations_on_a_group_of_ranks(args):
 def test_reference_regress_control_flow_on_a_group_of_ranks():
     """Regression::Regress written one object at a time (Regression.h:102-149), recorded, evaluated on a loopback group of three ranks:
     bit-identical to the explicit waves on one GPU and to the statements run at once."""
-    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HOST, "-j8"], stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(HOST, "test_regression"), "47", "5", "4", "1", "6", "--at-once", "--literal-devices=0,0,0"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "recorded operations run on 3 GPU rank(s)" in r.stdout
