@@ -898,6 +898,8 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
     if (ctx->opt.dot32_small == 2 && (size_t)ncol * 4 * 128 <= 40 * 1024) return launch_dot32_t<4, 4, true>(ctx, k, d_dig, ncol, count, d_out);          // four workgroups of four waves per CU
   }
   if (ctx->opt.dot32_half && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true>(ctx, k, d_dig, ncol, count, d_out);
+  // (the stress ring's 129 columns with tiles of 8 ciphertexts in 132 KB, one workgroup per CU -- half the key words per multiply-add -- measured
+  // 43.1 ms against 42.0 ms for the tiles of 4 below: profiles/r04_ab_dot_few_limbs.txt)
   if ((size_t)ncol * 8 * 256 <= 160 * 1024) return launch_dot32_t<8, 16, false>(ctx, k, d_dig, ncol, count, d_out);
   if (ctx->opt.dot32_half && (size_t)ncol * 4 * 128 <= 80 * 1024) return launch_dot32_t<4, 8, true>(ctx, k, d_dig, ncol, count, d_out);
   if ((size_t)ncol * 4 * 256 <= 160 * 1024) return launch_dot32_t<4, 16, false>(ctx, k, d_dig, ncol, count, d_out);
