@@ -1,8 +1,6 @@
 // capi_pipeline.hip -- the key-switch matrix and the fused ciphertext multiplication + key switch, per stage and per batch (include/fhesi_hip.h)
 #include "capi_common.h"
-#include <condition_variable>
-#include <mutex>
-#include <thread>
+#include "copy_pool.h"
 
 // --------------------------------------------------------------------------------------------- key-switch matrix
 extern "C" int fhesi_ksk_create(fhesi_ctx* c, int32_t ncomp, int32_t ndigits, fhesi_ksk** out) {
@@ -562,40 +560,10 @@ struct HostStage {
   hipStream_t up = nullptr, down = nullptr;
   hipEvent_t ev_up[NS] = {}, ev_comp[NS] = {}, ev_down[NS] = {};
   std::vector<hipEvent_t> ev_piece[NS];  // one per downloaded piece of a stage (pageable results)
-  // copy threads: parallel memcpy of one region, the caller's thread takes a share
-  std::vector<std::thread> th;
-  std::mutex mu;
-  std::condition_variable cv, cv_done;
-  const char* src = nullptr; char* dst = nullptr; size_t len = 0, piece = 0;
-  unsigned long long gen = 0; int pending = 0; bool quit = false;
-  void worker(int id, unsigned long long seen) {      // seen: the generation at the time the thread was started (a restarted pool must not replay the last job)
-    for (;;) {
-      const char* s; char* d; size_t n, pc;
-      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; s = src; d = dst; n = len; pc = piece; }
-      const size_t off = (size_t)(id + 1) * pc;
-      if (off < n) memcpy(d + off, s + off, std::min(pc, n - off));
-      { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
-    }
-  }
-  void start(int nthreads) { unsigned long long g0; { std::lock_guard<std::mutex> lk(mu); g0 = gen; pending = 0; } for (int i = 0; i < nthreads; ++i) th.emplace_back([this, i, g0] { worker(i, g0); }); }
-  void copy(void* d, const void* s, size_t n) {
-    const int T = (int)th.size() + 1;
-    if (T == 1 || n < (size_t)256 << 10) { memcpy(d, s, n); return; }
-    size_t pc = (n + T - 1) / T; pc = (pc + 4095) & ~(size_t)4095;
-    { std::lock_guard<std::mutex> lk(mu); src = (const char*)s; dst = (char*)d; len = n; piece = pc; pending = (int)th.size(); ++gen; }
-    cv.notify_all();
-    memcpy(d, s, std::min(pc, n));
-    std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return pending == 0; });
-  }
-  void stop() {
-    { std::lock_guard<std::mutex> lk(mu); quit = true; }
-    cv.notify_all();
-    for (auto& t : th) t.join();
-    th.clear();
-    quit = false;
-  }
+  CopyPool pool;                         // copy threads between pageable memory and the ring (copy_pool.h)
+  void copy(void* d, const void* s, size_t n) { pool.copy(d, s, n); }
   void release() {
-    stop();
+    pool.stop();
     for (int s = 0; s < NS; ++s) for (int k = 0; k < 3; ++k) { if (pin[s][k]) hipHostFree(pin[s][k]); if (dev[s][k]) hipFree(dev[s][k]); pin[s][k] = dev[s][k] = nullptr; }
     for (int s = 0; s < NS; ++s) { if (ev_up[s]) hipEventDestroy(ev_up[s]); if (ev_comp[s]) hipEventDestroy(ev_comp[s]); if (ev_down[s]) hipEventDestroy(ev_down[s]); for (hipEvent_t e : ev_piece[s]) hipEventDestroy(e); ev_piece[s].clear(); }
     if (up) hipStreamDestroy(up);
@@ -624,7 +592,7 @@ static int host_stage_get(fhesi_ctx* c, size_t slot_bytes, HostStage** out) {
   {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int T = c->opt.host_threads > 0 ? c->opt.host_threads : (int)std::min(8u, hw);      // (8 measured best on a 256-thread host: 4 slightly slower, 16 - 64 progressively slower -- the pieces are 8 MiB)
-    if ((int)h->th.size() != T - 1) { h->stop(); h->start(T - 1); }      // (first use, or the option changed)
+    if (h->pool.threads() != T) { h->pool.stop(); h->pool.start(T - 1); }      // (first use, or the option changed)
   }
   if (h->slot_bytes < slot_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipStreamSynchronize(h->up)); HIP_TRY(hipStreamSynchronize(h->down));

@@ -15,8 +15,10 @@ nd, nl = (logQ + 23) // 24, 8
 ctx = F.Context(m, primes, roots)
 for kv in sys.argv[1:]:
     k, _, v = kv.partition("=")
-    ctx.set_option(k, int(v))
-ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(B.rand_residue_rows(np.random.default_rng(8), primes, (2, 3 * nd), n))
+    if v:
+        ctx.set_option(k, int(v))
+B.LOGQ, B.P_PLAIN = logQ, p
+ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(B.KeyGen(ctx, F, n, nd).s2_matrix() if "uniform" not in sys.argv else B.rand_residue_rows(np.random.default_rng(8), primes, (2, 3 * nd), n))
 rng = np.random.default_rng(1)
 a, b = B.rand_coeffs(rng, (16, 2, n), nl), B.rand_coeffs(rng, (16, 2, n), nl)
 da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(a.nbytes)
