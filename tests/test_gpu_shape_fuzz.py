@@ -56,3 +56,47 @@ def test_mul_relin_on_random_shapes(seed):
     out = ctx.alloc(count * 2 * n * nl * 8)
     ctx.ct_mul_sum_relin_dev(ksk, logQ, p, dpool, nl, list(range(count)), list(range(count, 2 * count)), np.arange(count + 1), out)
     assert np.array_equal(out.download((count, 2, n, nl)), got), (m, logQ, p, count, "wave")
+
+
+BIG = [32768, 32768, 1 << 16, 8422, 16381]       # rings whose key switch runs over the four 30-bit auxiliary primes at full row length
+
+
+def _case_generated(seed):
+    rng = np.random.default_rng(5000 + seed)
+    m = int(BIG[seed - 12]) if seed >= 12 else int(rng.choice(SAFE + [101, 107, 227]))
+    logQ = int(rng.integers(64, 500))
+    p = int(rng.choice([2, 23, 257, 8423, 65537, int(rng.integers(2, 1 << 20))]))
+    count = 1 if seed >= 12 else int(rng.integers(1, 4))
+    return m, logQ, p, count
+
+
+@pytest.mark.parametrize("seed", range(17))
+def test_mul_relin_on_random_shapes_with_generated_keys(seed):
+    """The same walk with key-switch matrices shaped like the ones KeySwitchSI::Init produces (FHE-SI.cpp:176-204): integer coefficients
+    uniform in [-2^(logQ-1), 2^(logQ-1)) plus the extremes, as residue rows.  On the rings whose key switch runs over the four 30-bit auxiliary
+    primes the library measures them and cuts centred limbs (the count it reports must be ceil(nb / B)); everywhere the result is the oracle's."""
+    m, logQ, p, count = _case_generated(seed)
+    primes, roots = P.chain_for(m, logQ, p, 1, _sp_nbits(seed))
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    if m > 2000 and (m & (m - 1)) != 0:
+        orc.set_bluestein_fft(True)
+    n, nd, nl, W = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64, len(primes) + 2
+    rng = np.random.default_rng(seed)
+    half = 1 << (logQ - 1)
+    ksm = np.empty((2, 3 * nd, len(primes), n), dtype=np.uint64)
+    for r in range(2):
+        for c in range(3 * nd):
+            ksm[r, c] = orc.dcrt_from_poly(P.rand_limbs(rng, (n,), W, logQ))
+    ksm[0, 0] = orc.dcrt_from_poly(O.ints_to_limbs([-half if i % 3 else half - 1 for i in range(n)], W))
+    ksm[1, 3 * nd - 1] = orc.dcrt_from_poly(O.ints_to_limbs([half] + [0] * (n - 1), W))        # -poly for poly = -2^(logQ-1)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    form, rows, bits = ksk.form()
+    centred, nb = ksk.key_bits()
+    if form == 1:
+        assert centred and nb == logQ - 1 and rows == -(-nb // bits), (m, logQ, form, rows, bits, centred, nb)
+    for c in range(count):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), (m, logQ, p, count, c, form, rows)
