@@ -912,9 +912,13 @@ static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi
 // + 2^119 to make it non-negative (the constant sum_l 2^(119 + B l) is taken off the start value).  fold: the linear-convolution rings,
 // on the residues, as in ks_recombine_generic_kernel.  NWORDS = 64-bit words below bit logQ (8: logQ <= 512, 16: logQ <= 1024).
 struct CentredConsts { u64 d[16]; };
-template <int NWORDS>
-__global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __restrict__ o32, i64 n, i64 nrow, i64 fold_q, int S /* 1: rows of 2^15 left as their two sub-inverses (the tail stage is taken here) */, int LQ, int B, int NLB, u64 half_hi, u64 half_lo,
+// NLBF, BF, LQF > 0: the limb count, limb width and logQ as compile-time constants (the metric ring's 7 x 74 bits, logQ = 512; plain rows only):
+// the limb loop unrolls, the bit offsets are static and all 4 NLBF residues of the coefficient are requested before the first is used.
+template <int NWORDS, int NLBF = 0, int BF = 0, int LQF = 0>
+__global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __restrict__ o32, i64 n, i64 nrow, i64 fold_q, int S /* 1: rows of 2^15 left as their two sub-inverses (the tail stage is taken here) */, int LQ_, int B_, int NLB_, u64 half_hi, u64 half_lo,
                                                                    u64 a_hi, u64 a_lo, CentredConsts cc, u64* __restrict__ out, int nl_out, Garner32 gc) {
+  constexpr bool FIX = NLBF > 0;
+  const int LQ = FIX ? LQF : LQ_, B = FIX ? BF : B_, NLB = FIX ? NLBF : NLB_;
   const i64 poly = blockIdx.y;
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -924,6 +928,13 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
   const u128 half = ((u128)half_hi << 64) | half_lo, A = ((u128)a_hi << 64) | a_lo;
   const u32* base32 = o32 + poly * NLB * 4 * nrow;
   u32 cur[4] = {0, 0, 0, 0}, nxt[4] = {0, 0, 0, 0};
+  u32 vin[FIX ? NLBF : 1][4];
+  if constexpr (FIX) {
+#pragma unroll
+    for (int l = 0; l < NLBF; ++l)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) vin[l][a] = __builtin_nontemporal_load(&base32[(i64)(l * 4 + a) * nrow + j]);
+  }
   auto fetch = [&](int l, u32 (&v)[4]) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -949,9 +960,13 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
       v[a] = r >= p ? r - p : r;
     }
   };
-  fetch(0, cur);
-  for (int l = 0; l < NLB; ++l) {
-    if (l + 1 < NLB) fetch(l + 1, nxt);
+  if constexpr (!FIX) fetch(0, cur);
+#pragma unroll
+  for (int l = 0; l < (FIX ? NLBF : NLB); ++l) {
+    if constexpr (FIX) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cur[a] = vin[l][a];
+    } else if (l + 1 < NLB) fetch(l + 1, nxt);
     const u32 p0 = gc.p[0], p1 = gc.p[1], p2 = gc.p[2], p3 = gc.p[3];
     const u32 x1 = cur[0];
     const u32 x2 = g32_mul(g32_sub(cur[1], x1, p1), gc.c[0], gc.cp[0], p1);
@@ -961,8 +976,10 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
     u128 V = (u128)((u64)x3 + (u64)p2 * x4) * ((u64)p0 * p1) + ((u64)x1 + (u64)p0 * x2);
     if (V > half) V -= A;
     V += (u128)1 << 119;
+    if constexpr (!FIX) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) cur[a] = nxt[a];
+      for (int a = 0; a < 4; ++a) cur[a] = nxt[a];
+    }
     const int s = B * l, wd = s >> 6, bt = s & 63;
     const u64 lo = (u64)V, hi = (u64)(V >> 64);
     const u64 q0 = lo << bt, q1 = bt ? ((lo >> ((64 - bt) & 63)) | (hi << bt)) : hi, q2 = bt ? (hi >> ((64 - bt) & 63)) : 0;
@@ -1019,7 +1036,9 @@ static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const
   const i64 nrow = aux32_row_len(ctx);
   const i64 fold = k->aux_fold;
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
-  if (NW == 8) ks_recombine_centred_kernel<8><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  if (NW == 8 && LQ == 512 && B == 74 && NLB == 7 && !fold && !S)      // the metric ring with a generated matrix
+    ks_recombine_centred_kernel<8, 7, 74, 512><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  else if (NW == 8) ks_recombine_centred_kernel<8><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   else ks_recombine_centred_kernel<16><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   HIP_TRY(hipGetLastError());
   return 0;
