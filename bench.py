@@ -140,6 +140,10 @@ def cpu_baseline(primes, roots, ksm, a, b, n_sample, bluestein_sample=1):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     orc = O.Oracle(M_RING, primes, roots)
+    pow2 = M_RING & (M_RING - 1) == 0
+    if not pow2:
+        orc.set_bluestein_fft(True)            # (rows are Bluestein transforms, as in the reference: bluestein.cpp:93-144; the oracle's direct form of them is quadratic)
+        bluestein_sample = 0
     info = host_cpu_info()
     t0 = time.perf_counter()
     outs = []
@@ -158,8 +162,10 @@ def cpu_baseline(primes, roots, ksm, a, b, n_sample, bluestein_sample=1):
         list(ex.map(lambda i: orc.ct_mul_relin(ksm, a[i % n_sample], b[i % n_sample], LOGQ, P_PLAIN, DECOMP), range(threads)))
     dt_all = time.perf_counter() - t1
     rec = {"value": done / dt, "unit": "ciphertext-mults/s", "cores": 1, "kind": "port",
-           "sample": f"{done} ciphertext mult+relin at the bench config (n=2^{M_RING.bit_length() - 2}, L={len(primes)}, ndigits={ksm.shape[1] // 3}) "
-                     f"with the C oracle's direct negacyclic NTT (optimistic vs the reference's Bluestein over NTL), {dt:.1f} s",
+           "sample": (f"{done} ciphertext mult+relin at the bench config (n=2^{M_RING.bit_length() - 2}, L={len(primes)}, ndigits={ksm.shape[1] // 3}) "
+                      f"with the C oracle's direct negacyclic NTT (optimistic vs the reference's Bluestein over NTL), {dt:.1f} s") if pow2 else
+                     (f"{done} ciphertext mult+relin at the bench config (m={M_RING}, L={len(primes)}, ndigits={ksm.shape[1] // 3}), every row transform as Bluestein + "
+                      f"3-prime FFT convolution (the reference's algorithm, bluestein.cpp:93-144), {dt:.1f} s"),
            "host": info,
            "all_cores": {"value": threads / dt_all, "unit": "ciphertext-mults/s", "cores": threads,
                          "sample": f"{threads} mults, one per thread on {info['usable_cpus']} usable logical CPUs, {dt_all:.1f} s"}}
@@ -426,7 +432,9 @@ def main():
     ap.add_argument("--no-bluestein-cpu", action="store_true", help="skip the like-for-like (Bluestein-mode) CPU timing, about 20 s")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent half-batches inside the library (option lanes); 2 gave ~+4 %% with launches of 64 ciphertexts, +0.6 %% with today's launches of 1024; it "
                     "overlaps kernels, so per-kernel durations (and the roofline line) are no longer those of a kernel running alone")
-    ap.add_argument("--workload", default="metric", choices=["metric", "stress", "regression", "ntt"], help="metric = configs[2] (default, the contract line); "
+    ap.add_argument("--workload", default="metric", choices=["metric", "stress", "regression", "ntt", "refring"], help="metric = configs[2] (default, the contract line); "
+                    "refring = the same multiplication on the reference drivers' own ring at the metric's size (Test_AddMul.cpp:131: m = p - 1 for the safe prime p = 32603, "
+                    "phi(m) = 16300, logQ=512: Bluestein rows in the reference, linear convolutions on padded rows of 2^15 here) -- reporting only; "
                     "ntt = configs[1]: DoubleCRT forward+inverse round trips at n=2^13, 8 primes, --batch DoubleCRTs per GPU (default there: 8192); "
                     "stress = configs[4]: m=2^16 (n=2^15), logQ=1024, p=65537 (35 primes, 43 digits) -- reporting only; "
                     "regression = configs[3] replayed at the metric ring: Regression::Regress (d = --reg-dim, --reg-rows data blocks) in waves, "
@@ -452,6 +460,8 @@ def main():
     global M_RING, LOGQ, P_PLAIN
     if args.workload == "stress":
         M_RING, LOGQ, P_PLAIN = 1 << 16, 1024, 65537
+    if args.workload == "refring":
+        M_RING, LOGQ, P_PLAIN = 32602, 512, 32603
     if args.workload == "regression" and args.reg_ring == "reference":
         # Test_Regression.cpp:100-108: m = p - 1, logQ by its noise formula (p = 8423, d = 8: 341; p = 32603 -- phi(m) = 16300, the metric's size in
         # the reference's own parameterisation --: 377)
@@ -617,7 +627,8 @@ def main():
     launches, rows, ms = prof["ntt_fwd_digits_main"]       # fused ByteDecomp + forward NTT of the digit polynomials
     kname = names["ntt_fwd_digits_main"]
     aux32 = kname.startswith("ntt32_")                      # digit rows transformed modulo four 30-bit primes (kernels_aux32.hip): 4-byte residues
-    row_bytes = 2 * n * (4 if aux32 else 8)                 # row read once + written once
+    row_elems = (n if M_RING & (M_RING - 1) == 0 else max(1 << 14, 1 << (2 * n - 2).bit_length())) if aux32 else n      # (linear-convolution rings: padded rows of 2^14 / 2^15)
+    row_bytes = 2 * row_elems * (4 if aux32 else 8)         # row read once + written once
     if args.ntt_rows:
         # optional standalone measurement on a fixed row count
         cnt = max(1, args.ntt_rows // L)
@@ -663,11 +674,11 @@ def main():
     tl, trows, tms = prof["ntt_fwd"]
     if names["ntt_fwd"].startswith("ntt32_") and aux32 and not args.ntt_rows and trows > rows and tms > ms:
         t_rows, t_ms, t_l = trows - rows, tms - ms, max(1, tl - launches)
-        t_ach = t_rows * 2 * n * 4 / (t_ms * 1e-3) / 1e9
+        t_ach = t_rows * 2 * row_elems * 4 / (t_ms * 1e-3) / 1e9
         ttr, ttr_src = offline_traffic("pmc_t32_fwd.json", names["ntt_fwd"], "rows_per_launch", round(t_rows / t_l)) if args.workload == "metric" else (None, None)
         roofline_ntt_tensor = {"bound": "hbm", "kernel": names["ntt_fwd"], "achieved": round(t_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(t_ach / HBM_PEAK_GBS, 4), "traffic": ttr, "traffic_source": ttr_src, "traffic_measured": False, "launches": t_l,
-                               "avg_launch_ms": round(t_ms / t_l, 4), "rows_per_launch": round(t_rows / t_l, 1), "row_bytes": n * 4,
+                               "avg_launch_ms": round(t_ms / t_l, 4), "rows_per_launch": round(t_rows / t_l, 1), "row_bytes": row_elems * 4,
                                "row_ntts_per_s": round(t_rows / (t_ms * 1e-3), 1)}
     # The dominant kernel of the pipeline is the key-switch dot product through the auxiliary primes (kernels_ksaux.hip / kernels_aux32.hip):
     # algorithmic bytes per launch of c ciphertexts = (digit rows c*ncol*2 + key rows 2*R*2*ncol + output rows c*2*R*2) * n * 8
@@ -790,7 +801,7 @@ def main():
         breakdown = {k: round(v[2] / (args.steps * nblk), 3) for k, v in prof.items() if v[0] and k != "ntt_fwd_digits_main"}
         cpu, matches = None, None
         if args.cpu_sample > 0 and world == 1:       # CPU baseline on rank 0 at N=1 only; its outputs check the timed buffer
-            ns = min(args.cpu_sample, uniq)
+            ns = min(args.cpu_sample, uniq) if args.workload != "refring" else 1      # (a Bluestein-mode oracle multiplication takes ~20 s)
             cpu, want = cpu_baseline(primes, roots, ksm_host, a_host, b_host, ns, 0 if (args.no_bluestein_cpu or args.workload != "metric") else 1)
             got = dout.download((want.shape[0], 2, n, nl))
             last = np.frombuffer(ctx_download_tail(ctx, dout, B, ct_bytes), dtype=np.uint64).reshape(2, n, nl)
@@ -800,6 +811,7 @@ def main():
             ok = matches
         line = {
             "metric": "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^14, logQ=512" if args.workload == "metric"
+                      else f"homomorphic ciphertext-mults/sec (incl. relinearize) at phi(m)={n} (m={M_RING}), logQ={LOGQ} (the reference drivers' own ring)" if args.workload == "refring"
                       else "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^15, logQ=1024 (stress shape)",
             "value": round(value, 2), "unit": "ciphertext-mults/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -808,7 +820,9 @@ def main():
             "data": f"synthetic ({uniq} distinct uniform ciphertext pairs per GPU repeated to the batch; key-switch matrix " +
                     ("generated by KeySwitchSI::Init from a sampleHWt(64) secret key, FHE-SI.cpp:153-226)" if args.keys == "generated" else "of uniform residues)"),
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
-                       if args.workload == "metric" else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
+                       if args.workload == "metric" else f"Test_AddMul's parameterisation at the metric's size: m = p - 1 = {M_RING} for the safe prime p = {P_PLAIN}, phi(m) = {n}, fhe-si logQ={LOGQ}, decompSize=3 "
+                       "(rows are Bluestein transforms in the reference; here linear convolutions on padded rows of 2^15 over 30-bit primes)" if args.workload == "refring"
+                       else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
                        "L": L, "chain_bits": round(chain_bits, 1), "sp_nbits": args.sp_nbits, "ndigits": nd,
                        "key_switch_form": {"form": F.KeySwitchMatrix.FORMS.get(ks_form, str(ks_form)), "rows": ks_rows, "limb_bits": ks_limb_bits,
                                            "centred_limbs": ksk.key_bits()[0], "key_coefficient_bits": ksk.key_bits()[1]}, "keys": args.keys, "batch_per_gpu": B, "options": {k: ctx.get_option(k) for k in ("lanes", "ks_direct", "ks_residues", "ks_aux60", "tensor32", "batch_chunk")},
