@@ -914,7 +914,10 @@ static int launch_ks_recombine_t(fhesi_ctx* ctx, const CrtTables* t, const fhesi
 struct CentredConsts { u64 d[16]; };
 // NLBF, BF, LQF > 0: the limb count, limb width and logQ as compile-time constants (the metric ring's 7 x 74 bits, logQ = 512; plain rows only):
 // the limb loop unrolls, the bit offsets are static and all 4 NLBF residues of the coefficient are requested before the first is used.
-template <int NWORDS, int NLBF = 0, int BF = 0, int LQF = 0>
+// FS = 1 (m = 2q'), 2 (m prime): rows of 2^15 on a linear-convolution ring, left as their two sub-inverses -- the fold and the tail stage are both
+// taken in the loader: the (up to) four positions a coefficient is folded from are worked out once (they do not depend on the limb or the prime),
+// their sub-inverse pairs are loaded unconditionally, summed per half of the row with their signs and multiplied by the two tail constants.
+template <int NWORDS, int NLBF = 0, int BF = 0, int LQF = 0, int FS = 0>
 __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __restrict__ o32, i64 n, i64 nrow, i64 fold_q, int S /* 1: rows of 2^15 left as their two sub-inverses (the tail stage is taken here) */, int LQ_, int B_, int NLB_, u64 half_hi, u64 half_lo,
                                                                    u64 a_hi, u64 a_lo, CentredConsts cc, u64* __restrict__ out, int nl_out, Garner32 gc) {
   constexpr bool FIX = NLBF > 0;
@@ -935,10 +938,45 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
 #pragma unroll
       for (int a = 0; a < 4; ++a) vin[l][a] = __builtin_nontemporal_load(&base32[(i64)(l * 4 + a) * nrow + j]);
   }
+  constexpr int NT = FS == 1 ? 4 : 3;
+  u32 eb[NT];
+  bool up[NT], ok[NT], ng[NT];
+  if constexpr (FS != 0) {
+    const i64 off = fold_q > 0 ? fold_q : -fold_q;
+    const i64 e[4] = {j, j + off, n, n + off};
+    // m = 2q':  S_j - S_(j+q') -+ (S_n - S_(n+q'))  (upper signs for even j);   m prime:  S_j + S_(j+m) - S_(m-1)
+    const bool sg[4] = {false, FS == 1, FS == 1 ? !(j & 1) : true, (j & 1) != 0};
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      ok[k] = e[k] < nrow;
+      const u32 idx = ok[k] ? (u32)e[k] : 0u;
+      up[k] = idx >= (1u << 14);
+      eb[k] = idx & ((1u << 14) - 1);
+      ng[k] = sg[k];
+    }
+  }
   auto fetch = [&](int l, u32 (&v)[4]) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const u32* __restrict__ row = base32 + (i64)(l * 4 + a) * nrow;
+      if constexpr (FS != 0) {
+        const u32 p = gc.p[a], twop = 2 * p;
+        u32 Av[NT], Bv[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) { Av[k] = row[eb[k]]; Bv[k] = row[eb[k] + (1 << 14)]; }
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          const u32 t = up[k] ? Av[k] + p - Bv[k] : Av[k] + Bv[k];                  // at most 2p
+          const u32 val = ok[k] ? (ng[k] ? twop - t : t) : 0u;
+          const u32 l2 = lo + (up[k] ? 0u : val), h2 = hi + (up[k] ? val : 0u);     // below 4p
+          lo = min(l2, l2 - twop); hi = min(h2, h2 - twop);
+        }
+        u32 r = g32_mul_lazy(lo, gc.tw[a][0], gc.twp[a][0], p) + g32_mul_lazy(hi, gc.tw[a][1], gc.twp[a][1], p);      // below 4p
+        r = min(r, r - twop);
+        v[a] = min(r, r - p);
+        continue;
+      }
       if (S) {                 // (power-of-two rows of 2^15: no fold)
         const i64 e = j & ((i64)(1 << 14) - 1);
         const int up = (int)(j >> 14);
@@ -1038,6 +1076,10 @@ static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
   if (NW == 8 && LQ == 512 && B == 74 && NLB == 7 && !fold && !S)      // the metric ring with a generated matrix
     ks_recombine_centred_kernel<8, 7, 74, 512><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  else if (S && fold && NW == 8 && fold > 0) ks_recombine_centred_kernel<8, 0, 0, 0, 1><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  else if (S && fold && NW == 8) ks_recombine_centred_kernel<8, 0, 0, 0, 2><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  else if (S && fold && fold > 0) ks_recombine_centred_kernel<16, 0, 0, 0, 1><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  else if (S && fold) ks_recombine_centred_kernel<16, 0, 0, 0, 2><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   else if (NW == 8) ks_recombine_centred_kernel<8><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   else ks_recombine_centred_kernel<16><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   HIP_TRY(hipGetLastError());
@@ -1046,8 +1088,9 @@ static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const
 
 // does the recombination of this matrix take the tail of the 2^15-point inverse in its loader (so that launch_ntt32_inv leaves it out)?
 bool ks_recombine_takes_tail(const fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k) {
-  if (k->aux_fold || !k->aux32 || !ctx->pow2 || aux32_row_len(ctx) != 2 * kAux32N) return false;
-  if (k->aux_centred) return true;                       // ks_recombine_centred_kernel, any chain
+  if (!k->aux32 || aux32_row_len(ctx) != 2 * kAux32N) return false;
+  if (k->aux_centred) return true;                       // ks_recombine_centred_kernel, any chain; on a linear-convolution ring together with the fold
+  if (k->aux_fold || !ctx->pow2) return false;
   return t->W == 34 && k->aux_logQ == 1024 && k->aux_limb_bits == 72 && k->aux_rows == 30;
 }
 int launch_ks_recombine(fhesi_ctx* ctx, const CrtTables* t, const fhesi_ksk* k, const u64* d_o, i64 npolys, u64* d_out, int nl_out, bool tail_pending) {

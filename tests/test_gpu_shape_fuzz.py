@@ -58,7 +58,7 @@ def test_mul_relin_on_random_shapes(seed):
     assert np.array_equal(out.download((count, 2, n, nl)), got), (m, logQ, p, count, "wave")
 
 
-BIG = [32768, 32768, 1 << 16, 8422, 16381]       # rings whose key switch runs over the four 30-bit auxiliary primes at full row length
+BIG = [32768, 32768, 1 << 16, 8422, 16381, 32602]       # rings whose key switch runs over the four 30-bit auxiliary primes at full row length (the last two: fold and tail stage of padded 2^15-point rows in the recombination's loader, m prime and m = 2q')
 
 
 def _case_generated(seed):
@@ -70,7 +70,7 @@ def _case_generated(seed):
     return m, logQ, p, count
 
 
-@pytest.mark.parametrize("seed", range(17))
+@pytest.mark.parametrize("seed", range(18))
 def test_mul_relin_on_random_shapes_with_generated_keys(seed):
     """The same walk with key-switch matrices shaped like the ones KeySwitchSI::Init produces (FHE-SI.cpp:176-204): integer coefficients
     uniform in [-2^(logQ-1), 2^(logQ-1)) plus the extremes, as residue rows.  On the rings whose key switch runs over the four 30-bit auxiliary
