@@ -20,6 +20,7 @@ run regression --workload regression --steps 3 --warmup 1
 run regression_ref --workload regression --reg-ring reference --steps 5 --warmup 2
 run regression_ref_p32603 --workload regression --reg-ring reference --reg-p 32603 --steps 5 --warmup 2
 run ntt --workload ntt --steps 10 --warmup 2
+run refring --workload refring --steps 5 --warmup 2 --cpu-sample 0 --gpu-seconds 0
 fi
 for c in FETCH_SIZE WRITE_SIZE; do        # one counter per pass (combining them has hung the profiler on this pool)
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --batch 1024 --no-surface --gpu-seconds 0 > /dev/null 2> "$O/pmc_$c.log"
