@@ -159,7 +159,7 @@ def test_wire_format_bytes_match_python_model(tmp_path):
 
 @pytest.mark.parametrize("m", [64, 22, 1024])
 def test_single_crt_mirror_class(m):
-    """The mirrored SingleCRT class (fhe-si_amd/host/fhesi_host.h, SingleCRT.h:41-175): conversions, arithmetic and index-set handling
+    """The mirrored SingleCRT class (fhe-si_amd/host/fhesi_doublecrt.h, SingleCRT.h:41-175): conversions, arithmetic and index-set handling
     against big-integer arithmetic on the host and against the mirrored DoubleCRT (tests/host/test_scrt.cpp)."""
     build()
     r = subprocess.run([os.path.join(HOST, "test_scrt"), str(m)], capture_output=True, text=True, timeout=600)

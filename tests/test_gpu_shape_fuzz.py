@@ -19,7 +19,8 @@ GENERAL = [9, 12, 15, 20, 21, 45, 60, 100, 101, 105, 126]      # everything else
 
 def _case(seed):
     rng = np.random.default_rng(1000 + seed)
-    m = int(rng.choice(GENERAL if seed >= 24 else (POW2 if seed % 3 else SAFE)))
+    general = 24 <= seed < 36 or (seed >= 36 and seed % 4 == 3)          # (seeds from 36 upwards: tools/fuzz_shapes.py)
+    m = int(rng.choice(GENERAL if general else (POW2 if seed % 3 else SAFE)))
     logQ = int(rng.integers(40, 420))
     p = int(rng.choice([2, 3, 23, 257, 2027, 8423, 65537, int(rng.integers(2, 1 << 20)), (1 << 31) - 1]))
     count = int(rng.integers(1, 6))
@@ -63,10 +64,10 @@ BIG = [32768, 32768, 1 << 16, 8422, 16381, 32602]       # rings whose key switch
 
 def _case_generated(seed):
     rng = np.random.default_rng(5000 + seed)
-    m = int(BIG[seed - 12]) if seed >= 12 else int(rng.choice(SAFE + [101, 107, 227]))
+    m = int(BIG[seed - 12]) if 12 <= seed < 12 + len(BIG) else int(rng.choice(SAFE + [101, 107, 227] + (POW2 if seed >= 18 else [])))
     logQ = int(rng.integers(64, 500))
     p = int(rng.choice([2, 23, 257, 8423, 65537, int(rng.integers(2, 1 << 20))]))
-    count = 1 if seed >= 12 else int(rng.integers(1, 4))
+    count = 1 if 12 <= seed < 12 + len(BIG) else int(rng.integers(1, 4))
     return m, logQ, p, count
 
 
