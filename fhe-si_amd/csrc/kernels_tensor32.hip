@@ -323,8 +323,11 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   u32* __restrict__ o = rows + poly * NP * nrow + j0 + tid;
   // dup (padded rows of 2^15 on a linear-convolution ring: the polynomial's upper half is zero, so the head stage x +- w 0 leaves x in both
   // sub-rows): every value is written to sub-row 1 as well
+  // few polynomials (small batches): the primes are split over gridDim.z so that the launch fills the chip -- with one workgroup per CU
+  // every thread walked the 35 primes behind 35 exposed scalar-load latencies (21 us for one ciphertext)
+  const int i_first = (int)((i64)blockIdx.z * NP / gridDim.z), i_last = (int)((i64)(blockIdx.z + 1) * NP / gridDim.z);
   if (j0 >= n_src) {                                             // (whole block in the zero padding)
-    for (int i = 0; i < NP; ++i) { o[(i64)i * nrow] = 0; if (dup) o[(i64)i * nrow + A32_N] = 0; }
+    for (int i = i_first; i < i_last; ++i) { o[(i64)i * nrow] = 0; if (dup) o[(i64)i * nrow + A32_N] = 0; }
     return;
   }
   const i64 avail = (n_src - j0) * NL;                           // words of this block's 256 coefficients that exist
@@ -362,7 +365,7 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   if constexpr (HEAD) neg1 = x1[2 * NL - 1] >> 31;
   constexpr int STRIDE = (2 * NL + 6 + 7) & ~7;
 #pragma unroll 2
-  for (int i = 0; i < NP; ++i) {
+  for (int i = i_first; i < i_last; ++i) {
     const u32* __restrict__ t = tab + ((i64)cls * NP + i) * STRIDE;
     const u32 r0 = rns32_one<NL>(x, neg, t);
     if constexpr (!HEAD) {
@@ -641,7 +644,8 @@ template <int NL>
 static int t32_launch_rns(fhesi_ctx* ctx, const T32Config* c, const u64* d_a, const u64* d_b, i64 npolys, i64 na2, bool paired, u32* d_r) {
   const int S = ctx->tensor32->S;
   const i64 nrow = t32_nrow(ctx), n_src = ctx->phim;
-  const dim3 grid((unsigned)(A32_N / 256), (unsigned)npolys);
+  const unsigned zs = npolys * (A32_N / 256) >= 2048 ? 1u : (npolys * (A32_N / 256) >= 1024 ? 2u : 5u);      // (primes split over z for small launches)
+  const dim3 grid((unsigned)(A32_N / 256), (unsigned)npolys, zs);
   const int* ia = paired && ctx->op_idx ? ctx->op_idx + ctx->op_idx_done : nullptr;
   const int* ib = ia ? ia + ctx->op_idx_n : nullptr;
   const int dup = S && ctx->lin_q ? 1 : 0;
@@ -747,7 +751,7 @@ int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int n
   {
     ProfScope prof(ctx, PROF_NTT_INV, (double)(count * 3 * NP));
     PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, true, T32Primes>));
-    const dim3 grid((unsigned)(((count + 7) / 8) * 24), (unsigned)(NP << S));
+    const dim3 grid((unsigned)(count >= 8 ? ((count + 7) / 8) * 24 : count * 3), (unsigned)(NP << S));      // (groups of 8 ciphertexts x 3 rows, or the rows themselves: see the kernel)
     ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, c->pr, x->d_inv, S, (const u32*)d_r);
     HIP_TRY(hipGetLastError());
   }

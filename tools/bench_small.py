@@ -22,7 +22,7 @@ ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(B.KeyGen(ctx, F, n, nd).s2_matrix() i
 rng = np.random.default_rng(1)
 a, b = B.rand_coeffs(rng, (16, 2, n), nl), B.rand_coeffs(rng, (16, 2, n), nl)
 da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(a.nbytes)
-for cnt in (1, 2, 4, 8, 16):
+for cnt in [int(x) for x in os.environ.get("BENCH_SMALL_COUNTS", "1,2,4,8,16").split(",")]:
     for _ in range(5):
         ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, cnt)
     ctx.sync()
