@@ -789,6 +789,9 @@ def main():
                         mm = re.search(r"at once: .*? = ([0-9.]+) per second", r.stdout)
                         if mm and cnt == 64:
                             cs["per_object_statements_at_once"] = round(float(mm.group(1)), 1)
+                        every = [float(x) for x in re.findall(r"result asked after every object: .*? = ([0-9.]+) per second", r.stdout)]
+                        if every and cnt == 64:          # (the reference's semantics, Test_AddMul.cpp:59-86: the result of every statement is looked at before the next)
+                            cs["result_read_after_every_object"] = round(max(every), 1)
             except Exception as e:          # the surface figures are extras: never fail the contract line over them
                 surface["class_surface"] = {"ok": False, "error": str(e)[:200]}
 
