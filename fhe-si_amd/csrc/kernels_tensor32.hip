@@ -287,12 +287,35 @@ static int t32_config(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ, i64 gmax, 
 // n_src upwards (linear-convolution rings) are zero.
 // HEAD (rows of 2^15): a thread takes coefficients j and j + 2^14 and stores  x + w y  and  x + 2p - w y  into sub-rows 0 and 1 of the row
 // (the head stage of the 2^15-point transform, w = psi^brv(1)).
+// a * b_uniform + c in one v_mad_u64_u32, the wave-uniform factor taken from its scalar register
+__device__ __forceinline__ u64 mad64s(u32 a, u32 b_uniform, u64 c) {
+  u64 r, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
 template <int NL>
 __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const u32* __restrict__ t) {
   const u32 r32 = t[2 * NL + 1], mu = t[2 * NL + 2], p = t[2 * NL + 3];
   // products below 2^62 - 2^47: four fit a 64-bit accumulator, three on top of a folded value (below 2^62 + 2^32)
+#ifndef RNS32_CHAIN
+#define RNS32_CHAIN 1
+#endif
   u64 acc = 0;
   int room = 4;
+#if RNS32_CHAIN
+  // ONE dependency chain of v_mad_u64_u32 (the table words from their scalar registers): written as plain C++ the compiler splits the sum into
+  // five independent groups and joins them with 64-bit adds and moves -- 38 instructions per prime where the chain needs 32; the latency
+  // of the chain is covered by the other waves (34 registers: full occupancy)
+#pragma unroll
+  for (int k = 0; k < 2 * NL; ++k) {
+    if (room == 0) { acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc); room = 3; }
+    acc = mad64s(x[k], t[k], acc);
+    --room;
+  }
+  acc = mad64s(neg, t[2 * NL], acc);                          // (neg is 0 or 1: the two's complement correction without a branch)
+  acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^62 + 2^32
+  acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^61
+#else
 #pragma unroll
   for (int k = 0; k < 2 * NL; ++k) {
     if (room == 0) { acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc; room = 3; }
@@ -302,6 +325,7 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
   acc += neg ? t[2 * NL] : 0u;
   acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^62 + 2^32
   acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^61
+#endif
   const u32 q = __umulhi((u32)(acc >> 29), mu);        // at most 2 below floor(acc / p)
   return (u32)acc - q * p;                             // below 3p
 }
