@@ -313,8 +313,10 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
     --room;
   }
   acc = mad64s(neg, t[2 * NL], acc);                          // (neg is 0 or 1: the two's complement correction without a branch)
-  acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^62 + 2^32
-  acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^61
+  acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^32 r32 + 2^32
+  // The primes of the tensor half are the largest below 2^30, so 2^32 mod p = 4 (2^30 - p) is a small number (below 2^26 for the 72 largest
+  // primes that are 1 mod 2^16): one fold already leaves the total below 2^61.  Any other prime takes the second fold (a wave-uniform branch).
+  if (r32 >= (1u << 28)) acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^61
 #else
 #pragma unroll
   for (int k = 0; k < 2 * NL; ++k) {
