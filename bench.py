@@ -8,6 +8,12 @@ Inputs are synthetic (uniform coefficients in [-2^511, 2^511), uniform key-switc
 timed region.  N > 1: one process per GPU, ciphertext batches sharded (each rank its own B), key-switch matrix generated
 on rank 0 and broadcast with RCCL; no collective inside the timed loop (weak scaling).
 
+N > 1 (first contact with a real multi-GPU node is the driver's run, so the path is defensive): the process group is gloo for what lives
+in host memory + RCCL for what lives in HBM; before any device collective a ROLL CALL gathers every rank's GPU identity (UUID / PCI address)
+and ends the run on every rank, with a message, if two ranks drive the same GPU (unless --one-device); after the timed region every rank
+checks its own buffer against the oracle evaluated on its own copy of the broadcast key matrix, and all ranks recompute rank 0's first
+pair and compare digests (config.multi_gpu: RCCL version, communicator size, devices, broadcast staging vs collective time, parity).
+
 `python bench.py --gpus N` with N > 1 and no RANK in the environment launches the N ranks itself (torch.distributed.run as a child
 process, started before anything in this process touches the GPU) and relays rank 0's line; under an external launcher (RANK set) it
 is one of the ranks.
@@ -182,6 +188,16 @@ def cpu_baseline(primes, roots, ksm, a, b, n_sample, bluestein_sample=1):
                                  "sample": f"1 mult+relin with every row transform as Bluestein + 3-prime FFT convolution of 2^{(2 * M_RING - 1).bit_length()} points "
                                            f"(the reference's algorithm, bluestein.cpp:93-144), {dt_b:.1f} s"}
     return rec, np.stack(outs)
+
+
+def oracle_outputs(primes, roots, ksm, a, b, n_sample):
+    """the checker alone (no timing): the C oracle's results for the first n_sample pairs"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    orc = O.Oracle(M_RING, primes, roots)
+    if M_RING & (M_RING - 1):
+        orc.set_bluestein_fft(True)
+    return np.stack([orc.ct_mul_relin(ksm, a[i], b[i], LOGQ, P_PLAIN, DECOMP) for i in range(n_sample)])
 
 
 class _CountingBackend:
@@ -483,14 +499,33 @@ def main():
     import fhe_si_amd as F
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (HIP path only; there is no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench: rank {rank} wants cuda:{local_rank} but this process sees {torch.cuda.device_count()} GPU(s) "
+                         f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}); one process per GPU, or --one-device for plumbing checks on a 1-GPU box")
     torch.cuda.set_device(local_rank)
     dist = None
+    topo, cpu_side = None, False        # cpu_side: barriers, stopwatches and object collectives run on the CPU backend of the group
     if world > 1:
         import torch.distributed as dist
+        from fhe_si_amd import shard
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # gloo for what lives in host memory (roll call, barriers, stopwatches), RCCL for what lives in HBM (the key broadcast, the
+            # exchanges of the regression waves).  No device_id: the RCCL communicator is created by the first device collective, i.e.
+            # AFTER the roll call below has established that every rank drives its own GPU.
+            try:
+                dist.init_process_group("cpu:gloo,cuda:nccl")
+                cpu_side = True
+            except Exception as e:          # (a build without gloo: RCCL alone, as rounds 1-4 initialised it)
+                print(f"bench: mixed gloo + nccl process group not available ({e}); falling back to nccl only", file=sys.stderr)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+            cpu_side = True
+        try:
+            topo = shard.roll_call(dist, shard.device_identity(torch, local_rank), allow_shared=args.one_device)
+        except RuntimeError as e:          # raised on EVERY rank: nobody is left waiting in a collective
+            dist.destroy_process_group()
+            raise SystemExit(f"bench: {e}")
     options = {"lanes": args.lanes}
     for kv in args.option:
         k, _, v = kv.partition("=")
@@ -530,15 +565,16 @@ def main():
             ksm_host = keygen.s2_matrix()
         else:
             ksm_host = rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n)
-    bcast_s = None
+    bcast_s, bcast_t = None, None
     if world > 1:
         from fhe_si_amd import shard
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.perf_counter()
-        stage = shard.broadcast_key_matrix(ksm_host, ksk.nbytes, dist, device=f"cuda:{local_rank}")   # one RCCL broadcast
+        bcast_t = {}
+        stage = shard.broadcast_key_matrix(ksm_host, ksk.nbytes, dist, device=f"cuda:{local_rank}", timings=bcast_t)   # one RCCL broadcast
         torch.cuda.synchronize()
-        bcast_s = round(time.perf_counter() - tb, 4)           # (includes rank 0's host -> device staging of the matrix)
+        bcast_s = round(time.perf_counter() - tb, 4)           # (staging + collective: split in config.multi_gpu.key_broadcast)
         ksk.upload_dev(stage.data_ptr())
         del stage
     else:
@@ -579,7 +615,7 @@ def main():
         dist.barrier()
     ctx.prof_enable(True)
 
-    tdev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+    tdev = "cpu" if cpu_side else f"cuda:{local_rank}"
 
     def timed_block():
         """exactly --steps steps between barrier + synchronize on both sides; the maximum over the ranks"""
@@ -795,7 +831,40 @@ def main():
             except Exception as e:          # the surface figures are extras: never fail the contract line over them
                 surface["class_surface"] = {"ok": False, "error": str(e)[:200]}
 
-    ok = True
+    # ---- N > 1: parity of EVERY rank's timed buffer (the reference's predicate is per ciphertext, Test_AddMul.cpp:84-86), and of the
+    # replicas of the key matrix: (i) each rank checks its own first pair (and the batch's last) against the C oracle evaluated on THIS
+    # rank's HBM copy of the broadcast matrix; (ii) every rank recomputes rank 0's first pair on its own GPU with its own copy and the
+    # ranks compare 64-bit digests.  matches_oracle = all ranks equal rank 0 and every rank equals the oracle; exit code 1 otherwise, on
+    # every rank.
+    parity = None
+    if world > 1:
+        from fhe_si_amd import shard
+        mine_ok = None
+        first_chunk = dout.download((uniq, 2, n, nl))
+        if args.cpu_sample > 0:
+            ksm_local = ksm_host if rank == 0 else ksk.download()
+            want1 = oracle_outputs(primes, roots, ksm_local, a_host, b_host, 1)
+            last = np.frombuffer(ctx_download_tail(ctx, dout, B, ct_bytes), dtype=np.uint64).reshape(2, n, nl)
+            mine_ok = bool(np.array_equal(first_chunk[0], want1[0])) and bool(np.array_equal(last, first_chunk[(B - 1) % uniq]))
+            del ksm_local
+        if rank == 0:
+            a0, b0 = a_host[:1], b_host[:1]
+        else:                       # rank 0's generator (seed 7 + 0), drawn in its order: a, then b
+            rng0 = np.random.default_rng(7)
+            a0 = rand_coeffs(rng0, (uniq, 2, n), nl)[:1].copy()
+            b0 = rand_coeffs(rng0, (uniq, 2, n), nl)[:1].copy()
+        d1a, d1b, d1o = ctx.upload(a0), ctx.upload(b0), ctx.alloc(ct_bytes)
+        ctx.ct_mul_relin_dev(ksk, LOGQ, P_PLAIN, d1a, d1b, d1o, nl, 1, DECOMP)
+        common = d1o.download((1, 2, n, nl))
+        del d1a, d1b, d1o
+        agree, digests = shard.all_ranks_agree(dist, shard.digest64(common))
+        same_as_batch = bool(np.array_equal(common[0], first_chunk[0])) if rank == 0 else True      # (one ciphertext per call = the batch's first)
+        all_ok, per_rank_ok = shard.all_ranks_ok(dist, mine_ok is not False and agree and same_as_batch)
+        parity = {"all_ok": all_ok, "per_rank_ok": per_rank_ok, "oracle_checked_on_every_rank": args.cpu_sample > 0,
+                  "rank0_first_pair_digest_by_rank": [f"{d:016x}" for d in digests], "digests_equal": agree}
+        del first_chunk
+
+    ok = True if parity is None else parity["all_ok"]
     if rank == 0:
         total_mults = B * args.steps * world
         value = total_mults / dt
@@ -812,6 +881,23 @@ def main():
             first_chunk = dout.download((uniq, 2, n, nl))
             matches = bool(np.array_equal(got, want)) and bool(np.array_equal(last, first_chunk[(B - 1) % uniq]))
             ok = matches
+        if parity is not None:
+            matches = parity["all_ok"] if args.cpu_sample > 0 else None      # (without the oracle only the agreement of the ranks was checked: multi_gpu.parity)
+        multi_gpu = None
+        if world > 1:
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:
+                rccl = f"unavailable ({e})"
+            try:
+                nr = dist.group.WORLD._get_backend(torch.device("cuda")).size() if args.backend == "nccl" else dist.get_world_size()
+            except Exception:
+                nr = dist.get_world_size()
+            multi_gpu = {"backend": args.backend + (" (cuda) + gloo (cpu side)" if args.backend == "nccl" and cpu_side else ""), "rccl_version": rccl,
+                         "communicator_nranks": nr, "devices": topo, "distinct_devices": len({(t["host"], t["id"]) for t in topo}) if topo else None,
+                         "one_device_plumbing_mode": bool(args.one_device),
+                         "key_broadcast": dict(bcast_t, GBps=round(bcast_t["bytes"] / bcast_t["collective_s"] / 1e9, 2) if bcast_t and bcast_t.get("collective_s") else None) if bcast_t else None,
+                         "parity": parity}
         line = {
             "metric": "homomorphic ciphertext-mults/sec (incl. relinearize) at n=2^14, logQ=512" if args.workload == "metric"
                       else f"homomorphic ciphertext-mults/sec (incl. relinearize) at phi(m)={n} (m={M_RING}), logQ={LOGQ} (the reference drivers' own ring)" if args.workload == "refring"
@@ -831,7 +917,8 @@ def main():
                                            "centred_limbs": ksk.key_bits()[0], "key_coefficient_bits": ksk.key_bits()[1]}, "keys": args.keys, "batch_per_gpu": B, "options": {k: ctx.get_option(k) for k in ("lanes", "ks_direct", "ks_residues", "ks_aux60", "tensor32", "batch_chunk")},
                        "timed_region_s": round(dt, 3), "blocks": nblk, "block_values": [round(B * args.steps * world / d, 1) for d in block_dt],
                        "gpu_phase_s": round(gpu_phase_s, 3), "per_rank_value": per_rank, "key_broadcast_s": bcast_s,
-                       "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU"},
+                       "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU",
+                       "multi_gpu": multi_gpu},
             "matches_oracle": matches,
             "surface": surface,
             "roofline": roofline, "roofline_ntt": roofline_ntt, "roofline_ntt_tensor": roofline_ntt_tensor, "roofline_dot": roofline_dot, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
@@ -842,7 +929,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
-        raise SystemExit("bench: the timed output buffer differs from the oracle")
+        raise SystemExit("bench: the timed output buffer differs from the oracle" if parity is None else f"bench: parity failed on rank {rank} or another (per rank: {parity['per_rank_ok']}, digests equal: {parity['digests_equal']})")
 
 
 def ctx_download_tail(ctx, buf, B, ct_bytes):

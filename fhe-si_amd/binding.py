@@ -38,7 +38,9 @@ ABI_SYMBOLS = [
     "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
     "fhesi_ksk_form", "fhesi_ct_add_const_dev", "fhesi_ct_mul_poly_dev",
     "fhesi_encrypt_batch_seeded", "fhesi_keyswitch_init_batch_seeded", "fhesi_dcrt_sample",
+    "fhesi_abi_version", "fhesi_host_stage_release",
 ]
+ABI_VERSION = 6          # FHESI_ABI_VERSION of the include/fhesi_hip.h this table was written against (checked in _load)
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
 
@@ -81,6 +83,10 @@ def _load():
             pass
     lib = C.CDLL(_SO)
     lib.fhesi_last_error.restype = C.c_char_p
+    # a library of another ABI revision would accept this table's calls and shift their arguments: refuse it
+    have = lib.fhesi_abi_version() if hasattr(lib, "fhesi_abi_version") else None
+    if have != ABI_VERSION:
+        raise FhesiError(f"{_SO} has ABI revision {have}, this binding was written against {ABI_VERSION}: rebuild (make -C fhe-si_amd/csrc)")
     sig = {
         "fhesi_device_count": [_vp],
         "fhesi_ctx_create": [_vp, _i64, _i32, _vp, _vp, _i32],
@@ -143,6 +149,7 @@ def _load():
         "fhesi_ctx_copy_options": [_vp, _vp],
         "fhesi_host_alloc": [_vp, C.c_size_t, _vp],
         "fhesi_host_free": [_vp, _vp],
+        "fhesi_host_stage_release": [_vp],
         "fhesi_ksk_key_bits": [_vp, _vp, _vp],
         "fhesi_ksk_mark_dirty": [_vp],
         "fhesi_comm_init_all": [_i32, _vp, _vp],
@@ -435,9 +442,15 @@ class Context:
         buf = (C.c_char * max(n, 1)).from_address(ptr.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
         import weakref
-        h, lib, addr = self.h, _load(), ptr.value
-        weakref.finalize(buf, lambda: lib.fhesi_host_free(h, C.c_void_p(addr)))
+        # (the finalizer holds no context handle: fhesi_host_free does not dereference it, so the array may outlive the Context -- at
+        # interpreter shutdown the order of collection is arbitrary)
+        lib, addr = _load(), ptr.value
+        weakref.finalize(buf, lambda: lib.fhesi_host_free(None, C.c_void_p(addr)))
         return arr
+
+    def release_host_staging(self):
+        """hand back the pinned + device staging ring the host-buffer calls keep between uses"""
+        _ck(_load().fhesi_host_stage_release(self.h))
 
 
 class DoubleCRT:

@@ -37,6 +37,7 @@ int upload_idx(fhesi_ctx* ctx, const std::vector<int>& idx, int** d_out) {
 }
 
 // --------------------------------------------------------------------------------------------- context
+extern "C" int32_t fhesi_abi_version(void) { return FHESI_ABI_VERSION; }
 extern "C" int fhesi_device_count(int32_t* count) {
   int c = 0;
   hipError_t e = hipGetDeviceCount(&c);

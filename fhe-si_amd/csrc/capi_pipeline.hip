@@ -609,10 +609,20 @@ static int host_stage_get(fhesi_ctx* c, size_t slot_bytes, HostStage** out) {
   *out = h;
   return 0;
 }
-static bool is_pinned_host(const void* p) {
+// 0: pageable (or unknown to the runtime), 1: pinned / registered host memory covering [p, p + bytes), 2: device or managed memory (rejected
+// by the host-buffer entry: its staging copies are CPU memcpy).  A range only partly registered counts as pageable: the copy threads can
+// read and write it, the DMA engines could not.
+static int host_ptr_kind(const void* p, size_t bytes) {
   hipPointerAttribute_t at;
-  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return at.type == hipMemoryTypeHost;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeArray) return 2;
+  if (at.type != hipMemoryTypeHost) return 0;
+  if (bytes > 1) {
+    hipPointerAttribute_t end;
+    if (hipPointerGetAttributes(&end, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (end.type != hipMemoryTypeHost) return 0;
+  }
+  return 1;
 }
 extern "C" int fhesi_host_alloc(fhesi_ctx* c, size_t bytes, void** out) {
   CHECK_CTX(c);
@@ -620,9 +630,17 @@ extern "C" int fhesi_host_alloc(fhesi_ctx* c, size_t bytes, void** out) {
   if (hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; FHESI_FAIL("host_alloc: %zu pinned bytes not available", bytes); }
   return 0;
 }
-extern "C" int fhesi_host_free(fhesi_ctx* c, void* p) {
-  CHECK_CTX(c);
+// (the context is NOT dereferenced: pinned allocations are not counted in live_handles, so a caller -- or a garbage collector -- may free
+// them after fhesi_ctx_destroy; hipHostFree needs no current device)
+extern "C" int fhesi_host_free(fhesi_ctx* /*ctx: unused, may be null or already destroyed*/, void* p) {
   if (p) HIP_TRY(hipHostFree(p));
+  return 0;
+}
+// the staging ring of fhesi_ct_mul_relin_batch (two slots of pinned + device memory for three operands, ~1.5 GiB of each at the stress
+// ring) is kept between calls; a caller that is done with host-buffer batches hands it back here (the next call allocates it again)
+extern "C" int fhesi_host_stage_release(fhesi_ctx* c) {
+  CHECK_CTX(c);
+  if (c->host_stage) { HIP_TRY(hipStreamSynchronize(c->stream)); host_stage_free(c); }
   return 0;
 }
 
@@ -638,9 +656,12 @@ extern "C" int fhesi_ct_mul_relin_batch(fhesi_ctx* c, const fhesi_ksk* k, int32_
   // ciphertexts and 4 - 8 copy threads, 7.7 k with 128; 64 per call 8.5 k with stages of 16, 7.6 k with 32; 8 per call 5.1 k with two stages of 4)
   i64 hc = c->opt.host_chunk > 0 ? c->opt.host_chunk : (count >= 256 ? 32 : (count >= 32 ? 16 : std::max<i64>(1, (count + 1) / 2)));
   if (hc > count) hc = count;
+  const size_t total_bytes = (size_t)count * ct_bytes;
+  const int ka = host_ptr_kind(a, total_bytes), kb = host_ptr_kind(b, total_bytes), ko = host_ptr_kind(out, total_bytes);
+  if (ka == 2 || kb == 2 || ko == 2) FHESI_FAIL("ct_mul_relin_batch takes HOST buffers (operand %s is device memory): use fhesi_ct_mul_relin_batch_dev", ka == 2 ? "a" : kb == 2 ? "b" : "out");
+  const bool pa = ka == 1, pb = kb == 1, po = ko == 1;
   HostStage* h;
   FHESI_TRY(host_stage_get(c, (size_t)hc * ct_bytes, &h));
-  const bool pa = is_pinned_host(a), pb = is_pinned_host(b), po = is_pinned_host(out);
   const i64 nst = (count + hc - 1) / hc;
   // inside a stage the pageable side moves in pieces: the copy threads fill piece j + 1 of the ring while the DMA engine takes piece j up,
   // and on the way back they empty piece j while piece j + 1 comes down (one event per piece)

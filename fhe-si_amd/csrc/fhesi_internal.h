@@ -69,7 +69,7 @@ struct ProfRec { int cls; double units; hipEvent_t e0, e1; };
 // the context is created, as initial values -- never per call.
 struct CtxOptions {
   long long host_chunk = 0;  // ciphertexts per stage of the host-buffer pipeline of fhesi_ct_mul_relin_batch (0 = derived from the batch)
-  int host_threads = 0;     // threads that copy between the caller's pageable buffers and the pinned ring (0 = min(16, hardware threads))
+  int host_threads = 0;     // threads that copy between the caller's pageable buffers and the pinned ring (0 = min(8, hardware threads): 8 measured best, profiles/r04_host_buffers.txt)
   int ks_long_keys = 0;     // 1: limbs cut from the key coefficient in [0, P) whatever its size (the general form; A/B and checker of the centred limbs)
   int dot32_small = 0;      // key switch with at most 8 limbs (A/B): 0 = the plain 8-wave form (default), 1 = two groups of four waves on half of the tile's ciphertexts each, 2 = workgroups of four waves on tiles of 4 ciphertexts
   int ks_direct = 0;        // 1: per-chain-prime key-switch dot product (the reference's structure) instead of the auxiliary-prime path

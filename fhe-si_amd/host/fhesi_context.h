@@ -157,6 +157,8 @@ class FHEcontext {
       std::vector<uint64_t> q, r;
       for (auto& c : moduli) { q.push_back((uint64_t)c.getQ()); r.push_back((uint64_t)c.getRoot()); }
       if (q.empty()) Error("FHEcontext: no primes in the chain");
+      // (a library of another ABI revision would link and shift arguments silently: include/fhesi_hip.h, FHESI_ABI_VERSION)
+      if (fhesi_abi_version() != FHESI_ABI_VERSION) Error("libfhesi_hip.so and fhesi_hip.h disagree on the ABI revision: rebuild");
       ck(fhesi_ctx_create(&dev, m_, (int32_t)q.size(), q.data(), r.data(), device));
       std::vector<int32_t> idx(m_); std::vector<int64_t> phi(fhesi_ctx_phim(dev) + 1);
       ck(fhesi_ctx_zms_idx(dev, idx.data())); ck(fhesi_ctx_phi_m(dev, phi.data()));

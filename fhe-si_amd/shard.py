@@ -13,16 +13,88 @@ def shard_bounds(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def broadcast_key_matrix(ksm_host, nbytes: int, dist, device=None, src: int = 0):
+def broadcast_key_matrix(ksm_host, nbytes: int, dist, device=None, src: int = 0, timings: dict | None = None):
     """Rank `src` passes the [2][ncomp*nd][L][phim] uint64 key-switch matrix (KeySwitchSI::keySwitchMatrix,
     FHE-SI.cpp:206-208); every rank returns a torch tensor (int64 view, `nbytes` bytes) holding the broadcast copy on
-    `device` (None = CPU for the gloo tests)."""
+    `device` (None = CPU for the gloo tests).  `timings` (optional) receives staging_s (rank src: host -> device copy of the matrix)
+    and collective_s (the broadcast itself, synchronised) -- two different costs that a single stopwatch would add up."""
+    import time
     import torch
+    on_gpu = device is not None and str(device) != "cpu"
     t = torch.empty(nbytes // 8, dtype=torch.int64, device=device if device is not None else "cpu")
+    t0 = time.perf_counter()
     if dist.get_rank() == src:
         t.copy_(torch.from_numpy(np.ascontiguousarray(ksm_host).view(np.int64).reshape(-1)))
+    if on_gpu:
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
     dist.broadcast(t, src=src)
+    if on_gpu:
+        torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    if timings is not None:
+        timings["staging_s"] = round(t1 - t0, 4)
+        timings["collective_s"] = round(t2 - t1, 4)
+        timings["bytes"] = int(nbytes)
     return t
+
+
+def device_identity(torch, index: int) -> dict:
+    """What tells the GPU behind `cuda:index` of THIS process apart from any other GPU of the node: its UUID where the runtime
+    reports one, else its PCI address; plus the name and the host.  (LOCAL_RANK alone proves nothing: with HIP_VISIBLE_DEVICES set
+    per process, index 0 is a different GPU in every rank -- or the same one in all of them.)"""
+    import socket
+    props = torch.cuda.get_device_properties(index)
+    ident = None
+    u = getattr(props, "uuid", None)
+    if u is not None and str(u).strip("0-") != "":
+        ident = "uuid:" + str(u)
+    if ident is None:
+        pci = [getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        if any(v is not None for v in pci):
+            ident = "pci:" + ":".join("?" if v is None else f"{int(v):x}" for v in pci)
+    if ident is None:
+        ident = f"index:{index}"              # (nothing better: distinct only within one process's view)
+    return {"host": socket.gethostname(), "device_index": int(index), "id": ident, "name": getattr(props, "name", None),
+            "visible": __import__("os").environ.get("HIP_VISIBLE_DEVICES") or __import__("os").environ.get("CUDA_VISIBLE_DEVICES")}
+
+
+def roll_call(dist, ident: dict, allow_shared: bool = False) -> list:
+    """Every rank's device identity, gathered on every rank through the CPU side of the process group BEFORE any device collective
+    runs.  Two ranks naming the same (host, device id) raise RuntimeError on EVERY rank (all of them have left the gather, so none
+    is left waiting): an RCCL communicator over a shared GPU hangs or fails in ways that are hard to read, and a run with shared
+    devices measures nothing.  allow_shared = the plumbing mode of a 1-GPU box (bench.py --one-device)."""
+    world = dist.get_world_size()
+    got = [None] * world
+    dist.all_gather_object(got, dict(ident, rank=dist.get_rank()))
+    seen = {}
+    for g in got:
+        seen.setdefault((g["host"], g["id"]), []).append(g["rank"])
+    shared = {k: v for k, v in seen.items() if len(v) > 1}
+    if shared and not allow_shared:
+        raise RuntimeError("ranks share a GPU: " + "; ".join(f"{k[1]} on {k[0]} <- ranks {v}" for k, v in shared.items()) +
+                           " (one process per GPU is required: check LOCAL_RANK / HIP_VISIBLE_DEVICES; --one-device is the 1-GPU plumbing mode)")
+    return got
+
+
+def digest64(arr: np.ndarray) -> int:
+    """64-bit digest of an array's bytes (blake2b): what the ranks compare instead of shipping whole results"""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b(np.ascontiguousarray(arr).tobytes(), digest_size=8).digest(), "little")
+
+
+def all_ranks_agree(dist, value: int):
+    """(True if every rank holds rank 0's value, the list of values by rank) -- an object collective on the CPU side"""
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, int(value))
+    return all(v == got[0] for v in got), got
+
+
+def all_ranks_ok(dist, ok: bool):
+    """(True if `ok` on every rank, the list by rank)"""
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, bool(ok))
+    return all(got), got
 
 
 def gather_to_rank0(local: np.ndarray, total: int, dist):

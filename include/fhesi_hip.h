@@ -38,6 +38,13 @@ enum { FHESI_OP_ADD = 0, FHESI_OP_SUB = 1, FHESI_OP_MUL = 2, FHESI_OP_DIV = 3, F
 
 const char* fhesi_last_error(void);
 int fhesi_device_count(int32_t* count);
+/* ABI revision of this header.  It changes whenever an existing entry point changes its parameters (revision 5:
+ * fhesi_keyswitch_init_batch_seeded took its public_seed argument in round 4; revision 6 adds this query and
+ * fhesi_host_stage_release).  A binding compiled or written against another revision must refuse to run: the Python binding
+ * (fhe-si_amd/binding.py) and the C++ mirror (fhe-si_amd/host/fhesi_context.h) compare FHESI_ABI_VERSION with the library's
+ * answer when they load it -- a stale ctypes table or mirror would otherwise link and silently shift arguments. */
+#define FHESI_ABI_VERSION 6
+int32_t fhesi_abi_version(void);
 
 /* ---- context: FHEcontext::AddPrime (FHEContext.cpp:30-43) + Cmod::privateInit (CModulus.cpp:60-86) +
  * PAlgebra::init (PAlgebra.cpp:40-56).  Tables (twiddles / Bluestein powers and Rb) are built eagerly and
@@ -175,9 +182,12 @@ int fhesi_ct_mul_relin_batch(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, u
 /* The host-buffer form runs as a pipeline of stages over a pinned staging ring: upload of stage i + 1, compute of stage i and download of
  * stage i - 1 overlap on three streams, and pageable buffers are copied into / out of the ring by several threads (options "host_chunk":
  * ciphertexts per stage, "host_threads").  Buffers allocated with fhesi_host_alloc (pinned) are read and written by the DMA engines
- * directly, without the copy.  Same bits as the _dev form. */
+ * directly, without the copy (only when the WHOLE batch lies in pinned / registered memory; a partly registered range is treated as
+ * pageable).  Device or managed pointers are rejected with an error: this entry takes host memory, the _dev form device memory.
+ * Same bits as the _dev form. */
 int fhesi_host_alloc(fhesi_ctx* ctx, size_t bytes, void** out);                      /* pinned host memory for ciphertext batches */
-int fhesi_host_free(fhesi_ctx* ctx, void* p);
+int fhesi_host_free(fhesi_ctx* ctx, void* p);                                        /* ctx is not dereferenced (may be null or already destroyed) */
+int fhesi_host_stage_release(fhesi_ctx* ctx);                                        /* frees the pinned + device staging ring kept between host-buffer calls */
 int fhesi_ct_mul_relin_batch_dev(fhesi_ctx* ctx, const fhesi_ksk* k, int32_t logQ, uint64_t p, int32_t decomp_bytes,
                                  const uint64_t* a_dev, const uint64_t* b_dev, uint64_t* out_dev, int32_t nlimbs, int64_t count);
 /* Separately callable stages of the same pipeline (parity tests check each against the oracle) */

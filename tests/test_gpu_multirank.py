@@ -183,6 +183,44 @@ def test_bench_launches_its_own_ranks(workload, extra):
     assert d["roofline"]["kernel"] and d["roofline"]["frac"] > 0
     if workload == "metric":
         assert len(d["config"]["per_rank_value"]) == 2 and d["config"]["blocks"] >= 1 and d["config"]["key_broadcast_s"] > 0
+        mg = d["config"]["multi_gpu"]
+        assert mg["communicator_nranks"] == 2 and len(mg["devices"]) == 2 and mg["distinct_devices"] == 1 and mg["one_device_plumbing_mode"]
+        assert mg["key_broadcast"]["staging_s"] >= 0 and mg["key_broadcast"]["collective_s"] > 0 and mg["key_broadcast"]["bytes"] > 0
+        par = mg["parity"]          # every rank recomputed rank 0's first pair with its own copy of the key matrix
+        assert par["all_ok"] and par["digests_equal"] and len(set(par["rank0_first_pair_digest_by_rank"])) == 1 and par["per_rank_ok"] == [True, True]
+        assert d["matches_oracle"] is None          # (--cpu-sample 0: the ranks' agreement only)
+
+
+def test_bench_two_ranks_checks_every_rank_against_the_oracle():
+    """N > 1 with the oracle on: every rank holds its own timed buffer to the oracle evaluated on ITS copy of the broadcast key matrix,
+    all ranks agree on rank 0's first pair, and the line says so (matches_oracle true instead of null)."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "1", "--no-bluestein-cpu", "--gpu-seconds", "0", "--batch", "16"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["matches_oracle"] is True and d["config"]["multi_gpu"]["parity"]["oracle_checked_on_every_rank"] is True
+    assert d["cpu_baseline"] is None            # (the CPU figure is an N = 1 quantity)
+
+
+def test_bench_refuses_ranks_that_share_a_gpu():
+    """Two ranks driving the same GPU without --one-device (a launcher that hands every rank LOCAL_RANK=0) must END with a message, on
+    every rank, before any RCCL communicator exists -- not hang in a collective."""
+    import socket
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--batch", "8"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode != 0 and "ranks share a GPU" in se, se[-1500:]
+        assert not any(ln.startswith("{") for ln in so.splitlines())
 
 
 @pytest.mark.parametrize("args", [["--devices=0,0,0"], ["46", "90", "47", "5", "--devices=0,0"]])

@@ -439,6 +439,37 @@ def test_host_buffer_pipeline_equals_the_device_batch(count, host_chunk):
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, big, np.concatenate([b, b])), np.concatenate([want, want]))
 
 
+def test_host_buffer_entry_rejects_device_memory_and_releases_its_ring():
+    """The host-buffer entry copies with CPU threads: a device pointer must be refused with an error (not dereferenced); a pinned array may
+    outlive its Context (fhesi_host_free does not touch the context); fhesi_host_stage_release hands the staging ring back and the next
+    call allocates it again with the same results."""
+    import ctypes as C
+    m, logQ, p = 2048, 128, 23
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 91, 4)
+    n = ctx.phim
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    want = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert np.array_equal(want[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
+    da = ctx.upload(a)
+    lib = F.binding._load()
+    out = np.zeros_like(a)
+    rc = lib.fhesi_ct_mul_relin_batch(ctx.h, ksk.h, logQ, p, 3, C.c_void_p(da.ptr.value), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), nl, 4)
+    assert rc != 0 and b"device memory" in lib.fhesi_last_error()
+    ctx.release_host_staging()
+    ctx.release_host_staging()                     # (idempotent)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b), want)
+    assert lib.fhesi_abi_version() == F.binding.ABI_VERSION
+    # a pinned array that outlives its context
+    ctx2 = F.Context(m, *P.chain_for(m, logQ, p))
+    arr = ctx2.host_array((16,))
+    arr[...] = 7
+    ctx2.close()
+    assert int(arr.sum()) == 112
+    del arr
+    import gc
+    gc.collect()
+
+
 @pytest.mark.parametrize("m,logQ,p", [(32768, 512, 23), (32768, 130, 23), (1 << 16, 300, 65537), (8422, 341, 8423), (101, 80, 23)])
 def test_key_switch_centred_limbs_of_generated_matrices(m, logQ, p):
     """KeySwitchSI::Init (FHE-SI.cpp:176-204) samples its polynomial modulo 2^logQ and reduces b modulo 2^logQ: the integer coefficients of a

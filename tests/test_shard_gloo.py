@@ -72,3 +72,52 @@ def test_shard_bounds_cover_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _roll_call_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from fhe_si_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    # distinct devices: every rank gets the whole list
+    got = shard.roll_call(dist, {"host": "h", "id": f"uuid:{rank}", "device_index": rank, "name": "x", "visible": None})
+    res["distinct"] = [g["rank"] for g in got] == list(range(world)) and len({g["id"] for g in got}) == world
+    # a shared device: refused on EVERY rank (nobody is left waiting), with the ranks named
+    try:
+        shard.roll_call(dist, {"host": "h", "id": "uuid:same", "device_index": 0, "name": "x", "visible": None})
+        res["shared_refused"] = False
+    except RuntimeError as e:
+        res["shared_refused"] = "ranks share a GPU" in str(e) and "[0, 1]" in str(e)
+    # ... unless the caller asked for the one-GPU plumbing mode; the same id on two HOSTS is two devices
+    res["shared_allowed"] = len(shard.roll_call(dist, {"host": "h", "id": "uuid:same", "device_index": 0, "name": "x", "visible": None}, allow_shared=True)) == world
+    res["two_hosts"] = len(shard.roll_call(dist, {"host": f"h{rank}", "id": "uuid:same", "device_index": 0, "name": "x", "visible": None})) == world
+    # digests: equal arrays agree, a single differing bit on one rank is seen by all
+    a = np.arange(1000, dtype=np.uint64)
+    ok, vals = shard.all_ranks_agree(dist, shard.digest64(a))
+    res["agree"] = ok and len(vals) == world
+    if rank == 1:
+        a[500] ^= 1
+    ok, vals = shard.all_ranks_agree(dist, shard.digest64(a))
+    res["disagree_seen"] = (not ok) and vals[0] != vals[1]
+    ok_all, per = shard.all_ranks_ok(dist, rank != 1)
+    res["ok_flags"] = (not ok_all) and per == [True, False]
+    # the broadcast reports its two costs separately
+    t = {}
+    m = np.arange(64, dtype=np.uint64).reshape(2, 4, 2, 4) if rank == 0 else None
+    out = shard.broadcast_key_matrix(m, 64 * 8, dist, timings=t)
+    res["timings"] = set(t) == {"staging_s", "collective_s", "bytes"} and t["bytes"] == 512 and out.numpy().view(np.uint64).tolist() == list(range(64))
+    np.save(os.path.join(outdir, f"r{rank}.npy"), np.array([int(all(res.values()))] + [int(v) for v in res.values()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_roll_call_digests_and_broadcast_timings(tmp_path):
+    """What bench.py does before and after its timed region at N > 1 (CPU side of the process group): the device roll call refuses shared
+    GPUs on every rank, result digests are compared across ranks, ok flags are combined, the key broadcast splits staging from collective."""
+    port = _free_port()
+    mp.spawn(_roll_call_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        v = np.load(tmp_path / f"r{r}.npy")
+        assert v[0] == 1, (r, v.tolist())
