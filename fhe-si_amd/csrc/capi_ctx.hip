@@ -78,6 +78,8 @@ static const OptDesc kOptions[] = {
   {"wave_operands", "FHESI_WAVE_OPERANDS", offsetof(CtxOptions, wave_operands), true},
   {"wave_single", "FHESI_WAVE_SINGLE", offsetof(CtxOptions, wave_single), false},
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
+  {"digit_group", "FHESI_DIGIT_GROUP", offsetof(CtxOptions, digit_group), false},
+  {"parts_words", "FHESI_PARTS_WORDS", offsetof(CtxOptions, parts_words), false},
   {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
   {"dot32_half", "FHESI_DOT32_HALF", offsetof(CtxOptions, dot32_half), false},
   {"dot32_mfma", "FHESI_DOT32_MFMA", offsetof(CtxOptions, dot32_mfma), false},

@@ -102,8 +102,10 @@ extern "C" int fhesi_ct_mul_dev(fhesi_ctx* c, uint64_t p, const uint64_t* a, con
 // ByteDecomp + DoubleCRT(digit polys) + DotProduct + toPoly + ReduceCoefficients (FHE-SI.cpp:244-256) from parts that are already
 // positive residues mod 2^logQ in limb-major layout [count*ncomp][nlq][n].  d_t: scratch for count*2 DoubleCRTs, needed by the per-prime
 // and the residue forms only (null: reserved here, workspace slot 1, when one of those runs -- the limb forms never touch it).
+// parts_wm: d_parts are 32-bit word rows (launch_tensor32 parts_wm) -- only the four-prime limb form reads those; the caller asks for them
+// only when ksaux_mode says that form runs.
 static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32_t decomp_bytes, const u64* d_parts, int64_t count, u64* d_t,
-                           uint64_t* out, int32_t nlimbs) {
+                           uint64_t* out, int32_t nlimbs, bool parts_wm = false) {
   const i64 n = c->phim;
   const int L = c->L, ncomp = k->ncomp, nd = k->ndigits, ncol = ncomp * nd, nlq = (logQ + 63) / 64;
   const std::vector<int> all = full_set(c);
@@ -113,6 +115,7 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
   // option ks_direct keeps the per-prime dot product below (A/B measurements; also the path of every shape the other does not cover).
   const int ks_mode = ksaux_mode(c, t, ncol, 8 * decomp_bytes, logQ);
   const_cast<fhesi_ksk*>(k)->last_form = ks_mode;
+  if (parts_wm && ks_mode != KS_MODE_LIMB32) FHESI_FAIL("key switch: word-major parts handed to a form that reads limb rows (internal)");
   if (ks_mode != KS_MODE_DIRECT) {
     fhesi_ksk* km = const_cast<fhesi_ksk*>(k);
     if (!k->aux_valid || k->aux_mode != ks_mode || k->aux_suborder != ntt_digits_suborder(c, 8 * decomp_bytes) || k->aux_logQ != logQ || k->aux_long_opt != c->opt.ks_long_keys) FHESI_TRY(ksaux_build(c, km, 8 * decomp_bytes, logQ, ks_mode));
@@ -121,8 +124,9 @@ static int key_switch_tail(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, int32
     void *d_dig, *d_o;
     FHESI_TRY(ws_reserve(c, 0, (size_t)count * ncol * 2 * nrow * 8, &d_dig));
     FHESI_TRY(ws_reserve(c, 10, (size_t)count * 2 * R * 2 * nrow * 8, &d_o));
+    if (parts_wm && !k->aux32) FHESI_FAIL("key switch: word-major parts without the four-prime table (internal)");
     if (k->aux32) {       // four 30-bit primes (kernels_aux32.hip): the same buffer sizes, u32 rows
-      FHESI_TRY(launch_ntt32_fwd_digits(c, d_parts, nlq, 8 * decomp_bytes, nd, count * ncomp, (u32*)d_dig, kDigitSubCt * ncol));
+      FHESI_TRY(launch_ntt32_fwd_digits(c, d_parts, nlq, 8 * decomp_bytes, nd, count * ncomp, (u32*)d_dig, kDigitSubCt * ncol, parts_wm));
       if (c->mark_mid) { HIP_TRY(hipEventRecord(c->ev_mid, c->stream)); c->mark_mid = false; }
       bool mont = true;                 // dot32_kernel2 leaves the factor 2^-32 of its Montgomery step; the matrix-core form does not
       FHESI_TRY(launch_dot32(c, km, (const u32*)d_dig, ncol, count, (u32*)d_o, &mont));
@@ -404,8 +408,9 @@ extern "C" int fhesi_ct_mul_sum_relin_dev(fhesi_ctx* c, const fhesi_ksk* k, int3
     if (t32) {
       void* d_parts;
       FHESI_TRY(ws_reserve(c, 2, (size_t)ng * 3 * ((logQ + 63) / 64) * n * 8, &d_parts));
-      FHESI_TRY(tensor32_sum_finish(c, d_sum, ng, (u64*)d_parts));
-      FHESI_TRY(key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, ng, nullptr, out + (size_t)g * ct_words, nlimbs));
+      const bool wm = c->opt.parts_words && ksaux_mode(c, t_all, k->ncomp * k->ndigits, 8 * decomp_bytes, logQ) == KS_MODE_LIMB32;
+      FHESI_TRY(tensor32_sum_finish(c, d_sum, ng, (u64*)d_parts, wm));
+      FHESI_TRY(key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, ng, nullptr, out + (size_t)g * ct_words, nlimbs, wm));
     } else {
       FHESI_TRY(fhesi_apply_key_switch_dev(c, k, logQ, decomp_bytes, (const uint64_t*)d_sum, ng, out + (size_t)g * ct_words, nlimbs));
     }
@@ -475,8 +480,9 @@ static int mul_relin_chunks(fhesi_ctx* c, const fhesi_ksk* k, int32_t logQ, uint
       void* d_parts = nullptr;
       rc = ws_reserve(c, 2, (size_t)cnt * 3 * ((logQ + 63) / 64) * n * 8, &d_parts);
       if (c->op_idx) c->op_idx_done = done;                  // indexed operands: the chunk is a window of the index arrays, the buffer stays put
-      if (!rc) rc = launch_tensor32(c, p, c->op_idx ? a : a + off, c->op_idx ? b : b + off, nlimbs, logQ, cnt, (u64*)d_parts);
-      if (!rc) rc = key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, cnt, nullptr, out + off, nlimbs);
+      const bool wm = ks_mode == KS_MODE_LIMB32 && c->opt.parts_words;      // (the digit loader of the four-prime form reads word rows in whole lines)
+      if (!rc) rc = launch_tensor32(c, p, c->op_idx ? a : a + off, c->op_idx ? b : b + off, nlimbs, logQ, cnt, (u64*)d_parts, wm);
+      if (!rc) rc = key_switch_tail(c, k, logQ, decomp_bytes, (const u64*)d_parts, cnt, nullptr, out + off, nlimbs, wm);
     } else {
       if (c->op_idx) FHESI_FAIL("ct_mul_relin: indexed operands reached the chain path");      // (only the 30-bit tensor half reads through indices; the caller checks tensor32_applies)
       void* d_tp = nullptr;

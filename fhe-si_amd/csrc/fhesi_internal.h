@@ -87,6 +87,8 @@ struct CtxOptions {
   int dot32_v3 = 0;         // 1: dot32_kernel3 (two limbs per wave, 4 ciphertexts per tile, two workgroups per CU)
   int automorph_rows = 0;   // 1: Ciphertext >>= through DoubleCRT::automorph on evaluation rows (the reference's structure) even where the coefficient gather applies
   int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)
+  int digit_group = 1;      // units (digit polynomials) per XCD group of the 32-bit digit transform: 1 = single units (default: the order of rounds 2-4); -1 = one polynomial's digits per XCD when the launch has >= 32 polynomials (source rows leave HBM once: FETCH_SIZE 3.4x lower, the kernel 1.6 % SLOWER, profiles/r05_ab_digit_fwd.txt); g > 1 = groups of g units
+  int parts_words = 1;      // 1: inside the fused multiplication the scaled-down parts travel as 32-bit word rows (crt32_scale -> digit loader); 0 = 64-bit limb rows (A/B)
 };
 
 struct fhesi_ctx {
@@ -206,19 +208,21 @@ void aux32_free(fhesi_ctx* ctx);
 void tensor32_free(fhesi_ctx* ctx);
 void host_stage_free(fhesi_ctx* ctx);            // capi_pipeline.hip
 bool tensor32_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ);
-int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts /* [count*3][logQ/64][n] */);
+// parts_wm: the scaled-down parts leave as 32-bit WORD rows [count*3][2 ceil(logQ/64)][n] (same bytes per polynomial, word-major) -- the layout the
+// 32-bit digit loader (launch_ntt32_fwd_digits, wm) reads in whole cache lines; false: 64-bit limb rows, what every other consumer takes
+int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts /* [count*3][logQ/64][n] */, bool parts_wm = false);
 // ... and for sums of products per group (fhesi_ct_mul_sum_relin_dev): begin fixes the configuration for at most gmax terms per group
 bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax);
 int tensor32_sum_begin(fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 gmax);
 size_t tensor32_sum_bytes(const fhesi_ctx* ctx, i64 ngroups);
 int tensor32_sum_pass(fhesi_ctx* ctx, const u64* d_ops, i64 nua, i64 nub, const int* d_slot_a, const int* d_slot_b, const int* d_seg, i64 ng, i64 nterms, bool accumulate, void* d_sum);
-int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts);
+int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts, bool parts_wm = false);
 const u32* aux32_primes(fhesi_ctx* ctx);          // the four primes (host array), nullptr on error
 int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0);
 int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0, bool mont /* input scaled by 2^-32: dot32_kernel2 */, bool tail = true /* false: rows of 2^15 are left as their two sub-inverses */);
 constexpr i64 kDigitSubCt = 64;                   // ciphertexts per sub-chunk of the tiled 32-bit digit rows (launch_ntt32_fwd_digits <-> launch_dot32)
 int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out /* tiled, see ntt32_core.inc */,
-                            i64 sub_units /* units (digit polynomials) per sub-chunk */);
+                            i64 sub_units /* units (digit polynomials) per sub-chunk */, bool wm = false /* d_parts as 32-bit word rows (launch_tensor32 parts_wm) */);
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp /* one prime's rows */, bool centred = false /* d_kint holds centred two's complement values: top limb signed */);
 int ks32_key_bits(fhesi_ctx* ctx, const u64* d_kint /* [count][W] centred two's complement */, i64 count, int W, int* nbits /* smallest nb with every value in [-2^nb, 2^nb] */);
 bool aux32_applies(const fhesi_ctx* ctx);          // n = 2^14 or 2^15, or a ring with lin_q set

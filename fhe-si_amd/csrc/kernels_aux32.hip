@@ -116,6 +116,7 @@ static int aux32_init(fhesi_ctx* ctx) {
     if (!S) { x->pr.ninv_mw[a][1] = x->pr.ninv_mw[a][0]; x->pr.ninv_mw_p[a][1] = x->pr.ninv_mw_p[a][0]; }
     if (p > ((u64)1 << 30) - ((u64)1 << 15) + 1) { delete x; FHESI_FAIL("aux32: prime above 2^30 - 2^15 + 1"); }     // the bound dot32_kernel2's accumulation relies on
   }
+  a32_permute_phase_c(hf); a32_permute_phase_c(hi);      // (the last four stages' twiddles in the order the waves load them: A32_TWC)
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
   HIP_TRY(hipMemcpy(x->d_fwd, hf.data(), hf.size() * sizeof(Tw32), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(x->d_inv, hi.data(), hi.size() * sizeof(Tw32), hipMemcpyHostToDevice));
@@ -171,7 +172,7 @@ int aux32_tail_consts(fhesi_ctx* ctx, uint32_t (*tw)[2], uint32_t (*twp)[2]) {
   return 0;
 }
 // digit rows, tiled [4][row length / 64][npolys * nd][64] u32, straight from the scaled-down parts
-int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out, i64 sub_units) {
+int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digit_bits, int nd, i64 npolys, u32* d_out, i64 sub_units, bool wm) {
   FHESI_TRY(aux32_init(ctx));
   if (!npolys) return 0;
   const fhesi_aux32* x = ctx->aux32;
@@ -181,12 +182,25 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   const i64 units = npolys * nd;
   if (units > 0x7fffffff) FHESI_FAIL("ntt32: too many digit rows per launch");
   if (digit_bits > 30) FHESI_FAIL("ntt32: digits of %d bits (the first stage of a digit row assumes values below 2p)", digit_bits);
-  const Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
-  const i64 ug = A32_LAY_PAIR ? (units + 15) / 16 * 2 : (units + 7) / 8;      // groups of 8 units (one per XCD), x 4 primes x 2^S sub-blocks workgroups each
-  if (S && ctx->lin_q) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1, true>); ntt32_fwd_kernel3<true, 1, true><<<(unsigned)(ug * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
-  else if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 1>); ntt32_fwd_kernel3<true, 1><<<(unsigned)(ug * 64), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
-  else if (ctx->phim < A32_N) { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0, true>); ntt32_fwd_kernel3<true, 0, true><<<(unsigned)(ug * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
-  else { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<true, 0>); ntt32_fwd_kernel3<true, 0><<<(unsigned)(ug * 32), A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); }
+  Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
+  // XCD groups (ntt32_fwd_kernel3), option digit_group: 1 = single units (default), -1 = one polynomial's digits per XCD when that still leaves
+  // every XCD several polynomials, g > 1 = groups of g units
+  const int PS = 4 << S;
+  i64 grp = ctx->opt.digit_group < 0 ? (npolys >= 32 ? nd : 1) : std::max<i64>(1, ctx->opt.digit_group);
+  if (A32_LAY_PAIR) grp = 1;
+  src.grp = (u32)grp; src.gb = (u32)(grp * PS); src.gb_inv = div32_inv(src.gb);
+  const i64 ngroups = (units + grp - 1) / grp;
+  const i64 blocks = A32_LAY_PAIR ? (units + 15) / 16 * 2 * 8 * PS : (ngroups + 7) / 8 * 8 * grp * PS;      // groups dealt round-robin to the 8 XCDs, grp * PS workgroups each
+  if (blocks > 0x7fffffff) FHESI_FAIL("ntt32: too many workgroups per launch");
+#define A32_DIG_GO(SS, PP, WW) do { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, (ntt32_fwd_kernel3<true, SS, PP, Aux32Primes, true, WW>)); \
+    ntt32_fwd_kernel3<true, SS, PP, Aux32Primes, true, WW><<<(unsigned)blocks, A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); } while (0)
+#define A32_DIG_W(SS, PP) do { if (wm) A32_DIG_GO(SS, PP, true); else A32_DIG_GO(SS, PP, false); } while (0)
+  if (S && ctx->lin_q) A32_DIG_W(1, true);
+  else if (S) A32_DIG_W(1, false);
+  else if (ctx->phim < A32_N) A32_DIG_W(0, true);
+  else A32_DIG_W(0, false);
+#undef A32_DIG_W
+#undef A32_DIG_GO
   HIP_TRY(hipGetLastError());
   return 0;
 }

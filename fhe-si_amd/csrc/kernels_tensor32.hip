@@ -196,6 +196,7 @@ static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
   }
   hipFree(x->d_fwd); hipFree(x->d_inv);
   x->d_fwd = x->d_inv = nullptr;
+  a32_permute_phase_c(hf); a32_permute_phase_c(hi);      // (the last four stages' twiddles in the order the waves load them: A32_TWC)
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) FHESI_FAIL("tensor32: hipMalloc failed");
   HIP_TRY(hipMemcpy(x->d_fwd, hf.data(), hf.size() * sizeof(Tw32), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(x->d_inv, hi.data(), hi.size() * sizeof(Tw32), hipMemcpyHostToDevice));
@@ -470,7 +471,7 @@ __global__ void __launch_bounds__(256) tensor_sum32_kernel(const u32* __restrict
 template <int LQ, bool EXACT, int R, int WT, int S>
 __global__ void __launch_bounds__(128) crt32_scale_kernel(const u32* __restrict__ rows, i64 n, int NP, T32Primes pr, const Tw32* __restrict__ cinv,
                                                            const u32* __restrict__ inv57, const u32* __restrict__ Mw, u64* __restrict__ out,
-                                                           unsigned char* __restrict__ flags) {
+                                                           unsigned char* __restrict__ flags, int wm /* 1: out as 32-bit WORD rows [npolys][LQ/32][n] (what the 32-bit digit loader reads whole lines of) */) {
   static_assert((LQ & 63) == 0, "logQ a multiple of 64");
   constexpr int WU = (2 * LQ + R - 1) / R;            // words that reach below bit 2 logQ
   constexpr int J0 = EXACT ? 0 : (LQ - 64 - 30 - 8) / R;     // first word formed: R J0 + 30 + log2(NP + 1) + 1 <= logQ - 64
@@ -523,12 +524,14 @@ __global__ void __launch_bounds__(128) crt32_scale_kernel(const u32* __restrict_
   if (!EXACT) undecided = (G == 0x7fffffffffffffffull) ? 1 : 0;
   u64 c = G >> 63;                                     // round half up: + bit logQ-1
   u64* __restrict__ o = out + poly * (LQ / 64) * n + j;
+  u32* __restrict__ o32 = reinterpret_cast<u32*>(out) + poly * (LQ / 32) * n + j;
 #pragma unroll
   for (int i = 0; i < LQ / 64; ++i) {
     u64 v = limb(LQ + 64 * i);
     v += c;
     c = (c && v == 0) ? 1 : 0;
-    o[(i64)i * n] = v;
+    if (wm) { o32[(i64)(2 * i) * n] = (u32)v; o32[(i64)(2 * i + 1) * n] = (u32)(v >> 32); }
+    else o[(i64)i * n] = v;
   }
   if (!EXACT) {
     const int any = __syncthreads_or(undecided);
@@ -553,7 +556,7 @@ __global__ void __launch_bounds__(128) crt32_scale_kernel(const u32* __restrict_
 template <int NWMAX, bool EXACT, int S, int FOLD>
 __global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __restrict__ rows, i64 nrow, i64 n_out, i64 fold_off, int NP, int LQ, int J0, int NW, int WT,
                                                                    T32Primes pr, const Tw32* __restrict__ cinv, const u32* __restrict__ inv57, const u32* __restrict__ Mw,
-                                                                   u64* __restrict__ out, unsigned char* __restrict__ flags) {
+                                                                   u64* __restrict__ out, unsigned char* __restrict__ flags, int wm) {
   constexpr int R = 28;
   __shared__ u32 xs[NWMAX * 128];
   const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -649,13 +652,15 @@ __global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __r
     u64 c = G >> 63;                                     // round half up: + bit logQ-1
     const int nlq = (LQ + 63) >> 6;
     u64* __restrict__ o = out + poly * nlq * n_out + j;
+    u32* __restrict__ o32 = reinterpret_cast<u32*>(out) + poly * (2 * nlq) * n_out + j;
     for (int i = 0; i < nlq; ++i) {
       u64 v = limb(LQ + 64 * i);
       v += c;
       c = (c && v == 0) ? 1 : 0;
       const int bits_left = LQ - 64 * i;
       if (bits_left < 64) v &= ((u64)1 << bits_left) - 1;
-      o[(i64)i * n_out] = v;
+      if (wm) { o32[(i64)(2 * i) * n_out] = (u32)v; o32[(i64)(2 * i + 1) * n_out] = (u32)(v >> 32); }
+      else o[(i64)i * n_out] = v;
     }
   }
   if (!EXACT) {
@@ -705,30 +710,30 @@ static int t32_fwd(fhesi_ctx* ctx, const T32Config* c, u32* d_r, i64 npolys) {
   return 0;
 }
 template <int LQ, int R, int WT, int S>
-static int t32_launch_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npolys, u64* d_parts) {
+static int t32_launch_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npolys, u64* d_parts, bool wm) {
   const i64 n = (i64)A32_N << S;
   const dim3 grid((unsigned)(n / 128), (unsigned)npolys);
   void* d_fl;
   FHESI_TRY(ws_reserve(ctx, 6, (size_t)grid.x * grid.y, &d_fl));          // (per lane, like every workspace slot)
   unsigned char* fl = (unsigned char*)d_fl;
   PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_kernel<LQ, false, R, WT, S>));
-  crt32_scale_kernel<LQ, false, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, c->NP, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
+  crt32_scale_kernel<LQ, false, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, c->NP, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0);
   HIP_TRY(hipGetLastError());
   if (!ctx->opt.crt_skip_cleanup) {
-    crt32_scale_kernel<LQ, true, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, c->NP, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl);
+    crt32_scale_kernel<LQ, true, R, WT, S><<<grid, 128, 0, ctx->stream>>>(d_t, n, c->NP, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0);
     HIP_TRY(hipGetLastError());
   }
   return 0;
 }
 // d_t [npolys][NP][nrow] coefficient-form residues -> d_parts [npolys][ceil(logQ/64)][phi(m)]
-static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npolys, u64* d_parts) {
+static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npolys, u64* d_parts, bool wm) {
   const int S = ctx->tensor32->S, logQ = c->logQ;
   ProfScope prof(ctx, PROF_CRT, (double)npolys);
   if (!c->generic) {
-    if (logQ == 512 && !S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 0>(ctx, c, d_t, npolys, d_parts);
-    if (logQ == 512 && S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 1>(ctx, c, d_t, npolys, d_parts);
-    if (logQ == 1024 && !S) return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 0>(ctx, c, d_t, npolys, d_parts);
-    return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 1>(ctx, c, d_t, npolys, d_parts);
+    if (logQ == 512 && !S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 0>(ctx, c, d_t, npolys, d_parts, wm);
+    if (logQ == 512 && S) return t32_launch_crt<512, T32_R_512, T32_WT_512, 1>(ctx, c, d_t, npolys, d_parts, wm);
+    if (logQ == 1024 && !S) return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 0>(ctx, c, d_t, npolys, d_parts, wm);
+    return t32_launch_crt<1024, T32_R_1024, T32_WT_1024, 1>(ctx, c, d_t, npolys, d_parts, wm);
   }
   // the generic form: window from R J0 + 30 + log2(NP + 1) + 1 <= logQ - 64 up to bit 2 logQ
   const i64 n_out = ctx->phim, nrow = t32_nrow(ctx);
@@ -746,10 +751,10 @@ static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npoly
   // (S, FOLD) compile-time; the first pass over 16 or 24 words, whichever holds the window
 #define T32_GEN_GO(NWM, SS, FF) do { \
     PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_generic_kernel<NWM, false, SS, FF>)); \
-    crt32_scale_generic_kernel<NWM, false, SS, FF><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, logQ, J0, NW, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl); \
+    crt32_scale_generic_kernel<NWM, false, SS, FF><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, logQ, J0, NW, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0); \
     HIP_TRY(hipGetLastError()); \
     if (!ctx->opt.crt_skip_cleanup) { \
-      crt32_scale_generic_kernel<T32_GEN_NWX, true, SS, FF><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, logQ, 0, WU, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl); \
+      crt32_scale_generic_kernel<T32_GEN_NWX, true, SS, FF><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, logQ, 0, WU, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0); \
       HIP_TRY(hipGetLastError()); \
     } } while (0)
 #define T32_GEN_SF(NWM) do { \
@@ -762,7 +767,7 @@ static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npoly
 }
 
 // ---- pairs (fhesi_ct_mul_relin_batch_dev): a, b [count][2][phi(m)][nlimbs] -> d_parts [count * 3][ceil(logQ/64)][phi(m)]: the scaled-down tProd as ByteDecomp takes it
-int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts) {
+int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int nlimbs, int logQ, i64 count, u64* d_parts, bool parts_wm) {
   T32Config* c;
   FHESI_TRY(t32_config(ctx, p, nlimbs, logQ, 1, &c));
   if (!count) return 0;
@@ -781,7 +786,7 @@ int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int n
     ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, c->pr, x->d_inv, S, (const u32*)d_r);
     HIP_TRY(hipGetLastError());
   }
-  return t32_crt(ctx, c, (const u32*)d_t, count * 3, d_parts);
+  return t32_crt(ctx, c, (const u32*)d_t, count * 3, d_parts, parts_wm);
 }
 
 // ---- sums of products per group (fhesi_ct_mul_sum_relin_dev)
@@ -813,7 +818,7 @@ int tensor32_sum_pass(fhesi_ctx* ctx, const u64* d_ops, i64 nua, i64 nub, const 
   HIP_TRY(hipGetLastError());
   return 0;
 }
-int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts) {
+int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts, bool parts_wm) {
   const T32Config* c = ctx->tensor32->cur;
   const fhesi_tensor32* x = ctx->tensor32;
   {
@@ -822,5 +827,5 @@ int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts) {
     ntt32_inv_kernel3<false, false, T32Primes><<<dim3((unsigned)(ng * 3), (unsigned)(c->NP << x->S)), A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, x->S, nullptr);
     HIP_TRY(hipGetLastError());
   }
-  return t32_crt(ctx, c, (const u32*)d_sum, ng * 3, d_parts);
+  return t32_crt(ctx, c, (const u32*)d_sum, ng * 3, d_parts, parts_wm);
 }
