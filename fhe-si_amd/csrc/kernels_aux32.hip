@@ -484,6 +484,152 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
 #undef DL32
 }
 
+// ---- dot32_kernel2 for MORE COLUMNS THAN ONE LDS TILE HOLDS (the stress ring: 129 columns x 8 ciphertexts x 128 bytes = 132 KB, where two
+// workgroups per CU leave each other 80 KB).  Round 4 ran that shape on tiles of 4 ciphertexts -- every key word fetched from L2 feeds 4
+// multiply-adds per row instead of 8, and the key stream is what the kernel waits for (0.27 of the roofline against 0.41 at the metric ring).
+// Here the columns are taken in NH parts through the same LDS buffer: the accumulators of a wave (its two limbs, both key rows, 8
+// ciphertexts) stay in registers across the parts, so the tile keeps its 8 ciphertexts AND the CU its two workgroups.  The form needs
+// every wave to carry its limbs for the whole kernel: NLB <= 2 NW (15 limbs at the stress ring).  HALF layout only.
+template <int CT, int NW, int NH>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count, u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8,
+               int lognsl, int sub_lg, int ncp /* columns per part: a multiple of 8 */) {
+  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncp][CT][32 elements]
+  constexpr int LG = 5;
+  const u32 lane = threadIdx.x & 63, ln = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 s_lo = blockIdx.x & 7;
+  u32 tile = blockIdx.x >> 3, hf = 0;
+  if (tile >= (u32)ntiles) { hf = 1; tile -= (u32)ntiles; }
+  const u32 s_hi = blockIdx.y;
+  const int a = (int)blockIdx.z;
+  const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64 + hf * 32;
+  const int ct0 = (int)tile * CT;
+  const u32 p = pr.p[a], twop = 2 * p;
+#define DL32(k, c) (((((k) * CT) + (c)) << LG) + ln)
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  const int sub = ct0 >> sub_lg, sub_ct = 1 << sub_lg, ct_in = ct0 & (sub_ct - 1);
+  const i64 rest = count - ((i64)sub << sub_lg), cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
+  const u32* dbase = dig + ((i64)sub << sub_lg) * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + (i64)ct_in * ncol) * 64;
+  constexpr int TB = 6, CG = 2, NCG = CT / CG, WPG = NW / NCG;
+  static_assert(NW % NCG == 0, "waves per ciphertext group");
+  const int cg = w % NCG, q0 = w / NCG;
+  const u32 e0 = 4 * (lane & 7), dk = lane >> 4, dc = (lane >> 3) & 1;
+  const u32 goff = hf * 32 + e0;
+  const int cl = cg * CG + (int)dc;
+  const bool cok = ct0 + cl < count;
+  // the wave's limbs: lanes 0..31 limb 2w, lanes 32..63 limb 2w + 1 (a half wave without a limb only helps with the tile loads)
+  const int lraw = 2 * w + (int)(lane >> 5);
+  const bool lok = lraw < NLB;
+  const int l = lok ? lraw : NLB - 1;
+  const u32* kpa = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + hf * 32 + ln;
+  const u32 r48 = (u32)pr.r48[a], mont = pr.mont[a];
+  constexpr int CW = CT;
+  u64 tot[2][CW];
+  u32 th[2][CW];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { tot[r][c] = 0; th[r][c] = 0; }
+  auto fold = [&]() {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < CW; ++c) { th[r][c] += (u32)(tot[r][c] >> 48); tot[r][c] &= 0x0000ffffffffffffull; }
+  };
+  for (int part = 0; part < NH; ++part) {
+    const int kbeg = part * ncp, nc = (ncol - kbeg < ncp ? ncol - kbeg : ncp);
+    if (part) __syncthreads();                       // every wave is done with the previous part's tile
+    {
+      const int nq = (nc + 3) >> 2;
+      for (int qb = q0; qb < nq; qb += WPG * TB) {
+        v4u v[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+          const int q = qb + u * WPG, k = q * 4 + (int)dk;
+          v[u] = (q < nq && k < nc && cok) ? __builtin_nontemporal_load(reinterpret_cast<const v4u*>(dbase + (((i64)cl * ncol + kbeg + k) << 6) + goff)) : v4u{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+          const int q = qb + u * WPG, k = q * 4 + (int)dk;
+          if (q < nq && k < nc) {
+            v4u y = v[u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { u32 t = y[j]; t = t >= twop ? t - twop : t; y[j] = t >= p ? t - p : t; }
+            *reinterpret_cast<v4u*>(&dl32[((k * CT + cl) << LG) + e0]) = y;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (lok) {
+      const u32* kp0 = kpa + ((i64)kbeg << 6);
+      const u32* kp1 = kp0 + ((i64)ncol << 6);
+      constexpr int CH = 4;
+      const int nfull = nc & ~(CH - 1), n2 = nc & ~(2 * CH - 1);
+      u32 xa[2][CH], xb[2][CH];
+      auto loadc = [&](u32 (&x)[2][CH], int k0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { x[0][u] = kp0[(k0 + u) << 6]; x[1][u] = kp1[(k0 + u) << 6]; }
+      };
+      const int npair = n2 / (2 * CH);
+      int pst = npair > 1 ? (int)(tile & (0xffffffffu >> __builtin_clz((u32)npair - 1))) : 0;
+      if (pst >= npair) pst -= npair;
+      auto pk = [&](int i) { int q = i + pst; if (q >= npair) q -= npair; return q * 2 * CH; };
+      if (npair) loadc(xa, pk(0)); else if (nfull) loadc(xa, 0);
+      for (int i = 0; i < npair; ++i) {
+        const int kb = pk(i);
+        loadc(xb, kb + CH);
+        u32 d[2][CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) d[0][c] = dl32[DL32(kb, c)];
+#pragma unroll
+        for (int u = 0; u < 2 * CH; ++u) {
+          if (u == CH) loadc(xa, i + 1 < npair ? pk(i + 1) : (n2 < nfull ? n2 : 0));
+          if (u + 1 < 2 * CH) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) d[(u + 1) & 1][c] = dl32[DL32(kb + u + 1, c)];
+          }
+          const u32 x0 = u < CH ? xa[0][u & (CH - 1)] : xb[0][u & (CH - 1)], x1 = u < CH ? xa[1][u & (CH - 1)] : xb[1][u & (CH - 1)];
+#pragma unroll
+          for (int c = 0; c < CW; ++c) { tot[0][c] += (u64)x0 * d[u & 1][c]; tot[1][c] += (u64)x1 * d[u & 1][c]; }
+        }
+        if (i & 1) fold();                           // 16 columns since the last fold
+      }
+      if (nfull & CH) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+#pragma unroll
+          for (int c = 0; c < CW; ++c) { const u32 d = dl32[DL32(n2 + u, c)]; tot[0][c] += (u64)xa[0][u] * d; tot[1][c] += (u64)xa[1][u] * d; }
+        }
+      }
+      if ((nfull & (3 * CH)) != 0) fold();
+      for (int k = nfull; k < nc; ++k) {             // at most 3 columns
+        const u32 x0 = kp0[k << 6], x1 = kp1[k << 6];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) { const u32 d = dl32[DL32(k, c)]; tot[0][c] += (u64)x0 * d; tot[1][c] += (u64)x1 * d; }
+      }
+      fold();                                        // every total below 2^48 again: the next part (or the epilogue) starts clean
+    }
+  }
+  if (lok) {
+    u32* obase = out + ((((i64)l * 4 + a) << (lognsl + 6)) + soff) + ln;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        if (ct0 + c < count) {
+          const u64 v = tot[r][c] + (u64)th[r][c] * r48;          // one Montgomery step, as in dot32_kernel2
+          const u32 mq = (u32)v * mont;
+          u32 o = (u32)((v + (u64)mq * p) >> 32);
+          o = min(o, o - p);
+          __builtin_nontemporal_store(o, obase + (((i64)((ct0 + c) * 2 + r) * NLB * 4) << (lognsl + 6)));
+        }
+      }
+  }
+#undef DL32
+}
+
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp, bool centred) {
   FHESI_TRY(aux32_init(ctx));
   k->mfma_valid = false;
@@ -894,6 +1040,27 @@ static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int n
   HIP_TRY(hipGetLastError());
   return 0;
 }
+template <int CT, int NW, int NH>
+static int launch_dot32_p(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
+  const int ncp = ((ncol + NH - 1) / NH + 7) & ~7;                 // columns per part: whole 8-column pairs in every part but the last
+  const size_t shmem = (size_t)ncp * CT * 32 * 4;
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!(attr_done.load() >> ctx->device & 1)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2p<CT, NW, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done.fetch_or(1ull << ctx->device);
+  }
+  const i64 nrow = aux32_row_len(ctx);
+  const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
+  const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
+  const i64 blocks = (i64)8 * ntiles * 2;
+  if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");
+  int sub_lg = 0;
+  while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
+  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel2p<CT, NW, NH>));
+  dot32_kernel2p<CT, NW, NH><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, sub_lg, ncp);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out, bool* mont) {
   *mont = true;
   if (!count) return 0;
@@ -914,6 +1081,8 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   if (ctx->opt.dot32_half && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true>(ctx, k, d_dig, ncol, count, d_out);
   // (the stress ring's 129 columns with tiles of 8 ciphertexts in 132 KB, one workgroup per CU -- half the key words per multiply-add -- measured
   // 43.1 ms against 42.0 ms for the tiles of 4 below: profiles/r04_ab_dot_few_limbs.txt)
+  // ... the columns in two parts through an 80 KB tile of 8 ciphertexts (dot32_kernel2p): both, the 8-fold reuse of a key word and two workgroups per CU
+  if (ctx->opt.dot32_half && ctx->opt.dot32_parts && k->aux_rows <= 16 && (size_t)((((ncol + 1) / 2) + 7) & ~7) * 8 * 128 <= 80 * 1024) return launch_dot32_p<8, 8, 2>(ctx, k, d_dig, ncol, count, d_out);
   if ((size_t)ncol * 8 * 256 <= 160 * 1024) return launch_dot32_t<8, 16, false>(ctx, k, d_dig, ncol, count, d_out);
   if (ctx->opt.dot32_half && (size_t)ncol * 4 * 128 <= 80 * 1024) return launch_dot32_t<4, 8, true>(ctx, k, d_dig, ncol, count, d_out);
   if ((size_t)ncol * 4 * 256 <= 160 * 1024) return launch_dot32_t<4, 16, false>(ctx, k, d_dig, ncol, count, d_out);

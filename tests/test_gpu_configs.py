@@ -68,6 +68,52 @@ def test_config4_stress_ring_several_chunks():
         assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a[c:c + 1], b[c:c + 1])[0], got[c]), c
 
 
+def test_config4_generated_keys_column_parts():
+    """configs[4] with a GENERATED key-switch matrix (KeySwitchSI::Init, FHE-SI.cpp:153-226): 15 centred limbs, 129 columns.  The dot product
+    takes the columns in two parts through one 80 KB tile of 8 ciphertexts (dot32_kernel2p).  A ragged batch (two tiles, the second with one
+    ciphertext): first, last-of-tile and ragged ciphertexts vs the oracle, the whole batch vs the round-4 form (tiles of 4: option
+    dot32_parts = 0) and vs the general limbs."""
+    m, logQ, p, count = 1 << 16, 1024, 65537, 9
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    seed, pub = 0x0123456789ABCDEF, 0x0FEDCBA987654321
+    one = np.zeros((n, 1), dtype=np.uint64)
+    one[0, 0] = 1
+    d_one = F.DoubleCRT.from_poly(ctx, one)
+    t = F.DoubleCRT(ctx).sample(0, 64, seed, 1)
+    t2 = t.copy()
+    t2.op(t, 2)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([d_one, t, t2], t, logQ, seed, pub, 5000, 3)
+    ksm = ksk.download()
+    rng = np.random.default_rng(44)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    form, rows, _ = ksk.form()
+    assert form == 1 and rows == 15 and ksk.key_bits()[0], (form, rows, ksk.key_bits())
+    assert "dot32_kernel2p" in ctx_kernel_name(ctx, ksk, logQ, p, a, b, nl)
+    for c in (0, 7, 8):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    ctx.set_option("dot32_parts", 0)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b), got)
+    ctx.set_option("dot32_parts", 1)
+    ctx.set_option("ks_long_keys", 1)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b), got)
+
+
+def ctx_kernel_name(ctx, ksk, logQ, p, a, b, nl):
+    """name of the dot-product kernel a device-resident call launches (read back from the library's stopwatch)"""
+    da, db, dout = ctx.upload(a[:1]), ctx.upload(b[:1]), ctx.alloc(a[:1].nbytes)
+    ctx.prof_enable(True)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, 1)
+    ctx.sync()
+    name = ctx.prof_kernel_name("dot")
+    ctx.prof_enable(False)
+    return name
+
+
 def test_config4_1024_concurrent_mults():
     """configs[4] as BASELINE.json words it: 1024 concurrent ciphertext mults at the stress shape (n = 2^15, logQ = 1024) in ONE call on
     device-resident buffers (24 GiB of operands and results; the library takes them in launches of up to 292).  64 distinct random pairs are
@@ -120,6 +166,39 @@ def test_config2_metric_ring_several_chunks():
     got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     for c in (0, 63, 64, 128, 129):
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+
+
+def test_config2_generated_keys_several_chunks():
+    """configs[2] with the key-switch matrix EVERY reference driver holds -- KeySwitchSI(secretKey) of a sampleHWt(64) key (Test_AddMul.cpp:48-52
+    -> FHE-SI.cpp:153-226), generated on the device as bench.py does -- at a batch that spans three chunks of 64.  The library measures the
+    matrix and runs the 7 centred limbs (the form the headline times); first, last and chunk-boundary ciphertexts vs the oracle on the
+    downloaded matrix, and the whole batch again through the general limbs (option ks_long_keys) bit for bit."""
+    m, logQ, p, count = 1 << 15, 512, 23, 130
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    seed, pub = 0x5EC2E7C0FFEE1234, 0x1234ABCD9876FEDC
+    one = np.zeros((n, 1), dtype=np.uint64)
+    one[0, 0] = 1
+    d_one = F.DoubleCRT.from_poly(ctx, one)
+    t = F.DoubleCRT(ctx).sample(0, 64, seed, 1)                 # sampleHWt(64)
+    t2 = t.copy()
+    t2.op(t, 2)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([d_one, t, t2], t, logQ, seed, pub, 1000, 3)
+    ksm = ksk.download()
+    rng = np.random.default_rng(5)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    form, rows, limb_bits = ksk.form()
+    centred, key_bits = ksk.key_bits()
+    assert form == 1 and rows == 7 and centred and key_bits <= logQ - 1, (form, rows, limb_bits, centred, key_bits)      # (1 = four 30-bit auxiliary primes, limbs)
+    for c in (0, 63, 64, 127, 128, 129):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    ctx.set_option("ks_long_keys", 1)
+    again = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert ksk.form()[1] == 15 and np.array_equal(again, got)
 
 
 def test_config2_with_a_chain_of_50_bit_primes():
