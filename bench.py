@@ -460,6 +460,8 @@ def main():
     ap.add_argument("--reg-ring", default="metric", choices=["metric", "reference"], help="regression workload: replay at the metric ring (default) or on "
                     "the reference's own Test_Regression ring (p = 8423, m = 8422, logQ = 341: configs[3] itself)")
     ap.add_argument("--reg-p", type=int, default=8423, help="--reg-ring reference: the safe prime p (m = p - 1); 8423 = Test_Regression's, 32603 = phi(m) 16300")
+    ap.add_argument("--ref-p", type=int, default=32603, help="--workload refring: the safe prime p (m = p - 1); 32603 = phi(m) 16300 (padded rows of 2^15), 65267 = phi(m) 32632 "
+                    "(padded rows of 2^16: the largest safe prime below 2^16)")
     ap.add_argument("--keys", default="generated", choices=["generated", "uniform"], help="key-switch matrix of the mult workloads: generated = KeySwitchSI::Init of a "
                     "sampleHWt(64) secret key (what every reference driver holds; default); uniform = uniform residues in every row")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 plumbing)")
@@ -477,7 +479,9 @@ def main():
     if args.workload == "stress":
         M_RING, LOGQ, P_PLAIN = 1 << 16, 1024, 65537
     if args.workload == "refring":
-        M_RING, LOGQ, P_PLAIN = 32602, 512, 32603
+        if not _is_prime(args.ref_p) or not _is_prime((args.ref_p - 1) // 2):
+            raise SystemExit(f"--ref-p {args.ref_p}: the reference's rings are m = p - 1 for a safe prime p")
+        M_RING, LOGQ, P_PLAIN = args.ref_p - 1, 512, args.ref_p
     if args.workload == "regression" and args.reg_ring == "reference":
         # Test_Regression.cpp:100-108: m = p - 1, logQ by its noise formula (p = 8423, d = 8: 341; p = 32603 -- phi(m) = 16300, the metric's size in
         # the reference's own parameterisation --: 377)
@@ -910,7 +914,7 @@ def main():
                     ("generated by KeySwitchSI::Init from a sampleHWt(64) secret key, FHE-SI.cpp:153-226)" if args.keys == "generated" else "of uniform residues)"),
             "config": {"workload": "configs[2]: full ciphertext mul + relinearize + scale-down, m=2^15 n=2^14, fhe-si logQ=512, p=23, decompSize=3"
                        if args.workload == "metric" else f"Test_AddMul's parameterisation at the metric's size: m = p - 1 = {M_RING} for the safe prime p = {P_PLAIN}, phi(m) = {n}, fhe-si logQ={LOGQ}, decompSize=3 "
-                       "(rows are Bluestein transforms in the reference; here linear convolutions on padded rows of 2^15 over 30-bit primes)" if args.workload == "refring"
+                       f"(rows are Bluestein transforms in the reference; here linear convolutions on padded rows of 2^{(2 * n - 2).bit_length()} over 30-bit primes)" if args.workload == "refring"
                        else "configs[4] stress shape: m=2^16 n=2^15, fhe-si logQ=1024, p=65537, decompSize=3",
                        "L": L, "chain_bits": round(chain_bits, 1), "sp_nbits": args.sp_nbits, "ndigits": nd,
                        "key_switch_form": {"form": F.KeySwitchMatrix.FORMS.get(ks_form, str(ks_form)), "rows": ks_rows, "limb_bits": ks_limb_bits,

@@ -147,11 +147,12 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
   c->phi = hm::cyclotomic(m);
   c->pow2 = (m & (m - 1)) == 0 && m >= 4;
   c->logn = c->pow2 ? hm::ilog2_ceil(c->phim) : 0;
-  if (!c->pow2 && 2 * c->phim - 1 <= 2 * kAux32N) {
-    // rings whose products run as linear convolutions on padded power-of-two rows (larger ones keep the per-prime Bluestein rows)
+  if (!c->pow2 && 2 * c->phim - 1 <= 4 * kAux32N) {
+    // rings whose products run as linear convolutions on padded power-of-two rows of 2^14, 2^15 or 2^16 (larger ones keep the per-prime
+    // Bluestein rows): every safe prime p = m + 1 up to 65 537 (the reference's drivers: Test_AddMul.cpp:131, Test_Regression.cpp:122)
     if (m % 2 == 0 && (m / 2) % 2 == 1 && hm::is_prime((u64)(m / 2))) c->lin_q = m / 2;
     else if (m % 2 == 1 && m > 2 && hm::is_prime((u64)m)) { c->lin_q = m; c->lin_prime = true; }
-    if (c->lin_q) c->lin_lg = 2 * c->phim - 1 <= kAux32N ? 14 : 15;
+    if (c->lin_q) c->lin_lg = 2 * c->phim - 1 <= kAux32N ? 14 : (2 * c->phim - 1 <= 2 * kAux32N ? 15 : 16);
   }
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));

@@ -48,13 +48,17 @@ __global__ void __launch_bounds__(256) ntt32_tail_kernel(u32* __restrict__ rows,
 
 // ---------------------------------------------------------------------------------------------- host side
 bool aux32_applies(const fhesi_ctx* ctx) { return (ctx->pow2 && (ctx->logn == A32_LOGN || ctx->logn == A32_LOGN + 1)) || ctx->lin_q != 0; }
-i64 aux32_row_len(const fhesi_ctx* ctx) { return ((ctx->pow2 && ctx->logn == A32_LOGN + 1) || ctx->lin_lg == A32_LOGN + 1) ? 2 * (i64)A32_N : (i64)A32_N; }
+// 2^14, 2^15 (power-of-two rings and padded rows) or 2^16 (padded rows of the linear-convolution rings with 2^15 < 2 phi(m) - 1 <= 2^16)
+i64 aux32_row_len(const fhesi_ctx* ctx) {
+  if (ctx->lin_q) return (i64)1 << ctx->lin_lg;
+  return (ctx->pow2 && ctx->logn == A32_LOGN + 1) ? 2 * (i64)A32_N : (i64)A32_N;
+}
 static int aux32_init(fhesi_ctx* ctx) {
   if (ctx->aux32) return 0;
-  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14, 2^15 and for rings m = prime or 2 * prime with 2 phi(m) - 1 <= 2^15");
+  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14, 2^15 and for rings m = prime or 2 * prime with 2 phi(m) - 1 <= 2^16");
   fhesi_aux32* x = new fhesi_aux32();
-  const i64 n = aux32_row_len(ctx);                // 2^14, or 2^15 = two sub-transforms per row
-  const int S = n > A32_N ? 1 : 0, lg = A32_LOGN + S;
+  const i64 n = aux32_row_len(ctx);                // 2^14, or 2^15 / 2^16 = two / four sub-transforms per row
+  const int S = n > 2 * A32_N ? 2 : (n > A32_N ? 1 : 0), lg = A32_LOGN + S, NS = 1 << S;
   x->S = S;
   // the four largest primes below 2^30 that are 1 mod 2n
   int found = 0;
@@ -64,7 +68,7 @@ static int aux32_init(fhesi_ctx* ctx) {
   }
   if (found < 4) { delete x; FHESI_FAIL("aux32: no primes"); }
   const size_t per_prime = (size_t)A32_N << S;
-  std::vector<Tw32> hf(4 * per_prime, Tw32{0, 0}), hi(4 * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n);
+  std::vector<Tw32> hf(4 * per_prime, Tw32{0, 0}), hi(4 * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n), ht(4 * A32_HT, Tw32{0, 0});
   for (int a = 0; a < 4; ++a) {
     const u64 p = x->pr.p[a];
     u64 psi = 0;
@@ -84,17 +88,23 @@ static int aux32_init(fhesi_ctx* ctx) {
       std::transform(ff.begin(), ff.end(), hf.begin() + (size_t)a * per_prime, fwd_form);
       std::copy(fi.begin(), fi.end(), hi.begin() + (size_t)a * per_prime);
     } else {
-      // sub-block h runs stage s >= 1 of the row on its groups i = h 2^(s-1) + i':  own index m' + i' (m' = 2^(s-1))  <->  2 m' + h m' + i'
-      for (int h = 0; h < 2; ++h)
+      // sub-block h runs stage s >= S of the row on its groups i = h 2^(s-S) + i':  own index m' + i' (m' = 2^(s-S))  <->  (m' << S) + h m' + i'
+      for (int h = 0; h < NS; ++h)
         for (u64 mp = 1; mp < (u64)A32_N; mp <<= 1)
           for (u64 ip = 0; ip < mp; ++ip) {
-            hf[((size_t)a * 2 + h) * A32_N + mp + ip] = fwd_form(ff[2 * mp + h * mp + ip]);
-            hi[((size_t)a * 2 + h) * A32_N + mp + ip] = fi[2 * mp + h * mp + ip];
+            hf[((size_t)a * NS + h) * A32_N + mp + ip] = fwd_form(ff[(mp << S) + h * mp + ip]);
+            hi[((size_t)a * NS + h) * A32_N + mp + ip] = fi[(mp << S) + h * mp + ip];
           }
       const u64 inv2 = (p + 1) / 2;
       x->hd.head[a] = ff[1];
       x->hd.tail_sum[a] = tw(inv2);
       x->hd.tail_dif[a] = tw(hm::mulmod(fi[1].w, inv2, p));
+      if (S == 2) {
+        x->hd.head1[a][0] = ff[2]; x->hd.head1[a][1] = ff[3];
+        Tw32* c = &ht[(size_t)a * A32_HT];
+        c[0] = ff[1]; c[1] = ff[2]; c[2] = ff[3];
+        c[4] = tw(inv2); c[5] = tw(hm::mulmod(fi[2].w, inv2, p)); c[6] = tw(hm::mulmod(fi[3].w, inv2, p)); c[7] = tw(hm::mulmod(fi[1].w, inv2, p));
+      }
     }
     const u64 ninv = hm::invmod(A32_N % p, p);     // of the 2^14-point (sub-)transform; the tail of a 2^15-point row carries the other 1/2
     x->pr.ninv[a] = (u32)ninv;
@@ -107,25 +117,30 @@ static int aux32_init(fhesi_ctx* ctx) {
     x->pr.ninv_m[a] = (u32)nm; x->pr.ninv_m_p[a] = (u32)((nm << 32) / p);
     // the inverse transform's last stage carries the final scaling (ntt32_inv_kernel3): table entries 0 and 1 of every (prime, sub-block) become
     // 1/n and w / n, w = that sub-block's distance-16 twiddle; the Montgomery pair (2^32 / n, w 2^32 / n) travels with the primes
-    for (int h = 0; h < (S ? 2 : 1); ++h) {
-      Tw32* t0 = &hi[((size_t)a * (S ? 2 : 1) + h) * A32_N];
+    for (int h = 0; h < NS; ++h) {
+      Tw32* t0 = &hi[((size_t)a * NS + h) * A32_N];
       const u64 w1 = t0[1].w, wn = hm::mulmod(w1, ninv, p), wm = hm::mulmod(w1, nm, p);
       t0[0] = tw(ninv); t0[1] = tw(wn);
       x->pr.ninv_mw[a][h] = (u32)wm; x->pr.ninv_mw_p[a][h] = (u32)((wm << 32) / p);
     }
-    if (!S) { x->pr.ninv_mw[a][1] = x->pr.ninv_mw[a][0]; x->pr.ninv_mw_p[a][1] = x->pr.ninv_mw_p[a][0]; }
+    for (int h = NS; h < 4; ++h) { x->pr.ninv_mw[a][h] = x->pr.ninv_mw[a][0]; x->pr.ninv_mw_p[a][h] = x->pr.ninv_mw_p[a][0]; }
     if (p > ((u64)1 << 30) - ((u64)1 << 15) + 1) { delete x; FHESI_FAIL("aux32: prime above 2^30 - 2^15 + 1"); }     // the bound dot32_kernel2's accumulation relies on
   }
   a32_permute_phase_c(hf); a32_permute_phase_c(hi);      // (the last four stages' twiddles in the order the waves load them: A32_TWC)
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
   HIP_TRY(hipMemcpy(x->d_fwd, hf.data(), hf.size() * sizeof(Tw32), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(x->d_inv, hi.data(), hi.size() * sizeof(Tw32), hipMemcpyHostToDevice));
+  if (S == 2) {
+    if (hipMalloc(&x->d_ht, ht.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_p, 4 * sizeof(u32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
+    HIP_TRY(hipMemcpy(x->d_ht, ht.data(), ht.size() * sizeof(Tw32), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(x->d_p, x->pr.p, 4 * sizeof(u32), hipMemcpyHostToDevice));
+  }
   ctx->aux32 = x;
   return 0;
 }
 void aux32_free(fhesi_ctx* ctx) {
   if (!ctx->aux32) return;
-  hipFree(ctx->aux32->d_fwd); hipFree(ctx->aux32->d_inv);
+  hipFree(ctx->aux32->d_fwd); hipFree(ctx->aux32->d_inv); hipFree(ctx->aux32->d_ht); hipFree(ctx->aux32->d_p);
   delete ctx->aux32;
   ctx->aux32 = nullptr;
 }
@@ -136,13 +151,13 @@ int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
   if (!count) return 0;
   const fhesi_aux32* x = ctx->aux32;
   const int S = x->S;
-  if (S) {
-    ntt32_head_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
-    HIP_TRY(hipGetLastError());
-  }
+  if (S == 2) ntt32_head2_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, nslots, a0, x->d_p, x->d_ht);
+  else if (S) ntt32_head_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
+  if (S) HIP_TRY(hipGetLastError());
   if (count > 0x7fffffff || (nslots << S) > 65535) FHESI_FAIL("ntt32: too many rows per launch");
   const dim3 grid((unsigned)count, (unsigned)(nslots << S));
-  if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 1>); ntt32_fwd_kernel3<false, 1><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
+  if (S == 2) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 2>); ntt32_fwd_kernel3<false, 2><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
+  else if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 1>); ntt32_fwd_kernel3<false, 1><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
   else { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 0>); ntt32_fwd_kernel3<false, 0><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -159,8 +174,10 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0,
   if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   HIP_TRY(hipGetLastError());
+  if (S == 2 && !tail) FHESI_FAIL("ntt32: rows of 2^16 have no consumer that takes their tail stages");
   if (S && tail) {
-    ntt32_tail_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
+    if (S == 2) ntt32_tail2_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, nslots, a0, x->d_p, x->d_ht);
+    else ntt32_tail_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -195,7 +212,9 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
 #define A32_DIG_GO(SS, PP, WW) do { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, (ntt32_fwd_kernel3<true, SS, PP, Aux32Primes, true, WW>)); \
     ntt32_fwd_kernel3<true, SS, PP, Aux32Primes, true, WW><<<(unsigned)blocks, A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); } while (0)
 #define A32_DIG_W(SS, PP) do { if (wm) A32_DIG_GO(SS, PP, true); else A32_DIG_GO(SS, PP, false); } while (0)
-  if (S && ctx->lin_q) A32_DIG_W(1, true);
+  if (S == 2 && !ctx->lin_q) FHESI_FAIL("ntt32: digit rows of 2^16 exist for the padded linear-convolution rings only");
+  if (S == 2) A32_DIG_W(2, true);
+  else if (S && ctx->lin_q) A32_DIG_W(1, true);
   else if (S) A32_DIG_W(1, false);
   else if (ctx->phim < A32_N) A32_DIG_W(0, true);
   else A32_DIG_W(0, false);
@@ -790,7 +809,7 @@ static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig,
     attr_done.fetch_or(1ull << ctx->device);
   }
   const i64 nrow = aux32_row_len(ctx);
-  const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
+  const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;              // log2 of the 64-element slices per row
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
   const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
   if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
@@ -808,7 +827,7 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
     attr_done.fetch_or(1ull << ctx->device);
   }
   const i64 nrow = aux32_row_len(ctx);
-  const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
+  const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;              // log2 of the 64-element slices per row
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
   const i64 blocks = (i64)8 * ntiles * (HALF ? 2 : 1);
   if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");
@@ -1050,7 +1069,7 @@ static int launch_dot32_p(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
     attr_done.fetch_or(1ull << ctx->device);
   }
   const i64 nrow = aux32_row_len(ctx);
-  const int lognsl = nrow > A32_N ? A32_LOGN - 5 : A32_LOGN - 6;
+  const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;              // log2 of the 64-element slices per row
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
   const i64 blocks = (i64)8 * ntiles * 2;
   if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");

@@ -47,8 +47,11 @@ struct fhesi_tensor32 {
   int S = 0;                         // rows of 2^14 << S
   std::vector<u32> primes;           // the primes with transform tables, largest first
   std::vector<Tw32> head, tail;      // per prime: psi^brv(1), psi^-brv(1)   (S = 1)
+  std::vector<Tw32> head1;           // per prime: psi^brv(2), psi^brv(3)    (S = 2: the second head stage)
   Tw32* d_fwd = nullptr;             // [primes][2^S][2^14]
   Tw32* d_inv = nullptr;
+  Tw32* d_ht = nullptr;              // S = 2: [primes][A32_HT] constants of the stand-alone tail pass (ntt32_tail2_kernel)
+  u32* d_p = nullptr;                // S = 2: the primes
   std::vector<T32Config*> cfgs;
   T32Config* cur = nullptr;          // the configuration of the running sum (tensor32_sum_begin)
 };
@@ -57,7 +60,7 @@ void tensor32_free(fhesi_ctx* ctx) {
   fhesi_tensor32* x = ctx->tensor32;
   if (!x) return;
   for (T32Config* c : x->cfgs) delete c;
-  hipFree(x->d_fwd); hipFree(x->d_inv);
+  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_ht); hipFree(x->d_p);
   delete x;
   ctx->tensor32 = nullptr;
 }
@@ -146,15 +149,16 @@ bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64
 // transform tables of the first `want` primes (grown on demand; a growth waits for the streams)
 static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
   fhesi_tensor32* x = ctx->tensor32;
-  if (!x) { x = new fhesi_tensor32(); x->S = ((ctx->lin_q ? ctx->lin_lg : ctx->logn) == A32_LOGN + 1) ? 1 : 0; ctx->tensor32 = x; }
+  if (!x) { x = new fhesi_tensor32(); x->S = (ctx->lin_q ? ctx->lin_lg : ctx->logn) - A32_LOGN; ctx->tensor32 = x; }
   if (x->primes.size() >= primes.size()) return 0;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->lane_stream) HIP_TRY(hipStreamSynchronize(ctx->lane_stream));
-  const int S = x->S, lg = A32_LOGN + S, NP = (int)primes.size();
+  const int S = x->S, lg = A32_LOGN + S, NP = (int)primes.size(), NS = 1 << S;
+  if (S < 0 || S > 2) FHESI_FAIL("tensor32: rows of 2^%d", lg);
   const i64 n = (i64)A32_N << S;
   const size_t per_prime = (size_t)A32_N << S;
-  std::vector<Tw32> hf((size_t)NP * per_prime, Tw32{0, 0}), hi((size_t)NP * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n);
-  x->head.assign(NP, Tw32{0, 0}); x->tail.assign(NP, Tw32{0, 0});
+  std::vector<Tw32> hf((size_t)NP * per_prime, Tw32{0, 0}), hi((size_t)NP * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n), ht((size_t)NP * A32_HT, Tw32{0, 0});
+  x->head.assign(NP, Tw32{0, 0}); x->tail.assign(NP, Tw32{0, 0}); x->head1.assign((size_t)NP * 2, Tw32{0, 0});
   for (int a = 0; a < NP; ++a) {
     const u64 p = primes[a];
     u64 psi = 0;
@@ -175,27 +179,39 @@ static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
       std::copy(fi.begin(), fi.end(), hi.begin() + (size_t)a * per_prime);
     } else {
       // sub-block h runs stage s >= 1 of the row on its groups i = h 2^(s-1) + i':  own index m' + i' (m' = 2^(s-1))  <->  2 m' + h m' + i'  (as aux32_init)
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < NS; ++h)
         for (u64 mp = 1; mp < (u64)A32_N; mp <<= 1)
           for (u64 ip = 0; ip < mp; ++ip) {
-            hf[((size_t)a * 2 + h) * A32_N + mp + ip] = fwd_form(ff[2 * mp + h * mp + ip]);
-            hi[((size_t)a * 2 + h) * A32_N + mp + ip] = fi[2 * mp + h * mp + ip];
+            hf[((size_t)a * NS + h) * A32_N + mp + ip] = fwd_form(ff[(mp << S) + h * mp + ip]);
+            hi[((size_t)a * NS + h) * A32_N + mp + ip] = fi[(mp << S) + h * mp + ip];
           }
       x->head[a] = ff[1]; x->tail[a] = fi[1];
+      if (S == 2) {
+        x->head1[(size_t)a * 2] = ff[2]; x->head1[(size_t)a * 2 + 1] = ff[3];
+        const u64 inv2 = (p + 1) / 2;
+        Tw32* c = &ht[(size_t)a * A32_HT];
+        c[0] = ff[1]; c[1] = ff[2]; c[2] = ff[3];
+        c[4] = tw(inv2); c[5] = tw(hm::mulmod(fi[2].w, inv2, p)); c[6] = tw(hm::mulmod(fi[3].w, inv2, p)); c[7] = tw(hm::mulmod(fi[1].w, inv2, p));
+      }
     }
   }
   // the inverse transform's last stage carries the final scaling (ntt32_inv_kernel3): entries 0 and 1 of every (prime, sub-block) table
   // become 1/n and w / n, w = that sub-block's distance-16 twiddle (n = 2^14: the sub-transform's length)
   for (size_t a = 0; a < primes.size(); ++a) {
     const u64 p = primes[a], ninv = hm::invmod((u64)A32_N % p, p);
-    for (int h = 0; h < (S ? 2 : 1); ++h) {
-      Tw32* t0 = &hi[(a * (S ? 2 : 1) + h) * A32_N];
+    for (int h = 0; h < NS; ++h) {
+      Tw32* t0 = &hi[(a * NS + h) * A32_N];
       const u64 wn = hm::mulmod(t0[1].w, ninv, p);
       t0[0] = Tw32{(u32)ninv, (u32)((ninv << 32) / p)}; t0[1] = Tw32{(u32)wn, (u32)((wn << 32) / p)};
     }
   }
-  hipFree(x->d_fwd); hipFree(x->d_inv);
-  x->d_fwd = x->d_inv = nullptr;
+  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_ht); hipFree(x->d_p);
+  x->d_fwd = x->d_inv = x->d_ht = nullptr; x->d_p = nullptr;
+  if (S == 2) {
+    if (hipMalloc(&x->d_ht, ht.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_p, (size_t)NP * sizeof(u32)) != hipSuccess) FHESI_FAIL("tensor32: hipMalloc failed");
+    HIP_TRY(hipMemcpy(x->d_ht, ht.data(), ht.size() * sizeof(Tw32), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(x->d_p, primes.data(), (size_t)NP * sizeof(u32), hipMemcpyHostToDevice));
+  }
   a32_permute_phase_c(hf); a32_permute_phase_c(hi);      // (the last four stages' twiddles in the order the waves load them: A32_TWC)
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) FHESI_FAIL("tensor32: hipMalloc failed");
   HIP_TRY(hipMemcpy(x->d_fwd, hf.data(), hf.size() * sizeof(Tw32), hipMemcpyHostToDevice));
@@ -219,7 +235,7 @@ static int t32_config(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ, i64 gmax, 
   c->lift = lift; c->nl = nlimbs; c->logQ = logQ; c->NP = NP; c->generic = pl.generic;
   c->R = pl.generic ? 28 : (logQ == 512 ? T32_R_512 : T32_R_1024);
   c->WT = pl.generic ? (int)((have + 8) / 28) + 2 : (logQ == 512 ? T32_WT_512 : T32_WT_1024);
-  const int R = c->R, WT = c->WT, stride = (2 * nlimbs + 6 + 7) & ~7;          // (rows of whole 32-byte lines: the kernel reads them with scalar loads)
+  const int R = c->R, WT = c->WT, stride = (2 * nlimbs + 8 + 7) & ~7;          // (rows of whole 32-byte lines: the kernel reads them with scalar loads)
   std::vector<u32> rns((size_t)2 * NP * stride);
   for (int a = 0; a < NP; ++a) {
     const u64 p = primes[a];
@@ -237,8 +253,11 @@ static int t32_config(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ, i64 gmax, 
       e[2 * nlimbs + 1] = (u32)b32;
       e[2 * nlimbs + 2] = c->pr.mu61[a];
       e[2 * nlimbs + 3] = (u32)p;
-      e[2 * nlimbs + 4] = S ? x->head[a].w : 0;      // head stage of a 2^15-point row: psi^brv(1)
-      e[2 * nlimbs + 5] = S ? x->head[a].wp : 0;
+      // head stage of a 2^15-point row: psi^brv(1); padded rows of 2^16: the second head stage's psi^brv(2), psi^brv(3) (the first is a duplication)
+      e[2 * nlimbs + 4] = S == 2 ? x->head1[(size_t)a * 2].w : (S ? x->head[a].w : 0);
+      e[2 * nlimbs + 5] = S == 2 ? x->head1[(size_t)a * 2].wp : (S ? x->head[a].wp : 0);
+      e[2 * nlimbs + 6] = S == 2 ? x->head1[(size_t)a * 2 + 1].w : 0;
+      e[2 * nlimbs + 7] = S == 2 ? x->head1[(size_t)a * 2 + 1].wp : 0;
     }
   }
   // CRT tables
@@ -252,7 +271,7 @@ static int t32_config(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ, i64 gmax, 
     const u64 p = primes[a];
     const u64 ci = hm::invmod(big_mod_small(Mi, p), p);
     auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
-    if (!S) cinv[(size_t)a * 2] = cinv[(size_t)a * 2 + 1] = tw(ci);
+    if (S != 1) cinv[(size_t)a * 2] = cinv[(size_t)a * 2 + 1] = tw(ci);      // (rows of 2^16: the tail stages are a pass of their own, ntt32_tail2_kernel)
     else {
       const u64 inv2 = (p + 1) / 2;
       cinv[(size_t)a * 2] = tw(hm::mulmod(ci, inv2, p));
@@ -332,7 +351,10 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
   const u32 q = __umulhi((u32)(acc >> 29), mu);        // at most 2 below floor(acc / p)
   return (u32)acc - q * p;                             // below 3p
 }
-template <int NL, bool HEAD, bool PAIRED>
+// HEAD: 0 = plain rows (or, dup, padded rows of 2^15: the value goes to both sub-rows); 1 = rows of 2^15 with the head stage x +- w y of
+// coefficients j, j + 2^14; 2 = PADDED rows of 2^16 (fewer than 2^15 coefficients): the first head stage is a duplication, the second the same
+// x +- w y with the half's twiddle -- sub-rows 0, 1: psi^brv(2), sub-rows 2, 3: psi^brv(3); coefficients from n_src upwards are zero
+template <int NL, int HEAD, bool PAIRED>
 __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict__ a, const u64* __restrict__ b, i64 na2, i64 n_src, i64 nrow, u32* __restrict__ rows, int NP,
                                                             const u32* __restrict__ tab, const int* __restrict__ idx_a = nullptr, const int* __restrict__ idx_b = nullptr, int dup = 0) {
   __shared__ __attribute__((aligned(16))) u64 sl[NL * 256];       // [NL][256]
@@ -358,7 +380,7 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
     return;
   }
   const i64 avail = (n_src - j0) * NL;                           // words of this block's 256 coefficients that exist
-  u32 x[2 * NL], x1[HEAD ? 2 * NL : 1];
+  u32 x[2 * NL], x1[HEAD != 0 ? 2 * NL : 1];
   const u64* __restrict__ sblk = src + j0 * NL;
   if (avail >= 256 * NL) {                                       // (uniform: every block but the last one of a padded row)
 #pragma unroll
@@ -376,12 +398,13 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < NL; ++k) { const u64 v = sl[k * 256 + tid]; x[2 * k] = (u32)v; x[2 * k + 1] = (u32)(v >> 32); }
-  if constexpr (HEAD) {
+  if constexpr (HEAD != 0) {
     __syncthreads();
+    const i64 avail1 = HEAD == 2 ? (n_src - (j0 + A32_N)) * NL : (i64)256 * NL;      // (padded rows: the second block may lie partly or wholly in the padding)
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int e = it * 256 + tid;
-      sl[(e % NL) * 256 + e / NL] = src[(j0 + A32_N) * NL + e];
+      sl[(e % NL) * 256 + e / NL] = e < avail1 ? src[(j0 + A32_N) * NL + e] : 0;
     }
     __syncthreads();
 #pragma unroll
@@ -389,13 +412,13 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   }
   const u32 neg = x[2 * NL - 1] >> 31;
   u32 neg1 = 0;
-  if constexpr (HEAD) neg1 = x1[2 * NL - 1] >> 31;
-  constexpr int STRIDE = (2 * NL + 6 + 7) & ~7;
+  if constexpr (HEAD != 0) neg1 = x1[2 * NL - 1] >> 31;
+  constexpr int STRIDE = (2 * NL + 8 + 7) & ~7;
 #pragma unroll 2
   for (int i = i_first; i < i_last; ++i) {
     const u32* __restrict__ t = tab + ((i64)cls * NP + i) * STRIDE;
     const u32 r0 = rns32_one<NL>(x, neg, t);
-    if constexpr (!HEAD) {
+    if constexpr (HEAD == 0) {
       __builtin_nontemporal_store(r0, &o[(i64)i * nrow]);                  // (a zero coefficient gives 0: the padding inside a partial block)
       if (dup) __builtin_nontemporal_store(r0, &o[(i64)i * nrow + A32_N]);
     }
@@ -406,6 +429,11 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
       const u32 T = mul_lazy32(r1, Tw32{t[2 * NL + 4], t[2 * NL + 5]}, p);
       o[(i64)i * nrow] = X + T;
       o[(i64)i * nrow + A32_N] = X + twop - T;
+      if constexpr (HEAD == 2) {
+        const u32 Tb = mul_lazy32(r1, Tw32{t[2 * NL + 6], t[2 * NL + 7]}, p);
+        o[(i64)i * nrow + 2 * A32_N] = X + Tb;
+        o[(i64)i * nrow + 3 * A32_N] = X + twop - Tb;
+      }
     }
   }
 }
@@ -679,11 +707,13 @@ static int t32_launch_rns(fhesi_ctx* ctx, const T32Config* c, const u64* d_a, co
   const dim3 grid((unsigned)(A32_N / 256), (unsigned)npolys, zs);
   const int* ia = paired && ctx->op_idx ? ctx->op_idx + ctx->op_idx_done : nullptr;
   const int* ib = ia ? ia + ctx->op_idx_n : nullptr;
-  const int dup = S && ctx->lin_q ? 1 : 0;
+  const int dup = S == 1 && ctx->lin_q ? 1 : 0;
+  if (S == 2 && !ctx->lin_q) FHESI_FAIL("tensor32: rows of 2^16 exist for the padded linear-convolution rings only");
 #define T32_GO(HEAD, PAIRED) do { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, HEAD, PAIRED>); \
     rns32_reduce_kernel<NL, HEAD, PAIRED><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, na2, n_src, nrow, d_r, c->NP, c->d_rns, ia, ib, dup); } while (0)
-  if (S && !dup) { if (paired) T32_GO(true, true); else T32_GO(true, false); }
-  else { if (paired) T32_GO(false, true); else T32_GO(false, false); }
+  if (S == 2) { if (paired) T32_GO(2, true); else T32_GO(2, false); }
+  else if (S && !dup) { if (paired) T32_GO(1, true); else T32_GO(1, false); }
+  else { if (paired) T32_GO(0, true); else T32_GO(0, false); }
 #undef T32_GO
   HIP_TRY(hipGetLastError());
   return 0;
@@ -704,7 +734,8 @@ static int t32_fwd(fhesi_ctx* ctx, const T32Config* c, u32* d_r, i64 npolys) {
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * c->NP));
   if (npolys > 0x7fffffff) FHESI_FAIL("tensor32: too many rows per launch");
   const dim3 grid((unsigned)npolys, (unsigned)(c->NP << x->S));
-  if (x->S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
+  if (x->S == 2) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 2, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 2, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
+  else if (x->S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
   else { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 0, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -757,8 +788,12 @@ static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npoly
       crt32_scale_generic_kernel<T32_GEN_NWX, true, SS, FF><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, logQ, 0, WU, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0); \
       HIP_TRY(hipGetLastError()); \
     } } while (0)
+  if (S == 2) {      // rows of 2^16: the two tail stages as a pass of their own over the sub-inverses (in place), then the fold from whole rows
+    ntt32_tail2_kernel<<<dim3(16, (unsigned)(npolys * c->NP)), 256, 0, ctx->stream>>>(const_cast<u32*>(d_t), c->NP, 0, ctx->tensor32->d_p, ctx->tensor32->d_ht);
+    HIP_TRY(hipGetLastError());
+  }
 #define T32_GEN_SF(NWM) do { \
-    if (!S) { if (fold == 0) T32_GEN_GO(NWM, 0, 0); else if (fold == 1) T32_GEN_GO(NWM, 0, 1); else T32_GEN_GO(NWM, 0, 2); } \
+    if (S != 1) { if (fold == 0) T32_GEN_GO(NWM, 0, 0); else if (fold == 1) T32_GEN_GO(NWM, 0, 1); else T32_GEN_GO(NWM, 0, 2); } \
     else { if (fold == 0) T32_GEN_GO(NWM, 1, 0); else if (fold == 1) T32_GEN_GO(NWM, 1, 1); else T32_GEN_GO(NWM, 1, 2); } } while (0)
   if (NW <= 16) T32_GEN_SF(16); else T32_GEN_SF(T32_GEN_NW);
 #undef T32_GEN_SF

@@ -155,6 +155,7 @@ def test_sum_form_crt_undecided_coefficients(monkeypatch):
                                       (32768, 200, 23),          # run-time CRT window (any logQ <= 512)
                                       (8422, 341, 8423),         # the reference's Test_Regression ring: linear convolutions + fold
                                       (32602, 128, 32603),       # ... with phi(m) = 16300: padded rows of 2^15 (head = duplication, tail inside the CRT kernel)
+                                      (65266, 128, 65267),       # ... with phi(m) = 32632: padded rows of 2^16 (second head stage in rns32_reduce, the tail stages a pass of their own)
                                       (101, 128, 23), (16381, 128, 23)])      # odd prime m: the three-term fold modulo X^m - 1 and Phi_m
 def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     """At the metric ring the fused pipeline forms tProd's integers modulo 35 primes below 2^30 instead of the chain
@@ -203,7 +204,9 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     chain = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     ctx.set_option("tensor32", 1)
     assert np.array_equal(got, chain)
-    for c in ((2,) if ctx.phim > 10000 and (m & (m - 1)) != 0 else (1, 2)):      # (general m at this size: seconds per Bluestein row in the oracle)
+    # (general m at this size: seconds per Bluestein row in the oracle; at m = 65266 minutes per multiplication -- there the chain path above,
+    # per-prime Bluestein rows checked against the oracle on the smaller rings and in test_gpu_general_m.py, stands in)
+    for c in (() if m > 40000 else (2,) if ctx.phim > 10000 and (m & (m - 1)) != 0 else (1, 2)):
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
     ctx.set_option("crt_skip_cleanup", 1)
     bad = ctx.ct_mul_relin(ksk, logQ, p, a, b)
@@ -348,6 +351,7 @@ def test_safe_prime_ring_with_a_chain_too_narrow_for_the_limb_plan(m, logQ):
 
 @pytest.mark.parametrize("m,logQ", [(22, 80), (46, 120), (1006, 200), (8422, 341),
                                     (32602, 120),              # p = 32603: phi(m) = 16300, the metric's size in the reference's own parameterisation -- padded rows of 2^15
+                                    (65266, 120),              # p = 65267: phi(m) = 32632, 2 phi(m) - 1 = 65263 <= 2^16 -- padded rows of 2^16 (two head / tail stages: the largest ring FHEContext.cpp:89 allows a safe prime below 2^16 for)
                                     (101, 80), (16381, 120)])  # odd prime m: fold modulo X^m - 1 and Phi_m = 1 + X + ... + X^(m-1) (rows of 2^14 and 2^15)
 def test_key_switch_on_safe_prime_rings(m, logQ):
     """The reference's own rings (m = p - 1 = 2 q' for a safe prime p; Test_Regression: p = 8423, logQ = 341, 13 primes) take the exact
@@ -372,6 +376,22 @@ def test_key_switch_on_safe_prime_rings(m, logQ):
     got_d = ctx.ct_mul_relin(ksk_d, logQ, p, a, b)
     ctx.set_option("ks_direct", 0)
     assert np.array_equal(got_d, got)
+    if m > 20000:
+        # ... and with a GENERATED matrix (KeySwitchSI::Init on the device: centred limbs, the form the reference's drivers would run) against the
+        # per-prime Bluestein path on the same matrix
+        one = np.zeros((n, 1), dtype=np.uint64)
+        one[0, 0] = 1
+        t = F.DoubleCRT(ctx).sample(0, 64, 77, 1)
+        t2 = t.copy()
+        t2.op(t, 2)
+        kg = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([F.DoubleCRT.from_poly(ctx, one), t, t2], t, logQ, 77, 78, 100, 3)
+        got_g = ctx.ct_mul_relin(kg, logQ, p, a, b)
+        assert kg.form()[0] == 1 and kg.key_bits()[0], (kg.form(), kg.key_bits())
+        ctx.set_option("ks_direct", 1)
+        kg_d = F.KeySwitchMatrix(ctx, 3, nd).upload(kg.download())
+        got_gd = ctx.ct_mul_relin(kg_d, logQ, p, a, b)
+        ctx.set_option("ks_direct", 0)
+        assert kg_d.form()[0] == 0 and np.array_equal(got_gd, got_g)
     # crafted rows: scaled-down parts = (d X^pos, 0, 0), key row (r, 0) = edge polynomial e, so the dot product is d X^pos e mod Phi_m
     primes = [int(q) for q in ctx.primes]
     Pprod = 1
