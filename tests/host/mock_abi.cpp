@@ -15,6 +15,7 @@ struct fhesi_ksk { uint64_t tag; };
 static const char* g_err = "";
 extern "C" {
 const char* fhesi_last_error(void) { return g_err; }
+int32_t fhesi_abi_version(void) { return FHESI_ABI_VERSION; }
 int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t, const uint64_t*, const uint64_t*, int32_t) {
   int64_t phi = 0; for (int64_t i = 1; i < m; ++i) { int64_t a = i, b = m; while (b) { int64_t t = a % b; a = b; b = t; } if (a == 1) ++phi; }
   *out = new fhesi_ctx{m, phi}; return 0;
