@@ -80,6 +80,7 @@ static const OptDesc kOptions[] = {
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
   {"digit_group", "FHESI_DIGIT_GROUP", offsetof(CtxOptions, digit_group), false},
   {"dot32_parts", "FHESI_DOT32_PARTS", offsetof(CtxOptions, dot32_parts), false},
+  {"dot32_k4", "FHESI_DOT32_K4", offsetof(CtxOptions, dot32_k4), false},
   {"parts_words", "FHESI_PARTS_WORDS", offsetof(CtxOptions, parts_words), false},
   {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
   {"dot32_half", "FHESI_DOT32_HALF", offsetof(CtxOptions, dot32_half), false},

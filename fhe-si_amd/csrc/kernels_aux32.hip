@@ -649,6 +649,171 @@ dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int nco
 #undef DL32
 }
 
+// ---- dot32_kernel4: the KEY words in LDS, the DIGIT words straight from memory into registers (round 5).
+// dot32_kernel2 keeps a tile of digit words in LDS and streams the key words: every digit word read from LDS feeds two multiply-adds (both key
+// rows), so the LDS pipe (128 bytes per clock and CU) saturates exactly when the VALU does, and the kernel runs at 64 % VALU busy with the key
+// block (62 GB per launch) streaming L2 -> L1 on top.  Here a lane owns ONE coefficient position and CW ciphertexts: it holds all NOUT = 2 NLB
+// accumulators (limb, key row) of its CW ciphertexts in registers (NOUT CW 64-bit totals, two waves per SIMD), so a digit word -- loaded once
+// from memory in whole 256-byte lines, never through LDS -- feeds NOUT multiply-adds and a key word read from LDS feeds CW.  The key block of
+// the workgroup's (prime, slice) passes through LDS in chunks of KC columns (a double buffer; every wave fetches its rows of the next chunk
+// one column per step and writes them two steps later), once per 8 CW ciphertexts instead of once per 8.
+// What it takes to make this run at the VALU's pace with TWO waves per SIMD, learned the slow way:
+//  * the digit words come from HBM (~1.5 us under load, a step lasts ~0.4 us): they are fetched PD steps ahead into a ring of registers;
+//  * the loop body is BRANCH-FREE -- with a branch around a load hipcc drains every outstanding load at the next join (`s_waitcnt vmcnt(0)`
+//    at each step: the ring is empty and the kernel runs at the load latency, 6.4 ms per launch like dot32_kernel2) -- so columns past the
+//    last are clamped loads multiplied by key rows written as ZEROS, and waves without a second output row re-write a neighbour's row with
+//    the same words;
+//  * the written order is the schedule (sched_barrier between the phases of a step): left alone hipcc hoists the reads of later steps to the
+//    top of the 4000-instruction block and spills the accumulators.
+// Accumulation: products of a reduced digit (below p) and a key word (below p) are below 2^60; a total is folded once per chunk as
+// (hi 2^32 + lo) -> hi (2^32 mod p) + lo < 2^57 (2^32 mod p is below 2^24), and KC <= 12 more products keep it below 2^64.  The epilogue is
+// dot32_kernel2's Montgomery step (outputs carry the factor 2^-32, undone by the inverse transform).
+// Workgroup = 8 waves = 8 CW ciphertexts of one 64-coefficient slice of one prime; grid as dot32_kernel2 (x = slice low bits + 8 * group,
+// y = slice high bits, z = prime): the groups of a (slice, prime) sit on one XCD and share its key block in L2.
+template <int NLBT, int CW, int KC, int PD>
+__global__ void __launch_bounds__(512, 2)
+dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, i64 count, u32* __restrict__ out, Aux32Primes pr, int ngroups, int lognsl, int sub_lg) {
+  constexpr int NOUT = 2 * NLBT, NH2 = NOUT / 2, NW = 8, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = 2;
+  static_assert(KC <= 12 && KC % PD == 0 && KC % PK == 0, "ring slots are compile-time; KC products on top of a folded total stay below 2^64");
+  extern __shared__ __attribute__((aligned(16))) u32 kl[];        // [2][KC * NOUT][64]
+  const u32 lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 s_lo = blockIdx.x & 7, g = blockIdx.x >> 3, s_hi = blockIdx.y;
+  const int a = (int)blockIdx.z;
+  const i64 slice = (i64)(s_hi * 8 + s_lo);
+  const u32 p = pr.p[a], twop = 2 * p;
+  const u32 r32 = 0u - 4u * p;                                    // 2^32 mod p for p in (2^32 / 5, 2^30): below 2^24 for every prime the launcher admits
+  const i64 ct0 = (i64)g * (NW * CW) + (i64)w * CW;
+  // the CW digit streams of this wave: scalar bases (the tiled digit rows [sub-chunk][prime][slice][ciphertext * ncol + column][64])
+  const u32* dbase[CW];
+  bool live[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const i64 ct = ct0 + c;
+    live[c] = ct < count;
+    const i64 cc = live[c] ? ct : count - 1;                      // (a wave past the end repeats the last ciphertext's loads and stores nothing)
+    const i64 sub = cc >> sub_lg, ct_in = cc & (((i64)1 << sub_lg) - 1);
+    const i64 rest = count - (sub << sub_lg), cnt_s = rest < ((i64)1 << sub_lg) ? rest : ((i64)1 << sub_lg);
+    dbase[c] = dig + (sub << sub_lg) * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + ct_in * ncol) * 64;
+  }
+  // key rows k32 [a][l][slice][r][column][64]: this wave fetches the rows of outputs o = w, w + 8, ... (o = 2 l + r); a wave without such an
+  // output takes the last one again (same words, same LDS row: a benign double write)
+  const u32* kwave[RPS];
+  int orow[RPS];
+#pragma unroll
+  for (int j = 0; j < RPS; ++j) {
+    orow[j] = w + NW * j < NOUT ? w + NW * j : NOUT - 1;
+    kwave[j] = k32 + (((((i64)a * NLBT + (orow[j] >> 1)) << lognsl) + slice) * 2 + (orow[j] & 1)) * ncol * 64;
+  }
+  const u32 l4 = lane * 4;
+  const u32 koff_max = l4 + (u32)(ncol - 1) * 256;
+  u64 acc[NOUT][CW];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc[o][c] = 0;
+  // chunk 0 of the key block (columns that do not exist: zeros)
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) {
+    const u32 ko = min(l4 + (u32)kk * 256u, koff_max);
+#pragma unroll
+    for (int j = 0; j < RPS; ++j) { const u32 v = ld32(kwave[j], ko); kl[(kk * NOUT + orow[j]) * 64 + lane] = kk < ncol ? v : 0u; }
+  }
+  u32 dn[PD][CW];
+  u32 koff = l4;
+#pragma unroll
+  for (int s_ = 0; s_ < PD; ++s_) {
+    const u32 ko = min(koff, koff_max);
+#pragma unroll
+    for (int c = 0; c < CW; ++c) dn[s_][c] = ld32(dbase[c], ko);
+    koff += 256;
+  }
+  __syncthreads();
+  const int nch = (ncol + KC - 1) / KC;
+  u32 kcol = l4 + (u32)KC * 256u;                                  // byte offset of the column whose key rows are fetched next (the next chunk's)
+  int kleft = ncol - KC;                                           // columns that exist from there on
+  for (int ci = 0; ci < nch; ++ci) {
+    const u32* __restrict__ cur = kl + (ci & 1) * (ROWS * 64);
+    u32* __restrict__ nxt = kl + ((ci & 1) ^ 1) * (ROWS * 64);
+    u32 kr[PK][RPS];                                               // key rows on their way (fetched at step kk, written to LDS at step kk + PK)
+    u32 kqa[NH2], kqb[NH2];                                        // the two halves of a step's key words, each read from LDS while the other half's multiply-adds run
+#pragma unroll
+    for (int o = 0; o < NH2; ++o) kqa[o] = cur[o * 64 + lane];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk >= PK) {
+#pragma unroll
+        for (int j = 0; j < RPS; ++j) nxt[((kk - PK) * NOUT + orow[j]) * 64 + lane] = kr[kk % PK][j];
+      }
+      {
+        const u32 ko = min(kcol, koff_max);
+        const u32 keep = kleft > 0 ? 0xffffffffu : 0u;               // (scalar: a column past the end contributes zero key words)
+#pragma unroll
+        for (int j = 0; j < RPS; ++j) kr[kk % PK][j] = ld32(kwave[j], ko) & keep;
+        kcol += 256; --kleft;
+      }
+      u32 d[CW];
+#pragma unroll
+      for (int c = 0; c < CW; ++c) { u32 t = dn[kk % PD][c]; t = min(t, t - twop); d[c] = min(t, t - p); }
+      {
+        const u32 ko = min(koff, koff_max);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) dn[kk % PD][c] = ld32(dbase[c], ko);
+        koff += 256;
+      }
+#pragma unroll
+      for (int o = 0; o < NH2; ++o) kqb[o] = cur[(kk * NOUT + NH2 + o) * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int o = 0; o < NH2; ++o) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) acc[o][c] += (u64)kqa[o] * d[c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 1 < KC) {
+#pragma unroll
+        for (int o = 0; o < NH2; ++o) kqa[o] = cur[((kk + 1) * NOUT + o) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int o = 0; o < NH2; ++o) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) acc[NH2 + o][c] += (u64)kqb[o] * d[c];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the rows still on their way
+#pragma unroll
+    for (int s_ = KC - PK; s_ < KC; ++s_) {
+#pragma unroll
+      for (int j = 0; j < RPS; ++j) nxt[(s_ * NOUT + orow[j]) * 64 + lane] = kr[s_ % PK][j];
+    }
+    // fold: (hi 2^32 + lo) -> hi (2^32 mod p) + lo, below 2^57
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+      for (int c = 0; c < CW; ++c) acc[o][c] = (u64)(u32)(acc[o][c] >> 32) * r32 + (u32)acc[o][c];
+    __syncthreads();
+  }
+  const u32 mont = pr.mont[a];
+  const i64 soff = slice * 64;
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    u32* obase = out + ((((i64)(o >> 1) * 4 + a) << (lognsl + 6)) + soff) + lane;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      if (live[c]) {
+        const u64 v = acc[o][c];                          // below 2^57
+        const u32 mq = (u32)v * mont;
+        u32 ov = (u32)((v + (u64)mq * p) >> 32);          // v 2^-32 mod p, below p + 2^25
+        ov = min(ov, ov - p);
+        __builtin_nontemporal_store(ov, obase + (((i64)((ct0 + c) * 2 + (o & 1)) * NLBT * 4) << (lognsl + 6)));
+      }
+    }
+  }
+}
+
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp, bool centred) {
   FHESI_TRY(aux32_init(ctx));
   k->mfma_valid = false;
@@ -1080,6 +1245,28 @@ static int launch_dot32_p(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   HIP_TRY(hipGetLastError());
   return 0;
 }
+template <int NLBT, int CW, int KC, int PD>
+static int launch_dot32_k4(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
+  const size_t shmem = (size_t)2 * KC * 2 * NLBT * 64 * 4;
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!(attr_done.load() >> ctx->device & 1)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel4<NLBT, CW, KC, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done.fetch_or(1ull << ctx->device);
+  }
+  for (int a = 0; a < 4; ++a)
+    if ((u32)(0u - 4u * ctx->aux32->pr.p[a]) >= (1u << 26) || ctx->aux32->pr.p[a] >= (1u << 30)) FHESI_FAIL("dot32: prime %u outside the range of dot32_kernel4's fold", ctx->aux32->pr.p[a]);
+  const i64 nrow = aux32_row_len(ctx);
+  const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;
+  const int ngroups = (int)((count + 8 * CW - 1) / (8 * CW)), nsl8 = (int)(nrow / 64 / 8);
+  const i64 blocks = (i64)8 * ngroups;
+  if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");
+  int sub_lg = 0;
+  while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
+  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel4<NLBT, CW, KC, PD>));
+  dot32_kernel4<NLBT, CW, KC, PD><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), 512, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, count, d_out, ctx->aux32->pr, ngroups, lognsl, sub_lg);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out, bool* mont) {
   *mont = true;
   if (!count) return 0;
@@ -1093,6 +1280,12 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   // tile), two groups of four waves on half the ciphertexts each 7.0, workgroups of four waves on tiles of 4 / 8 ciphertexts 6.8 / 6.9, tiles of 16
   // 7.4-7.8: with half the multiply-adds gone the kernel runs at the rate the L2 delivers the key words (80 GB per launch through L2 -> L1),
   // so the plain form stays; option dot32_small selects the others (A/B)
+  // keys in LDS, digits in registers (dot32_kernel4): the limb counts of generated matrices at the benchmark rings
+  if (ctx->opt.dot32_k4 && count >= 24) {
+    if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 4>(ctx, k, d_dig, ncol, count, d_out);
+    if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 4>(ctx, k, d_dig, ncol, count, d_out);
+    if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1) return launch_dot32_k4<15, 3, 8, 4>(ctx, k, d_dig, ncol, count, d_out);      // (the stress ring: opt-in until measured)
+  }
   if (ctx->opt.dot32_half && k->aux_rows <= 8 && ctx->opt.dot32_small != 0) {
     if (ctx->opt.dot32_small == 1 && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true, 2>(ctx, k, d_dig, ncol, count, d_out);      // two wave groups of four ciphertexts each
     if (ctx->opt.dot32_small == 2 && (size_t)ncol * 4 * 128 <= 40 * 1024) return launch_dot32_t<4, 4, true>(ctx, k, d_dig, ncol, count, d_out);          // four workgroups of four waves per CU

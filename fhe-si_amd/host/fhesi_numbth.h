@@ -47,25 +47,6 @@ inline long FindPrimitiveRoot(long q, unsigned long e) {
   Error("FindPrimitiveRoot(): gave up after 1000 trials");
 }
 
-// the small number-theory helpers PAlgebra and the drivers use (NumbTh.h:43-66,202; NumbTh.cpp:20-200,421-429), on machine words
-inline void factorize(std::vector<long>& factors, long N) { factors.clear(); for (long f = 2; f * f <= N; ++f) if (N % f == 0) { factors.push_back(f); while (N % f == 0) N /= f; } if (N > 1) factors.push_back(N); }   // distinct primes, ascending
-inline int phi_N(int N) { std::vector<long> f; factorize(f, N); long r = N; for (long q : f) r = r / q * (q - 1); return (int)r; }
-inline int mobius(int n) { int r = 1; for (int f = 2; f * f <= n; ++f) if (n % f == 0) { n /= f; if (n % f == 0) return 0; r = -r; } return n > 1 ? -r : r; }
-inline int ord(int N, int p) { int o = 0; while (N % p == 0) { ++o; N /= p; } return o; }                                       // the exponent of p in N
-inline int primroot(int N, int phiN) {                                                                                          // smallest g >= 2 whose order modulo N is phiN
-  std::vector<long> f; factorize(f, phiN);
-  for (int g = 2;; ++g) { bool ok = true; for (long q : f) if (PowerMod((uint64_t)g, (uint64_t)(phiN / q), (uint64_t)N) == 1) { ok = false; break; } if (ok) return g; }
-}
-inline ZZX Cyclotomic(int N) {                                                                                                  // Phi_N = prod_{d | N} (X^(N/d) - 1)^mu(d), exact divisions on machine words
-  std::vector<long> num{1}, den{1};
-  auto times = [](std::vector<long>& a, int e) { std::vector<long> r(a.size() + e, 0); for (size_t i = 0; i < a.size(); ++i) { r[i + e] += a[i]; r[i] -= a[i]; } a.swap(r); };   // a *= (X^e - 1)
-  for (int d = 1; d <= N; ++d) if (N % d == 0) { const int mu = mobius(d); if (mu == 1) times(num, N / d); else if (mu == -1) times(den, N / d); }
-  std::vector<long> q(num.size() - den.size() + 1, 0);                                                                         // den is monic
-  for (long i = (long)q.size() - 1; i >= 0; --i) { q[i] = num[i + den.size() - 1]; for (size_t j = 0; j < den.size(); ++j) num[i + j] -= q[i] * den[j]; }
-  ZZX F; F.rep.resize(q.size()); for (size_t i = 0; i < q.size(); ++i) F.rep[i] = ZZ(q[i]); F.normalize();
-  return F;
-}
-inline ZZ largestCoeff(const ZZX& f) { ZZ mx; for (auto& c : f.rep) { ZZ a = c; a.neg = false; if (mx < a) mx = a; } return mx; }
 // PolyRed (NumbTh.cpp:209-232): coefficients modulo q into (-q/2, q/2] (q = 2: the sign of the input is kept), or [0, q) with abs
 inline void PolyRed(ZZX& out, const ZZX& in, const ZZ& q, bool abs = false) {
   ZZX r; r.rep.resize(in.rep.size()); const ZZ q2 = q >> 1, two(2L);
@@ -79,7 +60,5 @@ inline void PolyRed(ZZX& out, const ZZX& in, const ZZ& q, bool abs = false) {
 inline void PolyRed(ZZX& out, const ZZX& in, int q, bool abs = false) { PolyRed(out, in, ZZ((long)q), abs); }
 inline void PolyRed(ZZX& F, int q, bool abs = false) { PolyRed(F, F, q, abs); }
 inline void PolyRed(ZZX& F, const ZZ& q, bool abs = false) { PolyRed(F, F, q, abs); }
-template <class T> long argmax(std::vector<T>& v) { if (v.empty()) return -1; long b = 0; for (size_t i = 1; i < v.size(); ++i) if (v[b] < v[i]) b = (long)i; return b; }   // NumbTh.h:127-131
-template <class T> long argmin(std::vector<T>& v) { if (v.empty()) return -1; long b = 0; for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[b]) b = (long)i; return b; }
 
 }  // namespace fhesi

@@ -42,18 +42,6 @@ inline void Reduce(ZZ& val, unsigned logQ, bool positive = false) {   // Util.cp
   val = r;
 }
 inline void ReduceCoefficients(ZZX& poly, unsigned logQ, bool positive = false) { for (auto& c : poly.rep) Reduce(c, logQ, positive); poly.normalize(); }
-inline void ReduceCoefficientsSlow(ZZX& poly, const ZZ& modulus, bool positive = false) {   // Util.cpp:33-43: any modulus; NTL's % is non-negative for a positive modulus
-  const ZZ half = modulus / ZZ(2L);
-  for (auto& c : poly.rep) { c = c % modulus; if (!positive && c > half) c -= modulus; }
-  poly.normalize();
-}
-inline void ReduceCoefficientsSlow(ZZX& poly, unsigned modulus, bool positive = false) { ReduceCoefficientsSlow(poly, ZZ((unsigned long)modulus), positive); }
-template <typename T> unsigned ComputeLog(T val) { unsigned lg = 0; while (val != 0) { val >>= 1; ++lg; } return lg - 1; }            // Util.h:68-76
-template <typename T> void TensorProduct(std::vector<T>& res, const std::vector<T>& v1, const std::vector<T>& v2) {                // Util.h:100-111
-  res.resize(v1.size() * v2.size());
-  size_t ind = 0;
-  for (size_t i = 0; i < v1.size(); ++i) for (size_t j = 0; j < v2.size(); ++j) { res[ind] = v1[i]; res[ind++] *= v2[j]; }
-}
 template <typename T> void DotProduct(T& res, const std::vector<T>& v1, const std::vector<T>& v2) {   // Util.h:79-98
   if (v1.empty()) return;
   res = v1[0]; res *= v2[0];

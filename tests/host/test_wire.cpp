@@ -15,6 +15,7 @@
 #include <sstream>
 
 #include "../../fhe-si_amd/host/fhesi_serialization.h"
+#include "host_helpers_literal.h"
 
 using namespace fhesi;
 namespace fhesi { FHEcontext* activeContext = nullptr; }

@@ -196,6 +196,23 @@ def test_config2_generated_keys_several_chunks():
     assert form == 1 and rows == 7 and centred and key_bits <= logQ - 1, (form, rows, limb_bits, centred, key_bits)      # (1 = four 30-bit auxiliary primes, limbs)
     for c in (0, 63, 64, 127, 128, 129):
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    # the dot product ran with the keys in LDS and the digits in registers (dot32_kernel4); the digit-tile form (dot32_kernel2) gives the same bits,
+    # also on a ragged batch (the last workgroup's waves past the end) and on a batch below the new kernel's threshold
+    da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(a.nbytes)
+    ctx.prof_enable(True)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    ctx.sync()
+    assert "dot32_kernel4<7, 6" in ctx.prof_kernel_name("dot"), ctx.prof_kernel_name("dot")
+    ctx.prof_enable(False)
+    assert np.array_equal(dout.download((count, 2, n, nl)), got)
+    for cnt in (49, 25, 9):
+        ctx.set_option("dot32_k4", 1)
+        ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, cnt)
+        new = dout.download((cnt, 2, n, nl))
+        ctx.set_option("dot32_k4", 0)
+        ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, cnt)
+        assert np.array_equal(dout.download((cnt, 2, n, nl)), new) and np.array_equal(new, got[:cnt]), cnt
+    ctx.set_option("dot32_k4", 1)
     ctx.set_option("ks_long_keys", 1)
     again = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     assert ksk.form()[1] == 15 and np.array_equal(again, got)

@@ -21,6 +21,7 @@ run regression_ref --workload regression --reg-ring reference --steps 5 --warmup
 run regression_ref_p32603 --workload regression --reg-ring reference --reg-p 32603 --steps 5 --warmup 2
 run ntt --workload ntt --steps 10 --warmup 2
 run refring --workload refring --steps 5 --warmup 2 --cpu-sample 0 --gpu-seconds 0
+run refring_p65267 --workload refring --ref-p 65267 --steps 3 --warmup 1 --cpu-sample 0 --gpu-seconds 0 --batch 512
 fi
 for c in FETCH_SIZE WRITE_SIZE; do        # one counter per pass (combining them has hung the profiler on this pool)
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --batch 1024 --no-surface --gpu-seconds 0 > /dev/null 2> "$O/pmc_$c.log"
@@ -28,10 +29,10 @@ done
 F=$(find "$O/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 W=$(find "$O/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "dot32_kernel2<8, 8, true, 1>" "$O/pmc_dot_aux.json" ciphertexts_per_launch=1024
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true, 0, false, Aux32Primes, true>" "$O/pmc_ntt_fwd.json" rows_per_launch=270336
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<false, 0, false, T32Primes, true>" "$O/pmc_t32_fwd.json" rows_per_launch=143360
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true, 0, false, Aux32Primes, true, true>" "$O/pmc_ntt_fwd.json" rows_per_launch=270336
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<false, 0, false, T32Primes, true, false>" "$O/pmc_t32_fwd.json" rows_per_launch=143360
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<false, true, T32Primes>" "$O/pmc_t32_inv.json" rows_per_launch=107520
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "rns32_reduce_kernel<8, false, true>" "$O/pmc_t32_rns.json" ciphertexts_per_launch=1024
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "rns32_reduce_kernel<8, 0, true>" "$O/pmc_t32_rns.json" ciphertexts_per_launch=1024
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "crt32_scale_kernel<512, false, 28, 38, 0>" "$O/pmc_t32_crt.json" ciphertexts_per_launch=1024
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<true, false, Aux32Primes>" "$O/pmc_ntt_inv.json" rows_per_launch=57344
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ks_recombine_centred_kernel" "$O/pmc_recombine.json" ciphertexts_per_launch=1024
