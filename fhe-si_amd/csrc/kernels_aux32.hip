@@ -670,10 +670,10 @@ dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int nco
 // dot32_kernel2's Montgomery step (outputs carry the factor 2^-32, undone by the inverse transform).
 // Workgroup = 8 waves = 8 CW ciphertexts of one 64-coefficient slice of one prime; grid as dot32_kernel2 (x = slice low bits + 8 * group,
 // y = slice high bits, z = prime): the groups of a (slice, prime) sit on one XCD and share its key block in L2.
-template <int NLBT, int CW, int KC, int PD>
-__global__ void __launch_bounds__(512, 2)
+template <int NLBT, int CW, int KC, int PD, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4)
 dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, i64 count, u32* __restrict__ out, Aux32Primes pr, int ngroups, int lognsl, int sub_lg) {
-  constexpr int NOUT = 2 * NLBT, NH2 = NOUT / 2, NW = 8, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = 2;
+  constexpr int NOUT = 2 * NLBT, NH2 = NOUT / 2, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = 2;
   static_assert(KC <= 12 && KC % PD == 0 && KC % PK == 0, "ring slots are compile-time; KC products on top of a folded total stay below 2^64");
   extern __shared__ __attribute__((aligned(16))) u32 kl[];        // [2][KC * NOUT][64]
   const u32 lane = threadIdx.x & 63;
@@ -743,21 +743,27 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     for (int kk = 0; kk < KC; ++kk) {
       __builtin_amdgcn_sched_barrier(0);
       if (kk >= PK) {
+        // (a column past the end contributes zero key words; the mask is applied HERE, two steps after the fetch -- next to the load it made
+        // every step wait for its own key rows: an L2 round trip per step, half the kernel's time)
+        const u32 keep = kleft + PK > 0 ? 0xffffffffu : 0u;
 #pragma unroll
-        for (int j = 0; j < RPS; ++j) nxt[((kk - PK) * NOUT + orow[j]) * 64 + lane] = kr[kk % PK][j];
+        for (int j = 0; j < RPS; ++j) nxt[((kk - PK) * NOUT + orow[j]) * 64 + lane] = kr[kk % PK][j] & keep;
       }
       {
         const u32 ko = min(kcol, koff_max);
-        const u32 keep = kleft > 0 ? 0xffffffffu : 0u;               // (scalar: a column past the end contributes zero key words)
 #pragma unroll
-        for (int j = 0; j < RPS; ++j) kr[kk % PK][j] = ld32(kwave[j], ko) & keep;
+        for (int j = 0; j < RPS; ++j) kr[kk % PK][j] = ld32(kwave[j], ko);
         kcol += 256; --kleft;
       }
       u32 d[CW];
 #pragma unroll
       for (int c = 0; c < CW; ++c) { u32 t = dn[kk % PD][c]; t = min(t, t - twop); d[c] = min(t, t - p); }
       {
+#if defined(K4_ABL) && (K4_ABL & 1)       // ablation: the digit words always from the first columns (cache-resident)
+        const u32 ko = l4 + (u32)(kk % PD) * 256u;
+#else
         const u32 ko = min(koff, koff_max);
+#endif
 #pragma unroll
         for (int c = 0; c < CW; ++c) dn[kk % PD][c] = ld32(dbase[c], ko);
         koff += 256;
@@ -786,15 +792,18 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     // the rows still on their way
 #pragma unroll
     for (int s_ = KC - PK; s_ < KC; ++s_) {
+      const u32 keep = kleft + (KC - s_) > 0 ? 0xffffffffu : 0u;
 #pragma unroll
-      for (int j = 0; j < RPS; ++j) nxt[(s_ * NOUT + orow[j]) * 64 + lane] = kr[s_ % PK][j];
+      for (int j = 0; j < RPS; ++j) nxt[(s_ * NOUT + orow[j]) * 64 + lane] = kr[s_ % PK][j] & keep;
     }
     // fold: (hi 2^32 + lo) -> hi (2^32 mod p) + lo, below 2^57
 #pragma unroll
     for (int o = 0; o < NOUT; ++o)
 #pragma unroll
       for (int c = 0; c < CW; ++c) acc[o][c] = (u64)(u32)(acc[o][c] >> 32) * r32 + (u32)acc[o][c];
+#if !(defined(K4_ABL) && (K4_ABL & 2))   // ablation: no barrier between chunks (wrong results)
     __syncthreads();
+#endif
   }
   const u32 mont = pr.mont[a];
   const i64 soff = slice * 64;
@@ -1245,25 +1254,25 @@ static int launch_dot32_p(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   HIP_TRY(hipGetLastError());
   return 0;
 }
-template <int NLBT, int CW, int KC, int PD>
+template <int NLBT, int CW, int KC, int PD, int NW = 8>
 static int launch_dot32_k4(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)2 * KC * 2 * NLBT * 64 * 4;
   static std::atomic<unsigned long long> attr_done{0};
   if (!(attr_done.load() >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel4<NLBT, CW, KC, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel4<NLBT, CW, KC, PD, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.fetch_or(1ull << ctx->device);
   }
   for (int a = 0; a < 4; ++a)
     if ((u32)(0u - 4u * ctx->aux32->pr.p[a]) >= (1u << 26) || ctx->aux32->pr.p[a] >= (1u << 30)) FHESI_FAIL("dot32: prime %u outside the range of dot32_kernel4's fold", ctx->aux32->pr.p[a]);
   const i64 nrow = aux32_row_len(ctx);
   const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;
-  const int ngroups = (int)((count + 8 * CW - 1) / (8 * CW)), nsl8 = (int)(nrow / 64 / 8);
+  const int ngroups = (int)((count + NW * CW - 1) / (NW * CW)), nsl8 = (int)(nrow / 64 / 8);
   const i64 blocks = (i64)8 * ngroups;
   if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");
   int sub_lg = 0;
   while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
-  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel4<NLBT, CW, KC, PD>));
-  dot32_kernel4<NLBT, CW, KC, PD><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), 512, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, count, d_out, ctx->aux32->pr, ngroups, lognsl, sub_lg);
+  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel4<NLBT, CW, KC, PD, NW>));
+  dot32_kernel4<NLBT, CW, KC, PD, NW><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, count, d_out, ctx->aux32->pr, ngroups, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1282,7 +1291,19 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   // so the plain form stays; option dot32_small selects the others (A/B)
   // keys in LDS, digits in registers (dot32_kernel4): the limb counts of generated matrices at the benchmark rings
   if (ctx->opt.dot32_k4 && count >= 24) {
-    if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 4>(ctx, k, d_dig, ncol, count, d_out);
+#ifndef K4_CW
+#define K4_CW 6
+#endif
+#ifndef K4_PD
+#define K4_PD 3
+#endif
+#ifndef K4_KC
+#define K4_KC 12
+#endif
+#ifndef K4_NW
+#define K4_NW 8
+#endif
+    if (k->aux_rows == 7) return launch_dot32_k4<7, K4_CW, K4_KC, K4_PD, K4_NW>(ctx, k, d_dig, ncol, count, d_out);
     if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 4>(ctx, k, d_dig, ncol, count, d_out);
     if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1) return launch_dot32_k4<15, 3, 8, 4>(ctx, k, d_dig, ncol, count, d_out);      // (the stress ring: opt-in until measured)
   }
