@@ -1290,22 +1290,10 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   // 7.4-7.8: with half the multiply-adds gone the kernel runs at the rate the L2 delivers the key words (80 GB per launch through L2 -> L1),
   // so the plain form stays; option dot32_small selects the others (A/B)
   // keys in LDS, digits in registers (dot32_kernel4): the limb counts of generated matrices at the benchmark rings
-  if (ctx->opt.dot32_k4 && count >= 24) {
-#ifndef K4_CW
-#define K4_CW 6
-#endif
-#ifndef K4_PD
-#define K4_PD 3
-#endif
-#ifndef K4_KC
-#define K4_KC 12
-#endif
-#ifndef K4_NW
-#define K4_NW 8
-#endif
-    if (k->aux_rows == 7) return launch_dot32_k4<7, K4_CW, K4_KC, K4_PD, K4_NW>(ctx, k, d_dig, ncol, count, d_out);
-    if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 4>(ctx, k, d_dig, ncol, count, d_out);
-    if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1) return launch_dot32_k4<15, 3, 8, 4>(ctx, k, d_dig, ncol, count, d_out);      // (the stress ring: opt-in until measured)
+  if (ctx->opt.dot32_k4 && count >= 24 && !ctx->opt.dot32_small) {
+    if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)
+    if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 3>(ctx, k, d_dig, ncol, count, d_out);
+    // (15 limbs, the stress ring: 3 ciphertexts per lane, 104 bytes of spills and 81 ms per 1024 against 37.6 for dot32_kernel2p: not offered)
   }
   if (ctx->opt.dot32_half && k->aux_rows <= 8 && ctx->opt.dot32_small != 0) {
     if (ctx->opt.dot32_small == 1 && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true, 2>(ctx, k, d_dig, ncol, count, d_out);      // two wave groups of four ciphertexts each
