@@ -798,11 +798,19 @@ def main():
             ku = F.KeySwitchMatrix(ctx, 3, nd).upload(rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n))
             ctx.ct_mul_relin_dev(ku, LOGQ, P_PLAIN, da, db, dout, nl, B, DECOMP)
             ctx.sync()
+            ctx.prof_enable(True)
             t0 = time.perf_counter()
             for _ in range(5):
                 ctx.ct_mul_relin_dev(ku, LOGQ, P_PLAIN, da, db, dout, nl, B, DECOMP)
             ctx.sync()
-            surface["uniform_key_matrix"] = {"value": round(5 * B / (time.perf_counter() - t0), 1), "rows": ku.form()[1], "centred_limbs": ku.key_bits()[0]}
+            t_u = time.perf_counter() - t0
+            prof_u = {k: ctx.prof_read(k) for k in F.binding.PROF_CLASSES}
+            names_u = {k: ctx.prof_kernel_name(k) for k in ("dot", "ntt_fwd_digits_main")}
+            ctx.prof_enable(False)
+            surface["uniform_key_matrix"] = {"value": round(5 * B / t_u, 1), "rows": ku.form()[1], "centred_limbs": ku.key_bits()[0],
+                                             "kernel_ms_per_step": {k: round(v[2] / 5, 3) for k, v in prof_u.items() if v[0] and k != "ntt_fwd_digits_main"},
+                                             "digits_ms_per_launch": round(prof_u["ntt_fwd_digits_main"][2] / max(1, prof_u["ntt_fwd_digits_main"][0]), 3),
+                                             "kernels": names_u}
             ctx.ct_mul_relin_dev(ksk, LOGQ, P_PLAIN, da, db, dout, nl, B, DECOMP)      # (the timed buffer's contents again, for the check below)
             ctx.sync()
             del ku
