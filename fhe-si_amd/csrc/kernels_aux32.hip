@@ -670,10 +670,19 @@ dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int nco
 // dot32_kernel2's Montgomery step (outputs carry the factor 2^-32, undone by the inverse transform).
 // Workgroup = 8 waves = 8 CW ciphertexts of one 64-coefficient slice of one prime; grid as dot32_kernel2 (x = slice low bits + 8 * group,
 // y = slice high bits, z = prime): the groups of a (slice, prime) sit on one XCD and share its key block in L2.
-template <int NLBT, int CW, int KC, int PD, int NW = 8>
+#ifndef K4S_CW
+#define K4S_CW 5
+#endif
+#ifndef K4S_PD
+#define K4S_PD 2
+#endif
+template <int NLBT, int CW, int KC, int PD, int NW = 8, int NSP = 1>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, i64 count, u32* __restrict__ out, Aux32Primes pr, int ngroups, int lognsl, int sub_lg) {
-  constexpr int NOUT = 2 * NLBT, NH2 = NOUT / 2, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = 2;
+  // NSP > 1 (many limbs: 15 at the stress ring): the outputs are split over NSP wave groups -- a wave carries NO = NOUT / NSP outputs of its CW
+  // ciphertexts, the NSP waves of a ciphertext group load the same digit words (the second load hits in L1 / L2)
+  constexpr int NOUT = 2 * NLBT, NO = NOUT / NSP, NHA = (NO + 1) / 2, NHB = NO - NHA, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = 2;
+  static_assert(NOUT % NSP == 0 && NW % NSP == 0, "output split");
   static_assert(KC <= 12 && KC % PD == 0 && KC % PK == 0, "ring slots are compile-time; KC products on top of a folded total stay below 2^64");
   extern __shared__ __attribute__((aligned(16))) u32 kl[];        // [2][KC * NOUT][64]
   const u32 lane = threadIdx.x & 63;
@@ -683,7 +692,8 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   const i64 slice = (i64)(s_hi * 8 + s_lo);
   const u32 p = pr.p[a], twop = 2 * p;
   const u32 r32 = 0u - 4u * p;                                    // 2^32 mod p for p in (2^32 / 5, 2^30): below 2^24 for every prime the launcher admits
-  const i64 ct0 = (i64)g * (NW * CW) + (i64)w * CW;
+  const int osel = w % NSP, o_base = osel * NO;                     // this wave's block of outputs
+  const i64 ct0 = (i64)g * (NW / NSP * CW) + (i64)(w / NSP) * CW;
   // the CW digit streams of this wave: scalar bases (the tiled digit rows [sub-chunk][prime][slice][ciphertext * ncol + column][64])
   const u32* dbase[CW];
   bool live[CW];
@@ -707,9 +717,9 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   }
   const u32 l4 = lane * 4;
   const u32 koff_max = l4 + (u32)(ncol - 1) * 256;
-  u64 acc[NOUT][CW];
+  u64 acc[NO][CW];
 #pragma unroll
-  for (int o = 0; o < NOUT; ++o)
+  for (int o = 0; o < NO; ++o)
 #pragma unroll
     for (int c = 0; c < CW; ++c) acc[o][c] = 0;
   // chunk 0 of the key block (columns that do not exist: zeros)
@@ -736,9 +746,9 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     const u32* __restrict__ cur = kl + (ci & 1) * (ROWS * 64);
     u32* __restrict__ nxt = kl + ((ci & 1) ^ 1) * (ROWS * 64);
     u32 kr[PK][RPS];                                               // key rows on their way (fetched at step kk, written to LDS at step kk + PK)
-    u32 kqa[NH2], kqb[NH2];                                        // the two halves of a step's key words, each read from LDS while the other half's multiply-adds run
+    u32 kqa[NHA], kqb[NHB > 0 ? NHB : 1];                          // the two halves of a step's key words, each read from LDS while the other half's multiply-adds run
 #pragma unroll
-    for (int o = 0; o < NH2; ++o) kqa[o] = cur[o * 64 + lane];
+    for (int o = 0; o < NHA; ++o) kqa[o] = cur[(o_base + o) * 64 + lane];
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
       __builtin_amdgcn_sched_barrier(0);
@@ -769,23 +779,23 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
         koff += 256;
       }
 #pragma unroll
-      for (int o = 0; o < NH2; ++o) kqb[o] = cur[(kk * NOUT + NH2 + o) * 64 + lane];
+      for (int o = 0; o < NHB; ++o) kqb[o] = cur[(kk * NOUT + o_base + NHA + o) * 64 + lane];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int o = 0; o < NH2; ++o) {
+      for (int o = 0; o < NHA; ++o) {
 #pragma unroll
         for (int c = 0; c < CW; ++c) acc[o][c] += (u64)kqa[o] * d[c];
       }
       __builtin_amdgcn_sched_barrier(0);
       if (kk + 1 < KC) {
 #pragma unroll
-        for (int o = 0; o < NH2; ++o) kqa[o] = cur[((kk + 1) * NOUT + o) * 64 + lane];
+        for (int o = 0; o < NHA; ++o) kqa[o] = cur[((kk + 1) * NOUT + o_base + o) * 64 + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int o = 0; o < NH2; ++o) {
+      for (int o = 0; o < NHB; ++o) {
 #pragma unroll
-        for (int c = 0; c < CW; ++c) acc[NH2 + o][c] += (u64)kqb[o] * d[c];
+        for (int c = 0; c < CW; ++c) acc[NHA + o][c] += (u64)kqb[o] * d[c];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -798,7 +808,7 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     }
     // fold: (hi 2^32 + lo) -> hi (2^32 mod p) + lo, below 2^57
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o)
+    for (int o = 0; o < NO; ++o)
 #pragma unroll
       for (int c = 0; c < CW; ++c) acc[o][c] = (u64)(u32)(acc[o][c] >> 32) * r32 + (u32)acc[o][c];
 #if !(defined(K4_ABL) && (K4_ABL & 2))   // ablation: no barrier between chunks (wrong results)
@@ -808,12 +818,13 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   const u32 mont = pr.mont[a];
   const i64 soff = slice * 64;
 #pragma unroll
-  for (int o = 0; o < NOUT; ++o) {
+  for (int oo = 0; oo < NO; ++oo) {
+    const int o = o_base + oo;
     u32* obase = out + ((((i64)(o >> 1) * 4 + a) << (lognsl + 6)) + soff) + lane;
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       if (live[c]) {
-        const u64 v = acc[o][c];                          // below 2^57
+        const u64 v = acc[oo][c];                         // below 2^57
         const u32 mq = (u32)v * mont;
         u32 ov = (u32)((v + (u64)mq * p) >> 32);          // v 2^-32 mod p, below p + 2^25
         ov = min(ov, ov - p);
@@ -1254,25 +1265,25 @@ static int launch_dot32_p(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   HIP_TRY(hipGetLastError());
   return 0;
 }
-template <int NLBT, int CW, int KC, int PD, int NW = 8>
+template <int NLBT, int CW, int KC, int PD, int NW = 8, int NSP = 1>
 static int launch_dot32_k4(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)2 * KC * 2 * NLBT * 64 * 4;
   static std::atomic<unsigned long long> attr_done{0};
   if (!(attr_done.load() >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel4<NLBT, CW, KC, PD, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel4<NLBT, CW, KC, PD, NW, NSP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.fetch_or(1ull << ctx->device);
   }
   for (int a = 0; a < 4; ++a)
     if ((u32)(0u - 4u * ctx->aux32->pr.p[a]) >= (1u << 26) || ctx->aux32->pr.p[a] >= (1u << 30)) FHESI_FAIL("dot32: prime %u outside the range of dot32_kernel4's fold", ctx->aux32->pr.p[a]);
   const i64 nrow = aux32_row_len(ctx);
   const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;
-  const int ngroups = (int)((count + NW * CW - 1) / (NW * CW)), nsl8 = (int)(nrow / 64 / 8);
+  const int ngroups = (int)((count + NW / NSP * CW - 1) / (NW / NSP * CW)), nsl8 = (int)(nrow / 64 / 8);
   const i64 blocks = (i64)8 * ngroups;
   if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");
   int sub_lg = 0;
   while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
-  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel4<NLBT, CW, KC, PD, NW>));
-  dot32_kernel4<NLBT, CW, KC, PD, NW><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, count, d_out, ctx->aux32->pr, ngroups, lognsl, sub_lg);
+  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel4<NLBT, CW, KC, PD, NW, NSP>));
+  dot32_kernel4<NLBT, CW, KC, PD, NW, NSP><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, count, d_out, ctx->aux32->pr, ngroups, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1293,7 +1304,8 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   if (ctx->opt.dot32_k4 && count >= 24 && !ctx->opt.dot32_small) {
     if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)
     if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 3>(ctx, k, d_dig, ncol, count, d_out);
-    // (15 limbs, the stress ring: 3 ciphertexts per lane, 104 bytes of spills and 81 ms per 1024 against 37.6 for dot32_kernel2p: not offered)
+    // 15 limbs (the stress ring): the 30 outputs split over two wave groups (with all 30 in one lane only 3 ciphertexts fit: 81 ms per 1024 against 37.6 for dot32_kernel2p)
+    if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1) return launch_dot32_k4<15, K4S_CW, 8, K4S_PD, 8, 2>(ctx, k, d_dig, ncol, count, d_out);
   }
   if (ctx->opt.dot32_half && k->aux_rows <= 8 && ctx->opt.dot32_small != 0) {
     if (ctx->opt.dot32_small == 1 && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true, 2>(ctx, k, d_dig, ncol, count, d_out);      // two wave groups of four ciphertexts each

@@ -99,6 +99,20 @@ def test_config4_generated_keys_column_parts():
     ctx.set_option("dot32_parts", 0)
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b), got)
     ctx.set_option("dot32_parts", 1)
+    # the same 15 limbs through dot32_kernel4 with the 30 outputs split over two wave groups (option dot32_k4 = 2; a ragged batch of 27)
+    rep = np.concatenate([a, a, a])[:27], np.concatenate([b, b, b])[:27]
+    da, db, dout = ctx.upload(rep[0]), ctx.upload(rep[1]), ctx.alloc(rep[0].nbytes)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, 27)
+    want27 = dout.download((27, 2, n, nl))
+    assert np.array_equal(want27[:9], got) and np.array_equal(want27[18:27], got)
+    ctx.set_option("dot32_k4", 2)
+    ctx.prof_enable(True)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, 27)
+    ctx.sync()
+    assert "dot32_kernel4<15" in ctx.prof_kernel_name("dot"), ctx.prof_kernel_name("dot")
+    ctx.prof_enable(False)
+    assert np.array_equal(dout.download((27, 2, n, nl)), want27)
+    ctx.set_option("dot32_k4", 1)
     ctx.set_option("ks_long_keys", 1)
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b), got)
 
@@ -216,6 +230,41 @@ def test_config2_generated_keys_several_chunks():
     ctx.set_option("ks_long_keys", 1)
     again = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     assert ksk.form()[1] == 15 and np.array_equal(again, got)
+
+
+def test_refring_generated_keys_eight_limbs():
+    """The metric's multiplication on the reference drivers' own ring at its size (Test_AddMul.cpp:131: m = p - 1 = 32602, phi(m) = 16300,
+    logQ = 512; padded rows of 2^15) with a generated key matrix: 8 centred limbs of 72 bits -- the dot32_kernel4<8, 4, ...> instantiation.
+    A ragged batch of 25 against the digit-tile form (dot32_kernel2, option dot32_k4 = 0) bit for bit, and one ciphertext against the oracle
+    (Bluestein mode: ~20 s)."""
+    m, logQ, p, count = 32602, 512, 32603, 25
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    one = np.zeros((n, 1), dtype=np.uint64)
+    one[0, 0] = 1
+    t = F.DoubleCRT(ctx).sample(0, 64, 31, 1)
+    t2 = t.copy()
+    t2.op(t, 2)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([F.DoubleCRT.from_poly(ctx, one), t, t2], t, logQ, 31, 32, 7000, 3)
+    rng = np.random.default_rng(77)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(a.nbytes)
+    ctx.prof_enable(True)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    ctx.sync()
+    assert ksk.form()[1] == 8 and ksk.key_bits()[0], (ksk.form(), ksk.key_bits())
+    assert "dot32_kernel4<8, 4" in ctx.prof_kernel_name("dot"), ctx.prof_kernel_name("dot")
+    ctx.prof_enable(False)
+    got = dout.download((count, 2, n, nl))
+    ctx.set_option("dot32_k4", 0)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    assert np.array_equal(dout.download((count, 2, n, nl)), got)
+    ctx.set_option("dot32_k4", 1)
+    orc = O.Oracle(m, primes, roots)
+    orc.set_bluestein_fft(True)
+    assert np.array_equal(got[24], orc.ct_mul_relin(ksk.download(), a[24], b[24], logQ, p))
 
 
 def test_config2_with_a_chain_of_50_bit_primes():
