@@ -676,13 +676,14 @@ dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int nco
 #ifndef K4S_PD
 #define K4S_PD 2
 #endif
-template <int NLBT, int CW, int KC, int PD, int NW = 8, int NSP = 1>
+template <int NLBT, int CW, int KC, int PD, int NW = 8, int NSP = 1, int TAIL = 0>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, i64 count, u32* __restrict__ out, Aux32Primes pr, int ngroups, int lognsl, int sub_lg) {
   // NSP > 1 (many limbs: 15 at the stress ring): the outputs are split over NSP wave groups -- a wave carries NO = NOUT / NSP outputs of its CW
   // ciphertexts, the NSP waves of a ciphertext group load the same digit words (the second load hits in L1 / L2)
   constexpr int NOUT = 2 * NLBT, NO = NOUT / NSP, NHA = (NO + 1) / 2, NHB = NO - NHA, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = 2;
   static_assert(NOUT % NSP == 0 && NW % NSP == 0, "output split");
+  static_assert(TAIL >= 0 && TAIL < KC && (TAIL == 0 || TAIL >= PK), "tail chunk");
   static_assert(KC <= 12 && KC % PD == 0 && KC % PK == 0, "ring slots are compile-time; KC products on top of a folded total stay below 2^64");
   extern __shared__ __attribute__((aligned(16))) u32 kl[];        // [2][KC * NOUT][64]
   const u32 lane = threadIdx.x & 63;
@@ -739,82 +740,88 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     koff += 256;
   }
   __syncthreads();
-  const int nch = (ncol + KC - 1) / KC;
   u32 kcol = l4 + (u32)KC * 256u;                                  // byte offset of the column whose key rows are fetched next (the next chunk's)
   int kleft = ncol - KC;                                           // columns that exist from there on
-  for (int ci = 0; ci < nch; ++ci) {
-    const u32* __restrict__ cur = kl + (ci & 1) * (ROWS * 64);
-    u32* __restrict__ nxt = kl + ((ci & 1) ^ 1) * (ROWS * 64);
-    u32 kr[PK][RPS];                                               // key rows on their way (fetched at step kk, written to LDS at step kk + PK)
-    u32 kqa[NHA], kqb[NHB > 0 ? NHB : 1];                          // the two halves of a step's key words, each read from LDS while the other half's multiply-adds run
-#pragma unroll
-    for (int o = 0; o < NHA; ++o) kqa[o] = cur[(o_base + o) * 64 + lane];
-#pragma unroll
-    for (int kk = 0; kk < KC; ++kk) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (kk >= PK) {
-        // (a column past the end contributes zero key words; the mask is applied HERE, two steps after the fetch -- next to the load it made
-        // every step wait for its own key rows: an L2 round trip per step, half the kernel's time)
-        const u32 keep = kleft + PK > 0 ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int j = 0; j < RPS; ++j) nxt[((kk - PK) * NOUT + orow[j]) * 64 + lane] = kr[kk % PK][j] & keep;
-      }
-      {
-        const u32 ko = min(kcol, koff_max);
-#pragma unroll
-        for (int j = 0; j < RPS; ++j) kr[kk % PK][j] = ld32(kwave[j], ko);
-        kcol += 256; --kleft;
-      }
-      u32 d[CW];
-#pragma unroll
-      for (int c = 0; c < CW; ++c) { u32 t = dn[kk % PD][c]; t = min(t, t - twop); d[c] = min(t, t - p); }
-      {
-#if defined(K4_ABL) && (K4_ABL & 1)       // ablation: the digit words always from the first columns (cache-resident)
-        const u32 ko = l4 + (u32)(kk % PD) * 256u;
-#else
-        const u32 ko = min(koff, koff_max);
-#endif
-#pragma unroll
-        for (int c = 0; c < CW; ++c) dn[kk % PD][c] = ld32(dbase[c], ko);
-        koff += 256;
-      }
-#pragma unroll
-      for (int o = 0; o < NHB; ++o) kqb[o] = cur[(kk * NOUT + o_base + NHA + o) * 64 + lane];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int o = 0; o < NHA; ++o) {
-#pragma unroll
-        for (int c = 0; c < CW; ++c) acc[o][c] += (u64)kqa[o] * d[c];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (kk + 1 < KC) {
-#pragma unroll
-        for (int o = 0; o < NHA; ++o) kqa[o] = cur[((kk + 1) * NOUT + o_base + o) * 64 + lane];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int o = 0; o < NHB; ++o) {
-#pragma unroll
-        for (int c = 0; c < CW; ++c) acc[NHA + o][c] += (u64)kqb[o] * d[c];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the rows still on their way
-#pragma unroll
-    for (int s_ = KC - PK; s_ < KC; ++s_) {
-      const u32 keep = kleft + (KC - s_) > 0 ? 0xffffffffu : 0u;
-#pragma unroll
-      for (int j = 0; j < RPS; ++j) nxt[(s_ * NOUT + orow[j]) * 64 + lane] = kr[s_ % PK][j] & keep;
-    }
-    // fold: (hi 2^32 + lo) -> hi (2^32 mod p) + lo, below 2^57
-#pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-      for (int c = 0; c < CW; ++c) acc[o][c] = (u64)(u32)(acc[o][c] >> 32) * r32 + (u32)acc[o][c];
-#if !(defined(K4_ABL) && (K4_ABL & 2))   // ablation: no barrier between chunks (wrong results)
-    __syncthreads();
-#endif
+  // one chunk of NS column steps (NS = KC, or TAIL for a shorter last chunk that is compiled on its own instead of padded with zero columns);
+  // FETCH: the key rows of a next chunk are fetched.  (A macro, not a lambda: through a generic lambda the same body is allocated into 64 bytes
+  // of spills.)  Per step: [write the key rows fetched two steps ago to LDS -- masked HERE, not next to their load, where the mask made every
+  // step wait an L2 round trip] [fetch the next chunk's rows of this step's column] [reduce the digit words of this column, fetch column + PD
+  // into their ring slot] [read key half B from LDS] | multiply-adds of half A | [read the next step's half A] | multiply-adds of half B;
+  // then the rows still on their way, the fold hi (2^32 mod p) + lo (below 2^57) and the barrier.
+#define K4_CHUNK(NS, FETCH, ci) do { \
+    const u32* __restrict__ cur = kl + (ci & 1) * (ROWS * 64); \
+    u32* __restrict__ nxt = kl + ((ci & 1) ^ 1) * (ROWS * 64); \
+    u32 kr[PK][RPS]; \
+    u32 kqa[NHA], kqb[NHB > 0 ? NHB : 1]; \
+_Pragma("unroll") \
+    for (int o = 0; o < NHA; ++o) kqa[o] = cur[(o_base + o) * 64 + lane]; \
+_Pragma("unroll") \
+    for (int kk = 0; kk < NS; ++kk) { \
+      __builtin_amdgcn_sched_barrier(0); \
+      if (FETCH && kk >= PK) { \
+        const u32 keep = kleft + PK > 0 ? 0xffffffffu : 0u; \
+_Pragma("unroll") \
+        for (int j = 0; j < RPS; ++j) nxt[((kk - PK) * NOUT + orow[j]) * 64 + lane] = kr[kk % PK][j] & keep; \
+      } \
+      if (FETCH) { \
+        const u32 ko = min(kcol, koff_max); \
+_Pragma("unroll") \
+        for (int j = 0; j < RPS; ++j) kr[kk % PK][j] = ld32(kwave[j], ko); \
+        kcol += 256; --kleft; \
+      } \
+      u32 d[CW]; \
+_Pragma("unroll") \
+      for (int c = 0; c < CW; ++c) { u32 t = dn[kk % PD][c]; t = min(t, t - twop); d[c] = min(t, t - p); } \
+      { \
+        const u32 ko = min(koff, koff_max); \
+_Pragma("unroll") \
+        for (int c = 0; c < CW; ++c) dn[kk % PD][c] = ld32(dbase[c], ko); \
+        koff += 256; \
+      } \
+_Pragma("unroll") \
+      for (int o = 0; o < NHB; ++o) kqb[o] = cur[(kk * NOUT + o_base + NHA + o) * 64 + lane]; \
+      __builtin_amdgcn_sched_barrier(0); \
+_Pragma("unroll") \
+      for (int o = 0; o < NHA; ++o) { \
+_Pragma("unroll") \
+        for (int c = 0; c < CW; ++c) acc[o][c] += (u64)kqa[o] * d[c]; \
+      } \
+      __builtin_amdgcn_sched_barrier(0); \
+      if (kk + 1 < NS) { \
+_Pragma("unroll") \
+        for (int o = 0; o < NHA; ++o) kqa[o] = cur[((kk + 1) * NOUT + o_base + o) * 64 + lane]; \
+      } \
+      __builtin_amdgcn_sched_barrier(0); \
+_Pragma("unroll") \
+      for (int o = 0; o < NHB; ++o) { \
+_Pragma("unroll") \
+        for (int c = 0; c < CW; ++c) acc[NHA + o][c] += (u64)kqb[o] * d[c]; \
+      } \
+    } \
+    __builtin_amdgcn_sched_barrier(0); \
+    if (FETCH) { \
+_Pragma("unroll") \
+      for (int s_ = NS - PK; s_ < NS; ++s_) { \
+        const u32 keep = kleft + (NS - s_) > 0 ? 0xffffffffu : 0u; \
+_Pragma("unroll") \
+        for (int j = 0; j < RPS; ++j) nxt[(s_ * NOUT + orow[j]) * 64 + lane] = kr[s_ % PK][j] & keep; \
+      } \
+    } \
+_Pragma("unroll") \
+    for (int o = 0; o < NO; ++o) \
+_Pragma("unroll") \
+      for (int c = 0; c < CW; ++c) acc[o][c] = (u64)(u32)(acc[o][c] >> 32) * r32 + (u32)acc[o][c]; \
+    __syncthreads(); \
+  } while (0)
+  if constexpr (TAIL == 0) {                                       // any column count: the last chunk is padded with zero key rows
+    const int nch = (ncol + KC - 1) / KC;
+    for (int ci = 0; ci < nch; ++ci) K4_CHUNK(KC, true, ci);
+  } else {                                                         // ncol = nfull KC + TAIL: the last TAIL columns run a body of their own (66 = 5 x 12 + 6: no padded step)
+    const int nfull = ncol / KC;
+    for (int ci = 0; ci < nfull; ++ci) K4_CHUNK(KC, true, ci);
+    K4_CHUNK((TAIL ? TAIL : KC), false, nfull);
   }
+#undef K4_CHUNK
   const u32 mont = pr.mont[a];
   const i64 soff = slice * 64;
 #pragma unroll
@@ -1265,12 +1272,12 @@ static int launch_dot32_p(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   HIP_TRY(hipGetLastError());
   return 0;
 }
-template <int NLBT, int CW, int KC, int PD, int NW = 8, int NSP = 1>
+template <int NLBT, int CW, int KC, int PD, int NW = 8, int NSP = 1, int TAIL = 0>
 static int launch_dot32_k4(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)2 * KC * 2 * NLBT * 64 * 4;
   static std::atomic<unsigned long long> attr_done{0};
   if (!(attr_done.load() >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel4<NLBT, CW, KC, PD, NW, NSP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel4<NLBT, CW, KC, PD, NW, NSP, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.fetch_or(1ull << ctx->device);
   }
   for (int a = 0; a < 4; ++a)
@@ -1282,8 +1289,8 @@ static int launch_dot32_k4(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig,
   if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");
   int sub_lg = 0;
   while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
-  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel4<NLBT, CW, KC, PD, NW, NSP>));
-  dot32_kernel4<NLBT, CW, KC, PD, NW, NSP><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, count, d_out, ctx->aux32->pr, ngroups, lognsl, sub_lg);
+  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel4<NLBT, CW, KC, PD, NW, NSP, TAIL>));
+  dot32_kernel4<NLBT, CW, KC, PD, NW, NSP, TAIL><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, count, d_out, ctx->aux32->pr, ngroups, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1302,6 +1309,9 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   // so the plain form stays; option dot32_small selects the others (A/B)
   // keys in LDS, digits in registers (dot32_kernel4): the limb counts of generated matrices at the benchmark rings
   if (ctx->opt.dot32_k4 && count >= 24 && !ctx->opt.dot32_small) {
+#ifndef K4_NO_TAIL
+    if (k->aux_rows == 7 && ncol % 12 == 6) return launch_dot32_k4<7, 6, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);      // (66 columns = 5 x 12 + 6: the tail compiled on its own)
+#endif
     if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)
     if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 3>(ctx, k, d_dig, ncol, count, d_out);
     // 15 limbs (the stress ring): the 30 outputs split over two wave groups (with all 30 in one lane only 3 ciphertexts fit: 81 ms per 1024 against 37.6 for dot32_kernel2p)
