@@ -1313,7 +1313,10 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
     if (k->aux_rows == 7 && ncol % 12 == 6) return launch_dot32_k4<7, 6, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);      // (66 columns = 5 x 12 + 6: the tail compiled on its own)
 #endif
     if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)
-    if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 3>(ctx, k, d_dig, ncol, count, d_out);
+#ifndef K4_NO_TAIL
+    if (k->aux_rows == 8 && ncol % 12 == 6) return launch_dot32_k4<8, 4, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);
+#endif
+    if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (5 ciphertexts per lane: 160 bytes of spills -- odd counts leave the 64-bit pairs badly placed)
     // 15 limbs (the stress ring): the 30 outputs split over two wave groups (with all 30 in one lane only 3 ciphertexts fit: 81 ms per 1024 against 37.6 for dot32_kernel2p)
     if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1) return launch_dot32_k4<15, K4S_CW, 8, K4S_PD, 8, 2>(ctx, k, d_dig, ncol, count, d_out);
   }
