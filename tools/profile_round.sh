@@ -28,7 +28,7 @@ for c in FETCH_SIZE WRITE_SIZE; do        # one counter per pass (combining them
 done
 F=$(find "$O/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 W=$(find "$O/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "dot32_kernel4<7, 6, 12, 3, 8, 1>" "$O/pmc_dot_aux.json" ciphertexts_per_launch=1024
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "dot32_kernel4<7, 6, 12, 3, 8, 1, 6>" "$O/pmc_dot_aux.json" ciphertexts_per_launch=1024
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true, 0, false, Aux32Primes, true, true>" "$O/pmc_ntt_fwd.json" rows_per_launch=270336
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<false, 0, false, T32Primes, true, false>" "$O/pmc_t32_fwd.json" rows_per_launch=143360
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<false, true, T32Primes>" "$O/pmc_t32_inv.json" rows_per_launch=107520
