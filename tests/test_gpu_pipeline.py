@@ -459,6 +459,30 @@ def test_host_buffer_pipeline_equals_the_device_batch(count, host_chunk):
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, big, np.concatenate([b, b])), np.concatenate([want, want]))
 
 
+@pytest.mark.parametrize("m,logQ,p", [(32768, 512, 23), (1 << 16, 300, 65537), (32602, 128, 32603)])
+def test_round5_layout_switches_change_no_bit(m, logQ, p):
+    """The A/B switches of round 5 select layouts, never values: XCD groups of one polynomial's digits (digit_group = -1, and groups of 4), the
+    scaled-down parts as 64-bit limb rows instead of 32-bit word rows (parts_words = 0), the digit-tile dot product (dot32_k4 = 0) and the
+    stress ring's tiles of 4 ciphertexts (dot32_parts = 0) -- every combination gives the bits of the default, on rows of 2^14, of 2^15 and
+    on padded rows of a linear-convolution ring; 33 ciphertexts (groups past the end, a ragged last tile)."""
+    count = 33
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 606 + m, count)
+    n = ctx.phim
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(a.nbytes)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    want = dout.download((count, 2, n, nl))
+    if m == 32768:
+        assert np.array_equal(want[32], orc.ct_mul_relin(ksm, a[32], b[32], logQ, p))
+    for opts in ({"digit_group": -1}, {"digit_group": 4}, {"parts_words": 0}, {"dot32_k4": 0, "dot32_parts": 0}, {"digit_group": -1, "parts_words": 0, "dot32_k4": 0}):
+        for k_, v_ in opts.items():
+            ctx.set_option(k_, v_)
+        ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+        assert np.array_equal(dout.download((count, 2, n, nl)), want), opts
+        for k_ in opts:
+            ctx.set_option(k_, 1)
+
+
 def test_host_buffer_entry_rejects_device_memory_and_releases_its_ring():
     """The host-buffer entry copies with CPU threads: a device pointer must be refused with an error (not dereferenced); a pinned array may
     outlive its Context (fhesi_host_free does not touch the context); fhesi_host_stage_release hands the staging ring back and the next
