@@ -966,10 +966,25 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
   u32 cur[4] = {0, 0, 0, 0}, nxt[4] = {0, 0, 0, 0};
   u32 vin[FIX ? NLBF : 1][4];
   if constexpr (FIX) {
+    if (!S) {
 #pragma unroll
-    for (int l = 0; l < NLBF; ++l)
+      for (int l = 0; l < NLBF; ++l)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) vin[l][a] = __builtin_nontemporal_load(&base32[(i64)(l * 4 + a) * nrow + j]);
+        for (int a = 0; a < 4; ++a) vin[l][a] = __builtin_nontemporal_load(&base32[(i64)(l * 4 + a) * nrow + j]);
+    } else {
+      // power-of-two rows of 2^15 left as their two sub-inverses (the stress ring): the tail stage in the loader -- coefficient e of the lower
+      // half is (A_e + B_e) / 2, of the upper half (A_e - B_e) psi^-brv(1) / 2
+      const i64 e = j & ((i64)(1 << 14) - 1);
+      const int up = (int)(j >> 14);                   // (uniform per workgroup)
+#pragma unroll
+      for (int l = 0; l < NLBF; ++l)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const u32* __restrict__ row = base32 + (i64)(l * 4 + a) * nrow;
+          const u32 p = gc.p[a], Av = __builtin_nontemporal_load(&row[e]), Bv = __builtin_nontemporal_load(&row[e + (1 << 14)]);
+          vin[l][a] = g32_mul(up ? Av + p - Bv : Av + Bv, gc.tw[a][up], gc.twp[a][up], p);
+        }
+    }
   }
   constexpr int NT = FS == 1 ? 4 : 3;
   u32 eb[NT];
@@ -1151,7 +1166,9 @@ static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const
   const i64 nrow = aux32_row_len(ctx);
   const i64 fold = k->aux_fold;
   dim3 grid((unsigned)((ctx->phim + 127) / 128), (unsigned)npolys);
-  if (NW == 8 && LQ == 512 && B == 74 && NLB == 7 && !fold && !S)      // the metric ring with a generated matrix
+  if (NW == 16 && LQ == 1024 && B == 72 && NLB == 15 && !fold)         // the stress ring with a generated matrix (rows of 2^15: the tail stage in the loader when S)
+    ks_recombine_centred_kernel<16, 15, 72, 1024><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  else if (NW == 8 && LQ == 512 && B == 74 && NLB == 7 && !fold && !S)      // the metric ring with a generated matrix
     ks_recombine_centred_kernel<8, 7, 74, 512><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   else if (S && fold && NW == 8 && fold > 0) ks_recombine_centred_kernel<8, 0, 0, 0, 1><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   else if (S && fold && NW == 8) ks_recombine_centred_kernel<8, 0, 0, 0, 2><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
