@@ -45,16 +45,15 @@ def device_identity(torch, index: int) -> dict:
     per process, index 0 is a different GPU in every rank -- or the same one in all of them.)"""
     import socket
     props = torch.cuda.get_device_properties(index)
-    ident = None
+    parts = []
     u = getattr(props, "uuid", None)
     if u is not None and str(u).strip("0-") != "":
-        ident = "uuid:" + str(u)
-    if ident is None:
-        pci = [getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
-        if any(v is not None for v in pci):
-            ident = "pci:" + ":".join("?" if v is None else f"{int(v):x}" for v in pci)
-    if ident is None:
-        ident = f"index:{index}"              # (nothing better: distinct only within one process's view)
+        parts.append("uuid:" + str(u))
+    pci = [getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if any(v is not None for v in pci):
+        parts.append("pci:" + ":".join("?" if v is None else f"{int(v):x}" for v in pci))
+    # (both where the runtime reports both: two GPUs differ in at least one, one GPU agrees with itself in both)
+    ident = "|".join(parts) if parts else f"index:{index}"      # (index: nothing better -- distinct only within one process's view)
     return {"host": socket.gethostname(), "device_index": int(index), "id": ident, "name": getattr(props, "name", None),
             "visible": __import__("os").environ.get("HIP_VISIBLE_DEVICES") or __import__("os").environ.get("CUDA_VISIBLE_DEVICES")}
 
