@@ -267,6 +267,40 @@ def test_refring_generated_keys_eight_limbs():
     assert np.array_equal(got[24], orc.ct_mul_relin(ksk.download(), a[24], b[24], logQ, p))
 
 
+@pytest.mark.parametrize("logQ,limbs", [(480, 7), (536, 8)])
+def test_dot32_kernel4_on_column_counts_without_a_compiled_tail(logQ, limbs):
+    """dot32_kernel4 at column counts other than 66: logQ = 480 gives 60 columns (five whole chunks of 12), logQ = 536 gives 69 (five chunks + one
+    padded with zero key rows: the branch-free body multiplies clamped digit loads by zeros) and 8 limbs.  Generated key matrix, a ragged batch of
+    26; against the digit-tile form (option dot32_k4 = 0) bit for bit and one ciphertext against the oracle."""
+    m, p, count = 1 << 15, 23, 26
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    one = np.zeros((n, 1), dtype=np.uint64)
+    one[0, 0] = 1
+    t = F.DoubleCRT(ctx).sample(0, 64, 91, 1)
+    t2 = t.copy()
+    t2.op(t, 2)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([F.DoubleCRT.from_poly(ctx, one), t, t2], t, logQ, 91, 92, 3000, 3)
+    rng = np.random.default_rng(logQ)
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(a.nbytes)
+    ctx.prof_enable(True)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    ctx.sync()
+    assert ksk.form()[1] == limbs and ksk.key_bits()[0], (ksk.form(), ksk.key_bits())
+    assert f"dot32_kernel4<{limbs}," in ctx.prof_kernel_name("dot") and ctx.prof_kernel_name("dot").endswith(", 0>"), ctx.prof_kernel_name("dot")
+    ctx.prof_enable(False)
+    got = dout.download((count, 2, n, nl))
+    ctx.set_option("dot32_k4", 0)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    assert np.array_equal(dout.download((count, 2, n, nl)), got)
+    ctx.set_option("dot32_k4", 1)
+    assert np.array_equal(got[25], orc.ct_mul_relin(ksk.download(), a[25], b[25], logQ, p))
+
+
 def test_config2_with_a_chain_of_50_bit_primes():
     """configs[2] as the reference's era would have built it: FHEContext.cpp:92 starts the chain at 2^NTL_SP_NBITS, 50 in NTL 5.x / 6.x,
     which gives 22 primes instead of 18.  Multiplication + relinearisation against the oracle on the first, the last and
