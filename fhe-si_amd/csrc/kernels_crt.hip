@@ -1170,6 +1170,9 @@ static int launch_ks_recombine_centred(fhesi_ctx* ctx, const fhesi_ksk* k, const
     ks_recombine_centred_kernel<16, 15, 72, 1024><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   else if (NW == 8 && LQ == 512 && B == 74 && NLB == 7 && !fold && !S)      // the metric ring with a generated matrix
     ks_recombine_centred_kernel<8, 7, 74, 512><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
+  // (a compile-time instantiation <8, 8, 72, 512, FS = 1> for the reference drivers' ring at the metric's size, its residues fetched up front through the
+  // run-time loader, was measured: 106 registers, 256 loads before the first Garner step -- crt class 8.7 -> 10.9 ms per step there, and the same
+  // loader in front of the stress instantiation cost it 22.7 -> 26.8: the folds keep the run-time form, the compile-time forms their own loaders)
   else if (S && fold && NW == 8 && fold > 0) ks_recombine_centred_kernel<8, 0, 0, 0, 1><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   else if (S && fold && NW == 8) ks_recombine_centred_kernel<8, 0, 0, 0, 2><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
   else if (S && fold && fold > 0) ks_recombine_centred_kernel<16, 0, 0, 0, 1><<<grid, 128, 0, ctx->stream>>>((const u32*)d_o, ctx->phim, nrow, fold, S, LQ, B, NLB, (u64)(half >> 64), (u64)half, (u64)(A >> 64), (u64)A, cc, d_out, nl_out, gc);
