@@ -173,13 +173,17 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
     int k = 64 - __builtin_clzll(Q);
     pc.bar_k = (u32)k;
     pc.bar_mu = (u64)((((u128)1) << (2 * k)) / Q);
-    pc.pad0 = 0;
     pc.r64 = (u64)(((u128)1 << 64) % Q);
     pc.r64_sh = hm::shoup(pc.r64, Q);
     pc.one_sh = hm::shoup(1, Q);
     // modulus of the tile kernels: q itself, or for small primes the largest multiple of q below 2^60 (ntt_tile.inc)
     pc.q_tile = Q >= (1ull << 48) ? Q : Q * (((1ull << 60) - 1) / Q);
     pc.one_q63 = hm::shoup63(1, pc.q_tile);
+    {
+      const u64 qh = pc.q_tile >> 32;                  // >= 2^16
+      const int b = 64 - __builtin_clzll(qh);
+      pc.norm_m = (u32)((((u128)1) << (31 + b)) / (qh + 1));   // in [2^31, 2^32): qh + 1 lies in (2^(b-1), 2^b]
+    }
     if (Q < (1ull << 48)) c->has_small_prime = true; else c->n_big_primes++;
     pc.ninv = pc.ninv_sh = pc.ninv_w = pc.ninv_w_sh = 0;
   }

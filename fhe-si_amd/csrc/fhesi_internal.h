@@ -28,7 +28,7 @@ struct PrimeConst {
   u64 two_q;
   u64 bar_mu;       // Barrett: floor(2^(2k)/q), k = bit length of q
   u32 bar_k;        // bit length of q
-  u32 pad0;
+  u32 norm_m;       // floor(2^(31+b) / ((q_tile >> 32) + 1)), b = bit length of q_tile >> 32: quotient estimate of the tile kernels' store (modarith63.h)
   u64 one_sh;       // floor(2^64/q): Shoup quotient of the constant 1 (reduces any 64-bit word)
   u64 ninv, ninv_sh;        // phi(m)^-1 mod q and its Shoup quotient (power-of-two m: the /m of CModulus.cpp:125 folded with X^n=-1)
   u64 ninv_w, ninv_w_sh;    // ninv * psi^-brv(1) (last inverse stage twiddle folded with the scaling)

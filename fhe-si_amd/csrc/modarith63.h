@@ -170,6 +170,63 @@ __device__ __forceinline__ u64 csub63(u64 v, u64 c) {                 // v < 2^6
   asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mask) : "v"((u32)(d >> 32)));
   return d + (((u64)(mask & (u32)(c >> 32)) << 32) | (mask & (u32)c));
 }
+// Forward store, two residues per block.  v < 4q + 2^32 < 5q: the quotient k = floor(v / q) <= 4 is estimated from the high word,
+//   e = hi32(v.hi * M + 2^(31+b)) >> (b - 1) = floor(v.hi * M / 2^(31+b)) + 1,   M = floor(2^(31+b) / (q.hi + 1))   (PrimeConst::norm_m),
+// an under-estimate of v / q by less than 5 / q.hi + 2^-29 (q.hi >= 2^16), plus one: e is k or k + 1, so r = v - e q lies in [-q, q) and the
+// sign of its high word says whether to add q back.  9 instructions per residue where three csub63 steps took 24 (they were all of
+// the 3.4 instructions per butterfly that the forward kernel issued above its 24-instruction butterflies).
+struct Norm63 { u32 m, sh; u64 c; };      // M, b - 1, 2^(31+b)
+__device__ __forceinline__ Norm63 make_norm63(u64 q, u32 norm_m) {
+  const u32 b = 32u - (u32)__builtin_clz((u32)(q >> 32));
+  return Norm63{norm_m, b - 1, 1ull << (31 + b)};
+}
+__device__ __forceinline__ void norm_fwd63_x2(u64& Va, u64& Vb, const Mod63& m, const Norm63& nm) {
+  u64 cy, oa, ob;
+  asm("v_mad_u64_u32 v[104:105], %[cy], %[va1], %[M], %[C]\n\t"
+      "v_mad_u64_u32 v[116:117], %[cy], %[vb1], %[M], %[C]\n\t"
+      "v_lshrrev_b32 v106, %[sh], v105\n\t"
+      "v_lshrrev_b32 v118, %[sh], v117\n\t"
+      "v_mad_u64_u32 v[108:109], %[cy], v106, %[nq0], %[va]\n\t"
+      "v_mul_lo_u32 v107, v106, %[nq1]\n\t"
+      "v_mad_u64_u32 v[120:121], %[cy], v118, %[nq0], %[vb]\n\t"
+      "v_mul_lo_u32 v119, v118, %[nq1]\n\t"
+      "v_add_u32 v109, v109, v107\n\t"
+      "v_add_u32 v121, v121, v119\n\t"
+      "v_ashrrev_i32 v106, 31, v109\n\t"
+      "v_ashrrev_i32 v118, 31, v121\n\t"
+      "v_and_b32 v104, %[q0], v106\n\t"
+      "v_and_b32 v105, %[q1], v106\n\t"
+      "v_and_b32 v116, %[q0], v118\n\t"
+      "v_and_b32 v117, %[q1], v118\n\t"
+      "v_lshl_add_u64 %[oa], v[104:105], 0, v[108:109]\n\t"
+      "v_lshl_add_u64 %[ob], v[116:117], 0, v[120:121]\n\t"
+      : [oa] "=&v"(oa), [ob] "=&v"(ob), [cy] "=&s"(cy)
+      : [va] "v"(Va), [vb] "v"(Vb), [va1] "v"((u32)(Va >> 32)), [vb1] "v"((u32)(Vb >> 32)), [M] "v"(nm.m), [C] "s"(nm.c), [sh] "s"(nm.sh),
+        [nq0] "s"(m.nq0), [nq1] "s"(m.nq1), [q0] "s"((u32)m.q), [q1] "s"((u32)(m.q >> 32))
+      : "v104", "v105", "v106", "v107", "v108", "v109", "v116", "v117", "v118", "v119", "v120", "v121");
+  Va = oa;
+  Vb = ob;
+}
+// v < 2q -> [0,q), two residues per block (outputs of mulmod63): 5 instructions each
+__device__ __forceinline__ void norm_inv63_x2(u64& Va, u64& Vb, const Mod63& m) {
+  u64 oa, ob;
+  const u64 nq = ((u64)m.nq1 << 32) | m.nq0;
+  asm("v_lshl_add_u64 v[104:105], %[va], 0, %[nq]\n\t"
+      "v_lshl_add_u64 v[116:117], %[vb], 0, %[nq]\n\t"
+      "v_ashrrev_i32 v106, 31, v105\n\t"
+      "v_ashrrev_i32 v118, 31, v117\n\t"
+      "v_and_b32 v108, %[q0], v106\n\t"
+      "v_and_b32 v109, %[q1], v106\n\t"
+      "v_and_b32 v120, %[q0], v118\n\t"
+      "v_and_b32 v121, %[q1], v118\n\t"
+      "v_lshl_add_u64 %[oa], v[108:109], 0, v[104:105]\n\t"
+      "v_lshl_add_u64 %[ob], v[120:121], 0, v[116:117]\n\t"
+      : [oa] "=&v"(oa), [ob] "=&v"(ob)
+      : [va] "v"(Va), [vb] "v"(Vb), [nq] "s"(nq), [q0] "s"((u32)m.q), [q1] "s"((u32)(m.q >> 32))
+      : "v104", "v105", "v106", "v108", "v109", "v116", "v117", "v118", "v120", "v121");
+  Va = oa;
+  Vb = ob;
+}
 __device__ __forceinline__ u64 norm_fwd63(u64 v, const Mod63& m) {   // v < 4q + 2^32  ->  [0,q)
   v = csub63(v, m.twoq);
   v = csub63(v, m.q);
