@@ -1,3 +1,6 @@
+#!/bin/bash
+# The `stress` and `ntt` lines of tools/profile_round.sh alone (run ON THE GPU BOX through gpurun): kernel-trace statistics of the two workloads whose
+# kernels changed after the last full profile round; results in gpurun_out/prof_r05d/, copied into profiles/r05_d_* by hand.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_r05d
