@@ -45,6 +45,35 @@ def test_rows_fwd_inv_vs_oracle(logn):
         assert np.array_equal(got2[0, i], orc.cmod_ifft(i, ev[0, i])), (logn, i)
 
 
+@pytest.mark.parametrize("logn", [11, 13, 14])
+@pytest.mark.parametrize("bits", [49, 50, 53, 57, 59, 60])
+def test_tile_rows_across_prime_sizes(logn, bits):
+    """The tile kernels' store reduces a lazy value below 4q + 2^32 with a quotient ESTIMATE taken from the high word (norm_fwd63_x2,
+    modarith63.h; the constant depends on the bit length of q >> 32): every size of chain prime the kernels take as it is (2^48 <= q < 2^60),
+    on rows of extreme residues, against the oracle (CModulus.cpp:90-132)."""
+    n = 1 << logn
+    m = 2 * n
+    primes, roots = P.first_primes(m, 3, sp_nbits=bits)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    rng = np.random.default_rng(1000 * logn + bits)
+    count = 4
+    rows = P.rand_rows(rng, primes, n, count)
+    for i, q in enumerate(primes):
+        rows[1, i, :] = np.uint64(q - 1)                                  # every residue at the top of its range
+        rows[2, i, 0::2] = np.uint64(q - 1); rows[2, i, 1::2] = 0         # alternating extremes
+        rows[3, i, :] = 0; rows[3, i, n - 1] = np.uint64(q - 1)           # one coefficient
+    buf = ctx.upload(rows)
+    ctx.rows_ntt_fwd(buf, count)
+    got = buf.download(rows.shape)
+    for c in range(count):
+        for i in range(len(primes)):
+            assert np.array_equal(got[c, i], orc.fft_residues(i, rows[c, i])), (logn, bits, c, i)
+    assert int(got.max()) < max(primes)
+    ctx.rows_ntt_inv(buf, count)
+    assert np.array_equal(buf.download(rows.shape), rows)
+
+
 def test_cmod_fft_single_row_bigint():
     m = 64
     primes, roots = P.chain_for(m, 100, 23)
