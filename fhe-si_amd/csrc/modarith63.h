@@ -227,11 +227,3 @@ __device__ __forceinline__ void norm_inv63_x2(u64& Va, u64& Vb, const Mod63& m) 
   Va = oa;
   Vb = ob;
 }
-__device__ __forceinline__ u64 norm_fwd63(u64 v, const Mod63& m) {   // v < 4q + 2^32  ->  [0,q)
-  v = csub63(v, m.twoq);
-  v = csub63(v, m.q);
-  return csub63(v, m.q);
-}
-__device__ __forceinline__ u64 norm_inv63(u64 v, const Mod63& m) {   // v < 2q  ->  [0,q)   (outputs of mulmod63)
-  return csub63(v, m.q);
-}
