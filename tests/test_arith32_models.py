@@ -1,0 +1,178 @@
+"""CPU: integer models of the 32-bit kernels' lazy arithmetic, step for step with wrap-around, on worst-case and random operands.
+
+The kernels keep values in ranges that are argued in their comments (below 4p, below 2^61, "at most 2 below the quotient", no 64-bit
+overflow of a multiply-add chain).  These models follow the instruction sequences of
+  * rns32_one            (kernels_tensor32.hip: big integer -> residue below 3p, one v_mad_u64_u32 chain with folds through 2^32 mod p),
+  * the tensor loader's red()  (ntt32_core.inc, ntt32_inv_kernel3<.., TENSOR>: a product or a sum of two products -> [0, 2p)),
+  * a32_ct<NEGW> / a32_gs (ntt32_core.inc: the forward / inverse butterflies on lazy values),
+  * mul_lazy32            (ntt32_core.inc),
+with the table entries as the host builders compute them, and check every intermediate bound the comments state plus the congruence of
+the result.  What the GPU computes is checked against the oracle in the `-m gpu` tests; this file checks that the RANGES hold for operands the
+random GPU inputs may never hit (all-ones words, p - 1 everywhere, the most negative coefficient)."""
+import random
+
+import pytest
+
+import params as P
+import fhesi_pyref as R
+
+M32 = (1 << 32) - 1
+M64 = (1 << 64) - 1
+
+
+def primes_below_2_30(count, step):
+    """the tensor half's rule (t32_plan): the largest primes below 2^30 that are 1 mod `step`"""
+    out = []
+    p = (1 << 30) - ((1 << 30) % step) + 1
+    while len(out) < count:
+        p -= step
+        if R.is_prime(p):
+            out.append(p)
+    return out
+
+
+def mid_primes(count, step, start):
+    out = []
+    p = start - (start % step) + 1
+    while len(out) < count:
+        p -= step
+        if R.is_prime(p):
+            out.append(p)
+    return out
+
+
+TENSOR_PRIMES = primes_below_2_30(70, 1 << 16)[::9] + primes_below_2_30(35, 1 << 15)[-2:]
+GENERIC_PRIMES = mid_primes(2, 1 << 15, (1 << 30) - (1 << 28)) + mid_primes(2, 1 << 15, (1 << 29) + (1 << 27)) + mid_primes(1, 1 << 15, 1 << 29)
+
+
+# ---------------------------------------------------------------------------------------------- rns32_one
+def rns_table(p, lift, nl):
+    b32 = (1 << 32) % p
+    t, cur = [], lift % p
+    for _ in range(2 * nl):
+        t.append(cur)
+        cur = cur * b32 % p
+    return t, (p - cur) % p, b32, (1 << 61) // p
+
+
+def rns32_one(x, neg, t, tneg, r32, mu, p):
+    acc, room = 0, 4
+
+    def fold(a):
+        v = (a >> 32) * r32 + (a & M32)
+        assert v <= M64
+        return v
+    for k in range(len(x)):
+        if room == 0:
+            acc = fold(acc)
+            room = 3
+        acc = x[k] * t[k] + acc
+        assert acc <= M64, "the multiply-add chain overflowed 64 bits"
+        room -= 1
+    acc = neg * tneg + acc
+    assert acc <= M64
+    acc = fold(acc)
+    if r32 >= (1 << 28):
+        acc = fold(acc)
+    assert acc < (1 << 61), "the Barrett step takes a value below 2^61"
+    q = (((acc >> 29) & M32) * mu) >> 32
+    assert (acc >> 29) <= M32
+    r = ((acc & M32) - q * p) & M32
+    assert acc // p - 2 <= q <= acc // p
+    return r
+
+
+@pytest.mark.parametrize("nl", [8, 16])
+@pytest.mark.parametrize("p", TENSOR_PRIMES + GENERIC_PRIMES)
+def test_rns32_chain_never_overflows_and_stays_below_3p(nl, p):
+    rng = random.Random(p * 31 + nl)
+    for lift in (1, 23, 65537, 32603, (1 << 20) - 3):
+        t, tneg, r32, mu = rns_table(p, lift, nl)
+        cases = [[M32] * (2 * nl), [0] * (2 * nl), [M32] * (2 * nl - 1) + [0x7FFFFFFF], [0] * (2 * nl - 1) + [0x80000000], [1] + [0] * (2 * nl - 1),
+                 [M32] * (2 * nl - 1) + [0x80000000]]
+        cases += [[rng.getrandbits(32) for _ in range(2 * nl)] for _ in range(300)]
+        for x in cases:
+            neg = x[-1] >> 31
+            r = rns32_one(x, neg, t, tneg, r32, mu, p)
+            val = sum(w << (32 * k) for k, w in enumerate(x)) - (neg << (64 * nl))
+            assert r < 3 * p and r % p == (val * lift) % p, (p, lift, x[-1])
+
+
+# ---------------------------------------------------------------------------------------------- tensor loader
+def red61(x, p, mu):
+    assert x < (1 << 61)
+    q = (((x >> 29) & M32) * mu) >> 32
+    r = ((x & M32) - q * p) & M32
+    assert r < 3 * p
+    return r - 2 * p if r >= 2 * p else r
+
+
+@pytest.mark.parametrize("p", TENSOR_PRIMES + GENERIC_PRIMES)
+def test_tensor_loader_reduction(p):
+    rng = random.Random(p)
+    mu = (1 << 61) // p
+    ext = [0, 1, p - 1, p - 2, p // 2]
+    pairs = [(a, b) for a in ext for b in ext] + [(rng.randrange(p), rng.randrange(p)) for _ in range(2000)]
+    for a, b in pairs:
+        r = red61(a * b, p, mu)
+        assert r < 2 * p and r % p == a * b % p
+    quads = [(p - 1,) * 4, (p - 1, p - 1, 0, 0), (p - 1, p - 2, p - 2, p - 1)] + [tuple(rng.randrange(p) for _ in range(4)) for _ in range(2000)]
+    for a0, b1, a1, b0 in quads:
+        x = a0 * b1 + a1 * b0
+        r = red61(x, p, mu)
+        assert r < 2 * p and r % p == x % p
+
+
+# ---------------------------------------------------------------------------------------------- butterflies
+def tw(w, p):
+    return w, (w << 32) // p
+
+
+def mul_lazy32(y, w, wp, p):
+    return (y * w - ((y * wp) >> 32) * p) & M32
+
+
+def a32_ct_negw(x, y, w, p):
+    """forward butterfly, table entry (-w mod 2^32, floor(w 2^32 / p)): inputs below 4p -> outputs below 4p"""
+    wneg, wp = (-w) & M32, (w << 32) // p
+    twop = 2 * p
+    X = min(x, (x - twop) & M32)
+    Q = (y * wp) >> 32
+    nT = (Q * p + y * wneg) & M32                     # -T mod 2^32, T in [0, 2p)
+    T = (-nT) & M32
+    assert T < twop and T % p == y * w % p
+    return (X - nT) & M32, (X + nT + twop) & M32
+
+
+def a32_gs(x, y, w, p):
+    """inverse butterfly (A32_GS7): inputs below 2p -> sum below 2p, product below 2p"""
+    wv, wp = tw(w, p)
+    twop = 2 * p
+    s, d = (x + y) & M32, (x - y + twop) & M32
+    xo = min(s, (s - twop) & M32)
+    Q = (d * wp) >> 32
+    yo = (Q * ((-p) & M32) + d * wv) & M32
+    return xo, yo
+
+
+@pytest.mark.parametrize("p", TENSOR_PRIMES[:4] + GENERIC_PRIMES[:2])
+def test_butterflies_keep_their_ranges(p):
+    rng = random.Random(p + 7)
+    ws = [1, p - 1, 2, p // 2, rng.randrange(1, p), rng.randrange(1, p)]
+    lazy = [0, 1, p - 1, p, 2 * p - 1, 2 * p, 3 * p, 4 * p - 1]
+    for w in ws:
+        for x in lazy + [rng.randrange(4 * p) for _ in range(200)]:
+            for y in lazy + [rng.randrange(4 * p) for _ in range(20)]:
+                xo, yo = a32_ct_negw(x, y, w, p)
+                assert xo < 4 * p and yo < 4 * p
+                assert xo % p == (x + w * y) % p and yo % p == (x - w * y) % p
+        small = [v for v in lazy if v < 2 * p]
+        for x in small + [rng.randrange(2 * p) for _ in range(200)]:
+            for y in small + [rng.randrange(2 * p) for _ in range(20)]:
+                xo, yo = a32_gs(x, y, w, p)
+                assert xo < 2 * p and yo < 2 * p
+                assert xo % p == (x + y) % p and yo % p == (x - y) * w % p
+        for y in [0, 1, p, M32, M32 - 1, 1 << 31] + [rng.getrandbits(32) for _ in range(500)]:      # any 32-bit value -> [0, 2p)
+            wv, wp = tw(w, p)
+            r = mul_lazy32(y, wv, wp, p)
+            assert r < 2 * p and r % p == y * w % p
