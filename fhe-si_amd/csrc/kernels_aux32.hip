@@ -666,7 +666,9 @@ dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int nco
 //  * the written order is the schedule (sched_barrier between the phases of a step): left alone hipcc hoists the reads of later steps to the
 //    top of the 4000-instruction block and spills the accumulators.
 // Accumulation: products of a reduced digit (below p) and a key word (below p) are below 2^60; a total is folded once per chunk as
-// (hi 2^32 + lo) -> hi (2^32 mod p) + lo < 2^57 (2^32 mod p is below 2^24), and KC <= 12 more products keep it below 2^64.  The epilogue is
+// (hi 2^32 + lo) -> hi (2^32 mod p) + lo < 2^58 + 2^32 (2^32 mod p = 2^32 - 4p is below 2^26 for every prime launch_dot32_k4 admits -- below 2^24 on
+// rows of 2^14 and 2^15, 2^24.4 for the fourth prime on rows of 2^16), and KC <= 12 more products keep it below 2^58 + 12 2^60 < 2^64
+// (tests/test_arith32_models.py follows the chain on worst-case operands).  The epilogue is
 // dot32_kernel2's Montgomery step (outputs carry the factor 2^-32, undone by the inverse transform).
 // Workgroup = 8 waves = 8 CW ciphertexts of one 64-coefficient slice of one prime; grid as dot32_kernel2 (x = slice low bits + 8 * group,
 // y = slice high bits, z = prime): the groups of a (slice, prime) sit on one XCD and share its key block in L2.
@@ -692,7 +694,7 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   const int a = (int)blockIdx.z;
   const i64 slice = (i64)(s_hi * 8 + s_lo);
   const u32 p = pr.p[a], twop = 2 * p;
-  const u32 r32 = 0u - 4u * p;                                    // 2^32 mod p for p in (2^32 / 5, 2^30): below 2^24 for every prime the launcher admits
+  const u32 r32 = 0u - 4u * p;                                    // 2^32 mod p for p in (2^32 / 5, 2^30): below 2^26 for every prime the launcher admits
   const int osel = w % NSP, o_base = osel * NO;                     // this wave's block of outputs
   const i64 ct0 = (i64)g * (NW / NSP * CW) + (i64)(w / NSP) * CW;
   // the CW digit streams of this wave: scalar bases (the tiled digit rows [sub-chunk][prime][slice][ciphertext * ncol + column][64])
@@ -747,7 +749,7 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   // of spills.)  Per step: [write the key rows fetched two steps ago to LDS -- masked HERE, not next to their load, where the mask made every
   // step wait an L2 round trip] [fetch the next chunk's rows of this step's column] [reduce the digit words of this column, fetch column + PD
   // into their ring slot] [read key half B from LDS] | multiply-adds of half A | [read the next step's half A] | multiply-adds of half B;
-  // then the rows still on their way, the fold hi (2^32 mod p) + lo (below 2^57) and the barrier.
+  // then the rows still on their way, the fold hi (2^32 mod p) + lo (below 2^58 + 2^32) and the barrier.
 #define K4_CHUNK(NS, FETCH, ci) do { \
     const u32* __restrict__ cur = kl + (ci & 1) * (ROWS * 64); \
     u32* __restrict__ nxt = kl + ((ci & 1) ^ 1) * (ROWS * 64); \
@@ -831,9 +833,9 @@ _Pragma("unroll") \
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       if (live[c]) {
-        const u64 v = acc[oo][c];                         // below 2^57
+        const u64 v = acc[oo][c];                         // below 2^58 + 2^32
         const u32 mq = (u32)v * mont;
-        u32 ov = (u32)((v + (u64)mq * p) >> 32);          // v 2^-32 mod p, below p + 2^25
+        u32 ov = (u32)((v + (u64)mq * p) >> 32);          // v 2^-32 mod p, below p + 2^26 + 1
         ov = min(ov, ov - p);
         __builtin_nontemporal_store(ov, obase + (((i64)((ct0 + c) * 2 + (o & 1)) * NLBT * 4) << (lognsl + 6)));
       }
