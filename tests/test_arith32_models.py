@@ -214,3 +214,58 @@ def test_dot32_kernel4_totals(step, ncol):
             for KC in (8, 12):
                 o = dot4_model(digs, keys, p, KC)
                 assert o < p and o == sum(d * k for d, k in zip(digs, keys)) * rinv % p
+
+
+# ---------------------------------------------------------------------------------------------- dot32_kernel2 / dot32_kernel2p
+def dot2_model(digs, keys, p, ncp):
+    """one output of dot32_kernel2p (column parts of ncp columns; dot32_kernel2 = one part): 64-bit totals of products below p^2, folded into
+    48-bit units (the high part counted in a 32-bit word) every 16 columns, r48 = 2^48 mod p and one Montgomery step at the end"""
+    r48 = (1 << 48) % p
+    mont = (-pow(p, -1, 1 << 32)) & M32
+    tot, th = 0, 0
+
+    def add(k0, n):
+        nonlocal tot
+        for k in range(k0, k0 + n):
+            assert digs[k] < p and keys[k] < p               # (the tile loader reduces the lazy digit words before they enter LDS)
+            tot += digs[k] * keys[k]
+            assert tot <= M64, "sixteen products on top of a folded total overflowed 64 bits"
+
+    def fold():
+        nonlocal tot, th
+        th += tot >> 48
+        tot &= (1 << 48) - 1
+        assert th <= M32
+    CH = 4
+    for kbeg in range(0, len(digs), ncp):
+        nc = min(ncp, len(digs) - kbeg)
+        nfull, n2 = nc & ~(CH - 1), nc & ~(2 * CH - 1)
+        for i in range(n2 // (2 * CH)):
+            add(kbeg + i * 2 * CH, 2 * CH)
+            if i & 1:
+                fold()
+        if nfull & CH:
+            add(kbeg + n2, CH)
+        if nfull & (3 * CH):
+            fold()
+        add(kbeg + nfull, nc - nfull)
+        fold()
+    v = tot + th * r48
+    assert v < (1 << 62)
+    mq = ((v & M32) * mont) & M32
+    o = (v + mq * p) >> 32
+    assert o < 2 * p
+    return min(o, (o - p) & M32)
+
+
+@pytest.mark.parametrize("ncol,ncp", [(66, 66), (129, 72), (24, 24), (17, 17), (43, 24), (258, 136)])
+def test_dot32_kernel2_totals(ncol, ncp):
+    rng = random.Random(ncol * 7 + ncp)
+    for step in (1 << 15, 1 << 17):
+        for p in primes_below_2_30(4, step):
+            rinv = pow(1 << 32, -1, p)
+            cases = [([p - 1] * ncol, [p - 1] * ncol), ([0] * ncol, [p - 1] * ncol)]
+            cases += [([rng.randrange(p) for _ in range(ncol)], [rng.randrange(p) for _ in range(ncol)]) for _ in range(100)]
+            for digs, keys in cases:
+                o = dot2_model(digs, keys, p, ncp)
+                assert o < p and o == sum(d * k for d, k in zip(digs, keys)) * rinv % p
