@@ -1310,7 +1310,9 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   // 7.4-7.8: with half the multiply-adds gone the kernel runs at the rate the L2 delivers the key words (80 GB per launch through L2 -> L1),
   // so the plain form stays; option dot32_small selects the others (A/B)
   // keys in LDS, digits in registers (dot32_kernel4): the limb counts of generated matrices at the benchmark rings
-  if (ctx->opt.dot32_k4 && count >= 24 && !ctx->opt.dot32_small) {
+  bool k4_primes = true;                    // dot32_kernel4 folds through 2^32 mod p = 2^32 - 4p and needs it below 2^26 (true of every prime aux32_init picks; any other ring takes the LDS-tile kernels)
+  for (int a = 0; a < 4; ++a) k4_primes = k4_primes && ctx->aux32->pr.p[a] < (1u << 30) && (u32)(0u - 4u * ctx->aux32->pr.p[a]) < (1u << 26);
+  if (ctx->opt.dot32_k4 && count >= 24 && !ctx->opt.dot32_small && k4_primes) {
 #ifndef K4_NO_TAIL
     if (k->aux_rows == 7 && ncol % 12 == 6) return launch_dot32_k4<7, 6, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);      // (66 columns = 5 x 12 + 6: the tail compiled on its own)
 #endif
