@@ -269,3 +269,39 @@ def test_dot32_kernel2_totals(ncol, ncp):
             for digs, keys in cases:
                 o = dot2_model(digs, keys, p, ncp)
                 assert o < p and o == sum(d * k for d, k in zip(digs, keys)) * rinv % p
+
+
+# ---------------------------------------------------------------------------------------------- tensor_sum32_kernel (sums of tensor products)
+def tsum_red(v, p, r32, mu):
+    assert v <= M64
+    v = (v >> 32) * r32 + (v & M32)
+    assert v < (1 << 62) + (1 << 32)
+    v = (v >> 32) * r32 + (v & M32)
+    assert v < (1 << 61)
+    q = (((v >> 29) & M32) * mu) >> 32
+    r = ((v & M32) - q * p) & M32
+    assert r < 3 * p
+    return r - 2 * p if r >= 2 * p else r
+
+
+@pytest.mark.parametrize("p", TENSOR_PRIMES[:3] + GENERIC_PRIMES)
+def test_tensor_sum32_totals(p):
+    """four terms per round, the middle component two products per term: eight products below p^2 on top of a reduced total"""
+    rng = random.Random(p + 99)
+    r32, mu = (1 << 32) % p, (1 << 61) // p
+    for nterms in (1, 3, 4, 5, 8, 13):
+        for worst in (True, False):
+            r1, ref = 0, 0
+            t = 0
+            while t < nterms:
+                n = min(4, nterms - t) if t + 4 <= nterms else 1
+                for _ in range(n):
+                    a0, a1, b0, b1 = ((p - 1,) * 4) if worst else tuple(rng.randrange(p) for _ in range(4))
+                    r1 += a0 * b1 + a1 * b0
+                    ref += a0 * b1 + a1 * b0
+                    assert r1 <= M64
+                t += n
+                if n == 4:
+                    r1 = tsum_red(r1, p, r32, mu)
+            r1 = tsum_red(r1, p, r32, mu)
+            assert r1 < 2 * p and r1 % p == ref % p
