@@ -182,6 +182,45 @@ def test_config2_metric_ring_several_chunks():
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
 
 
+def test_config2_rounding_boundaries_take_the_exact_pass():
+    """configs[2], the tensor half's CRT (crt32_scale_kernel, kernels_tensor32.hip): it forms only the words of x from bit 392 upwards and flags a
+    workgroup whose bits logQ-64 .. logQ-1 read 0x7fff...f for a second pass with every word.  Coefficients of a . b placed ON ScaleDown's rounding
+    boundary (Ciphertext.cpp:205-213: x + 2^(logQ-1) within a few units of a multiple of 2^logQ) must come out as the oracle rounds them -- and must
+    NOT with the second pass switched off, so the inputs really exercise it (the host-side model of the same window: tests/test_crt32_model.py)."""
+    m, logQ, p, count = 1 << 15, 512, 23, 1
+    primes, roots = P.chain_for(m, logQ, p)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    rng = np.random.default_rng(77)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    mod = 1 << logQ
+    inv_p = pow(p, -1, mod)
+
+    def centred(v):
+        v %= mod
+        return v - mod if v >= mod // 2 else v
+    # c0 = (p a0) . b0 with b0 = 1: coefficient j of the tensor product is p * A_j, and (p A_j + 2^(logQ-1)) mod 2^logQ = delta_j
+    deltas = [0, 1, -1, 2, -2, 3, -3, 5, -7, 8, 100, -100, 1 << 40, -(1 << 40), (1 << 390) + 12345, -(1 << 391)]
+    A = [centred((d - (mod >> 1)) * inv_p) for d in deltas]
+    a = np.zeros((count, 2, n, nl), dtype=np.uint64)
+    b = np.zeros((count, 2, n, nl), dtype=np.uint64)
+    a0 = [0] * n
+    for k, v in enumerate(A):
+        a0[(k * 1021 + 5) % n] = v                   # spread over many workgroups of the CRT kernel (128 coefficients each)
+    a[0, 0] = O.ints_to_limbs(a0, nl)
+    a[0, 1] = P.rand_limbs(rng, (n,), nl, logQ)
+    b[0, 0] = O.ints_to_limbs([1] + [0] * (n - 1), nl)
+    b[0, 1] = P.rand_limbs(rng, (n,), nl, logQ)
+    want = orc.ct_mul_relin(ksm, a[0], b[0], logQ, p)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
+    ctx.set_option("crt_skip_cleanup", 1)
+    assert not np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
+    ctx.set_option("crt_skip_cleanup", 0)
+    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b)[0], want)
+
+
 def test_config2_generated_keys_several_chunks():
     """configs[2] with the key-switch matrix EVERY reference driver holds -- KeySwitchSI(secretKey) of a sampleHWt(64) key (Test_AddMul.cpp:48-52
     -> FHE-SI.cpp:153-226), generated on the device as bench.py does -- at a batch that spans three chunks of 64.  The library measures the
