@@ -182,12 +182,13 @@ def test_config2_metric_ring_several_chunks():
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
 
 
-def test_config2_rounding_boundaries_take_the_exact_pass():
-    """configs[2], the tensor half's CRT (crt32_scale_kernel, kernels_tensor32.hip): it forms only the words of x from bit 392 upwards and flags a
+@pytest.mark.parametrize("m,logQ,p", [(1 << 15, 512, 23), (1006, 512, 23), (1 << 16, 1024, 65537)])
+def test_rounding_boundaries_take_the_exact_pass(m, logQ, p):
+    """configs[2] (and the generic form on a linear-convolution ring, and configs[4]'s words of 26 bits), the tensor half's CRT (crt32_scale_kernel, kernels_tensor32.hip): it forms only the words of x from bit 392 upwards and flags a
     workgroup whose bits logQ-64 .. logQ-1 read 0x7fff...f for a second pass with every word.  Coefficients of a . b placed ON ScaleDown's rounding
     boundary (Ciphertext.cpp:205-213: x + 2^(logQ-1) within a few units of a multiple of 2^logQ) must come out as the oracle rounds them -- and must
     NOT with the second pass switched off, so the inputs really exercise it (the host-side model of the same window: tests/test_crt32_model.py)."""
-    m, logQ, p, count = 1 << 15, 512, 23, 1
+    count = 1
     primes, roots = P.chain_for(m, logQ, p)
     ctx = F.Context(m, primes, roots)
     orc = O.Oracle(m, primes, roots)
@@ -202,7 +203,7 @@ def test_config2_rounding_boundaries_take_the_exact_pass():
         v %= mod
         return v - mod if v >= mod // 2 else v
     # c0 = (p a0) . b0 with b0 = 1: coefficient j of the tensor product is p * A_j, and (p A_j + 2^(logQ-1)) mod 2^logQ = delta_j
-    deltas = [0, 1, -1, 2, -2, 3, -3, 5, -7, 8, 100, -100, 1 << 40, -(1 << 40), (1 << 390) + 12345, -(1 << 391)]
+    deltas = [0, 1, -1, 2, -2, 3, -3, 5, -7, 8, 100, -100, 1 << 40, -(1 << 40), (1 << (logQ - 122)) + 12345, -(1 << (logQ - 121))]
     A = [centred((d - (mod >> 1)) * inv_p) for d in deltas]
     a = np.zeros((count, 2, n, nl), dtype=np.uint64)
     b = np.zeros((count, 2, n, nl), dtype=np.uint64)
