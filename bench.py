@@ -703,7 +703,7 @@ def main():
     on_traffic = traffic * launches / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None
     roofline_ntt = {"bound": "hbm", "kernel": kname, "achieved": round(on_traffic if on_traffic else achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round((on_traffic if on_traffic else achieved) / HBM_PEAK_GBS, 4), "frac_nominal": round(achieved / HBM_PEAK_GBS, 4),
-                    "achieved_nominal": round(achieved, 1), "basis": "bytes moved (PMC)" if on_traffic else "algorithmic 2 x row bytes",
+                    "achieved_nominal": round(achieved, 1), "basis": "bytes moved (offline rocprofv3 --pmc passes of this command, committed under profiles/; not re-measured in this run)" if on_traffic else "algorithmic 2 x row bytes",
                     "traffic": traffic, "traffic_source": traffic_src, "traffic_measured": False,
                     "achieved_on_traffic": round(on_traffic, 1) if on_traffic else None,
                     "launches": launches, "avg_launch_ms": round(ms / launches, 4) if launches else None,
