@@ -6,6 +6,8 @@ overflow of a multiply-add chain).  These models follow the instruction sequence
   * the tensor loader's red()  (ntt32_core.inc, ntt32_inv_kernel3<.., TENSOR>: a product or a sum of two products -> [0, 2p)),
   * a32_ct<NEGW> / a32_gs (ntt32_core.inc: the forward / inverse butterflies on lazy values),
   * mul_lazy32            (ntt32_core.inc),
+  * dot32_kernel4 / dot32_kernel2(p)  (kernels_aux32.hip: 64-bit totals of products between folds, the Montgomery step of the epilogue),
+  * tensor_sum32_kernel   (kernels_tensor32.hip: eight products per reduction),
 with the table entries as the host builders compute them, and check every intermediate bound the comments state plus the congruence of
 the result.  What the GPU computes is checked against the oracle in the `-m gpu` tests; this file checks that the RANGES hold for operands the
 random GPU inputs may never hit (all-ones words, p - 1 everywhere, the most negative coefficient)."""
