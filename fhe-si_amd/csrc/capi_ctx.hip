@@ -78,6 +78,7 @@ static const OptDesc kOptions[] = {
   {"wave_operands", "FHESI_WAVE_OPERANDS", offsetof(CtxOptions, wave_operands), true},
   {"wave_single", "FHESI_WAVE_SINGLE", offsetof(CtxOptions, wave_single), false},
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
+  {"tensor_bits", "FHESI_TENSOR_BITS", offsetof(CtxOptions, tensor_bits), false},
   {"digit_group", "FHESI_DIGIT_GROUP", offsetof(CtxOptions, digit_group), false},
   {"dot32_parts", "FHESI_DOT32_PARTS", offsetof(CtxOptions, dot32_parts), false},
   {"dot32_k4", "FHESI_DOT32_K4", offsetof(CtxOptions, dot32_k4), false},

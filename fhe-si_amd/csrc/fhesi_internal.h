@@ -87,6 +87,7 @@ struct CtxOptions {
   int dot32_v3 = 0;         // 1: dot32_kernel3 (two limbs per wave, 4 ciphertexts per tile, two workgroups per CU)
   int automorph_rows = 0;   // 1: Ciphertext >>= through DoubleCRT::automorph on evaluation rows (the reference's structure) even where the coefficient gather applies
   int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)
+  int tensor_bits = 30;     // 30: the tensor half's primes are the largest below 2^30; 29: below 2^29 -- lazy values have room up to 8p, so the row transforms skip 8 of 14 (forward) / 6 of 13 (inverse) range steps, for one or two primes more (36 instead of 35 at the metric ring)
   int dot32_k4 = 1;         // 1: key switch with 7 or 8 limbs and at least 8 ciphertexts per call runs dot32_kernel4 (keys in LDS, digits and accumulators in registers); 0: dot32_kernel2 (A/B)
   int dot32_parts = 1;      // 1: more columns than an 80 KB tile of 8 ciphertexts holds (the stress ring) are taken in two parts by dot32_kernel2p; 0: tiles of 4 ciphertexts (round 4: A/B)
   int digit_group = 1;      // units (digit polynomials) per XCD group of the 32-bit digit transform: 1 = single units (default: the order of rounds 2-4); -1 = one polynomial's digits per XCD when the launch has >= 32 polynomials (source rows leave HBM once: FETCH_SIZE 3.4x lower, the kernel 1.6 % SLOWER, profiles/r05_ab_digit_fwd.txt); g > 1 = groups of g units

@@ -45,6 +45,7 @@ struct T32Config {
 };
 struct fhesi_tensor32 {
   int S = 0;                         // rows of 2^14 << S
+  int bits = 30;                     // 30: the largest primes below 2^30; 29: below 2^29 (option tensor_bits: one or two primes more, 6 of 14 / 7 of 13 range steps per row transform)
   std::vector<u32> primes;           // the primes with transform tables, largest first
   std::vector<Tw32> head, tail;      // per prime: psi^brv(1), psi^-brv(1)   (S = 1)
   std::vector<Tw32> head1;           // per prime: psi^brv(2), psi^brv(3)    (S = 2: the second head stage)
@@ -93,7 +94,7 @@ static T32Plan t32_plan(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64 g
   int gbits = 0;
   while (((i64)1 << gbits) < gmax) ++gbits;
   auto& memo = const_cast<fhesi_ctx*>(ctx)->t32_memo;          // (a context serves one host thread at a time)
-  const std::vector<long long> key{(long long)p, nlimbs, logQ, gbits, ctx->opt.tensor32};
+  const std::vector<long long> key{(long long)p, nlimbs, logQ, gbits, ctx->opt.tensor32, ctx->opt.tensor_bits};
   auto it = memo.find(key);
   if (it == memo.end()) {
     std::vector<u32> pr;
@@ -123,17 +124,22 @@ static T32Plan t32_plan_search(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ
   for (int i = 0; i < ctx->L; ++i) chain += std::log2((double)ctx->q[i]);
   if (chain < TB + 1.5) return pl;
   const int maxp = (compiled && logQ == 1024) ? T32_MAXP : 62;
+  // Primes of 30 bits keep M above 2^(TB + 3.5) (rounds 2-5).  Primes below 2^29 (option tensor_bits = 29) make do with 2^(TB + 1.5): |x / M| < 0.36
+  // and the fixed-point sum behind kappa is short by less than NP 2^-25, so round(sum y_i / p_i) is still kappa -- 36 primes at the metric ring
+  // (1043.5 bits for TB = 1042), 72 at the stress ring.
+  const int pb = ctx->opt.tensor_bits == 29 ? 29 : 30;
+  const double margin = pb == 29 ? 1.5 : 3.5;
   double have = 0;
   int np = 0;
-  for (u64 k = ((u64)1 << (29 - lg)) - 1; k > ((u64)1 << (28 - lg)) && have < TB + 3.5; --k) {
+  for (u64 k = ((u64)1 << (pb - 1 - lg)) - 1; k > ((u64)1 << (pb - 2 - lg)) && have < TB + margin; --k) {
     const u64 cand = (k << (lg + 1)) + 1;
-    if (cand > ((u64)1 << 30) - ((u64)1 << 15) + 1 || !hm::is_prime(cand)) continue;
+    if (cand > ((u64)1 << pb) - ((u64)1 << 15) + 1 || !hm::is_prime(cand)) continue;
     if (np == maxp) return pl;
     if (primes) primes->push_back((u32)cand);
     have += std::log2((double)cand);
     ++np;
   }
-  if (have < TB + 3.5) return pl;
+  if (have < TB + margin) return pl;
   // all of M inside the table row
   const double room = compiled ? (logQ == 512 ? (double)T32_R_512 * T32_WT_512 : (double)T32_R_1024 * T32_WT_1024) : 28.0 * ((have + 8) / 28 + 2);
   if (have > room - 8) return pl;
@@ -149,7 +155,14 @@ bool tensor32_sum_applies(const fhesi_ctx* ctx, u64 p, int nlimbs, int logQ, i64
 // transform tables of the first `want` primes (grown on demand; a growth waits for the streams)
 static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
   fhesi_tensor32* x = ctx->tensor32;
-  if (!x) { x = new fhesi_tensor32(); x->S = (ctx->lin_q ? ctx->lin_lg : ctx->logn) - A32_LOGN; ctx->tensor32 = x; }
+  const int pb = !primes.empty() && primes[0] < (1u << 29) ? 29 : 30;
+  if (x && x->bits != pb) {              // (option tensor_bits toggled on a live context: other primes, other tables)
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->lane_stream) HIP_TRY(hipStreamSynchronize(ctx->lane_stream));
+    tensor32_free(ctx);
+    x = nullptr;
+  }
+  if (!x) { x = new fhesi_tensor32(); x->S = (ctx->lin_q ? ctx->lin_lg : ctx->logn) - A32_LOGN; x->bits = pb; ctx->tensor32 = x; }
   if (x->primes.size() >= primes.size()) return 0;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->lane_stream) HIP_TRY(hipStreamSynchronize(ctx->lane_stream));
@@ -243,7 +256,7 @@ static int t32_config(fhesi_ctx* ctx, u64 lift, int nlimbs, int logQ, i64 gmax, 
     c->pr.p[a] = (u32)p;
     c->pr.ninv[a] = (u32)ninv;
     c->pr.ninv_p[a] = (u32)((ninv << 32) / p);
-    c->pr.mu61[a] = (u32)(((u64)1 << 61) / p);
+    c->pr.mu61[a] = (u32)(((u64)1 << (32 + t32_shift((u32)p))) / p);
     for (int cls = 0; cls < 2; ++cls) {
       u32* e = &rns[((size_t)cls * NP + a) * stride];
       const u64 b32 = ((u64)1 << 32) % p;
@@ -336,7 +349,9 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
   acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^32 r32 + 2^32
   // The primes of the tensor half are the largest below 2^30, so 2^32 mod p = 4 (2^30 - p) is a small number (below 2^26 for the 72 largest
   // primes that are 1 mod 2^16): one fold already leaves the total below 2^61.  Any other prime takes the second fold (a wave-uniform branch).
-  if (r32 >= (1u << 28)) acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^61
+  // (primes of 29 bits: sh = 28 -- one fold leaves the total below 2^60 when 2^32 mod p = 8 (2^29 - p) is below 2^27, the second fold otherwise)
+  const u32 sh = t32_shift(p);
+  if (r32 >= (1u << (sh - 1))) acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^(32 + sh)
 #else
 #pragma unroll
   for (int k = 0; k < 2 * NL; ++k) {
@@ -347,8 +362,9 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
   acc += neg ? t[2 * NL] : 0u;
   acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^62 + 2^32
   acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^61
+  const u32 sh = t32_shift(p);
 #endif
-  const u32 q = __umulhi((u32)(acc >> 29), mu);        // at most 2 below floor(acc / p)
+  const u32 q = __umulhi((u32)(acc >> sh), mu);        // at most 2 below floor(acc / p)
   return (u32)acc - q * p;                             // below 3p
 }
 // HEAD: 0 = plain rows (or, dup, padded rows of 2^15: the value goes to both sub-rows); 1 = rows of 2^15 with the head stage x +- w y of
@@ -445,7 +461,7 @@ __global__ void __launch_bounds__(256) tensor_sum32_kernel(const u32* __restrict
                                                            const int* __restrict__ slot_b, const int* __restrict__ seg, int accumulate, u32* __restrict__ out,
                                                            i64 nrow, int NP, T32Primes pr) {
   const int g = blockIdx.z, l = blockIdx.y;
-  const u32 p = pr.p[l], mu = pr.mu61[l], twop = 2 * p;
+  const u32 p = pr.p[l], mu = pr.mu61[l], twop = 2 * p, sh = t32_shift(p);
   const u32 r32 = (u32)((((u64)1) << 32) % p);
   const i64 rs = (i64)NP * nrow;
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -454,8 +470,8 @@ __global__ void __launch_bounds__(256) tensor_sum32_kernel(const u32* __restrict
   // a 64-bit total takes 8 products below 2^60; reduced to below 2p every 4 terms (t1 adds two products per term)
   auto red = [&](u64 v) -> u32 {
     v = (u64)(u32)(v >> 32) * r32 + (u32)v;          // below 2^62 + 2^32
-    v = (u64)(u32)(v >> 32) * r32 + (u32)v;          // below 2^61
-    const u32 q = __umulhi((u32)(v >> 29), mu);
+    v = (u64)(u32)(v >> 32) * r32 + (u32)v;          // below 2^61 (primes of 29 bits: below 2^59)
+    const u32 q = __umulhi((u32)(v >> sh), mu);
     const u32 r = (u32)v - q * p;                     // below 3p
     return r >= twop ? r - twop : r;
   };
@@ -734,9 +750,11 @@ static int t32_fwd(fhesi_ctx* ctx, const T32Config* c, u32* d_r, i64 npolys) {
   ProfScope prof(ctx, PROF_NTT_FWD, (double)(npolys * c->NP));
   if (npolys > 0x7fffffff) FHESI_FAIL("tensor32: too many rows per launch");
   const dim3 grid((unsigned)npolys, (unsigned)(c->NP << x->S));
-  if (x->S == 2) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 2, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 2, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
-  else if (x->S) { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 1, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 1, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
-  else { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, 0, false, T32Primes, true>)); ntt32_fwd_kernel3<false, 0, false, T32Primes, true><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); }
+#define T32_FWD_GO(SS, PB) do { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, SS, false, T32Primes, true, false, PB>)); \
+    ntt32_fwd_kernel3<false, SS, false, T32Primes, true, false, PB><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); } while (0)
+  if (x->bits == 29) { if (x->S == 2) T32_FWD_GO(2, 29); else if (x->S) T32_FWD_GO(1, 29); else T32_FWD_GO(0, 29); }
+  else { if (x->S == 2) T32_FWD_GO(2, 30); else if (x->S) T32_FWD_GO(1, 30); else T32_FWD_GO(0, 30); }
+#undef T32_FWD_GO
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -816,9 +834,14 @@ int launch_tensor32(fhesi_ctx* ctx, u64 p, const u64* d_a, const u64* d_b, int n
   FHESI_TRY(t32_fwd(ctx, c, (u32*)d_r, count * 4));
   {
     ProfScope prof(ctx, PROF_NTT_INV, (double)(count * 3 * NP));
-    PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, true, T32Primes>));
     const dim3 grid((unsigned)(count >= 8 ? ((count + 7) / 8) * 24 : count * 3), (unsigned)(NP << S));      // (groups of 8 ciphertexts x 3 rows, or the rows themselves: see the kernel)
-    ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, c->pr, x->d_inv, S, (const u32*)d_r);
+    if (x->bits == 29) {
+      PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, true, T32Primes, 29>));
+      ntt32_inv_kernel3<false, true, T32Primes, 29><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, c->pr, x->d_inv, S, (const u32*)d_r);
+    } else {
+      PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, true, T32Primes>));
+      ntt32_inv_kernel3<false, true, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_t, count * 3, NP, 0, c->pr, x->d_inv, S, (const u32*)d_r);
+    }
     HIP_TRY(hipGetLastError());
   }
   return t32_crt(ctx, c, (const u32*)d_t, count * 3, d_parts, parts_wm);
@@ -858,8 +881,14 @@ int tensor32_sum_finish(fhesi_ctx* ctx, void* d_sum, i64 ng, u64* d_parts, bool 
   const fhesi_tensor32* x = ctx->tensor32;
   {
     ProfScope prof(ctx, PROF_NTT_INV, (double)(ng * 3 * c->NP));
-    PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, false, T32Primes>));
-    ntt32_inv_kernel3<false, false, T32Primes><<<dim3((unsigned)(ng * 3), (unsigned)(c->NP << x->S)), A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, x->S, nullptr);
+    const dim3 grid((unsigned)(ng * 3), (unsigned)(c->NP << x->S));
+    if (x->bits == 29) {
+      PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, false, T32Primes, 29>));
+      ntt32_inv_kernel3<false, false, T32Primes, 29><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, x->S, nullptr);
+    } else {
+      PROF_KERNEL(ctx, PROF_NTT_INV, (ntt32_inv_kernel3<false, false, T32Primes>));
+      ntt32_inv_kernel3<false, false, T32Primes><<<grid, A32_T, 0, ctx->stream>>>((u32*)d_sum, ng * 3, c->NP, 0, c->pr, x->d_inv, x->S, nullptr);
+    }
     HIP_TRY(hipGetLastError());
   }
   return t32_crt(ctx, c, (const u32*)d_sum, ng * 3, d_parts, parts_wm);

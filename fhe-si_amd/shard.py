@@ -66,6 +66,10 @@ def roll_call(dist, ident: dict, allow_shared: bool = False) -> list:
     world = dist.get_world_size()
     got = [None] * world
     dist.all_gather_object(got, dict(ident, rank=dist.get_rank()))
+    return _check_shared(got, allow_shared)
+
+
+def _check_shared(got: list, allow_shared: bool) -> list:
     seen = {}
     for g in got:
         seen.setdefault((g["host"], g["id"]), []).append(g["rank"])
@@ -74,6 +78,16 @@ def roll_call(dist, ident: dict, allow_shared: bool = False) -> list:
         raise RuntimeError("ranks share a GPU: " + "; ".join(f"{k[1]} on {k[0]} <- ranks {v}" for k, v in shared.items()) +
                            " (one process per GPU is required: check LOCAL_RANK / HIP_VISIBLE_DEVICES; --one-device is the 1-GPU plumbing mode)")
     return got
+
+
+def roll_call_store(store, ident: dict, rank: int, world: int, allow_shared: bool = False) -> list:
+    """The roll call through the rendezvous key-value store itself (torch.distributed.TCPStore), for a build whose process group has no CPU
+    backend: every rank posts its identity under its own key and reads everyone's (a blocking get) BEFORE any process group -- and with it
+    any RCCL communicator -- exists.  Same verdict on every rank as roll_call."""
+    import json
+    store.set(f"fhesi_roll_call/{rank}", json.dumps(dict(ident, rank=rank)))
+    got = [json.loads(bytes(store.get(f"fhesi_roll_call/{r}")).decode()) for r in range(world)]
+    return _check_shared(got, allow_shared)
 
 
 def digest64(arr: np.ndarray) -> int:

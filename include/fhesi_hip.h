@@ -65,7 +65,8 @@ void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t a
 /* Behaviour switches of one context (A/B measurements, test hooks).  Names: "ks_direct" (1 = per-chain-prime key-switch dot product, the
  * reference's own structure FHE-SI.cpp:251-254), "ks_residues", "ks_aux60", "crt_exact", "crt_skip_cleanup" (test hook), "lanes" (2 = two
  * concurrent half-batches), "stagger", "batch_chunk", "wave_operands", "tensor32" (0 = the fused pipeline keeps the tensor product on the
- * chain primes); layout switches that never change a result (round 5): "dot32_k4" (0 = the digit-tile dot product dot32_kernel2 where the
+ * chain primes), "tensor_bits" (30 / 29: the size of the tensor half's primes -- below 2^29 the row transforms skip half of their range steps
+ * for one or two primes more; the integers formed are the same); layout switches that never change a result (round 5): "dot32_k4" (0 = the digit-tile dot product dot32_kernel2 where the
  * key-in-LDS form dot32_kernel4 would run; 2 = also offer its split form for 15 limbs), "dot32_parts" (0 = tiles of 4 ciphertexts where the
  * columns do not fit one tile of 8), "parts_words" (0 = 64-bit limb rows between the tensor half and the digit loader), "digit_group"
  * (units per XCD group of the digit transform; -1 = one polynomial's digits), "ks_long_keys", "dot32_small", "host_chunk", "host_threads".

@@ -43,7 +43,24 @@ def mid_primes(count, step, start):
     return out
 
 
+def primes_below_2_29(count, step):
+    """option tensor_bits = 29 (t32_plan): the largest primes below 2^29 that are 1 mod `step`"""
+    out = []
+    p = (1 << 29) - ((1 << 29) % step) + 1
+    while len(out) < count:
+        p -= step
+        if R.is_prime(p):
+            out.append(p)
+    return out
+
+
+def t32_shift(p):
+    """ntt32_core.inc: 29 for primes of 30 bits, 28 for primes of 29 bits; mu = floor(2^(32 + sh) / p) fits 32 bits"""
+    return 29 if p >> 29 else 28
+
+
 TENSOR_PRIMES = primes_below_2_30(70, 1 << 16)[::9] + primes_below_2_30(35, 1 << 15)[-2:]
+TENSOR_PRIMES_29 = primes_below_2_29(72, 1 << 16)[::9] + primes_below_2_29(37, 1 << 15)[-2:] + primes_below_2_29(76, 1 << 17)[-2:]
 GENERIC_PRIMES = mid_primes(2, 1 << 15, (1 << 30) - (1 << 28)) + mid_primes(2, 1 << 15, (1 << 29) + (1 << 27)) + mid_primes(1, 1 << 15, 1 << 29)
 
 
@@ -54,7 +71,9 @@ def rns_table(p, lift, nl):
     for _ in range(2 * nl):
         t.append(cur)
         cur = cur * b32 % p
-    return t, (p - cur) % p, b32, (1 << 61) // p
+    mu = (1 << (32 + t32_shift(p))) // p
+    assert mu <= M32 or p < (1 << 28), "the quotient constant is a 32-bit word"
+    return t, (p - cur) % p, b32, mu
 
 
 def rns32_one(x, neg, t, tneg, r32, mu, p):
@@ -74,18 +93,19 @@ def rns32_one(x, neg, t, tneg, r32, mu, p):
     acc = neg * tneg + acc
     assert acc <= M64
     acc = fold(acc)
-    if r32 >= (1 << 28):
+    sh = t32_shift(p)
+    if r32 >= (1 << (sh - 1)):
         acc = fold(acc)
-    assert acc < (1 << 61), "the Barrett step takes a value below 2^61"
-    q = (((acc >> 29) & M32) * mu) >> 32
-    assert (acc >> 29) <= M32
+    assert acc < (1 << (32 + sh)), "the Barrett step takes a value below 2^(32 + sh)"
+    q = (((acc >> sh) & M32) * mu) >> 32
+    assert (acc >> sh) <= M32
     r = ((acc & M32) - q * p) & M32
     assert acc // p - 2 <= q <= acc // p
     return r
 
 
 @pytest.mark.parametrize("nl", [8, 16])
-@pytest.mark.parametrize("p", TENSOR_PRIMES + GENERIC_PRIMES)
+@pytest.mark.parametrize("p", TENSOR_PRIMES + TENSOR_PRIMES_29 + GENERIC_PRIMES)
 def test_rns32_chain_never_overflows_and_stays_below_3p(nl, p):
     rng = random.Random(p * 31 + nl)
     for lift in (1, 23, 65537, 32603, (1 << 20) - 3):
@@ -102,17 +122,18 @@ def test_rns32_chain_never_overflows_and_stays_below_3p(nl, p):
 
 # ---------------------------------------------------------------------------------------------- tensor loader
 def red61(x, p, mu):
-    assert x < (1 << 61)
-    q = (((x >> 29) & M32) * mu) >> 32
+    sh = t32_shift(p)
+    assert x < (1 << (32 + sh)) and mu <= M32
+    q = (((x >> sh) & M32) * mu) >> 32
     r = ((x & M32) - q * p) & M32
     assert r < 3 * p
     return r - 2 * p if r >= 2 * p else r
 
 
-@pytest.mark.parametrize("p", TENSOR_PRIMES + GENERIC_PRIMES)
+@pytest.mark.parametrize("p", TENSOR_PRIMES + TENSOR_PRIMES_29 + GENERIC_PRIMES)
 def test_tensor_loader_reduction(p):
     rng = random.Random(p)
-    mu = (1 << 61) // p
+    mu = (1 << (32 + t32_shift(p))) // p
     ext = [0, 1, p - 1, p - 2, p // 2]
     pairs = [(a, b) for a in ext for b in ext] + [(rng.randrange(p), rng.randrange(p)) for _ in range(2000)]
     for a, b in pairs:
@@ -178,6 +199,99 @@ def test_butterflies_keep_their_ranges(p):
             wv, wp = tw(w, p)
             r = mul_lazy32(y, wv, wp, p)
             assert r < 2 * p and r % p == y * w % p
+
+
+# ---------------------------------------------------------------------------------------------- primes below 2^29: fewer range steps
+def a32_ct29(x, y, w, p, step):
+    """a32_ct<NEGW>(.., step): 0 = x as it is, 2 = min(x, x - 4p); every sum must stay a 32-bit value WITHOUT wrapping"""
+    wneg, wp = (-w) & M32, (w << 32) // p
+    X = x if step == 0 else min(x, (x - 4 * p) & M32)
+    Q = (y * wp) >> 32
+    nT = (Q * p + y * wneg) & M32
+    T = (-nT) & M32
+    assert T < 2 * p and T % p == y * w % p
+    assert X + T <= M32 and X + 2 * p - T >= 0 and X - T + 2 * p <= M32
+    return (X - nT) & M32, (X + nT + 2 * p) & M32
+
+
+def fwd_step29(g):
+    return 2 if g >= 2 and not g & 1 else 0
+
+
+@pytest.mark.parametrize("p", TENSOR_PRIMES_29[:3] + TENSOR_PRIMES_29[-2:])
+def test_forward_rows_of_29_bit_primes_skip_range_steps(p):
+    """ntt32_fwd_kernel3<.., PB = 29>: rows enter below 4p; stage g takes its x input as it is except the even stages from 2 on; the bound
+    4p -> 6p -> 8p -> (step) 6p -> 8p ... never wraps 32 bits and the store's three range steps end below p"""
+    assert 8 * p <= M32 + 1
+    rng = random.Random(p)
+    bound = 4 * p
+    vals = [4 * p - 1, 0, p, 3 * p + 5] + [rng.randrange(4 * p) for _ in range(60)]
+    want = [v % p for v in vals]
+    for g in range(14):
+        st = fwd_step29(g)
+        if st == 2:
+            assert bound <= 8 * p
+            bound = 4 * p
+        bound += 2 * p
+        assert bound <= 8 * p
+        nxt, nwant = [], []
+        for i in range(0, len(vals), 2):
+            w = rng.choice([1, p - 1, rng.randrange(1, p)])
+            for (x, y, wx, wy) in ((vals[i], vals[i + 1], want[i], want[i + 1]), (bound - 2 * p - 1 if st == 0 else 8 * p - 1, M32, None, None)):
+                if wx is None:
+                    if st == 2:
+                        x = min(x, 8 * p - 1)
+                    xo, yo = a32_ct29(x, y, w, p, st)
+                    assert xo < bound and yo < bound
+                    continue
+                xo, yo = a32_ct29(x, y, w, p, st)
+                assert xo < bound and yo < bound
+                nxt += [xo, yo]
+                nwant += [(wx + w * wy) % p, (wx - w * wy) % p]
+        vals, want = nxt, nwant
+    assert bound == 8 * p
+    for v, wv in zip(vals + [8 * p - 1, 4 * p, 2 * p, p], want + [(8 * p - 1) % p, 0, 0, 0]):
+        v = min(v, (v - 4 * p) & M32)
+        v = min(v, (v - 2 * p) & M32)
+        v = min(v, (v - p) & M32)
+        assert v < p and v == wv
+
+
+def a32_gs29(x, y, w, p, fresh):
+    """a32_gs29 (ntt32_core.inc): fresh = both inputs below 2p (product outputs of the stage before); otherwise both below 4p"""
+    wv, wp = tw(w, p)
+    lim = 2 * p if fresh else 4 * p
+    assert x < lim and y < lim
+    s = x + y
+    d = x - y + lim
+    assert 0 <= d <= M32 and s <= M32
+    xo = s if fresh else min(s, (s - 4 * p) & M32)
+    Q = (d * wp) >> 32
+    yo = (Q * ((-p) & M32) + d * wv) & M32
+    return xo, yo
+
+
+@pytest.mark.parametrize("p", TENSOR_PRIMES_29[:3] + TENSOR_PRIMES_29[-2:])
+def test_inverse_butterfly_of_29_bit_primes(p):
+    """sum outputs below 4p, product outputs below 2p, whichever form runs; the last stage's sums and differences (below 8p) enter mulc"""
+    assert 8 * p <= M32 + 1
+    rng = random.Random(p + 1)
+    ws = [1, p - 1, 2, rng.randrange(1, p), rng.randrange(1, p)]
+    for w in ws:
+        for fresh in (True, False):
+            lim = 2 * p if fresh else 4 * p
+            ext = [0, 1, p, lim - 1, lim // 2]
+            for x in ext + [rng.randrange(lim) for _ in range(100)]:
+                for y in ext + [rng.randrange(lim) for _ in range(20)]:
+                    xo, yo = a32_gs29(x, y, w, p, fresh)
+                    assert xo < 4 * p and yo < 2 * p
+                    assert xo % p == (x + y) % p and yo % p == (x - y) * w % p
+                    # the last stage (ntt32_inv_kernel3): sm = x + y, df = x - y + lim, each through mulc (any 32-bit value -> [0, 2p))
+                    sm, df = x + y, x - y + lim
+                    assert sm <= M32 and 0 <= df <= M32
+                    wv, wp = tw(w, p)
+                    r = mul_lazy32(df, wv, wp, p)
+                    assert r < 2 * p and r % p == (x - y) * w % p
 
 
 # ---------------------------------------------------------------------------------------------- dot32_kernel4
@@ -275,22 +389,23 @@ def test_dot32_kernel2_totals(ncol, ncp):
 
 # ---------------------------------------------------------------------------------------------- tensor_sum32_kernel (sums of tensor products)
 def tsum_red(v, p, r32, mu):
-    assert v <= M64
+    sh = t32_shift(p)
+    assert v <= M64 and mu <= M32
     v = (v >> 32) * r32 + (v & M32)
     assert v < (1 << 62) + (1 << 32)
     v = (v >> 32) * r32 + (v & M32)
-    assert v < (1 << 61)
-    q = (((v >> 29) & M32) * mu) >> 32
+    assert v < (1 << (32 + sh))
+    q = (((v >> sh) & M32) * mu) >> 32
     r = ((v & M32) - q * p) & M32
     assert r < 3 * p
     return r - 2 * p if r >= 2 * p else r
 
 
-@pytest.mark.parametrize("p", TENSOR_PRIMES[:3] + GENERIC_PRIMES)
+@pytest.mark.parametrize("p", TENSOR_PRIMES[:3] + TENSOR_PRIMES_29[:3] + TENSOR_PRIMES_29[-2:] + GENERIC_PRIMES)
 def test_tensor_sum32_totals(p):
     """four terms per round, the middle component two products per term: eight products below p^2 on top of a reduced total"""
     rng = random.Random(p + 99)
-    r32, mu = (1 << 32) % p, (1 << 61) // p
+    r32, mu = (1 << 32) % p, (1 << (32 + t32_shift(p))) // p
     for nterms in (1, 3, 4, 5, 8, 13):
         for worst in (True, False):
             r1, ref = 0, 0

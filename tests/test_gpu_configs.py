@@ -182,8 +182,9 @@ def test_config2_metric_ring_several_chunks():
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
 
 
+@pytest.mark.parametrize("bits", [30, 29])
 @pytest.mark.parametrize("m,logQ,p", [(1 << 15, 512, 23), (1006, 512, 23), (1 << 16, 1024, 65537)])
-def test_rounding_boundaries_take_the_exact_pass(m, logQ, p):
+def test_rounding_boundaries_take_the_exact_pass(m, logQ, p, bits):
     """configs[2] (and the generic form on a linear-convolution ring, and configs[4]'s words of 26 bits), the tensor half's CRT (crt32_scale_kernel, kernels_tensor32.hip): it forms only the words of x from bit 392 upwards and flags a
     workgroup whose bits logQ-64 .. logQ-1 read 0x7fff...f for a second pass with every word.  Coefficients of a . b placed ON ScaleDown's rounding
     boundary (Ciphertext.cpp:205-213: x + 2^(logQ-1) within a few units of a multiple of 2^logQ) must come out as the oracle rounds them -- and must
@@ -191,6 +192,7 @@ def test_rounding_boundaries_take_the_exact_pass(m, logQ, p):
     count = 1
     primes, roots = P.chain_for(m, logQ, p)
     ctx = F.Context(m, primes, roots)
+    ctx.set_option("tensor_bits", bits)               # (primes below 2^30, or below 2^29 with M only 1.5 bits above the bound: kappa's rounding has less room there)
     orc = O.Oracle(m, primes, roots)
     n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
     rng = np.random.default_rng(77)

@@ -206,8 +206,10 @@ def test_wave_of_products_on_linear_convolution_rings(m, logQ, p):
     seg = np.cumsum([0] + [len(g) for g in groups])
     dpool = ctx.upload(pool)
     outs = []
-    for t32 in (1, 0):
-        ctx.set_option("tensor32", t32)
+    bits = ctx.get_option("tensor_bits")
+    for t32 in (1, 0, 2):                                  # (2: the tensor half over the other prime size -- option tensor_bits 30 / 29)
+        ctx.set_option("tensor32", 1 if t32 else 0)
+        ctx.set_option("tensor_bits", 59 - bits if t32 == 2 else bits)
         ctx.set_option("wave_single", 0)
         out = ctx.alloc(len(groups) * 2 * n * nl * 8)
         ctx.prof_enable(True)
@@ -217,7 +219,8 @@ def test_wave_of_products_on_linear_convolution_rings(m, logQ, p):
         ctx.prof_enable(False)
         outs.append(out.download((len(groups), 2, n, nl)))
     ctx.set_option("tensor32", 1)
-    assert np.array_equal(outs[0], outs[1])
+    ctx.set_option("tensor_bits", bits)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     for gi in (() if m > 40000 else (0,) if m > 20000 else range(len(groups))):      # (m = 65266: minutes per oracle product; the chain path above stands in)
         tp = None
         for x, y in groups[gi]:

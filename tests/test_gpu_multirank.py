@@ -201,7 +201,12 @@ def test_bench_two_ranks_checks_every_rank_against_the_oracle():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["matches_oracle"] is True and d["config"]["multi_gpu"]["parity"]["oracle_checked_on_every_rank"] is True
-    assert d["cpu_baseline"] is None            # (the CPU figure is an N = 1 quantity)
+    # every N > 1 line is a complete measurement record: rank 0 times the single-thread oracle sample while the other ranks wait
+    cb = d["cpu_baseline"]
+    assert cb is not None and cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and cb["all_cores"] is None
+    rf = d["roofline"]
+    assert rf["kernel"] and rf["frac"] > 0 and rf["bound"] in ("hbm", "valu") and "valu_busy" in rf and rf["avg_launch_ms"] > 0
+    assert d["config"]["n1_equivalent"] == d["config"]["per_rank_value"][0] > 0
 
 
 def test_bench_refuses_ranks_that_share_a_gpu():

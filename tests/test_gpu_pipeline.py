@@ -204,6 +204,15 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     chain = ctx.ct_mul_relin(ksk, logQ, p, a, b)
     ctx.set_option("tensor32", 1)
     assert np.array_equal(got, chain)
+    # ... and over the OTHER prime size (option tensor_bits: 30 = the largest primes below 2^30, 29 = below 2^29 with fewer range steps in the
+    # row transforms and one or two primes more): other primes, other tables, other kernels -- the same integers
+    bits = ctx.get_option("tensor_bits")
+    assert bits in (29, 30)
+    ctx.set_option("tensor_bits", 59 - bits)
+    other = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert ctx.get_option("tensor_bits") == 59 - bits
+    ctx.set_option("tensor_bits", bits)
+    assert np.array_equal(got, other)
     # (general m at this size: seconds per Bluestein row in the oracle; at m = 65266 minutes per multiplication -- there the chain path above,
     # per-prime Bluestein rows checked against the oracle on the smaller rings and in test_gpu_general_m.py, stands in)
     for c in (() if m > 40000 else (2,) if ctx.phim > 10000 and (m & (m - 1)) != 0 else (1, 2)):

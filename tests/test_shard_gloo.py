@@ -121,3 +121,40 @@ def test_roll_call_digests_and_broadcast_timings(tmp_path):
     for r in range(2):
         v = np.load(tmp_path / f"r{r}.npy")
         assert v[0] == 1, (r, v.tolist())
+
+
+def _store_roll_call_worker(rank, world, port, outdir, shared):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import datetime
+    import torch.distributed as dist
+    from fhe_si_amd import shard
+    store = dist.TCPStore("127.0.0.1", port, world, rank == 0, timeout=datetime.timedelta(seconds=60))
+    ident = {"host": "box", "id": "uuid:same" if shared else f"uuid:gpu{rank}", "device_index": 0, "name": "test", "visible": None}
+    res = {}
+    try:
+        topo = shard.roll_call_store(store, ident, rank, world)
+        res["refused"] = False
+        res["topo"] = [t["rank"] for t in topo] == list(range(world)) and len({t["id"] for t in topo}) == world
+    except RuntimeError as e:
+        res["refused"] = "ranks share a GPU" in str(e)
+        res["topo"] = True
+    if not shared:
+        # the process group is created on the SAME store afterwards (bench.py's fallback: nccl there, gloo here) and works
+        dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
+        ok, per = shard.all_ranks_ok(dist, True)
+        res["group"] = ok and per == [True] * world
+        dist.barrier()
+        dist.destroy_process_group()
+    np.save(os.path.join(outdir, f"s{rank}.npy"), np.array([int(res["refused"]), int(res["topo"]), int(res.get("group", True))]))
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_roll_call_through_the_rendezvous_store(tmp_path, shared):
+    """bench.py's fallback when the mixed gloo + nccl group is not available: the roll call goes through the TCPStore BEFORE any process group
+    (and so any RCCL communicator) exists; shared GPUs are refused on every rank, distinct ones go on to a group built on that store."""
+    port = _free_port()
+    mp.spawn(_store_roll_call_worker, args=(2, port, str(tmp_path), shared), nprocs=2, join=True)
+    for r in range(2):
+        v = np.load(tmp_path / f"s{r}.npy").tolist()
+        assert v == [int(shared), 1, 1], (r, v)

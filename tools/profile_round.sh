@@ -29,12 +29,12 @@ done
 F=$(find "$O/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
 W=$(find "$O/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "dot32_kernel4<7, 6, 12, 3, 8, 1, 6>" "$O/pmc_dot_aux.json" ciphertexts_per_launch=1024
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true, 0, false, Aux32Primes, true, true>" "$O/pmc_ntt_fwd.json" rows_per_launch=270336
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<false, 0, false, T32Primes, true, false>" "$O/pmc_t32_fwd.json" rows_per_launch=143360
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<false, true, T32Primes>" "$O/pmc_t32_inv.json" rows_per_launch=107520
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<true, 0, false, Aux32Primes, true, true, 30>" "$O/pmc_ntt_fwd.json" rows_per_launch=270336
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_fwd_kernel3<false, 0, false, T32Primes, true, false, 30>" "$O/pmc_t32_fwd.json" rows_per_launch=143360
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<false, true, T32Primes, 30>" "$O/pmc_t32_inv.json" rows_per_launch=107520
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "rns32_reduce_kernel<8, 0, true>" "$O/pmc_t32_rns.json" ciphertexts_per_launch=1024
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "crt32_scale_kernel<512, false, 28, 38, 0>" "$O/pmc_t32_crt.json" ciphertexts_per_launch=1024
-python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<true, false, Aux32Primes>" "$O/pmc_ntt_inv.json" rows_per_launch=57344
+python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ntt32_inv_kernel3<true, false, Aux32Primes, 30>" "$O/pmc_ntt_inv.json" rows_per_launch=57344
 python3 "$R/tools/pmc_traffic.py" "$F" "$W" "ks_recombine_centred_kernel" "$O/pmc_recombine.json" ciphertexts_per_launch=1024
 find "$O" -name '*.db' -delete; find "$O" -name '*agent_info.csv' -delete; find "$O" -name '*kernel_trace.csv' -delete; find "$O" -name '*counter_collection.csv' -delete
 ls -la "$O"
