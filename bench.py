@@ -284,7 +284,7 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
     counter = _CountingBackend(nin)
     G.regress_waves(counter, X, y)
     pool = G.ShardedPool(2 * n * nl, counter.used + 8, device=dev, dist=dist)
-    be = G.DeviceBackend(ctx, LOGQ, P_PLAIN, ksk, autos, ks, pool, DECOMP)
+    be = G.DeviceBackend(ctx, LOGQ, P_PLAIN, ksk, autos, ks, pool, DECOMP, overlap=args.reg_overlap)
     first = be.upload(rand_coeffs(np.random.default_rng(7), (nin, 2, n), nl))      # same inputs on every rank
     assert first == 0
     mark = pool.used
@@ -335,7 +335,8 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
                                            "centred_limbs": ksk.key_bits()[0], "key_coefficient_bits": ksk.key_bits()[1]}, "keys": args.keys, "automorphism_keys": len(ks), "waves": stats["waves"],
                        "products_per_regress": stats["products"], "key_switches_per_regress": stats["key_switches"],
                        "automorph_key_switches_per_regress": stats["automorph_key_switches"], "regress_per_s": round(args.steps / dt, 3),
-                       "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if world > 1 else "single GPU"},
+                       "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if world > 1 else "single GPU",
+                       "exchange_overlap_chunks": args.reg_overlap, "waves_run_in_chunks": sum(1 for _, c in pool.schedule if c > 1)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches,
                          "avg_launch_ms": round(ms / launches, 4) if launches else None},
@@ -465,6 +466,8 @@ def parse_args():
     ap.add_argument("--reg-rows", type=int, default=1)
     ap.add_argument("--reg-ring", default="metric", choices=["metric", "reference"], help="regression workload: replay at the metric ring (default) or on "
                     "the reference's own Test_Regression ring (p = 8423, m = 8422, logQ = 341: configs[3] itself)")
+    ap.add_argument("--reg-overlap", type=int, default=1, help="regression workload at N > 1: every wave in this many chunks, the exchange of a chunk (asynchronous RCCL broadcasts) "
+                    "travelling while the next chunk is computed (1 = compute the shard, then exchange)")
     ap.add_argument("--reg-p", type=int, default=8423, help="--reg-ring reference: the safe prime p (m = p - 1); 8423 = Test_Regression's, 32603 = phi(m) 16300")
     ap.add_argument("--ref-p", type=int, default=32603, help="--workload refring: the safe prime p (m = p - 1); 32603 = phi(m) 16300 (padded rows of 2^15), 65267 = phi(m) 32632 "
                     "(padded rows of 2^16: the largest safe prime below 2^16)")

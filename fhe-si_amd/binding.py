@@ -35,12 +35,12 @@ ABI_SYMBOLS = [
     "fhesi_ctx_set_option", "fhesi_ctx_get_option", "fhesi_ctx_copy_options", "fhesi_host_alloc", "fhesi_host_free", "fhesi_ksk_key_bits", "fhesi_prof_kernel_name", "fhesi_ksk_mark_dirty", "fhesi_ksk_upload_dev",
     "fhesi_dcrt_add_primes_and_scale", "fhesi_dcrt_scale_down_to_set",
     "fhesi_keyswitch_init_batch", "fhesi_ksk_download", "fhesi_comm_init_all", "fhesi_comm_from_rccl", "fhesi_comm_destroy", "fhesi_comm_rank",
-    "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
+    "fhesi_comm_size", "fhesi_ksk_broadcast", "fhesi_comm_broadcast_dev", "fhesi_comm_exchange", "fhesi_comm_exchange_begin", "fhesi_comm_exchange_end", "fhesi_comm_allreduce_rows", "fhesi_scrt_alloc", "fhesi_scrt_from_poly", "fhesi_scrt_to_poly", "fhesi_scrt_op_scalar", "fhesi_dcrt_assign_scrt", "fhesi_scrt_assign_dcrt",
     "fhesi_ksk_form", "fhesi_ct_add_const_dev", "fhesi_ct_mul_poly_dev",
     "fhesi_encrypt_batch_seeded", "fhesi_keyswitch_init_batch_seeded", "fhesi_dcrt_sample",
     "fhesi_abi_version", "fhesi_host_stage_release",
 ]
-ABI_VERSION = 6          # FHESI_ABI_VERSION of the include/fhesi_hip.h this table was written against (checked in _load)
+ABI_VERSION = 7          # FHESI_ABI_VERSION of the include/fhesi_hip.h this table was written against (checked in _load)
 PROF_CLASSES = {"ntt_fwd": 0, "ntt_inv": 1, "rns_reduce": 2, "tensor": 3, "crt": 4, "digits": 5, "dot": 6, "ew": 7, "ntt_fwd_digits_main": 8}
 
 
@@ -158,6 +158,8 @@ def _load():
         "fhesi_ksk_broadcast": [_vp, _vp, _i32],
         "fhesi_comm_broadcast_dev": [_vp, _vp, _vp, C.c_size_t, _i32],
         "fhesi_comm_exchange": [_vp, _vp, _vp, _vp],
+        "fhesi_comm_exchange_begin": [_vp, _vp, _vp, _vp],
+        "fhesi_comm_exchange_end": [_vp, _vp],
         "fhesi_comm_allreduce_rows": [_vp, _vp, _vp, _i64],
         "fhesi_ksk_download": [_vp, _vp],
         "fhesi_keyswitch_init_batch": [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp],
@@ -689,6 +691,15 @@ class Comm:
     def exchange(self, ctx: Context, base: DevBuf, offsets_words):
         off = np.ascontiguousarray(offsets_words, dtype=np.int64)
         _ck(_load().fhesi_comm_exchange(ctx.h, self.h, base.ptr, _p(off)))
+
+    def exchange_begin(self, ctx: Context, base: DevBuf, offsets_words):
+        """the exchange enqueued on the communicator's own stream behind the context's stream; returns without waiting for the GPU"""
+        off = np.ascontiguousarray(offsets_words, dtype=np.int64)
+        _ck(_load().fhesi_comm_exchange_begin(ctx.h, self.h, base.ptr, _p(off)))
+
+    def exchange_end(self, ctx: Context):
+        """every exchange begun since the last end has landed"""
+        _ck(_load().fhesi_comm_exchange_end(ctx.h, self.h))
 
     def allreduce_rows(self, ctx: Context, rows: DevBuf, count: int):
         _ck(_load().fhesi_comm_allreduce_rows(ctx.h, self.h, rows.ptr, count))

@@ -79,16 +79,11 @@ static const OptDesc kOptions[] = {
   {"wave_single", "FHESI_WAVE_SINGLE", offsetof(CtxOptions, wave_single), false},
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
   {"tensor_bits", "FHESI_TENSOR_BITS", offsetof(CtxOptions, tensor_bits), false},
-  {"digit_group", "FHESI_DIGIT_GROUP", offsetof(CtxOptions, digit_group), false},
-  {"dot32_parts", "FHESI_DOT32_PARTS", offsetof(CtxOptions, dot32_parts), false},
+  {"crt_compiled", "FHESI_CRT_COMPILED", offsetof(CtxOptions, crt_compiled), false},
   {"dot32_k4", "FHESI_DOT32_K4", offsetof(CtxOptions, dot32_k4), false},
   {"parts_words", "FHESI_PARTS_WORDS", offsetof(CtxOptions, parts_words), false},
-  {"dot32_v3", "FHESI_DOT32_V3", offsetof(CtxOptions, dot32_v3), false},
-  {"dot32_half", "FHESI_DOT32_HALF", offsetof(CtxOptions, dot32_half), false},
-  {"dot32_mfma", "FHESI_DOT32_MFMA", offsetof(CtxOptions, dot32_mfma), false},
   {"automorph_rows", "FHESI_AUTOMORPH_ROWS", offsetof(CtxOptions, automorph_rows), false},
   {"ks_long_keys", "FHESI_KS_LONG_KEYS", offsetof(CtxOptions, ks_long_keys), false},
-  {"dot32_small", "FHESI_DOT32_SMALL", offsetof(CtxOptions, dot32_small), false},
   {"host_chunk", "FHESI_HOST_CHUNK", offsetof(CtxOptions, host_chunk), true},
   {"host_threads", "FHESI_HOST_THREADS", offsetof(CtxOptions, host_threads), false},
 };

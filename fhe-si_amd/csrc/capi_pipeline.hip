@@ -21,7 +21,6 @@ extern "C" int fhesi_ksk_free(fhesi_ksk* k) {
   hipStreamSynchronize(k->ctx->stream);
   hipFree(k->d_rows);
   if (k->d_aux) hipFree(k->d_aux);
-  if (k->d_mfma) hipFree(k->d_mfma);
   if (k->d_aux_consts) hipFree(k->d_aux_consts);
   if (k->d_limb_consts) hipFree(k->d_limb_consts);
   --k->ctx->live_handles;
@@ -621,8 +620,8 @@ static int host_stage_get(fhesi_ctx* c, size_t slot_bytes, HostStage** out) {
 static int host_ptr_kind(const void* p, size_t bytes) {
   hipPointerAttribute_t at;
   if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeArray) return 2;
-  if (at.type != hipMemoryTypeHost) return 0;
+  if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeArray) return 2;
+  if (at.type != hipMemoryTypeHost) return 0;          // (unregistered and MANAGED memory: the CPU can read it -- the staging path, like pageable memory)
   if (bytes > 1) {
     hipPointerAttribute_t end;
     if (hipPointerGetAttributes(&end, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return 0; }

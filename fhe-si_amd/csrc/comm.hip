@@ -72,6 +72,7 @@ struct LoopGroup {
   long generation = 0;
   std::atomic<long> failed_at{-1};     // generation of the closing barrier of a collective in which some rank failed
   std::vector<void*> ptr;
+  std::vector<hipEvent_t> ev;          // exchange_begin: "my shard is complete" on each rank's compute stream
   long barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const long gen = generation;
@@ -98,6 +99,11 @@ struct fhesi_comm {
   nccl_comm_t nccl = nullptr;          // RCCL communicator (owned when made by fhesi_comm_init_all)
   bool owns_nccl = false;
   LoopGroup* loop = nullptr;           // loopback group (ranks sharing a device)
+  // fhesi_comm_exchange_begin / _end: the exchanges run on a stream of the communicator's own, behind an event of the compute stream
+  hipStream_t xs = nullptr;
+  hipEvent_t ready = nullptr;
+  int xs_device = -1;
+  int pending = 0;                     // exchanges begun and not yet ended
 };
 
 #define RCCL_TRY(api, expr) do { int r__ = (expr); if (r__ != 0) { fhesi_set_error("%s failed: %s", #expr, (api)->GetErrorString ? (api)->GetErrorString(r__) : "RCCL error"); return 1; } } while (0)
@@ -109,7 +115,7 @@ extern "C" int fhesi_comm_init_all(int32_t ndev, const int32_t* devices, fhesi_c
   if (!distinct) {
     // ranks sharing a device: RCCL rejects duplicate GPUs, so this group moves its bytes with device copies (plumbing checks on a 1-GPU box)
     LoopGroup* g = new LoopGroup();
-    g->nranks = ndev; g->refs = ndev; g->ptr.assign(ndev, nullptr);
+    g->nranks = ndev; g->refs = ndev; g->ptr.assign(ndev, nullptr); g->ev.assign(ndev, nullptr);
     for (int i = 0; i < ndev; ++i) { fhesi_comm* c = new fhesi_comm(); c->rank = i; c->nranks = ndev; c->loop = g; comms_out[i] = c; }
     return 0;
   }
@@ -135,6 +141,8 @@ extern "C" int fhesi_comm_from_rccl(void* nccl_comm, fhesi_comm** out) {
 
 extern "C" int fhesi_comm_destroy(fhesi_comm* c) {
   if (!c) return 0;
+  if (c->xs) { hipSetDevice(c->xs_device); hipStreamSynchronize(c->xs); hipStreamDestroy(c->xs); }
+  if (c->ready) hipEventDestroy(c->ready);
   if (c->nccl && c->owns_nccl) { RcclApi* api = rccl(); if (api) api->CommDestroy(c->nccl); }
   if (c->loop) { bool last; { std::lock_guard<std::mutex> lk(c->loop->mu); last = --c->loop->refs == 0; } if (last) delete c->loop; }
   delete c;
@@ -224,6 +232,76 @@ extern "C" int fhesi_comm_exchange(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* b
   }
   RCCL_TRY(api, api->GroupEnd());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// The same exchange in two halves, so that a rank can go on computing while its finished shard travels (the waves of Regression::Regress,
+// Regression.h:102-149 over Matrix.cpp:182-263: a wave's outputs are needed by the NEXT wave only, so a wave cut into chunks can exchange
+// chunk k while chunk k + 1 is computed).
+//   begin: the exchange of [offsets[0], offsets[G]) is ENQUEUED on the communicator's own stream behind everything already on the
+//          context's stream (an event, no host wait); the context's stream is free for further launches at once.  Every rank of the
+//          group calls begin for the same exchanges in the same order.
+//   end:   returns when every exchange begun since the last end has landed in THIS rank's buffer (and, in a loopback group, in every
+//          rank's); later work on the context's stream may read all of it.
+static int comm_xs(fhesi_ctx* ctx, fhesi_comm* c) {
+  if (c->xs) return 0;
+  HIP_TRY(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+  c->xs_device = ctx->device;
+  return 0;
+}
+extern "C" int fhesi_comm_exchange_begin(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* base_dev, const int64_t* offsets_words) {
+  if (!ctx || !comm || !offsets_words) FHESI_FAIL("exchange_begin: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (comm->nranks == 1 && !comm->nccl) return 0;
+  FHESI_TRY(comm_xs(ctx, comm));
+  HIP_TRY(hipEventRecord(comm->ready, ctx->stream));          // my shard is complete when this event fires
+  if (comm->loop) {
+    LoopGroup* g = comm->loop;
+    int rc = 0;
+    g->ptr[comm->rank] = base_dev;
+    g->ev[comm->rank] = comm->ready;
+    g->barrier();                                               // (host side only: nobody waits for the GPU here)
+    for (int r = 0; r < comm->nranks && !rc; ++r) {
+      const i64 lo = offsets_words[r], hi = offsets_words[r + 1];
+      if (r == comm->rank || hi <= lo) continue;
+      HIP_SOFT(rc, hipStreamWaitEvent(comm->xs, g->ev[r], 0));  // rank r's shard is complete before it is read
+      HIP_SOFT(rc, hipMemcpyAsync(base_dev + lo, (const u64*)g->ptr[r] + lo, (size_t)(hi - lo) * 8, hipMemcpyDeviceToDevice, comm->xs));
+    }
+    ++comm->pending;
+    return g->close(rc);                                        // every wait is enqueued: the events may be recorded again
+  }
+  RcclApi* api = rccl();
+  if (!api) FHESI_FAIL("exchange_begin: librccl.so.1 could not be loaded");
+  HIP_TRY(hipStreamWaitEvent(comm->xs, comm->ready, 0));
+  const i64 each = offsets_words[1] - offsets_words[0];
+  bool uniform = each > 0;
+  for (int r = 0; r < comm->nranks && uniform; ++r) uniform = offsets_words[r + 1] - offsets_words[r] == each;
+  ++comm->pending;
+  if (uniform) {
+    RCCL_TRY(api, api->AllGather(base_dev + offsets_words[comm->rank], base_dev + offsets_words[0], (size_t)each, kNcclUint64, comm->nccl, comm->xs));
+    return 0;
+  }
+  RCCL_TRY(api, api->GroupStart());
+  for (int r = 0; r < comm->nranks; ++r) {
+    const i64 lo = offsets_words[r], hi = offsets_words[r + 1];
+    if (hi <= lo) continue;
+    RCCL_TRY(api, api->Broadcast(base_dev + lo, base_dev + lo, (size_t)(hi - lo), kNcclUint64, r, comm->nccl, comm->xs));
+  }
+  RCCL_TRY(api, api->GroupEnd());
+  return 0;
+}
+extern "C" int fhesi_comm_exchange_end(fhesi_ctx* ctx, fhesi_comm* comm) {
+  if (!ctx || !comm) FHESI_FAIL("exchange_end: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!comm->pending) return 0;
+  comm->pending = 0;
+  if (comm->loop) {
+    int rc = 0;
+    HIP_SOFT(rc, hipStreamSynchronize(comm->xs));
+    return comm->loop->close(rc);            // every rank has read every shard: the buffers may be reallocated
+  }
+  HIP_TRY(hipStreamSynchronize(comm->xs));
   return 0;
 }
 

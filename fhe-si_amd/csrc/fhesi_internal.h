@@ -71,7 +71,6 @@ struct CtxOptions {
   long long host_chunk = 0;  // ciphertexts per stage of the host-buffer pipeline of fhesi_ct_mul_relin_batch (0 = derived from the batch)
   int host_threads = 0;     // threads that copy between the caller's pageable buffers and the pinned ring (0 = min(8, hardware threads): 8 measured best, profiles/r04_host_buffers.txt)
   int ks_long_keys = 0;     // 1: limbs cut from the key coefficient in [0, P) whatever its size (the general form; A/B and checker of the centred limbs)
-  int dot32_small = 0;      // key switch with at most 8 limbs (A/B): 0 = the plain 8-wave form (default), 1 = two groups of four waves on half of the tile's ciphertexts each, 2 = workgroups of four waves on tiles of 4 ciphertexts
   int ks_direct = 0;        // 1: per-chain-prime key-switch dot product (the reference's structure) instead of the auxiliary-prime path
   int ks_residues = 0;      // 1: auxiliary-prime key switch in residue mode (no limb mode)
   int ks_aux60 = 0;         // 1: two 60-bit auxiliary primes even where the four 30-bit primes apply
@@ -82,15 +81,11 @@ struct CtxOptions {
   long long batch_chunk = 0;      // ciphertexts per pipeline chunk (0 = derived from the ring)
   long long wave_operands = 0;    // distinct operands per pass of fhesi_ct_mul_sum_relin_dev (0 = about 4 GiB of rows)
   int wave_single = 1;      // 1: a wave whose groups are single products takes the batch pipeline of fhesi_ct_mul_relin_batch_dev on gathered operands (0: the sum kernels, the checker)
-  int dot32_mfma = 0;       // 1: the dot product on the int8 matrix cores (experimental; metric shape only: rows of 2^14, ncol <= 96, <= 16 limbs)
-  int dot32_half = 1;       // 1: dot32_kernel2<.., HALF>: tiles of 32 coefficients, two limbs per wave, two workgroups per CU (0: round 2's first form, one 135 KB workgroup per CU)
-  int dot32_v3 = 0;         // 1: dot32_kernel3 (two limbs per wave, 4 ciphertexts per tile, two workgroups per CU)
   int automorph_rows = 0;   // 1: Ciphertext >>= through DoubleCRT::automorph on evaluation rows (the reference's structure) even where the coefficient gather applies
   int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)
+  int crt_compiled = 1;     // 1: the tensor half's CRT on the reference drivers' own shapes (m = p - 1, logQ = 512 / 341) runs its compiled form (crt32_scale_fold_kernel); 0: the run-time form (crt32_scale_generic_kernel: A/B and checker)
   int tensor_bits = 30;     // 30: the tensor half's primes are the largest below 2^30; 29: below 2^29 -- lazy values have room up to 8p, so the row transforms skip 8 of 14 (forward) / 6 of 13 (inverse) range steps, for one or two primes more (36 instead of 35 at the metric ring)
-  int dot32_k4 = 1;         // 1: key switch with 7 or 8 limbs and at least 8 ciphertexts per call runs dot32_kernel4 (keys in LDS, digits and accumulators in registers); 0: dot32_kernel2 (A/B)
-  int dot32_parts = 1;      // 1: more columns than an 80 KB tile of 8 ciphertexts holds (the stress ring) are taken in two parts by dot32_kernel2p; 0: tiles of 4 ciphertexts (round 4: A/B)
-  int digit_group = 1;      // units (digit polynomials) per XCD group of the 32-bit digit transform: 1 = single units (default: the order of rounds 2-4); -1 = one polynomial's digits per XCD when the launch has >= 32 polynomials (source rows leave HBM once: FETCH_SIZE 3.4x lower, the kernel 1.6 % SLOWER, profiles/r05_ab_digit_fwd.txt); g > 1 = groups of g units
+  int dot32_k4 = 1;         // 1: key switch with 7 or 8 limbs and at least 24 ciphertexts per call runs dot32_kernel4 (keys in LDS, digits and accumulators in registers); 0: dot32_kernel2 (A/B)
   int parts_words = 1;      // 1: inside the fused multiplication the scaled-down parts travel as 32-bit word rows (crt32_scale -> digit loader); 0 = 64-bit limb rows (A/B)
 };
 
@@ -194,9 +189,6 @@ struct fhesi_ksk {
   bool aux_centred = false;
   int aux_key_bits = 0;                // nb of the matrix the table was built from (measured on the device at build time)
   int aux_long_opt = 0;                // option ks_long_keys at build time (a change rebuilds the table)
-  void* d_mfma = nullptr;              // (option dot32_mfma) the aux32 table as signed bytes in the int8 matrix-core operand layout + column sums (kernels_aux32.hip)
-  size_t mfma_bytes = 0;
-  bool mfma_valid = false;
   bool aux32 = false;                  // the table holds residues modulo the four 30-bit primes of kernels_aux32.hip (u32, 2^14-point rows)
   i64 aux_fold = 0;                    // q' when the rows are linear convolutions to be folded modulo X^q' + 1 and Phi_m (ctx->lin_q), -m for a prime m (modulo X^m - 1 and Phi_m), else 0
   u64* d_limb_consts = nullptr;        // [W+1] offset constant D, [2] floor(2^(64(W-2)+128) / P), then the quotient bound's bit count

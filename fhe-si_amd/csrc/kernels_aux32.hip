@@ -200,14 +200,8 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   if (units > 0x7fffffff) FHESI_FAIL("ntt32: too many digit rows per launch");
   if (digit_bits > 30) FHESI_FAIL("ntt32: digits of %d bits (the first stage of a digit row assumes values below 2p)", digit_bits);
   Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
-  // XCD groups (ntt32_fwd_kernel3), option digit_group: 1 = single units (default), -1 = one polynomial's digits per XCD when that still leaves
-  // every XCD several polynomials, g > 1 = groups of g units
   const int PS = 4 << S;
-  i64 grp = ctx->opt.digit_group < 0 ? (npolys >= 32 ? nd : 1) : std::max<i64>(1, ctx->opt.digit_group);
-  if (A32_LAY_PAIR) grp = 1;
-  src.grp = (u32)grp; src.gb = (u32)(grp * PS); src.gb_inv = div32_inv(src.gb);
-  const i64 ngroups = (units + grp - 1) / grp;
-  const i64 blocks = A32_LAY_PAIR ? (units + 15) / 16 * 2 * 8 * PS : (ngroups + 7) / 8 * 8 * grp * PS;      // groups dealt round-robin to the 8 XCDs, grp * PS workgroups each
+  const i64 blocks = (units + 7) / 8 * 8 * PS;      // units dealt round-robin to the 8 XCDs, PS workgroups (primes x sub-blocks) each
   if (blocks > 0x7fffffff) FHESI_FAIL("ntt32: too many workgroups per launch");
 #define A32_DIG_GO(SS, PP, WW) do { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, (ntt32_fwd_kernel3<true, SS, PP, Aux32Primes, true, WW>)); \
     ntt32_fwd_kernel3<true, SS, PP, Aux32Primes, true, WW><<<(unsigned)blocks, A32_T, 0, ctx->stream>>>(d_out, npolys * nd, 4, 0, x->pr, x->d_fwd, src, x->hd); } while (0)
@@ -319,9 +313,6 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 // halves read the same LDS words, which the LDS broadcasts).  Same multiply-adds per key word and per LDS read, but the tile is half
 // as large (66 KB at the metric shape) and the workgroup has half the waves: TWO workgroups share a CU and the tile load, the barrier
 // and the ragged end of one overlap the arithmetic of the other (with one 135 KB workgroup per CU the VALU sat idle 37 % of the time).
-#ifndef DOT32_MASK_IDLE
-#define DOT32_MASK_IDLE 1
-#endif
 // CSPLIT (few limbs: NLB <= 2 NW / CSPLIT in the HALF form): the waves form CSPLIT groups, every group walks the limbs for its own CT / CSPLIT
 // ciphertexts of the tile -- with 7 limbs (centred limbs of a generated matrix) and CSPLIT = 2 all eight waves carry multiply-adds where the plain
 // form leaves waves 4 .. 7 without a limb.  A key word then feeds CT / CSPLIT ciphertexts per wave (the second group's loads hit in L1 / L2).
@@ -345,7 +336,6 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   const int ct0 = (int)tile * CT;
   const u32 p = pr.p[a], twop = 2 * p;
 #define DL32(k, c) (((((k) * CT) + (c)) << LG) + ln)
-#if !(defined(DOT32_ABLATE) && (DOT32_ABLATE & 4))   // ablation: no tile load
   {
     // One load instruction moves 1 KiB: lane i takes the 16 bytes = elements 4 (i & 15) .. + 3 of column k0 + (i >> 4) of one ciphertext
     // (four consecutive columns of a ciphertext are contiguous in the tiled digit rows), reduces them and writes them with one
@@ -383,7 +373,6 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
       }
     }
   }
-#endif
   __syncthreads();
   const u32 r48 = (u32)pr.r48[a];                 // 2^48 mod p: 30 bits, one multiply-add
   const u32 mont = pr.mont[a];
@@ -393,11 +382,9 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   for (int lw = wl; lw * (HALF ? 2 : 1) < NLB; lw += NWG) {
     const int lraw = HALF ? 2 * lw + (int)(lane >> 5) : lw;          // HALF: the upper lanes of the last wave may have no limb: they repeat the lower one's
     const bool lok = lraw < NLB;
-#if DOT32_MASK_IDLE
     // the half wave without a limb (15 limbs on 16 half waves) leaves the loop: its lanes are masked off for the multiply-adds instead of
     // repeating the neighbour's -- same issue slots, but the step runs at the power limit and idle lanes draw less
     if (HALF && !lok) continue;
-#endif
     const int l = lok ? lraw : NLB - 1;
     const u32* kp0 = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + (HALF ? hf * 32 + ln : lane);      // row r = 0; row 1 follows after ncol slices
     const u32* kp1 = kp0 + ((i64)ncol << 6);
@@ -419,25 +406,15 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     const int nfull = ncol & ~(CH - 1), n2 = ncol & ~(2 * CH - 1);
     u32 xa[2][CH], xb[2][CH];
     auto loadc = [&](u32 (&x)[2][CH], int k0) {
-#if defined(DOT32_ABLATE) && (DOT32_ABLATE & 1)      // ablation: no key loads
-#pragma unroll
-      for (int u = 0; u < CH; ++u) { x[0][u] = (u32)(k0 + u) * 2654435761u + lane; x[1][u] = x[0][u] ^ 0x9e3779b9u; }
-#else
 #pragma unroll
       for (int u = 0; u < CH; ++u) { x[0][u] = kp0[(k0 + u) << 6]; x[1][u] = kp1[(k0 + u) << 6]; }
-#endif
     };
     auto macc = [&](const u32 (&x)[2][CH], int k0) {
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         u32 d[CW];
-#if defined(DOT32_ABLATE) && (DOT32_ABLATE & 2)      // ablation: no LDS reads
-#pragma unroll
-        for (int c = 0; c < CW; ++c) d[c] = x[0][u] + (u32)c * 40503u;
-#else
 #pragma unroll
         for (int c = 0; c < CW; ++c) d[c] = dl32[DL32(k0 + u, c0 + c)];
-#endif
 #pragma unroll
         for (int c = 0; c < CW; ++c) { tot[0][c] += (u64)x[0][u] * d[c]; tot[1][c] += (u64)x[1][u] * d[c]; }
       }
@@ -678,12 +655,23 @@ dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int nco
 #ifndef K4S_PD
 #define K4S_PD 2
 #endif
+// K4_PK: steps between the fetch of a key row and its write to LDS.  Loads return IN ORDER (one vmcnt counter): the wait for the key rows fetched
+// PK steps ago also waits for every digit word requested before them, so the digit ring is never more than PK steps ahead whatever PD says.
+#ifndef K4_PK
+#define K4_PK 2
+#endif
+#ifndef K4_PD7
+#define K4_PD7 3
+#endif
+#ifndef K4_CW7
+#define K4_CW7 6
+#endif
 template <int NLBT, int CW, int KC, int PD, int NW = 8, int NSP = 1, int TAIL = 0>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, i64 count, u32* __restrict__ out, Aux32Primes pr, int ngroups, int lognsl, int sub_lg) {
   // NSP > 1 (many limbs: 15 at the stress ring): the outputs are split over NSP wave groups -- a wave carries NO = NOUT / NSP outputs of its CW
   // ciphertexts, the NSP waves of a ciphertext group load the same digit words (the second load hits in L1 / L2)
-  constexpr int NOUT = 2 * NLBT, NO = NOUT / NSP, NHA = (NO + 1) / 2, NHB = NO - NHA, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = 2;
+  constexpr int NOUT = 2 * NLBT, NO = NOUT / NSP, NHA = (NO + 1) / 2, NHB = NO - NHA, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = K4_PK;
   static_assert(NOUT % NSP == 0 && NW % NSP == 0, "output split");
   static_assert(TAIL >= 0 && TAIL < KC && (TAIL == 0 || TAIL >= PK), "tail chunk");
   static_assert(KC <= 12 && KC % PD == 0 && KC % PK == 0, "ring slots are compile-time; KC products on top of a folded total stay below 2^64");
@@ -845,7 +833,6 @@ _Pragma("unroll") \
 
 int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, int NLB, void* d_tmp, bool centred) {
   FHESI_TRY(aux32_init(ctx));
-  k->mfma_valid = false;
   const int ncol = k->ncomp * k->ndigits;
   const i64 rows_per_a = (i64)NLB * 2 * ncol, nrow = aux32_row_len(ctx);
   u32* rows32 = (u32*)k->d_aux;
@@ -865,153 +852,6 @@ int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, in
 }
 
 // d_dig: tiled [4][n/64][count*ncol][64] u32; d_out: [count*2*NLB][4][n] u32
-// ---- third form: a wave owns TWO limbs (LP = 2) and both key rows of each, so one digit value read from LDS feeds four multiply-adds
-// and the tile is half as tall (CT = 4: 66 KB at the metric shape): TWO workgroups of 8 waves share a CU, the tile load and the
-// barriers of one overlap the arithmetic of the other.  The price is twice the key words through L2 per multiply-add (CT halved).
-template <int CT, int NW, int LP>
-__global__ void __launch_bounds__(NW * 64, 4) dot32_kernel3(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                            u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl, int sub_ct) {
-  extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT/4][64 lanes][4]
-  static_assert(CT == 4, "one 16-byte LDS read per column");
-  const u32 lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  u32 b = blockIdx.x;
-  const u32 s_lo = b & 7; b >>= 3;
-  const u32 tile = b % (u32)ntiles; b /= (u32)ntiles;
-  const u32 s_hi = b % (u32)nsl8;
-  const int a = (int)(b / (u32)nsl8);
-  const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64;
-  const i64 ct0 = (i64)tile * CT;
-  const u32 p = pr.p[a], twop = 2 * p;
-#define DL32(k, c) ((((k) * (CT / 4) + ((c) >> 2)) * 64 + lane) * 4 + ((c) & 3))
-  const i64 sub = ct0 / sub_ct, ct_in = ct0 - sub * sub_ct, rest = count - sub * sub_ct, cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
-  const u32* dtile = dig + sub * sub_ct * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + ct_in * ncol) * 64 + lane;
-  for (int k0 = w * 2; k0 < ncol; k0 += NW * 2) {       // two columns (8 loads) per wave and round
-    u32 v[2][CT];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int c = 0; c < CT; ++c) v[u][c] = (k0 + u < ncol && ct0 + c < count) ? __builtin_nontemporal_load(&dtile[((i64)c * ncol + k0 + u) << 6]) : 0;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (k0 + u < ncol) {
-        uint4 q;
-        u32 x;
-        x = v[u][0]; x = x >= twop ? x - twop : x; q.x = x >= p ? x - p : x;
-        x = v[u][1]; x = x >= twop ? x - twop : x; q.y = x >= p ? x - p : x;
-        x = v[u][2]; x = x >= twop ? x - twop : x; q.z = x >= p ? x - p : x;
-        x = v[u][3]; x = x >= twop ? x - twop : x; q.w = x >= p ? x - p : x;
-        *reinterpret_cast<uint4*>(&dl32[DL32(k0 + u, 0)]) = q;
-      }
-  }
-  __syncthreads();
-  const u32 r48 = (u32)pr.r48[a];                 // 2^48 mod p: 30 bits, one multiply-add
-  const u32 mont = pr.mont[a];
-  for (int l0 = w; l0 < NLB; l0 += NW * LP) {
-    // limbs l0 and l0 + NW (the second one may not exist: its arithmetic then repeats the first limb's and nothing is stored)
-    const u32* kp[LP][2];
-#pragma unroll
-    for (int j = 0; j < LP; ++j) {
-      const int l = l0 + j * NW < NLB ? l0 + j * NW : l0;
-      kp[j][0] = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + lane;
-      kp[j][1] = kp[j][0] + ((i64)ncol << 6);
-    }
-    u64 tot[LP][2][CT];
-    u32 th[LP][2][CT];
-#pragma unroll
-    for (int j = 0; j < LP; ++j)
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) { tot[j][r][c] = 0; th[j][r][c] = 0; }
-    auto fold = [&]() {
-#pragma unroll
-      for (int j = 0; j < LP; ++j)
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) { th[j][r][c] += (u32)(tot[j][r][c] >> 48); tot[j][r][c] &= 0x0000ffffffffffffull; }
-    };
-    constexpr int CH = 4;
-    const int nfull = ncol & ~(CH - 1), n2 = ncol & ~(2 * CH - 1);
-    u32 xa[LP][2][CH], xb[LP][2][CH];
-    auto loadc = [&](u32 (&x)[LP][2][CH], int k0) {
-#pragma unroll
-      for (int u = 0; u < CH; ++u)
-#pragma unroll
-        for (int j = 0; j < LP; ++j) { x[j][0][u] = kp[j][0][(k0 + u) << 6]; x[j][1][u] = kp[j][1][(k0 + u) << 6]; }
-    };
-    auto macc = [&](const u32 (&x)[LP][2][CH], int k0) {
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const uint4 q = *reinterpret_cast<const uint4*>(&dl32[DL32(k0 + u, 0)]);
-        const u32 d[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int j = 0; j < LP; ++j)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) { tot[j][0][c] += (u64)x[j][0][u] * d[c]; tot[j][1][c] += (u64)x[j][1][u] * d[c]; }
-      }
-    };
-    if (nfull) loadc(xa, 0);
-    int kb = 0;
-    for (; kb < n2; kb += 2 * CH) {
-      loadc(xb, kb + CH);
-      macc(xa, kb);
-      if (kb + 2 * CH < nfull) loadc(xa, kb + 2 * CH);
-      macc(xb, kb + CH);
-      if (kb & (2 * CH)) fold();                     // 16 columns since the last fold
-    }
-    if (nfull & CH) { macc(xa, kb); }
-    if ((nfull & (3 * CH)) != 0) fold();
-    for (int k = nfull; k < ncol; ++k) {             // at most 3 columns
-      const uint4 q = *reinterpret_cast<const uint4*>(&dl32[DL32(k, 0)]);
-      const u32 d[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-      for (int j = 0; j < LP; ++j) {
-        const u32 x0 = kp[j][0][k << 6], x1 = kp[j][1][k << 6];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) { tot[j][0][c] += (u64)x0 * d[c]; tot[j][1][c] += (u64)x1 * d[c]; }
-      }
-    }
-    fold();
-#pragma unroll
-    for (int j = 0; j < LP; ++j) {
-      const int l = l0 + j * NW;
-      if (l >= NLB) continue;
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          if (ct0 + c < count) {
-            const u64 v = tot[j][r][c] + (u64)th[j][r][c] * r48;      // one Montgomery step, as in dot32_kernel2
-            const u32 mq = (u32)v * mont;
-            u32 o = (u32)((v + (u64)mq * p) >> 32);
-            o = o >= p ? o - p : o;
-            (out + ((((((ct0 + c) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + soff))[lane] = o;
-          }
-        }
-    }
-  }
-#undef DL32
-}
-static int launch_dot32_v3(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
-  constexpr int CT = 4, NW = 8, LP = 2;
-  const size_t shmem = (size_t)ncol * CT * 64 * 4;
-  static std::atomic<unsigned long long> attr_done{0};
-  if (!(attr_done.load() >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel3<CT, NW, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_done.fetch_or(1ull << ctx->device);
-  }
-  const i64 nrow = aux32_row_len(ctx);
-  const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;              // log2 of the 64-element slices per row
-  const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
-  const i64 blocks = (i64)8 * ntiles * nsl8 * 4;
-  if (blocks > 0x7fffffff) FHESI_FAIL("dot32: too many ciphertexts per call");
-  PROF_KERNEL(ctx, PROF_DOT, dot32_kernel3<CT, NW, LP>);
-  dot32_kernel3<CT, NW, LP><<<(unsigned)blocks, NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, (int)kDigitSubCt);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
 template <int CT, int NW, bool HALF, int CSPLIT = 1>
 static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
   const size_t shmem = (size_t)ncol * CT * (HALF ? 32 : 64) * 4;
@@ -1030,226 +870,6 @@ static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, 
   while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
   PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel2<CT, NW, HALF, CSPLIT>));
   dot32_kernel2<CT, NW, HALF, CSPLIT><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, sub_lg);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-// ---- (experimental, option dot32_mfma) the dot product on the int8 matrix cores.  For one coefficient position and prime the dot
-// product of a tile is a dense matrix product with reuse: C[ct][(limb, row)] = sum_k D[ct][k] K[k][(limb, row)].  Both 30-bit operands are
-// cut into four signed bytes (digits: byte - 128, the offset repaid by 128 x the key's column sums; key: balanced bytes, precomputed):
-// rows (byte plane i, ciphertext) = 32, one 32-column block per key byte plane j, depth 66 -> 96 = three v_mfma_i32_32x32x32_i8 per
-// block.  The 16 partial sums of an output are 16 accumulator registers of one lane (C[i][j]: lane j + 32 ((i / 4) mod 2), register
-// 4 (i / 8) + i mod 4), recombined as sum_d t_d (256^d mod p).  DESIGN.md section 8 (1); tools/mfma_dot_plan.py, tools/mfma_dot_tile.hip.
-typedef int v16i_t __attribute__((ext_vector_type(16)));
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-constexpr int MF_KS = 3, MF_E = 16 /* coefficients per workgroup: 66 KB of LDS, two workgroups per CU */, MF_ESTRIDE = MF_KS * 64 * 16 + 16 /* bytes of a coefficient's A operands in LDS, padded */;
-__device__ __forceinline__ int mf_balanced_byte(u32 x, int j) {
-  int carry = 0, b = 0;
-  for (int jj = 0; jj <= j; ++jj) {
-    b = (int)((x >> (8 * jj)) & 255) + carry;
-    if (jj < 3 && b >= 128) { b -= 256; carry = 1; } else carry = 0;
-  }
-  return b;
-}
-// B table [a][coef][MF_KS][4 planes][64 lanes] x 16 bytes, then the column sums [a][coef][4][32] int
-__global__ void mfma_table_kernel(const u32* __restrict__ k32, int ncol, int NLB, int lognsl, i64 n, v4i_t* __restrict__ tb, int* __restrict__ ts) {
-  const i64 nB = (i64)4 * n * MF_KS * 4 * 64, nS = (i64)4 * n * 4 * 32;
-  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < nB + nS; g += (i64)gridDim.x * blockDim.x) {
-    if (g < nB) {
-      const int lane = (int)(g & 63), j = (int)((g >> 6) & 3);
-      const i64 q = g >> 8;
-      const int s = (int)(q % MF_KS);
-      const i64 ac = q / MF_KS, coef = ac % n;
-      const int a = (int)(ac / n), c = lane & 31, l = c >> 1, r = c & 1;
-      u32 w[4] = {0, 0, 0, 0};
-      for (int t = 0; t < 16; ++t) {
-        const int k = 32 * s + 16 * (lane >> 5) + t;
-        int b = 0;
-        if (k < ncol && l < NLB) b = mf_balanced_byte(k32[(((((((i64)a * NLB + l) << lognsl) + (coef >> 6)) * 2 + r) * ncol + k) << 6) + (coef & 63)], j);
-        w[t >> 2] |= (u32)(b & 255) << (8 * (t & 3));
-      }
-      tb[g] = v4i_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-    } else {
-      const i64 h = g - nB;
-      const int c = (int)(h & 31), j = (int)((h >> 5) & 3), l = c >> 1, r = c & 1;
-      const i64 ac = h >> 7, coef = ac % n;
-      const int a = (int)(ac / n);
-      int sum = 0;
-      if (l < NLB)
-        for (int k = 0; k < ncol; ++k) sum += mf_balanced_byte(k32[(((((((i64)a * NLB + l) << lognsl) + (coef >> 6)) * 2 + r) * ncol + k) << 6) + (coef & 63)], j);
-      ts[h] = sum;
-    }
-  }
-}
-struct MfConst { u32 wpow[4][7] /* 256^d mod p */, mu61[4] /* floor(2^61 / p) */; };     // (computed on the host: a 64-bit remainder costs a wave ~100 instructions)
-// G: groups of 8 ciphertexts per tile -- every key operand fetched from L2 feeds G matrix instructions
-template <int G>
-__global__ void __launch_bounds__(256, G == 1 ? 2 : 1) dot_mfma_kernel(const v4i_t* __restrict__ tb, const int* __restrict__ ts, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
-                                                       u32* __restrict__ out, Aux32Primes pr, MfConst mc, int lognsl, int sub_lg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
-  constexpr int CT = 8 * G, QH = 256 / (MF_E * CT);        // QH: threads per (ciphertext, coefficient)
-  const u32 tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const u32 s_lo = blockIdx.x & 7, tile = blockIdx.x >> 3, s_hi = blockIdx.y >> 2, e0 = (blockIdx.y & 3) * MF_E;      // e0: first coefficient within the 64-slice
-  const int a = (int)blockIdx.z;
-  const i64 slice = (i64)(s_hi * 8 + s_lo), n = (i64)64 << lognsl;
-  const int ct0 = (int)tile * CT;
-  const u32 p = pr.p[a], twop = 2 * p;
-  u32* o_lds = reinterpret_cast<u32*>(mf_lds + G * MF_E * MF_ESTRIDE);          // [CT][32 columns][MF_E + 1]
-  // ---- the digit tile: thread (ct = tid >> 5, e = tid & 31) takes the column quads one after the other, reduces the four words below p,
-  //      flips the top bit of every byte (byte - 128 as a signed byte) and writes the four byte planes as words of four consecutive columns
-  {
-    const int sub = ct0 >> sub_lg, sub_ct = 1 << sub_lg, ct_in = ct0 & (sub_ct - 1);
-    const i64 rest = count - ((i64)sub << sub_lg), cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
-    const u32* dbase = dig + ((i64)sub << sub_lg) * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + (i64)ct_in * ncol) * 64;
-    const u32 e = tid & (MF_E - 1), ct = (tid >> 4) % CT, qh = tid / (MF_E * CT);       // (G = 1: the two halves of the workgroup take alternate column quads)
-    const bool cok = ct0 + (int)ct < count;
-    const u32* src = dbase + (((i64)ct * ncol) << 6) + e0 + e;
-    unsigned char* dst = mf_lds + ((ct >> 3) * MF_E + e) * MF_ESTRIDE;
-    // every word of the thread's ciphertext is requested before the first one is used (one memory latency per tile, not one per quad:
-    // with a single workgroup of four waves on the CU nothing else hides it)
-    constexpr int NQ = 8 * MF_KS / QH;                       // the thread's share of the 24 column quads (96 columns)
-    u32 xs[4 * NQ];
-#pragma unroll
-    for (int m = 0; m < NQ; ++m)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int k = 4 * (QH * m + (int)qh) + u; xs[4 * m + u] = (cok && k < ncol) ? __builtin_nontemporal_load(src + ((i64)k << 6)) : 0u; }
-#pragma unroll
-    for (int m = 0; m < NQ; ++m) {
-      const int it = QH * m + (int)qh;
-      if (4 * it >= ncol) break;
-      u32 x[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        u32 t = xs[4 * m + u];
-        t = t >= twop ? t - twop : t; t = t >= p ? t - p : t;
-        x[u] = t ^ 0x80808080u;
-      }
-      const int s = it >> 3, half = (it >> 2) & 1, t0 = 4 * (it & 3);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const u32 sel = (u32)i | ((u32)(4 + i) << 8) | 0x0c0c0000u;
-        const u32 lo16 = __builtin_amdgcn_perm(x[1], x[0], sel), hi16 = __builtin_amdgcn_perm(x[3], x[2], sel);
-        const u32 wd = __builtin_amdgcn_perm(hi16, lo16, 0x05040100u);
-        *reinterpret_cast<u32*>(dst + ((s * 64 + half * 32 + i * 8 + (int)(ct & 7)) * 16) + t0) = wd;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- per wave: 8 of the 32 coefficients, 12 matrix-core instructions each, then the lane-local recombination
-  u32 wpow[7];
-#pragma unroll
-  for (int d = 0; d < 7; ++d) wpow[d] = mc.wpow[a][d];
-  const u32 mu61 = mc.mu61[a];
-  const i64 off = (i64)p << 30;                               // a multiple of p above the magnitude of the signed sum
-  const int c = (int)(lane & 31), h = (int)(lane >> 5);
-  // the key operands of coefficient ee + 1 are fetched while coefficient ee is multiplied and recombined (12 x 16 bytes per lane)
-  const i64 coef0 = slice * 64 + e0 + wv * (MF_E / 4);
-  const v4i_t* bp0 = tb + (((i64)a * n + coef0) * MF_KS * 4) * 64 + lane;
-  const int* sp0 = ts + (((i64)a * n + coef0) * 4) * 32 + c;
-  v4i_t bn[MF_KS * 4];
-  int sn[4];
-#pragma unroll
-  for (int u = 0; u < MF_KS * 4; ++u) bn[u] = bp0[u * 64];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) sn[j] = sp0[j * 32];
-#pragma unroll 1
-  for (int ee = 0; ee < MF_E / 4; ++ee) {
-    const int e = wv * (MF_E / 4) + ee;
-    v4i_t bc[MF_KS * 4];
-    int sj[4];
-#pragma unroll
-    for (int u = 0; u < MF_KS * 4; ++u) bc[u] = bn[u];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sj[j] = 128 * sn[j];
-    if (ee + 1 < MF_E / 4) {
-#pragma unroll
-      for (int u = 0; u < MF_KS * 4; ++u) bn[u] = bp0[((i64)(ee + 1) * MF_KS * 4 + u) * 64];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sn[j] = sp0[((ee + 1) * 4 + j) * 32];
-    }
-    v16i_t acc[G][4];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][j][r] = 0;
-#pragma unroll
-    for (int s = 0; s < MF_KS; ++s) {
-      v4i_t av[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) av[g] = *reinterpret_cast<const v4i_t*>(mf_lds + (g * MF_E + e) * MF_ESTRIDE + (s * 64 + (int)lane) * 16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int g = 0; g < G; ++g) acc[g][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[g], bc[s * 4 + j], acc[g][j], 0, 0, 0);
-    }
-    int cd[7] = {0, 0, 0, 0, 0, 0, 0};                    // the offset term of every diagonal i + j, the same for the four ciphertexts of the lane
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cd[i + j] += sj[j];
-#pragma unroll
-    for (int gq = 0; gq < 4 * G; ++gq) {
-      const int g = gq >> 2, q = gq & 3;
-      int t[7];
-#pragma unroll
-      for (int d = 0; d < 7; ++d) t[d] = cd[d];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t[i + j] += acc[g][j][4 * i + q];
-      i64 v = off;
-#pragma unroll
-      for (int d = 0; d < 7; ++d) v += (i64)t[d] * (i64)wpow[d];
-      const u32 qq = __umulhi((u32)((u64)v >> 29), mu61);
-      u32 r = (u32)v - qq * p;
-      r = r >= twop ? r - twop : r;
-      r = r >= p ? r - p : r;
-      o_lds[((8 * g + 4 * h + q) * 32 + c) * (MF_E + 1) + e] = r;
-    }
-  }
-  __syncthreads();
-  // ---- the rows: 32 consecutive coefficients of (ciphertext, limb, row) per instruction and half wave
-  {
-    const u32 e = tid & (MF_E - 1), ct = (tid >> 4) % CT, r0 = tid / (MF_E * CT);       // (G = 1: the two halves of the workgroup write the two key rows)
-    if (ct0 + (int)ct < count)
-      for (u32 r = r0; r < 2; r += QH)
-      for (int l = 0; l < NLB; ++l)
-        __builtin_nontemporal_store(o_lds[(ct * 32 + 2 * l + r) * (MF_E + 1) + e], &out[((((((i64)(ct0 + (int)ct) * 2 + r) * NLB + l) * 4 + a) << (lognsl + 6)) + slice * 64 + e0 + e)]);
-  }
-}
-template <int G>
-static int launch_dot_mfma(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
-  const i64 n = aux32_row_len(ctx);
-  const int lognsl = A32_LOGN - 6, NLB = k->aux_rows;
-  const size_t nB = (size_t)4 * n * MF_KS * 4 * 64 * 16, nS = (size_t)4 * n * 4 * 32 * 4;
-  if (!k->mfma_valid) {
-    if (k->d_mfma && k->mfma_bytes < nB + nS) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(k->d_mfma)); k->d_mfma = nullptr; }
-    if (!k->d_mfma) { HIP_TRY(hipMalloc(&k->d_mfma, nB + nS)); k->mfma_bytes = nB + nS; }
-    mfma_table_kernel<<<4096, 256, 0, ctx->stream>>>((const u32*)k->d_aux, ncol, NLB, lognsl, n, (v4i_t*)k->d_mfma, (int*)((char*)k->d_mfma + nB));
-    HIP_TRY(hipGetLastError());
-    k->mfma_valid = true;
-  }
-  const size_t shmem = (size_t)G * MF_E * MF_ESTRIDE + (size_t)8 * G * 32 * (MF_E + 1) * 4;
-  static std::atomic<unsigned long long> attr_done{0};
-  if (!(attr_done.load() >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot_mfma_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done.fetch_or(1ull << ctx->device);
-  }
-  const int ntiles = (int)((count + 8 * G - 1) / (8 * G));
-  int sub_lg = 0;
-  while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
-  MfConst mc;
-  for (int a = 0; a < 4; ++a) {
-    const u64 p = ctx->aux32->pr.p[a];
-    u64 w = 1;
-    for (int d = 0; d < 7; ++d) { mc.wpow[a][d] = (u32)w; w = (w * 256) % p; }
-    mc.mu61[a] = (u32)(((u64)1 << 61) / p);
-  }
-  PROF_KERNEL(ctx, PROF_DOT, dot_mfma_kernel<G>);
-  dot_mfma_kernel<G><<<dim3((unsigned)(8 * ntiles), (unsigned)((n / 64 / 8) * (64 / MF_E)), 4), 256, shmem, ctx->stream>>>((const v4i_t*)k->d_mfma, (const int*)((const char*)k->d_mfma + nB), d_dig, ncol, NLB, count, d_out,
-                                                                                                    ctx->aux32->pr, mc, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1300,42 +920,28 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   *mont = true;
   if (!count) return 0;
   ProfScope prof(ctx, PROF_DOT, (double)count);
-  if (ctx->opt.dot32_mfma && aux32_row_len(ctx) == A32_N && ncol <= 32 * MF_KS && k->aux_rows <= 16) { *mont = false; return ctx->opt.dot32_mfma == 2 ? launch_dot_mfma<2>(ctx, k, d_dig, ncol, count, d_out) : launch_dot_mfma<1>(ctx, k, d_dig, ncol, count, d_out); }
-  if (ctx->opt.dot32_v3 && (size_t)ncol * 4 * 256 <= 80 * 1024) return launch_dot32_v3(ctx, k, d_dig, ncol, count, d_out);
-  // ciphertexts per LDS tile: 8 while ncol * 8 digit slices fit (half slices of 128 bytes in 80 KiB, two workgroups per CU; whole slices
-  // of 256 bytes in 160 KiB with option dot32_half = 0): ncol <= 80; else 4 (ncol <= 160)
-  // at most 8 limbs (centred limbs of a generated matrix: 7 at the metric ring): four of the eight waves carry them all, two each.  Measured at
-  // the metric ring (profiles/r04_ab_dot_few_limbs.txt, ms per launch of 1024): the plain 8-wave form 6.4-6.7 (waves 4 .. 7 only help to load the
-  // tile), two groups of four waves on half the ciphertexts each 7.0, workgroups of four waves on tiles of 4 / 8 ciphertexts 6.8 / 6.9, tiles of 16
-  // 7.4-7.8: with half the multiply-adds gone the kernel runs at the rate the L2 delivers the key words (80 GB per launch through L2 -> L1),
-  // so the plain form stays; option dot32_small selects the others (A/B)
   // keys in LDS, digits in registers (dot32_kernel4): the limb counts of generated matrices at the benchmark rings
   bool k4_primes = true;                    // dot32_kernel4 folds through 2^32 mod p = 2^32 - 4p and needs it below 2^26 (true of every prime aux32_init picks; any other ring takes the LDS-tile kernels)
   for (int a = 0; a < 4; ++a) k4_primes = k4_primes && ctx->aux32->pr.p[a] < (1u << 30) && (u32)(0u - 4u * ctx->aux32->pr.p[a]) < (1u << 26);
-  if (ctx->opt.dot32_k4 && count >= 24 && !ctx->opt.dot32_small && k4_primes) {
-#ifndef K4_NO_TAIL
-    if (k->aux_rows == 7 && ncol % 12 == 6) return launch_dot32_k4<7, 6, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);      // (66 columns = 5 x 12 + 6: the tail compiled on its own)
-#endif
-    if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)
-#ifndef K4_NO_TAIL
+  if (ctx->opt.dot32_k4 && count >= 24 && k4_primes) {
+    if (k->aux_rows == 7 && ncol % 12 == 6) return launch_dot32_k4<7, K4_CW7, 12, K4_PD7, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);      // (66 columns = 5 x 12 + 6: the tail compiled on its own)
+    if (k->aux_rows == 7) return launch_dot32_k4<7, K4_CW7, 12, K4_PD7>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)
     if (k->aux_rows == 8 && ncol % 12 == 6) return launch_dot32_k4<8, 4, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);
-#endif
     if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (5 ciphertexts per lane: 160 bytes of spills -- odd counts leave the 64-bit pairs badly placed)
     // 15 limbs (the stress ring): the 30 outputs split over two wave groups (with all 30 in one lane only 3 ciphertexts fit: 81 ms per 1024 against 37.6 for dot32_kernel2p)
+#if defined(K4S_KC) && defined(K4S_TAIL)
+    if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1 && ncol % K4S_KC == K4S_TAIL) return launch_dot32_k4<15, K4S_CW, K4S_KC, K4S_PD, 8, 2, K4S_TAIL>(ctx, k, d_dig, ncol, count, d_out);
+#endif
     if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1) return launch_dot32_k4<15, K4S_CW, 8, K4S_PD, 8, 2>(ctx, k, d_dig, ncol, count, d_out);
   }
-  if (ctx->opt.dot32_half && k->aux_rows <= 8 && ctx->opt.dot32_small != 0) {
-    if (ctx->opt.dot32_small == 1 && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true, 2>(ctx, k, d_dig, ncol, count, d_out);      // two wave groups of four ciphertexts each
-    if (ctx->opt.dot32_small == 2 && (size_t)ncol * 4 * 128 <= 40 * 1024) return launch_dot32_t<4, 4, true>(ctx, k, d_dig, ncol, count, d_out);          // four workgroups of four waves per CU
-  }
-  if (ctx->opt.dot32_half && (size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true>(ctx, k, d_dig, ncol, count, d_out);
-  // (the stress ring's 129 columns with tiles of 8 ciphertexts in 132 KB, one workgroup per CU -- half the key words per multiply-add -- measured
-  // 43.1 ms against 42.0 ms for the tiles of 4 below: profiles/r04_ab_dot_few_limbs.txt)
-  // ... the columns in two parts through an 80 KB tile of 8 ciphertexts (dot32_kernel2p): both, the 8-fold reuse of a key word and two workgroups per CU
-  if (ctx->opt.dot32_half && ctx->opt.dot32_parts && k->aux_rows <= 16 && (size_t)((((ncol + 1) / 2) + 7) & ~7) * 8 * 128 <= 80 * 1024) return launch_dot32_p<8, 8, 2>(ctx, k, d_dig, ncol, count, d_out);
-  if ((size_t)ncol * 8 * 256 <= 160 * 1024) return launch_dot32_t<8, 16, false>(ctx, k, d_dig, ncol, count, d_out);
-  if (ctx->opt.dot32_half && (size_t)ncol * 4 * 128 <= 80 * 1024) return launch_dot32_t<4, 8, true>(ctx, k, d_dig, ncol, count, d_out);
-  if ((size_t)ncol * 4 * 256 <= 160 * 1024) return launch_dot32_t<4, 16, false>(ctx, k, d_dig, ncol, count, d_out);
+  // the digit-tile forms (dot32_kernel2): tiles of 32 coefficients x 8 ciphertexts x all columns in 80 KB, two workgroups per CU (ncol <= 80);
+  // more columns (the stress ring's 129) in two parts through one such tile (dot32_kernel2p: the 8-fold reuse of a key word AND two workgroups
+  // per CU); matrices with more than 16 limbs (general limbs at the stress ring) in tiles of 4 ciphertexts (ncol <= 160).  The forms measured
+  // slower and removed in round 6 -- whole-slice tiles in one 135 KB workgroup, groups of four waves for few limbs, two limbs per wave on tiles
+  // of 4 (dot32_kernel3), the int8 matrix-core product (dot_mfma_kernel) -- are in the history of this file and in profiles/HISTORY.md.
+  if ((size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true>(ctx, k, d_dig, ncol, count, d_out);
+  if (k->aux_rows <= 16 && (size_t)((((ncol + 1) / 2) + 7) & ~7) * 8 * 128 <= 80 * 1024) return launch_dot32_p<8, 8, 2>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 4 * 128 <= 80 * 1024) return launch_dot32_t<4, 8, true>(ctx, k, d_dig, ncol, count, d_out);
   FHESI_FAIL("dot32: %d columns do not fit the LDS tile", ncol);
 }
 

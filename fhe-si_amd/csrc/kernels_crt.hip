@@ -321,7 +321,6 @@ __device__ __forceinline__ void crt_store_fixed(const u64 (&x)[MAXW], int mode, 
       // block -- through LDS rows of their own and store 512 contiguous bytes per instruction; a lane's direct stores touch 32-64 cache lines
       // per instruction for 8-16 bytes each (round 5, as ks_recombine_centred_kernel: -0.5 ms per 1024 there)
       constexpr int NLQ = (LQ + 63) >> 6;
-#ifndef KS_STORE_DIRECT
       if (nl_out == NLQ && NLQ <= MAXW && (NLQ & (NLQ - 1)) == 0 && (n & 63) == 0 && (blockDim.x & 63) == 0) {
         __shared__ u64 stg[4][64 * (NLQ + 1)];
         const u32 lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
@@ -341,7 +340,6 @@ __device__ __forceinline__ void crt_store_fixed(const u64 (&x)[MAXW], int mode, 
           return;
         }
       }
-#endif
       u64* o = out + (poly * n + j) * nl_out;
 #pragma unroll
       for (int i = 0; i < MAXW; ++i) {
@@ -1121,7 +1119,6 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
   // for 8-16 bytes each.  When the wave is whole (n a multiple of 64) and the caller's limb count is the kernel's, the wave's 64 x NWORDS limbs --
   // one contiguous block of memory -- pass through its own LDS rows (stride NWORDS + 1: conflict-free) and leave 512 contiguous bytes per
   // store instruction (round 5: the kernel was 43 % VALU busy at 3.7 TB/s).
-#ifndef KS_STORE_DIRECT
   if (nl_out == NWORDS && (n & 63) == 0) {
     __shared__ u64 stg[2][64 * (NWORDS + 1)];
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1137,7 +1134,6 @@ __global__ void __launch_bounds__(128) ks_recombine_centred_kernel(const u32* __
     }
     return;
   }
-#endif
 #pragma unroll
   for (int i = 0; i < NWORDS; ++i) if (i < nl_out) o[i] = x[i];
   for (int i = NWORDS; i < nl_out; ++i) o[i] = hbit ? ~0ull : 0ull;

@@ -330,12 +330,8 @@ template <int NL>
 __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const u32* __restrict__ t) {
   const u32 r32 = t[2 * NL + 1], mu = t[2 * NL + 2], p = t[2 * NL + 3];
   // products below 2^62 - 2^47: four fit a 64-bit accumulator, three on top of a folded value (below 2^62 + 2^32)
-#ifndef RNS32_CHAIN
-#define RNS32_CHAIN 1
-#endif
   u64 acc = 0;
   int room = 4;
-#if RNS32_CHAIN
   // ONE dependency chain of v_mad_u64_u32 (the table words from their scalar registers): written as plain C++ the compiler splits the sum into
   // five independent groups and joins them with 64-bit adds and moves -- 38 instructions per prime where the chain needs 32; the latency
   // of the chain is covered by the other waves (34 registers: full occupancy)
@@ -352,18 +348,6 @@ __device__ __forceinline__ u32 rns32_one(const u32 (&x)[2 * NL], u32 neg, const 
   // (primes of 29 bits: sh = 28 -- one fold leaves the total below 2^60 when 2^32 mod p = 8 (2^29 - p) is below 2^27, the second fold otherwise)
   const u32 sh = t32_shift(p);
   if (r32 >= (1u << (sh - 1))) acc = mad64s((u32)(acc >> 32), r32, (u64)(u32)acc);       // below 2^(32 + sh)
-#else
-#pragma unroll
-  for (int k = 0; k < 2 * NL; ++k) {
-    if (room == 0) { acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc; room = 3; }
-    acc += (u64)x[k] * t[k];
-    --room;
-  }
-  acc += neg ? t[2 * NL] : 0u;
-  acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^62 + 2^32
-  acc = (u64)(u32)(acc >> 32) * r32 + (u32)acc;       // below 2^61
-  const u32 sh = t32_shift(p);
-#endif
   const u32 q = __umulhi((u32)(acc >> sh), mu);        // at most 2 below floor(acc / p)
   return (u32)acc - q * p;                             // below 3p
 }
@@ -713,6 +697,125 @@ __global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __r
   }
 }
 
+// The run-time form above with everything that can be a constant made one -- for the shapes the reference's own drivers produce at scale
+// (Test_AddMul.cpp:131 / Test_Regression.cpp:100-122: m = p - 1 for a safe prime, so FOLD = 1): logQ, the window of words [J0, J0 + NW) and the
+// bit positions of the output limbs are compile-time, so the words stay in registers from the multiply-adds to the limbs (no LDS round trip,
+// no run-time shifts), exactly as in crt32_scale_kernel; the loader (positions folded from, sub-rows of a 2^15-point row) is the run-time
+// form's.  LQ need not be a multiple of 64 (configs[3]: logQ = 341): the top limb is masked.  wt: words per table row (run-time: it depends
+// on the prime count of the configuration).
+template <int LQ, bool EXACT, int S, int FOLD>
+__global__ void __launch_bounds__(128) crt32_scale_fold_kernel(const u32* __restrict__ rows, i64 nrow, i64 n_out, i64 fold_off, int NP, int wt, T32Primes pr,
+                                                                const Tw32* __restrict__ cinv, const u32* __restrict__ inv57, const u32* __restrict__ Mw,
+                                                                u64* __restrict__ out, unsigned char* __restrict__ flags, int wm) {
+  constexpr int R = 28;
+  constexpr int WU = (2 * LQ + R - 1) / R;            // words that reach below bit 2 logQ
+  constexpr int J0 = (EXACT || LQ < 64 + 38) ? 0 : (LQ - 64 - 30 - 8) / R;     // first word formed: R J0 + 30 + log2(NP + 1) + 1 <= logQ - 64
+  constexpr int NW = WU - J0, NLQ = (LQ + 63) / 64;
+  static_assert(LQ >= 64 && FOLD >= 0 && FOLD <= 2 && (S == 0 || S == 1), "shape");
+  const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (EXACT && !flags[wg]) return;
+  const i64 poly = blockIdx.y;
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < n_out;
+  const u32* __restrict__ src = rows + poly * NP * nrow;
+  int undecided = 0;
+  if (active) {
+    u64 acc[NW];
+#pragma unroll
+    for (int l = 0; l < NW; ++l) acc[l] = 0;
+    u32 fsum = 0;
+    // term 0: position j, +;  term 1: position j + off, - (m = 2q') or + (m prime);  term 2: position off - 1, -(-1)^j (m = 2q') or - (m prime)
+    constexpr int NT = FOLD ? 3 : 1;
+    u32 eb[NT];
+    bool up[NT], ok[NT], neg[NT];
+    {
+      const i64 e[3] = {j, j + fold_off, fold_off - 1};
+      const bool ng[3] = {false, FOLD == 1, FOLD == 2 || !(j & 1)};
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        ok[k] = e[k] < nrow;
+        const u32 idx = ok[k] ? (u32)e[k] : 0u;
+        up[k] = S && idx >= (u32)A32_N;
+        eb[k] = S ? (idx & (u32)(A32_N - 1)) : idx;
+        neg[k] = ng[k];
+      }
+    }
+#pragma unroll 2
+    for (int i = 0; i < NP; ++i) {
+      const u32 p = pr.p[i], twop = 2 * p;
+      const u32* __restrict__ ri = src + (i64)i * nrow;
+      u32 y;
+      if (S) {
+        u32 A[NT], B[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) { A[k] = ri[eb[k]]; B[k] = ri[eb[k] + A32_N]; }
+        auto red2 = [&](u32 v) -> u32 { return min(v, v - twop); };                 // [0, 4p) -> [0, 2p)
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          const u32 t = up[k] ? A[k] + p - B[k] : A[k] + B[k];                       // at most 2p
+          const u32 v = ok[k] ? (neg[k] ? twop - t : t) : 0u;
+          if (k == 0) { lo = up[0] ? 0u : v; hi = up[0] ? v : 0u; }
+          else { lo = red2(lo + (up[k] ? 0u : v)); hi = red2(hi + (up[k] ? v : 0u)); }
+        }
+        if (NT == 1) { lo = red2(lo); hi = red2(hi); }
+        y = mul_lazy32(lo, cinv[2 * i], p) + mul_lazy32(hi, cinv[2 * i + 1], p);    // below 4p
+        y = min(y, y - twop);
+        y = min(y, y - p);
+      } else {
+        u32 r = ri[eb[0]];
+        if (FOLD) {
+          const u32 b = ok[1] ? ri[eb[1]] : 0u, c = ri[eb[2]];
+          if (FOLD == 1) r = r + (p - b) + (neg[2] ? p - c : c);                    // r_j - r_(j+q') - (-1)^j r_(q'-1): below 4p
+          else r = r + b + (p - c);                                                  // r_j + r_(j+m) - r_(m-1): below 3p
+        }
+        y = mul_lazy32(r, cinv[2 * i], p);
+        y = y >= p ? y - p : y;
+      }
+      fsum += __umulhi(y, inv57[i]);
+      const u32* __restrict__ Mi = Mw + (i64)i * wt + J0;
+#pragma unroll
+      for (int l = 0; l < NW; ++l) acc[l] += (u64)y * Mi[l];
+    }
+    const u32 kappa = (fsum + (1u << 24)) >> 25;
+    {
+      const u32* __restrict__ Nm = Mw + (i64)NP * wt + J0;
+#pragma unroll
+      for (int l = 0; l < NW; ++l) acc[l] += (u64)kappa * Nm[l];
+    }
+    u64 carry = 0;
+#pragma unroll
+    for (int l = 0; l < NW; ++l) { const u64 v = acc[l] + carry; acc[l] = v & (((u64)1 << R) - 1); carry = v >> R; }
+    // 64 bits from bit B of x (two's complement, bits above R WU dropped)
+    auto limb = [&](int B) -> u64 {
+      const int l0 = B / R - J0, o = B % R;
+      u64 v = l0 < NW ? acc[l0 < NW ? l0 : 0] >> o : 0;
+      if (l0 + 1 < NW) v |= acc[l0 + 1 < NW ? l0 + 1 : 0] << (R - o);
+      if (l0 + 2 < NW) v |= acc[l0 + 2 < NW ? l0 + 2 : 0] << (2 * R - o);
+      if (l0 + 3 < NW && 3 * R - o < 64) v |= acc[l0 + 3 < NW ? l0 + 3 : 0] << (3 * R - o);
+      return v;
+    };
+    const u64 G = limb(LQ - 64);                         // bits logQ-64 .. logQ-1
+    if (!EXACT) undecided = (G == 0x7fffffffffffffffull) ? 1 : 0;
+    u64 c = G >> 63;                                     // round half up: + bit logQ-1
+    u64* __restrict__ o = out + poly * NLQ * n_out + j;
+    u32* __restrict__ o32 = reinterpret_cast<u32*>(out) + poly * (2 * NLQ) * n_out + j;
+#pragma unroll
+    for (int i = 0; i < NLQ; ++i) {
+      u64 v = limb(LQ + 64 * i);
+      v += c;
+      c = (c && v == 0) ? 1 : 0;
+      if (LQ - 64 * i < 64) v &= ((u64)1 << ((LQ - 64 * i) & 63)) - 1;
+      if (wm) { o32[(i64)(2 * i) * n_out] = (u32)v; o32[(i64)(2 * i + 1) * n_out] = (u32)(v >> 32); }
+      else o[(i64)i * n_out] = v;
+    }
+  }
+  if (!EXACT) {
+    const int any = __syncthreads_or(undecided);
+    if (threadIdx.x == 0) flags[wg] = any ? 1 : 0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- launchers
 static i64 t32_nrow(const fhesi_ctx* ctx) { return (i64)A32_N << ctx->tensor32->S; }
 template <int NL>
@@ -810,6 +913,23 @@ static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npoly
     ntt32_tail2_kernel<<<dim3(16, (unsigned)(npolys * c->NP)), 256, 0, ctx->stream>>>(const_cast<u32*>(d_t), c->NP, 0, ctx->tensor32->d_p, ctx->tensor32->d_ht);
     HIP_TRY(hipGetLastError());
   }
+  // the compiled forms of the reference drivers' own shapes (m = p - 1 for a safe prime: fold 1): Test_AddMul's logQ = 512 on padded rows of
+  // 2^15 (p = 32603) and of 2^16 (p = 65267: whole rows after the tail pass), Test_Regression's logQ = 341 at p = 8423 (rows of 2^14)
+#define T32_FOLD_GO(LQ_, SS) do { \
+    PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_fold_kernel<LQ_, false, SS, 1>)); \
+    crt32_scale_fold_kernel<LQ_, false, SS, 1><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0); \
+    HIP_TRY(hipGetLastError()); \
+    if (!ctx->opt.crt_skip_cleanup) { \
+      crt32_scale_fold_kernel<LQ_, true, SS, 1><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0); \
+      HIP_TRY(hipGetLastError()); \
+    } \
+    return 0; } while (0)
+  if (fold == 1 && ctx->opt.crt_compiled) {
+    if (logQ == 512 && S == 1) T32_FOLD_GO(512, 1);
+    if (logQ == 512 && S != 1) T32_FOLD_GO(512, 0);
+    if (logQ == 341 && S == 0) T32_FOLD_GO(341, 0);
+  }
+#undef T32_FOLD_GO
 #define T32_GEN_SF(NWM) do { \
     if (S != 1) { if (fold == 0) T32_GEN_GO(NWM, 0, 0); else if (fold == 1) T32_GEN_GO(NWM, 0, 1); else T32_GEN_GO(NWM, 0, 2); } \
     else { if (fold == 0) T32_GEN_GO(NWM, 1, 0); else if (fold == 1) T32_GEN_GO(NWM, 1, 1); else T32_GEN_GO(NWM, 1, 2); } } while (0)

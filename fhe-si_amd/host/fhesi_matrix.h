@@ -203,12 +203,18 @@ class SingleGpuExecutor : public WaveExecutor {
 // a full copy of the pool.  The groups of a wave are sharded over the ranks by shard_bounds; the wave's outputs are then exchanged
 // (fhesi_comm_exchange: one grouped RCCL broadcast per producing rank) because the next wave reads ciphertexts produced by every
 // rank.  Every ciphertext operation is deterministic, so the pool contents -- and the results -- are bit-identical to one GPU.
+// Exchange / compute overlap (option, SetOverlap): a wave's outputs are read by the NEXT wave only, so a wave is cut into chunks of groups,
+// every chunk sharded over all ranks; the exchange of chunk k (fhesi_comm_exchange_begin: the communicator's own stream, behind an event of
+// the compute stream) travels while chunk k + 1 is computed, and fhesi_comm_exchange_end closes the wave.  The group -> rank assignment
+// differs from the unchunked one; the ciphertexts do not (every group is computed by exactly one rank, deterministically).
 class GroupExecutor : public WaveExecutor {
   const FHEcontext& context;
   std::vector<std::unique_ptr<RankState>> ranks;
   std::vector<fhesi_comm*> comms;
   const std::vector<unsigned>& autoK;
   long used = 0;
+  int overlap_chunks = 1;                          // chunks per wave (1 = compute the whole shard, then exchange: no overlap)
+  std::vector<std::string> schedule_log;           // what ran, wave by wave (the overlap cannot be TIMED on ranks that share one GPU; it can be read)
   template <class F> void parallel(F f) {
     std::vector<std::thread> th;
     for (size_t r = 1; r < ranks.size(); ++r) th.emplace_back([&f, r] { f((int)r); });
@@ -245,7 +251,9 @@ class GroupExecutor : public WaveExecutor {
   }
   ~GroupExecutor() { ranks.clear(); for (auto cm : comms) fhesi_comm_destroy(cm); }
   int world() const { return (int)ranks.size(); }
-  void reset() { used = 0; }
+  void reset() { used = 0; schedule_log.clear(); }
+  void SetOverlap(int chunks) { overlap_chunks = chunks < 1 ? 1 : chunks; }
+  const std::vector<std::string>& Schedule() const { return schedule_log; }
   void reserve(long entries) override { for (auto& r : ranks) r->reserve(entries, used); }
   long add(const Ciphertext& ct) override {
     if (ct.isScaledUp() || ct.parts.size() != 2) Error("pool: expects an unscaled 2-part ciphertext");
@@ -259,8 +267,28 @@ class GroupExecutor : public WaveExecutor {
     reserve(used + w.groups());
     const long first = used, count = w.groups(); used += count;
     const int G = (int)ranks.size();
-    parallel([&](int r) { long lo, hi; shard_bounds(count, r, G, lo, hi); ranks[r]->run_shard(w, first, lo, hi, sum_batched, autoK); });
-    exchange(first, count);
+    // chunks of at least one group per rank; a single chunk is the plain form (compute, then the blocking exchange)
+    const int C = (int)std::max<long>(1, std::min<long>(overlap_chunks, count / G));
+    if (C == 1) {
+      parallel([&](int r) { long lo, hi; shard_bounds(count, r, G, lo, hi); ranks[r]->run_shard(w, first, lo, hi, sum_batched, autoK); });
+      exchange(first, count);
+      schedule_log.push_back("wave of " + std::to_string(count) + " groups: compute, then exchange");
+      return first;
+    }
+    std::string log = "wave of " + std::to_string(count) + " groups in " + std::to_string(C) + " chunks:";
+    parallel([&](int r) {
+      std::vector<int64_t> off(G + 1);
+      for (int c = 0; c < C; ++c) {
+        long c0, c1; shard_bounds(count, c, C, c0, c1);                 // chunk c = groups [c0, c1), sharded over ALL ranks
+        long lo, hi; shard_bounds(c1 - c0, r, G, lo, hi);
+        ranks[r]->run_shard(w, first, c0 + lo, c0 + hi, sum_batched, autoK);
+        for (int q = 0; q < G; ++q) { long ql, qh; shard_bounds(c1 - c0, q, G, ql, qh); off[q] = (first + c0 + ql) * ranks[0]->words; off[q + 1] = (first + c0 + qh) * ranks[0]->words; }
+        ck(fhesi_comm_exchange_begin(ranks[r]->h, comms[r], ranks[r]->d, off.data()));      // travels while chunk c + 1 is computed
+      }
+      ck(fhesi_comm_exchange_end(ranks[r]->h, comms[r]));
+    });
+    for (int c = 0; c < C; ++c) { long c0, c1; shard_bounds(count, c, C, c0, c1); log += " [" + std::to_string(c0) + "," + std::to_string(c1) + ") compute -> exchange begun" + (c + 1 < C ? " (overlaps the next chunk's compute);" : ";"); }
+    schedule_log.push_back(log + " exchange end");
     return first;
   }
   long negated(const std::vector<int32_t>& idx) override {      // cheap and local: every rank computes all of them
@@ -336,11 +364,14 @@ class Regression {
     RegressWaves(*single, theta, det);
   }
   // ... sharded over the GPUs `devices` of this node (devices[0] = the context's GPU); keys are broadcast on the first call
-  void RegressBatchedMultiGpu(const std::vector<int>& devices, std::vector<Ciphertext>& theta, Ciphertext& det) {
+  // overlap_chunks > 1: every wave in that many chunks, the exchange of a chunk overlapped with the next chunk's compute (GroupExecutor)
+  void RegressBatchedMultiGpu(const std::vector<int>& devices, std::vector<Ciphertext>& theta, Ciphertext& det, int overlap_chunks = 1) {
     if (!group || group->world() != (int)devices.size()) group.reset(new GroupExecutor(context, devices, keySwitch, autoKeySwitch, autoK));
     group->reset();
+    group->SetOverlap(overlap_chunks);
     RegressWaves(*group, theta, det);
   }
+  const std::vector<std::string>& LastSchedule() const { static const std::vector<std::string> none; return group ? group->Schedule() : none; }
 
   // The expression DAG of Regression::Regress level by level (inner products -> SumBatchedData -> minors of growing size ->
   // determinant -> adj * last), every level one wave on the executor

@@ -81,6 +81,8 @@ class ShardedPool:
         self.t = torch.zeros((capacity, words), dtype=torch.int64, device=device if device is not None else "cpu")
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
+        self._pending = []
+        self.schedule = []          # (entries, chunks) of every sharded step since the pool was made
 
     def alloc(self, count: int) -> int:
         if self.used + count > self.t.shape[0]:
@@ -100,14 +102,52 @@ class ShardedPool:
             if hi > lo:
                 self.dist.broadcast(self.t[first + lo:first + hi], src=r)
 
+    def exchange_begin(self, first: int, count: int):
+        """the same broadcasts issued asynchronously (RCCL's own stream on GPUs): they travel while the caller computes its next chunk"""
+        if self.world == 1 or count == 0:
+            return
+        for r in range(self.world):
+            lo, hi = shard_bounds(count, r, self.world)
+            if hi > lo:
+                self._pending.append(self.dist.broadcast(self.t[first + lo:first + hi], src=r, async_op=True))
+
+    def exchange_end(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def run_sharded(self, first: int, count: int, compute, overlap: int = 1, sync_out=None, sync_in=None):
+        """Entries [first, first + count) of a wave: `compute(lo, hi)` produces the entries first + lo .. first + hi of this rank, then the
+        ranks exchange.  overlap > 1 cuts the wave into that many chunks (each sharded over ALL ranks) and lets the exchange of chunk k travel
+        while chunk k + 1 is computed -- a wave's outputs are read by the NEXT wave only (Regression.h:102-149 over Matrix.cpp:182-263).  Which
+        rank computes which entry changes with the chunking; the entries do not.  sync_out / sync_in: the stream hand-over between the
+        compute side (C ABI) and the collective side (torch)."""
+        C = max(1, min(int(overlap), count // self.world)) if self.world > 1 else 1
+        for c in range(C):
+            c0, c1 = shard_bounds(count, c, C)
+            lo, hi = shard_bounds(c1 - c0, self.rank, self.world)
+            if hi > lo:
+                compute(c0 + lo, c0 + hi)
+            if sync_out:
+                sync_out()
+            if C == 1:
+                self.exchange(first, count)
+            else:
+                self.exchange_begin(first + c0, c1 - c0)
+        self.exchange_end()
+        if sync_in:
+            sync_in()
+        self.schedule.append((count, C))
+
 
 class DeviceBackend:
     """The five operations of the schedule on an MI355X through the C ABI."""
 
-    def __init__(self, ctx, logQ: int, p: int, ksk, auto_ksks: Sequence, auto_ks: Sequence[int], pool: ShardedPool, decomp_bytes: int = 3):
+    def __init__(self, ctx, logQ: int, p: int, ksk, auto_ksks: Sequence, auto_ks: Sequence[int], pool: ShardedPool, decomp_bytes: int = 3, overlap: int = 1):
         from .binding import DevBuf  # noqa: F401  (documentation of what .ptr means)
         self.ctx, self.logQ, self.p, self.ksk, self.auto_ksks, self.auto_ks, self.pool = ctx, logQ, p, ksk, list(auto_ksks), list(auto_ks), pool
         self.decomp_bytes = decomp_bytes
+        self.overlap = overlap          # chunks per wave whose exchange overlaps the next chunk's compute (1 = none)
         self.nl = (logQ + 63) // 64
         assert pool.words == 2 * ctx.phim * self.nl
         self._tmp = None
@@ -140,29 +180,26 @@ class DeviceBackend:
 
     def run_wave(self, w: Wave) -> int:
         first = self.pool.alloc(w.groups)
-        lo, hi = self.pool.my_span(w.groups)
-        if hi > lo:
+
+        def compute(lo, hi):
             a, b, seg = w.slice(lo, hi)
             self.ctx.ct_mul_sum_relin_dev(self.ksk, self.logQ, self.p, self._at(0), self.nl, a, b, seg, self._at(first + lo), self.decomp_bytes)
-        self._sync_out()
-        self.pool.exchange(first, w.groups)
-        self._sync_in()
+        self.pool.run_sharded(first, w.groups, compute, self.overlap, self._sync_out, self._sync_in)
         return first
 
     def sum_batched(self, first: int, count: int):
         """Regression::SumBatchedData (Regression.h:166-178) on `count` consecutive entries, in place, each rank on its slice."""
-        lo, hi = self.pool.my_span(count)
-        if hi > lo and self.auto_ksks:
+        def compute(lo, hi):
             n = hi - lo
+            if not self.auto_ksks:
+                return
             if self._tmp is None or self._tmp.shape[0] < n:
                 self._tmp = self.pool.torch.empty((n, self.pool.words), dtype=self.pool.torch.int64, device=self.pool.t.device)
             tmp = self._Raw(self._tmp.data_ptr())
             for ksk, k in zip(self.auto_ksks, self.auto_ks):
                 self.ctx.ct_automorph_key_switch_dev(ksk, self.logQ, k, self._at(first + lo), self.nl, n, tmp, self.nl, self.decomp_bytes)
                 self.ctx.ct_add_dev(self.logQ, self._at(first + lo), tmp, 2, self.nl, n)
-        self._sync_out()
-        self.pool.exchange(first, count)
-        self._sync_in()
+        self.pool.run_sharded(first, count, compute, self.overlap, self._sync_out, self._sync_in)
 
     def negated(self, idx: Sequence[int]) -> int:
         """new entries = -1 * pool[idx] (Ciphertext::operator*=(long), Ciphertext.cpp:232-237); cheap, done by every rank"""

@@ -43,7 +43,7 @@ int fhesi_device_count(int32_t* count);
  * fhesi_host_stage_release).  A binding compiled or written against another revision must refuse to run: the Python binding
  * (fhe-si_amd/binding.py) and the C++ mirror (fhe-si_amd/host/fhesi_context.h) compare FHESI_ABI_VERSION with the library's
  * answer when they load it -- a stale ctypes table or mirror would otherwise link and silently shift arguments. */
-#define FHESI_ABI_VERSION 6
+#define FHESI_ABI_VERSION 7
 int32_t fhesi_abi_version(void);
 
 /* ---- context: FHEcontext::AddPrime (FHEContext.cpp:30-43) + Cmod::privateInit (CModulus.cpp:60-86) +
@@ -66,10 +66,10 @@ void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t a
  * reference's own structure FHE-SI.cpp:251-254), "ks_residues", "ks_aux60", "crt_exact", "crt_skip_cleanup" (test hook), "lanes" (2 = two
  * concurrent half-batches), "stagger", "batch_chunk", "wave_operands", "tensor32" (0 = the fused pipeline keeps the tensor product on the
  * chain primes), "tensor_bits" (30 / 29: the size of the tensor half's primes -- below 2^29 the row transforms skip half of their range steps
- * for one or two primes more; the integers formed are the same); layout switches that never change a result (round 5): "dot32_k4" (0 = the digit-tile dot product dot32_kernel2 where the
- * key-in-LDS form dot32_kernel4 would run; 2 = also offer its split form for 15 limbs), "dot32_parts" (0 = tiles of 4 ciphertexts where the
- * columns do not fit one tile of 8), "parts_words" (0 = 64-bit limb rows between the tensor half and the digit loader), "digit_group"
- * (units per XCD group of the digit transform; -1 = one polynomial's digits), "ks_long_keys", "dot32_small", "host_chunk", "host_threads".
+ * for one or two primes more; the integers formed are the same), "crt_compiled" (0 = the run-time form of the tensor half's CRT where a compiled
+ * one exists for the shape: the reference drivers' rings m = p - 1 at logQ = 512 / 341); layout switches that never change a result (round 5): "dot32_k4" (0 = the digit-tile dot product dot32_kernel2 where the
+ * key-in-LDS form dot32_kernel4 would run; 2 = also offer its split form for 15 limbs), "parts_words" (0 = 64-bit limb rows between the tensor half and the digit loader),
+ * "ks_long_keys", "host_chunk", "host_threads".
  * The FHESI_<NAME> environment variables give the initial values, read once in fhesi_ctx_create -- never per call.
  * fhesi_ctx_destroy fails while DoubleCRT / key-switch handles of the context are alive (they hold the reference's `const FHEcontext&`). */
 int fhesi_ctx_set_option(fhesi_ctx* ctx, const char* name, int64_t value);
@@ -298,6 +298,12 @@ int fhesi_comm_broadcast_dev(fhesi_ctx* ctx, fhesi_comm* comm, void* buf_dev, si
 /* exchange of sharded wave outputs (Matrix<Ciphertext> waves, Matrix.cpp:150-174): rank r produced the words
  * [offsets_words[r], offsets_words[r+1]) of base_dev; afterwards every rank holds all of them (one grouped broadcast per producer) */
 int fhesi_comm_exchange(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* base_dev, const int64_t* offsets_words);
+/* the same exchange split for overlap with compute (the waves of Regression::Regress, Regression.h:102-149 over Matrix.cpp:182-263: a
+ * wave's outputs are read by the NEXT wave only).  _begin enqueues the exchange on the communicator's own stream behind everything already
+ * on the context's stream and returns without waiting for the GPU -- the context's stream goes on with the next chunk of the wave;
+ * _end returns when every exchange begun since the last _end has landed.  All ranks call _begin for the same exchanges in the same order. */
+int fhesi_comm_exchange_begin(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* base_dev, const int64_t* offsets_words);
+int fhesi_comm_exchange_end(fhesi_ctx* ctx, fhesi_comm* comm);
 /* exact all-reduce of partial scaled-up sums held by the ranks (Ciphertext::operator+= on scaled-up ciphertexts is linear,
  * Ciphertext.cpp:135-142): rows_dev [count][L][phi(m)] <- (sum over ranks) mod q_i; at most 16 ranks (64-bit partial sums of 60-bit residues) */
 int fhesi_comm_allreduce_rows(fhesi_ctx* ctx, fhesi_comm* comm, uint64_t* rows_dev, int64_t count);

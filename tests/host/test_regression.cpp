@@ -1,7 +1,7 @@
 // test_regression.cpp -- counterpart of the reference's Test_Regression driver (Test_Regression.cpp:10-131) on the mirrored
 // classes, with coefficient-form plaintexts (slot packing is outside the hot-path scope, see fhe-si_amd/host/fhesi_matrix.h).
 //
-//   test_regression p generator dim nrows [seed] [--batched-only] [--check=ring|slots|none] [--m=M] [--logQ=B] [--devices=0,1,...]
+//   test_regression p generator dim nrows [seed] [--batched-only] [--check=ring|slots|none] [--m=M] [--logQ=B] [--devices=0,1,...] [--overlap=C]
 //
 // Context as in Test_Regression.cpp:97-125: m = p-1, logQ from the same noise formula, SetUpSIContext(xi).  The data matrix
 // (nrows x dim) and the labels are random polynomials over Z_p; Regression::Regress is evaluated three ways
@@ -46,6 +46,7 @@ int main(int argc, char* argv[]) {
   bool batchedOnly = false, atOnce = false; std::string check = "ring"; unsigned mOverride = 0, logQOverride = 0; int repeat = 1;
   std::vector<int> literalDevices;         // --literal-devices=0,1,...: the recorded literal control flow runs on this group of GPUs (EnableCiphertextGroup)
   std::vector<int> devices;                // --devices=0,1,...: also run the wave evaluator sharded over these GPUs (first = the context's)
+  int overlapChunks = 1;                   // --overlap=C: with --devices, every wave in C chunks, the exchange of a chunk overlapped with the next chunk's compute
   std::vector<char*> args;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--batched-only")) batchedOnly = true;
@@ -53,6 +54,7 @@ int main(int argc, char* argv[]) {
     else if (!strncmp(argv[i], "--check=", 8)) check = argv[i] + 8;
     else if (!strncmp(argv[i], "--repeat=", 9)) repeat = atoi(argv[i] + 9);
     else if (!strncmp(argv[i], "--literal-devices=", 18)) { for (char* t = strtok(argv[i] + 18, ","); t; t = strtok(nullptr, ",")) literalDevices.push_back(atoi(t)); }
+    else if (!strncmp(argv[i], "--overlap=", 10)) overlapChunks = atoi(argv[i] + 10);
     else if (!strncmp(argv[i], "--devices=", 10)) { for (char* t = strtok(argv[i] + 10, ","); t; t = strtok(nullptr, ",")) devices.push_back(atoi(t)); }
     else if (!strncmp(argv[i], "--m=", 4)) mOverride = atoi(argv[i] + 4);
     else if (!strncmp(argv[i], "--logQ=", 7)) logQOverride = atoi(argv[i] + 7);
@@ -174,6 +176,20 @@ int main(int argc, char* argv[]) {
     for (unsigned i = 0; same && i < thetaG.size(); ++i) same = thetaG[i][0] == thetaB[i][0] && thetaG[i][1] == thetaB[i][1];
     std::cout << "multi-rank ciphertexts bit-identical to one GPU: " << (same ? "yes" : "NO") << std::endl;
     if (!same) ++failures;
+    if (overlapChunks > 1) {
+      // ... and with every wave cut into chunks whose exchange overlaps the next chunk's compute (fhesi_comm_exchange_begin / _end)
+      std::vector<Ciphertext> thetaO; Ciphertext detO(context);
+      double tO = 0;
+      for (int it = 0; it < std::max(repeat, 1); ++it) { t0 = now(); regress.RegressBatchedMultiGpu(devices, thetaO, detO, overlapChunks); tO = now() - t0; }
+      std::cout << "batched on " << devices.size() << " rank(s), exchange overlapped (" << overlapChunks << " chunks per wave): " << tO << " s" << std::endl;
+      long chunked = 0;
+      for (auto& line : regress.LastSchedule()) { std::cout << "  schedule: " << line << std::endl; if (line.find("chunks:") != std::string::npos) ++chunked; }
+      std::cout << "waves run in chunks: " << chunked << " of " << regress.LastSchedule().size() << std::endl;
+      bool sameO = thetaO.size() == thetaB.size() && detO[0] == detB[0] && detO[1] == detB[1];
+      for (unsigned i = 0; sameO && i < thetaO.size(); ++i) sameO = thetaO[i][0] == thetaB[i][0] && thetaO[i][1] == thetaB[i][1];
+      std::cout << "overlapped-exchange ciphertexts bit-identical to one GPU: " << (sameO ? "yes" : "NO") << std::endl;
+      if (!sameO) ++failures;
+    }
   }
   if (!batchedOnly) {
     std::vector<Ciphertext> thetaA; Ciphertext detA(context);

@@ -71,8 +71,8 @@ def test_config4_stress_ring_several_chunks():
 def test_config4_generated_keys_column_parts():
     """configs[4] with a GENERATED key-switch matrix (KeySwitchSI::Init, FHE-SI.cpp:153-226): 15 centred limbs, 129 columns.  The dot product
     takes the columns in two parts through one 80 KB tile of 8 ciphertexts (dot32_kernel2p).  A ragged batch (two tiles, the second with one
-    ciphertext): first, last-of-tile and ragged ciphertexts vs the oracle, the whole batch vs the round-4 form (tiles of 4: option
-    dot32_parts = 0) and vs the general limbs."""
+    ciphertext): first, last-of-tile and ragged ciphertexts vs the oracle, the whole batch vs the general limbs (30 of them: tiles of 4
+    ciphertexts through dot32_kernel2)."""
     m, logQ, p, count = 1 << 16, 1024, 65537, 9
     primes, roots = P.chain_for(m, logQ, p)
     ctx = F.Context(m, primes, roots)
@@ -96,9 +96,6 @@ def test_config4_generated_keys_column_parts():
     assert "dot32_kernel2p" in ctx_kernel_name(ctx, ksk, logQ, p, a, b, nl)
     for c in (0, 7, 8):
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
-    ctx.set_option("dot32_parts", 0)
-    assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b), got)
-    ctx.set_option("dot32_parts", 1)
     # the same 15 limbs through dot32_kernel4 with the 30 outputs split over two wave groups (option dot32_k4 = 2; a ragged batch of 27)
     rep = np.concatenate([a, a, a])[:27], np.concatenate([b, b, b])[:27]
     da, db, dout = ctx.upload(rep[0]), ctx.upload(rep[1]), ctx.alloc(rep[0].nbytes)
@@ -304,6 +301,11 @@ def test_refring_generated_keys_eight_limbs():
     ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
     assert np.array_equal(dout.download((count, 2, n, nl)), got)
     ctx.set_option("dot32_k4", 1)
+    # the tensor half's CRT ran its compiled form for this shape (crt32_scale_fold_kernel<512, .., S = 1, FOLD = 1>); the run-time form gives the same bits
+    ctx.set_option("crt_compiled", 0)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    assert np.array_equal(dout.download((count, 2, n, nl)), got)
+    ctx.set_option("crt_compiled", 1)
     orc = O.Oracle(m, primes, roots)
     orc.set_bluestein_fft(True)
     assert np.array_equal(got[24], orc.ct_mul_relin(ksk.download(), a[24], b[24], logQ, p))

@@ -138,16 +138,27 @@ def test_metric_key_matrix_through_the_broadcast(devices):
         c.destroy()
 
 
-@pytest.mark.parametrize("args,devices", [(("23", "7", "3", "2", "2"), "0,0"), (("257", "3", "4", "2", "5"), "0,0,0"), (("47", "5", "3", "1", "6"), "0")])
-def test_wave_evaluator_sharded_over_ranks_is_bit_identical(args, devices):
+@pytest.mark.parametrize("overlap", [1, 2, 3])
+@pytest.mark.parametrize("args,devices", [(("23", "7", "3", "2", "2"), "0,0"), (("257", "3", "4", "2", "5"), "0,0,0"), (("47", "5", "3", "1", "6"), "0"),
+                                          (("47", "5", "5", "1", "6"), "0,0,0,0,0,0,0,0")])
+def test_wave_evaluator_sharded_over_ranks_is_bit_identical(args, devices, overlap):
     """fhesi::Regression::RegressBatchedMultiGpu (fhe-si_amd/host/fhesi_matrix.h: GroupExecutor, one host thread per rank, keys
     broadcast from rank 0, every wave's groups sharded by shard_bounds, outputs exchanged) against the one-GPU waves and the plaintext
-    regression.  `0` = one rank through real RCCL; `0,0` / `0,0,0` = ranks sharing GPU 0 (loopback group)."""
+    regression.  `0` = one rank through real RCCL; `0,0` / `0,0,0` / eight zeros = ranks sharing GPU 0 (loopback group).
+    overlap > 1: every wave in that many chunks, the exchange of chunk k (fhesi_comm_exchange_begin, the communicator's own stream) travelling
+    while chunk k + 1 is computed, fhesi_comm_exchange_end closing the wave -- the same ciphertexts bit for bit, and the schedule is printed."""
     subprocess.check_call(["make", "-C", HOST, "-j8"], stdout=subprocess.DEVNULL)
-    r = subprocess.run([os.path.join(HOST, "test_regression"), *args, "--batched-only", f"--devices={devices}"], capture_output=True, text=True, timeout=900)
+    extra = [f"--overlap={overlap}"] if overlap > 1 else []
+    r = subprocess.run([os.path.join(HOST, "test_regression"), *args, "--batched-only", f"--devices={devices}", *extra], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "multi-rank ciphertexts bit-identical to one GPU: yes" in r.stdout
     assert "batched: decrypts to the plaintext regression: yes" in r.stdout
+    if overlap > 1:
+        assert "overlapped-exchange ciphertexts bit-identical to one GPU: yes" in r.stdout, r.stdout[-3000:]
+        if devices != "0":          # (one rank: nothing to exchange, every wave is one chunk)
+            import re
+            m = re.search(r"waves run in chunks: (\d+) of (\d+)", r.stdout)
+            assert m and int(m.group(1)) >= 1 and "overlaps the next chunk's compute" in r.stdout, r.stdout[-3000:]
 
 
 def test_config3_sharded_over_eight_ranks():

@@ -213,6 +213,10 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     assert ctx.get_option("tensor_bits") == 59 - bits
     ctx.set_option("tensor_bits", bits)
     assert np.array_equal(got, other)
+    # ... and through the run-time form of the CRT where a compiled one exists for the shape (option crt_compiled: m = p - 1 with logQ = 341 / 512)
+    ctx.set_option("crt_compiled", 0)
+    assert np.array_equal(got, ctx.ct_mul_relin(ksk, logQ, p, a, b))
+    ctx.set_option("crt_compiled", 1)
     # (general m at this size: seconds per Bluestein row in the oracle; at m = 65266 minutes per multiplication -- there the chain path above,
     # per-prime Bluestein rows checked against the oracle on the smaller rings and in test_gpu_general_m.py, stands in)
     for c in (() if m > 40000 else (2,) if ctx.phim > 10000 and (m & (m - 1)) != 0 else (1, 2)):
@@ -305,12 +309,11 @@ def test_key_switch_paths_agree_on_a_full_batch(monkeypatch):
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 4242, count)
     ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     ref = ctx.ct_mul_relin(ksk, logQ, p, a, b)
-    # (dot32_v3 = 1 / dot32_half = 0: other tilings of the 30-bit dot product; dot32_mfma = 1: the same product on the int8 matrix cores)
-    for opt, val in (("ks_aux60", 1), ("ks_residues", 1), ("ks_direct", 1), ("dot32_v3", 1), ("dot32_half", 0), ("dot32_mfma", 1), ("dot32_mfma", 2)):
+    for opt, val in (("ks_aux60", 1), ("ks_residues", 1), ("ks_direct", 1)):
         ctx.set_option(opt, val)
         ksk2 = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)        # a fresh matrix: the derived table is built for the selected form
         assert np.array_equal(ctx.ct_mul_relin(ksk2, logQ, p, a, b), ref), opt
-        ctx.set_option(opt, 1 if opt == "dot32_half" else 0)
+        ctx.set_option(opt, 0)
     assert np.array_equal(ref[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
     # ... and on ONE live matrix: an option that selects another form rebuilds the derived table (it used to be kept silently)
     assert ksk.form()[0] == 1
@@ -470,9 +473,9 @@ def test_host_buffer_pipeline_equals_the_device_batch(count, host_chunk):
 
 @pytest.mark.parametrize("m,logQ,p", [(32768, 512, 23), (1 << 16, 300, 65537), (32602, 128, 32603)])
 def test_round5_layout_switches_change_no_bit(m, logQ, p):
-    """The A/B switches of round 5 select layouts, never values: XCD groups of one polynomial's digits (digit_group = -1, and groups of 4), the
-    scaled-down parts as 64-bit limb rows instead of 32-bit word rows (parts_words = 0), the digit-tile dot product (dot32_k4 = 0) and the
-    stress ring's tiles of 4 ciphertexts (dot32_parts = 0) -- every combination gives the bits of the default, on rows of 2^14, of 2^15 and
+    """The layout switches select layouts, never values: the
+    scaled-down parts as 64-bit limb rows instead of 32-bit word rows (parts_words = 0), the digit-tile dot product (dot32_k4 = 0)
+    -- every combination gives the bits of the default, on rows of 2^14, of 2^15 and
     on padded rows of a linear-convolution ring; 33 ciphertexts (groups past the end, a ragged last tile)."""
     count = 33
     ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 606 + m, count)
@@ -483,13 +486,36 @@ def test_round5_layout_switches_change_no_bit(m, logQ, p):
     want = dout.download((count, 2, n, nl))
     if m == 32768:
         assert np.array_equal(want[32], orc.ct_mul_relin(ksm, a[32], b[32], logQ, p))
-    for opts in ({"digit_group": -1}, {"digit_group": 4}, {"parts_words": 0}, {"dot32_k4": 0, "dot32_parts": 0}, {"digit_group": -1, "parts_words": 0, "dot32_k4": 0}):
+    for opts in ({"parts_words": 0}, {"dot32_k4": 0}, {"parts_words": 0, "dot32_k4": 0}):
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
         ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
         assert np.array_equal(dout.download((count, 2, n, nl)), want), opts
         for k_ in opts:
             ctx.set_option(k_, 1)
+    if m == 32768:
+        # the uploaded matrix of uniform residues has 15 general limbs: dot32_kernel2 runs whatever dot32_k4 says.  A GENERATED matrix (7 centred
+        # limbs) takes dot32_kernel4, and there the switch really selects the other kernel -- same bits
+        one = np.zeros((n, 1), dtype=np.uint64)
+        one[0, 0] = 1
+        t = F.DoubleCRT(ctx).sample(0, 64, 17, 1)
+        t2 = t.copy()
+        t2.op(t, 2)
+        kg = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([F.DoubleCRT.from_poly(ctx, one), t, t2], t, logQ, 17, 18, 500, 3)
+        names = {}
+        for k4 in (1, 0):
+            ctx.set_option("dot32_k4", k4)
+            ctx.prof_enable(True)
+            ctx.ct_mul_relin_dev(kg, logQ, p, da, db, dout, nl, count)
+            ctx.sync()
+            names[k4] = ctx.prof_kernel_name("dot")
+            ctx.prof_enable(False)
+            if k4:
+                want_g = dout.download((count, 2, n, nl))
+            else:
+                assert np.array_equal(dout.download((count, 2, n, nl)), want_g)
+        ctx.set_option("dot32_k4", 1)
+        assert "dot32_kernel4<7" in names[1] and "dot32_kernel2<" in names[0], names
 
 
 def test_host_buffer_entry_rejects_device_memory_and_releases_its_ring():

@@ -15,12 +15,14 @@ from fhe_si_amd import regression as G
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_waves(case, dist=None):
+def run_waves(case, dist=None, overlap=1, pool_out=None):
     c = case["ctx"]
     nl = (c.logQ + 63) // 64
     N, d = len(case["X"]), len(case["X"][0])
     pool = G.ShardedPool(2 * c.phim * nl, 8 * (N * (d + 1) + 6 * d * d + 2 ** d * d + 16), dist=dist)
-    be = WB.PyrefBackend(c, case["ksm"], case["auto"], case["ks"], pool)
+    if pool_out is not None:
+        pool_out.append(pool)
+    be = WB.PyrefBackend(c, case["ksm"], case["auto"], case["ks"], pool, overlap)
     first = be.upload([case["X"][i][j] for i in range(N) for j in range(d)] + case["y"])
     X = [[first + i * d + j for j in range(d)] for i in range(N)]
     y = [first + N * d + i for i in range(N)]
@@ -89,30 +91,34 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, overlap):
     for q in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, q)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     case = WB.regression_case(d=3, N=1, seed=73)
-    theta, det, stats = run_waves(case, dist=dist)
+    pools = []
+    theta, det, stats = run_waves(case, dist=dist, overlap=overlap, pool_out=pools)
     if rank == 0:
         import pickle
         with open(os.path.join(outdir, "res.pkl"), "wb") as f:
-            pickle.dump((theta, det, stats), f)
+            pickle.dump((theta, det, stats, pools[0].schedule), f)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_waves_equal_single_rank(tmp_path):
-    """Each rank evaluates its shard of every wave's groups and the outputs are exchanged (ShardedPool.exchange); the result
-    must not depend on the number of ranks."""
+@pytest.mark.parametrize("overlap", [1, 2, 3])
+def test_two_rank_sharded_waves_equal_single_rank(tmp_path, overlap):
+    """Each rank evaluates its shard of every wave's groups and the outputs are exchanged (ShardedPool.run_sharded); the result must not
+    depend on the number of ranks -- nor on the exchange / compute overlap (overlap > 1: a wave in chunks, the asynchronous exchange of chunk k
+    issued before chunk k + 1 is computed, all of them awaited at the end of the wave)."""
     import pickle
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
     with open(os.path.join(str(tmp_path), "res.pkl"), "rb") as f:
-        theta2, det2, stats2 = pickle.load(f)
+        theta2, det2, stats2, schedule = pickle.load(f)
     case = WB.regression_case(d=3, N=1, seed=73)
     theta1, det1, stats1 = run_waves(case)
     assert det2 == det1 and theta2 == theta1 and stats2 == stats1
+    assert all(c == max(1, min(overlap, n // 2)) for n, c in schedule) and (overlap == 1 or any(c > 1 for _, c in schedule)), schedule

@@ -8,8 +8,8 @@ import oracle_lib as O
 
 
 class PyrefBackend:
-    def __init__(self, rctx, ksm, auto_ksms, auto_ks, pool):
-        self.c, self.ksm, self.auto_ksms, self.auto_ks, self.pool = rctx, ksm, list(auto_ksms), list(auto_ks), pool
+    def __init__(self, rctx, ksm, auto_ksms, auto_ks, pool, overlap=1):
+        self.c, self.ksm, self.auto_ksms, self.auto_ks, self.pool, self.overlap = rctx, ksm, list(auto_ksms), list(auto_ks), pool, overlap
         self.nl = (rctx.logQ + 63) // 64
         assert pool.words == 2 * rctx.phim * self.nl
 
@@ -32,21 +32,22 @@ class PyrefBackend:
 
     def run_wave(self, w):
         first = self.pool.alloc(w.groups)
-        lo, hi = self.pool.my_span(w.groups)
-        for g in range(lo, hi):
-            tp = None
-            for t in range(w.seg[g], w.seg[g + 1]):
-                prod = R.ct_mul(self.c, self._get(w.a[t]), self._get(w.b[t]))
-                tp = prod if tp is None else R.tprod_add(self.c, tp, prod)
-            self._put(first + g, R.apply_key_switch(self.c, self.ksm, tp))
-        self.pool.exchange(first, w.groups)
+
+        def compute(lo, hi):
+            for g in range(lo, hi):
+                tp = None
+                for t in range(w.seg[g], w.seg[g + 1]):
+                    prod = R.ct_mul(self.c, self._get(w.a[t]), self._get(w.b[t]))
+                    tp = prod if tp is None else R.tprod_add(self.c, tp, prod)
+                self._put(first + g, R.apply_key_switch(self.c, self.ksm, tp))
+        self.pool.run_sharded(first, w.groups, compute, self.overlap)
         return first
 
     def sum_batched(self, first, count):
-        lo, hi = self.pool.my_span(count)
-        for i in range(lo, hi):
-            self._put(first + i, R.sum_batched_data(self.c, self.auto_ksms, self.auto_ks, self._get(first + i)))
-        self.pool.exchange(first, count)
+        def compute(lo, hi):
+            for i in range(lo, hi):
+                self._put(first + i, R.sum_batched_data(self.c, self.auto_ksms, self.auto_ks, self._get(first + i)))
+        self.pool.run_sharded(first, count, compute, self.overlap)
 
     def negated(self, idx):
         first = self.pool.alloc(len(idx))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library OPTIONS on the GPU box (one library, same box, interleaved): tools/ab_options.sh <outdir> "<name>:<bench args>" ...
-# e.g. tools/ab_options.sh ab_grp "new:" "grp1:--option digit_group=1" "limbrows:--option parts_words=0"
+# e.g. tools/ab_options.sh ab_grp "new:" "limbrows:--option parts_words=0" "b29:--option tensor_bits=29"
 # a spec whose arguments start with @name runs the library variant fhe-si_amd/csrc/variants/lib_name.so (csrc/build_variant.sh)
 out=$1; shift
 mkdir -p gpurun_out/$out
