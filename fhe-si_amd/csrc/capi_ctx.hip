@@ -79,7 +79,6 @@ static const OptDesc kOptions[] = {
   {"wave_single", "FHESI_WAVE_SINGLE", offsetof(CtxOptions, wave_single), false},
   {"tensor32", "FHESI_TENSOR32", offsetof(CtxOptions, tensor32), false},
   {"tensor_bits", "FHESI_TENSOR_BITS", offsetof(CtxOptions, tensor_bits), false},
-  {"crt_compiled", "FHESI_CRT_COMPILED", offsetof(CtxOptions, crt_compiled), false},
   {"dot32_k4", "FHESI_DOT32_K4", offsetof(CtxOptions, dot32_k4), false},
   {"parts_words", "FHESI_PARTS_WORDS", offsetof(CtxOptions, parts_words), false},
   {"automorph_rows", "FHESI_AUTOMORPH_ROWS", offsetof(CtxOptions, automorph_rows), false},
@@ -144,12 +143,18 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
   c->phi = hm::cyclotomic(m);
   c->pow2 = (m & (m - 1)) == 0 && m >= 4;
   c->logn = c->pow2 ? hm::ilog2_ceil(c->phim) : 0;
-  if (!c->pow2 && 2 * c->phim - 1 <= 4 * kAux32N) {
-    // rings whose products run as linear convolutions on padded power-of-two rows of 2^14, 2^15 or 2^16 (larger ones keep the per-prime
-    // Bluestein rows): every safe prime p = m + 1 up to 65 537 (the reference's drivers: Test_AddMul.cpp:131, Test_Regression.cpp:122)
+  if (!c->pow2 && 2 * c->phim - 1 <= 64 * kAux32N) {
+    // rings whose products run as linear convolutions on padded power-of-two rows of 2^14 .. 2^20: every m = p - 1 (safe prime p) and every
+    // prime m the reference admits (m < 2^20, FHEContext.cpp:89; its drivers: Test_AddMul.cpp:131, Test_Regression.cpp:122).  Rows up to 2^16
+    // run the fused loaders, longer ones the simple path (head / tail stages as passes of their own, ntt32_core.inc)
     if (m % 2 == 0 && (m / 2) % 2 == 1 && hm::is_prime((u64)(m / 2))) c->lin_q = m / 2;
     else if (m % 2 == 1 && m > 2 && hm::is_prime((u64)m)) { c->lin_q = m; c->lin_prime = true; }
-    if (c->lin_q) c->lin_lg = 2 * c->phim - 1 <= kAux32N ? 14 : (2 * c->phim - 1 <= 2 * kAux32N ? 15 : 16);
+    if (c->lin_q) {
+      c->lin_lg = 14;
+      while (((i64)1 << c->lin_lg) < 2 * c->phim - 1) ++c->lin_lg;
+      // FHESI_LIN_LG: LONGER padded rows than the ring needs (a test hook: the long-row paths on rings small enough for the oracle)
+      if (const char* e = getenv("FHESI_LIN_LG")) { const int want = atoi(e); if (want > c->lin_lg && want <= 20) c->lin_lg = want; }
+    }
   }
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));

@@ -83,7 +83,6 @@ struct CtxOptions {
   int wave_single = 1;      // 1: a wave whose groups are single products takes the batch pipeline of fhesi_ct_mul_relin_batch_dev on gathered operands (0: the sum kernels, the checker)
   int automorph_rows = 0;   // 1: Ciphertext >>= through DoubleCRT::automorph on evaluation rows (the reference's structure) even where the coefficient gather applies
   int tensor32 = 1;         // 1: the fused pipeline's tensor half runs over 30-bit primes where that path applies (fhesi_ct_mul_relin_batch_dev)
-  int crt_compiled = 1;     // 1: the tensor half's CRT on the reference drivers' own shapes (m = p - 1, logQ = 512 / 341) runs its compiled form (crt32_scale_fold_kernel); 0: the run-time form (crt32_scale_generic_kernel: A/B and checker)
   int tensor_bits = 30;     // 30: the tensor half's primes are the largest below 2^30; 29: below 2^29 -- lazy values have room up to 8p, so the row transforms skip 8 of 14 (forward) / 6 of 13 (inverse) range steps, for one or two primes more (36 instead of 35 at the metric ring)
   int dot32_k4 = 1;         // 1: key switch with 7 or 8 limbs and at least 24 ciphertexts per call runs dot32_kernel4 (keys in LDS, digits and accumulators in registers); 0: dot32_kernel2 (A/B)
   int parts_words = 1;      // 1: inside the fused multiplication the scaled-down parts travel as 32-bit word rows (crt32_scale -> digit loader); 0 = 64-bit limb rows (A/B)
@@ -107,7 +106,7 @@ struct fhesi_ctx {
   // S_j - S_(j+q') - (-1)^j S_(q'-1))  or modulo X^m - 1 and Phi_m = sum X^i  (m prime:  out_j = S_j + S_(j+m) - S_(m-1))
   i64 lin_q = 0;                       // the fold's offset: q' (m = 2q') or m (m prime); 0 = not such a ring
   bool lin_prime = false;              // m itself is the prime
-  int lin_lg = 0;                      // log2 of the padded rows: 14 or 15
+  int lin_lg = 0;                      // log2 of the padded rows: 14 .. 20
   std::vector<u64> q, root;
   std::vector<int> zms_idx;            // PAlgebra::zmsIdx (PAlgebra.cpp:50-52)
   std::vector<i64> phi;                // Phi_m(X) (PAlgebra.cpp:55)

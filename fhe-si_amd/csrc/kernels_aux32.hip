@@ -55,10 +55,13 @@ i64 aux32_row_len(const fhesi_ctx* ctx) {
 }
 static int aux32_init(fhesi_ctx* ctx) {
   if (ctx->aux32) return 0;
-  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14, 2^15 and for rings m = prime or 2 * prime with 2 phi(m) - 1 <= 2^16");
+  if (!aux32_applies(ctx)) FHESI_FAIL("aux32: only for n = 2^14, 2^15 and for rings m = prime or 2 * prime with 2 phi(m) - 1 <= 2^20");
   fhesi_aux32* x = new fhesi_aux32();
-  const i64 n = aux32_row_len(ctx);                // 2^14, or 2^15 / 2^16 = two / four sub-transforms per row
-  const int S = n > 2 * A32_N ? 2 : (n > A32_N ? 1 : 0), lg = A32_LOGN + S, NS = 1 << S;
+  const i64 n = aux32_row_len(ctx);                // 2^14, or 2^15 .. 2^20 = 2^S sub-transforms per row
+  int S = 0;
+  while (((i64)A32_N << S) < n) ++S;
+  if (S > 6) { delete x; FHESI_FAIL("aux32: rows of 2^%d", A32_LOGN + S); }
+  const int lg = A32_LOGN + S, NS = 1 << S;
   x->S = S;
   // the four largest primes below 2^30 that are 1 mod 2n
   int found = 0;
@@ -69,6 +72,8 @@ static int aux32_init(fhesi_ctx* ctx) {
   if (found < 4) { delete x; FHESI_FAIL("aux32: no primes"); }
   const size_t per_prime = (size_t)A32_N << S;
   std::vector<Tw32> hf(4 * per_prime, Tw32{0, 0}), hi(4 * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n), ht(4 * A32_HT, Tw32{0, 0});
+  const int HSN = A32_HSN(S);
+  std::vector<Tw32> hs(S >= 3 ? (size_t)4 * 2 * HSN : 0, Tw32{0, 0});      // S >= 3: head / tail twiddles of the stand-alone passes (ntt32_core.inc)
   for (int a = 0; a < 4; ++a) {
     const u64 p = x->pr.p[a];
     u64 psi = 0;
@@ -105,6 +110,13 @@ static int aux32_init(fhesi_ctx* ctx) {
         c[0] = ff[1]; c[1] = ff[2]; c[2] = ff[3];
         c[4] = tw(inv2); c[5] = tw(hm::mulmod(fi[2].w, inv2, p)); c[6] = tw(hm::mulmod(fi[3].w, inv2, p)); c[7] = tw(hm::mulmod(fi[1].w, inv2, p));
       }
+      if (S >= 3) {
+        Tw32* f = &hs[(size_t)a * 2 * HSN];
+        Tw32* b = f + HSN;
+        for (int idx = 1; idx < NS; ++idx) { f[idx] = ff[idx]; b[idx] = fi[idx]; }
+        const u64 c = hm::invmod((u64)NS % p, p), cm = hm::mulmod(c, ((u64)1 << 32) % p, p);      // 2^-S and 2^-S 2^32
+        b[NS] = tw(c); b[NS + 1] = tw(hm::mulmod(fi[1].w, c, p)); b[NS + 2] = tw(cm); b[NS + 3] = tw(hm::mulmod(fi[1].w, cm, p));
+      }
     }
     const u64 ninv = hm::invmod(A32_N % p, p);     // of the 2^14-point (sub-)transform; the tail of a 2^15-point row carries the other 1/2
     x->pr.ninv[a] = (u32)ninv;
@@ -121,7 +133,7 @@ static int aux32_init(fhesi_ctx* ctx) {
       Tw32* t0 = &hi[((size_t)a * NS + h) * A32_N];
       const u64 w1 = t0[1].w, wn = hm::mulmod(w1, ninv, p), wm = hm::mulmod(w1, nm, p);
       t0[0] = tw(ninv); t0[1] = tw(wn);
-      x->pr.ninv_mw[a][h] = (u32)wm; x->pr.ninv_mw_p[a][h] = (u32)((wm << 32) / p);
+      if (h < 4) { x->pr.ninv_mw[a][h] = (u32)wm; x->pr.ninv_mw_p[a][h] = (u32)((wm << 32) / p); }      // (S >= 3 runs the plain inverse: the 2^32 sits in the tail pass)
     }
     for (int h = NS; h < 4; ++h) { x->pr.ninv_mw[a][h] = x->pr.ninv_mw[a][0]; x->pr.ninv_mw_p[a][h] = x->pr.ninv_mw_p[a][0]; }
     if (p > ((u64)1 << 30) - ((u64)1 << 15) + 1) { delete x; FHESI_FAIL("aux32: prime above 2^30 - 2^15 + 1"); }     // the bound dot32_kernel2's accumulation relies on
@@ -130,17 +142,21 @@ static int aux32_init(fhesi_ctx* ctx) {
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
   HIP_TRY(hipMemcpy(x->d_fwd, hf.data(), hf.size() * sizeof(Tw32), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(x->d_inv, hi.data(), hi.size() * sizeof(Tw32), hipMemcpyHostToDevice));
-  if (S == 2) {
+  if (S >= 2) {
     if (hipMalloc(&x->d_ht, ht.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_p, 4 * sizeof(u32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
     HIP_TRY(hipMemcpy(x->d_ht, ht.data(), ht.size() * sizeof(Tw32), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(x->d_p, x->pr.p, 4 * sizeof(u32), hipMemcpyHostToDevice));
+  }
+  if (S >= 3) {
+    if (hipMalloc(&x->d_hs, hs.size() * sizeof(Tw32)) != hipSuccess) { delete x; FHESI_FAIL("aux32: hipMalloc failed"); }
+    HIP_TRY(hipMemcpy(x->d_hs, hs.data(), hs.size() * sizeof(Tw32), hipMemcpyHostToDevice));
   }
   ctx->aux32 = x;
   return 0;
 }
 void aux32_free(fhesi_ctx* ctx) {
   if (!ctx->aux32) return;
-  hipFree(ctx->aux32->d_fwd); hipFree(ctx->aux32->d_inv); hipFree(ctx->aux32->d_ht); hipFree(ctx->aux32->d_p);
+  hipFree(ctx->aux32->d_fwd); hipFree(ctx->aux32->d_inv); hipFree(ctx->aux32->d_ht); hipFree(ctx->aux32->d_p); hipFree(ctx->aux32->d_hs);
   delete ctx->aux32;
   ctx->aux32 = nullptr;
 }
@@ -151,12 +167,26 @@ int launch_ntt32_fwd(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0)
   if (!count) return 0;
   const fhesi_aux32* x = ctx->aux32;
   const int S = x->S;
-  if (S == 2) ntt32_head2_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, nslots, a0, x->d_p, x->d_ht);
+  if (S >= 2) {      // head stages as a pass of their own, at most 65535 rows (a multiple of nslots) per launch
+    const i64 nr = count * nslots, step = (65535 / nslots) * (i64)nslots;
+    for (i64 r0 = 0; r0 < nr; r0 += step) {
+      const unsigned ny = (unsigned)std::min(step, nr - r0);
+      u32* rp = d_rows + (r0 << (A32_LOGN + S));
+      if (S == 2) ntt32_head2_kernel<<<dim3(16, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_ht);
+      else if (S == 3) ntt32_headS_kernel<3><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_hs);
+      else if (S == 4) ntt32_headS_kernel<4><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_hs);
+      else if (S == 5) ntt32_headS_kernel<5><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_hs);
+      else ntt32_headS_kernel<6><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_hs);
+    }
+  }
   else if (S) ntt32_head_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
   if (S) HIP_TRY(hipGetLastError());
   if (count > 0x7fffffff || (nslots << S) > 65535) FHESI_FAIL("ntt32: too many rows per launch");
   const dim3 grid((unsigned)count, (unsigned)(nslots << S));
-  if (S == 2) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 2>); ntt32_fwd_kernel3<false, 2><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
+#define A32_PLAIN_GO(SS) do { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, SS>); ntt32_fwd_kernel3<false, SS><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); } while (0)
+  if (S == 3) A32_PLAIN_GO(3); else if (S == 4) A32_PLAIN_GO(4); else if (S == 5) A32_PLAIN_GO(5); else if (S == 6) A32_PLAIN_GO(6);
+#undef A32_PLAIN_GO
+  else if (S == 2) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 2>); ntt32_fwd_kernel3<false, 2><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
   else if (S) { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 1>); ntt32_fwd_kernel3<false, 1><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
   else { PROF_KERNEL(ctx, PROF_NTT_FWD, ntt32_fwd_kernel3<false, 0>); ntt32_fwd_kernel3<false, 0><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_fwd, Dig32Src{}, x->hd); }
   HIP_TRY(hipGetLastError());
@@ -171,12 +201,24 @@ int launch_ntt32_inv(fhesi_ctx* ctx, u32* d_rows, i64 count, int nslots, int a0,
   ProfScope prof(ctx, PROF_NTT_INV, (double)(count * nslots));
   if (count > 0x7fffffff || (nslots << S) > 65535) FHESI_FAIL("ntt32: too many rows per launch");
   const dim3 grid((unsigned)count, (unsigned)(nslots << S));
-  if (mont) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
+  // (S >= 3: the plain inverse; the 2^32 of a Montgomery-form row is a constant of the tail pass)
+  if (mont && S < 3) { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<true>); ntt32_inv_kernel3<true><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   else { PROF_KERNEL(ctx, PROF_NTT_INV, ntt32_inv_kernel3<false>); ntt32_inv_kernel3<false><<<grid, A32_T, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->d_inv, S, nullptr); }
   HIP_TRY(hipGetLastError());
-  if (S == 2 && !tail) FHESI_FAIL("ntt32: rows of 2^16 have no consumer that takes their tail stages");
+  if (S >= 2 && !tail) FHESI_FAIL("ntt32: rows of 2^16 and longer have no consumer that takes their tail stages");
   if (S && tail) {
-    if (S == 2) ntt32_tail2_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, nslots, a0, x->d_p, x->d_ht);
+    if (S >= 2) {
+      const i64 nr = count * nslots, step = (65535 / nslots) * (i64)nslots;
+      for (i64 r0 = 0; r0 < nr; r0 += step) {
+        const unsigned ny = (unsigned)std::min(step, nr - r0);
+        u32* rp = d_rows + (r0 << (A32_LOGN + S));
+        if (S == 2) ntt32_tail2_kernel<<<dim3(16, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_ht);
+        else if (S == 3) ntt32_tailS_kernel<3><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_hs, mont ? 1 : 0);
+        else if (S == 4) ntt32_tailS_kernel<4><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_hs, mont ? 1 : 0);
+        else if (S == 5) ntt32_tailS_kernel<5><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_hs, mont ? 1 : 0);
+        else ntt32_tailS_kernel<6><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, nslots, a0, x->d_p, x->d_hs, mont ? 1 : 0);
+      }
+    }
     else ntt32_tail_kernel<<<dim3(16, (unsigned)(count * nslots)), 256, 0, ctx->stream>>>(d_rows, count, nslots, a0, x->pr, x->hd);
     HIP_TRY(hipGetLastError());
   }
@@ -200,6 +242,28 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   if (units > 0x7fffffff) FHESI_FAIL("ntt32: too many digit rows per launch");
   if (digit_bits > 30) FHESI_FAIL("ntt32: digits of %d bits (the first stage of a digit row assumes values below 2p)", digit_bits);
   Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
+  if (S >= 3) {
+    // rows of 2^17 .. 2^20, the simple path: digits + head stages into plain rows (workspace slot 11), the sub-transforms in place, then the
+    // tiled layout the dot product reads
+    if (!ctx->lin_q) FHESI_FAIL("ntt32: digit rows of 2^%d exist for the padded linear-convolution rings only", A32_LOGN + S);
+    if (units > 65535) FHESI_FAIL("ntt32: %lld digit rows of 2^%d in one launch (at least 2 MB each: the caller's chunks are smaller)", (long long)units, A32_LOGN + S);
+    void* tmp;
+    FHESI_TRY(ws_reserve(ctx, 11, (size_t)units * 4 * ((size_t)A32_N << S) * 4, &tmp));
+    u32* d_plain = (u32*)tmp;
+    const dim3 hg(A32_N / 256, (unsigned)units);
+#define A32_DH(SS) do { if (wm) dig32_headS_kernel<SS, true><<<hg, 256, 0, ctx->stream>>>(src, d_plain, x->pr, x->d_hs); else dig32_headS_kernel<SS, false><<<hg, 256, 0, ctx->stream>>>(src, d_plain, x->pr, x->d_hs); } while (0)
+    if (S == 3) A32_DH(3); else if (S == 4) A32_DH(4); else if (S == 5) A32_DH(5); else A32_DH(6);
+#undef A32_DH
+    HIP_TRY(hipGetLastError());
+    const dim3 grid((unsigned)units, (unsigned)(4 << S));
+#define A32_PLAIN_GO(SS) do { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<false, SS>); ntt32_fwd_kernel3<false, SS><<<grid, A32_T, 0, ctx->stream>>>(d_plain, units, 4, 0, x->pr, x->d_fwd, Dig32Src{}, x->hd); } while (0)
+    if (S == 3) A32_PLAIN_GO(3); else if (S == 4) A32_PLAIN_GO(4); else if (S == 5) A32_PLAIN_GO(5); else A32_PLAIN_GO(6);
+#undef A32_PLAIN_GO
+    HIP_TRY(hipGetLastError());
+    dig32_retile_kernel<<<dim3(8 << S, (unsigned)units, 4), 256, 0, ctx->stream>>>(d_plain, d_out, units, A32_LOGN - 6 + S, (u32)sub_units, div32_inv((u32)sub_units));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const int PS = 4 << S;
   const i64 blocks = (units + 7) / 8 * 8 * PS;      // units dealt round-robin to the 8 XCDs, PS workgroups (primes x sub-blocks) each
   if (blocks > 0x7fffffff) FHESI_FAIL("ntt32: too many workgroups per launch");
@@ -649,29 +713,16 @@ dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int nco
 // dot32_kernel2's Montgomery step (outputs carry the factor 2^-32, undone by the inverse transform).
 // Workgroup = 8 waves = 8 CW ciphertexts of one 64-coefficient slice of one prime; grid as dot32_kernel2 (x = slice low bits + 8 * group,
 // y = slice high bits, z = prime): the groups of a (slice, prime) sit on one XCD and share its key block in L2.
-#ifndef K4S_CW
-#define K4S_CW 5
-#endif
-#ifndef K4S_PD
-#define K4S_PD 2
-#endif
-// K4_PK: steps between the fetch of a key row and its write to LDS.  Loads return IN ORDER (one vmcnt counter): the wait for the key rows fetched
-// PK steps ago also waits for every digit word requested before them, so the digit ring is never more than PK steps ahead whatever PD says.
-#ifndef K4_PK
-#define K4_PK 2
-#endif
-#ifndef K4_PD7
-#define K4_PD7 3
-#endif
-#ifndef K4_CW7
-#define K4_CW7 6
-#endif
+// PK (below): steps between the fetch of a key row and its write to LDS.  Loads return IN ORDER (one vmcnt counter): the wait for the key rows
+// fetched PK steps ago also waits for every digit word requested before them, so the digit ring is never more than PK steps ahead whatever PD
+// says -- which is why ring depths 2 / 3 / 4 measured the same in round 5.  PK = 4 with 4 ciphertexts per lane (the registers for it) measured
+// 5.04 ms against 5.14 at PK = 2 and 4.95 for the shipped 6 ciphertexts per lane: profiles/r06_ab_stress_dot.txt.
 template <int NLBT, int CW, int KC, int PD, int NW = 8, int NSP = 1, int TAIL = 0>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, i64 count, u32* __restrict__ out, Aux32Primes pr, int ngroups, int lognsl, int sub_lg) {
   // NSP > 1 (many limbs: 15 at the stress ring): the outputs are split over NSP wave groups -- a wave carries NO = NOUT / NSP outputs of its CW
   // ciphertexts, the NSP waves of a ciphertext group load the same digit words (the second load hits in L1 / L2)
-  constexpr int NOUT = 2 * NLBT, NO = NOUT / NSP, NHA = (NO + 1) / 2, NHB = NO - NHA, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = K4_PK;
+  constexpr int NOUT = 2 * NLBT, NO = NOUT / NSP, NHA = (NO + 1) / 2, NHB = NO - NHA, ROWS = KC * NOUT, RPS = (NOUT + NW - 1) / NW, PK = 2;
   static_assert(NOUT % NSP == 0 && NW % NSP == 0, "output split");
   static_assert(TAIL >= 0 && TAIL < KC && (TAIL == 0 || TAIL >= PK), "tail chunk");
   static_assert(KC <= 12 && KC % PD == 0 && KC % PK == 0, "ring slots are compile-time; KC products on top of a folded total stay below 2^64");
@@ -924,15 +975,14 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   bool k4_primes = true;                    // dot32_kernel4 folds through 2^32 mod p = 2^32 - 4p and needs it below 2^26 (true of every prime aux32_init picks; any other ring takes the LDS-tile kernels)
   for (int a = 0; a < 4; ++a) k4_primes = k4_primes && ctx->aux32->pr.p[a] < (1u << 30) && (u32)(0u - 4u * ctx->aux32->pr.p[a]) < (1u << 26);
   if (ctx->opt.dot32_k4 && count >= 24 && k4_primes) {
-    if (k->aux_rows == 7 && ncol % 12 == 6) return launch_dot32_k4<7, K4_CW7, 12, K4_PD7, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);      // (66 columns = 5 x 12 + 6: the tail compiled on its own)
-    if (k->aux_rows == 7) return launch_dot32_k4<7, K4_CW7, 12, K4_PD7>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)
+    if (k->aux_rows == 7 && ncol % 12 == 6) return launch_dot32_k4<7, 6, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);      // (66 columns = 5 x 12 + 6: the tail compiled on its own)
+    if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)
     if (k->aux_rows == 8 && ncol % 12 == 6) return launch_dot32_k4<8, 4, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);
     if (k->aux_rows == 8) return launch_dot32_k4<8, 4, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (5 ciphertexts per lane: 160 bytes of spills -- odd counts leave the 64-bit pairs badly placed)
     // 15 limbs (the stress ring): the 30 outputs split over two wave groups (with all 30 in one lane only 3 ciphertexts fit: 81 ms per 1024 against 37.6 for dot32_kernel2p)
-#if defined(K4S_KC) && defined(K4S_TAIL)
-    if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1 && ncol % K4S_KC == K4S_TAIL) return launch_dot32_k4<15, K4S_CW, K4S_KC, K4S_PD, 8, 2, K4S_TAIL>(ctx, k, d_dig, ncol, count, d_out);
-#endif
-    if (k->aux_rows == 15 && ctx->opt.dot32_k4 > 1) return launch_dot32_k4<15, K4S_CW, 8, K4S_PD, 8, 2>(ctx, k, d_dig, ncol, count, d_out);
+    // (15 limbs -- the stress ring -- keep dot32_kernel2p: with all 30 outputs in one lane only 3 ciphertexts fit (81 ms per 1024 against 37.6); the
+    // outputs split over two wave groups, NSP = 2, measured 37.8-42 ms in six configurations of ciphertexts per lane, ring depth, key lead and chunk
+    // size against 37.5-38.2 -- profiles/r06_ab_stress_dot.txt; that instantiation left the library in round 6)
   }
   // the digit-tile forms (dot32_kernel2): tiles of 32 coefficients x 8 ciphertexts x all columns in 80 KB, two workgroups per CU (ncol <= 80);
   // more columns (the stress ring's 129) in two parts through one such tile (dot32_kernel2p: the 8-fold reuse of a key word AND two workgroups

@@ -52,7 +52,8 @@ struct fhesi_tensor32 {
   Tw32* d_fwd = nullptr;             // [primes][2^S][2^14]
   Tw32* d_inv = nullptr;
   Tw32* d_ht = nullptr;              // S = 2: [primes][A32_HT] constants of the stand-alone tail pass (ntt32_tail2_kernel)
-  u32* d_p = nullptr;                // S = 2: the primes
+  u32* d_p = nullptr;                // S >= 2: the primes
+  Tw32* d_hs = nullptr;              // S >= 3: [primes][2][A32_HSN(S)] head / tail twiddles of the stand-alone passes (ntt32_headS_kernel / ntt32_tailS_kernel)
   std::vector<T32Config*> cfgs;
   T32Config* cur = nullptr;          // the configuration of the running sum (tensor32_sum_begin)
 };
@@ -61,7 +62,7 @@ void tensor32_free(fhesi_ctx* ctx) {
   fhesi_tensor32* x = ctx->tensor32;
   if (!x) return;
   for (T32Config* c : x->cfgs) delete c;
-  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_ht); hipFree(x->d_p);
+  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_ht); hipFree(x->d_p); hipFree(x->d_hs);
   delete x;
   ctx->tensor32 = nullptr;
 }
@@ -167,7 +168,9 @@ static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->lane_stream) HIP_TRY(hipStreamSynchronize(ctx->lane_stream));
   const int S = x->S, lg = A32_LOGN + S, NP = (int)primes.size(), NS = 1 << S;
-  if (S < 0 || S > 2) FHESI_FAIL("tensor32: rows of 2^%d", lg);
+  if (S < 0 || S > 6) FHESI_FAIL("tensor32: rows of 2^%d", lg);
+  const int HSN = A32_HSN(S);
+  std::vector<Tw32> hs(S >= 3 ? (size_t)NP * 2 * HSN : 0, Tw32{0, 0});
   const i64 n = (i64)A32_N << S;
   const size_t per_prime = (size_t)A32_N << S;
   std::vector<Tw32> hf((size_t)NP * per_prime, Tw32{0, 0}), hi((size_t)NP * per_prime, Tw32{0, 0}), ff((size_t)n), fi((size_t)n), ht((size_t)NP * A32_HT, Tw32{0, 0});
@@ -206,6 +209,13 @@ static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
         c[0] = ff[1]; c[1] = ff[2]; c[2] = ff[3];
         c[4] = tw(inv2); c[5] = tw(hm::mulmod(fi[2].w, inv2, p)); c[6] = tw(hm::mulmod(fi[3].w, inv2, p)); c[7] = tw(hm::mulmod(fi[1].w, inv2, p));
       }
+      if (S >= 3) {          // (as aux32_init)
+        Tw32* f = &hs[(size_t)a * 2 * HSN];
+        Tw32* b = f + HSN;
+        for (int idx = 1; idx < NS; ++idx) { f[idx] = ff[idx]; b[idx] = fi[idx]; }
+        const u64 c = hm::invmod((u64)NS % p, p), cm = hm::mulmod(c, ((u64)1 << 32) % p, p);
+        b[NS] = tw(c); b[NS + 1] = tw(hm::mulmod(fi[1].w, c, p)); b[NS + 2] = tw(cm); b[NS + 3] = tw(hm::mulmod(fi[1].w, cm, p));
+      }
     }
   }
   // the inverse transform's last stage carries the final scaling (ntt32_inv_kernel3): entries 0 and 1 of every (prime, sub-block) table
@@ -218,12 +228,16 @@ static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
       t0[0] = Tw32{(u32)ninv, (u32)((ninv << 32) / p)}; t0[1] = Tw32{(u32)wn, (u32)((wn << 32) / p)};
     }
   }
-  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_ht); hipFree(x->d_p);
-  x->d_fwd = x->d_inv = x->d_ht = nullptr; x->d_p = nullptr;
-  if (S == 2) {
+  hipFree(x->d_fwd); hipFree(x->d_inv); hipFree(x->d_ht); hipFree(x->d_p); hipFree(x->d_hs);
+  x->d_fwd = x->d_inv = x->d_ht = x->d_hs = nullptr; x->d_p = nullptr;
+  if (S >= 2) {
     if (hipMalloc(&x->d_ht, ht.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_p, (size_t)NP * sizeof(u32)) != hipSuccess) FHESI_FAIL("tensor32: hipMalloc failed");
     HIP_TRY(hipMemcpy(x->d_ht, ht.data(), ht.size() * sizeof(Tw32), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(x->d_p, primes.data(), (size_t)NP * sizeof(u32), hipMemcpyHostToDevice));
+  }
+  if (S >= 3) {
+    if (hipMalloc(&x->d_hs, hs.size() * sizeof(Tw32)) != hipSuccess) FHESI_FAIL("tensor32: hipMalloc failed");
+    HIP_TRY(hipMemcpy(x->d_hs, hs.data(), hs.size() * sizeof(Tw32), hipMemcpyHostToDevice));
   }
   a32_permute_phase_c(hf); a32_permute_phase_c(hi);      // (the last four stages' twiddles in the order the waves load them: A32_TWC)
   if (hipMalloc(&x->d_fwd, hf.size() * sizeof(Tw32)) != hipSuccess || hipMalloc(&x->d_inv, hi.size() * sizeof(Tw32)) != hipSuccess) FHESI_FAIL("tensor32: hipMalloc failed");
@@ -697,125 +711,6 @@ __global__ void __launch_bounds__(128) crt32_scale_generic_kernel(const u32* __r
   }
 }
 
-// The run-time form above with everything that can be a constant made one -- for the shapes the reference's own drivers produce at scale
-// (Test_AddMul.cpp:131 / Test_Regression.cpp:100-122: m = p - 1 for a safe prime, so FOLD = 1): logQ, the window of words [J0, J0 + NW) and the
-// bit positions of the output limbs are compile-time, so the words stay in registers from the multiply-adds to the limbs (no LDS round trip,
-// no run-time shifts), exactly as in crt32_scale_kernel; the loader (positions folded from, sub-rows of a 2^15-point row) is the run-time
-// form's.  LQ need not be a multiple of 64 (configs[3]: logQ = 341): the top limb is masked.  wt: words per table row (run-time: it depends
-// on the prime count of the configuration).
-template <int LQ, bool EXACT, int S, int FOLD>
-__global__ void __launch_bounds__(128) crt32_scale_fold_kernel(const u32* __restrict__ rows, i64 nrow, i64 n_out, i64 fold_off, int NP, int wt, T32Primes pr,
-                                                                const Tw32* __restrict__ cinv, const u32* __restrict__ inv57, const u32* __restrict__ Mw,
-                                                                u64* __restrict__ out, unsigned char* __restrict__ flags, int wm) {
-  constexpr int R = 28;
-  constexpr int WU = (2 * LQ + R - 1) / R;            // words that reach below bit 2 logQ
-  constexpr int J0 = (EXACT || LQ < 64 + 38) ? 0 : (LQ - 64 - 30 - 8) / R;     // first word formed: R J0 + 30 + log2(NP + 1) + 1 <= logQ - 64
-  constexpr int NW = WU - J0, NLQ = (LQ + 63) / 64;
-  static_assert(LQ >= 64 && FOLD >= 0 && FOLD <= 2 && (S == 0 || S == 1), "shape");
-  const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-  if (EXACT && !flags[wg]) return;
-  const i64 poly = blockIdx.y;
-  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = j < n_out;
-  const u32* __restrict__ src = rows + poly * NP * nrow;
-  int undecided = 0;
-  if (active) {
-    u64 acc[NW];
-#pragma unroll
-    for (int l = 0; l < NW; ++l) acc[l] = 0;
-    u32 fsum = 0;
-    // term 0: position j, +;  term 1: position j + off, - (m = 2q') or + (m prime);  term 2: position off - 1, -(-1)^j (m = 2q') or - (m prime)
-    constexpr int NT = FOLD ? 3 : 1;
-    u32 eb[NT];
-    bool up[NT], ok[NT], neg[NT];
-    {
-      const i64 e[3] = {j, j + fold_off, fold_off - 1};
-      const bool ng[3] = {false, FOLD == 1, FOLD == 2 || !(j & 1)};
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        ok[k] = e[k] < nrow;
-        const u32 idx = ok[k] ? (u32)e[k] : 0u;
-        up[k] = S && idx >= (u32)A32_N;
-        eb[k] = S ? (idx & (u32)(A32_N - 1)) : idx;
-        neg[k] = ng[k];
-      }
-    }
-#pragma unroll 2
-    for (int i = 0; i < NP; ++i) {
-      const u32 p = pr.p[i], twop = 2 * p;
-      const u32* __restrict__ ri = src + (i64)i * nrow;
-      u32 y;
-      if (S) {
-        u32 A[NT], B[NT];
-#pragma unroll
-        for (int k = 0; k < NT; ++k) { A[k] = ri[eb[k]]; B[k] = ri[eb[k] + A32_N]; }
-        auto red2 = [&](u32 v) -> u32 { return min(v, v - twop); };                 // [0, 4p) -> [0, 2p)
-        u32 lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-          const u32 t = up[k] ? A[k] + p - B[k] : A[k] + B[k];                       // at most 2p
-          const u32 v = ok[k] ? (neg[k] ? twop - t : t) : 0u;
-          if (k == 0) { lo = up[0] ? 0u : v; hi = up[0] ? v : 0u; }
-          else { lo = red2(lo + (up[k] ? 0u : v)); hi = red2(hi + (up[k] ? v : 0u)); }
-        }
-        if (NT == 1) { lo = red2(lo); hi = red2(hi); }
-        y = mul_lazy32(lo, cinv[2 * i], p) + mul_lazy32(hi, cinv[2 * i + 1], p);    // below 4p
-        y = min(y, y - twop);
-        y = min(y, y - p);
-      } else {
-        u32 r = ri[eb[0]];
-        if (FOLD) {
-          const u32 b = ok[1] ? ri[eb[1]] : 0u, c = ri[eb[2]];
-          if (FOLD == 1) r = r + (p - b) + (neg[2] ? p - c : c);                    // r_j - r_(j+q') - (-1)^j r_(q'-1): below 4p
-          else r = r + b + (p - c);                                                  // r_j + r_(j+m) - r_(m-1): below 3p
-        }
-        y = mul_lazy32(r, cinv[2 * i], p);
-        y = y >= p ? y - p : y;
-      }
-      fsum += __umulhi(y, inv57[i]);
-      const u32* __restrict__ Mi = Mw + (i64)i * wt + J0;
-#pragma unroll
-      for (int l = 0; l < NW; ++l) acc[l] += (u64)y * Mi[l];
-    }
-    const u32 kappa = (fsum + (1u << 24)) >> 25;
-    {
-      const u32* __restrict__ Nm = Mw + (i64)NP * wt + J0;
-#pragma unroll
-      for (int l = 0; l < NW; ++l) acc[l] += (u64)kappa * Nm[l];
-    }
-    u64 carry = 0;
-#pragma unroll
-    for (int l = 0; l < NW; ++l) { const u64 v = acc[l] + carry; acc[l] = v & (((u64)1 << R) - 1); carry = v >> R; }
-    // 64 bits from bit B of x (two's complement, bits above R WU dropped)
-    auto limb = [&](int B) -> u64 {
-      const int l0 = B / R - J0, o = B % R;
-      u64 v = l0 < NW ? acc[l0 < NW ? l0 : 0] >> o : 0;
-      if (l0 + 1 < NW) v |= acc[l0 + 1 < NW ? l0 + 1 : 0] << (R - o);
-      if (l0 + 2 < NW) v |= acc[l0 + 2 < NW ? l0 + 2 : 0] << (2 * R - o);
-      if (l0 + 3 < NW && 3 * R - o < 64) v |= acc[l0 + 3 < NW ? l0 + 3 : 0] << (3 * R - o);
-      return v;
-    };
-    const u64 G = limb(LQ - 64);                         // bits logQ-64 .. logQ-1
-    if (!EXACT) undecided = (G == 0x7fffffffffffffffull) ? 1 : 0;
-    u64 c = G >> 63;                                     // round half up: + bit logQ-1
-    u64* __restrict__ o = out + poly * NLQ * n_out + j;
-    u32* __restrict__ o32 = reinterpret_cast<u32*>(out) + poly * (2 * NLQ) * n_out + j;
-#pragma unroll
-    for (int i = 0; i < NLQ; ++i) {
-      u64 v = limb(LQ + 64 * i);
-      v += c;
-      c = (c && v == 0) ? 1 : 0;
-      if (LQ - 64 * i < 64) v &= ((u64)1 << ((LQ - 64 * i) & 63)) - 1;
-      if (wm) { o32[(i64)(2 * i) * n_out] = (u32)v; o32[(i64)(2 * i + 1) * n_out] = (u32)(v >> 32); }
-      else o[(i64)i * n_out] = v;
-    }
-  }
-  if (!EXACT) {
-    const int any = __syncthreads_or(undecided);
-    if (threadIdx.x == 0) flags[wg] = any ? 1 : 0;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------- launchers
 static i64 t32_nrow(const fhesi_ctx* ctx) { return (i64)A32_N << ctx->tensor32->S; }
 template <int NL>
@@ -823,14 +718,17 @@ static int t32_launch_rns(fhesi_ctx* ctx, const T32Config* c, const u64* d_a, co
   const int S = ctx->tensor32->S;
   const i64 nrow = t32_nrow(ctx), n_src = ctx->phim;
   const unsigned zs = npolys * (A32_N / 256) >= 2048 ? 1u : (npolys * (A32_N / 256) >= 1024 ? 2u : 5u);      // (primes split over z for small launches)
-  const dim3 grid((unsigned)(A32_N / 256), (unsigned)npolys, zs);
+  // (rows of 2^17 and longer -- S >= 3, the simple path -- are converted as plain zero-padded rows, one block per 256 positions of the whole row;
+  // their head stages are a pass of their own in t32_fwd)
+  const dim3 grid((unsigned)((S >= 3 ? nrow : (i64)A32_N) / 256), (unsigned)npolys, zs);
   const int* ia = paired && ctx->op_idx ? ctx->op_idx + ctx->op_idx_done : nullptr;
   const int* ib = ia ? ia + ctx->op_idx_n : nullptr;
   const int dup = S == 1 && ctx->lin_q ? 1 : 0;
-  if (S == 2 && !ctx->lin_q) FHESI_FAIL("tensor32: rows of 2^16 exist for the padded linear-convolution rings only");
+  if (S >= 2 && !ctx->lin_q) FHESI_FAIL("tensor32: rows of 2^16 and longer exist for the padded linear-convolution rings only");
 #define T32_GO(HEAD, PAIRED) do { PROF_KERNEL(ctx, PROF_RNS, rns32_reduce_kernel<NL, HEAD, PAIRED>); \
     rns32_reduce_kernel<NL, HEAD, PAIRED><<<grid, 256, 0, ctx->stream>>>(d_a, d_b, na2, n_src, nrow, d_r, c->NP, c->d_rns, ia, ib, dup); } while (0)
-  if (S == 2) { if (paired) T32_GO(2, true); else T32_GO(2, false); }
+  if (S >= 3) { if (paired) T32_GO(0, true); else T32_GO(0, false); }
+  else if (S == 2) { if (paired) T32_GO(2, true); else T32_GO(2, false); }
   else if (S && !dup) { if (paired) T32_GO(1, true); else T32_GO(1, false); }
   else { if (paired) T32_GO(0, true); else T32_GO(0, false); }
 #undef T32_GO
@@ -855,8 +753,22 @@ static int t32_fwd(fhesi_ctx* ctx, const T32Config* c, u32* d_r, i64 npolys) {
   const dim3 grid((unsigned)npolys, (unsigned)(c->NP << x->S));
 #define T32_FWD_GO(SS, PB) do { PROF_KERNEL(ctx, PROF_NTT_FWD, (ntt32_fwd_kernel3<false, SS, false, T32Primes, true, false, PB>)); \
     ntt32_fwd_kernel3<false, SS, false, T32Primes, true, false, PB><<<grid, A32_T, 0, ctx->stream>>>(d_r, npolys, c->NP, 0, c->pr, x->d_fwd, Dig32Src{}, Aux32Head{}); } while (0)
-  if (x->bits == 29) { if (x->S == 2) T32_FWD_GO(2, 29); else if (x->S) T32_FWD_GO(1, 29); else T32_FWD_GO(0, 29); }
-  else { if (x->S == 2) T32_FWD_GO(2, 30); else if (x->S) T32_FWD_GO(1, 30); else T32_FWD_GO(0, 30); }
+  if (x->S >= 3) {       // head stages of the plain rows as a pass of their own (at most 65535 rows, a multiple of NP, per launch)
+    const i64 nr = npolys * c->NP, step = (65535 / c->NP) * (i64)c->NP;
+    for (i64 r0 = 0; r0 < nr; r0 += step) {
+      const dim3 hg(A32_N / 256, (unsigned)std::min(step, nr - r0));
+      u32* rp = d_r + (r0 << (A32_LOGN + x->S));
+      if (x->S == 3) ntt32_headS_kernel<3><<<hg, 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_hs);
+      else if (x->S == 4) ntt32_headS_kernel<4><<<hg, 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_hs);
+      else if (x->S == 5) ntt32_headS_kernel<5><<<hg, 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_hs);
+      else ntt32_headS_kernel<6><<<hg, 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_hs);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+#define T32_FWD_S(PB) do { switch (x->S) { case 0: T32_FWD_GO(0, PB); break; case 1: T32_FWD_GO(1, PB); break; case 2: T32_FWD_GO(2, PB); break; case 3: T32_FWD_GO(3, PB); break; \
+    case 4: T32_FWD_GO(4, PB); break; case 5: T32_FWD_GO(5, PB); break; default: T32_FWD_GO(6, PB); break; } } while (0)
+  if (x->bits == 29) T32_FWD_S(29); else T32_FWD_S(30);
+#undef T32_FWD_S
 #undef T32_FWD_GO
   HIP_TRY(hipGetLastError());
   return 0;
@@ -909,27 +821,24 @@ static int t32_crt(fhesi_ctx* ctx, const T32Config* c, const u32* d_t, i64 npoly
       crt32_scale_generic_kernel<T32_GEN_NWX, true, SS, FF><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, logQ, 0, WU, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0); \
       HIP_TRY(hipGetLastError()); \
     } } while (0)
-  if (S == 2) {      // rows of 2^16: the two tail stages as a pass of their own over the sub-inverses (in place), then the fold from whole rows
-    ntt32_tail2_kernel<<<dim3(16, (unsigned)(npolys * c->NP)), 256, 0, ctx->stream>>>(const_cast<u32*>(d_t), c->NP, 0, ctx->tensor32->d_p, ctx->tensor32->d_ht);
+  if (S >= 2) {      // rows of 2^16 and longer: the tail stages as a pass of their own over the sub-inverses (in place), then the fold from whole rows
+    const fhesi_tensor32* x = ctx->tensor32;
+    const i64 nr = npolys * c->NP, step = (65535 / c->NP) * (i64)c->NP;
+    for (i64 r0 = 0; r0 < nr; r0 += step) {
+      const unsigned ny = (unsigned)std::min(step, nr - r0);
+      u32* rp = const_cast<u32*>(d_t) + (r0 << (A32_LOGN + S));
+      if (S == 2) ntt32_tail2_kernel<<<dim3(16, ny), 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_ht);
+      else if (S == 3) ntt32_tailS_kernel<3><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_hs, 0);
+      else if (S == 4) ntt32_tailS_kernel<4><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_hs, 0);
+      else if (S == 5) ntt32_tailS_kernel<5><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_hs, 0);
+      else ntt32_tailS_kernel<6><<<dim3(A32_N / 256, ny), 256, 0, ctx->stream>>>(rp, c->NP, 0, x->d_p, x->d_hs, 0);
+    }
     HIP_TRY(hipGetLastError());
   }
-  // the compiled forms of the reference drivers' own shapes (m = p - 1 for a safe prime: fold 1): Test_AddMul's logQ = 512 on padded rows of
-  // 2^15 (p = 32603) and of 2^16 (p = 65267: whole rows after the tail pass), Test_Regression's logQ = 341 at p = 8423 (rows of 2^14)
-#define T32_FOLD_GO(LQ_, SS) do { \
-    PROF_KERNEL(ctx, PROF_CRT, (crt32_scale_fold_kernel<LQ_, false, SS, 1>)); \
-    crt32_scale_fold_kernel<LQ_, false, SS, 1><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0); \
-    HIP_TRY(hipGetLastError()); \
-    if (!ctx->opt.crt_skip_cleanup) { \
-      crt32_scale_fold_kernel<LQ_, true, SS, 1><<<grid, 128, 0, ctx->stream>>>(d_t, nrow, n_out, off, c->NP, c->WT, c->pr, c->d_cinv, c->d_inv57, c->d_Mw, d_parts, fl, wm ? 1 : 0); \
-      HIP_TRY(hipGetLastError()); \
-    } \
-    return 0; } while (0)
-  if (fold == 1 && ctx->opt.crt_compiled) {
-    if (logQ == 512 && S == 1) T32_FOLD_GO(512, 1);
-    if (logQ == 512 && S != 1) T32_FOLD_GO(512, 0);
-    if (logQ == 341 && S == 0) T32_FOLD_GO(341, 0);
-  }
-#undef T32_FOLD_GO
+  // (A compiled form of this kernel for the reference drivers' own shapes -- logQ, word window and limb positions as constants, the words in
+  // registers from the multiply-adds to the limbs -- was measured in round 6 and removed: crt class 8.80-8.85 ms per 1024 multiplications at
+  // m = 32602 with this run-time form, 8.92-8.99 with the compiled one (profiles/r06_ab_crt_compiled.txt).  The kernel's time is its loads -- two
+  // sub-rows at three folded positions per prime -- and its multiply-adds, twice the metric ring's for rows twice as long, not its indexing.)
 #define T32_GEN_SF(NWM) do { \
     if (S != 1) { if (fold == 0) T32_GEN_GO(NWM, 0, 0); else if (fold == 1) T32_GEN_GO(NWM, 0, 1); else T32_GEN_GO(NWM, 0, 2); } \
     else { if (fold == 0) T32_GEN_GO(NWM, 1, 0); else if (fold == 1) T32_GEN_GO(NWM, 1, 1); else T32_GEN_GO(NWM, 1, 2); } } while (0)

@@ -66,9 +66,8 @@ void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t a
  * reference's own structure FHE-SI.cpp:251-254), "ks_residues", "ks_aux60", "crt_exact", "crt_skip_cleanup" (test hook), "lanes" (2 = two
  * concurrent half-batches), "stagger", "batch_chunk", "wave_operands", "tensor32" (0 = the fused pipeline keeps the tensor product on the
  * chain primes), "tensor_bits" (30 / 29: the size of the tensor half's primes -- below 2^29 the row transforms skip half of their range steps
- * for one or two primes more; the integers formed are the same), "crt_compiled" (0 = the run-time form of the tensor half's CRT where a compiled
- * one exists for the shape: the reference drivers' rings m = p - 1 at logQ = 512 / 341); layout switches that never change a result (round 5): "dot32_k4" (0 = the digit-tile dot product dot32_kernel2 where the
- * key-in-LDS form dot32_kernel4 would run; 2 = also offer its split form for 15 limbs), "parts_words" (0 = 64-bit limb rows between the tensor half and the digit loader),
+ * for one or two primes more; the integers formed are the same); layout switches that never change a result (round 5): "dot32_k4" (0 = the digit-tile dot product dot32_kernel2 where the
+ * key-in-LDS form dot32_kernel4 would run), "parts_words" (0 = 64-bit limb rows between the tensor half and the digit loader),
  * "ks_long_keys", "host_chunk", "host_threads".
  * The FHESI_<NAME> environment variables give the initial values, read once in fhesi_ctx_create -- never per call.
  * fhesi_ctx_destroy fails while DoubleCRT / key-switch handles of the context are alive (they hold the reference's `const FHEcontext&`). */

@@ -96,20 +96,6 @@ def test_config4_generated_keys_column_parts():
     assert "dot32_kernel2p" in ctx_kernel_name(ctx, ksk, logQ, p, a, b, nl)
     for c in (0, 7, 8):
         assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
-    # the same 15 limbs through dot32_kernel4 with the 30 outputs split over two wave groups (option dot32_k4 = 2; a ragged batch of 27)
-    rep = np.concatenate([a, a, a])[:27], np.concatenate([b, b, b])[:27]
-    da, db, dout = ctx.upload(rep[0]), ctx.upload(rep[1]), ctx.alloc(rep[0].nbytes)
-    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, 27)
-    want27 = dout.download((27, 2, n, nl))
-    assert np.array_equal(want27[:9], got) and np.array_equal(want27[18:27], got)
-    ctx.set_option("dot32_k4", 2)
-    ctx.prof_enable(True)
-    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, 27)
-    ctx.sync()
-    assert "dot32_kernel4<15" in ctx.prof_kernel_name("dot"), ctx.prof_kernel_name("dot")
-    ctx.prof_enable(False)
-    assert np.array_equal(dout.download((27, 2, n, nl)), want27)
-    ctx.set_option("dot32_k4", 1)
     ctx.set_option("ks_long_keys", 1)
     assert np.array_equal(ctx.ct_mul_relin(ksk, logQ, p, a, b), got)
 
@@ -301,11 +287,6 @@ def test_refring_generated_keys_eight_limbs():
     ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
     assert np.array_equal(dout.download((count, 2, n, nl)), got)
     ctx.set_option("dot32_k4", 1)
-    # the tensor half's CRT ran its compiled form for this shape (crt32_scale_fold_kernel<512, .., S = 1, FOLD = 1>); the run-time form gives the same bits
-    ctx.set_option("crt_compiled", 0)
-    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
-    assert np.array_equal(dout.download((count, 2, n, nl)), got)
-    ctx.set_option("crt_compiled", 1)
     orc = O.Oracle(m, primes, roots)
     orc.set_bluestein_fft(True)
     assert np.array_equal(got[24], orc.ct_mul_relin(ksk.download(), a[24], b[24], logQ, p))

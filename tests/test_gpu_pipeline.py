@@ -213,10 +213,6 @@ def test_tensor_half_over_30_bit_primes_equals_the_chain(m, logQ, p):
     assert ctx.get_option("tensor_bits") == 59 - bits
     ctx.set_option("tensor_bits", bits)
     assert np.array_equal(got, other)
-    # ... and through the run-time form of the CRT where a compiled one exists for the shape (option crt_compiled: m = p - 1 with logQ = 341 / 512)
-    ctx.set_option("crt_compiled", 0)
-    assert np.array_equal(got, ctx.ct_mul_relin(ksk, logQ, p, a, b))
-    ctx.set_option("crt_compiled", 1)
     # (general m at this size: seconds per Bluestein row in the oracle; at m = 65266 minutes per multiplication -- there the chain path above,
     # per-prime Bluestein rows checked against the oracle on the smaller rings and in test_gpu_general_m.py, stands in)
     for c in (() if m > 40000 else (2,) if ctx.phim > 10000 and (m & (m - 1)) != 0 else (1, 2)):
@@ -621,3 +617,59 @@ def test_key_switch_centred_limbs_of_generated_matrices(m, logQ, p):
     got3 = ctx.ct_mul_relin(ksk3, logQ, p, a, b)
     assert not ksk3.key_bits()[0]
     assert np.array_equal(got3[0], orc.ct_mul_relin(ksm, a[0], b[0], logQ, p))
+
+
+@pytest.mark.parametrize("m,logQ,p,lin_lg", [(1006, 128, 23, 17), (1006, 200, 23, 18), (46, 128, 47, 19), (101, 128, 23, 17), (22, 100, 23, 20),
+                                             (65542, 128, 65543, 0)])      # p = 65543: the first safe prime beyond 2^16 -- phi(m) = 32770, 2 phi(m) - 1 = 65539 > 2^16: rows of 2^17
+def test_padded_rows_beyond_2_16_take_the_simple_path(m, logQ, p, lin_lg, monkeypatch):
+    """The reference admits every m below 2^20 (FHEContext.cpp:89) and its drivers use m = p - 1 (Test_AddMul.cpp:131): for safe primes beyond
+    65 537 the padded rows of the linear convolutions are 2^17 .. 2^20 long.  Those run the SIMPLE path (ntt32_core.inc): head and tail stages as
+    passes of their own (ntt32_headS_kernel / ntt32_tailS_kernel, the digit polynomials through dig32_headS_kernel + dig32_retile_kernel), 2^S
+    sub-transforms of 2^14 points in between, folds from whole rows -- instead of per-prime Bluestein rows (bluestein.cpp:93-144,
+    CModulus.cpp:90-132).  FHESI_LIN_LG forces longer rows than a ring needs, so that rings the oracle finishes in seconds exercise every row
+    length (2^17 .. 2^20); the ring that NEEDS rows of 2^17 (p = 65543) is held to the per-prime device path, uniform and generated keys."""
+    if lin_lg:
+        monkeypatch.setenv("FHESI_LIN_LG", str(lin_lg))
+    count = 3
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 900 + m, count)
+    n = ctx.phim
+    lo, hi = -(1 << (logQ - 1)), (1 << (logQ - 1)) - 1
+    rng = np.random.default_rng(3)
+    a[1, 0] = O.ints_to_limbs([lo] * n, nl)                       # the extremes of the centred range everywhere
+    b[1, 0] = O.ints_to_limbs([lo] * n, nl)
+    a[1, 1] = O.ints_to_limbs([lo if v else hi for v in rng.integers(0, 2, n)], nl)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(a.nbytes)
+    ctx.prof_enable(True)
+    ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
+    ctx.sync()
+    S = (lin_lg if lin_lg else 17) - 14
+    assert f"ntt32_fwd_kernel3<false, {S}," in ctx.prof_kernel_name("ntt_fwd_digits_main"), ctx.prof_kernel_name("ntt_fwd_digits_main")
+    assert "rns32_reduce_kernel" in ctx.prof_kernel_name("rns_reduce") and ksk.form()[0] == 1
+    ctx.prof_enable(False)
+    got = dout.download((count, 2, n, nl))
+    if m < 2000:
+        for c in range(count):
+            assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    # the reference's own structure on the device: tensor product over the chain, one dot product per chain prime (Bluestein rows)
+    ctx.set_option("tensor32", 0)
+    ctx.set_option("ks_direct", 1)
+    kd = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    assert np.array_equal(ctx.ct_mul_relin(kd, logQ, p, a, b), got)
+    ctx.set_option("tensor32", 1)
+    ctx.set_option("ks_direct", 0)
+    # a GENERATED matrix (centred limbs: the other recombination kernel), and a wave of sums of products (Matrix arithmetic of Regression)
+    one = np.zeros((n, 1), dtype=np.uint64)
+    one[0, 0] = 1
+    t = F.DoubleCRT(ctx).sample(0, min(64, n // 2), 77, 1)
+    t2 = t.copy()
+    t2.op(t, 2)
+    kg = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([F.DoubleCRT.from_poly(ctx, one), t, t2], t, logQ, 77, 78, 100, 3)
+    got_g = ctx.ct_mul_relin(kg, logQ, p, a, b)
+    assert kg.form()[0] == 1
+    ctx.set_option("ks_direct", 1)
+    kg_d = F.KeySwitchMatrix(ctx, 3, nd).upload(kg.download())
+    assert np.array_equal(ctx.ct_mul_relin(kg_d, logQ, p, a, b), got_g)
+    ctx.set_option("ks_direct", 0)
+    if m < 2000:
+        assert np.array_equal(got_g[2], orc.ct_mul_relin(kg.download(), a[2], b[2], logQ, p))
