@@ -168,7 +168,7 @@ def cpu_baseline(primes, roots, ksm, a, b, n_sample, bluestein_sample=1, all_cor
     from concurrent.futures import ThreadPoolExecutor
     threads = max(1, min(info["usable_cpus"], 64))        # (each oracle call holds ~0.4 GB of digit rows)
     dt_all = None
-    if all_cores:
+    if all_cores and pow2:          # (Bluestein-mode multiplications on the reference's rings take minutes each: the single-thread sample alone)
         t1 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=threads) as ex:
             list(ex.map(lambda i: orc.ct_mul_relin(ksm, a[i % n_sample], b[i % n_sample], LOGQ, P_PLAIN, DECOMP), range(threads)))

@@ -75,6 +75,27 @@ def test_key_broadcast_exchange_and_allreduce(devices):
     _threads(G, lambda r: comms[r].exchange(ctxs[r], bufs[r], off))
     for r in range(G):
         assert np.array_equal(bufs[r].download(full.shape), full), r
+    # the same exchange in two chunks through begin / end (the communicator's own stream behind an event of the compute stream): chunk 0 =
+    # entries [0, 4), chunk 1 = entries [4, 7), each sharded over all ranks; work queued on the compute stream in between
+    bufs2 = []
+    chunks = [(0, 4), (4, 7)]
+    for r in range(G):
+        mine = np.zeros_like(full)
+        for c0, c1 in chunks:
+            lo, hi = shard.shard_bounds(c1 - c0, r, G)
+            mine[c0 + lo:c0 + hi] = full[c0 + lo:c0 + hi]
+        bufs2.append(ctxs[r].upload(mine))
+
+    def overlapped(r):
+        for c0, c1 in chunks:
+            bb = [shard.shard_bounds(c1 - c0, q, G) for q in range(G)]
+            comms[r].exchange_begin(ctxs[r], bufs2[r], [(c0 + bb[0][0]) * words] + [(c0 + hi) * words for _, hi in bb])
+            ctxs[r].ct_mul_relin(ksks[r], logQ, p, a, b)          # (compute between the begins: the exchange travels meanwhile)
+        comms[r].exchange_end(ctxs[r])
+        comms[r].exchange_end(ctxs[r])                             # (idempotent: nothing pending)
+    _threads(G, overlapped)
+    for r in range(G):
+        assert np.array_equal(bufs2[r].download(full.shape), full), r
     # exact all-reduce of partial scaled-up sums: 2 DoubleCRTs per rank
     parts = [P.rand_rows(np.random.default_rng(50 + r), primes, n, 2) for r in range(G)]
     parts[0][0, 0, :] = np.uint64(primes[0] - 1)

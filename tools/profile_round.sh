@@ -11,6 +11,20 @@ run() {   # name, then bench.py arguments
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$name" -o "$name" -- python3 "$R/bench.py" "$@" > "$O/${name}_bench.json" 2> "$O/${name}.log"
   cp "$O/$name"/*/"${name}_kernel_stats.csv" "$O/${name}_kernel_stats.csv" 2>/dev/null || cp "$O/$name/${name}_kernel_stats.csv" "$O/${name}_kernel_stats.csv" 2>/dev/null
+  # min / median / mean per kernel from the trace (the stats file has no median, and its mean includes the cold first launch)
+  python3 - "$O/$name" "$O/${name}_kernel_times.csv" <<'PY'
+import csv, glob, sys, collections
+tr = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
+if tr:
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr[0])):
+        d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    with open(sys.argv[2], "w") as f:
+        f.write("kernel,calls,min_ms,median_ms,mean_ms,max_ms,total_ms\n")
+        for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+            v.sort()
+            f.write('"%s",%d,%.4f,%.4f,%.4f,%.4f,%.3f\n' % (k.replace('"', "'"), len(v), v[0], v[(len(v) - 1) // 2], sum(v) / len(v), v[-1], sum(v)))
+PY
   tail -1 "$O/${name}_bench.json" | cut -c1-400
 }
 if [ -z "${PROFILE_ONLY_PMC:-}" ]; then
@@ -22,6 +36,7 @@ run regression_ref_p32603 --workload regression --reg-ring reference --reg-p 326
 run ntt --workload ntt --steps 10 --warmup 2
 run refring --workload refring --steps 5 --warmup 2 --cpu-sample 0 --gpu-seconds 0
 run refring_p65267 --workload refring --ref-p 65267 --steps 3 --warmup 1 --cpu-sample 0 --gpu-seconds 0 --batch 512
+run refring_p65543 --workload refring --ref-p 65543 --steps 3 --warmup 1 --cpu-sample 0 --gpu-seconds 0 --batch 256
 fi
 for c in FETCH_SIZE WRITE_SIZE; do        # one counter per pass (combining them has hung the profiler on this pool)
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-sample 0 --batch 1024 --no-surface --gpu-seconds 0 > /dev/null 2> "$O/pmc_$c.log"
