@@ -243,8 +243,7 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
   if (digit_bits > 30) FHESI_FAIL("ntt32: digits of %d bits (the first stage of a digit row assumes values below 2p)", digit_bits);
   Dig32Src src{d_parts, nl, digit_bits, nd, (u32)ctx->phim, (u32)sub_units, div32_inv((u32)nd), div32_inv((u32)sub_units)};
   if (S >= 3) {
-    // rows of 2^17 .. 2^20, the simple path: digits + head stages into plain rows (workspace slot 11), the sub-transforms in place, then the
-    // tiled layout the dot product reads
+    // rows of 2^17 .. 2^20, the simple path: digits + head stages into plain rows (workspace slot 11)
     if (!ctx->lin_q) FHESI_FAIL("ntt32: digit rows of 2^%d exist for the padded linear-convolution rings only", A32_LOGN + S);
     if (units > 65535) FHESI_FAIL("ntt32: %lld digit rows of 2^%d in one launch (at least 2 MB each: the caller's chunks are smaller)", (long long)units, A32_LOGN + S);
     void* tmp;
@@ -255,12 +254,15 @@ int launch_ntt32_fwd_digits(fhesi_ctx* ctx, const u64* d_parts, int nl, int digi
     if (S == 3) A32_DH(3); else if (S == 4) A32_DH(4); else if (S == 5) A32_DH(5); else A32_DH(6);
 #undef A32_DH
     HIP_TRY(hipGetLastError());
-    const dim3 grid((unsigned)units, (unsigned)(4 << S));
-#define A32_PLAIN_GO(SS) do { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, ntt32_fwd_kernel3<false, SS>); ntt32_fwd_kernel3<false, SS><<<grid, A32_T, 0, ctx->stream>>>(d_plain, units, 4, 0, x->pr, x->d_fwd, Dig32Src{}, x->hd); } while (0)
-    if (S == 3) A32_PLAIN_GO(3); else if (S == 4) A32_PLAIN_GO(4); else if (S == 5) A32_PLAIN_GO(5); else A32_PLAIN_GO(6);
-#undef A32_PLAIN_GO
-    HIP_TRY(hipGetLastError());
-    dig32_retile_kernel<<<dim3(8 << S, (unsigned)units, 4), 256, 0, ctx->stream>>>(d_plain, d_out, units, A32_LOGN - 6 + S, (u32)sub_units, div32_inv((u32)sub_units));
+    // the sub-transforms read those rows and store the tiled layout the dot product reads (ntt32_fwd_kernel3<DIGITS, S >= 3>: row source)
+    Dig32Src rs = src;
+    rs.parts = reinterpret_cast<const u64*>(d_plain);
+    const i64 blocks3 = (units + 7) / 8 * 8 * (4 << S);
+    if (blocks3 > 0x7fffffff) FHESI_FAIL("ntt32: too many workgroups per launch");
+#define A32_ROWS_GO(SS) do { PROF_KERNEL(ctx, PROF_NTT_FWD_DIGITS_MAIN, (ntt32_fwd_kernel3<true, SS, true, Aux32Primes, true, false>)); \
+    ntt32_fwd_kernel3<true, SS, true, Aux32Primes, true, false><<<(unsigned)blocks3, A32_T, 0, ctx->stream>>>(d_out, units, 4, 0, x->pr, x->d_fwd, rs, x->hd); } while (0)
+    if (S == 3) A32_ROWS_GO(3); else if (S == 4) A32_ROWS_GO(4); else if (S == 5) A32_ROWS_GO(5); else A32_ROWS_GO(6);
+#undef A32_ROWS_GO
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -707,8 +709,9 @@ dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int nco
 //  * the written order is the schedule (sched_barrier between the phases of a step): left alone hipcc hoists the reads of later steps to the
 //    top of the 4000-instruction block and spills the accumulators.
 // Accumulation: products of a reduced digit (below p) and a key word (below p) are below 2^60; a total is folded once per chunk as
-// (hi 2^32 + lo) -> hi (2^32 mod p) + lo < 2^58 + 2^32 (2^32 mod p = 2^32 - 4p is below 2^26 for every prime launch_dot32_k4 admits -- below 2^24 on
-// rows of 2^14 and 2^15, 2^24.4 for the fourth prime on rows of 2^16), and KC <= 12 more products keep it below 2^58 + 12 2^60 < 2^64
+// (hi 2^32 + lo) -> hi (2^32 mod p) + lo < 2^60 + 2^32 (2^32 mod p = 2^32 - 4p is below 2^28 for every prime launch_dot32_k4 admits -- below 2^24 on
+// rows of 2^14 and 2^15, 2^24.4 for the fourth prime on rows of 2^16, 2^27.9 on rows of 2^19; the primes of rows of 2^20 sit above the guard and
+// take the LDS-tile kernels), and KC <= 12 more products keep it below 2^60 + 2^32 + 12 2^60 < 2^64
 // (tests/test_arith32_models.py follows the chain on worst-case operands).  The epilogue is
 // dot32_kernel2's Montgomery step (outputs carry the factor 2^-32, undone by the inverse transform).
 // Workgroup = 8 waves = 8 CW ciphertexts of one 64-coefficient slice of one prime; grid as dot32_kernel2 (x = slice low bits + 8 * group,
@@ -733,7 +736,7 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   const int a = (int)blockIdx.z;
   const i64 slice = (i64)(s_hi * 8 + s_lo);
   const u32 p = pr.p[a], twop = 2 * p;
-  const u32 r32 = 0u - 4u * p;                                    // 2^32 mod p for p in (2^32 / 5, 2^30): below 2^26 for every prime the launcher admits
+  const u32 r32 = 0u - 4u * p;                                    // 2^32 mod p for p in (2^32 / 5, 2^30): below 2^28 for every prime the launcher admits
   const int osel = w % NSP, o_base = osel * NO;                     // this wave's block of outputs
   const i64 ct0 = (i64)g * (NW / NSP * CW) + (i64)(w / NSP) * CW;
   // the CW digit streams of this wave: scalar bases (the tiled digit rows [sub-chunk][prime][slice][ciphertext * ncol + column][64])
@@ -788,7 +791,7 @@ dot32_kernel4(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   // of spills.)  Per step: [write the key rows fetched two steps ago to LDS -- masked HERE, not next to their load, where the mask made every
   // step wait an L2 round trip] [fetch the next chunk's rows of this step's column] [reduce the digit words of this column, fetch column + PD
   // into their ring slot] [read key half B from LDS] | multiply-adds of half A | [read the next step's half A] | multiply-adds of half B;
-  // then the rows still on their way, the fold hi (2^32 mod p) + lo (below 2^58 + 2^32) and the barrier.
+  // then the rows still on their way, the fold hi (2^32 mod p) + lo (below 2^60 + 2^32) and the barrier.
 #define K4_CHUNK(NS, FETCH, ci) do { \
     const u32* __restrict__ cur = kl + (ci & 1) * (ROWS * 64); \
     u32* __restrict__ nxt = kl + ((ci & 1) ^ 1) * (ROWS * 64); \
@@ -872,9 +875,9 @@ _Pragma("unroll") \
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       if (live[c]) {
-        const u64 v = acc[oo][c];                         // below 2^58 + 2^32
+        const u64 v = acc[oo][c];                         // below 2^60 + 2^32
         const u32 mq = (u32)v * mont;
-        u32 ov = (u32)((v + (u64)mq * p) >> 32);          // v 2^-32 mod p, below p + 2^26 + 1
+        u32 ov = (u32)((v + (u64)mq * p) >> 32);          // v 2^-32 mod p, below p + 2^28 + 1 < 2p
         ov = min(ov, ov - p);
         __builtin_nontemporal_store(ov, obase + (((i64)((ct0 + c) * 2 + (o & 1)) * NLBT * 4) << (lognsl + 6)));
       }
@@ -954,7 +957,7 @@ static int launch_dot32_k4(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig,
     attr_done.fetch_or(1ull << ctx->device);
   }
   for (int a = 0; a < 4; ++a)
-    if ((u32)(0u - 4u * ctx->aux32->pr.p[a]) >= (1u << 26) || ctx->aux32->pr.p[a] >= (1u << 30)) FHESI_FAIL("dot32: prime %u outside the range of dot32_kernel4's fold", ctx->aux32->pr.p[a]);
+    if ((u32)(0u - 4u * ctx->aux32->pr.p[a]) >= (1u << 28) || ctx->aux32->pr.p[a] >= (1u << 30)) FHESI_FAIL("dot32: prime %u outside the range of dot32_kernel4's fold", ctx->aux32->pr.p[a]);
   const i64 nrow = aux32_row_len(ctx);
   const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;
   const int ngroups = (int)((count + NW / NSP * CW - 1) / (NW / NSP * CW)), nsl8 = (int)(nrow / 64 / 8);
@@ -972,8 +975,8 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   if (!count) return 0;
   ProfScope prof(ctx, PROF_DOT, (double)count);
   // keys in LDS, digits in registers (dot32_kernel4): the limb counts of generated matrices at the benchmark rings
-  bool k4_primes = true;                    // dot32_kernel4 folds through 2^32 mod p = 2^32 - 4p and needs it below 2^26 (true of every prime aux32_init picks; any other ring takes the LDS-tile kernels)
-  for (int a = 0; a < 4; ++a) k4_primes = k4_primes && ctx->aux32->pr.p[a] < (1u << 30) && (u32)(0u - 4u * ctx->aux32->pr.p[a]) < (1u << 26);
+  bool k4_primes = true;                    // dot32_kernel4 folds through 2^32 mod p = 2^32 - 4p and needs it below 2^28 (true of every prime aux32_init picks for rows up to 2^19; any other ring takes the LDS-tile kernels)
+  for (int a = 0; a < 4; ++a) k4_primes = k4_primes && ctx->aux32->pr.p[a] < (1u << 30) && (u32)(0u - 4u * ctx->aux32->pr.p[a]) < (1u << 28);
   if (ctx->opt.dot32_k4 && count >= 24 && k4_primes) {
     if (k->aux_rows == 7 && ncol % 12 == 6) return launch_dot32_k4<7, 6, 12, 3, 8, 1, 6>(ctx, k, d_dig, ncol, count, d_out);      // (66 columns = 5 x 12 + 6: the tail compiled on its own)
     if (k->aux_rows == 7) return launch_dot32_k4<7, 6, 12, 3>(ctx, k, d_dig, ncol, count, d_out);      // (measured: digit ring 2 / 3 / 4 steps ahead the same; 12 waves x 4 ciphertexts slower, profiles/r05_ab_dot_k4.txt)

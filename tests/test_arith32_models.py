@@ -299,7 +299,7 @@ def dot4_model(digs, keys, p, KC):
     """one output of dot32_kernel4 (kernels_aux32.hip): digits reduced below p at use, KC products per chunk on top of a folded total, the fold
     hi (2^32 mod p) + lo with 2^32 mod p = 2^32 - 4p, the Montgomery step of the epilogue"""
     r32 = (0 - 4 * p) & M32
-    assert r32 == (1 << 32) % p and r32 < (1 << 26), "launch_dot32_k4 admits primes with 2^32 mod p below 2^26 only"
+    assert r32 == (1 << 32) % p and r32 < (1 << 28), "launch_dot32_k4 admits primes with 2^32 mod p below 2^28 only"
     mont = (-pow(p, -1, 1 << 32)) & M32
     acc = 0
     for c0 in range(0, len(digs), KC):
@@ -310,18 +310,21 @@ def dot4_model(digs, keys, p, KC):
             acc += k * t
             assert acc <= M64, "a chunk's products overflowed the 64-bit total"
         acc = (acc >> 32) * r32 + (acc & M32)
-        assert acc < (1 << 58) + (1 << 32)
+        assert acc < (1 << 60) + (1 << 32)
     mq = ((acc & M32) * mont) & M32
     ov = (acc + mq * p) >> 32
     assert (acc + mq * p) & M32 == 0 and ov < 2 * p
     return min(ov, (ov - p) & M32)
 
 
-@pytest.mark.parametrize("step", [1 << 15, 1 << 16, 1 << 17])
+@pytest.mark.parametrize("step", [1 << 15, 1 << 16, 1 << 17, 1 << 18, 1 << 20, 1 << 21])
 @pytest.mark.parametrize("ncol", [24, 66, 129])
 def test_dot32_kernel4_totals(step, ncol):
     rng = random.Random(step + ncol)
     for p in primes_below_2_30(4, step):
+        if (1 << 32) % p >= (1 << 28):          # (rows of 2^20: above the launcher's guard -- those rings take dot32_kernel2)
+            assert step == 1 << 21
+            continue
         rinv = pow(1 << 32, -1, p)
         lazy = lambda v: v + rng.randrange(4) * p if v + 3 * p <= M32 else v       # the digit rows arrive below 4p
         cases = [([p - 1 + 3 * p] * ncol, [p - 1] * ncol), ([0] * ncol, [p - 1] * ncol), ([4 * p - 1] * ncol, [p - 1] * ncol)]

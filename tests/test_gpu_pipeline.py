@@ -624,7 +624,7 @@ def test_key_switch_centred_limbs_of_generated_matrices(m, logQ, p):
 def test_padded_rows_beyond_2_16_take_the_simple_path(m, logQ, p, lin_lg, monkeypatch):
     """The reference admits every m below 2^20 (FHEContext.cpp:89) and its drivers use m = p - 1 (Test_AddMul.cpp:131): for safe primes beyond
     65 537 the padded rows of the linear convolutions are 2^17 .. 2^20 long.  Those run the SIMPLE path (ntt32_core.inc): head and tail stages as
-    passes of their own (ntt32_headS_kernel / ntt32_tailS_kernel, the digit polynomials through dig32_headS_kernel + dig32_retile_kernel), 2^S
+    passes of their own (ntt32_headS_kernel / ntt32_tailS_kernel, the digit polynomials through dig32_headS_kernel into plain rows), 2^S
     sub-transforms of 2^14 points in between, folds from whole rows -- instead of per-prime Bluestein rows (bluestein.cpp:93-144,
     CModulus.cpp:90-132).  FHESI_LIN_LG forces longer rows than a ring needs, so that rings the oracle finishes in seconds exercise every row
     length (2^17 .. 2^20); the ring that NEEDS rows of 2^17 (p = 65543) is held to the per-prime device path, uniform and generated keys."""
@@ -644,7 +644,7 @@ def test_padded_rows_beyond_2_16_take_the_simple_path(m, logQ, p, lin_lg, monkey
     ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
     ctx.sync()
     S = (lin_lg if lin_lg else 17) - 14
-    assert f"ntt32_fwd_kernel3<false, {S}," in ctx.prof_kernel_name("ntt_fwd_digits_main"), ctx.prof_kernel_name("ntt_fwd_digits_main")
+    assert f"ntt32_fwd_kernel3<true, {S}, true" in ctx.prof_kernel_name("ntt_fwd_digits_main"), ctx.prof_kernel_name("ntt_fwd_digits_main")
     assert "rns32_reduce_kernel" in ctx.prof_kernel_name("rns_reduce") and ksk.form()[0] == 1
     ctx.prof_enable(False)
     got = dout.download((count, 2, n, nl))
