@@ -542,6 +542,8 @@ def init_ranks(args, torch):
     try:
         if args.backend == "nccl":
             try:
+                if os.environ.get("FHESI_BENCH_NO_MIXED_GROUP") == "1":          # (test hook: take the fallback below as a build without gloo would)
+                    raise RuntimeError("mixed group disabled by FHESI_BENCH_NO_MIXED_GROUP")
                 dist.init_process_group("cpu:gloo,cuda:nccl")
                 r.cpu_side = True
             except Exception as e:

@@ -85,8 +85,18 @@ def roll_call_store(store, ident: dict, rank: int, world: int, allow_shared: boo
     backend: every rank posts its identity under its own key and reads everyone's (a blocking get) BEFORE any process group -- and with it
     any RCCL communicator -- exists.  Same verdict on every rank as roll_call."""
     import json
+    import time
     store.set(f"fhesi_roll_call/{rank}", json.dumps(dict(ident, rank=rank)))
     got = [json.loads(bytes(store.get(f"fhesi_roll_call/{r}")).decode()) for r in range(world)]
+    # Nobody leaves before everybody has read everything: the rank that hosts the store may be about to end the run (a shared GPU), and a
+    # rank still reading would see a dead connection instead of the verdict.
+    try:
+        store.add("fhesi_roll_call/done", 1)
+        t0 = time.time()
+        while store.add("fhesi_roll_call/done", 0) < world and time.time() - t0 < 60.0:
+            time.sleep(0.01)
+    except Exception:          # (the host of the store left after seeing every rank done: this rank has all it needs)
+        pass
     return _check_shared(got, allow_shared)
 
 

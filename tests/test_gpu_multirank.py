@@ -198,6 +198,7 @@ def test_config3_sharded_over_eight_ranks():
 
 
 @pytest.mark.parametrize("workload,extra", [("metric", ["--batch", "64"]), ("regression", ["--reg-dim", "3"]), ("ntt", ["--batch", "64"]),
+                                            ("regression", ["--reg-dim", "4", "--reg-overlap", "2"]),      # waves in chunks, exchange of a chunk overlapped with the next chunk's compute
                                             ("regression", ["--reg-dim", "3", "--reg-ring", "reference"])])      # configs[3] on the reference's own ring
 def test_bench_launches_its_own_ranks(workload, extra):
     """`python bench.py --gpus 2` without an external launcher (how a single-command driver starts it): the parent spawns the ranks
@@ -213,6 +214,8 @@ def test_bench_launches_its_own_ranks(workload, extra):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     assert d["roofline"]["kernel"] and d["roofline"]["frac"] > 0
+    if "--reg-overlap" in extra:
+        assert d["config"]["exchange_overlap_chunks"] == 2 and d["config"]["waves_run_in_chunks"] >= 1, d["config"]
     if workload == "metric":
         assert len(d["config"]["per_rank_value"]) == 2 and d["config"]["blocks"] >= 1 and d["config"]["key_broadcast_s"] > 0
         mg = d["config"]["multi_gpu"]
@@ -241,20 +244,26 @@ def test_bench_two_ranks_checks_every_rank_against_the_oracle():
     assert d["config"]["n1_equivalent"] == d["config"]["per_rank_value"][0] > 0
 
 
-def test_bench_refuses_ranks_that_share_a_gpu():
+@pytest.mark.parametrize("mixed_group", [True, False])
+def test_bench_refuses_ranks_that_share_a_gpu(mixed_group):
     """Two ranks driving the same GPU without --one-device (a launcher that hands every rank LOCAL_RANK=0) must END with a message, on
-    every rank, before any RCCL communicator exists -- not hang in a collective."""
+    every rank, before any RCCL communicator exists -- not hang in a collective.  mixed_group = False: the fallback of a build without gloo
+    (FHESI_BENCH_NO_MIXED_GROUP: the roll call goes through the rendezvous store, shard.roll_call_store, before the nccl-only group is made)."""
     import socket
     import sys
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--batch", "8"],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
-    outs = [p.communicate(timeout=600) for p in procs]
+    extra_env = {} if mixed_group else {"FHESI_BENCH_NO_MIXED_GROUP": "1"}
+    for attempt in range(3):          # (the port is found by bind-then-close: another process of a shared box may take it in between -- try again then)
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra_env)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--batch", "8"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+        outs = [p.communicate(timeout=600) for p in procs]
+        if not any("address already in use" in se.lower() for _, se in outs):
+            break
     for p, (so, se) in zip(procs, outs):
         assert p.returncode != 0 and "ranks share a GPU" in se, se[-1500:]
         assert not any(ln.startswith("{") for ln in so.splitlines())
