@@ -26,7 +26,11 @@
 // X^q' + 1 and Phi_m -- out_j = S_j - S_(j+q') - (-1)^j S_(q'-1), linear, so it is applied to the residues in the loader of the CRT
 // kernel (crt32_scale_generic_kernel: any logQ, words at run-time positions through LDS).  Sums of products per group
 // (fhesi_ct_mul_sum_relin_dev: Matrix products inside Regression) are formed in evaluation form by tensor_sum32_kernel.
-// fhesi_ct_mul_dev keeps the reference chain (its rows ARE visible).  Option tensor32 = 0 keeps the chain in the fused pipeline too.
+// Padded rows of 2^16 take their second head stage in rns32_reduce_kernel<NL, 2> and their tails as a pass of their own; rows of 2^17 .. 2^20
+// (round 6: every m = p - 1 below 2^20) are converted as plain zero-padded rows and take head AND tail stages as passes of their own
+// (ntt32_headS_kernel / ntt32_tailS_kernel, ntt32_core.inc); the CRT kernel then folds from whole rows.
+// fhesi_ct_mul_dev keeps the reference chain (its rows ARE visible).  Option tensor32 = 0 keeps the chain in the fused pipeline too; option
+// tensor_bits = 29 takes the primes below 2^29 (fewer range steps in the row transforms, one or two primes more: measured a tie).
 #include "fhesi_internal.h"
 #include "ntt32_core.inc"
 #include <cmath>

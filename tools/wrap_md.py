@@ -21,8 +21,14 @@ def wrap(text, width):
             flush(); fence = not fence; out.append(line); continue
         if fence or not s or s.startswith('#') or s.startswith('|') or s.startswith('{') or re.match(r'^[-=]{3,}$', s):
             flush(); out.append(line); continue
-        new_item = re.match(r'^\s*(?:[-*+]|\d+\.)\s+', line) is not None
-        if new_item:
+        m = re.match(r'^(\s*)((?:[-*+]|\d+\.)\s+)', line)
+        if m and para:
+            # a wrapped continuation line may begin with "35." or "- ": it is a new item only if it is not indented under the current one
+            m0 = re.match(r'^(\s*)((?:[-*+]|\d+\.)\s+)?', para[0])
+            under = len(m0.group(1)) + len(m0.group(2) or '')
+            if m0.group(2) and len(m.group(1)) >= under:
+                m = None
+        if m:
             flush()
         para.append(line)
     flush()
