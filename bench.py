@@ -270,7 +270,7 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
         host = None
         if rank == 0:
             host = keygen.automorph_matrix(ks[i]) if keygen is not None else rand_residue_rows(np.random.default_rng(100 + i), primes, (2, 2 * nd), n)
-        if world > 1:
+        if dist is not None:
             stage = shard.broadcast_key_matrix(host, a.nbytes, dist, device=dev)
             torch.cuda.synchronize()
             a.upload_dev(stage.data_ptr())
@@ -335,7 +335,7 @@ def run_regression(args, ctx, ksk, primes, n, nd, nl, rank, world, local_rank, d
                                            "centred_limbs": ksk.key_bits()[0], "key_coefficient_bits": ksk.key_bits()[1]}, "keys": args.keys, "automorphism_keys": len(ks), "waves": stats["waves"],
                        "products_per_regress": stats["products"], "key_switches_per_regress": stats["key_switches"],
                        "automorph_key_switches_per_regress": stats["automorph_key_switches"], "regress_per_s": round(args.steps / dt, 3),
-                       "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if world > 1 else "single GPU",
+                       "sharding": "groups of every wave sharded over ranks, outputs exchanged by RCCL broadcast" if dist is not None else "single GPU",
                        "exchange_overlap_chunks": args.reg_overlap, "waves_run_in_chunks": sum(1 for _, c in pool.schedule if c > 1)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches,
@@ -533,8 +533,18 @@ def init_ranks(args, torch):
         raise SystemExit(f"bench: rank {r.rank} wants cuda:{r.local_rank} but this process sees {torch.cuda.device_count()} GPU(s) "
                          f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}); one process per GPU, or --one-device for plumbing checks on a 1-GPU box")
     torch.cuda.set_device(r.local_rank)
-    if r.world == 1:
+    if r.world == 1 and os.environ.get("FHESI_BENCH_GROUP_AT_N1") != "1":
         return r
+    if r.world == 1:
+        # Test hook: ONE rank runs the whole N > 1 path -- process group over gloo + real RCCL, roll call, key broadcast, per-rank parity, digests --
+        # so that a 1-GPU box exercises every call the first multi-GPU run will make (RCCL forms a communicator of one rank; it refuses two
+        # ranks on one GPU, which is why the 2-rank tests of that box have to use gloo).
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port))):
+            os.environ.setdefault(k_, v_)
     import torch.distributed as dist
     from fhe_si_amd import shard
     r.dist = dist
@@ -798,6 +808,7 @@ def ranks_parity(args, r, ctx, ksk, ksm_host, primes, roots, n, nl, B, uniq, ct_
 def run_mult(args, r, torch, F, options):
     """metric (configs[2], the contract line), stress (configs[4]) and refring: one step = one batch of B ciphertext mult + relinearize per GPU"""
     rank, world, local_rank, dist = r.rank, r.world, r.local_rank, r.dist
+    grouped = dist is not None          # (N > 1 -- or one rank with the process group of an N > 1 run: FHESI_BENCH_GROUP_AT_N1)
     n = sum(1 for k in range(1, M_RING) if math.gcd(k, M_RING) == 1) if M_RING & (M_RING - 1) else M_RING // 2       # phi(m)
     primes = prime_chain(M_RING, LOGQ, P_PLAIN, n, 1, args.sp_nbits)
     roots = [root_2m(q, M_RING) for q in primes]
@@ -826,7 +837,7 @@ def run_mult(args, r, torch, F, options):
         else:
             ksm_host = rand_residue_rows(np.random.default_rng(8), primes, (2, ncol), n)
     bcast_s, bcast_t = None, None
-    if world > 1:
+    if grouped:
         from fhe_si_amd import shard
         torch.cuda.synchronize()
         dist.barrier()
@@ -999,10 +1010,10 @@ def run_mult(args, r, torch, F, options):
     roofline = roofline_dot if dms >= ms else roofline_ntt
 
     surface = None
-    if rank == 0 and world == 1 and args.workload == "metric" and args.surface:
+    if rank == 0 and not grouped and args.workload == "metric" and args.surface:
         surface = surface_rates(args, ctx, F, ksk, primes, n, nd, nl, B, uniq, a_host, b_host, da, db, dout)
 
-    parity = ranks_parity(args, r, ctx, ksk, ksm_host, primes, roots, n, nl, B, uniq, ct_bytes, a_host, b_host, dout) if world > 1 else None
+    parity = ranks_parity(args, r, ctx, ksk, ksm_host, primes, roots, n, nl, B, uniq, ct_bytes, a_host, b_host, dout) if grouped else None
     ok = True if parity is None else parity["all_ok"]
     if rank == 0:
         total_mults = B * args.steps * world
@@ -1015,9 +1026,9 @@ def run_mult(args, r, torch, F, options):
             # The CPU baseline runs on rank 0 at ANY N (the reference's path is timed per ciphertext, Test_Regression.cpp:24-64): the full record
             # (all cores, Bluestein mode) at N = 1, the single-thread sample alone at N > 1 while the other ranks wait at the closing barrier.
             ns = min(args.cpu_sample, uniq) if args.workload != "refring" else 1      # (a Bluestein-mode oracle multiplication takes ~20 s)
-            cpu, want = cpu_baseline(primes, roots, ksm_host, a_host, b_host, ns, 0 if (args.no_bluestein_cpu or args.workload != "metric" or world > 1) else 1,
-                                     all_cores=world == 1)
-            if world == 1:                       # its outputs check the timed buffer (N > 1: every rank was checked above)
+            cpu, want = cpu_baseline(primes, roots, ksm_host, a_host, b_host, ns, 0 if (args.no_bluestein_cpu or args.workload != "metric" or grouped) else 1,
+                                     all_cores=not grouped)
+            if not grouped:                      # its outputs check the timed buffer (N > 1: every rank was checked above)
                 got = dout.download((want.shape[0], 2, n, nl))
                 last = np.frombuffer(ctx_download_tail(ctx, dout, B, ct_bytes), dtype=np.uint64).reshape(2, n, nl)
                 # the batch repeats the `uniq` pairs: the last ciphertext of the batch equals output (B-1) % uniq of the first chunk
@@ -1027,7 +1038,7 @@ def run_mult(args, r, torch, F, options):
         if parity is not None:
             matches = parity["all_ok"] if args.cpu_sample > 0 else None      # (without the oracle only the agreement of the ranks was checked: multi_gpu.parity)
         multi_gpu = None
-        if world > 1:
+        if grouped:
             try:
                 rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception as e:
@@ -1062,7 +1073,7 @@ def run_mult(args, r, torch, F, options):
                        "timed_region_s": round(dt, 3), "blocks": nblk, "block_values": [round(B * args.steps * world / d, 1) for d in block_dt],
                        "gpu_phase_s": round(gpu_phase_s, 3), "per_rank_value": per_rank, "n1_equivalent": per_rank[0] if per_rank else round(value, 1),
                        "key_broadcast_s": bcast_s,
-                       "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if world > 1 else "single GPU",
+                       "sharding": "independent ciphertexts per GPU, key-switch matrix RCCL-broadcast" if grouped else "single GPU",
                        "multi_gpu": multi_gpu},
             "matches_oracle": matches,
             "surface": surface,

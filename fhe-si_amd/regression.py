@@ -95,7 +95,7 @@ class ShardedPool:
         return shard_bounds(count, self.rank, self.world)
 
     def exchange(self, first: int, count: int):
-        if self.world == 1 or count == 0:
+        if self.dist is None or count == 0:          # (a process group of ONE rank still runs its collectives: bench.py's FHESI_BENCH_GROUP_AT_N1)
             return
         for r in range(self.world):           # shards differ by at most one entry: one broadcast per producing rank
             lo, hi = shard_bounds(count, r, self.world)
@@ -104,7 +104,7 @@ class ShardedPool:
 
     def exchange_begin(self, first: int, count: int):
         """the same broadcasts issued asynchronously (RCCL's own stream on GPUs): they travel while the caller computes its next chunk"""
-        if self.world == 1 or count == 0:
+        if self.dist is None or count == 0:
             return
         for r in range(self.world):
             lo, hi = shard_bounds(count, r, self.world)
@@ -122,7 +122,7 @@ class ShardedPool:
         while chunk k + 1 is computed -- a wave's outputs are read by the NEXT wave only (Regression.h:102-149 over Matrix.cpp:182-263).  Which
         rank computes which entry changes with the chunking; the entries do not.  sync_out / sync_in: the stream hand-over between the
         compute side (C ABI) and the collective side (torch)."""
-        C = max(1, min(int(overlap), count // self.world)) if self.world > 1 else 1
+        C = max(1, min(int(overlap), count // self.world)) if self.dist is not None else 1
         for c in range(C):
             c0, c1 = shard_bounds(count, c, C)
             lo, hi = shard_bounds(c1 - c0, self.rank, self.world)

@@ -288,3 +288,36 @@ def test_reference_regress_control_flow_on_a_group_of_ranks():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "recorded operations run on 3 GPU rank(s)" in r.stdout
     assert "ciphertexts of both evaluators bit-identical: yes" in r.stdout and "recorded and at-once ciphertexts bit-identical: yes" in r.stdout
+
+
+@pytest.mark.parametrize("mixed_group", [True, False])
+def test_bench_one_rank_runs_the_whole_multi_rank_path_over_real_rccl(mixed_group):
+    """RCCL refuses two ranks on one GPU, so the 2-rank bench tests of a 1-GPU box run over gloo.  FHESI_BENCH_GROUP_AT_N1 makes ONE rank take
+    every step of an N > 1 run over the real thing: the gloo + nccl process group (or, mixed_group = False, the nccl-only fallback with its roll
+    call through the rendezvous store), the device roll call, the RCCL broadcast of the key matrix, barriers and stopwatches, per-rank parity
+    against the oracle, digests, the multi_gpu record and the single-thread cpu_baseline of an N > 1 line."""
+    import json
+    import sys
+    env = dict(os.environ, FHESI_BENCH_GROUP_AT_N1="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if not mixed_group:
+        env["FHESI_BENCH_NO_MIXED_GROUP"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "1", "--no-bluestein-cpu",
+                        "--gpu-seconds", "0", "--batch", "16"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    mg = d["config"]["multi_gpu"]
+    assert mg is not None and mg["communicator_nranks"] == 1 and mg["distinct_devices"] == 1 and not mg["one_device_plumbing_mode"], mg
+    assert mg["backend"].startswith("nccl") and ("gloo" in mg["backend"]) == mixed_group, mg["backend"]
+    assert "unavailable" not in mg["rccl_version"] and mg["key_broadcast"]["collective_s"] > 0 and mg["key_broadcast"]["bytes"] > 0, mg
+    assert mg["parity"]["all_ok"] and mg["parity"]["oracle_checked_on_every_rank"] and mg["parity"]["per_rank_ok"] == [True]
+    assert d["matches_oracle"] is True and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["all_cores"] is None and d["config"]["n1_equivalent"] == d["config"]["per_rank_value"][0]
+    if mixed_group:
+        # ... and the regression workload with its waves in chunks: the asynchronous broadcasts of ShardedPool.exchange_begin over RCCL
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "regression", "--reg-dim", "4", "--reg-overlap", "2",
+                            "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["value"] > 0 and d["config"]["exchange_overlap_chunks"] == 2 and d["config"]["waves_run_in_chunks"] >= 1, d["config"]
