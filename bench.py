@@ -18,6 +18,10 @@ pair and compare digests (config.multi_gpu: RCCL version, communicator size, dev
 process, started before anything in this process touches the GPU) and relays rank 0's line; under an external launcher (RANK set) it
 is one of the ranks.
 
+Test hooks (environment; tests/test_gpu_multirank.py): FHESI_BENCH_GROUP_AT_N1=1 -- ONE rank runs the whole N > 1 path (process group,
+roll call, RCCL key broadcast, per-rank parity, digests) so that a 1-GPU box exercises it over real RCCL; FHESI_BENCH_NO_MIXED_GROUP=1 --
+take the nccl-only fallback (roll call through the rendezvous store) as a build without gloo would.
+
 Prints ONE JSON line on rank 0 (contract in the task description) including
   roofline       -- the kernel with the largest share of the step: algorithmic bytes (for the fused digit transform the rows
                     written + the source read once) / HIP-event time of its launches, vs 8 TB/s, with `bound` naming what binds the kernel
