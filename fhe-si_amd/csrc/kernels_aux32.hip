@@ -375,27 +375,26 @@ __global__ void __launch_bounds__(256) ks32_retile_kernel(const u32* __restrict_
 // 2^64 - 2^50 + 2^34 and a total below 2^48 cannot wrap: no carry detection, 3 registers per output, 2-3 extra instructions per
 // output and 16 columns.
 //
-// HALF: the tile is 32 coefficients wide instead of 64 and a wave carries TWO limbs (lanes 0..31 limb 2w, lanes 32..63 limb 2w + 1; both
+// The tile is 32 coefficients wide (half a slice) and a wave carries TWO limbs (lanes 0..31 limb 2w, lanes 32..63 limb 2w + 1; both
 // halves read the same LDS words, which the LDS broadcasts).  Same multiply-adds per key word and per LDS read, but the tile is half
 // as large (66 KB at the metric shape) and the workgroup has half the waves: TWO workgroups share a CU and the tile load, the barrier
 // and the ragged end of one overlap the arithmetic of the other (with one 135 KB workgroup per CU the VALU sat idle 37 % of the time).
-// CSPLIT (few limbs: NLB <= 2 NW / CSPLIT in the HALF form): the waves form CSPLIT groups, every group walks the limbs for its own CT / CSPLIT
-// ciphertexts of the tile -- with 7 limbs (centred limbs of a generated matrix) and CSPLIT = 2 all eight waves carry multiply-adds where the plain
-// form leaves waves 4 .. 7 without a limb.  A key word then feeds CT / CSPLIT ciphertexts per wave (the second group's loads hit in L1 / L2).
-template <int CT, int NW, bool HALF, int CSPLIT = 1>
+// (The whole-slice form of round 2 -- one 135 KB workgroup per CU -- and the wave-group split for few limbs left the source in round 6: neither
+// is reached since dot32_kernel4 took the matrices with 7 or 8 limbs; profiles/HISTORY.md.)
+template <int CT, int NW>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count,
                                                          u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8, int lognsl /* log2 of the 64-element slices per row */, int sub_lg /* log2 of the ciphertexts per sub-chunk of the tiled digit rows */) {
   extern __shared__ __attribute__((aligned(16))) u32 dl32[];       // [ncol][CT][64 or 32 elements]
-  constexpr int LG = HALF ? 5 : 6;
+  constexpr int LG = 5;
   const u32 lane = threadIdx.x & 63;
-  const u32 ln = HALF ? (lane & 31) : lane;                        // element within the tile
+  const u32 ln = lane & 31;                        // element within the tile
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // grid: x = s_lo + 8 (tile + ntiles hf), y = s_hi, z = prime -- the same linear order as one flat index (workgroups 8 apart share an
   // XCD), without the three integer divisions a flat index costs every wave (the SALU cannot divide: ~25 VALU instructions each)
   const u32 s_lo = blockIdx.x & 7;
   u32 tile = blockIdx.x >> 3, hf = 0;
-  if (HALF && tile >= (u32)ntiles) { hf = 1; tile -= (u32)ntiles; }
+  if (tile >= (u32)ntiles) { hf = 1; tile -= (u32)ntiles; }
   const u32 s_hi = blockIdx.y;
   const int a = (int)blockIdx.z;
   const i64 slice = (i64)(s_hi * 8 + s_lo), soff = slice * 64 + hf * 32;
@@ -410,14 +409,14 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
     const int sub = ct0 >> sub_lg, sub_ct = 1 << sub_lg, ct_in = ct0 & (sub_ct - 1);
     const i64 rest = count - ((i64)sub << sub_lg), cnt_s = rest < sub_ct ? rest : (i64)sub_ct;
     const u32* dbase = dig + ((i64)sub << sub_lg) * ncol * (((i64)4 << lognsl) * 64) + ((((i64)a << lognsl) + slice) * (cnt_s * ncol) + (i64)ct_in * ncol) * 64;
-    // (HALF: 8 lanes per 128-byte half row; 16 consecutive lanes take the same column of TWO ciphertexts, which are adjacent in LDS.)
+    // (8 lanes per 128-byte half row; 16 consecutive lanes take the same column of TWO ciphertexts, which are adjacent in LDS.)
     // Work split without divisions: NW / NCG waves share a group of ciphertexts and take its column quads round robin.
-    constexpr int TB = 6, CG = HALF ? 2 : 1, NCG = CT / CG, WPG = NW / NCG;
+    constexpr int TB = 6, CG = 2, NCG = CT / CG, WPG = NW / NCG;
     static_assert(NW % NCG == 0, "waves per ciphertext group");
     const int nq = (ncol + 3) >> 2;
     const int cg = w % NCG, q0 = w / NCG;
-    const u32 e0 = HALF ? 4 * (lane & 7) : 4 * (lane & 15), dk = lane >> 4, dc = HALF ? ((lane >> 3) & 1) : 0;
-    const u32 goff = HALF ? hf * 32 + e0 : e0;
+    const u32 e0 = 4 * (lane & 7), dk = lane >> 4, dc = (lane >> 3) & 1;
+    const u32 goff = hf * 32 + e0;
     const int c = cg * CG + (int)dc;
     const bool cok = ct0 + c < count;
     for (int qb = q0; qb < nq; qb += WPG * TB) {
@@ -442,17 +441,16 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
   __syncthreads();
   const u32 r48 = (u32)pr.r48[a];                 // 2^48 mod p: 30 bits, one multiply-add
   const u32 mont = pr.mont[a];
-  constexpr int CW = CT / CSPLIT, NWG = NW / CSPLIT;      // ciphertexts per wave, waves per group
-  static_assert(CT % CSPLIT == 0 && NW % CSPLIT == 0, "wave groups");
+  constexpr int CW = CT, NWG = NW;      // ciphertexts per wave, waves per group
   const int wl = w % NWG, c0 = (w / NWG) * CW;            // the wave's place in its group; first ciphertext of the group
-  for (int lw = wl; lw * (HALF ? 2 : 1) < NLB; lw += NWG) {
-    const int lraw = HALF ? 2 * lw + (int)(lane >> 5) : lw;          // HALF: the upper lanes of the last wave may have no limb: they repeat the lower one's
+  for (int lw = wl; lw * 2 < NLB; lw += NWG) {
+    const int lraw = 2 * lw + (int)(lane >> 5);          // the upper lanes of the last wave may have no limb
     const bool lok = lraw < NLB;
     // the half wave without a limb (15 limbs on 16 half waves) leaves the loop: its lanes are masked off for the multiply-adds instead of
     // repeating the neighbour's -- same issue slots, but the step runs at the power limit and idle lanes draw less
-    if (HALF && !lok) continue;
+    if (!lok) continue;
     const int l = lok ? lraw : NLB - 1;
-    const u32* kp0 = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + (HALF ? hf * 32 + ln : lane);      // row r = 0; row 1 follows after ncol slices
+    const u32* kp0 = k32 + (((((((i64)a * NLB + l) << lognsl) + slice) * 2) * ncol) << 6) + (hf * 32 + ln);      // row r = 0; row 1 follows after ncol slices
     const u32* kp1 = kp0 + ((i64)ncol << 6);
     u64 tot[2][CW];
     u32 th[2][CW];
@@ -539,7 +537,7 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
           u32 o = (u32)((v + (u64)mq * p) >> 32);
           o = min(o, o - p);                          // o < 2p: o - p wraps to a large value exactly when o < p
           u32* q = obase + (((i64)((ct0 + c0 + c) * 2 + r) * NLB * 4) << (lognsl + 6));
-          if (!HALF || lok) __builtin_nontemporal_store(o, q);
+          if (lok) __builtin_nontemporal_store(o, q);
         }
       }
   }
@@ -551,7 +549,7 @@ dot32_kernel2(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol
 // multiply-adds per row instead of 8, and the key stream is what the kernel waits for (0.27 of the roofline against 0.41 at the metric ring).
 // Here the columns are taken in NH parts through the same LDS buffer: the accumulators of a wave (its two limbs, both key rows, 8
 // ciphertexts) stay in registers across the parts, so the tile keeps its 8 ciphertexts AND the CU its two workgroups.  The form needs
-// every wave to carry its limbs for the whole kernel: NLB <= 2 NW (15 limbs at the stress ring).  HALF layout only.
+// every wave to carry its limbs for the whole kernel: NLB <= 2 NW (15 limbs at the stress ring).  Half-slice layout.
 template <int CT, int NW, int NH>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 dot32_kernel2p(const u32* __restrict__ k32, const u32* __restrict__ dig, int ncol, int NLB, i64 count, u32* __restrict__ out, Aux32Primes pr, int ntiles, int nsl8,
@@ -906,24 +904,24 @@ int ks32_build(fhesi_ctx* ctx, fhesi_ksk* k, const u64* d_kint, int W, int B, in
 }
 
 // d_dig: tiled [4][n/64][count*ncol][64] u32; d_out: [count*2*NLB][4][n] u32
-template <int CT, int NW, bool HALF, int CSPLIT = 1>
+template <int CT, int NW>
 static int launch_dot32_t(fhesi_ctx* ctx, const fhesi_ksk* k, const u32* d_dig, int ncol, i64 count, u32* d_out) {
-  const size_t shmem = (size_t)ncol * CT * (HALF ? 32 : 64) * 4;
+  const size_t shmem = (size_t)ncol * CT * 32 * 4;
   static std::atomic<unsigned long long> attr_done{0};
   if (!(attr_done.load() >> ctx->device & 1)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW, HALF, CSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dot32_kernel2<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.fetch_or(1ull << ctx->device);
   }
   const i64 nrow = aux32_row_len(ctx);
   const int lognsl = hm::ilog2_ceil((u64)nrow) - 6;              // log2 of the 64-element slices per row
   const int ntiles = (int)((count + CT - 1) / CT), nsl8 = (int)(nrow / 64 / 8);
-  const i64 blocks = (i64)8 * ntiles * (HALF ? 2 : 1);
+  const i64 blocks = (i64)8 * ntiles * 2;
   if (blocks > 0x7fffffff || nsl8 > 65535) FHESI_FAIL("dot32: too many ciphertexts per call");
   static_assert((kDigitSubCt & (kDigitSubCt - 1)) == 0, "sub-chunks of a power of two");
   int sub_lg = 0;
   while (((i64)1 << sub_lg) < kDigitSubCt) ++sub_lg;
-  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel2<CT, NW, HALF, CSPLIT>));
-  dot32_kernel2<CT, NW, HALF, CSPLIT><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, sub_lg);
+  PROF_KERNEL(ctx, PROF_DOT, (dot32_kernel2<CT, NW>));
+  dot32_kernel2<CT, NW><<<dim3((unsigned)blocks, (unsigned)nsl8, 4), NW * 64, shmem, ctx->stream>>>((const u32*)k->d_aux, d_dig, ncol, k->aux_rows, count, d_out, ctx->aux32->pr, ntiles, nsl8, lognsl, sub_lg);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -992,9 +990,9 @@ int launch_dot32(fhesi_ctx* ctx, fhesi_ksk* k, const u32* d_dig, int ncol, i64 c
   // per CU); matrices with more than 16 limbs (general limbs at the stress ring) in tiles of 4 ciphertexts (ncol <= 160).  The forms measured
   // slower and removed in round 6 -- whole-slice tiles in one 135 KB workgroup, groups of four waves for few limbs, two limbs per wave on tiles
   // of 4 (dot32_kernel3), the int8 matrix-core product (dot_mfma_kernel) -- are in the history of this file and in profiles/HISTORY.md.
-  if ((size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8, true>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 8 * 128 <= 80 * 1024) return launch_dot32_t<8, 8>(ctx, k, d_dig, ncol, count, d_out);
   if (k->aux_rows <= 16 && (size_t)((((ncol + 1) / 2) + 7) & ~7) * 8 * 128 <= 80 * 1024) return launch_dot32_p<8, 8, 2>(ctx, k, d_dig, ncol, count, d_out);
-  if ((size_t)ncol * 4 * 128 <= 80 * 1024) return launch_dot32_t<4, 8, true>(ctx, k, d_dig, ncol, count, d_out);
+  if ((size_t)ncol * 4 * 128 <= 80 * 1024) return launch_dot32_t<4, 8>(ctx, k, d_dig, ncol, count, d_out);
   FHESI_FAIL("dot32: %d columns do not fit the LDS tile", ncol);
 }
 
