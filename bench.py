@@ -518,6 +518,7 @@ class Ranks:
     dist = None
     topo = None
     cpu_side = False
+    comm_init_s = None      # seconds of the first device collective (it creates the RCCL communicator: kept out of the key broadcast's GB/s)
 
 
 def init_ranks(args, torch):
@@ -575,6 +576,14 @@ def init_ranks(args, torch):
         if dist.is_initialized():
             dist.destroy_process_group()
         raise SystemExit(f"bench: {e}")
+    if args.backend == "nccl":
+        # the first device collective creates the RCCL communicator (seconds on a real node): done here, timed on its own, so that the key
+        # broadcast's GB/s is the broadcast's
+        t0 = time.perf_counter()
+        w = torch.zeros(2, dtype=torch.int64, device=f"cuda:{r.local_rank}")
+        dist.broadcast(w, src=0)
+        torch.cuda.synchronize()
+        r.comm_init_s = round(time.perf_counter() - t0, 4)
     return r
 
 
@@ -1052,7 +1061,7 @@ def run_mult(args, r, torch, F, options):
             except Exception:
                 nr = dist.get_world_size()
             multi_gpu = {"backend": args.backend + (" (cuda) + gloo (cpu side)" if args.backend == "nccl" and r.cpu_side else ""), "rccl_version": rccl,
-                         "communicator_nranks": nr, "devices": r.topo, "distinct_devices": len({(t["host"], t["id"]) for t in r.topo}) if r.topo else None,
+                         "communicator_nranks": nr, "communicator_init_s": r.comm_init_s, "devices": r.topo, "distinct_devices": len({(t["host"], t["id"]) for t in r.topo}) if r.topo else None,
                          "one_device_plumbing_mode": bool(args.one_device),
                          "key_broadcast": dict(bcast_t, GBps=round(bcast_t["bytes"] / bcast_t["collective_s"] / 1e9, 2) if bcast_t and bcast_t.get("collective_s") else None) if bcast_t else None,
                          "parity": parity}
