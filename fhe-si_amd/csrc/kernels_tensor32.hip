@@ -394,7 +394,13 @@ __global__ void __launch_bounds__(256) rns32_reduce_kernel(const u64* __restrict
   // every thread walked the 35 primes behind 35 exposed scalar-load latencies (21 us for one ciphertext)
   const int i_first = (int)((i64)blockIdx.z * NP / gridDim.z), i_last = (int)((i64)(blockIdx.z + 1) * NP / gridDim.z);
   if (j0 >= n_src) {                                             // (whole block in the zero padding)
-    for (int i = i_first; i < i_last; ++i) { o[(i64)i * nrow] = 0; if (dup) o[(i64)i * nrow + A32_N] = 0; }
+    // (every sub-row this block owns: a ring needing rows of 2^16 has more than 2^14 coefficients and never comes here with HEAD = 2, the
+    // FHESI_LIN_LG test hook on a small ring does)
+    for (int i = i_first; i < i_last; ++i) {
+      o[(i64)i * nrow] = 0;
+      if (dup || HEAD != 0) o[(i64)i * nrow + A32_N] = 0;
+      if constexpr (HEAD == 2) { o[(i64)i * nrow + 2 * A32_N] = 0; o[(i64)i * nrow + 3 * A32_N] = 0; }
+    }
     return;
   }
   const i64 avail = (n_src - j0) * NL;                           // words of this block's 256 coefficients that exist

@@ -70,8 +70,8 @@ void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t a
  * key-in-LDS form dot32_kernel4 would run), "parts_words" (0 = 64-bit limb rows between the tensor half and the digit loader),
  * "ks_long_keys", "host_chunk", "host_threads".
  * The FHESI_<NAME> environment variables give the initial values, read once in fhesi_ctx_create -- never per call.  FHESI_LIN_LG (also read
- * there; a test hook) asks for LONGER zero-padded rows than a linear-convolution ring needs (17 .. 20: the paths of rings with safe primes
- * beyond 65 537 on rings small enough for an oracle).
+ * there; a test hook) asks for LONGER zero-padded rows than a linear-convolution ring needs (15 .. 20: the fused loaders of rows of 2^15 / 2^16 and
+ * the paths of rings with safe primes beyond 65 537, on rings small enough for an oracle).
  * fhesi_ctx_destroy fails while DoubleCRT / key-switch handles of the context are alive (they hold the reference's `const FHEcontext&`). */
 int fhesi_ctx_set_option(fhesi_ctx* ctx, const char* name, int64_t value);
 int fhesi_ctx_get_option(const fhesi_ctx* ctx, const char* name, int64_t* value);
