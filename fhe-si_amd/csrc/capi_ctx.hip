@@ -20,6 +20,9 @@ int ws_reserve(fhesi_ctx* ctx, int slot, size_t bytes, void** out) {
     ctx->ws_bytes[slot] = want;
   }
   *out = ctx->ws[slot];
+  // FHESI_WS_POISON=1 (a test hook, read at context creation): every reservation is filled with 0xA5 bytes first, so that a kernel relying on
+  // what an earlier call happened to leave in a workspace -- zeros, mostly -- fails the parity tests instead of passing by luck
+  if (ctx->ws_poison && bytes) HIP_TRY(hipMemsetAsync(ctx->ws[slot], 0xA5, bytes, ctx->stream));
   return 0;
 }
 
@@ -156,6 +159,7 @@ extern "C" int fhesi_ctx_create(fhesi_ctx** out, int64_t m, int32_t nprimes, con
       if (const char* e = getenv("FHESI_LIN_LG")) { const int want = atoi(e); if (want > c->lin_lg && want <= 20) c->lin_lg = want; }
     }
   }
+  if (const char* e = getenv("FHESI_WS_POISON")) c->ws_poison = atoi(e) != 0;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

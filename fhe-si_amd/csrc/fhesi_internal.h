@@ -138,6 +138,7 @@ struct fhesi_ctx {
   void* lane_ws[FHESI_WS_SLOTS] = {};
   size_t lane_ws_bytes[FHESI_WS_SLOTS] = {};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+  bool ws_poison = false;              // FHESI_WS_POISON=1: ws_reserve fills what it hands out with 0xA5 (test hook)
   bool ws_oom = false;                 // the last failing ws_reserve failed in hipMalloc (mul_relin_chunks then retries with smaller chunks)
   // operands of the fused multiplication addressed through pool indices instead of two contiguous batches (single-product waves of
   // fhesi_ct_mul_sum_relin_dev): device array [2][op_idx_n] (a's, then b's) of ciphertext slots in the buffer passed as `a`; null = contiguous
