@@ -178,14 +178,18 @@ def test_wave_of_products_sum_and_key_switch(chunk, operands, monkeypatch):
     assert np.array_equal(g_out.download((3, 2, n, nl)), pool[[5, 0, 5]])
 
 
-@pytest.mark.parametrize("m,logQ,p", [(46, 128, 47), (101, 128, 23), (16381, 128, 23), (32602, 128, 32603),
-                                      (65266, 128, 65267),      # padded rows of 2^16 (phi(m) = 32632): second head stage in the operand conversion, tail stages a pass of their own
-                                      (1 << 16, 200, 23)])      # power-of-two rows of 2^15: head stage in the conversion, tail in the run-time CRT kernel
-def test_wave_of_products_on_linear_convolution_rings(m, logQ, p):
+@pytest.mark.parametrize("m,logQ,p,lin_lg", [(46, 128, 47, 0), (101, 128, 23, 0), (16381, 128, 23, 0), (32602, 128, 32603, 0),
+                                             (65266, 128, 65267, 0),   # padded rows of 2^16 (phi(m) = 32632): second head stage in the operand conversion, tail stages a pass of their own
+                                             (1 << 16, 200, 23, 0),    # power-of-two rows of 2^15: head stage in the conversion, tail in the run-time CRT kernel
+                                             # FHESI_LIN_LG: longer padded rows than the ring needs -- every group of the wave against the oracle on rows of 2^15 .. 2^18
+                                             (46, 128, 47, 16), (101, 128, 23, 15), (1006, 128, 23, 17), (46, 128, 47, 18)])
+def test_wave_of_products_on_linear_convolution_rings(m, logQ, p, lin_lg, monkeypatch):
     """Sums of products per group on the rings whose products run as linear convolutions over primes below 2^30 (kernels_tensor32.hip:
     m = 2q' and m an odd prime, padded rows of 2^14 or of 2^15 -- phi(m) = 16300 at p = 32603, the metric's size in the reference's own
     m = p - 1 parameterisation): the same bits as the chain path (option tensor32 = 0: per-prime Bluestein rows, CModulus.cpp:90-132 +
     bluestein.cpp:93-144) on every group, and as the oracle composed the way Matrix.cpp does where that takes seconds."""
+    if lin_lg:
+        monkeypatch.setenv("FHESI_LIN_LG", str(lin_lg))
     primes, roots = P.chain_for(m, logQ, p, 8)             # SetUpSIContext(xi = 8): the chain leaves room for sums of 8 products (FHEContext.cpp:83-85)
     ctx = F.Context(m, primes, roots)
     orc = O.Oracle(m, primes, roots)

@@ -630,7 +630,8 @@ def test_padded_rows_beyond_2_16_take_the_simple_path(m, logQ, p, lin_lg, monkey
     passes of their own (ntt32_headS_kernel / ntt32_tailS_kernel, the digit polynomials through dig32_headS_kernel into plain rows), 2^S
     sub-transforms of 2^14 points in between, folds from whole rows -- instead of per-prime Bluestein rows (bluestein.cpp:93-144,
     CModulus.cpp:90-132).  FHESI_LIN_LG forces longer rows than a ring needs, so that rings the oracle finishes in seconds exercise every row
-    length (2^17 .. 2^20); the ring that NEEDS rows of 2^17 (p = 65543) is held to the per-prime device path, uniform and generated keys.
+    length (2^17 .. 2^20); the ring that NEEDS rows of 2^17 (p = 65543) is held to the per-prime device path, uniform and generated keys (waves of
+    sums of products on forced rows: test_gpu_ct_algebra.py::test_wave_of_products_on_linear_convolution_rings).
     The same hook at 15 and 16 puts the FUSED long-row loaders (second head stage inside rns32_reduce and the digit loader, ntt32_tail2_kernel:
     what m = 65266 runs) under the oracle for full multiplications."""
     if lin_lg:
