@@ -217,10 +217,21 @@ int bluestein_init(fhesi_ctx* c) {
   for (int i = 0; i < L; ++i) {
     const u64 q = c->q[i], root = c->root[i], rinv = hm::invmod(root, q);
     std::vector<u64> p0(m), p1(m);
+    // root^(j^2) by the recurrence (j + 1)^2 = j^2 + (2j + 1): two products per entry where a power per entry took ~30 (12 s of the
+    // context's creation at m = 2^19, 50 s at 2^20); valid when root^(2m) = 1, which is what reducing the exponent modulo 2m assumed
+    const bool rec = hm::powmod(root, 2 * (u64)m, q) == 1;
+    u64 g0 = root, g1 = rinv;                                // root^(2j + 1), rinv^(2j + 1)
+    const u64 r2 = hm::mulmod(root, root, q), ri2 = hm::mulmod(rinv, rinv, q);
     for (i64 j = 0; j < m; ++j) {
-      const u64 e = (u64)(((u128)j * j) % (2 * (u64)m));
-      p0[j] = hm::powmod(root, e, q);
-      p1[j] = hm::powmod(rinv, e, q);
+      if (!rec) {
+        const u64 e = (u64)(((u128)j * j) % (2 * (u64)m));
+        p0[j] = hm::powmod(root, e, q);
+        p1[j] = hm::powmod(rinv, e, q);
+      } else if (j == 0) p0[0] = p1[0] = 1 % q;
+      else {
+        p0[j] = hm::mulmod(p0[j - 1], g0, q); g0 = hm::mulmod(g0, r2, q);
+        p1[j] = hm::mulmod(p1[j - 1], g1, q); g1 = hm::mulmod(g1, ri2, q);
+      }
       pw[((size_t)i * 2 + 0) * m + j] = {p0[j], hm::shoup(p0[j], q)};
       pw[((size_t)i * 2 + 1) * m + j] = {p1[j], hm::shoup(p1[j], q)};
     }

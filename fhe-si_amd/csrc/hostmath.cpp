@@ -93,29 +93,29 @@ static int mobius(i64 n) {
   return n > 1 ? -mu : mu;
 }
 
-// Phi_m = prod_{d | m} (X^{m/d} - 1)^{mu(d)}; numerator and denominator are built as dense integer polynomials and
-// divided exactly (coefficients of cyclotomic polynomials for m <= 2^20 fit easily in 64 bits).
+// Phi_m = prod_{d | m} (X^{m/d} - 1)^{mu(d)}: the factors with mu = 1 are multiplied in, those with mu = -1 divided out ONE AT A TIME --
+// both are O(degree) for a binomial X^e - 1 (quotient: Q[i] = Q[i - e] - A[i]), and every partial quotient is exact because the product
+// of the mu = -1 binomials divides the numerator.  (A dense division by that product was quadratic: 46 s at m = 2^19, 194 s at the
+// largest ring FHEContext.cpp:89 admits.)  Coefficients of cyclotomic polynomials for m <= 2^20 fit easily in 64 bits.
 std::vector<i64> cyclotomic(i64 m) {
-  std::vector<i64> num(1, 1), den(1, 1);
+  std::vector<i64> t(1, 1);
+  std::vector<i64> neg;
   for (i64 d = 1; d <= m; ++d) {
     if (m % d) continue;
-    int mu = mobius(d);
-    if (!mu) continue;
-    std::vector<i64>& t = (mu == 1) ? num : den;
-    i64 e = m / d;
-    std::vector<i64> r(t.size() + e, 0);
-    for (size_t i = 0; i < t.size(); ++i) { r[i + e] += t[i]; r[i] -= t[i]; }
-    t.swap(r);
+    const int mu = mobius(d);
+    const i64 e = m / d;
+    if (mu == 1) {
+      std::vector<i64> r(t.size() + e, 0);
+      for (size_t i = 0; i < t.size(); ++i) { r[i + e] += t[i]; r[i] -= t[i]; }
+      t.swap(r);
+    } else if (mu == -1) neg.push_back(e);
   }
-  std::vector<i64> quo(num.size() - den.size() + 1, 0);
-  i64 lead = den.back();
-  for (i64 i = (i64)quo.size() - 1; i >= 0; --i) {
-    i64 c = num[i + den.size() - 1] / lead;
-    quo[i] = c;
-    if (c)
-      for (size_t j = 0; j < den.size(); ++j) num[i + j] -= c * den[j];
+  for (const i64 e : neg) {
+    std::vector<i64> q(t.size() - (size_t)e);
+    for (size_t i = 0; i < q.size(); ++i) q[i] = (i >= (size_t)e ? q[i - e] : 0) - t[i];
+    t.swap(q);
   }
-  return quo;
+  return t;
 }
 
 bool is_primitive_2m_root(u64 root, i64 m, u64 q) {

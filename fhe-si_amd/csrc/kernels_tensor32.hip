@@ -190,10 +190,7 @@ static int t32_ring(fhesi_ctx* ctx, const std::vector<u32>& primes) {
     const u64 ipsi = hm::invmod(psi, p);
     auto tw = [&](u64 w) { return Tw32{(u32)w, (u32)((w << 32) / p)}; };
     auto fwd_form = [](Tw32 t) { return Tw32{0u - t.w, t.wp}; };      // what a32_ct<NEGW> takes: (-w mod 2^32, floor(w 2^32 / p)), as aux32_init
-    for (u64 idx = 0; idx < (u64)n; ++idx) {       // the full table of the n-point transform: psi^brv(idx)
-      const u64 e = hm::brv(idx, lg);
-      ff[idx] = tw(hm::powmod(psi, e, p)); fi[idx] = tw(hm::powmod(ipsi, e, p));
-    }
+    a32_bitrev_powers(p, psi, lg, ff); a32_bitrev_powers(p, ipsi, lg, fi);       // the full table of the n-point transform: psi^brv(idx)
     if (!S) {
       std::transform(ff.begin(), ff.end(), hf.begin() + (size_t)a * per_prime, fwd_form);
       std::copy(fi.begin(), fi.end(), hi.begin() + (size_t)a * per_prime);

@@ -623,7 +623,8 @@ def test_key_switch_centred_limbs_of_generated_matrices(m, logQ, p):
 
 
 @pytest.mark.parametrize("m,logQ,p,lin_lg", [(1006, 128, 23, 16), (46, 100, 23, 15), (1006, 128, 23, 17), (1006, 200, 23, 18), (46, 128, 47, 19), (101, 128, 23, 17), (22, 100, 23, 20),
-                                             (65542, 128, 65543, 0)])      # p = 65543: the first safe prime beyond 2^16 -- phi(m) = 32770, 2 phi(m) - 1 = 65539 > 2^16: rows of 2^17
+                                             (65542, 128, 65543, 0),
+                                             (65537, 128, 23, 0)])          # m a Fermat prime: phi(m) = 2^16, the product's 2^17 - 1 coefficients fill the padded row to its last slot but one      # p = 65543: the first safe prime beyond 2^16 -- phi(m) = 32770, 2 phi(m) - 1 = 65539 > 2^16: rows of 2^17
 def test_padded_rows_beyond_2_16_take_the_simple_path(m, logQ, p, lin_lg, monkeypatch):
     """The reference admits every m below 2^20 (FHEContext.cpp:89) and its drivers use m = p - 1 (Test_AddMul.cpp:131): for safe primes beyond
     65 537 the padded rows of the linear convolutions are 2^17 .. 2^20 long.  Those run the SIMPLE path (ntt32_core.inc): head and tail stages as
@@ -679,3 +680,37 @@ def test_padded_rows_beyond_2_16_take_the_simple_path(m, logQ, p, lin_lg, monkey
     ctx.set_option("ks_direct", 0)
     if m < 2000:
         assert np.array_equal(got_g[2], orc.ct_mul_relin(kg.download(), a[2], b[2], logQ, p))
+
+
+def test_the_largest_ring_the_reference_admits():
+    """FHEContext.cpp:89 admits every m below 2^20; with the drivers' m = p - 1 (Test_AddMul.cpp:131) the largest is p = 1048343 (the largest safe
+    prime below 2^20): phi(m) = 524170, padded rows of 2^20 = 64 sub-transforms of 2^14.  The context comes up in seconds (Phi_m by linear-time
+    binomial divisions, chirp powers and twiddle tables by running products -- the quadratic division alone took minutes at this size),
+    Phi_m = sum (-X)^i, and a multiplication on the fused path carries the same bits as the reference's own structure on the device (per-prime
+    Bluestein rows of 2^21 points, tensor product over the chain, one dot product per chain prime)."""
+    import time
+    p, logQ, count = 1048343, 128, 2
+    m = p - 1
+    primes, roots = P.chain_for(m, logQ, p, 1, 60)
+    t0 = time.time()
+    ctx = F.Context(m, primes, roots)
+    t_ctx = time.time() - t0
+    n, nd, nl = ctx.phim, R.ndigits(logQ), (logQ + 63) // 64
+    assert n == 524170 and t_ctx < 60, t_ctx
+    assert np.array_equal(ctx.phi_m(), np.array([1 if i % 2 == 0 else -1 for i in range(n + 1)], dtype=np.int64))      # Phi_2q(X) = Phi_q(-X)
+    rng = np.random.default_rng(11)
+    ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+    a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+    lo = -(1 << (logQ - 1))
+    a[1, 0] = O.ints_to_limbs([lo] * n, nl)                       # the extreme of the centred range everywhere
+    b[1, 0] = O.ints_to_limbs([lo] * n, nl)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    ctx.prof_enable(True)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert "ntt32_fwd_kernel3<true, 6, " in ctx.prof_kernel_name("ntt_fwd_digits_main"), ctx.prof_kernel_name("ntt_fwd_digits_main")
+    ctx.prof_enable(False)
+    ctx.set_option("tensor32", 0)
+    ctx.set_option("ks_direct", 1)
+    kd = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    assert np.array_equal(ctx.ct_mul_relin(kd, logQ, p, a, b), got)
