@@ -26,7 +26,9 @@ struct BluesteinTables {
   u64* d_crt = nullptr;           // [L][4] : P0 mod q, P0*P1 mod q, m^-1 mod q, unused
   u64* d_garner = nullptr;        // [2] : P0^-1 mod P1, (P0 P1)^-1 mod P2
   i64* d_phi = nullptr;           // [phim+1] Phi_m coefficients
-  int phi_kind = 0;               // 0 generic long division, 1 m prime, 2 m = 2 * odd prime
+  int phi_kind = 0;               // 0 generic (long division in LDS, or two convolutions: phi_conv), 1 m prime, 2 m = 2 * odd prime
+  bool phi_conv = false;          // generic m above 16384 (or FHESI_PHI_CONV=1): rem(f, Phi_m) = f - Phi_m * top(f * Psi_m), see blue_conv_*
+  u64* d_khat = nullptr;          // [L][2][3][N] transforms of Psi_m (dir 0) and Phi_m (dir 1), coefficients taken modulo q_i first
   // N = 2^15 .. 2^17: the auxiliary transforms run order-free (head stages + in-place sub-transforms; sub-transforms + tail
   // stages), the chirp transform is stored in that order.  N = 2^15 additionally fuses the single head stage into blue_pre
   // (its partner words are zero: m <= N/2) and the single tail stage into blue_post.
@@ -176,6 +178,53 @@ __global__ void __launch_bounds__(256) blue_phi_generic(const u64* __restrict__ 
   for (i64 i = threadIdx.x; i < phim; i += blockDim.x) rows[r * phim + i] = s[i];
 }
 
+// ---- rem(f, Phi_m) for general m by two exact convolutions (CModulus.cpp:128-129 calls NTL's rem, itself FFT-based)
+// f = Q Phi + r, deg r < phi(m), deg Q < t = m - phi(m).  With Psi = (X^m - 1) / Phi (integer coefficients, hm::cyclotomic_cofactor):
+//   f Psi = Q (X^m - 1) + r Psi,  deg(r Psi) < m   =>   Q = the coefficients m .. m + t - 1 of f Psi      (deg(f Psi) <= 2m - 2 < N: no wrap)
+//   r = (f - Q Phi) mod X^phi(m)                                                                          (deg(Q Phi) < m)
+// Both products run like the chirp convolution: modulo the three auxiliary primes, Garner, mod q; the kernels' coefficients are reduced
+// modulo q first, so every integer is non-negative and below m q^2.  The long division in LDS needs the whole polynomial in 128 KB and
+// m - phi(m) dependent steps; this form has neither limit (any m below 2^20, FHEContext.cpp:89).
+// X_j[i] = src[r][i] mod P_j for i < len, 0 above.  grid: (ceil(N/256), rows)
+__global__ void __launch_bounds__(256) blue_conv_pre(const u64* __restrict__ src, i64 stride, i64 len, i64 N, u64 P0, u64 P1, u64 P2, u64* __restrict__ X) {
+  const i64 r = blockIdx.y;
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const u64 t = k < len ? src[r * stride + k] : 0;
+  u64* x = X + r * 3 * N;
+  x[k] = t >= P0 ? t % P0 : t;
+  x[N + k] = t >= P1 ? t % P1 : t;
+  x[2 * N + k] = t >= P2 ? t % P2 : t;
+}
+// the integer behind (c0, c1, c2) modulo the chain prime q (Garner's mixed radix digits, as blue_post)
+static __device__ __forceinline__ u64 blue_garner_mod_q(u64 c0, u64 c1, u64 c2, const PrimeConst* __restrict__ aux_pcs, const u64* __restrict__ garner,
+                                                        const u64* __restrict__ crt, int prime, const PrimeConst& pc) {
+  const PrimeConst a1 = aux_pcs[1], a2 = aux_pcs[2];
+  const u64 v0 = c0;
+  const u64 v1 = d_mulmod(d_submod(c1, v0 >= a1.q ? v0 % a1.q : v0, a1.q), garner[0], a1);
+  const u64 v0m2 = v0 >= a2.q ? v0 % a2.q : v0, v1m2 = v1 >= a2.q ? v1 % a2.q : v1;
+  const u64 p0m2 = aux_pcs[0].q % a2.q;
+  const u64 t2 = d_submod(d_submod(c2, v0m2, a2.q), d_mulmod(v1m2, p0m2, a2), a2.q);
+  const u64 v2 = d_mulmod(t2, garner[1], a2);
+  const u64 q = pc.q;
+  const u64 r0 = v0 % q, r1 = v1 % q, r2 = v2 % q;
+  return d_addmod(r0, d_addmod(d_mulmod(r1, crt[prime * 4 + 0], pc), d_mulmod(r2, crt[prime * 4 + 1], pc), q), q);
+}
+// out[r][j] = (sub ? sub[r][j] - v : v) mod q with v = coefficient first + j of the product in X, j < len.  grid: (ceil(len/256), rows)
+__global__ void __launch_bounds__(256) blue_conv_post(const u64* __restrict__ X, i64 N, i64 first, i64 len, int nslots, const int* __restrict__ prime_of_slot,
+                                                      const PrimeConst* __restrict__ pcs, const PrimeConst* __restrict__ aux_pcs, const u64* __restrict__ crt,
+                                                      const u64* __restrict__ garner, const u64* __restrict__ sub, i64 sub_stride, u64* __restrict__ out, i64 out_stride) {
+  const i64 r = blockIdx.y;
+  const int slot = (int)(r % nslots);
+  const int prime = prime_of_slot ? prime_of_slot[slot] : slot;
+  const PrimeConst pc = pcs[prime];
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  const u64* x = X + r * 3 * N + first + j;
+  const u64 v = blue_garner_mod_q(x[0], x[N], x[2 * N], aux_pcs, garner, crt, prime, pc);
+  out[r * out_stride + j] = sub ? d_submod(sub[r * sub_stride + j], v, pc.q) : v;
+}
+
 // ------------------------------------------------------------------------------------------------ setup
 static u64 root_of_two_power_order(u64 p, int k) {       // element of exact order 2^k modulo prime p (2^k | p-1)
   for (u64 h = 2;; ++h) {
@@ -269,7 +318,38 @@ int bluestein_init(fhesi_ctx* c) {
   if (hm::is_prime((u64)m)) B->phi_kind = 1;
   else if (m % 2 == 0 && (m / 2) % 2 == 1 && hm::is_prime((u64)(m / 2))) B->phi_kind = 2;
   else B->phi_kind = 0;
-  if (B->phi_kind == 0 && m > 16384) FHESI_FAIL("general m = %lld: reduction modulo Phi_m only implemented for m prime, m = 2*prime, or m <= 16384", (long long)m);
+  // generic m: the long division in LDS up to m = 16384, two convolutions above (FHESI_PHI_CONV=1, a test hook read here, asks for them at
+  // any size: the rings small enough for the oracle and for the long division to stand beside it)
+  if (B->phi_kind == 0) { const char* e = getenv("FHESI_PHI_CONV"); B->phi_conv = m > 16384 || (e && atoi(e) != 0); }
+  if (B->phi_conv) {
+    const std::vector<i64> psi = hm::cyclotomic_cofactor(m);
+    const i64 t = m - c->phim;
+    if ((i64)psi.size() != t + 1 || (i64)c->phi.size() != c->phim + 1) FHESI_FAIL("Phi_m / Psi_m: unexpected degrees");
+    {   // Phi_m(x) Psi_m(x) = x^m - 1 at two points modulo the first chain prime (a wrong table would only show as wrong coefficients)
+      const u64 q = c->q[0];
+      for (u64 x : {(u64)3, (u64)0x9e3779b97f4a7c15ull % q}) {
+        auto eval = [&](const std::vector<i64>& f) { u64 v = 0; for (size_t i = f.size(); i-- > 0;) { const i64 co = f[i]; const u64 cm = co >= 0 ? (u64)co % q : (q - (u64)(-co) % q) % q; v = (hm::mulmod(v, x, q) + cm) % q; } return v; };
+        if (hm::mulmod(eval(c->phi), eval(psi), q) != (hm::powmod(x, (u64)m, q) + q - 1) % q) FHESI_FAIL("Phi_m * Psi_m != X^m - 1 for m = %lld", (long long)m);
+      }
+    }
+    std::vector<u64> kh((size_t)L * 2 * 3 * N, 0);
+    for (int i = 0; i < L; ++i) {
+      const u64 q = c->q[i];
+      for (int dir = 0; dir < 2; ++dir) {
+        const std::vector<i64>& f = dir == 0 ? psi : c->phi;
+        for (size_t j = 0; j < f.size(); ++j) {
+          const i64 co = f[j];
+          if (!co) continue;
+          const u64 cm = co > 0 ? (u64)co % q : (q - ((u64)(-co) % q)) % q;
+          for (int a = 0; a < 3; ++a) kh[(((size_t)i * 2 + dir) * 3 + a) * N + j] = cm % B->P[a];
+        }
+      }
+    }
+    HIP_TRY(hipMalloc(&B->d_khat, kh.size() * 8));
+    HIP_TRY(hipMemcpy(B->d_khat, kh.data(), kh.size() * 8, hipMemcpyHostToDevice));
+    FHESI_TRY(launch_ntt_fwd(B->aux, B->d_khat, (i64)L * 2, 3, nullptr, !B->orderfree));
+    HIP_TRY(hipStreamSynchronize(B->aux->stream));
+  }
   return 0;
 }
 
@@ -277,7 +357,7 @@ void bluestein_destroy(fhesi_ctx* c) {
   BluesteinTables* B = c->blue;
   if (!B) return;
   if (B->aux) fhesi_ctx_destroy(B->aux);
-  hipFree(B->d_pow); hipFree(B->d_bhat); hipFree(B->d_crt); hipFree(B->d_garner); hipFree(B->d_phi);
+  hipFree(B->d_pow); hipFree(B->d_bhat); hipFree(B->d_khat); hipFree(B->d_crt); hipFree(B->d_garner); hipFree(B->d_phi);
   delete B;
   c->blue = nullptr;
 }
@@ -318,6 +398,24 @@ static int blue_chunk(fhesi_ctx* c, u64* d_rows, i64 count, int nslots, const in
   HIP_TRY(hipGetLastError());
   if (B->phi_kind) {
     blue_phi_fast<<<dim3((unsigned)((phim + 255) / 256), (unsigned)R), 256, 0, c->stream>>>((const u64*)dF, phim, m, B->phi_kind, nslots, d_pos, c->d_pc, d_rows);
+  } else if (B->phi_conv) {
+    const i64 t = m - phim;
+    u64* Q = dF + R * m;                       // [R][t], behind the polynomials (blue_run reserves both)
+    const unsigned gN = (unsigned)((N + 255) / 256);
+    // Q = coefficients m .. m + t - 1 of f Psi
+    blue_conv_pre<<<dim3(gN, (unsigned)R), 256, 0, c->stream>>>((const u64*)dF, m, m, N, B->P[0], B->P[1], B->P[2], X);
+    FHESI_TRY(launch_ntt_fwd(B->aux, X, R, 3, nullptr, !B->orderfree));
+    blue_mul<<<dim3(gx, (unsigned)(R * 3)), 256, 0, c->stream>>>(X, N, nslots, d_pos, 0, B->d_khat, B->aux->d_pc);
+    FHESI_TRY(launch_ntt_inv(B->aux, X, R, 3, nullptr, !B->orderfree));
+    blue_conv_post<<<dim3((unsigned)((t + 255) / 256), (unsigned)R), 256, 0, c->stream>>>(X, N, m, t, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_crt, B->d_garner,
+                                                                                          nullptr, 0, Q, t);
+    // rows = (f - Q Phi) mod X^phi(m)
+    blue_conv_pre<<<dim3(gN, (unsigned)R), 256, 0, c->stream>>>((const u64*)Q, t, t, N, B->P[0], B->P[1], B->P[2], X);
+    FHESI_TRY(launch_ntt_fwd(B->aux, X, R, 3, nullptr, !B->orderfree));
+    blue_mul<<<dim3(gx, (unsigned)(R * 3)), 256, 0, c->stream>>>(X, N, nslots, d_pos, 1, B->d_khat, B->aux->d_pc);
+    FHESI_TRY(launch_ntt_inv(B->aux, X, R, 3, nullptr, !B->orderfree));
+    blue_conv_post<<<dim3((unsigned)((phim + 255) / 256), (unsigned)R), 256, 0, c->stream>>>(X, N, 0, phim, nslots, d_pos, c->d_pc, B->aux->d_pc, B->d_crt, B->d_garner,
+                                                                                             (const u64*)dF, m, d_rows, phim);
   } else {
     const size_t shmem = (size_t)m * 8;
     HIP_TRY(hipFuncSetAttribute((const void*)blue_phi_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -352,7 +450,7 @@ static int blue_run(fhesi_ctx* c, u64* d_rows, i64 count, int nslots, const int*
   if (chunk > count) chunk = count;
   void *dX, *dF = nullptr;
   FHESI_TRY(ws_reserve(c, 8, (size_t)chunk * nslots * 3 * N * 8, &dX));
-  if (inv) FHESI_TRY(ws_reserve(c, 9, (size_t)chunk * nslots * m * 8, &dF));
+  if (inv) FHESI_TRY(ws_reserve(c, 9, (size_t)chunk * nslots * (B->phi_conv ? 2 * m - phim : m) * 8, &dF));      // (phi_conv: the quotients behind the polynomials)
   hipStream_t aux_stream = B->aux->stream;
   B->aux->stream = c->stream;
   int rc = 0;

@@ -261,6 +261,7 @@ u64 brv(u64 x, int bits);
 int ilog2_ceil(i64 n);
 std::vector<int> zms_idx(i64 m, i64* phim);
 std::vector<i64> cyclotomic(i64 m);
+std::vector<i64> cyclotomic_cofactor(i64 m);     // (X^m - 1) / Phi_m
 bool is_primitive_2m_root(u64 root, i64 m, u64 q);
 u64 bn_mod(const u64* limbs, int nlimbs, u64 q);          // signed two's complement -> [0,q)  (role of NTL rem(ZZ,long))
 std::vector<u64> bn_mul_small(const std::vector<u64>& a, u64 b);   // non-negative

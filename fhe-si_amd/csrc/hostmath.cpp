@@ -118,6 +118,30 @@ std::vector<i64> cyclotomic(i64 m) {
   return t;
 }
 
+// Psi_m = (X^m - 1) / Phi_m = prod_{mu(d) = -1} (X^{m/d} - 1) / prod_{mu(d) = 1, d > 1} (X^{m/d} - 1), degree m - phi(m): the same
+// binomial products and exact binomial divisions.  1 / Phi_m = -Psi_m (1 + X^m + X^2m + ...) as a power series, which is what makes the
+// quotient of a division by Phi_m one product with Psi_m (bluestein.hip, the reduction modulo Phi_m for general m).
+std::vector<i64> cyclotomic_cofactor(i64 m) {
+  std::vector<i64> t(1, 1);
+  std::vector<i64> pos;
+  for (i64 d = 1; d <= m; ++d) {
+    if (m % d) continue;
+    const int mu = mobius(d);
+    const i64 e = m / d;
+    if (mu == -1) {
+      std::vector<i64> r(t.size() + e, 0);
+      for (size_t i = 0; i < t.size(); ++i) { r[i + e] += t[i]; r[i] -= t[i]; }
+      t.swap(r);
+    } else if (mu == 1 && d > 1) pos.push_back(e);
+  }
+  for (const i64 e : pos) {
+    std::vector<i64> q(t.size() - (size_t)e);
+    for (size_t i = 0; i < q.size(); ++i) q[i] = (i >= (size_t)e ? q[i - e] : 0) - t[i];
+    t.swap(q);
+  }
+  return t;
+}
+
 bool is_primitive_2m_root(u64 root, i64 m, u64 q) {
   if (root == 0 || root >= q) return false;
   // order divides 2m; it is exactly 2m iff root^(2m/f) != 1 for every prime f | 2m

@@ -72,7 +72,9 @@ void* fhesi_ctx_stream(fhesi_ctx* ctx);                     /* the hipStream_t a
  * The FHESI_<NAME> environment variables give the initial values, read once in fhesi_ctx_create -- never per call.  FHESI_LIN_LG (also read
  * there; a test hook) asks for LONGER zero-padded rows than a linear-convolution ring needs (15 .. 20: the fused loaders of rows of 2^15 / 2^16 and
  * the paths of rings with safe primes beyond 65 537, on rings small enough for an oracle).  FHESI_WS_POISON=1 (also a test hook) fills every
- * workspace reservation with 0xA5 bytes before use: results must not depend on what a workspace held.
+ * workspace reservation with 0xA5 bytes before use: results must not depend on what a workspace held.  FHESI_PHI_CONV=1 (test hook) makes
+ * the reduction modulo Phi_m of a generic m (not a power of two, a prime or twice a prime) run as two convolutions at any size; above
+ * m = 16384 that is the only form.
  * fhesi_ctx_destroy fails while DoubleCRT / key-switch handles of the context are alive (they hold the reference's `const FHEcontext&`). */
 int fhesi_ctx_set_option(fhesi_ctx* ctx, const char* name, int64_t value);
 int fhesi_ctx_get_option(const fhesi_ctx* ctx, const char* name, int64_t* value);
