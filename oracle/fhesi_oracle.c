@@ -130,7 +130,7 @@ static i64* cyclotomic(i64 m, i64 phim) {
   }
   /* exact division num/den, den monic up to sign */
   i64* quo = calloc(phim + 1, 8);
-  for (i64 i = dn - dd; i >= 0; i--) { i64 c = num[i + dd] / den[dd]; quo[i] = c; for (i64 j = 0; j <= dd; j++) num[i + j] -= c * den[j]; }
+  for (i64 i = dn - dd; i >= 0; i--) { i64 c = num[i + dd] / den[dd]; quo[i] = c; if (!c) continue; for (i64 j = 0; j <= dd; j++) num[i + j] -= c * den[j]; }
   free(num); free(den); return quo;
 }
 

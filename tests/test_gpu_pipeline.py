@@ -714,3 +714,27 @@ def test_the_largest_ring_the_reference_admits():
     ctx.set_option("ks_direct", 1)
     kd = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     assert np.array_equal(ctx.ct_mul_relin(kd, logQ, p, a, b), got)
+
+
+def test_the_largest_power_of_two_ring():
+    """m = 2^20, the largest m FHEContext.cpp:89 admits (n = 2^19 coefficients): rows beyond the fused 32-bit path (n = 2^14, 2^15), so the
+    multiplication runs over the chain with the 64-bit row kernels in their multi-pass form; against the oracle, and DoubleCRT <-> polynomial."""
+    m, logQ, p, count = 1 << 20, 100, 23, 2
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 5, count)
+    n = ctx.phim
+    assert n == 1 << 19
+    lo, hi = -(1 << (logQ - 1)), (1 << (logQ - 1)) - 1
+    rng = np.random.default_rng(8)
+    a[1, 0] = O.ints_to_limbs([lo] * n, nl)
+    b[1, 0] = O.ints_to_limbs([lo] * n, nl)
+    a[1, 1] = O.ints_to_limbs([lo if v else hi for v in rng.integers(0, 2, n)], nl)
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    for c in range(count):
+        assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    limbs = P.rand_limbs(rng, (n,), nl + 1, logQ + 20)
+    d = F.DoubleCRT.from_poly(ctx, limbs)
+    rows = orc.dcrt_from_poly(limbs)
+    assert np.array_equal(d.rows(), rows)
+    W = ctx.L + 2
+    assert np.array_equal(d.to_poly(W), orc.dcrt_to_poly(rows, W))
