@@ -624,7 +624,8 @@ def test_key_switch_centred_limbs_of_generated_matrices(m, logQ, p):
 
 @pytest.mark.parametrize("m,logQ,p,lin_lg", [(1006, 128, 23, 16), (46, 100, 23, 15), (1006, 128, 23, 17), (1006, 200, 23, 18), (46, 128, 47, 19), (101, 128, 23, 17), (22, 100, 23, 20),
                                              (65542, 128, 65543, 0),
-                                             (65537, 128, 23, 0)])          # m a Fermat prime: phi(m) = 2^16, the product's 2^17 - 1 coefficients fill the padded row to its last slot but one      # p = 65543: the first safe prime beyond 2^16 -- phi(m) = 32770, 2 phi(m) - 1 = 65539 > 2^16: rows of 2^17
+                                             (65537, 128, 23, 0),
+                                             (524287, 128, 23, 0)])         # the largest odd prime m on this path (2^19 - 1: 2 phi(m) - 1 = 2^20 - 5, rows of 2^20; three-term fold)          # m a Fermat prime: phi(m) = 2^16, the product's 2^17 - 1 coefficients fill the padded row to its last slot but one      # p = 65543: the first safe prime beyond 2^16 -- phi(m) = 32770, 2 phi(m) - 1 = 65539 > 2^16: rows of 2^17
 def test_padded_rows_beyond_2_16_take_the_simple_path(m, logQ, p, lin_lg, monkeypatch):
     """The reference admits every m below 2^20 (FHEContext.cpp:89) and its drivers use m = p - 1 (Test_AddMul.cpp:131): for safe primes beyond
     65 537 the padded rows of the linear convolutions are 2^17 .. 2^20 long.  Those run the SIMPLE path (ntt32_core.inc): head and tail stages as
@@ -650,7 +651,7 @@ def test_padded_rows_beyond_2_16_take_the_simple_path(m, logQ, p, lin_lg, monkey
     ctx.prof_enable(True)
     ctx.ct_mul_relin_dev(ksk, logQ, p, da, db, dout, nl, count)
     ctx.sync()
-    S = (lin_lg if lin_lg else 17) - 14
+    S = max(lin_lg, (2 * n - 2).bit_length(), 14) - 14              # rows of 2^(14 + S): what the ring needs, or what the hook forces
     assert f"ntt32_fwd_kernel3<true, {S}, " in ctx.prof_kernel_name("ntt_fwd_digits_main"), ctx.prof_kernel_name("ntt_fwd_digits_main")
     assert "rns32_reduce_kernel" in ctx.prof_kernel_name("rns_reduce") and ksk.form()[0] == 1
     ctx.prof_enable(False)
