@@ -122,14 +122,15 @@ def test_generic_m_reduction_modulo_phi_by_convolutions(m, hook, monkeypatch):
         assert np.array_equal(b2.download(ev.shape), got)
 
 
-def test_generic_m_at_the_largest_composite_ring():
-    """m = 1048575 = 3 * 5^2 * 11 * 31 * 41, the largest m below 2^20 with five prime factors (phi(m) = 480000; convolutions of 2^21 points):
-    the context comes up, and polynomial -> evaluations -> polynomial is the identity -- the inverse transform scatters the evaluations
-    over Z_m^*, which gives a polynomial of degree m - 1 that only the reduction modulo Phi_m brings back below phi(m)."""
-    m = 1048575
+@pytest.mark.parametrize("m,phim", [(1048575, 480000), (1048574, 524286), (1048573, 1048572)])
+def test_rows_at_the_largest_rings_of_each_kind(m, phim):
+    """The three largest m below 2^20 happen to be one of each kind: 1048575 = 3 * 5^2 * 11 * 31 * 41 (generic: rem Phi_m by convolutions),
+    1048574 = 2 * 524287 (twice a prime, beyond the padded rows of the linear-convolution path) and 1048573 (prime).  Bluestein convolutions
+    of 2^21 points: the context comes up, and polynomial -> evaluations -> polynomial is the identity -- the inverse transform scatters the
+    evaluations over Z_m^*, which gives a polynomial of degree m - 1 that only the reduction modulo Phi_m brings back below phi(m)."""
     primes, roots = P.first_primes(m, 2)
     ctx = F.Context(m, primes, roots)
-    assert ctx.phim == 480000
+    assert ctx.phim == phim
     rng = np.random.default_rng(1)
     rows = P.rand_rows(rng, primes, ctx.phim, 2)
     rows[1, 1, :] = np.uint64(primes[1] - 1)
