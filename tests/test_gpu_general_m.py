@@ -12,7 +12,7 @@ import params as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("m", [9, 15, 22, 46, 101, 1006, 45])
+@pytest.mark.parametrize("m", [3, 6, 9, 12, 15, 21, 22, 46, 101, 1006, 45])      # (3, 6: phi(m) = 2, the smallest rings that are not powers of two)
 def test_rows_general_m(m):
     primes, roots = P.first_primes(m, 3)
     ctx = F.Context(m, primes, roots)
@@ -60,7 +60,7 @@ def test_large_safe_prime_ring_single_rows(m):
     assert np.array_equal(b2.download(ev.shape)[0, 1], orc.cmod_ifft(1, ev[0, 1]))
 
 
-@pytest.mark.parametrize("m,logQ,p", [(22, 80, 23), (46, 90, 47), (166, 120, 167)])
+@pytest.mark.parametrize("m,logQ,p", [(3, 80, 7), (6, 80, 7), (12, 80, 13), (22, 80, 23), (46, 90, 47), (166, 120, 167)])
 def test_mul_relin_reference_parameterisation(m, logQ, p):
     """README smoke parameters `80 23 7` (README:46-47) and friends: full mult + key switch on the GPU."""
     primes, roots = P.chain_for(m, logQ, p)
