@@ -262,7 +262,9 @@ int ksaux_mode(fhesi_ctx* ctx, const CrtTables* t, int ncol, int digit_bits, int
   if (ctx->L < 2 || digit_bits >= 32 || ctx->opt.ks_direct) return KS_MODE_DIRECT;
   // (1) limb mode over the four 30-bit auxiliary primes (kernels_aux32.hip): rows of 2^14 / 2^15 and the linear-convolution rings, ANY
   //     chain -- the auxiliary modulus does not involve the chain primes, so a chain of 50-bit primes (NTL_SP_NBITS = 50) takes it too
-  if (aux32_applies(ctx) && !ctx->opt.ks_aux60 && !ctx->opt.ks_residues) {
+  //     (up to 160 digit columns: what the dot products' LDS tiles hold whatever the limb count of the matrix -- launch_dot32; logQ <= 1264 with
+  //     byte digits.  Beyond that the chain forms below run: slower, not refused.)
+  if (aux32_applies(ctx) && !ctx->opt.ks_aux60 && !ctx->opt.ks_residues && ncol <= 160) {
     const u32* p32 = aux32_primes(ctx);
     KsLimbPlan plan;
     if (p32 && ks_limb_plan(ctx, t, ncol, digit_bits, logQ, &plan, p32) && plan.a32) return KS_MODE_LIMB32;

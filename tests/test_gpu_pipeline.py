@@ -739,3 +739,24 @@ def test_the_largest_power_of_two_ring():
     assert np.array_equal(d.rows(), rows)
     W = ctx.L + 2
     assert np.array_equal(d.to_poly(W), orc.dcrt_to_poly(rows, W))
+
+
+@pytest.mark.parametrize("m,logQ,p", [(22, 1280, 23), (46, 1300, 47), (1006, 1280, 23)])
+def test_more_digit_columns_than_the_dot_product_tiles_hold(m, logQ, p):
+    """logQ above 1264 gives more than 160 digit columns (3 x 162 at logQ = 1280, ByteDecomp digits): past what the LDS tiles of the exact
+    integer dot products hold (launch_dot32).  Rings that take the 30-bit key switch otherwise (the linear-convolution rings here; n = 2^14 /
+    2^15 likewise) then run the chain forms -- the call used to be refused with 'columns do not fit the LDS tile'.  Against the oracle on the
+    small rings, against the reference's own structure on the device (tensor32 = 0, ks_direct = 1) everywhere."""
+    count = 2
+    ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 31 + m, count)
+    assert 3 * nd > 160
+    ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+    assert ksk.form()[0] != 1                                    # not the 30-bit limb form
+    if m < 100:
+        for c in range(count):
+            assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), c
+    ctx.set_option("tensor32", 0)
+    ctx.set_option("ks_direct", 1)
+    kd = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+    assert np.array_equal(ctx.ct_mul_relin(kd, logQ, p, a, b), got)
