@@ -760,3 +760,48 @@ def test_more_digit_columns_than_the_dot_product_tiles_hold(m, logQ, p):
     ctx.set_option("ks_direct", 1)
     kd = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
     assert np.array_equal(ctx.ct_mul_relin(kd, logQ, p, a, b), got)
+
+
+@pytest.mark.parametrize("m,logQ,p,sizes", [(64, 100, 23, (1, 2, 4, 5, 7)), (22, 100, 23, (1, 2, 4, 7)), (1006, 128, 23, (1, 2, 4, 7)), (32768, 128, 23, (1, 2, 4))])
+def test_digit_sizes_other_than_three_bytes(m, logQ, p, sizes):
+    """FHEcontext's decompSize (FHEContext.h:86-115: bytes per ByteDecomp digit, default 3 and 3 in every driver) is a run-time argument of the
+    key-switch calls: 1 and 2 bytes take the 30-bit limb form where the ring has it (other byte selectors in the digit loader, more columns),
+    4 bytes and more the chain forms (a digit no longer fits a 30-bit residue).  Uniform and generated matrices, the extreme of the centred
+    range in every coefficient; against the oracle on the small rings and against the reference's own structure on the device."""
+    count = 3
+    primes, roots = P.chain_for(m, logQ, p, 1, 60)
+    ctx = F.Context(m, primes, roots)
+    orc = O.Oracle(m, primes, roots)
+    n, nl = ctx.phim, (logQ + 63) // 64
+    one = np.zeros((n, 1), dtype=np.uint64)
+    one[0, 0] = 1
+    t = F.DoubleCRT(ctx).sample(0, min(64, n // 2), 77, 1)
+    t2 = t.copy()
+    t2.op(t, 2)
+    for db in sizes:
+        nd = R.ndigits(logQ, db)
+        rng = np.random.default_rng(db)
+        ksm = np.stack([P.rand_rows(rng, primes, n, 3 * nd) for _ in range(2)])
+        a = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+        b = P.rand_limbs(rng, (count, 2, n), nl, logQ)
+        lo = -(1 << (logQ - 1))
+        a[1, 0] = O.ints_to_limbs([lo] * n, nl)
+        b[1, 0] = O.ints_to_limbs([lo] * n, nl)
+        ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+        kg = F.KeySwitchMatrix(ctx, 3, nd).init_batch_seeded([F.DoubleCRT.from_poly(ctx, one), t, t2], t, logQ, 77, 78, 100, db)
+        got = ctx.ct_mul_relin(ksk, logQ, p, a, b, decomp_bytes=db)
+        got_g = ctx.ct_mul_relin(kg, logQ, p, a, b, decomp_bytes=db)
+        limb32 = db < 4 and (ctx.phim == 1 << 14 or m in (22, 1006))
+        assert (ksk.form()[0] == 1) == limb32 and (kg.form()[0] == 1) == limb32, (db, ksk.form(), kg.form())
+        if m < 2000:
+            for c in range(count):
+                assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p, db)), (db, c)
+            assert np.array_equal(got_g[1], orc.ct_mul_relin(kg.download(), a[1], b[1], logQ, p, db)), db
+        ctx.set_option("tensor32", 0)
+        ctx.set_option("ks_direct", 1)
+        kd = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+        kgd = F.KeySwitchMatrix(ctx, 3, nd).upload(kg.download())
+        assert np.array_equal(ctx.ct_mul_relin(kd, logQ, p, a, b, decomp_bytes=db), got), db
+        assert np.array_equal(ctx.ct_mul_relin(kgd, logQ, p, a, b, decomp_bytes=db), got_g), db
+        ctx.set_option("tensor32", 1)
+        ctx.set_option("ks_direct", 0)
