@@ -805,3 +805,26 @@ def test_digit_sizes_other_than_three_bytes(m, logQ, p, sizes):
         assert np.array_equal(ctx.ct_mul_relin(kgd, logQ, p, a, b, decomp_bytes=db), got_g), db
         ctx.set_option("tensor32", 1)
         ctx.set_option("ks_direct", 0)
+
+
+@pytest.mark.parametrize("m,logQ", [(64, 128), (22, 128), (1006, 160), (32768, 200)])
+def test_plaintext_moduli_from_two_to_sixty_one_bits(m, logQ):
+    """The plaintext modulus is a ZZ in the reference (FHEContext.h:97) and the factor of Ciphertext::operator*= and ScaleDown
+    (Ciphertext.cpp:167-218); the C ABI takes 64 bits.  p = 2, a 31-, a 33-, a 41- and a 61-bit prime: the chain and the tensor half's prime
+    plan are sized from p per call.  Against the oracle on the small rings, against the reference's own structure on the device everywhere."""
+    count = 2
+    for p in (2, (1 << 31) - 1, (1 << 32) + 15, (1 << 40) + 15, (1 << 61) - 1):
+        ctx, orc, ksm, a, b, nd, nl = setup(m, logQ, p, 1, count)
+        n = ctx.phim
+        lo = -(1 << (logQ - 1))
+        a[1, 0] = O.ints_to_limbs([lo] * n, nl)
+        b[1, 0] = O.ints_to_limbs([lo] * n, nl)
+        ksk = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+        got = ctx.ct_mul_relin(ksk, logQ, p, a, b)
+        if m < 2000:
+            for c in range(count):
+                assert np.array_equal(got[c], orc.ct_mul_relin(ksm, a[c], b[c], logQ, p)), (p, c)
+        ctx.set_option("tensor32", 0)
+        ctx.set_option("ks_direct", 1)
+        kd = F.KeySwitchMatrix(ctx, 3, nd).upload(ksm)
+        assert np.array_equal(ctx.ct_mul_relin(kd, logQ, p, a, b), got), p
