@@ -73,11 +73,14 @@ def test_fixtures_add_mul_long_automorph_sum_batched():
 
 @pytest.mark.parametrize("m,logQ,p", [(2048, 128, 23), (46, 90, 47), (4096, 300, 65537),
                                       (101, 90, 23),      # prime m: Ciphertext >>= as a gather with the Phi_m = sum X^i correction
-                                      (45, 90, 23)])      # a ring the gather does not cover: evaluation-form automorphism
+                                      (45, 90, 23),       # a ring the gather does not cover: evaluation-form automorphism
+                                      (17325, 90, 23)])   # ... and one beyond the long division in LDS (3^2 5^2 7 11: rem Phi_m by convolutions)
 def test_batches_vs_oracle(m, logQ, p):
     primes, roots = P.chain_for(m, logQ, p)
     ctx = F.Context(m, primes, roots)
     orc = O.Oracle(m, primes, roots)
+    if m > 10000:
+        orc.set_bluestein_fft(True)
     n, L, nd, nl = ctx.phim, len(primes), R.ndigits(logQ), (logQ + 63) // 64
     rng = np.random.default_rng(m + logQ)
     count = 3
