@@ -18,11 +18,14 @@ def dcrt_from_rows(ctx, rows):
     return d
 
 
-@pytest.mark.parametrize("m,logQ,p", [(2048, 128, 23), (46, 90, 47), (4096, 511, 65537), (64, 64, 257)])
+@pytest.mark.parametrize("m,logQ,p", [(2048, 128, 23), (46, 90, 47), (4096, 511, 65537), (64, 64, 257),
+                                      (45, 90, 23), (17325, 90, 23)])      # generic m: rem Phi_m by the long division in LDS / by convolutions
 def test_encrypt_decrypt_vs_oracle(m, logQ, p):
     primes, roots = P.chain_for(m, logQ, p)
     ctx = F.Context(m, primes, roots)
     orc = O.Oracle(m, primes, roots)
+    if m > 10000:
+        orc.set_bluestein_fft(True)
     n, L, nl = ctx.phim, len(primes), (logQ + 63) // 64
     rng = np.random.default_rng(m + logQ)
     count = 3
